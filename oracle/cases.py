@@ -1,0 +1,546 @@
+"""TEST INFRASTRUCTURE ONLY -- deterministic parity cases (inputs) shared by the golden generator, the oracle
+tests and the GPU parity tests.
+
+A case is a plain dict in NumPy terms:
+
+  mesh                "flat" | "spherical"
+  lon, lat, depth     node coordinates in the dataset's own dtype (lon/lat 1-D rectilinear or 2-D curvilinear;
+                      depth may be None)
+  x_pad,y_pad,z_pad   SGRID padding of the face dims ("low" | "high" | "both" | "none")
+  time_s              seconds of the time levels (None/len 1 => time-invariant fields)
+  fields, field_dims  name -> TZYX ndarray, name -> 4 dimension names
+                      (nodes XG/YG/depth, faces XC/YC/ZC, "time"; "mockT"/"mockZ"/... for absent axes)
+  cgrid               UV/UVW interpolator is CGrid_Velocity instead of XLinear_Velocity
+  constants           name -> value of constant fields (FieldSet.add_constant_field), const_mesh
+  context             fieldset.context entries (RK45_tol, RK45_min_dt, RK45_max_dt, dres)
+  kernels             list of built-in kernel names
+  spatial_dtype       "float32" (default Particle) | "float64"
+  x, y, z, t0         release positions / times (z None => default, t0 None => 0)
+  dt, runtime|endtime execute() arguments (seconds)
+  seed                RNG seed of the stochastic kernels
+
+The synthetic datasets restate the reference's analytic generators
+(src/parcels/_datasets/structured/generated.py:10-366) and the shapes its hot-path tests use.
+"""
+
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+TZYX_NODE = ("time", "depth", "YG", "XG")
+
+
+def _rng(seed):
+    return np.random.default_rng(seed)
+
+
+def smooth_random_field(rng, shape, scale=1.0, dtype=np.float64):
+    """Random but smooth-ish field: white noise lightly box-filtered along y and x."""
+    a = rng.standard_normal(shape)
+    a = (a + np.roll(a, 1, axis=-1) + np.roll(a, -1, axis=-1)) / 3.0
+    a = (a + np.roll(a, 1, axis=-2) + np.roll(a, -1, axis=-2)) / 3.0
+    return (scale * a).astype(dtype)
+
+
+def rect_agrid_case(
+    name,
+    *,
+    mesh,
+    kernels,
+    seed=0,
+    nx=36,
+    ny=18,
+    nz=5,
+    nt=4,
+    npart=300,
+    field_dtype=np.float64,
+    spatial_dtype="float64",
+    coord_dtype=np.float64,
+    with_w=False,
+    dt=3600.0,
+    runtime=None,
+    vel=None,
+    margin=0.12,
+    stagger=False,
+    level_dt=86400.0,
+    wscale=0.004,
+):
+    rng = _rng(seed)
+    if mesh == "spherical":
+        lon = np.linspace(0, 360, nx).astype(coord_dtype)
+        lat = np.linspace(-80, 80, ny).astype(coord_dtype)
+        vel = 1.0 if vel is None else vel  # m/s
+    else:
+        lon = np.linspace(0, 4.0e5, nx).astype(coord_dtype)
+        lat = np.linspace(0, 2.0e5, ny).astype(coord_dtype)
+        vel = 0.4 if vel is None else vel
+    depth = np.linspace(0, 5000, nz).astype(coord_dtype)
+    time_s = np.arange(nt) * level_dt
+    shp = (nt, nz, ny, nx)
+    fields = {"U": smooth_random_field(rng, shp, vel, field_dtype), "V": smooth_random_field(rng, shp, vel, field_dtype)}
+    dims = {"U": TZYX_NODE, "V": TZYX_NODE}
+    if with_w:
+        fields["W"] = smooth_random_field(rng, shp, wscale * vel, field_dtype)
+        dims["W"] = TZYX_NODE
+    lx, ly = float(lon[-1] - lon[0]), float(lat[-1] - lat[0])
+    x = rng.uniform(lon[0] + margin * lx, lon[-1] - margin * lx, npart)
+    y = rng.uniform(lat[0] + margin * ly, lat[-1] - margin * ly, npart)
+    z = rng.uniform(200, 4800, npart)
+    case = dict(
+        name=name,
+        mesh=mesh,
+        lon=lon,
+        lat=lat,
+        depth=depth,
+        x_pad="low",
+        y_pad="low",
+        z_pad="both",
+        time_s=time_s,
+        fields=fields,
+        field_dims=dims,
+        cgrid=False,
+        kernels=list(kernels),
+        spatial_dtype=spatial_dtype,
+        x=x,
+        y=y,
+        z=z,
+        t0=None,
+        dt=dt,
+        runtime=runtime if runtime is not None else 30 * abs(dt),
+        seed=seed,
+    )
+    if stagger:
+        case["t0"] = rng.integers(0, 6, npart) * abs(dt) * 0.5
+    return case
+
+
+# ---- restated analytic datasets of the reference (generated.py) ---------------------------------------------------
+
+
+def peninsula_case(name, *, mesh="flat", grid_type="A", kernels=("AdvectionRK4",), xdim=100, ydim=50, npart=20,
+                   spatial_dtype="float32", dt=1800.0, runtime=23 * 3600.0):
+    """generated.py:206-298 (flow around an idealised peninsula; P is the conserved streamfunction)."""
+    domainsizeX, domainsizeY = (1.0e5, 5.0e4)
+    La = np.linspace(0, domainsizeX, xdim, dtype=np.float32)
+    Wa = np.linspace(0, domainsizeY, ydim, dtype=np.float32)
+    u0 = 1
+    x0 = domainsizeX / 2
+    R = 0.32 * domainsizeX / 2
+    P = np.zeros((ydim, xdim), dtype=np.float32)
+    U = np.zeros_like(P)
+    V = np.zeros_like(P)
+    x, y = np.meshgrid(La, Wa, sparse=True, indexing="xy")
+    P[:, :] = u0 * R**2 * y / ((x - x0) ** 2 + y**2) - u0 * y
+    landpoints = P >= 0.0
+    P[landpoints] = 0.0
+    if grid_type == "A":
+        U[:, :] = u0 - u0 * R**2 * ((x - x0) ** 2 - y**2) / (((x - x0) ** 2 + y**2) ** 2)
+        V[:, :] = -2 * u0 * R**2 * ((x - x0) * y) / (((x - x0) ** 2 + y**2) ** 2)
+        U[landpoints] = 0.0
+        V[landpoints] = 0.0
+        udims = ("mockT", "mockZ", "YC", "XC")
+        vdims = ("mockT", "mockZ", "YC", "XC")
+    else:
+        U = np.zeros(P.shape)
+        V = np.zeros(P.shape)
+        U[1:, :] = -(P[1:, :] - P[:-1, :]) / (Wa[1] - Wa[0])
+        V[:, 1:] = (P[:, 1:] - P[:, :-1]) / (La[1] - La[0])
+        udims = ("mockT", "mockZ", "YG", "XC")
+        vdims = ("mockT", "mockZ", "YC", "XG")
+    lon = La / 1852.0 / 60.0 if mesh == "spherical" else La
+    lat = Wa / 1852.0 / 60.0 if mesh == "spherical" else Wa
+    # release line of tests/test_advection.py:405-408
+    if mesh == "spherical":
+        px = np.full(npart, 3.0e3 / 1852.0 / 60.0)
+        py = np.linspace(3.0e3, 47.0e3, npart) / 1852.0 / 60.0
+    else:
+        px = np.full(npart, 3.0e3)
+        py = np.linspace(3.0e3, 47.0e3, npart)
+    return dict(
+        name=name,
+        mesh=mesh,
+        lon=lon,
+        lat=lat,
+        depth=None,
+        x_pad="low",
+        y_pad="low",
+        z_pad="both",
+        time_s=None,
+        fields={"U": U[None, None], "V": V[None, None], "P": P[None, None]},
+        field_dims={"U": udims, "V": vdims, "P": ("mockT", "mockZ", "YC", "XC")},
+        cgrid=(grid_type == "C"),
+        kernels=list(kernels),
+        spatial_dtype=spatial_dtype,
+        x=px,
+        y=py,
+        z=None,
+        t0=None,
+        dt=dt,
+        runtime=runtime,
+        seed=0,
+    )
+
+
+def stommel_case(name, *, grid_type="A", kernels=("AdvectionRK4",), xdim=60, ydim=60, npart=16,
+                 spatial_dtype="float32", dt=3600.0, runtime=20 * 86400.0):
+    """generated.py:301-366 (Stommel gyre; P conserved)."""
+    a = b = 10000 * 1e3
+    scalefac = 0.05
+    dx, dy = a / xdim, b / ydim
+    lon = np.linspace(0, a, xdim, dtype=np.float32)
+    lat = np.linspace(0, b, ydim, dtype=np.float32)
+    U = np.zeros((lat.size, lon.size), dtype=np.float32)
+    V = np.zeros((lat.size, lon.size), dtype=np.float32)
+    P = np.zeros((lat.size, lon.size), dtype=np.float32)
+    beta = 2e-11
+    r = 1 / (11.6 * 86400)
+    es = r / (beta * a)
+    for j in range(lat.size):
+        for i in range(lon.size):
+            xi = lon[i] / a
+            yi = lat[j] / b
+            P[j, i] = (1 - math.exp(-xi / es) - xi) * math.pi * np.sin(math.pi * yi) * scalefac
+            if grid_type == "A":
+                U[j, i] = -(1 - math.exp(-xi / es) - xi) * math.pi**2 * np.cos(math.pi * yi) * scalefac
+                V[j, i] = (math.exp(-xi / es) / es - 1) * math.pi * np.sin(math.pi * yi) * scalefac
+    if grid_type == "C":
+        U[1:, :] = -(P[1:, :] - P[0:-1, :]) / dy * b
+        V[:, 1:] = (P[:, 1:] - P[:, 0:-1]) / dx * a
+        udims = ("mockT", "mockZ", "YG", "XC")
+        vdims = ("mockT", "mockZ", "YC", "XG")
+    else:
+        udims = ("mockT", "mockZ", "YC", "XC")
+        vdims = ("mockT", "mockZ", "YC", "XC")
+    px = np.linspace(a * 0.1, a * 0.4, npart)
+    py = np.full(npart, b * 0.5)
+    return dict(
+        name=name,
+        mesh="flat",
+        lon=lon,
+        lat=lat,
+        depth=None,
+        x_pad="low",
+        y_pad="low",
+        z_pad="both",
+        time_s=None,
+        fields={"U": U[None, None], "V": V[None, None], "P": P[None, None]},
+        field_dims={"U": udims, "V": vdims, "P": ("mockT", "mockZ", "YG", "XG")},
+        cgrid=(grid_type == "C"),
+        kernels=list(kernels),
+        spatial_dtype=spatial_dtype,
+        x=px,
+        y=py,
+        z=None,
+        t0=None,
+        dt=dt,
+        runtime=runtime,
+        seed=0,
+    )
+
+
+def moving_eddy_case(name, *, kernels=("AdvectionRK4",), spatial_dtype="float32", dt=900.0, runtime=6 * 3600.0,
+                     context=None):
+    """generated.py:94-140 (eddy moving in time, no spatial variation); closed form in tests/test_advection.py:254-307."""
+    f, u_0, u_g = 1.0e-4, 0.3, 0.04
+    xdim = ydim = 2
+    lon = np.linspace(0, 25000, xdim, dtype=np.float32)
+    lat = np.linspace(0, 25000, ydim, dtype=np.float32)
+    time_s = np.arange(0, 7 * 3600, 60).astype(np.float64)
+    U = np.zeros((len(time_s), 1, ydim, xdim), dtype=np.float32)
+    V = np.zeros((len(time_s), 1, ydim, xdim), dtype=np.float32)
+    for t in range(len(time_s)):
+        U[t] = u_g + (u_0 - u_g) * np.cos(f * time_s[t])
+        V[t] = -(u_0 - u_g) * np.sin(f * time_s[t])
+    case = dict(
+        name=name,
+        mesh="flat",
+        lon=lon,
+        lat=lat,
+        depth=np.array([0.0]),
+        x_pad="low",
+        y_pad="high",
+        z_pad="both",
+        time_s=time_s,
+        fields={"U": U, "V": V},
+        field_dims={"U": TZYX_NODE, "V": TZYX_NODE},
+        cgrid=False,
+        kernels=list(kernels),
+        spatial_dtype=spatial_dtype,
+        x=np.array([12000.0, 12500.0]),
+        y=np.array([12500.0, 12000.0]),
+        z=np.array([0.0, 0.0]),
+        t0=None,
+        dt=dt,
+        runtime=runtime,
+        seed=0,
+        attrs=dict(f=f, u_0=u_0, u_g=u_g),
+    )
+    if context:
+        case["context"] = dict(context)
+    return case
+
+
+def rect_cgrid_case(name, *, mesh, kernels, seed=0, nx=30, ny=20, nz=6, nt=3, npart=300, field_dtype=np.float32,
+                    spatial_dtype="float64", with_w=True, dt=3600.0, runtime=None, vel=0.5):
+    """NEMO-like rectilinear C-grid (X,Y LOW padding, Z HIGH: convert.py:382-398): U on x-faces, V on y-faces,
+    W on z-faces, all with the same array extents as the node grid."""
+    rng = _rng(seed)
+    if mesh == "spherical":
+        lon = np.linspace(-20, 40, nx)
+        lat = np.linspace(-30, 30, ny)
+    else:
+        lon = np.linspace(0, 3.0e5, nx)
+        lat = np.linspace(0, 2.0e5, ny)
+    depth = np.linspace(0, 3000, nz)
+    time_s = np.arange(nt) * 86400.0
+    shp = (nt, nz, ny, nx)
+    fields = {"U": smooth_random_field(rng, shp, vel, field_dtype), "V": smooth_random_field(rng, shp, vel, field_dtype)}
+    dims = {"U": ("time", "ZC", "YC", "XG"), "V": ("time", "ZC", "YG", "XC")}
+    if with_w:
+        fields["W"] = smooth_random_field(rng, shp, 0.01 * vel, field_dtype)
+        dims["W"] = ("time", "depth", "YC", "XC")
+    lx, ly = lon[-1] - lon[0], lat[-1] - lat[0]
+    x = rng.uniform(lon[0] + 0.15 * lx, lon[-1] - 0.15 * lx, npart)
+    y = rng.uniform(lat[0] + 0.15 * ly, lat[-1] - 0.15 * ly, npart)
+    z = rng.uniform(300, 2700, npart)
+    return dict(
+        name=name,
+        mesh=mesh,
+        lon=lon,
+        lat=lat,
+        depth=depth,
+        x_pad="low",
+        y_pad="low",
+        z_pad="high",
+        time_s=time_s,
+        fields=fields,
+        field_dims=dims,
+        cgrid=True,
+        kernels=list(kernels),
+        spatial_dtype=spatial_dtype,
+        x=x,
+        y=y,
+        z=z,
+        t0=None,
+        dt=dt,
+        runtime=runtime if runtime is not None else 24 * abs(dt),
+        seed=seed,
+    )
+
+
+def curvilinear_grid(nx, ny, *, mesh, seed=0):
+    """Smoothly warped + rotated lon/lat mesh (in the spirit of _datasets/structured/generic.py:13-62)."""
+    i = np.arange(nx)[None, :] / (nx - 1)
+    j = np.arange(ny)[:, None] / (ny - 1)
+    if mesh == "spherical":
+        lon0 = -30 + 70 * i + 0 * j
+        lat0 = 20 + 45 * j + 0 * i
+        lon = lon0 + 4.0 * np.sin(2 * np.pi * j) * (0.3 + i) + 6.0 * j
+        lat = lat0 + 3.0 * np.sin(2 * np.pi * i) * (0.5 + 0.5 * j) - 4.0 * i
+    else:
+        lon0 = 1.0e5 * i + 0 * j
+        lat0 = 0.6e5 * j + 0 * i
+        lon = lon0 + 4.0e3 * np.sin(2 * np.pi * j) * (0.3 + i) + 8.0e3 * j
+        lat = lat0 + 3.0e3 * np.sin(2 * np.pi * i) * (0.5 + 0.5 * j) - 5.0e3 * i
+    return np.ascontiguousarray(lon), np.ascontiguousarray(lat)
+
+
+def curv_cgrid_case(name, *, mesh, kernels, seed=0, nx=40, ny=30, nz=5, nt=3, npart=300, field_dtype=np.float32,
+                    spatial_dtype="float64", with_w=True, dt=1800.0, runtime=None, vel=0.3, cgrid=True):
+    rng = _rng(seed)
+    lon, lat = curvilinear_grid(nx, ny, mesh=mesh, seed=seed)
+    depth = np.linspace(0, 2000, nz)
+    time_s = np.arange(nt) * 86400.0
+    shp = (nt, nz, ny, nx)
+    fields = {"U": smooth_random_field(rng, shp, vel, field_dtype), "V": smooth_random_field(rng, shp, vel, field_dtype)}
+    if cgrid:
+        dims = {"U": ("time", "ZC", "YC", "XG"), "V": ("time", "ZC", "YG", "XC")}
+    else:
+        dims = {"U": TZYX_NODE, "V": TZYX_NODE}
+    if with_w:
+        fields["W"] = smooth_random_field(rng, shp, 0.01 * vel, field_dtype)
+        dims["W"] = ("time", "depth", "YC", "XC") if cgrid else TZYX_NODE
+    # release inside the mesh: bilinear blend of interior cells
+    ci = rng.uniform(0.2, 0.8, npart) * (nx - 1)
+    cj = rng.uniform(0.2, 0.8, npart) * (ny - 1)
+    i0, j0 = ci.astype(int), cj.astype(int)
+    fi, fj = ci - i0, cj - j0
+    def blend(a):
+        return (a[j0, i0] * (1 - fi) * (1 - fj) + a[j0, i0 + 1] * fi * (1 - fj) + a[j0 + 1, i0] * (1 - fi) * fj
+                + a[j0 + 1, i0 + 1] * fi * fj)
+    x, y = blend(lon), blend(lat)
+    z = rng.uniform(200, 1800, npart)
+    return dict(
+        name=name,
+        mesh=mesh,
+        lon=lon,
+        lat=lat,
+        depth=depth,
+        x_pad="low",
+        y_pad="low",
+        z_pad="high" if cgrid else "both",
+        time_s=time_s,
+        fields=fields,
+        field_dims=dims,
+        cgrid=cgrid,
+        kernels=list(kernels),
+        spatial_dtype=spatial_dtype,
+        x=x,
+        y=y,
+        z=z,
+        t0=None,
+        dt=dt,
+        runtime=runtime if runtime is not None else 24 * abs(dt),
+        seed=seed,
+    )
+
+
+def diffusion_case(name, *, mesh, kernels, seed=0, npart=200, const_kh=None, spatial_dtype="float64", dt=600.0,
+                   runtime=6 * 3600.0):
+    """Kh fields like tests/test_diffusion.py:49-78 (tanh profile) or constant Kh (:19-46)."""
+    rng = _rng(seed)
+    nx, ny = 40, 30
+    if mesh == "spherical":
+        lon = np.linspace(-10, 10, nx)
+        lat = np.linspace(-8, 8, ny)
+        dres = 0.05
+        khscale = 100.0
+    else:
+        lon = np.linspace(-2.0e4, 2.0e4, nx)
+        lat = np.linspace(-1.5e4, 1.5e4, ny)
+        dres = 100.0
+        khscale = 10.0
+    depth = np.array([0.0, 100.0])
+    time_s = np.array([0.0, 86400.0])
+    shp = (2, 2, ny, nx)
+    U = smooth_random_field(rng, shp, 0.05, np.float64)
+    V = smooth_random_field(rng, shp, 0.05, np.float64)
+    fields = {"U": U, "V": V}
+    dims = {"U": TZYX_NODE, "V": TZYX_NODE}
+    constants = {}
+    if const_kh is not None:
+        constants = {"Kh_zonal": const_kh, "Kh_meridional": const_kh}
+    else:
+        xs = lon / lon[-1]
+        khz = khscale * (1 + 0.5 * np.tanh(3 * xs))[None, None, None, :] * np.ones(shp)
+        ys = lat / lat[-1]
+        khm = khscale * (1 + 0.3 * np.tanh(2 * ys))[None, None, :, None] * np.ones(shp)
+        fields["Kh_zonal"] = khz
+        fields["Kh_meridional"] = khm
+        dims["Kh_zonal"] = TZYX_NODE
+        dims["Kh_meridional"] = TZYX_NODE
+    x = rng.uniform(lon[0] * 0.3, lon[-1] * 0.3, npart)
+    y = rng.uniform(lat[0] * 0.3, lat[-1] * 0.3, npart)
+    return dict(
+        name=name,
+        mesh=mesh,
+        lon=lon,
+        lat=lat,
+        depth=depth,
+        x_pad="low",
+        y_pad="low",
+        z_pad="both",
+        time_s=time_s,
+        fields=fields,
+        field_dims=dims,
+        cgrid=False,
+        constants=constants,
+        const_mesh=mesh,
+        context={"dres": dres},
+        kernels=list(kernels),
+        spatial_dtype=spatial_dtype,
+        x=x,
+        y=y,
+        z=np.full(npart, 10.0),
+        t0=None,
+        dt=dt,
+        runtime=runtime,
+        seed=1234 + seed,
+    )
+
+
+def all_cases() -> dict:
+    """name -> case.  Keep every case small: the fixtures are committed."""
+    c = {}
+
+    def add(case):
+        c[case["name"]] = case
+
+    # --- rectilinear A-grid (BASELINE config 2 shape, scaled down) ---------------------------------------------
+    add(rect_agrid_case("agrid_flat_rk4_f64", mesh="flat", kernels=["AdvectionRK4"], seed=1))
+    add(rect_agrid_case("agrid_sph_rk4_f64", mesh="spherical", kernels=["AdvectionRK4"], seed=2))
+    add(rect_agrid_case("agrid_sph_rk4_3d_f64", mesh="spherical", kernels=["AdvectionRK4_3D"], seed=3, with_w=True))
+    add(rect_agrid_case("agrid_flat_rk4_3d_f64", mesh="flat", kernels=["AdvectionRK4_3D"], seed=4, with_w=True))
+    add(rect_agrid_case("agrid_sph_rk4_f32part", mesh="spherical", kernels=["AdvectionRK4"], seed=5, spatial_dtype="float32"))
+    add(rect_agrid_case("agrid_flat_rk4_f32part", mesh="flat", kernels=["AdvectionRK4"], seed=6, spatial_dtype="float32"))
+    add(rect_agrid_case("agrid_sph_rk4_f32field", mesh="spherical", kernels=["AdvectionRK4"], seed=7, field_dtype=np.float32))
+    add(rect_agrid_case("agrid_sph_rk4_f32all", mesh="spherical", kernels=["AdvectionRK4_3D"], seed=8, with_w=True,
+                        field_dtype=np.float32, spatial_dtype="float32", coord_dtype=np.float32))
+    add(rect_agrid_case("agrid_sph_rk4_backward", mesh="spherical", kernels=["AdvectionRK4"], seed=9, dt=-3600.0,
+                        runtime=30 * 3600.0))
+    # backward needs particles to start at the end of the interval
+    c["agrid_sph_rk4_backward"]["t0"] = np.full(300, 3 * 86400.0)
+    add(rect_agrid_case("agrid_sph_rk4_oddstep", mesh="spherical", kernels=["AdvectionRK4"], seed=10, dt=1000.0,
+                        runtime=86400.0 + 777.0))
+    add(rect_agrid_case("agrid_sph_rk4_stagger", mesh="spherical", kernels=["AdvectionRK4"], seed=11, stagger=True))
+    # escaping particles: large velocities, small margin -> out-of-bounds codes (and the silent left/bottom exit)
+    add(rect_agrid_case("agrid_flat_rk4_escape", mesh="flat", kernels=["AdvectionRK4"], seed=12, vel=6.0, margin=0.01,
+                        dt=1800.0, runtime=20 * 1800.0))
+    add(rect_agrid_case("agrid_flat_rk4_3d_escape_delete", mesh="flat", kernels=["AdvectionRK4_3D", "DeleteParticle"],
+                        seed=13, vel=6.0, margin=0.01, with_w=True, dt=1800.0, runtime=20 * 1800.0, wscale=0.02))
+    add(rect_agrid_case("agrid_sph_rk4_3d_submerge", mesh="spherical", seed=20, with_w=True, wscale=0.05,
+                        kernels=["AdvectionRK4_3D", "SubmergeParticle", "DeleteOutOfBounds"]))
+    add(rect_agrid_case("agrid_sph_ee", mesh="spherical", kernels=["AdvectionEE"], seed=14))
+    add(rect_agrid_case("agrid_sph_rk2", mesh="spherical", kernels=["AdvectionRK2"], seed=15))
+    add(rect_agrid_case("agrid_sph_rk2_3d", mesh="spherical", kernels=["AdvectionRK2_3D"], seed=16, with_w=True))
+    add(rect_agrid_case("agrid_sph_rk45", mesh="spherical", kernels=["AdvectionRK45"], seed=17, runtime=12 * 3600.0))
+    add(rect_agrid_case("agrid_flat_rk45", mesh="flat", kernels=["AdvectionRK45"], seed=18, runtime=12 * 3600.0))
+    c["agrid_flat_rk45"]["context"] = {"RK45_tol": 0.5, "RK45_min_dt": 10.0, "RK45_max_dt": 7200.0}
+    add(rect_agrid_case("agrid_sph_rk4_outside_time", mesh="spherical", kernels=["AdvectionRK4"], seed=19, nt=2,
+                        runtime=30 * 3600.0))
+
+    # --- restated analytic datasets (BASELINE config 1) --------------------------------------------------------
+    add(peninsula_case("peninsula_A_flat", mesh="flat", grid_type="A"))
+    add(peninsula_case("peninsula_A_spherical", mesh="spherical", grid_type="A"))
+    add(peninsula_case("peninsula_C_flat", mesh="flat", grid_type="C"))
+    add(peninsula_case("peninsula_C_spherical", mesh="spherical", grid_type="C"))
+    add(peninsula_case("peninsula_A_flat_f64", mesh="flat", grid_type="A", spatial_dtype="float64"))
+    add(stommel_case("stommel_A", grid_type="A"))
+    add(stommel_case("stommel_C", grid_type="C"))
+    add(moving_eddy_case("moving_eddy_rk4"))
+    add(moving_eddy_case("moving_eddy_rk45", kernels=["AdvectionRK45"],
+                         context={"RK45_tol": 1e-5, "RK45_min_dt": 1.0, "RK45_max_dt": 3600.0}))
+    add(moving_eddy_case("moving_eddy_ee", kernels=["AdvectionEE"]))
+
+    # --- rectilinear C-grid with W -------------------------------------------------------------------------------
+    add(rect_cgrid_case("cgrid_rect_flat_rk4_3d", mesh="flat", kernels=["AdvectionRK4_3D"], seed=21))
+    add(rect_cgrid_case("cgrid_rect_sph_rk4_3d", mesh="spherical", kernels=["AdvectionRK4_3D"], seed=22))
+    add(rect_cgrid_case("cgrid_rect_sph_rk4_f64field", mesh="spherical", kernels=["AdvectionRK4"], seed=23,
+                        field_dtype=np.float64, with_w=False))
+
+    # --- curvilinear (spatial hash + tangent-plane point-in-cell) --------------------------------------------------
+    add(curv_cgrid_case("cgrid_curv_sph_rk4_3d", mesh="spherical", kernels=["AdvectionRK4_3D", "DeleteParticle"], seed=31))
+    add(curv_cgrid_case("cgrid_curv_sph_rk4_3d_err", mesh="spherical", kernels=["AdvectionRK4_3D"], seed=31))
+    add(curv_cgrid_case("cgrid_curv_flat_rk4", mesh="flat", kernels=["AdvectionRK4"], seed=32, with_w=False))
+    add(curv_cgrid_case("agrid_curv_sph_rk4", mesh="spherical", kernels=["AdvectionRK4", "DeleteParticle"], seed=33,
+                        with_w=False, cgrid=False))
+    for nm in ("cgrid_curv_sph_rk4_3d", "cgrid_curv_flat_rk4", "agrid_curv_sph_rk4"):
+        pc = dict(c[nm])
+        pc["name"] = nm + "_populated"
+        pc["populate"] = True  # ParticleSet.populate_indices() first: every evaluation has an ei guess
+        add(pc)
+    add(curv_cgrid_case("cgrid_curv_sph_rk45", mesh="spherical", kernels=["AdvectionRK45"], seed=34, with_w=False,
+                        runtime=8 * 3600.0))
+
+    # --- stochastic kernels (counter-based RNG injected into the reference run) ----------------------------------
+    add(diffusion_case("diff_m1_flat", mesh="flat", kernels=["AdvectionDiffusionM1"], seed=41))
+    add(diffusion_case("diff_m1_sph", mesh="spherical", kernels=["AdvectionDiffusionM1"], seed=42))
+    add(diffusion_case("diff_em_sph", mesh="spherical", kernels=["AdvectionDiffusionEM"], seed=43))
+    add(diffusion_case("diff_uniform_sph", mesh="spherical", kernels=["AdvectionRK4", "DiffusionUniformKh"], seed=44,
+                       const_kh=50.0))
+    add(diffusion_case("diff_m1_constkh_flat", mesh="flat", kernels=["AdvectionDiffusionM1"], seed=45, const_kh=5.0))
+    add(diffusion_case("diff_m1_sph_f32part", mesh="spherical", kernels=["AdvectionDiffusionM1"], seed=46,
+                       spatial_dtype="float32"))
+    return c
