@@ -1,0 +1,207 @@
+/*
+ * parcels_hip.h -- C ABI of libparcels_hip.so, the MI355X (gfx950) engine behind the Parcels
+ * ParticleSet.execute() hot path.
+ *
+ * The reference (Parcels v4-alpha, pure Python/NumPy) has no FFI for this path; its plug-in points are
+ * Python protocols.  Each entry point below names the reference interface it stands in for
+ * (paths relative to /root/reference/src/parcels).  INTEGRATION.md shows the ctypes stub a Parcels
+ * maintainer would add to route `Kernel.execute` through this library.
+ *
+ * Conventions
+ *   - every function returns int32: 0 = ok, <0 = library error (text via pk_last_error);
+ *     no C++ exception crosses the ABI;
+ *   - per-particle failures are NOT library errors: they are the reference's StatusCode integers in the
+ *     particle `state` column (statuscodes.py:19-34), and pk_exec_stats.state_counts summarises them;
+ *   - host buffers are owned by the caller (C-contiguous, dtype as stated) and must outlive the call
+ *     (for async uploads: until pk_field_sync); the library owns all device memory and pinned staging;
+ *   - one pk_ctx per device and per host thread; not thread-safe.
+ */
+#ifndef PARCELS_HIP_H
+#define PARCELS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PK_ABI_VERSION 1
+#define PK_MAX_GRIDS 4
+#define PK_MAX_FIELDS 8
+#define PK_MAX_KERNELS 8
+#define PK_NUM_STATE_CODES 80
+
+typedef struct pk_ctx pk_ctx;
+
+/* dtype tags */
+#define PK_F32 0
+#define PK_F64 1
+
+/* StatusCode (statuscodes.py:19-34) */
+#define PK_SUCCESS 0
+#define PK_ENDOFLOOP 1
+#define PK_EVALUATE 10
+#define PK_REPEAT 20
+#define PK_DELETE 30
+#define PK_STOPEXECUTION 40
+#define PK_STOPALLEXECUTION 41
+#define PK_ERROR 50
+#define PK_ERRORINTERPOLATION 51
+#define PK_ERRORGRIDSEARCHING 52
+#define PK_ERROROUTOFBOUNDS 60
+#define PK_ERRORTHROUGHSURFACE 61
+#define PK_ERROROUTSIDETIMEINTERVAL 70
+
+/* Built-in kernels, recognised by identity on the Python side like kernel.py:129-134 does.
+ * 1-9: kernels/_advection.py:21-155, kernels/_advectiondiffusion.py:21-153.
+ * 20-22: native forms of the recovery kernels the reference's tests interleave with them
+ *        (tests/common_kernels.py:12-13, tests/test_advection.py:157-174). */
+#define PK_KERNEL_ADVECTION_EE 1
+#define PK_KERNEL_ADVECTION_RK2 2
+#define PK_KERNEL_ADVECTION_RK2_3D 3
+#define PK_KERNEL_ADVECTION_RK4 4
+#define PK_KERNEL_ADVECTION_RK4_3D 5
+#define PK_KERNEL_ADVECTION_RK45 6
+#define PK_KERNEL_ADVECTIONDIFFUSION_M1 7
+#define PK_KERNEL_ADVECTIONDIFFUSION_EM 8
+#define PK_KERNEL_DIFFUSION_UNIFORM_KH 9
+#define PK_KERNEL_DELETE_ON_ERROR 20
+#define PK_KERNEL_DELETE_OUT_OF_BOUNDS 21
+#define PK_KERNEL_SUBMERGE_THROUGH_SURFACE 22
+
+/* ---- context ------------------------------------------------------------------------------------ */
+int32_t pk_abi_version(void);
+int32_t pk_init(int32_t device, pk_ctx** out);
+int32_t pk_destroy(pk_ctx* ctx);
+const char* pk_last_error(const pk_ctx* ctx); /* ctx may be NULL: error of the last failed pk_init */
+
+typedef struct pk_device_info {
+    char name[128];
+    char arch[64];
+    int32_t compute_units;
+    int32_t wavefront_size;
+    int32_t lds_bytes_per_block;
+    int32_t clock_khz;
+    int64_t total_mem;
+    int64_t free_mem;
+} pk_device_info;
+int32_t pk_get_device_info(pk_ctx* ctx, pk_device_info* out);
+
+/* ---- grids: XGrid (xgrid.py:108-356) + its SpatialHash table (spatialhash.py:269-387) ------------ */
+typedef struct pk_grid_desc {
+    int32_t kind;      /* 0 rectilinear (1-D lon/lat), 1 curvilinear (2-D lon/lat)                  */
+    int32_t spherical; /* mesh.py:23-47                                                            */
+    int32_t has_x, has_y, has_z; /* XGrid.axes                                                     */
+    int32_t nx, ny, nz;          /* node counts (nz = 0 without a vertical axis)                   */
+    int32_t xdim, ydim, zdim;    /* ravel dims of `ei` (xgrid.py:21-24,208-231; basegrid.py:83-152) */
+    int32_t off_x, off_y, off_z; /* C-grid index offsets from SGRID padding (_xinterpolators.py:99-109) */
+    int32_t lon_f32, lat_f32, depth_f32; /* the dataset stores that coordinate as float32 (NumPy keeps
+                                            f32-f32 arithmetic in f32; the kernels reproduce it)    */
+    int32_t reserved0;
+    double deg2m;      /* XGrid.deg2m (xgrid.py:201-206): radius*pi/180, or 1.0 on a flat mesh      */
+    const double* lon; /* nx, or ny*nx row-major; exact widening of the dataset's values           */
+    const double* lat; /* ny, or ny*nx                                                             */
+    const double* depth; /* nz (may be NULL when nz == 0)                                          */
+    /* CSR Morton hash, curvilinear only (all NULL/0 otherwise) */
+    const uint32_t* h_keys;
+    const int64_t* h_starts;
+    const int64_t* h_counts;
+    const uint32_t* h_faces;
+    int64_t h_nkeys;
+    int64_t h_nentries;
+    int32_t h_bitwidth;
+    int32_t reserved1;
+    double h_bbox[6]; /* xmin,xmax,ymin,ymax,zmin,zmax of the hash grid                             */
+} pk_grid_desc;
+int32_t pk_grid_create(pk_ctx* ctx, const pk_grid_desc* desc, int32_t* grid_id);
+
+/* ---- fields: Field data backend (model.py:67-113, _windowed_array.py:25-113) --------------------- */
+typedef struct pk_field_desc {
+    int32_t grid;  /* grid id == `igrid` (column of the particle `ei` array)                       */
+    int32_t dtype; /* PK_F32 | PK_F64 of the TZYX data                                              */
+    int32_t nt, nz, ny, nx; /* TZYX extents; size 1 for axes the field does not have               */
+    int32_t has_t, has_z, has_y, has_x; /* the field has a dimension on that axis                   */
+    int32_t has_time_interval; /* Field.time_interval is not None (field.py:111-116)                */
+    int32_t is_const;   /* XConstantField (_xinterpolators.py:156-166): value = data[0,0,0,0]       */
+    int32_t nslots;     /* device-resident time levels: >= nt keeps all, else a ring (>= 2)         */
+    int32_t reserved0;
+    const double* time; /* nt level times, seconds since time_interval.left (index_search.py:88)    */
+} pk_field_desc;
+int32_t pk_field_create(pk_ctx* ctx, const pk_field_desc* desc, int32_t* field_id);
+/* Copy time level `level` (nz*ny*nx values, host) into ring slot level % nslots on the copy stream.
+ *   async == 0: blocking; the level is usable when the call returns.
+ *   async != 0: enqueued through a pinned staging ring and returns at once; the level whose slot is being
+ *               overwritten is evicted immediately, the new level becomes usable at the next pk_field_sync().
+ * pk_execute only reads committed levels and never waits on the copy stream, so an async upload of level k+1
+ * overlaps the RK sub-steps running on level k.  Stands in for WindowedArray._ensure (_windowed_array.py:56-72). */
+int32_t pk_field_upload_level(pk_ctx* ctx, int32_t field_id, int32_t level, const void* host_data, int32_t async);
+int32_t pk_field_sync(pk_ctx* ctx); /* wait for the copy stream and commit every pending level */
+/* which committed level each ring slot currently holds (-1 = empty/pending); `levels` has room for nslots ints */
+int32_t pk_field_slots(pk_ctx* ctx, int32_t field_id, int32_t* levels, int32_t* nslots);
+
+/* ---- particles: the SoA dict of ParticleSet (particle.py:182-222) -------------------------------- */
+typedef struct pk_particles_desc {
+    int64_t n;
+    int32_t ngrids;        /* columns of ei                                                        */
+    int32_t spatial_dtype; /* PK_F32 (default Particle) | PK_F64 for z,y,x,dz,dy,dx                 */
+    double* t;
+    void *z, *y, *x, *dz, *dy, *dx;
+    double* dt;
+    double* next_dt; /* NULL unless the particle class has it (AdvectionRK45)                      */
+    int32_t* state;
+    int32_t* ei; /* n * ngrids                                                                     */
+    int64_t* particle_id;
+} pk_particles_desc;
+int32_t pk_particles_bind(pk_ctx* ctx, const pk_particles_desc* host); /* remember host columns, size device columns */
+int32_t pk_particles_h2d(pk_ctx* ctx);
+int32_t pk_particles_d2h(pk_ctx* ctx);
+/* device pointers of the bound columns in CURRENT device order (for RCCL all-gather of the output
+ * columns at write-out; see parcels_amd/distributed.py).  perm (int64*, may be NULL when the particles
+ * have not been cell-sorted) maps device row -> original row. */
+int32_t pk_particles_device(pk_ctx* ctx, pk_particles_desc* dev, int64_t** perm);
+
+/* ---- execution: Kernel.execute (kernel.py:174-247) ----------------------------------------------- */
+typedef struct pk_exec_params {
+    int32_t nk;
+    int32_t kernels[PK_MAX_KERNELS]; /* PK_KERNEL_*, applied in order to every evaluated particle   */
+    int32_t interp_uv;  /* 0 XLinear_Velocity (A-grid), 1 CGrid_Velocity                            */
+    int32_t rk45_mode;  /* hasattr(fieldset, "RK45_tol") (kernel.py:118,225)                        */
+    int32_t reset_state; /* 1: state[:] = Evaluate first (kernel.py:188); 0: continue a paused call */
+    int32_t have_guess0; /* a particle had a non-zero xi guess at entry (index_search.py:269)       */
+    int32_t fU, fV, fW, fKh_zonal, fKh_meridional; /* field ids, -1 if absent                       */
+    int32_t sort_by_cell; /* 1: reorder device rows by cell key before stepping (row order on the
+                              host is unaffected)                                                  */
+    int32_t reserved0;
+    double endtime; /* seconds; every live particle is advanced from its own t to endtime           */
+    double dt0;     /* execute()'s dt (sign gives the time direction)                               */
+    double rk45_tol, rk45_min_dt, rk45_max_dt; /* fieldset.context (kernel.py:134-159)              */
+    double dres;    /* fieldset.dres (_advectiondiffusion.py:40-58)                                 */
+    uint64_t seed;  /* counter-based RNG seed of the stochastic kernels                             */
+} pk_exec_params;
+
+typedef struct pk_exec_stats {
+    int64_t steps;    /* accepted position updates (kernel.py:219-222)                              */
+    int64_t attempts; /* kernel evaluations including RK45 repeats                                  */
+    int64_t paused;   /* particles that stopped because their next step needs a non-resident level  */
+    int64_t state_counts[PK_NUM_STATE_CODES]; /* histogram of `state` after the call                 */
+    double t_min_live, t_max_live; /* over particles still in Evaluate (NaN if none)                */
+    double kernel_ms; /* HIP-event time of the advection kernel(s) on the compute stream            */
+    double sort_ms;   /* HIP-event time of the cell sort (0 when not sorting)                        */
+    int32_t launches;
+    int32_t reserved0;
+} pk_exec_stats;
+int32_t pk_execute(pk_ctx* ctx, const pk_exec_params* params, pk_exec_stats* stats);
+
+/* ---- sampling: Field.eval / VectorField.eval at explicit points (field.py:145-195, 250-304) ------ */
+/* what = field id, or -1 for UV, -2 for UVW (fields taken from params).  All pointers are host
+ * arrays of length m; out_v/out_w/out_state may be NULL. */
+int32_t pk_eval(pk_ctx* ctx, const pk_exec_params* params, int32_t what, int64_t m, const double* t, const double* z,
+                const double* y, const double* x, double* out_u, double* out_v, double* out_w, int32_t* out_state);
+
+/* achieved copy bandwidth probe (device-to-device float4 copy), GB/s; used as a measured roofline denominator */
+int32_t pk_measure_copy_bandwidth(pk_ctx* ctx, int64_t bytes, int32_t iters, double* gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PARCELS_HIP_H */

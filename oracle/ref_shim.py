@@ -156,6 +156,8 @@ def load_reference() -> dict:
 
     import importlib
 
+    sys.dont_write_bytecode = True  # never write .pyc files into the read-only reference tree
+
     names = {
         "statuscodes": "parcels._core.statuscodes",
         "mesh": "parcels._core.mesh",

@@ -1,0 +1,694 @@
+// pk_api.hip -- host side of libparcels_hip.so: the C ABI of include/parcels_hip.h.
+//
+// Owns device memory (grids, field-level rings, particle columns), two HIP streams (compute + copy, so that
+// the upload of the next time level overlaps the RK sub-steps of the current one) and the launch logic.
+// gfx950 only; no CUDA/other-backend paths.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pk_kernels.h"
+
+using namespace pk;
+
+namespace {
+std::string g_init_error;
+}
+
+struct HostGrid {
+    pk_grid_desc desc;
+    DGrid d;
+    std::vector<void*> allocs;
+};
+
+struct HostField {
+    pk_field_desc desc;
+    DField d;
+    void* dev_data = nullptr;
+    double* dev_time = nullptr;
+    size_t level_bytes = 0;
+    std::vector<double> time;
+    std::vector<int32_t> slot_level;    // committed (usable) level per ring slot, -1 = empty
+    std::vector<int32_t> slot_pending;  // level being copied into the slot (async upload), -1 = none
+};
+
+struct pk_ctx {
+    int device = 0;
+    hipStream_t compute = nullptr, copy = nullptr;
+    hipEvent_t copy_done = nullptr, ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    bool copy_pending = false;
+    std::string err;
+    std::vector<HostGrid> grids;
+    std::vector<HostField> fields;
+    // particles
+    pk_particles_desc host{};
+    DParticles dev{};
+    int64_t capacity = 0;
+    bool bound = false;
+    // sorted-order bookkeeping
+    int64_t* d_perm = nullptr;  // device row -> original row (nullptr: identity)
+    // scratch
+    DCounters* d_counters = nullptr;
+    unsigned long long* d_summary = nullptr;  // PK_NUM_STATE_CODES counts + 2 ordered-double slots
+    // pinned staging ring for async level uploads
+    void* stage[2] = {nullptr, nullptr};
+    size_t stage_bytes[2] = {0, 0};
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    int stage_next = 0;
+    hipDeviceProp_t prop;
+
+    int32_t fail(const char* where, hipError_t e) {
+        err = std::string(where) + ": " + hipGetErrorString(e);
+        return -1;
+    }
+    int32_t fail(const std::string& msg) {
+        err = msg;
+        return -2;
+    }
+};
+
+#define PK_HIP(ctx, call)                                  \
+    do {                                                   \
+        hipError_t e_ = (call);                            \
+        if (e_ != hipSuccess) return (ctx)->fail(#call, e_); \
+    } while (0)
+
+// ---- small device kernels owned by this TU ------------------------------------------------------------
+namespace pk {
+
+PK_DEV unsigned long long order_double(double v) {  // order-preserving map double -> u64
+    unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
+
+// histogram of `state` + min/max of t over particles still in Evaluate
+__global__ void __launch_bounds__(256) summarize_kernel(const int32_t* state, const double* t, int64_t n,
+                                                        unsigned long long* out) {
+    __shared__ unsigned int hist[PK_NUM_STATE_CODES];
+    __shared__ unsigned long long smin, smax;
+    for (int k = threadIdx.x; k < PK_NUM_STATE_CODES; k += 256) hist[k] = 0;
+    if (threadIdx.x == 0) { smin = ~0ull; smax = 0ull; }
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        int s = state[i];
+        if (s >= 0 && s < PK_NUM_STATE_CODES) atomicAdd(&hist[s], 1u);
+        if (s == PK_EVALUATE) {
+            unsigned long long o = order_double(t[i]);
+            atomicMin(&smin, o);
+            atomicMax(&smax, o);
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < PK_NUM_STATE_CODES; k += 256)
+        if (hist[k]) atomicAdd(&out[k], (unsigned long long)hist[k]);
+    if (threadIdx.x == 0) {
+        atomicMin(&out[PK_NUM_STATE_CODES], smin);
+        atomicMax(&out[PK_NUM_STATE_CODES + 1], smax);
+    }
+}
+
+// Field.eval / VectorField.eval at explicit points (no particles): what >= 0 scalar field, -1 UV, -2 UVW
+template <class FT, int INTERP>
+__global__ void __launch_bounds__(256) eval_kernel(const KArgs a, int what, int64_t m, const double* t, const double* z,
+                                                   const double* y, const double* x, double* ou, double* ov, double* ow,
+                                                   int32_t* ost) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const DField& mf = a.fields[a.main_field];
+    const DGrid& mg = a.grids[a.main_grid];
+    Coords mc{mf.time, mg.depth, mg.lat, mg.lon};
+    PCtx c;
+    c.state = PK_EVALUATE;
+    c.pf = false;
+    c.hz = c.hy = c.hx = c.ht = 0;
+    for (int g = 0; g < PK_MAX_GRIDS; g++) c.first_eval[g] = true;
+    int32_t ei[PK_MAX_GRIDS] = {0, 0, 0, 0};
+    if (what < 0) {
+        double u, v, w;
+        eval_uvw<FT, -1, INTERP>(a, mc, c, ei, what == -2, t[i], z[i], y[i], x[i], false, u, v, w);
+        ou[i] = u;
+        if (ov) ov[i] = v;
+        if (ow) ow[i] = w;
+    } else {
+        ou[i] = eval_scalar<FT>(a, mc, c, ei, what, t[i], z[i], y[i], x[i], false);
+    }
+    if (ost) ost[i] = c.state;
+}
+
+__global__ void __launch_bounds__(256) copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+}  // namespace pk
+
+template <class T>
+static int32_t upload(pk_ctx* ctx, HostGrid& g, const T* host, size_t n, const T** dev) {
+    *dev = nullptr;
+    if (!host || n == 0) return 0;
+    void* p = nullptr;
+    PK_HIP(ctx, hipMalloc(&p, n * sizeof(T)));
+    g.allocs.push_back(p);
+    PK_HIP(ctx, hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice));
+    *dev = (const T*)p;
+    return 0;
+}
+
+
+// ---- context -------------------------------------------------------------------------------------------
+extern "C" {
+
+int32_t pk_abi_version(void) { return PK_ABI_VERSION; }
+
+const char* pk_last_error(const pk_ctx* ctx) { return ctx ? ctx->err.c_str() : g_init_error.c_str(); }
+
+int32_t pk_init(int32_t device, pk_ctx** out) {
+    if (!out) return -2;
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_init_error = std::string("no HIP device available: ") + hipGetErrorString(e);
+        return -1;
+    }
+    if (device < 0 || device >= ndev) {
+        g_init_error = "device index out of range";
+        return -2;
+    }
+    pk_ctx* ctx = new pk_ctx();
+    ctx->device = device;
+    *out = ctx;
+    PK_HIP(ctx, hipSetDevice(device));
+    PK_HIP(ctx, hipGetDeviceProperties(&ctx->prop, device));
+    PK_HIP(ctx, hipStreamCreateWithFlags(&ctx->compute, hipStreamNonBlocking));
+    PK_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
+    PK_HIP(ctx, hipEventCreateWithFlags(&ctx->copy_done, hipEventDisableTiming));
+    PK_HIP(ctx, hipEventCreate(&ctx->ev0));
+    PK_HIP(ctx, hipEventCreate(&ctx->ev1));
+    PK_HIP(ctx, hipEventCreate(&ctx->ev2));
+    PK_HIP(ctx, hipEventCreateWithFlags(&ctx->stage_ev[0], hipEventDisableTiming));
+    PK_HIP(ctx, hipEventCreateWithFlags(&ctx->stage_ev[1], hipEventDisableTiming));
+    PK_HIP(ctx, hipMalloc((void**)&ctx->d_counters, sizeof(DCounters)));
+    PK_HIP(ctx, hipMalloc((void**)&ctx->d_summary, sizeof(unsigned long long) * (PK_NUM_STATE_CODES + 2)));
+    return 0;
+}
+
+static void free_particles(pk_ctx* ctx) {
+    void* cols[] = {ctx->dev.t,  ctx->dev.z,  ctx->dev.y,       ctx->dev.x,     ctx->dev.dz, ctx->dev.dy,
+                    ctx->dev.dx, ctx->dev.dt, ctx->dev.next_dt, ctx->dev.state, ctx->dev.ei, ctx->dev.particle_id};
+    for (void* p : cols)
+        if (p) (void)hipFree(p);
+    if (ctx->d_perm) (void)hipFree(ctx->d_perm);
+    ctx->d_perm = nullptr;
+    ctx->dev = DParticles{};
+    ctx->capacity = 0;
+}
+
+int32_t pk_destroy(pk_ctx* ctx) {
+    if (!ctx) return 0;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (auto& g : ctx->grids)
+        for (void* p : g.allocs) (void)hipFree(p);
+    for (auto& f : ctx->fields) {
+        if (f.dev_data) (void)hipFree(f.dev_data);
+        if (f.dev_time) (void)hipFree(f.dev_time);
+    }
+    free_particles(ctx);
+    if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    if (ctx->d_summary) (void)hipFree(ctx->d_summary);
+    for (int k = 0; k < 2; k++) {
+        if (ctx->stage[k]) (void)hipHostFree(ctx->stage[k]);
+        if (ctx->stage_ev[k]) (void)hipEventDestroy(ctx->stage_ev[k]);
+    }
+    if (ctx->copy_done) (void)hipEventDestroy(ctx->copy_done);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
+    if (ctx->compute) (void)hipStreamDestroy(ctx->compute);
+    if (ctx->copy) (void)hipStreamDestroy(ctx->copy);
+    delete ctx;
+    return 0;
+}
+
+int32_t pk_get_device_info(pk_ctx* ctx, pk_device_info* out) {
+    if (!ctx || !out) return -2;
+    memset(out, 0, sizeof(*out));
+    snprintf(out->name, sizeof(out->name), "%s", ctx->prop.name);
+    snprintf(out->arch, sizeof(out->arch), "%s", ctx->prop.gcnArchName);
+    out->compute_units = ctx->prop.multiProcessorCount;
+    out->wavefront_size = ctx->prop.warpSize;
+    out->lds_bytes_per_block = (int32_t)ctx->prop.sharedMemPerBlock;
+    out->clock_khz = ctx->prop.clockRate;
+    size_t fr = 0, tot = 0;
+    PK_HIP(ctx, hipSetDevice(ctx->device));
+    PK_HIP(ctx, hipMemGetInfo(&fr, &tot));
+    out->total_mem = (int64_t)tot;
+    out->free_mem = (int64_t)fr;
+    return 0;
+}
+
+// ---- grids ---------------------------------------------------------------------------------------------
+int32_t pk_grid_create(pk_ctx* ctx, const pk_grid_desc* desc, int32_t* grid_id) {
+    if (!ctx || !desc || !grid_id) return -2;
+    if ((int)ctx->grids.size() >= PK_MAX_GRIDS) return ctx->fail("too many grids (PK_MAX_GRIDS)");
+    PK_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->grids.emplace_back();
+    HostGrid& g = ctx->grids.back();
+    g.desc = *desc;
+    DGrid& d = g.d;
+    memset(&d, 0, sizeof(d));
+    d.kind = desc->kind;
+    d.spherical = desc->spherical;
+    d.has_x = desc->has_x; d.has_y = desc->has_y; d.has_z = desc->has_z;
+    d.nx = desc->nx; d.ny = desc->ny; d.nz = desc->nz;
+    d.xdim = desc->xdim; d.ydim = desc->ydim; d.zdim = desc->zdim;
+    d.off_x = desc->off_x; d.off_y = desc->off_y; d.off_z = desc->off_z;
+    d.lon_f32 = desc->lon_f32; d.lat_f32 = desc->lat_f32; d.depth_f32 = desc->depth_f32;
+    d.deg2m = desc->deg2m;
+    const size_t nlon = desc->kind == 1 ? (size_t)desc->ny * desc->nx : (size_t)desc->nx;
+    const size_t nlat = desc->kind == 1 ? (size_t)desc->ny * desc->nx : (size_t)desc->ny;
+    int32_t rc;
+    if ((rc = upload(ctx, g, desc->lon, nlon, &d.lon))) return rc;
+    if ((rc = upload(ctx, g, desc->lat, nlat, &d.lat))) return rc;
+    if ((rc = upload(ctx, g, desc->depth, (size_t)desc->nz, &d.depth))) return rc;
+    if (desc->kind == 1) {
+        if (!desc->h_keys || desc->h_nkeys <= 0) return ctx->fail("curvilinear grid needs a spatial-hash table");
+        if ((rc = upload(ctx, g, desc->h_keys, (size_t)desc->h_nkeys, &d.h_keys))) return rc;
+        if ((rc = upload(ctx, g, desc->h_starts, (size_t)desc->h_nkeys, &d.h_starts))) return rc;
+        if ((rc = upload(ctx, g, desc->h_counts, (size_t)desc->h_nkeys, &d.h_counts))) return rc;
+        if ((rc = upload(ctx, g, desc->h_faces, (size_t)desc->h_nentries, &d.h_faces))) return rc;
+        d.h_nkeys = desc->h_nkeys;
+        d.h_bitwidth = desc->h_bitwidth;
+        for (int k = 0; k < 6; k++) d.h_bbox[k] = desc->h_bbox[k];
+    }
+    *grid_id = (int32_t)ctx->grids.size() - 1;
+    return 0;
+}
+
+// ---- fields --------------------------------------------------------------------------------------------
+int32_t pk_field_create(pk_ctx* ctx, const pk_field_desc* desc, int32_t* field_id) {
+    if (!ctx || !desc || !field_id) return -2;
+    if ((int)ctx->fields.size() >= PK_MAX_FIELDS) return ctx->fail("too many fields (PK_MAX_FIELDS)");
+    if (desc->grid < 0 || desc->grid >= (int)ctx->grids.size()) return ctx->fail("field refers to an unknown grid");
+    if (desc->dtype != PK_F32 && desc->dtype != PK_F64) return ctx->fail("field dtype must be PK_F32 or PK_F64");
+    if (desc->nt < 1 || desc->nz < 1 || desc->ny < 1 || desc->nx < 1) return ctx->fail("field extents must be >= 1");
+    PK_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->fields.emplace_back();
+    HostField& f = ctx->fields.back();
+    f.desc = *desc;
+    const size_t esz = desc->dtype == PK_F64 ? 8 : 4;
+    const size_t level_elems = (size_t)desc->nz * desc->ny * desc->nx;
+    f.level_bytes = level_elems * esz;
+    int nslots = desc->nslots;
+    if (nslots <= 0 || nslots >= desc->nt) nslots = desc->nt;
+    if (nslots < desc->nt && nslots < 2) nslots = 2;
+    f.slot_level.assign(nslots, -1);
+    f.slot_pending.assign(nslots, -1);
+    PK_HIP(ctx, hipMalloc(&f.dev_data, f.level_bytes * nslots));
+    PK_HIP(ctx, hipMemset(f.dev_data, 0, f.level_bytes * nslots));  // never expose NaN garbage (weight-0 reads)
+    f.time.assign(desc->nt, 0.0);
+    if (desc->time) std::copy(desc->time, desc->time + desc->nt, f.time.begin());
+    PK_HIP(ctx, hipMalloc((void**)&f.dev_time, sizeof(double) * desc->nt));
+    PK_HIP(ctx, hipMemcpy(f.dev_time, f.time.data(), sizeof(double) * desc->nt, hipMemcpyHostToDevice));
+    DField& d = f.d;
+    memset(&d, 0, sizeof(d));
+    d.grid = desc->grid;
+    d.dtype = desc->dtype;
+    d.nt = desc->nt; d.nz = desc->nz; d.ny = desc->ny; d.nx = desc->nx;
+    d.has_time_interval = desc->has_time_interval && desc->nt > 1;
+    d.is_const = desc->is_const;
+    d.nslots = nslots;
+    d.st_t = desc->has_t ? (int64_t)level_elems : 0;
+    d.st_z = desc->has_z ? (int64_t)desc->ny * desc->nx : 0;
+    d.st_y = desc->has_y ? (int64_t)desc->nx : 0;
+    d.st_x = desc->has_x ? 1 : 0;
+    d.data = f.dev_data;
+    d.time = f.dev_time;
+    d.tlen = f.time.back() - f.time.front();
+    *field_id = (int32_t)ctx->fields.size() - 1;
+    return 0;
+}
+
+int32_t pk_field_upload_level(pk_ctx* ctx, int32_t field_id, int32_t level, const void* host_data, int32_t async) {
+    if (!ctx || !host_data) return -2;
+    if (field_id < 0 || field_id >= (int)ctx->fields.size()) return ctx->fail("unknown field id");
+    HostField& f = ctx->fields[field_id];
+    if (level < 0 || level >= f.desc.nt) return ctx->fail("time level out of range");
+    PK_HIP(ctx, hipSetDevice(ctx->device));
+    const int slot = level % f.d.nslots;
+    char* dst = (char*)f.dev_data + (size_t)slot * f.level_bytes;
+    if (!async) {
+        PK_HIP(ctx, hipMemcpyAsync(dst, host_data, f.level_bytes, hipMemcpyHostToDevice, ctx->copy));
+        PK_HIP(ctx, hipStreamSynchronize(ctx->copy));
+    } else {
+        // pageable NumPy memory cannot be DMA'd asynchronously: bounce through a pinned staging ring (2 buffers)
+        const int k = ctx->stage_next;
+        ctx->stage_next ^= 1;
+        if (ctx->stage_bytes[k] < f.level_bytes) {
+            if (ctx->stage[k]) {
+                PK_HIP(ctx, hipEventSynchronize(ctx->stage_ev[k]));
+                PK_HIP(ctx, hipHostFree(ctx->stage[k]));
+                ctx->stage[k] = nullptr;
+            }
+            PK_HIP(ctx, hipHostMalloc(&ctx->stage[k], f.level_bytes, hipHostMallocDefault));
+            ctx->stage_bytes[k] = f.level_bytes;
+        } else {
+            PK_HIP(ctx, hipEventSynchronize(ctx->stage_ev[k]));  // previous DMA out of this buffer finished
+        }
+        memcpy(ctx->stage[k], host_data, f.level_bytes);
+        PK_HIP(ctx, hipMemcpyAsync(dst, ctx->stage[k], f.level_bytes, hipMemcpyHostToDevice, ctx->copy));
+        PK_HIP(ctx, hipEventRecord(ctx->stage_ev[k], ctx->copy));
+    }
+    if (async) {  // usable only after pk_field_sync(); the level that lived in this slot is gone as of now
+        f.slot_level[slot] = -1;
+        f.slot_pending[slot] = level;
+        ctx->copy_pending = true;
+    } else {
+        f.slot_level[slot] = level;
+        f.slot_pending[slot] = -1;
+    }
+    return 0;
+}
+
+int32_t pk_field_sync(pk_ctx* ctx) {
+    if (!ctx) return -2;
+    PK_HIP(ctx, hipSetDevice(ctx->device));
+    PK_HIP(ctx, hipStreamSynchronize(ctx->copy));
+    for (auto& f : ctx->fields)
+        for (size_t k = 0; k < f.slot_pending.size(); k++)
+            if (f.slot_pending[k] >= 0) {
+                f.slot_level[k] = f.slot_pending[k];
+                f.slot_pending[k] = -1;
+            }
+    ctx->copy_pending = false;
+    return 0;
+}
+
+int32_t pk_field_slots(pk_ctx* ctx, int32_t field_id, int32_t* levels, int32_t* nslots) {
+    if (!ctx) return -2;
+    if (field_id < 0 || field_id >= (int)ctx->fields.size()) return ctx->fail("unknown field id");
+    HostField& f = ctx->fields[field_id];
+    if (nslots) *nslots = f.d.nslots;
+    if (levels)
+        for (int k = 0; k < f.d.nslots; k++) levels[k] = f.slot_level[k];
+    return 0;
+}
+
+// ---- particles -----------------------------------------------------------------------------------------
+static size_t spatial_size(const pk_ctx* ctx) { return ctx->host.spatial_dtype == PK_F32 ? 4 : 8; }
+
+int32_t pk_particles_bind(pk_ctx* ctx, const pk_particles_desc* host) {
+    if (!ctx || !host) return -2;
+    if (host->n < 0 || host->ngrids < 1 || host->ngrids > PK_MAX_GRIDS) return ctx->fail("bad particle descriptor");
+    if (host->n > 0 && (!host->t || !host->z || !host->y || !host->x || !host->dz || !host->dy || !host->dx || !host->dt ||
+                        !host->state || !host->ei || !host->particle_id))
+        return ctx->fail("particle columns must not be NULL");
+    PK_HIP(ctx, hipSetDevice(ctx->device));
+    const bool realloc_needed = !ctx->bound || host->n > ctx->capacity || host->ngrids != ctx->host.ngrids ||
+                                host->spatial_dtype != ctx->host.spatial_dtype || (host->next_dt != nullptr) != (ctx->dev.next_dt != nullptr);
+    ctx->host = *host;
+    if (realloc_needed) {
+        free_particles(ctx);
+        const int64_t cap = std::max<int64_t>(host->n, 1);
+        const size_t ss = spatial_size(ctx);
+        PK_HIP(ctx, hipMalloc((void**)&ctx->dev.t, cap * 8));
+        PK_HIP(ctx, hipMalloc(&ctx->dev.z, cap * ss));
+        PK_HIP(ctx, hipMalloc(&ctx->dev.y, cap * ss));
+        PK_HIP(ctx, hipMalloc(&ctx->dev.x, cap * ss));
+        PK_HIP(ctx, hipMalloc(&ctx->dev.dz, cap * ss));
+        PK_HIP(ctx, hipMalloc(&ctx->dev.dy, cap * ss));
+        PK_HIP(ctx, hipMalloc(&ctx->dev.dx, cap * ss));
+        PK_HIP(ctx, hipMalloc((void**)&ctx->dev.dt, cap * 8));
+        if (host->next_dt) PK_HIP(ctx, hipMalloc((void**)&ctx->dev.next_dt, cap * 8));
+        PK_HIP(ctx, hipMalloc((void**)&ctx->dev.state, cap * 4));
+        PK_HIP(ctx, hipMalloc((void**)&ctx->dev.ei, cap * 4 * host->ngrids));
+        PK_HIP(ctx, hipMalloc((void**)&ctx->dev.particle_id, cap * 8));
+        ctx->capacity = cap;
+    }
+    ctx->dev.n = host->n;
+    ctx->dev.ngrids = host->ngrids;
+    ctx->dev.spatial_f32 = host->spatial_dtype == PK_F32;
+    ctx->bound = true;
+    return 0;
+}
+
+static int32_t copy_particles(pk_ctx* ctx, bool to_device) {
+    if (!ctx->bound) return ctx->fail("no particles bound");
+    PK_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t n = ctx->host.n;
+    if (n == 0) return 0;
+    const size_t ss = spatial_size(ctx);
+    struct Col { void* h; void* d; size_t bytes; };
+    const Col cols[] = {
+        {ctx->host.t, ctx->dev.t, (size_t)n * 8},         {ctx->host.z, ctx->dev.z, (size_t)n * ss},
+        {ctx->host.y, ctx->dev.y, (size_t)n * ss},        {ctx->host.x, ctx->dev.x, (size_t)n * ss},
+        {ctx->host.dz, ctx->dev.dz, (size_t)n * ss},      {ctx->host.dy, ctx->dev.dy, (size_t)n * ss},
+        {ctx->host.dx, ctx->dev.dx, (size_t)n * ss},      {ctx->host.dt, ctx->dev.dt, (size_t)n * 8},
+        {ctx->host.next_dt, ctx->dev.next_dt, (size_t)n * 8}, {ctx->host.state, ctx->dev.state, (size_t)n * 4},
+        {ctx->host.ei, ctx->dev.ei, (size_t)n * 4 * ctx->host.ngrids},
+        {ctx->host.particle_id, ctx->dev.particle_id, (size_t)n * 8},
+    };
+    for (const Col& c : cols) {
+        if (!c.h || !c.d) continue;
+        if (to_device) PK_HIP(ctx, hipMemcpyAsync(c.d, c.h, c.bytes, hipMemcpyHostToDevice, ctx->compute));
+        else PK_HIP(ctx, hipMemcpyAsync(c.h, c.d, c.bytes, hipMemcpyDeviceToHost, ctx->compute));
+    }
+    PK_HIP(ctx, hipStreamSynchronize(ctx->compute));
+    return 0;
+}
+
+int32_t pk_particles_h2d(pk_ctx* ctx) {
+    if (!ctx) return -2;
+    return copy_particles(ctx, true);
+}
+int32_t pk_particles_d2h(pk_ctx* ctx) {
+    if (!ctx) return -2;
+    return copy_particles(ctx, false);
+}
+
+int32_t pk_particles_device(pk_ctx* ctx, pk_particles_desc* dev, int64_t** perm) {
+    if (!ctx || !dev) return -2;
+    if (!ctx->bound) return ctx->fail("no particles bound");
+    dev->n = ctx->dev.n;
+    dev->ngrids = ctx->dev.ngrids;
+    dev->spatial_dtype = ctx->host.spatial_dtype;
+    dev->t = ctx->dev.t;
+    dev->z = ctx->dev.z; dev->y = ctx->dev.y; dev->x = ctx->dev.x;
+    dev->dz = ctx->dev.dz; dev->dy = ctx->dev.dy; dev->dx = ctx->dev.dx;
+    dev->dt = ctx->dev.dt;
+    dev->next_dt = ctx->dev.next_dt;
+    dev->state = ctx->dev.state;
+    dev->ei = ctx->dev.ei;
+    dev->particle_id = ctx->dev.particle_id;
+    if (perm) *perm = ctx->d_perm;
+    return 0;
+}
+
+// ---- execution -----------------------------------------------------------------------------------------
+static int32_t fill_args(pk_ctx* ctx, const pk_exec_params* prm, KArgs& a, size_t& lds_bytes, int& use_lds) {
+    memset(&a, 0, sizeof(a));
+    for (size_t g = 0; g < ctx->grids.size(); g++) a.grids[g] = ctx->grids[g].d;
+    for (size_t f = 0; f < ctx->fields.size(); f++) a.fields[f] = ctx->fields[f].d;
+    a.p = ctx->dev;
+    a.prm = *prm;
+    a.counters = ctx->d_counters;
+    const int nf = (int)ctx->fields.size();
+    auto valid = [&](int f) { return f >= 0 && f < nf; };
+    if (!valid(prm->fU) || !valid(prm->fV)) return ctx->fail("params.fU/fV must name existing fields");
+    if (prm->fW >= nf || prm->fKh_zonal >= nf || prm->fKh_meridional >= nf) return ctx->fail("params refer to unknown fields");
+    a.main_field = prm->fU;
+    a.main_grid = ctx->fields[prm->fU].d.grid;
+    const HostField& mf = ctx->fields[prm->fU];
+    const HostGrid& mg = ctx->grids[a.main_grid];
+    // resident time window of the main field's ring (all time-varying fields are uploaded in lock step)
+    a.win_lo = -INFINITY;
+    a.win_hi = INFINITY;
+    if (mf.d.has_time_interval) {
+        int lo = 1 << 30, hi = -1, cnt = 0;
+        for (int lv : mf.slot_level)
+            if (lv >= 0) { lo = std::min(lo, lv); hi = std::max(hi, lv); cnt++; }
+        if (cnt == 0) return ctx->fail("no time level of the velocity field is resident (pk_field_upload_level)");
+        if (hi - lo + 1 != cnt) return ctx->fail("resident time levels are not contiguous");
+        a.win_lo = mf.time[lo];
+        a.win_hi = mf.time[hi];
+        if (lo == 0) a.win_lo = -INFINITY;            // nothing earlier exists: let the kernels raise code 70
+        if (hi == mf.desc.nt - 1) a.win_hi = INFINITY;
+    }
+    // LDS staging of the main grid's 1-D vectors
+    const int nt = mf.d.has_time_interval ? mf.d.nt : 0;
+    const int nz = mg.d.has_z ? mg.d.nz : 0;
+    const int ny = mg.d.kind == 0 ? mg.d.ny : 0;
+    const int nx = mg.d.kind == 0 ? mg.d.nx : 0;
+    a.lds_time = 0;
+    a.lds_depth = a.lds_time + nt;
+    a.lds_lat = a.lds_depth + nz;
+    a.lds_lon = a.lds_lat + ny;
+    a.lds_total = a.lds_lon + nx;
+    lds_bytes = (size_t)std::max(a.lds_total, 1) * sizeof(double);
+    use_lds = lds_bytes <= 64 * 1024;
+    if (!use_lds) lds_bytes = 0;
+    return 0;
+}
+
+int32_t pk_execute(pk_ctx* ctx, const pk_exec_params* prm, pk_exec_stats* stats) {
+    if (!ctx || !prm) return -2;
+    if (!ctx->bound) return ctx->fail("no particles bound");
+    if (prm->nk < 1 || prm->nk > PK_MAX_KERNELS) return ctx->fail("params.nk out of range");
+    PK_HIP(ctx, hipSetDevice(ctx->device));
+    if (stats) memset(stats, 0, sizeof(*stats));
+    KArgs a;
+    size_t lds_bytes = 0;
+    int use_lds = 0;
+    int32_t rc = fill_args(ctx, prm, a, lds_bytes, use_lds);
+    if (rc) return rc;
+    bool need_kh = false;
+    for (int k = 0; k < prm->nk; k++) {
+        const int id = prm->kernels[k];
+        if (id == PK_KERNEL_ADVECTIONDIFFUSION_M1 || id == PK_KERNEL_ADVECTIONDIFFUSION_EM || id == PK_KERNEL_DIFFUSION_UNIFORM_KH)
+            need_kh = true;
+        if (id == PK_KERNEL_ADVECTION_RK45 && !ctx->dev.next_dt) return ctx->fail("AdvectionRK45 needs the next_dt column");
+        if ((id == PK_KERNEL_ADVECTION_RK4_3D || id == PK_KERNEL_ADVECTION_RK2_3D) && prm->fW < 0)
+            return ctx->fail("3-D advection needs the W field");
+    }
+    if (need_kh && (prm->fKh_zonal < 0 || prm->fKh_meridional < 0)) return ctx->fail("diffusion kernels need Kh_zonal/Kh_meridional");
+    const HostField& U = ctx->fields[prm->fU];
+    const int field_f32 = U.d.dtype == PK_F32;
+    for (int f : {prm->fV, prm->fW})
+        if (f >= 0 && ctx->fields[f].d.dtype != U.d.dtype) return ctx->fail("U, V, W must share one dtype");
+    const int curv = ctx->grids[a.main_grid].d.kind == 1;
+    const int64_t n = ctx->dev.n;
+    PK_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(DCounters), ctx->compute));
+    PK_HIP(ctx, hipMemsetAsync(ctx->d_summary, 0, sizeof(unsigned long long) * PK_NUM_STATE_CODES, ctx->compute));
+    const unsigned long long init_mm[2] = {~0ull, 0ull};
+    PK_HIP(ctx, hipMemcpyAsync(ctx->d_summary + PK_NUM_STATE_CODES, init_mm, sizeof(init_mm), hipMemcpyHostToDevice, ctx->compute));
+    int launches = 0;
+    if (n > 0) {
+        const dim3 grid((unsigned)((n + 255) / 256));
+        int prog = PROG_GENERIC;
+        if (prm->nk == 1 && use_lds) {
+            if (prm->kernels[0] == PK_KERNEL_ADVECTION_RK4) prog = PROG_RK4;
+            if (prm->kernels[0] == PK_KERNEL_ADVECTION_RK4_3D) prog = PROG_RK4_3D;
+        }
+        PK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->compute));
+        switch (prog) {
+            case PROG_RK4: launch_program<PROG_RK4>(field_f32, curv, prm->interp_uv, use_lds, a, grid, lds_bytes, ctx->compute); break;
+            case PROG_RK4_3D: launch_program<PROG_RK4_3D>(field_f32, curv, prm->interp_uv, use_lds, a, grid, lds_bytes, ctx->compute); break;
+            default: launch_program<PROG_GENERIC>(field_f32, curv, prm->interp_uv, use_lds, a, grid, lds_bytes, ctx->compute); break;
+        }
+        PK_HIP(ctx, hipGetLastError());
+        PK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->compute));
+        launches = 1;
+        const unsigned sgrid = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
+        hipLaunchKernelGGL(summarize_kernel, dim3(sgrid), dim3(256), 0, ctx->compute, ctx->dev.state, ctx->dev.t, n, ctx->d_summary);
+        PK_HIP(ctx, hipGetLastError());
+    }
+    DCounters hc{};
+    unsigned long long hs[PK_NUM_STATE_CODES + 2];
+    PK_HIP(ctx, hipMemcpyAsync(&hc, ctx->d_counters, sizeof(hc), hipMemcpyDeviceToHost, ctx->compute));
+    PK_HIP(ctx, hipMemcpyAsync(hs, ctx->d_summary, sizeof(hs), hipMemcpyDeviceToHost, ctx->compute));
+    PK_HIP(ctx, hipStreamSynchronize(ctx->compute));
+    if (stats) {
+        stats->steps = (int64_t)hc.steps;
+        stats->attempts = (int64_t)hc.attempts;
+        stats->paused = (int64_t)hc.paused;
+        for (int k = 0; k < PK_NUM_STATE_CODES; k++) stats->state_counts[k] = (int64_t)hs[k];
+        auto unorder = [](unsigned long long o) {
+            unsigned long long b = (o & 0x8000000000000000ull) ? (o & 0x7fffffffffffffffull) : ~o;
+            double v;
+            memcpy(&v, &b, 8);
+            return v;
+        };
+        const bool any_live = n > 0 && hs[PK_EVALUATE] > 0;
+        stats->t_min_live = any_live ? unorder(hs[PK_NUM_STATE_CODES]) : NAN;
+        stats->t_max_live = any_live ? unorder(hs[PK_NUM_STATE_CODES + 1]) : NAN;
+        float ms = 0.f;
+        if (launches) PK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        stats->kernel_ms = ms;
+        stats->sort_ms = 0.0;
+        stats->launches = launches;
+    }
+    return 0;
+}
+
+// ---- sampling ------------------------------------------------------------------------------------------
+int32_t pk_eval(pk_ctx* ctx, const pk_exec_params* prm, int32_t what, int64_t m, const double* t, const double* z,
+                const double* y, const double* x, double* out_u, double* out_v, double* out_w, int32_t* out_state) {
+    if (!ctx || !prm || !t || !z || !y || !x || !out_u) return -2;
+    PK_HIP(ctx, hipSetDevice(ctx->device));
+    if (m <= 0) return 0;
+    pk_exec_params p2 = *prm;
+    if (what >= 0) {  // scalar sampling: the main grid is the sampled field's grid
+        if (what >= (int)ctx->fields.size()) return ctx->fail("unknown field id");
+        if (p2.fU < 0) { p2.fU = what; p2.fV = what; }
+    }
+    DParticles saved = ctx->dev;
+    const bool was_bound = ctx->bound;
+    KArgs a;
+    size_t lds_bytes;
+    int use_lds;
+    ctx->bound = true;
+    int32_t rc = fill_args(ctx, &p2, a, lds_bytes, use_lds);
+    ctx->bound = was_bound;
+    ctx->dev = saved;
+    if (rc) return rc;
+    a.win_lo = -INFINITY;
+    a.win_hi = INFINITY;
+    double* d = nullptr;
+    int32_t* ds = nullptr;
+    PK_HIP(ctx, hipMalloc((void**)&d, sizeof(double) * m * 7));
+    PK_HIP(ctx, hipMalloc((void**)&ds, sizeof(int32_t) * m));
+    double *dt_ = d, *dz = d + m, *dy = d + 2 * m, *dx = d + 3 * m, *du = d + 4 * m, *dv = d + 5 * m, *dw = d + 6 * m;
+    PK_HIP(ctx, hipMemcpyAsync(dt_, t, sizeof(double) * m, hipMemcpyHostToDevice, ctx->compute));
+    PK_HIP(ctx, hipMemcpyAsync(dz, z, sizeof(double) * m, hipMemcpyHostToDevice, ctx->compute));
+    PK_HIP(ctx, hipMemcpyAsync(dy, y, sizeof(double) * m, hipMemcpyHostToDevice, ctx->compute));
+    PK_HIP(ctx, hipMemcpyAsync(dx, x, sizeof(double) * m, hipMemcpyHostToDevice, ctx->compute));
+    const dim3 grid((unsigned)((m + 255) / 256));
+    const int fsel = what >= 0 ? what : p2.fU;
+    const bool f32 = ctx->fields[fsel].d.dtype == PK_F32;
+    if (f32) {
+        if (p2.interp_uv) hipLaunchKernelGGL((eval_kernel<float, 1>), grid, dim3(256), 0, ctx->compute, a, what, m, dt_, dz, dy, dx, du, dv, dw, ds);
+        else hipLaunchKernelGGL((eval_kernel<float, 0>), grid, dim3(256), 0, ctx->compute, a, what, m, dt_, dz, dy, dx, du, dv, dw, ds);
+    } else {
+        if (p2.interp_uv) hipLaunchKernelGGL((eval_kernel<double, 1>), grid, dim3(256), 0, ctx->compute, a, what, m, dt_, dz, dy, dx, du, dv, dw, ds);
+        else hipLaunchKernelGGL((eval_kernel<double, 0>), grid, dim3(256), 0, ctx->compute, a, what, m, dt_, dz, dy, dx, du, dv, dw, ds);
+    }
+    PK_HIP(ctx, hipGetLastError());
+    PK_HIP(ctx, hipMemcpyAsync(out_u, du, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->compute));
+    if (out_v) PK_HIP(ctx, hipMemcpyAsync(out_v, dv, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->compute));
+    if (out_w) PK_HIP(ctx, hipMemcpyAsync(out_w, dw, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->compute));
+    if (out_state) PK_HIP(ctx, hipMemcpyAsync(out_state, ds, sizeof(int32_t) * m, hipMemcpyDeviceToHost, ctx->compute));
+    PK_HIP(ctx, hipStreamSynchronize(ctx->compute));
+    PK_HIP(ctx, hipFree(d));
+    PK_HIP(ctx, hipFree(ds));
+    return 0;
+}
+
+int32_t pk_measure_copy_bandwidth(pk_ctx* ctx, int64_t bytes, int32_t iters, double* gbps) {
+    if (!ctx || !gbps || bytes < 16 || iters < 1) return -2;
+    PK_HIP(ctx, hipSetDevice(ctx->device));
+    void *src = nullptr, *dst = nullptr;
+    const int64_t n16 = bytes / 16;
+    PK_HIP(ctx, hipMalloc(&src, n16 * 16));
+    PK_HIP(ctx, hipMalloc(&dst, n16 * 16));
+    PK_HIP(ctx, hipMemsetAsync(src, 1, n16 * 16, ctx->compute));
+    const unsigned grid = (unsigned)std::min<int64_t>((n16 + 255) / 256, 256 * 8 * 4);
+    hipLaunchKernelGGL(copy_kernel, dim3(grid), dim3(256), 0, ctx->compute, (const float4*)src, (float4*)dst, n16);
+    PK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->compute));
+    for (int k = 0; k < iters; k++)
+        hipLaunchKernelGGL(copy_kernel, dim3(grid), dim3(256), 0, ctx->compute, (const float4*)src, (float4*)dst, n16);
+    PK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->compute));
+    PK_HIP(ctx, hipStreamSynchronize(ctx->compute));
+    float ms = 0.f;
+    PK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *gbps = (2.0 * (double)n16 * 16.0 * iters) / ((double)ms * 1e-3) / 1e9;
+    PK_HIP(ctx, hipFree(src));
+    PK_HIP(ctx, hipFree(dst));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,701 @@
+// pk_device.h -- device-side numerics of the MI355X particle engine (gfx950 only, HIP).
+//
+// One lane == one particle.  Everything a particle needs for a field evaluation happens in registers:
+// time search, 1-D / curvilinear cell search, corner gather, interpolation, status-code update.
+// The arithmetic follows the reference expression by expression (file:line cited per function, paths
+// relative to /root/reference/src/parcels) and the library is built with -ffp-contract=off because
+// NumPy never fuses a*b+c; that is what makes fp64 trajectories agree with the reference to rounding.
+//
+// This file is written from scratch for CDNA4; it shares no code with oracle/ (the checker).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/parcels_hip.h"
+
+namespace pk {
+
+// ---- device descriptors (built on the host from pk_grid_desc / pk_field_desc) ------------------------
+struct DGrid {
+    int32_t kind, spherical;
+    int32_t has_x, has_y, has_z;
+    int32_t nx, ny, nz;
+    int32_t xdim, ydim, zdim;
+    int32_t off_x, off_y, off_z;
+    int32_t lon_f32, lat_f32, depth_f32;
+    int32_t h_bitwidth;
+    double deg2m;
+    const double* lon;
+    const double* lat;
+    const double* depth;
+    const uint32_t* h_keys;
+    const int64_t* h_starts;
+    const int64_t* h_counts;
+    const uint32_t* h_faces;
+    int64_t h_nkeys;
+    double h_bbox[6];
+};
+
+struct DField {
+    int32_t grid, dtype;
+    int32_t nt, nz, ny, nx;
+    int32_t has_time_interval, is_const;
+    int32_t nslots, pad;
+    int64_t st_t, st_z, st_y, st_x;  // element strides (0 for axes the field does not have)
+    const void* data;                // nslots * st_t elements (ring of time levels)
+    const double* time;              // nt
+    double tlen;                     // time[nt-1] - time[0]
+};
+
+struct DParticles {
+    int64_t n;
+    int32_t ngrids, spatial_f32;
+    double* t;
+    void *z, *y, *x, *dz, *dy, *dx;
+    double* dt;
+    double* next_dt;
+    int32_t* state;
+    int32_t* ei;
+    int64_t* particle_id;
+};
+
+struct DCounters {
+    unsigned long long steps, attempts, paused;
+};
+
+struct KArgs {
+    DGrid grids[PK_MAX_GRIDS];
+    DField fields[PK_MAX_FIELDS];
+    DParticles p;
+    pk_exec_params prm;
+    double win_lo, win_hi;  // resident time window of the time-varying fields (seconds)
+    DCounters* counters;
+    // LDS layout of the main grid's 1-D arrays (element offsets into the dynamic shared array, -1 = global)
+    int32_t lds_time, lds_depth, lds_lat, lds_lon, lds_total;
+    int32_t main_grid, main_field;
+};
+
+// ---- small helpers ------------------------------------------------------------------------------------
+#define PK_DEV __device__ __forceinline__
+
+PK_DEV int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+PK_DEV int mini(int a, int b) { return a < b ? a : b; }
+
+// NumPy's sort order puts NaN last; searchsorted uses it (index_search.py:47)
+PK_DEV bool np_less(double a, double b) { return a < b || (b != b && a == a); }
+
+static constexpr double DEG2RAD = 3.14159265358979323846 / 180.0;          // npy_deg2rad: x*(NPY_PI/180.0)
+static constexpr float DEG2RADF = 3.14159265358979323846f / 180.0f;        // float32 ufunc loop
+static constexpr int GRID_SEARCH_ERROR = -3;                                // index_search.py:15-17
+static constexpr int LEFT_OUT_OF_BOUNDS = -2;
+static constexpr int RIGHT_OUT_OF_BOUNDS = -1;
+
+struct GPos {
+    int ti, zi, yi, xi;
+    double tau, zeta, eta, xsi;
+};
+
+// Coordinate vectors of the main grid, either LDS-staged or global (address space is inferred after inlining).
+struct Coords {
+    const double* time;
+    const double* depth;
+    const double* lat;
+    const double* lon;
+};
+
+// clip(searchsorted(arr, x, "left") - 1, 0, n-2) (index_search.py:47), found by walking from `hint`
+// (the cell of the previous evaluation: particles move < 1 cell per stage) with a binary-search fallback.
+PK_DEV int cell_index(const double* arr, int n, double x, int hint) {
+    if (x != x) return n - 2;  // NaN sorts last
+    int i = clampi(hint, 0, n - 2);
+    // invariant wanted: (i == 0 || arr[i] < x) && (i == n-2 || !(arr[i+1] < x))
+    if (arr[i] < x) {
+        int k = 0;
+        while (i < n - 2 && arr[i + 1] < x) {
+            ++i;
+            if (++k == 3) {  // far from the hint: bisect the rest
+                int lo = i + 1, hi = n;  // first index in (i, n) with !(arr < x)
+                while (lo < hi) {
+                    int mid = (lo + hi) >> 1;
+                    if (arr[mid] < x) lo = mid + 1; else hi = mid;
+                }
+                i = clampi(lo - 1, 0, n - 2);
+                break;
+            }
+        }
+    } else {
+        int k = 0;
+        while (i > 0 && !(arr[i] < x)) {
+            --i;
+            if (++k == 3) {
+                int lo = 0, hi = i + 1;
+                while (lo < hi) {
+                    int mid = (lo + hi) >> 1;
+                    if (arr[mid] < x) lo = mid + 1; else hi = mid;
+                }
+                i = clampi(lo - 1, 0, n - 2);
+                break;
+            }
+        }
+    }
+    return i;
+}
+
+// _search_1d_array (index_search.py:20-62)
+PK_DEV void search_1d(const double* arr, int n, double x, bool arr_f32, bool x_f32, int hint, int& idx, double& bc) {
+    if (n < 2) {  // :45-46, no out-of-bounds codes in this branch
+        idx = 0;
+        bc = 0.0;
+        return;
+    }
+    int i = cell_index(arr, n, x, hint);
+    double a0 = arr[i], a1 = arr[i + 1];
+    if (arr_f32) {
+        float d = (float)a1 - (float)a0;  // f32 array: the width is an f32 subtraction in NumPy
+        bc = x_f32 ? (double)(((float)x - (float)a0) / d) : (x - a0) / (double)d;
+    } else {
+        bc = (x - a0) / (a1 - a0);
+    }
+    if (x < arr[0]) i = LEFT_OUT_OF_BOUNDS;        // :59
+    if (x > arr[n - 1]) i = RIGHT_OUT_OF_BOUNDS;   // :60
+    idx = i;
+}
+
+// ---- curvilinear point-in-cell (index_search.py:94-239, 439-450) -------------------------------------
+// np.dot(_invA, p): the integer matrix is promoted to float and every product is formed, also 0*p and 1*p
+// (exact for finite p), accumulated left to right.
+PK_DEV void bilinear_inverse(const double px[4], const double py[4], double xq, double yq, double& xsi, double& eta) {
+    double a0 = px[0];
+    double a1 = -px[0] + px[1];
+    double a2 = -px[0] + px[3];
+    double a3 = ((px[0] + -px[1]) + px[2]) + -px[3];
+    double b0 = py[0];
+    double b1 = -py[0] + py[1];
+    double b2 = -py[0] + py[3];
+    double b3 = ((py[0] + -py[1]) + py[2]) + -py[3];
+    double aa = a3 * b2 - a2 * b3;
+    double bb = a3 * b0 - a0 * b3 + a1 * b2 - a2 * b1 + xq * b3 - yq * a3;
+    double cc = a1 * b0 - a0 * b1 + xq * b1 - yq * a1;
+    double det2 = bb * bb - 4 * aa * cc;
+    double det = det2 > 0 ? sqrt(det2) : -1.0;
+    double e;
+    if (fabs(aa) < 1e-12) e = -cc / bb;
+    else e = det2 > 0 ? (-bb + det) / (2 * aa) : -1.0;
+    double x;
+    if (fabs(a1 + a3 * e) < 1e-12) x = ((yq - py[0]) / (py[1] - py[0]) + (yq - py[3]) / (py[2] - py[3])) * 0.5;
+    else x = (xq - a0 - a2 * e) / (a1 + a3 * e);
+    xsi = x;
+    eta = e;
+}
+
+PK_DEV void latlon_rad_to_xyz(double lat, double lon, double& X, double& Y, double& Z) {
+    double sl, cl, so, co;
+    sincos(lat, &sl, &cl);
+    sincos(lon, &so, &co);
+    X = co * cl;
+    Y = so * cl;
+    Z = sl;
+}
+
+PK_DEV void spherical_project(const double clon[4], const double clat[4], double x, double y, double pu[4], double pv[4],
+                              double& xq, double& yq) {
+    double cX[4], cY[4], cZ[4], qX, qY, qZ;
+#pragma unroll
+    for (int k = 0; k < 4; k++) latlon_rad_to_xyz(clat[k] * DEG2RAD, clon[k] * DEG2RAD, cX[k], cY[k], cZ[k]);
+    latlon_rad_to_xyz(y * DEG2RAD, x * DEG2RAD, qX, qY, qZ);
+    double ux = (cX[1] + cX[2]) - (cX[0] + cX[3]);
+    double uy = (cY[1] + cY[2]) - (cY[0] + cY[3]);
+    double uz = (cZ[1] + cZ[2]) - (cZ[0] + cZ[3]);
+    double un = sqrt(ux * ux + uy * uy + uz * uz);
+    if (un == 0.0) un = 1.0;
+    double eux = ux / un, euy = uy / un, euz = uz / un;
+    double vx = (cX[2] + cX[3]) - (cX[0] + cX[1]);
+    double vy = (cY[2] + cY[3]) - (cY[0] + cY[1]);
+    double vz = (cZ[2] + cZ[3]) - (cZ[0] + cZ[1]);
+    double vd = vx * eux + vy * euy + vz * euz;
+    vx = vx - vd * eux;
+    vy = vy - vd * euy;
+    vz = vz - vd * euz;
+    double vn = sqrt(vx * vx + vy * vy + vz * vz);
+    if (vn == 0.0) vn = 1.0;
+    double evx = vx / vn, evy = vy / vn, evz = vz / vn;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        pu[k] = cX[k] * eux + cY[k] * euy + cZ[k] * euz;
+        pv[k] = cX[k] * evx + cY[k] * evy + cZ[k] * evz;
+    }
+    xq = qX * eux + qY * euy + qZ * euz;
+    yq = qX * evx + qY * evy + qZ * evz;
+}
+
+// curvilinear_point_in_cell (index_search.py:94-120); (yi, xi) must be a valid cell
+PK_DEV bool point_in_cell(const DGrid& g, double y, double x, int yi, int xi, double& xsi, double& eta) {
+    const int64_t i00 = (int64_t)yi * g.nx + xi, i10 = i00 + g.nx;
+    double clon[4] = {g.lon[i00], g.lon[i00 + 1], g.lon[i10 + 1], g.lon[i10]};
+    double clat[4] = {g.lat[i00], g.lat[i00 + 1], g.lat[i10 + 1], g.lat[i10]};
+    if (g.spherical) {
+        double pu[4], pv[4], xq, yq;
+        spherical_project(clon, clat, x, y, pu, pv, xq, yq);
+        bilinear_inverse(pu, pv, xq, yq, xsi, eta);
+    } else {
+        bilinear_inverse(clon, clat, x, y, xsi, eta);
+    }
+    return (xsi >= 0) && (xsi <= 1) && (eta >= 0) && (eta <= 1);
+}
+
+// ---- Morton spatial hash query (spatialhash.py:389-535, 554-597, 647-765) ------------------------------
+PK_DEV uint32_t dilate_bits(uint32_t n) {
+    n &= 0x000003FFu;
+    n = (n | (n << 16)) & 0xFF0000FFu;
+    n = (n | (n << 8)) & 0x0300F00Fu;
+    n = (n | (n << 4)) & 0x030C30C3u;
+    n = (n | (n << 2)) & 0x09249249u;
+    return n;
+}
+PK_DEV uint32_t quantize(double v, double vmin, double vmax, int bitwidth) {
+    double d = vmax - vmin;
+    double vn = (d != 0) ? (v - vmin) / d : 0.0;
+    double q = vn * bitwidth;
+    if (!(q >= 0)) q = 0;  // also NaN (rejected by the finite mask anyway)
+    if (q > bitwidth) q = bitwidth;
+    return (uint32_t)q;
+}
+PK_DEV uint32_t morton_code(const DGrid& g, double y, double x) {
+    double qx, qy, qz;
+    if (g.spherical) latlon_rad_to_xyz(y * DEG2RAD, x * DEG2RAD, qx, qy, qz);
+    else { qx = x; qy = y; qz = 0.0; }
+    return (dilate_bits(quantize(qz, g.h_bbox[4], g.h_bbox[5], g.h_bitwidth)) << 2) |
+           (dilate_bits(quantize(qy, g.h_bbox[2], g.h_bbox[3], g.h_bitwidth)) << 1) |
+           dilate_bits(quantize(qx, g.h_bbox[0], g.h_bbox[1], g.h_bitwidth));
+}
+// first candidate (table order) whose cell contains the point; coords rounded to float32 like the
+// reference's float32 coords_best buffer (spatialhash.py:505)
+PK_DEV void hash_query(const DGrid& g, double y, double x, int& yi, int& xi, double& xsi, double& eta) {
+    yi = GRID_SEARCH_ERROR;
+    xi = GRID_SEARCH_ERROR;
+    xsi = -1.0;
+    eta = -1.0;
+    if (!(isfinite(x) && isfinite(y)) || g.h_nkeys <= 0) return;
+    const uint32_t code = morton_code(g, y, x);
+    int64_t lo = 0, hi = g.h_nkeys;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (g.h_keys[mid] < code) lo = mid + 1; else hi = mid;
+    }
+    if (lo >= g.h_nkeys || g.h_keys[lo] != code) return;
+    const int64_t s = g.h_starts[lo], c = g.h_counts[lo];
+    const uint32_t ncx = (uint32_t)(g.nx - 1);
+    for (int64_t k = 0; k < c; k++) {
+        uint32_t face = g.h_faces[s + k];
+        int j = (int)(face / ncx), i = (int)(face % ncx);
+        double xs, et;
+        if (point_in_cell(g, y, x, j, i, xs, et)) {
+            yi = j;
+            xi = i;
+            xsi = (double)(float)xs;
+            eta = (double)(float)et;
+            return;
+        }
+    }
+}
+
+// ravel/unravel of `ei` over XGrid.axes (basegrid.py:83-152, 219-278)
+PK_DEV int64_t ravel_ei(const DGrid& g, int zi, int yi, int xi) {
+    int64_t ei = 0, stride = 1;
+    if (g.has_x) { ei += (int64_t)xi * stride; stride *= g.xdim; }
+    if (g.has_y) { ei += (int64_t)yi * stride; stride *= g.ydim; }
+    if (g.has_z) { ei += (int64_t)zi * stride; }
+    return ei;
+}
+PK_DEV int64_t floordiv64(int64_t a, int64_t b) {
+    if (b == 0) return 0;
+    int64_t q = a / b;
+    if ((a % b != 0) && ((a < 0) != (b < 0))) q--;
+    return q;
+}
+PK_DEV int64_t mod64(int64_t a, int64_t b) {
+    if (b == 0) return 0;
+    int64_t r = a % b;
+    if (r != 0 && ((r < 0) != (b < 0))) r += b;
+    return r;
+}
+PK_DEV void unravel_yx(const DGrid& g, int64_t ei, int& yi, int& xi) {
+    // strides[i] = prod(dims[i:]); idx[i] = ei // strides[i+1]; ei %= strides[i+1]
+    int64_t sx = g.has_x ? (int64_t)g.xdim : 1;             // stride of Y (product of dims after Y)
+    int64_t sy = (g.has_y ? (int64_t)g.ydim : 1) * sx;      // stride of Z
+    if (g.has_z && (g.has_y || g.has_x)) ei = mod64(ei, sy);
+    if (g.has_y) {
+        if (g.has_x) { yi = (int)floordiv64(ei, sx); ei = mod64(ei, sx); }
+        else yi = (int)ei;
+    } else yi = 0;
+    xi = g.has_x ? (int)ei : 0;
+}
+
+// ---- per-particle evaluation context -------------------------------------------------------------------
+struct PCtx {
+    int state;
+    bool pf;             // particle positions are stored as float32 (default Particle, particle.py:123-178)
+    int hz, hy, hx, ht;  // search hints of the main grid (indices of the previous evaluation)
+    bool first_eval[PK_MAX_GRIDS];
+};
+
+// XGrid.search (xgrid.py:316-356) + ei write + state update (field.py:307-356)
+// KIND: 0 rectilinear, 1 curvilinear, -1 decide at run time (scalar fields on secondary grids)
+template <int KIND>
+PK_DEV void grid_search(const DGrid& g, const Coords* mc, double z, double y, double x, bool pos_f32, int32_t* ei,
+                        PCtx& c, bool use_guess, GPos& p) {
+    const bool curv = (KIND < 0) ? (g.kind == 1) : (KIND == 1);
+    const double* depth = mc ? mc->depth : g.depth;
+    const double* lat = mc ? mc->lat : g.lat;
+    const double* lon = mc ? mc->lon : g.lon;
+    const bool hint = mc != nullptr;
+    if (g.has_z) search_1d(depth, g.nz, z, g.depth_f32, pos_f32, hint ? c.hz : 0, p.zi, p.zeta);
+    else { p.zi = 0; p.zeta = 0.0; }
+    if (curv) {
+        bool found = false;
+        if (use_guess) {  // index_search.py:269-274
+            int gy, gx;
+            unravel_yx(g, (int64_t)*ei, gy, gx);
+            double xs = -1.0, et = -1.0;
+            if (gy >= 0 && gy < g.ny - 1 && gx >= 0 && gx < g.nx - 1 && point_in_cell(g, y, x, gy, gx, xs, et)) {
+                p.yi = gy; p.xi = gx; p.xsi = xs; p.eta = et;
+                found = true;
+            }
+        }
+        if (!found) hash_query(g, y, x, p.yi, p.xi, p.xsi, p.eta);
+    } else {
+        if (g.has_y) search_1d(lat, g.ny, y, g.lat_f32, pos_f32, hint ? c.hy : 0, p.yi, p.eta);
+        else { p.yi = 0; p.eta = 0.0; }
+        if (g.has_x) search_1d(lon, g.nx, x, g.lon_f32, pos_f32, hint ? c.hx : 0, p.xi, p.xsi);
+        else { p.xi = 0; p.xsi = 0.0; }
+    }
+    if (hint) { c.hz = p.zi; c.hy = p.yi; c.hx = p.xi; }
+    *ei = (int32_t)ravel_ei(g, p.zi, p.yi, p.xi);
+    int s = c.state;
+    if (p.xi == -1 && s < PK_ERROROUTOFBOUNDS) s = PK_ERROROUTOFBOUNDS;
+    if (p.xi == GRID_SEARCH_ERROR && s < PK_ERRORGRIDSEARCHING) s = PK_ERRORGRIDSEARCHING;
+    if (p.yi == -1 && s < PK_ERROROUTOFBOUNDS) s = PK_ERROROUTOFBOUNDS;
+    if (p.yi == GRID_SEARCH_ERROR && s < PK_ERRORGRIDSEARCHING) s = PK_ERRORGRIDSEARCHING;
+    if (p.zi == RIGHT_OUT_OF_BOUNDS && s < PK_ERROROUTOFBOUNDS) s = PK_ERROROUTOFBOUNDS;
+    if (p.zi == LEFT_OUT_OF_BOUNDS && s < PK_ERRORTHROUGHSURFACE) s = PK_ERRORTHROUGHSURFACE;
+    c.state = s;
+}
+
+// _search_time_index (index_search.py:65-91). false => OutsideTimeInterval
+PK_DEV bool time_search(const DField& f, const double* time, double t, int hint, GPos& p) {
+    if (!f.has_time_interval) { p.ti = 0; p.tau = 0.0; return true; }
+    if (!(0 <= t) || !(t <= f.tlen)) return false;  // utils/time.py:60-62
+    search_1d(time, f.nt, t, false, false, hint, p.ti, p.tau);
+    return true;
+}
+
+// ---- corner gather + interpolation -----------------------------------------------------------------------
+template <class FT>
+PK_DEV double ldv(const FT* p, int64_t off) { return (double)p[off]; }
+
+PK_DEV int64_t slot_off(const DField& f, int ti) {
+    int s = (f.nslots >= f.nt) ? ti : (ti % f.nslots);
+    return (int64_t)s * f.st_t;
+}
+
+// XLinear.interp (_xinterpolators.py:112-153) on the corners of _gather_corners (:25-96)
+template <class FT>
+PK_DEV double xlinear(const DField& f, const GPos& p) {
+    const FT* d = (const FT*)f.data;
+    const bool lenT = p.tau > 0, lenZ = p.zeta > 0;
+    const int64_t ot0 = slot_off(f, p.ti), ot1 = slot_off(f, mini(p.ti + 1, f.nt - 1));
+    const int64_t oz0 = (int64_t)p.zi * f.st_z, oz1 = (int64_t)mini(p.zi + 1, f.nz - 1) * f.st_z;
+    const int64_t oy0 = (int64_t)p.yi * f.st_y, oy1 = (int64_t)mini(p.yi + 1, f.ny - 1) * f.st_y;
+    const int64_t ox0 = (int64_t)p.xi * f.st_x, ox1 = (int64_t)mini(p.xi + 1, f.nx - 1) * f.st_x;
+    // issue every load of this field first (independent), combine afterwards
+    double a[2][2][2];   // [z][y][x] at t0
+    double b[2][2][2];   // at t1
+    a[0][0][0] = ldv(d, ot0 + oz0 + oy0 + ox0);
+    a[0][0][1] = ldv(d, ot0 + oz0 + oy0 + ox1);
+    a[0][1][0] = ldv(d, ot0 + oz0 + oy1 + ox0);
+    a[0][1][1] = ldv(d, ot0 + oz0 + oy1 + ox1);
+    if (lenZ) {
+        a[1][0][0] = ldv(d, ot0 + oz1 + oy0 + ox0);
+        a[1][0][1] = ldv(d, ot0 + oz1 + oy0 + ox1);
+        a[1][1][0] = ldv(d, ot0 + oz1 + oy1 + ox0);
+        a[1][1][1] = ldv(d, ot0 + oz1 + oy1 + ox1);
+    }
+    if (lenT) {
+        b[0][0][0] = ldv(d, ot1 + oz0 + oy0 + ox0);
+        b[0][0][1] = ldv(d, ot1 + oz0 + oy0 + ox1);
+        b[0][1][0] = ldv(d, ot1 + oz0 + oy1 + ox0);
+        b[0][1][1] = ldv(d, ot1 + oz0 + oy1 + ox1);
+        if (lenZ) {
+            b[1][0][0] = ldv(d, ot1 + oz1 + oy0 + ox0);
+            b[1][0][1] = ldv(d, ot1 + oz1 + oy0 + ox1);
+            b[1][1][0] = ldv(d, ot1 + oz1 + oy1 + ox0);
+            b[1][1][1] = ldv(d, ot1 + oz1 + oy1 + ox1);
+        }
+    }
+    const double tau = p.tau, zeta = p.zeta, xsi = p.xsi, eta = p.eta;
+    double c[2][2];
+#pragma unroll
+    for (int iy = 0; iy < 2; iy++)
+#pragma unroll
+        for (int ix = 0; ix < 2; ix++) {
+            double v0 = a[0][iy][ix];
+            if (lenT) v0 = v0 * (1 - tau) + b[0][iy][ix] * tau;
+            if (lenZ) {
+                double v1 = a[1][iy][ix];
+                if (lenT) v1 = v1 * (1 - tau) + b[1][iy][ix] * tau;
+                v0 = v0 * (1 - zeta) + v1 * zeta;
+            }
+            c[iy][ix] = v0;
+        }
+    return (1 - xsi) * (1 - eta) * c[0][0] + xsi * (1 - eta) * c[0][1] + (1 - xsi) * eta * c[1][0] + xsi * eta * c[1][1];
+}
+
+// _geodetic_distance (utils/interpolation.py:178-185), including NumPy's float32 behaviour for f32 coordinates
+PK_DEV double geodetic_distance(const DGrid& g, double lat1, double lat2, double lon1, double lon2, double lat, bool cf32) {
+    if (g.spherical) {
+        if (cf32) {
+            double dl = (double)(((float)lon2 - (float)lon1) * (float)g.deg2m);
+            float dlaf = ((float)lat2 - (float)lat1) * (float)g.deg2m;
+            double a = dl * cos(DEG2RAD * lat);
+            return sqrt(a * a + (double)(dlaf * dlaf));
+        }
+        double dl = (lon2 - lon1) * g.deg2m, dla = (lat2 - lat1) * g.deg2m;
+        double a = dl * cos(DEG2RAD * lat);
+        return sqrt(a * a + dla * dla);
+    }
+    if (cf32) {
+        float a = (float)lon2 - (float)lon1, b = (float)lat2 - (float)lat1;
+        return (double)sqrtf(a * a + b * b);
+    }
+    double a = lon2 - lon1, b = lat2 - lat1;
+    return sqrt(a * a + b * b);
+}
+
+// two bracketing face values, reduced over time (_xinterpolators.py:249-270)
+template <class FT>
+PK_DEV void cgrid_pair(const DField& f, const GPos& p, int zA, int yA, int xA, int zB, int yB, int xB, double& oa, double& ob) {
+    const FT* d = (const FT*)f.data;
+    const bool lenT = p.tau > 0;
+    const int64_t ot0 = slot_off(f, p.ti);
+    const int64_t offA = (int64_t)zA * f.st_z + (int64_t)yA * f.st_y + (int64_t)xA * f.st_x;
+    const int64_t offB = (int64_t)zB * f.st_z + (int64_t)yB * f.st_y + (int64_t)xB * f.st_x;
+    double a = ldv(d, ot0 + offA), b = ldv(d, ot0 + offB);
+    if (lenT) {
+        const int64_t ot1 = slot_off(f, mini(p.ti + 1, f.nt - 1));
+        double a1 = ldv(d, ot1 + offA), b1 = ldv(d, ot1 + offB);
+        a = a * (1 - p.tau) + a1 * p.tau;
+        b = b * (1 - p.tau) + b1 * p.tau;
+    }
+    oa = a;
+    ob = b;
+}
+
+PK_DEV double pymod360(double v) {  // Python/NumPy % with a positive divisor
+    double q = fmod(v, 360.0);
+    if (q < 0) q += 360.0;
+    return q;
+}
+PK_DEV float pymod360f(float v) {
+    float q = fmodf(v, 360.0f);
+    if (q < 0) q += 360.0f;
+    return q;
+}
+
+// CGrid_Velocity.interp (_xinterpolators.py:193-332)
+template <class FT, int KIND>
+PK_DEV void cgrid_velocity(const DGrid& g, const Coords* mc, const DField& U, const DField& V, const DField* W, const GPos& p,
+                           double ypos, bool ypos_f32, double& u, double& v, double& w) {
+    const int xi = p.xi, yi = p.yi, zi = p.zi;
+    const double xsi = p.xsi, eta = p.eta, zeta = p.zeta;
+    const int ydim = U.ny, xdim = U.nx, zdim = U.nz;
+    double px[4], py[4];
+    const bool rect = (KIND < 0) ? (g.kind == 0) : (KIND == 0);
+    if (rect) {
+        const double* lon = mc ? mc->lon : g.lon;
+        const double* lat = mc ? mc->lat : g.lat;
+        px[0] = lon[xi]; px[1] = lon[xi + 1]; px[2] = px[1]; px[3] = px[0];
+        py[0] = lat[yi]; py[1] = py[0]; py[2] = lat[yi + 1]; py[3] = py[2];
+    } else {
+        const int64_t i00 = (int64_t)yi * g.nx + xi, i10 = i00 + g.nx;
+        px[0] = g.lon[i00]; px[1] = g.lon[i00 + 1]; px[2] = g.lon[i10 + 1]; px[3] = g.lon[i10];
+        py[0] = g.lat[i00]; py[1] = g.lat[i00 + 1]; py[2] = g.lat[i10 + 1]; py[3] = g.lat[i10];
+    }
+    const bool cf32x = g.lon_f32, cf32 = g.lon_f32 && g.lat_f32;
+    if (g.spherical) {  // :230-233
+        if (cf32x) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) px[k] = (double)(pymod360f((float)px[k] + 180.0f) - 180.0f);
+#pragma unroll
+            for (int k = 1; k < 4; k++)
+                if ((float)px[k] - (float)px[0] > 180.0f) px[k] = (double)((float)px[k] - 360.0f);
+#pragma unroll
+            for (int k = 1; k < 4; k++)
+                if (-(float)px[k] + (float)px[0] > 180.0f) px[k] = (double)((float)px[k] + 360.0f);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) px[k] = pymod360(px[k] + 180.0) - 180.0;
+#pragma unroll
+            for (int k = 1; k < 4; k++)
+                if (px[k] - px[0] > 180) px[k] = px[k] - 360;
+#pragma unroll
+            for (int k = 1; k < 4; k++)
+                if (-px[k] + px[0] > 180) px[k] = px[k] + 360;
+        }
+    }
+    // einsum("ij,ji->i", phi2D_lin(eta, xsi), py): products formed for all four corners, summed in corner order
+#define PK_PHI_DOT(e, x_) \
+    (((((1 - (x_)) * (1 - (e))) * py[0] + ((x_) * (1 - (e))) * py[1]) + ((x_) * (e)) * py[2]) + ((1 - (x_)) * (e)) * py[3])
+    const double c1 = geodetic_distance(g, py[0], py[1], px[0], px[1], PK_PHI_DOT(0.0, xsi), cf32);
+    const double c2 = geodetic_distance(g, py[1], py[2], px[1], px[2], PK_PHI_DOT(eta, 1.0), cf32);
+    const double c3 = geodetic_distance(g, py[2], py[3], px[2], px[3], PK_PHI_DOT(1.0, xsi), cf32);
+    const double c4 = geodetic_distance(g, py[3], py[0], px[3], px[0], PK_PHI_DOT(eta, 0.0), cf32);
+#undef PK_PHI_DOT
+    const int yi_o = clampi(yi + g.off_y, 0, ydim - 1), xi_1 = clampi(xi + 1, 0, xdim - 1);
+    const int yi_1 = clampi(yi + 1, 0, ydim - 1), xi_o = clampi(xi + g.off_x, 0, xdim - 1);
+    double ua, ub, va, vb;
+    cgrid_pair<FT>(U, p, zi, yi_o, xi, zi, yi_o, xi_1, ua, ub);   // :272-279
+    cgrid_pair<FT>(V, p, zi, yi, xi_o, zi, yi_1, xi_o, va, vb);   // :281-288
+    const double U0 = ua * c4, U1 = ub * c2;
+    const double Uvel = (1 - xsi) * U0 + xsi * U1;
+    const double V0 = va * c1, V1 = vb * c3;
+    const double Vvel = (1 - eta) * V0 + eta * V1;
+    // _compute_jacobian_determinant (utils/interpolation.py:188-198)
+    const double dxs0 = eta - 1, dxs1 = 1 - eta, dxs2 = eta, dxs3 = -eta;
+    const double det0 = xsi - 1, det1 = -xsi, det2 = xsi, det3 = 1 - xsi;
+    const double dxdxsi = ((dxs0 * px[0] + dxs1 * px[1]) + dxs2 * px[2]) + dxs3 * px[3];
+    const double dxdeta = ((det0 * px[0] + det1 * px[1]) + det2 * px[2]) + det3 * px[3];
+    const double dydxsi = ((dxs0 * py[0] + dxs1 * py[1]) + dxs2 * py[2]) + dxs3 * py[3];
+    const double dydeta = ((det0 * py[0] + det1 * py[1]) + det2 * py[2]) + det3 * py[3];
+    double jac = dxdxsi * dydeta - dxdeta * dydxsi;
+    if (g.spherical) jac = jac * g.deg2m;
+    const double A = -(1 - eta) * Uvel - (1 - xsi) * Vvel;
+    const double B = (1 - eta) * Uvel - xsi * Vvel;
+    const double C = eta * Uvel + xsi * Vvel;
+    const double D = -eta * Uvel + (1 - xsi) * Vvel;
+    double uu = (A * px[0] + B * px[1] + C * px[2] + D * px[3]) / jac;
+    double vv = (A * py[0] + B * py[1] + C * py[2] + D * py[3]) / jac;
+    if (g.spherical) {  // :311-314 (both components divided by deg2m*cos(lat))
+        double conv;
+        if (ypos_f32) conv = (double)((float)g.deg2m * cosf((float)ypos * DEG2RADF));
+        else conv = g.deg2m * cos(ypos * DEG2RAD);
+        uu /= conv;
+        vv /= conv;
+    }
+    u = uu;
+    v = vv;
+    if (W) {  // :316-328 (clipped with U's z extent, like the reference)
+        const int zi_0 = clampi(zi + g.off_z, 0, zdim - 1), zi_1 = clampi(zi + g.off_z + 1, 0, zdim - 1);
+        double wa, wb;
+        cgrid_pair<FT>(*W, p, zi_0, yi_o, xi_o, zi_1, yi_o, xi_o, wa, wb);
+        w = wa * (1 - zeta) + wb * zeta;
+    } else {
+        w = 0.0;
+    }
+}
+
+// NaN -> ErrorInterpolation (field.py:373-378) then out-of-bounds -> 0 (field.py:359-370)
+PK_DEV double finish_value(PCtx& c, const GPos& p, double v) {
+    if (v != v && c.state < PK_ERRORINTERPOLATION) c.state = PK_ERRORINTERPOLATION;
+    if (p.xi < 0 || p.yi < 0 || p.zi < 0) v = 0.0;
+    return v;
+}
+
+// VectorField.eval (field.py:250-304). INTERP: 0 XLinear_Velocity, 1 CGrid_Velocity. pos_f32: z,y,x come
+// straight from float32 particle storage (NumPy then evaluates cos(lat) in float32).
+template <class FT, int KIND, int INTERP>
+PK_DEV void eval_uvw(const KArgs& a, const Coords& mc, PCtx& c, int32_t* ei_row, bool want_w, double t, double z, double y,
+                     double x, bool pos_f32, double& u, double& v, double& w) {
+    const DField& U = a.fields[a.prm.fU];
+    const DField& V = a.fields[a.prm.fV];
+    const DGrid& g = a.grids[U.grid];
+    GPos p;
+    u = v = w = 0.0;
+    if (!time_search(U, mc.time, t, c.ht, p)) {  // field.py:303-304 -> _deal_with_errors: state := 70, zeros
+        c.state = PK_ERROROUTSIDETIMEINTERVAL;
+        return;
+    }
+    c.ht = p.ti;
+    const bool use_guess = c.first_eval[U.grid] ? (a.prm.have_guess0 != 0) : true;
+    c.first_eval[U.grid] = false;
+    grid_search<KIND>(g, &mc, z, y, x, pos_f32, &ei_row[U.grid], c, use_guess, p);
+    const bool oob = (p.xi < 0 || p.yi < 0 || p.zi < 0);
+    double uu = 0, vv = 0, ww = 0;
+    if (!oob) {
+        const DField* W = (want_w && a.prm.fW >= 0) ? &a.fields[a.prm.fW] : nullptr;
+        if (INTERP == 1) {
+            cgrid_velocity<FT, KIND>(g, &mc, U, V, W, p, y, pos_f32, uu, vv, ww);
+        } else {  // XLinear_Velocity.interp (_xinterpolators.py:169-190)
+            uu = xlinear<FT>(U, p);
+            vv = xlinear<FT>(V, p);
+            if (W) ww = xlinear<FT>(*W, p);
+            if (g.spherical) {
+                double conv;
+                if (pos_f32) conv = (double)((float)g.deg2m * cosf((float)y * DEG2RADF));
+                else conv = g.deg2m * cos(y * DEG2RAD);
+                uu /= conv;
+                vv /= g.deg2m;
+            }
+        }
+    }
+    u = finish_value(c, p, uu);
+    v = finish_value(c, p, vv);
+    w = finish_value(c, p, ww);
+}
+
+// Field.eval for a scalar field (field.py:145-195): XLinear or XConstantField
+template <class FT>
+PK_DEV double eval_scalar(const KArgs& a, const Coords& mc, PCtx& c, int32_t* ei_row, int fidx, double t, double z, double y,
+                          double x, bool pos_f32) {
+    const DField& f = a.fields[fidx];
+    const DGrid& g = a.grids[f.grid];
+    const bool on_main = (f.grid == a.main_grid);
+    GPos p;
+    const double* time = (on_main && f.time == a.fields[a.main_field].time) ? mc.time : f.time;
+    if (!time_search(f, time, t, on_main ? c.ht : 0, p)) {
+        c.state = PK_ERROROUTSIDETIMEINTERVAL;
+        return 0.0;
+    }
+    const bool use_guess = c.first_eval[f.grid] ? (a.prm.have_guess0 != 0) : true;
+    c.first_eval[f.grid] = false;
+    grid_search<-1>(g, on_main ? &mc : nullptr, z, y, x, pos_f32, &ei_row[f.grid], c, use_guess, p);
+    double v = 0.0;
+    if (!(p.xi < 0 || p.yi < 0 || p.zi < 0)) {
+        if (f.is_const) v = (f.dtype == PK_F64) ? ((const double*)f.data)[0] : (double)((const float*)f.data)[0];
+        else v = (f.dtype == PK_F64) ? xlinear<double>(f, p) : xlinear<float>(f, p);
+    }
+    return finish_value(c, p, v);
+}
+
+// ---- counter-based RNG for the stochastic kernels --------------------------------------------------------
+// The reference draws from NumPy's global MT19937 stream (_advectiondiffusion.py:37-38), which no parallel
+// engine can reproduce.  Here: Philox4x32-10, key = (seed, kernel slot), counter = (particle_id, bits of the
+// particle's time) -> two standard normals by Box-Muller.  Stateless, so trajectories do not depend on
+// launch partitioning or on how particles are sharded over GPUs.
+PK_DEV void philox_round(uint32_t c[4], const uint32_t k[2]) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0], n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1], n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+PK_DEV void normal_pair(uint64_t seed, int kslot, int64_t particle_id, double t, double& z0, double& z1) {
+    uint32_t k[2] = {(uint32_t)seed ^ (0x9E3779B9u * (uint32_t)(kslot + 1)), (uint32_t)(seed >> 32)};
+    const uint64_t tb = (uint64_t)__double_as_longlong(t);
+    uint32_t c[4] = {(uint32_t)particle_id, (uint32_t)((uint64_t)particle_id >> 32), (uint32_t)tb, (uint32_t)(tb >> 32)};
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        philox_round(c, k);
+        k[0] += 0x9E3779B9u;
+        k[1] += 0xBB67AE85u;
+    }
+    const uint64_t a = ((uint64_t)c[1] << 32) | c[0], b = ((uint64_t)c[3] << 32) | c[2];
+    const double u1 = ((double)(a >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+    const double u2 = ((double)(b >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+    const double r = sqrt(-2.0 * log(u1));
+    const double th = 6.283185307179586476925286766559 * u2;
+    double s, co;
+    sincos(th, &s, &co);
+    z0 = r * co;
+    z1 = r * s;
+}
+
+}  // namespace pk

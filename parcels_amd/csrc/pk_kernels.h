@@ -1,0 +1,503 @@
+// pk_kernels.h -- the fused advection kernel: Kernel.execute (kernel.py:174-247) for one particle per lane.
+//
+// A launch advances every live particle from its own t to `endtime`: dt clipping, the kernel list, the
+// RK45 Repeat loop, the position update, EndofLoop marking and the status-code state machine all run in
+// registers; particle state is read once and written once per launch (not once per step as in the NumPy
+// reference), so HBM traffic is the field gather only.
+//
+// Every built-in kernel is written as a small stage machine: prepare(stage) names the next sample point,
+// the step loop performs the field evaluation at ONE call site, consume(stage) folds the result into the
+// kernel's registers.  That keeps the code (and its instruction-cache footprint) at one copy of the
+// search+gather+interpolate sequence per kernel instead of one per Runge-Kutta stage, and lets the same
+// source serve the specialised programs (KID fixed at compile time: the switch folds away) and the generic
+// kernel-list program (KID = -1).
+#pragma once
+#include "pk_device.h"
+
+namespace pk {
+
+// programs: a single built-in kernel fixed at compile time, or the generic kernel-list interpreter
+enum Program { PROG_RK4 = 0, PROG_RK4_3D = 1, PROG_GENERIC = 2 };
+
+struct PState {
+    double t, z, y, x, dz, dy, dx, dt, next_dt;
+    int64_t id;
+};
+
+PK_DEV double ldp(const void* col, int64_t i, bool pf) { return pf ? (double)((const float*)col)[i] : ((const double*)col)[i]; }
+PK_DEV void stp(void* col, int64_t i, double v, bool pf) {
+    if (pf) ((float*)col)[i] = (float)v; else ((double*)col)[i] = v;
+}
+// storage-dtype arithmetic of the particle columns (particlesetview.py:202-205): f32 + f32 is an f32 add
+PK_DEV double padd(bool pf, double a, double b) { return pf ? (double)((float)a + (float)b) : a + b; }
+PK_DEV double psub(bool pf, double a, double b) { return pf ? (double)((float)a - (float)b) : a - b; }
+PK_DEV double pstore(bool pf, double v) { return pf ? (double)(float)v : v; }
+
+// what the current stage wants sampled
+enum { RQ_UV = 0, RQ_UVW = 1, RQ_SCALAR = 2 };
+struct Request {
+    int kind, fidx;
+    double t, z, y, x;
+    bool f32;  // sample point comes straight from float32 particle storage
+};
+
+// kernel-local registers (all indices are compile-time constants -> scalar-replaced into VGPRs)
+struct KLocal {
+    double r[14];
+};
+
+// meters_to_degrees_zonal / _meridional (_advectiondiffusion.py:11-18); `particles.y * np.pi / 180` is float32
+// arithmetic for the default Particle
+PK_DEV double m2_to_deg2_zonal(bool pf, double v, double lat, double deg2m) {
+    if (pf) {
+        float a_ = (float)deg2m * cosf((float)lat * 3.14159265358979323846f / 180.0f);
+        return v / (double)(a_ * a_);
+    }
+    double a_ = deg2m * cos(lat * 3.14159265358979323846 / 180);
+    return v / (a_ * a_);
+}
+PK_DEV double m2_to_deg2_merid(double v, double deg2m) { return v / (deg2m * deg2m); }
+
+// Fehlberg tableau of AdvectionRK45 (_advection.py:96-106)
+namespace rk45c {
+constexpr double c0 = 1.0 / 4.0, c1 = 3.0 / 8.0, c2 = 12.0 / 13.0, c3 = 1.0, c4 = 1.0 / 2.0;
+constexpr double A00 = 1.0 / 4.0;
+constexpr double A10 = 3.0 / 32.0, A11 = 9.0 / 32.0;
+constexpr double A20 = 1932.0 / 2197.0, A21 = -7200.0 / 2197.0, A22 = 7296.0 / 2197.0;
+constexpr double A30 = 439.0 / 216.0, A31 = -8.0, A32 = 3680.0 / 513.0, A33 = -845.0 / 4104.0;
+constexpr double A40 = -8.0 / 27.0, A41 = 2.0, A42 = -3544.0 / 2565.0, A43 = 1859.0 / 4104.0, A44 = -11.0 / 40.0;
+constexpr double b40 = 25.0 / 216.0, b41 = 0.0, b42 = 1408.0 / 2565.0, b43 = 2197.0 / 4104.0, b44 = -1.0 / 5.0;
+constexpr double b50 = 16.0 / 135.0, b51 = 0.0, b52 = 6656.0 / 12825.0, b53 = 28561.0 / 56430.0, b54 = -9.0 / 50.0,
+                 b55 = 2.0 / 55.0;
+}  // namespace rk45c
+
+// prepare(): returns true when the kernel is finished (after writing its result into p / c), otherwise fills rq.
+PK_DEV bool prepare(const KArgs& a, int kid, int stage, int kslot, PCtx& c, PState& p, KLocal& L, Request& rq) {
+    const pk_exec_params& prm = a.prm;
+    const bool pf = c.pf;
+    rq.kind = RQ_UV;
+    rq.fidx = 0;
+    rq.f32 = false;
+    rq.t = p.t; rq.z = p.z; rq.y = p.y; rq.x = p.x;
+    switch (kid) {
+        case PK_KERNEL_ADVECTION_RK4:
+        case PK_KERNEL_ADVECTION_RK4_3D: {  // _advection.py:42-75; r[0..2] running sum, r[3..5] last u,v,w
+            const bool d3 = kid == PK_KERNEL_ADVECTION_RK4_3D;
+            rq.kind = d3 ? RQ_UVW : RQ_UV;
+            if (stage == 0) { rq.f32 = pf; return false; }
+            if (stage == 4) {
+                p.dx = pstore(pf, p.dx + L.r[0] / 6.0 * p.dt);
+                p.dy = pstore(pf, p.dy + L.r[1] / 6.0 * p.dt);
+                if (d3) p.dz = pstore(pf, p.dz + L.r[2] / 6 * p.dt);
+                return true;
+            }
+            const double cdt = stage == 3 ? 1.0 : 0.5;  // u*1.0 == u and 1.0*dt == dt exactly
+            rq.x = p.x + L.r[3] * cdt * p.dt;
+            rq.y = p.y + L.r[4] * cdt * p.dt;
+            if (d3) rq.z = p.z + L.r[5] * cdt * p.dt;
+            rq.t = p.t + cdt * p.dt;
+            return false;
+        }
+        case PK_KERNEL_ADVECTION_RK2:
+        case PK_KERNEL_ADVECTION_RK2_3D: {  // _advection.py:21-39
+            const bool d3 = kid == PK_KERNEL_ADVECTION_RK2_3D;
+            rq.kind = d3 ? RQ_UVW : RQ_UV;
+            if (stage == 0) { rq.f32 = pf; return false; }
+            if (stage == 2) {
+                p.dx = pstore(pf, p.dx + L.r[3] * p.dt);
+                p.dy = pstore(pf, p.dy + L.r[4] * p.dt);
+                if (d3) p.dz = pstore(pf, p.dz + L.r[5] * p.dt);
+                return true;
+            }
+            rq.x = p.x + L.r[3] * 0.5 * p.dt;
+            rq.y = p.y + L.r[4] * 0.5 * p.dt;
+            if (d3) rq.z = p.z + L.r[5] * 0.5 * p.dt;
+            rq.t = p.t + 0.5 * p.dt;
+            return false;
+        }
+        case PK_KERNEL_ADVECTION_EE: {  // _advection.py:78-82
+            if (stage == 0) { rq.f32 = pf; return false; }
+            p.dx = pstore(pf, p.dx + L.r[3] * p.dt);
+            p.dy = pstore(pf, p.dy + L.r[4] * p.dt);
+            return true;
+        }
+        case PK_KERNEL_ADVECTION_RK45: {  // _advection.py:85-155; r[0..5] = u1..u6, r[6..11] = v1..v6
+            using namespace rk45c;
+            const double dt = p.dt;
+            const double *u = &L.r[0], *v = &L.r[6];
+            switch (stage) {
+                case 0: rq.f32 = pf; return false;
+                case 1:
+                    rq.x = p.x + u[0] * A00 * dt; rq.y = p.y + v[0] * A00 * dt; rq.t = p.t + c0 * dt;
+                    return false;
+                case 2:
+                    rq.x = p.x + (u[0] * A10 + u[1] * A11) * dt; rq.y = p.y + (v[0] * A10 + v[1] * A11) * dt;
+                    rq.t = p.t + c1 * dt;
+                    return false;
+                case 3:
+                    rq.x = p.x + (u[0] * A20 + u[1] * A21 + u[2] * A22) * dt;
+                    rq.y = p.y + (v[0] * A20 + v[1] * A21 + v[2] * A22) * dt;
+                    rq.t = p.t + c2 * dt;
+                    return false;
+                case 4:
+                    rq.x = p.x + (u[0] * A30 + u[1] * A31 + u[2] * A32 + u[3] * A33) * dt;
+                    rq.y = p.y + (v[0] * A30 + v[1] * A31 + v[2] * A32 + v[3] * A33) * dt;
+                    rq.t = p.t + c3 * dt;
+                    return false;
+                case 5:
+                    rq.x = p.x + (u[0] * A40 + u[1] * A41 + u[2] * A42 + u[3] * A43 + u[4] * A44) * dt;
+                    rq.y = p.y + (v[0] * A40 + v[1] * A41 + v[2] * A42 + v[3] * A43 + v[4] * A44) * dt;
+                    rq.t = p.t + c4 * dt;
+                    return false;
+                default: break;
+            }
+            const double sign_dt = (dt > 0) ? 1.0 : ((dt < 0) ? -1.0 : dt);  // np.sign
+            const double x_4th = (u[0] * b40 + u[1] * b41 + u[2] * b42 + u[3] * b43 + u[4] * b44) * dt;
+            const double y_4th = (v[0] * b40 + v[1] * b41 + v[2] * b42 + v[3] * b43 + v[4] * b44) * dt;
+            const double x_5th = (u[0] * b50 + u[1] * b51 + u[2] * b52 + u[3] * b53 + u[4] * b54 + u[5] * b55) * dt;
+            const double y_5th = (v[0] * b50 + v[1] * b51 + v[2] * b52 + v[3] * b53 + v[4] * b54 + v[5] * b55) * dt;
+            const double ex = x_5th - x_4th, ey = y_5th - y_4th;
+            const double kappa = sqrt(ex * ex + ey * ey);
+            const bool good = (kappa <= prm.rk45_tol) || (fabs(dt) <= fabs(prm.rk45_min_dt));
+            p.dx = pstore(pf, p.dx + (good ? x_5th : 0.0));
+            p.dy = pstore(pf, p.dy + (good ? y_5th : 0.0));
+            const bool increase = good && (kappa <= prm.rk45_tol / 10) && (fabs(dt * 2) <= fabs(prm.rk45_max_dt));
+            double next_dt = increase ? dt * 2 : dt;
+            if (fabs(next_dt) > fabs(prm.rk45_max_dt)) next_dt = prm.rk45_max_dt * sign_dt;
+            p.next_dt = next_dt;
+            if (good) c.state = PK_EVALUATE;  // :146 overwrites any sampling error code
+            double ndt = good ? dt : dt / 2;
+            if (fabs(ndt) < fabs(prm.rk45_min_dt)) ndt = prm.rk45_min_dt * sign_dt;
+            p.dt = ndt;
+            if (!good) c.state = PK_REPEAT;
+            return true;
+        }
+        case PK_KERNEL_ADVECTIONDIFFUSION_M1:
+        case PK_KERNEL_ADVECTIONDIFFUSION_EM: {
+            // _advectiondiffusion.py:21-117.  evaluation order M1: Kxp1 Kxm1 UV khz Kyp1 Kym1 khm ; EM: UV Kxp1 Kxm1 khz ...
+            // r[0] Kxp1, r[1] Kxm1, r[2] u, r[3] v, r[4] khz, r[5] Kyp1, r[6] Kym1, r[7] khm
+            const bool em = kid == PK_KERNEL_ADVECTIONDIFFUSION_EM;
+            const double dres = prm.dres;
+            int what = stage;  // M1 order
+            if (em) what = stage == 0 ? 2 : (stage <= 2 ? stage - 1 : stage);
+            rq.f32 = pf;
+            switch (stage < 7 ? what : 7) {
+                case 0: rq.kind = RQ_SCALAR; rq.fidx = prm.fKh_zonal; rq.x = padd(pf, p.x, dres); return false;
+                case 1: rq.kind = RQ_SCALAR; rq.fidx = prm.fKh_zonal; rq.x = psub(pf, p.x, dres); return false;
+                case 2: rq.kind = RQ_UV; return false;
+                case 3: rq.kind = RQ_SCALAR; rq.fidx = prm.fKh_zonal; return false;
+                case 4: rq.kind = RQ_SCALAR; rq.fidx = prm.fKh_meridional; rq.y = padd(pf, p.y, dres); return false;
+                case 5: rq.kind = RQ_SCALAR; rq.fidx = prm.fKh_meridional; rq.y = psub(pf, p.y, dres); return false;
+                case 6: rq.kind = RQ_SCALAR; rq.fidx = prm.fKh_meridional; return false;
+                default: break;
+            }
+            const DGrid& gz = a.grids[a.fields[prm.fKh_zonal].grid];
+            const DGrid& gm = a.grids[a.fields[prm.fKh_meridional].grid];
+            double Kxp1 = L.r[0], Kxm1 = L.r[1], khz = L.r[4], Kyp1 = L.r[5], Kym1 = L.r[6], khm = L.r[7];
+            const double u = L.r[2], v = L.r[3];
+            if (gz.spherical) {
+                Kxp1 = m2_to_deg2_zonal(pf, Kxp1, p.y, gz.deg2m);
+                Kxm1 = m2_to_deg2_zonal(pf, Kxm1, p.y, gz.deg2m);
+                khz = m2_to_deg2_zonal(pf, khz, p.y, gz.deg2m);
+            }
+            if (gm.spherical) {
+                Kyp1 = m2_to_deg2_merid(Kyp1, gm.deg2m);
+                Kym1 = m2_to_deg2_merid(Kym1, gm.deg2m);
+                khm = m2_to_deg2_merid(khm, gm.deg2m);
+            }
+            const double dKdx = (Kxp1 - Kxm1) / (2 * dres), dKdy = (Kyp1 - Kym1) / (2 * dres);
+            const double bx = sqrt(2 * khz), by = sqrt(2 * khm);
+            double z0, z1;
+            normal_pair(prm.seed, kslot, p.id, p.t, z0, z1);
+            const double s = sqrt(fabs(p.dt));
+            const double dWx = s * z0, dWy = s * z1;
+            if (!em) {  // :66-67
+                p.dx = pstore(pf, p.dx + (u * p.dt + 0.5 * dKdx * (dWx * dWx + p.dt) + bx * dWx));
+                p.dy = pstore(pf, p.dy + (v * p.dt + 0.5 * dKdy * (dWy * dWy + p.dt) + by * dWy));
+            } else {  // :116-117
+                const double ax = u + dKdx, ay = v + dKdy;
+                p.dx = pstore(pf, p.dx + (ax * p.dt + bx * dWx));
+                p.dy = pstore(pf, p.dy + (ay * p.dt + by * dWy));
+            }
+            return true;
+        }
+        case PK_KERNEL_DIFFUSION_UNIFORM_KH: {  // _advectiondiffusion.py:120-153; r[0] kh_zonal, r[1] kh_meridional
+            rq.f32 = pf;
+            if (stage == 0) { rq.kind = RQ_SCALAR; rq.fidx = prm.fKh_zonal; return false; }
+            if (stage == 1) { rq.kind = RQ_SCALAR; rq.fidx = prm.fKh_meridional; return false; }
+            const DGrid& gz = a.grids[a.fields[prm.fKh_zonal].grid];
+            const DGrid& gm = a.grids[a.fields[prm.fKh_meridional].grid];
+            double khz = L.r[0], khm = L.r[1];
+            if (gz.spherical) {
+                khz = m2_to_deg2_zonal(pf, khz, p.y, gz.deg2m);
+                khm = m2_to_deg2_merid(khm, gm.deg2m);
+            }
+            double z0, z1;
+            normal_pair(prm.seed, kslot, p.id, p.t, z0, z1);
+            const double s = sqrt(fabs(p.dt));
+            p.dx = pstore(pf, p.dx + sqrt(2 * khz) * (s * z0));
+            p.dy = pstore(pf, p.dy + sqrt(2 * khm) * (s * z1));
+            return true;
+        }
+        case PK_KERNEL_DELETE_ON_ERROR:  // tests/common_kernels.py:12-13
+            if (c.state >= PK_ERROR) c.state = PK_DELETE;
+            return true;
+        case PK_KERNEL_DELETE_OUT_OF_BOUNDS:  // tests/test_advection.py:157-161
+            if (c.state == PK_ERROROUTOFBOUNDS || c.state == PK_ERRORTHROUGHSURFACE) c.state = PK_DELETE;
+            return true;
+        case PK_KERNEL_SUBMERGE_THROUGH_SURFACE:  // tests/test_advection.py:163-174
+            if (stage == 0) {
+                if (c.state != PK_ERRORTHROUGHSURFACE) return true;
+                rq.f32 = pf;
+                return false;
+            }
+            p.dx = pstore(pf, L.r[3] * p.dt);
+            p.dy = pstore(pf, L.r[4] * p.dt);
+            p.dz = 0.0;
+            p.z = 0.0;
+            c.state = PK_EVALUATE;
+            return true;
+        default: c.state = PK_ERROR; return true;
+    }
+}
+
+// consume(): fold the sampled (u, v, w) of `stage` into the kernel's registers
+PK_DEV void consume(int kid, int stage, KLocal& L, double u, double v, double w) {
+    switch (kid) {
+        case PK_KERNEL_ADVECTION_RK4:
+        case PK_KERNEL_ADVECTION_RK4_3D:
+            // (u1 + 2*u2 + 2*u3 + u4), summed left to right
+            if (stage == 0) { L.r[0] = u; L.r[1] = v; L.r[2] = w; }
+            else if (stage == 3) { L.r[0] = L.r[0] + u; L.r[1] = L.r[1] + v; L.r[2] = L.r[2] + w; }
+            else { L.r[0] = L.r[0] + 2 * u; L.r[1] = L.r[1] + 2 * v; L.r[2] = L.r[2] + 2 * w; }
+            L.r[3] = u; L.r[4] = v; L.r[5] = w;
+            break;
+        case PK_KERNEL_ADVECTION_RK45:
+            switch (stage) {
+                case 0: L.r[0] = u; L.r[6] = v; break;
+                case 1: L.r[1] = u; L.r[7] = v; break;
+                case 2: L.r[2] = u; L.r[8] = v; break;
+                case 3: L.r[3] = u; L.r[9] = v; break;
+                case 4: L.r[4] = u; L.r[10] = v; break;
+                default: L.r[5] = u; L.r[11] = v; break;
+            }
+            break;
+        case PK_KERNEL_ADVECTIONDIFFUSION_M1:
+            switch (stage) {
+                case 0: L.r[0] = u; break;
+                case 1: L.r[1] = u; break;
+                case 2: L.r[2] = u; L.r[3] = v; break;
+                case 3: L.r[4] = u; break;
+                case 4: L.r[5] = u; break;
+                case 5: L.r[6] = u; break;
+                default: L.r[7] = u; break;
+            }
+            break;
+        case PK_KERNEL_ADVECTIONDIFFUSION_EM:
+            switch (stage) {
+                case 0: L.r[2] = u; L.r[3] = v; break;
+                case 1: L.r[0] = u; break;
+                case 2: L.r[1] = u; break;
+                case 3: L.r[4] = u; break;
+                case 4: L.r[5] = u; break;
+                case 5: L.r[6] = u; break;
+                default: L.r[7] = u; break;
+            }
+            break;
+        case PK_KERNEL_DIFFUSION_UNIFORM_KH:
+            if (stage == 0) L.r[0] = u; else L.r[1] = u;
+            break;
+        default:  // RK2, RK2_3D, EE, Submerge: only the latest sample matters
+            L.r[3] = u; L.r[4] = v; L.r[5] = w;
+            break;
+    }
+}
+
+PK_DEV unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// blockIdx -> logical tile: the dispatcher places block b on XCD b % 8 (MI355X_MICROARCH.md); give every XCD a
+// contiguous range of (cell-sorted) particles so that its private L2 sees one compact region of the fields.
+PK_DEV unsigned xcd_swizzle(unsigned bid, unsigned nb) {
+    const unsigned xcd = bid & 7u, j = bid >> 3;
+    const unsigned per = nb >> 3, rem = nb & 7u;
+    return xcd * per + (xcd < rem ? xcd : rem) + j;
+}
+
+// KID: compile-time kernel id of a single-kernel program, or -1 for the kernel-list interpreter
+template <class FT, int KIND, int INTERP, int KID, bool LDS>
+__global__ void __launch_bounds__(256) advect_kernel(const KArgs a) {
+    extern __shared__ double smem[];
+    const DField& mf = a.fields[a.main_field];
+    const DGrid& mg = a.grids[a.main_grid];
+    Coords mc;
+    if (LDS) {
+        // stage the 1-D coordinate vectors of the main grid once per workgroup (coalesced), search them from LDS
+        double* s_time = smem + a.lds_time;
+        double* s_depth = smem + a.lds_depth;
+        double* s_lat = smem + a.lds_lat;
+        double* s_lon = smem + a.lds_lon;
+        const int nt = mf.has_time_interval ? mf.nt : 0;
+        for (int k = threadIdx.x; k < nt; k += 256) s_time[k] = mf.time[k];
+        const int nz = mg.has_z ? mg.nz : 0;
+        for (int k = threadIdx.x; k < nz; k += 256) s_depth[k] = mg.depth[k];
+        if (KIND == 0) {
+            for (int k = threadIdx.x; k < mg.ny; k += 256) s_lat[k] = mg.lat[k];
+            for (int k = threadIdx.x; k < mg.nx; k += 256) s_lon[k] = mg.lon[k];
+        }
+        __syncthreads();
+        mc.time = s_time;
+        mc.depth = s_depth;
+        mc.lat = (KIND == 0) ? s_lat : mg.lat;
+        mc.lon = (KIND == 0) ? s_lon : mg.lon;
+    } else {
+        mc.time = mf.time;
+        mc.depth = mg.depth;
+        mc.lat = mg.lat;
+        mc.lon = mg.lon;
+    }
+
+    const int64_t i = (int64_t)xcd_swizzle(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    unsigned long long steps = 0, attempts = 0, paused = 0;
+    if (i < a.p.n) {
+        const DParticles& P = a.p;
+        const pk_exec_params& prm = a.prm;
+        PCtx c;
+        const bool pf = P.spatial_f32 != 0;
+        c.pf = pf;
+        c.state = prm.reset_state ? PK_EVALUATE : P.state[i];  // kernel.py:188
+        if (c.state == PK_EVALUATE) {
+            c.hz = c.hy = c.hx = c.ht = 0;
+#pragma unroll
+            for (int g = 0; g < PK_MAX_GRIDS; g++) c.first_eval[g] = (prm.reset_state != 0);
+            PState p;
+            p.t = P.t[i];
+            p.z = ldp(P.z, i, pf);
+            p.y = ldp(P.y, i, pf);
+            p.x = ldp(P.x, i, pf);
+            p.dz = ldp(P.dz, i, pf);
+            p.dy = ldp(P.dy, i, pf);
+            p.dx = ldp(P.dx, i, pf);
+            p.dt = P.dt[i];
+            p.next_dt = P.next_dt ? P.next_dt[i] : 0.0;
+            p.id = P.particle_id[i];
+            int32_t ei[PK_MAX_GRIDS];
+#pragma unroll
+            for (int g = 0; g < PK_MAX_GRIDS; g++) ei[g] = g < P.ngrids ? P.ei[i * P.ngrids + g] : 0;
+            const double endtime = prm.endtime;
+            const int sign = prm.dt0 > 0 ? 1 : -1;  // kernel.py:186
+            const bool windowed = mf.has_time_interval != 0;
+            const int nk = KID >= 0 ? 1 : prm.nk;
+            while (c.state == PK_EVALUATE || c.state == PK_REPEAT) {  // :190
+                const double tte = sign * (endtime - p.t);
+                if (!(tte >= 0)) break;  // :193-197 (state is Evaluate here)
+                double dtc;
+                if (sign == 1) dtc = fmax(fmin(p.dt, tte), 0.0);  // :200-203
+                else dtc = fmin(fmax(p.dt, -tte), 0.0);
+                if (windowed) {
+                    // field-slab streaming: only step while [t, t+dt] lies inside the resident time window;
+                    // otherwise leave the particle untouched (state Evaluate) for the next launch
+                    const double t1 = p.t + dtc;
+                    const double lo = fmin(p.t, t1), hi = fmax(p.t, t1);
+                    if (lo < a.win_lo || hi > a.win_hi) { paused = 1; break; }
+                }
+                p.dt = dtc;
+                for (int k = 0; k < nk; k++) {  // :206-216
+                    const int kid = KID >= 0 ? KID : prm.kernels[k];
+                    do {
+                        KLocal L;
+                        Request rq;
+                        attempts++;
+                        for (int stage = 0; !prepare(a, kid, stage, k, c, p, L, rq); stage++) {
+                            double u, v = 0.0, w = 0.0;
+                            if (rq.kind == RQ_SCALAR) {
+                                u = eval_scalar<FT>(a, mc, c, ei, rq.fidx, rq.t, rq.z, rq.y, rq.x, rq.f32);
+                            } else {
+                                eval_uvw<FT, KIND, INTERP>(a, mc, c, ei, rq.kind == RQ_UVW, rq.t, rq.z, rq.y, rq.x, rq.f32, u, v, w);
+                            }
+                            consume(kid, stage, L, u, v, w);
+                        }
+                    } while (c.state == PK_REPEAT);
+                }
+                if (c.state == PK_EVALUATE || c.state == PK_SUCCESS) {  // :219-222 -> _position_update :108-120
+                    p.x = padd(pf, p.x, p.dx);
+                    p.y = padd(pf, p.y, p.dy);
+                    p.z = padd(pf, p.z, p.dz);
+                    p.t += p.dt;
+                    p.dx = p.dy = p.dz = 0.0;
+                    if (prm.rk45_mode) p.dt = p.next_dt;
+                    steps++;
+                }
+                if (!prm.rk45_mode) p.dt = prm.dt0;                                 // :225-226
+                if (c.state == PK_EVALUATE && p.t == endtime) c.state = PK_ENDOFLOOP;  // :229-230
+            }
+            P.t[i] = p.t;
+            stp(P.z, i, p.z, pf);
+            stp(P.y, i, p.y, pf);
+            stp(P.x, i, p.x, pf);
+            stp(P.dz, i, p.dz, pf);
+            stp(P.dy, i, p.dy, pf);
+            stp(P.dx, i, p.dx, pf);
+            P.dt[i] = p.dt;
+            if (P.next_dt) P.next_dt[i] = p.next_dt;
+            P.state[i] = c.state;
+#pragma unroll
+            for (int g = 0; g < PK_MAX_GRIDS; g++)
+                if (g < P.ngrids) P.ei[i * P.ngrids + g] = ei[g];
+        }
+    }
+    steps = wave_sum(steps);
+    attempts = wave_sum(attempts);
+    paused = wave_sum(paused);
+    if ((threadIdx.x & 63) == 0) {
+        if (steps) atomicAdd(&a.counters->steps, steps);
+        if (attempts) atomicAdd(&a.counters->attempts, attempts);
+        if (paused) atomicAdd(&a.counters->paused, paused);
+    }
+}
+
+// One translation unit per program (compiled in parallel) defines launch_program<PROG>.
+// key bits: field f32 | curvilinear | C-grid ; lds: coordinate vectors staged in LDS
+template <int PROG>
+void launch_program(int field_f32, int curvilinear, int interp, int lds, const KArgs& a, dim3 grid, size_t lds_bytes,
+                    hipStream_t stream);
+
+#define PK_LAUNCH_CASE(FT, KD, IN, LD) \
+    hipLaunchKernelGGL((advect_kernel<FT, KD, IN, KIDV, LD>), grid, dim3(256), lds_bytes, stream, a)
+
+// single-kernel programs require LDS staging (the host falls back to the generic program otherwise)
+#define PK_DEFINE_LAUNCH_PROGRAM(PROGV, KID_, WITH_NOLDS)                                                            \
+    template <>                                                                                                      \
+    void launch_program<PROGV>(int field_f32, int curvilinear, int interp, int lds, const KArgs& a, dim3 grid,       \
+                               size_t lds_bytes, hipStream_t stream) {                                               \
+        constexpr int KIDV = KID_;                                                                                   \
+        const int key = (field_f32 ? 4 : 0) | (curvilinear ? 2 : 0) | (interp ? 1 : 0);                              \
+        if (lds || !(WITH_NOLDS)) {                                                                                  \
+            switch (key) {                                                                                           \
+                case 0: PK_LAUNCH_CASE(double, 0, 0, true); break;                                                   \
+                case 1: PK_LAUNCH_CASE(double, 0, 1, true); break;                                                   \
+                case 2: PK_LAUNCH_CASE(double, 1, 0, true); break;                                                   \
+                case 3: PK_LAUNCH_CASE(double, 1, 1, true); break;                                                   \
+                case 4: PK_LAUNCH_CASE(float, 0, 0, true); break;                                                    \
+                case 5: PK_LAUNCH_CASE(float, 0, 1, true); break;                                                    \
+                case 6: PK_LAUNCH_CASE(float, 1, 0, true); break;                                                    \
+                case 7: PK_LAUNCH_CASE(float, 1, 1, true); break;                                                    \
+            }                                                                                                        \
+        } else if (WITH_NOLDS) {                                                                                     \
+            switch (key) {                                                                                           \
+                case 0: PK_LAUNCH_CASE(double, 0, 0, !(WITH_NOLDS)); break;                                          \
+                case 1: PK_LAUNCH_CASE(double, 0, 1, !(WITH_NOLDS)); break;                                          \
+                case 2: PK_LAUNCH_CASE(double, 1, 0, !(WITH_NOLDS)); break;                                          \
+                case 3: PK_LAUNCH_CASE(double, 1, 1, !(WITH_NOLDS)); break;                                          \
+                case 4: PK_LAUNCH_CASE(float, 0, 0, !(WITH_NOLDS)); break;                                           \
+                case 5: PK_LAUNCH_CASE(float, 0, 1, !(WITH_NOLDS)); break;                                           \
+                case 6: PK_LAUNCH_CASE(float, 1, 0, !(WITH_NOLDS)); break;                                           \
+                case 7: PK_LAUNCH_CASE(float, 1, 1, !(WITH_NOLDS)); break;                                           \
+            }                                                                                                        \
+        }                                                                                                            \
+    }
+
+}  // namespace pk

@@ -1,0 +1,361 @@
+"""DeviceEngine: the device-resident copy of a FieldSet and the driver of ``pk_execute``.
+
+Replaces the body of the reference's ``Kernel.execute`` (src/parcels/_core/kernel.py:174-247) and its field backend
+(``WindowedArray``, src/parcels/_core/_windowed_array.py:25-113):
+
+* grids (coordinates, ravel dims, C-grid offsets, Morton hash table) and field time levels live in HBM;
+* when all time levels of a field fit the memory budget they are uploaded once; otherwise each field keeps a ring
+  of ``nslots`` levels and the next level is copied on a second HIP stream while the RK sub-steps of the current
+  levels run (particles whose next step would leave the resident window pause and are resumed by the next launch,
+  so the trajectory is independent of the window size);
+* particle columns are bound from the ParticleSet's NumPy SoA dict, copied once per ``execute`` and advanced on
+  the device until ``endtime``.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _hip
+from .field import Field, VectorField
+from .interpolators import CGrid_Velocity, XConstantField
+from .statuscodes import StatusCode
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class DeviceEngine:
+    def __init__(self, fieldset, device: int = 0, nslots: int | None = None, memory_fraction: float = 0.6):
+        self.fieldset = fieldset
+        self.device = int(device)
+        self.ctx = _hip.Context(self.device)
+        self.lib = self.ctx.lib
+        self._keep = []  # host buffers referenced by the library during calls
+        self.grids = list(fieldset.gridset)
+        self.grid_ids = []
+        for g in self.grids:
+            self.grid_ids.append(self._create_grid(g))
+        # scalar fields in fieldset order
+        self.scalar_fields = [f for f in fieldset.fields.values() if isinstance(f, Field)]
+        if len(self.scalar_fields) > _hip.PK_MAX_FIELDS:
+            raise ValueError(f"at most {_hip.PK_MAX_FIELDS} fields are supported on the device")
+        self.field_ids: dict[str, int] = {}
+        self.field_host: dict[str, np.ndarray] = {}
+        self.field_nslots: dict[str, int] = {}
+        self._plan_and_create_fields(nslots, memory_fraction)
+        self._bound_sig = None
+        self.last_stats: dict | None = None
+
+    # ---- grids -----------------------------------------------------------------------------------------------
+    def _create_grid(self, g) -> int:
+        d = _hip.GridDesc()
+        axes = g.axes
+        lon, lat = np.asarray(g.lon), np.asarray(g.lat)
+        depth = np.asarray(g.depth) if "Z" in axes else None
+        d.kind = 1 if g.is_curvilinear else 0
+        d.spherical = int(g._mesh.is_spherical())
+        d.has_x, d.has_y, d.has_z = int("X" in axes), int("Y" in axes), int("Z" in axes)
+        d.nx = lon.shape[-1]
+        d.ny = lat.shape[0]
+        d.nz = depth.shape[0] if depth is not None else 0
+        d.xdim = g.xdim if "X" in axes else 0
+        d.ydim = g.ydim if "Y" in axes else 0
+        d.zdim = g.zdim if "Z" in axes else 0
+        off = g.offsets()
+        d.off_x, d.off_y, d.off_z = off["X"], off["Y"], off["Z"]
+        d.lon_f32 = int(lon.dtype == np.float32)
+        d.lat_f32 = int(lat.dtype == np.float32)
+        d.depth_f32 = int(depth is not None and depth.dtype == np.float32)
+        d.deg2m = float(g.deg2m)
+        lon64 = np.ascontiguousarray(lon, dtype=np.float64)
+        lat64 = np.ascontiguousarray(lat, dtype=np.float64)
+        dep64 = np.ascontiguousarray(depth, dtype=np.float64) if depth is not None else None
+        d.lon, d.lat, d.depth = _ptr(lon64), _ptr(lat64), _ptr(dep64)
+        keep = [lon64, lat64, dep64]
+        if d.kind == 1:
+            t = g.get_spatial_hash().table()
+            keys = np.ascontiguousarray(t["keys"], dtype=np.uint32)
+            starts = np.ascontiguousarray(t["starts"], dtype=np.int64)
+            counts = np.ascontiguousarray(t["counts"], dtype=np.int64)
+            faces = np.ascontiguousarray(t["faces"], dtype=np.uint32)
+            keep += [keys, starts, counts, faces]
+            d.h_keys, d.h_starts, d.h_counts, d.h_faces = _ptr(keys), _ptr(starts), _ptr(counts), _ptr(faces)
+            d.h_nkeys = keys.size
+            d.h_nentries = faces.size
+            d.h_bitwidth = int(t["bitwidth"])
+            for i, v in enumerate(np.asarray(t["bbox"], dtype=np.float64)):
+                d.h_bbox[i] = float(v)
+        gid = C.c_int32(-1)
+        self.ctx.check(self.lib.pk_grid_create(self.ctx.handle, C.byref(d), C.byref(gid)), "pk_grid_create")
+        del keep  # copied on call
+        return gid.value
+
+    # ---- fields ----------------------------------------------------------------------------------------------
+    def _plan_and_create_fields(self, nslots, memory_fraction):
+        fs = self.fieldset
+        # U, V, W of a vector field must share one dtype on the device; widening f32 -> f64 is exact
+        share = {}
+        for f in fs.fields.values():
+            if isinstance(f, VectorField):
+                comps = [c for c in (f.U, f.V, f.W) if c is not None]
+                dts = {np.asarray(c.data.data).dtype for c in comps}
+                tgt = np.float32 if dts == {np.dtype(np.float32)} else np.float64
+                for c in comps:
+                    share[c.name] = np.float64 if share.get(c.name) is np.float64 else tgt
+        hosts = {}
+        for f in self.scalar_fields:
+            a = np.asarray(f.data.data)
+            tgt = share.get(f.name, np.float32 if a.dtype == np.float32 else np.float64)
+            hosts[f.name] = np.ascontiguousarray(a, dtype=tgt)
+        # residency plan: keep all levels if they fit the budget, else a ring
+        info = self.ctx.device_info()
+        budget = memory_fraction * info["free_mem"]
+        total_all = sum(h.nbytes for h in hosts.values())
+        for f in self.scalar_fields:
+            h = hosts[f.name]
+            nt = h.shape[0]
+            if nslots is not None:
+                ns = nt if nslots >= nt else max(int(nslots), 2)
+            elif total_all <= budget:
+                ns = nt
+            else:
+                level_bytes = sum(x.nbytes // x.shape[0] for x in hosts.values() if x.shape[0] > 1)
+                ns = max(4, min(nt, int(budget // max(level_bytes, 1))))
+                ns = nt if h.shape[0] == 1 else min(ns, nt)
+            self.field_nslots[f.name] = ns
+        for f in self.scalar_fields:
+            h = hosts[f.name]
+            dims = f.data.dims
+            d = _hip.FieldDesc()
+            d.grid = self.grid_ids[self.grids.index(f.grid)]
+            d.dtype = _hip.PK_F64 if h.dtype == np.float64 else _hip.PK_F32
+            d.nt, d.nz, d.ny, d.nx = h.shape
+            d2a = f.grid.sgrid_metadata.dim_to_axis()
+            d.has_t = int(dims[0] == "time")
+            d.has_z = int(d2a.get(dims[1]) == "Z")
+            d.has_y = int(d2a.get(dims[2]) == "Y")
+            d.has_x = int(d2a.get(dims[3]) == "X")
+            tflt = f.model.time_flt
+            has_ti = f.time_interval is not None and tflt is not None
+            d.has_time_interval = int(has_ti)
+            is_const = False
+            try:
+                is_const = isinstance(f.interp_method, XConstantField)
+            except AttributeError:
+                pass
+            d.is_const = int(is_const)
+            if is_const:
+                d.has_y = d.has_x = 1
+            d.nslots = self.field_nslots[f.name]
+            tarr = np.ascontiguousarray(tflt, dtype=np.float64) if has_ti else np.zeros(h.shape[0])
+            d.time = _ptr(tarr)
+            fid = C.c_int32(-1)
+            self.ctx.check(self.lib.pk_field_create(self.ctx.handle, C.byref(d), C.byref(fid)), f"pk_field_create({f.name})")
+            self.field_ids[f.name] = fid.value
+            self.field_host[f.name] = h
+            if d.nslots >= d.nt:
+                for lv in range(d.nt):
+                    self._upload(f.name, lv, asynchronous=False)
+        self.windowed = any(self.field_nslots[f.name] < self.field_host[f.name].shape[0] for f in self.scalar_fields)
+
+    def _upload(self, name, level, asynchronous):
+        h = self.field_host[name]
+        lvl = h[level]
+        self.ctx.check(
+            self.lib.pk_field_upload_level(self.ctx.handle, self.field_ids[name], int(level), _ptr(lvl), int(asynchronous)),
+            f"pk_field_upload_level({name}, {level})",
+        )
+
+    def _slots(self, name):
+        ns = self.field_nslots[name]
+        arr = (C.c_int32 * ns)()
+        n = C.c_int32()
+        self.ctx.check(self.lib.pk_field_slots(self.ctx.handle, self.field_ids[name], arr, C.byref(n)), "pk_field_slots")
+        return list(arr)
+
+    # field-slab streaming --------------------------------------------------------------------------------------
+    def _windowed_fields(self):
+        return [f for f in self.scalar_fields if self.field_nslots[f.name] < self.field_host[f.name].shape[0]]
+
+    def _ensure_window(self, t_live: float, sign: int, prefetch: bool = True):
+        """Make levels [k0, k0 + ncommit) resident (forward; mirrored backward), k0 = level bracket of t_live,
+        and start the asynchronous copy of the next level into the spare slot."""
+        wf = self._windowed_fields()
+        if not wf:
+            return
+        time = wf[0].model.time_flt
+        nt = len(time)
+        ns = min(self.field_nslots[f.name] for f in wf)
+        ncommit = ns - 1 if prefetch and ns > 2 else ns
+        if sign > 0:
+            k0 = int(np.clip(np.searchsorted(time, t_live, side="right") - 1, 0, nt - 1))
+            want = list(range(k0, min(k0 + ncommit, nt)))
+            nxt = k0 + ncommit if k0 + ncommit < nt else None
+        else:
+            k1 = int(np.clip(np.searchsorted(time, t_live, side="left"), 0, nt - 1))
+            want = list(range(max(k1 - ncommit + 1, 0), k1 + 1))
+            nxt = k1 - ncommit if k1 - ncommit >= 0 else None
+        self.ctx.check(self.lib.pk_field_sync(self.ctx.handle), "pk_field_sync")  # commit earlier prefetches
+        for f in wf:
+            have = set(self._slots(f.name))
+            for lv in want:
+                if lv not in have:
+                    self._upload(f.name, lv, asynchronous=False)
+        if prefetch and nxt is not None and ncommit < ns:
+            for f in wf:
+                if nxt not in set(self._slots(f.name)):
+                    self._upload(f.name, nxt, asynchronous=True)
+        self._window = (want[0], want[-1])
+
+    # ---- particles -------------------------------------------------------------------------------------------
+    def bind_particles(self, data: dict):
+        n = data["x"].shape[0]
+        for k in ("t", "z", "y", "x", "dz", "dy", "dx", "dt", "state", "ei", "particle_id"):
+            a = data[k]
+            if not a.flags["C_CONTIGUOUS"]:
+                data[k] = np.ascontiguousarray(a)
+        sdt = data["x"].dtype
+        if any(data[k].dtype != sdt for k in ("z", "y", "dz", "dy", "dx")) or sdt not in (np.float32, np.float64):
+            raise TypeError("z, y, x, dz, dy, dx must share one dtype (float32 or float64)")
+        if data["t"].dtype != np.float64 or data["dt"].dtype != np.float64:
+            raise TypeError("t and dt must be float64")
+        if data["state"].dtype != np.int32 or data["ei"].dtype != np.int32 or data["particle_id"].dtype != np.int64:
+            raise TypeError("state/ei must be int32 and particle_id int64")
+        d = _hip.ParticlesDesc()
+        d.n = n
+        d.ngrids = data["ei"].shape[1]
+        d.spatial_dtype = _hip.PK_F32 if sdt == np.float32 else _hip.PK_F64
+        d.t = _ptr(data["t"])
+        d.z, d.y, d.x = _ptr(data["z"]), _ptr(data["y"]), _ptr(data["x"])
+        d.dz, d.dy, d.dx = _ptr(data["dz"]), _ptr(data["dy"]), _ptr(data["dx"])
+        d.dt = _ptr(data["dt"])
+        nd = data.get("next_dt")
+        if nd is not None and nd.dtype != np.float64:
+            raise TypeError("next_dt must be float64")
+        d.next_dt = _ptr(nd) if nd is not None else None
+        d.state, d.ei, d.particle_id = _ptr(data["state"]), _ptr(data["ei"]), _ptr(data["particle_id"])
+        self.ctx.check(self.lib.pk_particles_bind(self.ctx.handle, C.byref(d)), "pk_particles_bind")
+        self._bound = data
+
+    def h2d(self):
+        self.ctx.check(self.lib.pk_particles_h2d(self.ctx.handle), "pk_particles_h2d")
+
+    def d2h(self):
+        self.ctx.check(self.lib.pk_particles_d2h(self.ctx.handle), "pk_particles_d2h")
+
+    # ---- execution -------------------------------------------------------------------------------------------
+    def make_params(self, kernel_ids, *, endtime, dt0, context=None, seed=0, reset_state=1, have_guess0=0, sort_by_cell=0):
+        fs = self.fieldset
+        context = context or {}
+        p = _hip.ExecParams()
+        if not (1 <= len(kernel_ids) <= _hip.PK_MAX_KERNELS):
+            raise ValueError(f"between 1 and {_hip.PK_MAX_KERNELS} kernels are supported")
+        p.nk = len(kernel_ids)
+        for i, k in enumerate(kernel_ids):
+            p.kernels[i] = int(k)
+        uv = fs.fields.get("UV")
+        uvw = fs.fields.get("UVW")
+        vec = uvw if uvw is not None else uv
+        p.interp_uv = int(isinstance(vec.interp_method, CGrid_Velocity)) if vec is not None else 0
+        fid = self.field_ids
+        p.fU = fid.get(vec.U.name, -1) if vec is not None else -1
+        p.fV = fid.get(vec.V.name, -1) if vec is not None else -1
+        p.fW = fid.get(uvw.W.name, -1) if uvw is not None else -1
+        p.fKh_zonal = fid.get("Kh_zonal", -1)
+        p.fKh_meridional = fid.get("Kh_meridional", -1)
+        p.rk45_mode = int("RK45_tol" in context)
+        p.reset_state = int(reset_state)
+        p.have_guess0 = int(have_guess0)
+        p.sort_by_cell = int(sort_by_cell)
+        p.endtime = float(endtime)
+        p.dt0 = float(dt0)
+        p.rk45_tol = float(context.get("RK45_tol", 0.0))
+        p.rk45_min_dt = float(context.get("RK45_min_dt", 0.0))
+        p.rk45_max_dt = float(context.get("RK45_max_dt", 0.0))
+        p.dres = float(context.get("dres", 0.0))
+        p.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        return p
+
+    def execute(self, kernel_ids, *, endtime, dt0, context=None, seed=0, have_guess0=0, sort_by_cell=0, t_start=None) -> dict:
+        """One Kernel.execute(pset, endtime, dt) on the bound (device-resident) particle columns."""
+        sign = 1 if dt0 > 0 else -1
+        total = {"steps": 0, "attempts": 0, "kernel_ms": 0.0, "sort_ms": 0.0, "launches": 0}
+        reset = 1
+        t_live = t_start
+        last_live = None
+        while True:
+            if self.windowed:
+                if t_live is None or not np.isfinite(t_live):
+                    t_live = 0.0 if sign > 0 else float(self._windowed_fields()[0].model.time_flt[-1])
+                self._ensure_window(float(t_live), sign)
+            prm = self.make_params(kernel_ids, endtime=endtime, dt0=dt0, context=context, seed=seed, reset_state=reset,
+                                   have_guess0=(have_guess0 if reset else 1), sort_by_cell=sort_by_cell)
+            st = _hip.ExecStats()
+            self.ctx.check(self.lib.pk_execute(self.ctx.handle, C.byref(prm), C.byref(st)), "pk_execute")
+            reset = 0
+            total["steps"] += st.steps
+            total["attempts"] += st.attempts
+            total["kernel_ms"] += st.kernel_ms
+            total["sort_ms"] += st.sort_ms
+            total["launches"] += st.launches
+            counts = {code: int(st.state_counts[code]) for code in range(_hip.PK_NUM_STATE_CODES) if st.state_counts[code]}
+            if st.paused == 0:
+                break
+            if not self.windowed:
+                raise _hip.HipLibraryError("particles paused although all time levels are resident (internal error)")
+            t_live = st.t_min_live if sign > 0 else st.t_max_live
+            if last_live is not None and t_live == last_live:
+                raise RuntimeError(
+                    "field window too small: a single step does not fit into the resident time levels; "
+                    "increase nslots (FieldSet.to_device(nslots=...))"
+                )
+            last_live = t_live
+        total["state_counts"] = counts
+        self.last_stats = total
+        return total
+
+    # ---- sampling (Field.eval / VectorField.eval) ---------------------------------------------------------------
+    def sample(self, name, t, z, y, x):
+        fs = self.fieldset
+        f = fs.fields[name]
+        t, z, y, x = np.broadcast_arrays(*(np.atleast_1d(np.asarray(v, dtype=np.float64)) for v in (t, z, y, x)))
+        t, z, y, x = (np.ascontiguousarray(v) for v in (t, z, y, x))
+        m = x.shape[0]
+        if self.windowed:
+            raise NotImplementedError("host-driven sampling needs all time levels resident (use nslots >= nt)")
+        u, v, w = np.zeros(m), np.zeros(m), np.zeros(m)
+        st = np.zeros(m, np.int32)
+        prm = self.make_params([4], endtime=0.0, dt0=1.0)
+        if isinstance(f, VectorField):
+            prm.interp_uv = int(isinstance(f.interp_method, CGrid_Velocity))
+            prm.fU, prm.fV = self.field_ids[f.U.name], self.field_ids[f.V.name]
+            prm.fW = self.field_ids[f.W.name] if f.W is not None else -1
+            what = -2 if f.W is not None else -1
+        else:
+            what = self.field_ids[name]
+            prm.fU = prm.fV = what
+            prm.fW = -1
+        self.ctx.check(
+            self.lib.pk_eval(self.ctx.handle, C.byref(prm), what, m, _ptr(t), _ptr(z), _ptr(y), _ptr(x), _ptr(u), _ptr(v), _ptr(w), _ptr(st)),
+            "pk_eval",
+        )
+        self.last_sample_state = st
+        return u, v, w
+
+
+def raise_particle_errors(data: dict):
+    """kernel.py:236-245: raise for the first error code present, in ErrorsToThrow order."""
+    from .statuscodes import ErrorsToThrow
+
+    state = data["state"]
+    for code, fn in ErrorsToThrow.items():
+        inds = state == code
+        if np.any(inds):
+            if code == StatusCode.ErrorOutsideTimeInterval:
+                fn(data["t"][inds])
+            else:
+                fn(data["z"][inds], data["y"][inds], data["x"][inds])

@@ -1,0 +1,244 @@
+"""Field / VectorField (mirrors src/parcels/_core/field.py) and the structured model that owns them
+(the part of src/parcels/_core/model.py the hot path needs).
+
+Sampling -- ``fieldset.UV[t, z, y, x]`` / ``field.eval(...)`` -- runs on the GPU through ``pk_eval``
+(include/parcels_hip.h); nothing here interpolates on the host.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from .dataset import DataArray, Dataset
+from .interpolators import (
+    CGrid_Velocity,
+    ScalarInterpolator,
+    VectorInterpolator,
+    XConstantField,
+    XLinear,
+    XLinear_Velocity,
+)
+from .xgrid import XGrid
+
+_FIELD_DATA_ORDERING = ("T", "Z", "Y", "X")
+
+
+class TimeInterval:
+    """Closed interval [left, right] (utils/time.py:17-91)."""
+
+    def __init__(self, left, right):
+        if left >= right:
+            raise ValueError(f"Expected left to be strictly less than right, got left={left} and right={right}.")
+        self.left = left
+        self.right = right
+
+    @property
+    def time_length_as_flt(self) -> float:
+        return to_seconds(self.right - self.left)
+
+    def __contains__(self, item):
+        return self.left <= item <= self.right
+
+    def __eq__(self, other):
+        return isinstance(other, TimeInterval) and self.left == other.left and self.right == other.right
+
+    def __repr__(self):
+        return f"TimeInterval(left={self.left!r}, right={self.right!r})"
+
+    def intersection(self, other):
+        start, end = max(self.left, other.left), min(self.right, other.right)
+        return TimeInterval(start, end) if start < end else None
+
+
+def to_seconds(dt) -> float | np.ndarray:
+    """utils/time.py:197-214 (timedelta_to_float)."""
+    import datetime as _dt
+
+    if isinstance(dt, _dt.timedelta):
+        return dt.total_seconds()
+    if isinstance(dt, np.timedelta64):
+        return float(dt / np.timedelta64(1, "s"))
+    if hasattr(dt, "dtype") and np.issubdtype(dt.dtype, np.timedelta64):
+        return (dt / np.timedelta64(1, "s")).astype(float)
+    return float(dt) if np.ndim(dt) == 0 else np.asarray(dt, dtype=float)
+
+
+def transpose_to_tzyx(da: DataArray, metadata) -> DataArray:
+    """xgrid.py:71-105: order TZYX, size-1 "mock" dims for absent axes."""
+    d2a = dict(metadata.dim_to_axis())
+    d2a["time"] = "T"
+    if all(d not in d2a for d in da.dims):
+        if da.shape != (1, 1, 1, 1):
+            raise ValueError(f"DataArray with dims {da.dims} has no dimension on the grid")
+        return DataArray(tuple(f"mock{a}" for a in _FIELD_DATA_ORDERING), da.data, da.attrs)
+    unknown = [d for d in da.dims if d not in d2a]
+    if unknown:
+        raise ValueError(f"DataArray with dims {da.dims} has dimensions {unknown} that are not on the provided grid")
+    axes = [d2a[d] for d in da.dims]
+    if len(set(axes)) != len(axes):
+        raise ValueError(f"two dimensions of {da.dims} lie on the same axis")
+    data = da.data
+    dims = list(da.dims)
+    for ax in _FIELD_DATA_ORDERING:
+        if ax not in axes:
+            data = data[None]
+            dims.insert(0, f"mock{ax}")
+            axes.insert(0, ax)
+    order = [axes.index(ax) for ax in _FIELD_DATA_ORDERING]
+    return DataArray(tuple(dims[i] for i in order), np.transpose(data, order), da.attrs)
+
+
+class StructuredModelData:
+    """Dataset + grid + interpolator registry (model.py:146-250)."""
+
+    def __init__(self, ds: Dataset, mesh, vector_field_components: dict, skip_field_data_validation=False):
+        if not isinstance(ds, Dataset):
+            raise ValueError(f"Expected `ds` to be a parcels_amd.Dataset. Got {type(ds)}")
+        ds = ds.copy()
+        md = ds.sgrid
+        for name in list(ds.data_vars):
+            da = transpose_to_tzyx(ds.data_vars[name], md)
+            if not skip_field_data_validation and np.issubdtype(da.data.dtype, np.floating):
+                if np.isnan(da.data).any():  # model.py:135-143 fillna(0)
+                    da = DataArray(da.dims, np.nan_to_num(da.data, nan=0.0), da.attrs)
+            ds.data_vars[name] = da
+        self.data = ds
+        self.grid = XGrid(ds, mesh)
+        self.vector_field_components = dict(vector_field_components)
+        self.field_to_interpolator: dict = {}
+        self._fields = None
+        # time axis in float seconds since its first level
+        self.time_values = None
+        self.time_flt = None
+        if "time" in ds.coords and ds.coords["time"].data.size > 1:
+            tv = np.asarray(ds.coords["time"].data)
+            self.time_values = tv
+            if np.issubdtype(tv.dtype, np.datetime64) or np.issubdtype(tv.dtype, np.timedelta64):
+                self.time_flt = to_seconds(tv - tv[0])
+            else:
+                self.time_flt = tv.astype(np.float64) - float(tv[0])
+            if not np.all(np.diff(self.time_flt) > 0):
+                raise ValueError("time levels must be strictly increasing")
+
+    @property
+    def time_interval(self):  # model.py:511-515
+        if self.time_values is None:
+            return None
+        tv = self.time_values
+        if np.issubdtype(tv.dtype, np.datetime64) or np.issubdtype(tv.dtype, np.timedelta64):
+            return TimeInterval(tv[0], tv[-1])
+        return TimeInterval(np.timedelta64(int(round(float(tv[0]) * 1e9)), "ns"), np.timedelta64(int(round(float(tv[-1]) * 1e9)), "ns"))
+
+    def field_data(self, name):
+        return self.data.data_vars[name]
+
+    def construct_fields(self):
+        single = {name: Field(str(name), self) for name in self.data.data_vars}
+        vectors = {}
+        for vname, comps in self.vector_field_components.items():
+            u, v = self.data.data_vars[comps[0]], self.data.data_vars[comps[1]]
+            agrid = set(u.dims) == set(v.dims)  # model.py:505-508
+            interp = XLinear_Velocity() if agrid else CGrid_Velocity()
+            vectors[vname] = VectorField(vname, *[single[c] for c in comps], interp_method=interp)
+        return list({**single, **vectors}.values())
+
+
+class Field:
+    """Scalar field (field.py:47-195)."""
+
+    def __init__(self, name: str, model: StructuredModelData):
+        if not isinstance(name, str) or not name.isidentifier():
+            raise ValueError(f"Field name has to be a valid Python variable name. Got {name!r}")
+        self.name = name
+        self.model = model
+        self.igrid = -1
+        self._fieldset = None
+
+    @property
+    def data(self) -> DataArray:
+        return self.model.field_data(self.name)
+
+    @property
+    def grid(self) -> XGrid:
+        return self.model.grid
+
+    @property
+    def time_interval(self):
+        if "time" not in self.data.dims:
+            return None
+        return self.model.time_interval
+
+    def __repr__(self):
+        return f"Field(name={self.name})"
+
+    @property
+    def interp_method(self):
+        try:
+            return self.model.field_to_interpolator[self.name]
+        except KeyError as e:
+            raise AttributeError(f"{type(self).__name__} doesn't have an interp_method defined for it.") from e
+
+    @interp_method.setter
+    def interp_method(self, value):
+        if not isinstance(value, ScalarInterpolator):
+            raise ValueError(f"interp_method must be a `ScalarInterpolator` object. Got {type(value)=!r}")
+        if not isinstance(value, (XLinear, XConstantField)):
+            raise NotImplementedError(f"{type(value).__name__} has no HIP implementation yet (XLinear, XConstantField do)")
+        self.model.field_to_interpolator[self.name] = value
+
+    def eval(self, t, z, y, x, particles=None):
+        """Interpolate in space and time on the GPU (field.py:145-185). Returns the values as float64."""
+        if self._fieldset is None:
+            raise RuntimeError("Field is not attached to a FieldSet")
+        return self._fieldset._engine_or_create().sample(self.name, t, z, y, x)[0]
+
+    def __getitem__(self, key):
+        if hasattr(key, "_data"):
+            d = key._data
+            return self.eval(d["t"], d["z"], d["y"], d["x"])
+        return self.eval(*key[:4])
+
+
+class VectorField:
+    """Vector field (field.py:198-304)."""
+
+    def __init__(self, name, U: Field, V: Field, W: Field | None = None, interp_method=None):
+        if interp_method is None:
+            raise ValueError("interp_method must be provided for VectorField initialization.")
+        if not isinstance(interp_method, VectorInterpolator):
+            raise ValueError(f"interp_method must be a `VectorInterpolator` object. Got {type(interp_method)=!r}")
+        self.name = name
+        self.U, self.V, self.W = U, V, W
+        self.grid = U.grid
+        self.igrid = U.igrid
+        tis = [f.time_interval for f in (U, V) + ((W,) if W is not None else ())]
+        if any(ti != tis[0] for ti in tis[1:]):
+            raise ValueError("Fields must have the same time domain.")
+        self.time_interval = U.time_interval
+        self.vector_type = "3D" if W is not None else "2D"
+        self._interp_method = interp_method
+        self._fieldset = None
+
+    @property
+    def interp_method(self):
+        return self._interp_method
+
+    @interp_method.setter
+    def interp_method(self, method):
+        if not isinstance(method, VectorInterpolator):
+            raise ValueError(f"method must be a `VectorInterpolator` object. Got {type(method)=!r}")
+        if not isinstance(method, (XLinear_Velocity, CGrid_Velocity)):
+            raise NotImplementedError(f"{type(method).__name__} has no HIP implementation yet")
+        self._interp_method = method
+
+    def eval(self, t, z, y, x, particles=None):
+        if self._fieldset is None:
+            raise RuntimeError("VectorField is not attached to a FieldSet")
+        u, v, w = self._fieldset._engine_or_create().sample(self.name, t, z, y, x)
+        return (u, v, w) if self.vector_type == "3D" else (u, v)
+
+    def __getitem__(self, key):
+        if hasattr(key, "_data"):
+            d = key._data
+            return self.eval(d["t"], d["z"], d["y"], d["x"])
+        return self.eval(*key[:4])

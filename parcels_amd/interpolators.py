@@ -1,0 +1,29 @@
+"""Interpolator markers (mirrors src/parcels/interpolators/_xinterpolators.py class names).
+
+The arithmetic lives in the HIP kernels (csrc/pk_device.h: xlinear, cgrid_velocity); these classes select it,
+exactly as assigning ``Field.interp_method`` does in the reference (field.py:130-135, 244-248).
+"""
+
+
+class ScalarInterpolator:
+    kind = None
+
+
+class VectorInterpolator:
+    kind = None
+
+
+class XLinear(ScalarInterpolator):  # _xinterpolators.py:112-153
+    kind = "xlinear"
+
+
+class XConstantField(ScalarInterpolator):  # _xinterpolators.py:156-166
+    kind = "constant"
+
+
+class XLinear_Velocity(VectorInterpolator):  # noqa: N801  _xinterpolators.py:169-190
+    kind = 0
+
+
+class CGrid_Velocity(VectorInterpolator):  # noqa: N801  _xinterpolators.py:193-332
+    kind = 1

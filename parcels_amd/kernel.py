@@ -1,0 +1,123 @@
+"""Kernel: validation of the kernel list and the device replacement of ``Kernel.execute``
+(mirrors src/parcels/_core/kernel.py).
+
+The reference runs every kernel function on a NumPy view of the particle set, one dt at a time
+(kernel.py:188-245).  Here the kernel list is translated to PK_KERNEL_* ids and ONE ``pk_execute`` call advances all
+particles to ``endtime`` on the GPU.  Only the built-in kernels of ``parcels_amd.kernels`` are accepted: a Python
+function cannot run inside a HIP kernel and this package deliberately has no host execution path.
+"""
+
+from __future__ import annotations
+
+import inspect
+import types
+import warnings
+
+import numpy as np
+
+from . import kernels as _k
+from .engine import raise_particle_errors
+from .statuscodes import StatusCode
+
+
+class KernelWarning(RuntimeWarning):
+    pass
+
+
+def _same_signature(f, ref):  # _python.py:31-49
+    pf, pr = inspect.signature(f).parameters, inspect.signature(ref).parameters
+    return [(p.name, p.kind) for p in pf.values()] == [(p.name, p.kind) for p in pr.values()]
+
+
+class Kernel:
+    def __init__(self, kernels, pset):
+        if not isinstance(kernels, list):
+            raise ValueError(f"kernels must be a list. Got {kernels=!r}")
+        for f in kernels:
+            if not isinstance(f, types.FunctionType):
+                raise TypeError(f"Argument `kernels` should be a function or list of functions. Got {type(f)}")
+            if not _same_signature(f, _k.AdvectionRK4):
+                raise ValueError(f"Kernel function {f.__name__} must have the signature (particles, fieldset)")
+        if len(kernels) == 0:
+            raise ValueError("List of `kernels` should have at least one function.")
+        unknown = [f.__name__ for f in kernels if f not in _k.KERNEL_IDS]
+        if unknown:
+            raise NotImplementedError(
+                f"{unknown} are not built-in device kernels. parcels_amd executes kernels inside a HIP kernel and has "
+                f"no host (NumPy) path; supported: {sorted(f.__name__ for f in _k.KERNEL_IDS)}"
+            )
+        self._fieldset = pset.fieldset
+        self._pclass = pset._pclass
+        for f in kernels:
+            self.check_fieldsets_in_kernels(f)
+        self._kernels = kernels
+        self.kernel_ids = [_k.KERNEL_IDS[f] for f in kernels]
+
+    @property
+    def funcname(self):
+        return "".join(f.__name__ for f in self._kernels)
+
+    @property
+    def fieldset(self):
+        return self._fieldset
+
+    @property
+    def pclass(self):
+        return self._pclass
+
+    def check_fieldsets_in_kernels(self, kernel):
+        """kernel.py:122-159, including its context side effects (RK45 defaults; the tolerance is divided by
+        deg2m on a spherical mesh on EVERY Kernel construction, as in the reference)."""
+        fs = self.fieldset
+        if kernel is _k.AdvectionRK45:
+            if "next_dt" not in [v.name for v in self.pclass.variables]:
+                raise ValueError('ParticleClass requires a "next_dt" for AdvectionRK45 Kernel.')
+            if not hasattr(fs, "RK45_tol"):
+                warnings.warn("Setting RK45 tolerance to 10 m. Use fieldset.add_context('RK45_tol', [distance]) to change.",
+                              KernelWarning, stacklevel=2)
+                fs.add_context("RK45_tol", 10)
+            if fs.U.grid._mesh.is_spherical():
+                fs.context["RK45_tol"] = fs.RK45_tol / fs.U.grid.deg2m
+            if not hasattr(fs, "RK45_min_dt"):
+                warnings.warn("Setting RK45 minimum timestep to 1 s. Use fieldset.add_context('RK45_min_dt', [timestep]) to change.",
+                              KernelWarning, stacklevel=2)
+                fs.add_context("RK45_min_dt", 1)
+            if not hasattr(fs, "RK45_max_dt"):
+                warnings.warn("Setting RK45 maximum timestep to 1 day. Use fieldset.add_context('RK45_max_dt', [timestep]) to change.",
+                              KernelWarning, stacklevel=2)
+                fs.add_context("RK45_max_dt", 60 * 60 * 24)
+        if kernel in (_k.AdvectionDiffusionM1, _k.AdvectionDiffusionEM, _k.DiffusionUniformKh):
+            for name in ("Kh_zonal", "Kh_meridional"):
+                if name not in fs.fields:
+                    raise ValueError(f"{kernel.__name__} needs the field {name}")
+            if kernel is not _k.DiffusionUniformKh and not hasattr(fs, "dres"):
+                raise ValueError(f"{kernel.__name__} needs fieldset.add_context('dres', ...)")
+        if kernel in (_k.AdvectionRK4_3D, _k.AdvectionRK2_3D) and "UVW" not in fs.fields:
+            raise ValueError(f"{kernel.__name__} needs a W field (UVW)")
+
+    def execute(self, pset, endtime, dt):
+        """Advance every particle to ``endtime`` on the device (kernel.py:174-247)."""
+        if len(pset) == 0:
+            return StatusCode.Success
+        engine = pset._engine()
+        data = pset._data
+        sign = 1 if dt > 0 else -1
+        t = data["t"]
+        t_start = float(np.nanmin(t) if sign > 0 else np.nanmax(t))
+        have_guess0 = 0
+        g0 = self.fieldset.gridset[0]
+        if g0.is_curvilinear and "X" in g0.axes:  # np.any(xi) over the guesses (index_search.py:269)
+            xdim = max(g0.xdim, 1)
+            have_guess0 = int(np.any(np.mod(data["ei"][:, 0].astype(np.int64), xdim) != 0))
+        engine.bind_particles(data)
+        engine.h2d()
+        stats = engine.execute(self.kernel_ids, endtime=endtime, dt0=dt, context=self.fieldset.context, seed=pset.seed,
+                               have_guess0=have_guess0, sort_by_cell=int(pset.sort_by_cell), t_start=t_start)
+        engine.d2h()
+        pset._last_stats = stats
+        # delete particles that signalled deletion (kernel.py:98-106); relative order is preserved
+        deleted = data["state"] == StatusCode.Delete
+        if np.any(deleted):
+            pset.remove_indices(np.where(deleted)[0])
+        raise_particle_errors(pset._data)
+        return pset

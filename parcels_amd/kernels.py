@@ -1,0 +1,107 @@
+"""Built-in kernels (names and signatures of src/parcels/kernels/_advection.py and _advectiondiffusion.py).
+
+These functions are *tokens*: ``Kernel`` recognises them by identity (the reference does the same for
+AdvectionRK45, kernel.py:129-134) and maps each to the PK_KERNEL_* id of the HIP implementation in
+csrc/pk_kernels.h.  Their bodies never run; calling one directly is an error, because this package has no
+NumPy execution path.
+"""
+
+from __future__ import annotations
+
+__all__ = [
+    "AdvectionDiffusionEM",
+    "AdvectionDiffusionM1",
+    "AdvectionEE",
+    "AdvectionRK2",
+    "AdvectionRK2_3D",
+    "AdvectionRK4",
+    "AdvectionRK4_3D",
+    "AdvectionRK45",
+    "DeleteOutOfBounds",
+    "DeleteParticle",
+    "DiffusionUniformKh",
+    "SubmergeParticle",
+]
+
+
+def _device_only(name):
+    raise RuntimeError(
+        f"{name} is a device kernel of parcels_amd: pass it to ParticleSet.execute(); it cannot be called on the host"
+    )
+
+
+def AdvectionEE(particles, fieldset):  # _advection.py:78-82
+    """Explicit Euler advection."""
+    _device_only("AdvectionEE")
+
+
+def AdvectionRK2(particles, fieldset):  # _advection.py:21-28
+    """Second-order Runge-Kutta advection."""
+    _device_only("AdvectionRK2")
+
+
+def AdvectionRK2_3D(particles, fieldset):  # _advection.py:31-39
+    """Second-order Runge-Kutta advection including vertical velocity."""
+    _device_only("AdvectionRK2_3D")
+
+
+def AdvectionRK4(particles, fieldset):  # _advection.py:42-55
+    """Fourth-order Runge-Kutta advection."""
+    _device_only("AdvectionRK4")
+
+
+def AdvectionRK4_3D(particles, fieldset):  # _advection.py:58-75
+    """Fourth-order Runge-Kutta advection including vertical velocity."""
+    _device_only("AdvectionRK4_3D")
+
+
+def AdvectionRK45(particles, fieldset):  # _advection.py:85-155
+    """Adaptive Runge-Kutta-Fehlberg 4(5) advection (needs RK45_tol/RK45_min_dt/RK45_max_dt and a next_dt Variable)."""
+    _device_only("AdvectionRK45")
+
+
+def AdvectionDiffusionM1(particles, fieldset):  # _advectiondiffusion.py:21-67
+    """2-D advection-diffusion, Milstein scheme of order 1 (needs Kh_zonal, Kh_meridional, fieldset.dres)."""
+    _device_only("AdvectionDiffusionM1")
+
+
+def AdvectionDiffusionEM(particles, fieldset):  # _advectiondiffusion.py:70-117
+    """2-D advection-diffusion, Euler-Maruyama scheme."""
+    _device_only("AdvectionDiffusionEM")
+
+
+def DiffusionUniformKh(particles, fieldset):  # _advectiondiffusion.py:120-153
+    """2-D diffusion with uniform Kh (no advection)."""
+    _device_only("DiffusionUniformKh")
+
+
+# Native forms of the recovery kernels that the reference's tests write in Python and append to the kernel list.
+def DeleteParticle(particles, fieldset):  # tests/common_kernels.py:12-13
+    """state >= 50 -> Delete."""
+    _device_only("DeleteParticle")
+
+
+def DeleteOutOfBounds(particles, fieldset):  # tests/test_advection.py:157-161
+    """ErrorOutOfBounds / ErrorThroughSurface -> Delete."""
+    _device_only("DeleteOutOfBounds")
+
+
+def SubmergeParticle(particles, fieldset):  # tests/test_advection.py:163-174
+    """ErrorThroughSurface -> resample UV, dz = 0, z = 0, state = Evaluate."""
+    _device_only("SubmergeParticle")
+
+
+KERNEL_IDS = {
+    AdvectionEE: 1,
+    AdvectionRK2: 2,
+    AdvectionRK2_3D: 3,
+    AdvectionRK4: 4,
+    AdvectionRK4_3D: 5,
+    AdvectionRK45: 6,
+    AdvectionDiffusionM1: 7,
+    AdvectionDiffusionEM: 8,
+    DiffusionUniformKh: 9,
+    DeleteParticle: 20,
+    DeleteOutOfBounds: 21,
+    SubmergeParticle: 22,
+}

@@ -1,0 +1,86 @@
+"""Particle schema and SoA storage (mirrors src/parcels/_core/particle.py)."""
+
+from __future__ import annotations
+
+import numpy as np
+
+from .statuscodes import StatusCode
+
+__all__ = ["Particle", "ParticleClass", "Variable", "get_default_particle"]
+
+
+class Variable:  # particle.py:20-76
+    def __init__(self, name, dtype=np.float32, initial=0, to_write=True, attrs=None):
+        if not isinstance(name, str) or not name.isidentifier():
+            raise ValueError(f"Particle variable has to be a valid Python variable name. Got {name!r}")
+        self.name = name
+        self.dtype = np.dtype(dtype).type
+        self.initial = initial
+        self.to_write = to_write
+        self.attrs = dict(attrs or {})
+
+    def __repr__(self):
+        return f"Variable(name={self.name!r}, dtype={self.dtype.__name__}, initial={self.initial!r}, to_write={self.to_write!r})"
+
+
+class ParticleClass:  # particle.py:79-113
+    def __init__(self, variables):
+        if not all(isinstance(v, Variable) for v in variables):
+            raise ValueError("All items in variables must be instances of Variable")
+        names = [v.name for v in variables]
+        if len(set(names)) != len(names):
+            raise ValueError("Variable name already exists")
+        self.variables = list(variables)
+
+    def add_variable(self, variable):
+        if isinstance(variable, Variable):
+            variable = [variable]
+        for v in variable:
+            if not isinstance(v, Variable):
+                raise TypeError(f"Expected Variable, got {type(v)}")
+        existing = {v.name for v in self.variables}
+        for v in variable:
+            if v.name in existing:
+                raise ValueError(f"Variable name already exists: {v.name}")
+        return ParticleClass(self.variables + list(variable))
+
+
+def get_default_particle(spatial_dtype) -> ParticleClass:  # particle.py:123-175
+    if spatial_dtype not in (np.float32, np.float64):
+        raise ValueError(f"spatial_dtype must be np.float32 or np.float64. Got {spatial_dtype=!r}")
+    return ParticleClass(
+        [
+            Variable("t", dtype=np.float64, attrs={"standard_name": "time", "units": "seconds", "axis": "T"}),
+            Variable("z", dtype=spatial_dtype, attrs={"standard_name": "vertical coordinate", "units": "m", "positive": "down"}),
+            Variable("y", dtype=spatial_dtype, attrs={"standard_name": "latitude", "units": "degrees_north", "axis": "Y"}),
+            Variable("x", dtype=spatial_dtype, attrs={"standard_name": "longitude", "units": "degrees_east", "axis": "X"}),
+            Variable("dz", dtype=spatial_dtype, to_write=False),
+            Variable("dy", dtype=spatial_dtype, to_write=False),
+            Variable("dx", dtype=spatial_dtype, to_write=False),
+            Variable("particle_id", dtype=np.int64, attrs={"long_name": "Unique identifier for each particle", "cf_role": "trajectory_id"}),
+            Variable("dt", dtype=np.float64, initial=1.0, to_write=False),
+            Variable("state", dtype=np.int32, initial=StatusCode.Evaluate, to_write=False),
+        ]
+    )
+
+
+Particle = get_default_particle(np.float32)
+
+
+def create_particle_data(*, pclass: ParticleClass, nparticles: int, ngrids: int, initial=None) -> dict:
+    """particle.py:182-222: SoA dict of NumPy columns, ``ei`` is (n, ngrids) int32."""
+    initial = dict(initial or {})
+    variables = {v.name: v for v in pclass.variables}
+    assert "ei" not in initial, "'ei' is for internal use"
+    for name, values in initial.items():
+        if name not in variables:
+            raise ValueError(f"Variable {name} is not defined in the ParticleClass.")
+        values = np.asarray(values)
+        if values.shape != (nparticles,):
+            raise ValueError(f"Initial value for {name} must have shape ({nparticles},). Got {values.shape=}")
+        initial[name] = np.ascontiguousarray(values.astype(variables[name].dtype))
+    data = {"ei": np.zeros((nparticles, ngrids), dtype=np.int32), **initial}
+    for v in variables.values():
+        if v.name not in data:
+            data[v.name] = np.full((nparticles,), v.initial, dtype=v.dtype)
+    return data

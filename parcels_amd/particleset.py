@@ -1,0 +1,182 @@
+"""ParticleSet: SoA particle container and the outer time loop (mirrors src/parcels/_core/particleset.py)."""
+
+from __future__ import annotations
+
+import datetime
+import types
+import warnings
+
+import numpy as np
+
+from .field import to_seconds
+from .kernel import Kernel
+from .particle import Particle, create_particle_data
+
+__all__ = ["ParticleSet"]
+
+
+class ParticleSetWarning(RuntimeWarning):
+    pass
+
+
+def _convert_dt_to_float(dt):  # particleset.py:488-505
+    if isinstance(dt, (datetime.timedelta, np.timedelta64)):
+        dt = to_seconds(dt)
+    dt = float(dt)
+    if not np.isfinite(dt) or dt == 0:
+        raise ValueError(f"dt must be a non-zero finite number of seconds. Got {dt!r}")
+    return dt, (1 if dt > 0 else -1)
+
+
+class ParticleSet:
+    """Collection of particles stored as a dict of NumPy columns (particle.py:182-222).
+
+    ``seed`` keys the counter-based RNG of the stochastic kernels; ``sort_by_cell`` lets the engine reorder the
+    device copy by grid cell for gather locality (host row order is never affected)."""
+
+    def __init__(self, fieldset, pclass=Particle, *, t=None, z=None, y=None, x=None, particle_ids=None, seed=0,
+                 sort_by_cell=False, **kwargs):
+        object.__setattr__(self, "_data", None)
+        self.fieldset = fieldset
+        self._kernel = None
+        self.seed = int(seed)
+        self.sort_by_cell = bool(sort_by_cell)
+        self._last_stats = None
+        t = np.empty(shape=0) if t is None else np.array(t).flatten()
+        y = np.empty(shape=0) if y is None else np.array(y).flatten()
+        x = np.empty(shape=0) if x is None else np.array(x).flatten()
+        if particle_ids is None:
+            particle_ids = np.arange(x.size)
+        if z is None:  # particleset.py:82-93
+            minz = None
+            for field in self.fieldset.fields.values():
+                for depth in field.grid.depth:
+                    if minz is None or np.abs(depth) < np.abs(minz):
+                        minz = depth
+            z = np.ones(x.size) * minz if minz is not None else np.zeros(x.size)
+        else:
+            z = np.array(z).flatten()
+            if z.size == 1 and x.size > 1:
+                z = np.repeat(z, x.size)
+        assert x.size == y.size and x.size == z.size, "x, y, z don't all have the same lengths"
+        if t is None or len(t) == 0:
+            t = np.array(np.nan)
+        elif isinstance(t[0], np.datetime64) and self.fieldset.time_interval:
+            t = to_seconds(t - self.fieldset.time_interval.left)
+        elif isinstance(t[0], np.timedelta64):
+            t = to_seconds(t)
+        elif np.issubdtype(np.asarray(t).dtype, np.floating) or np.issubdtype(np.asarray(t).dtype, np.integer):
+            t = np.asarray(t, dtype=np.float64)  # seconds since fieldset.time_interval.left
+        else:
+            raise TypeError("particle t must be a datetime, timedelta, or float seconds")
+        t = np.repeat(t, x.size) if np.size(t) == 1 else np.asarray(t)
+        assert x.size == t.size, "t and positions (x, y, z) do not have the same lengths."
+        for kwvar in kwargs:
+            kwargs[kwvar] = np.array(kwargs[kwvar]).flatten()
+            assert x.size == kwargs[kwvar].size, f"{kwvar} and positions (x, y, z) don't have the same lengths."
+        self._data = create_particle_data(
+            pclass=pclass, nparticles=x.size, ngrids=len(fieldset.gridset),
+            initial=dict(t=t, z=z, y=y, x=x, particle_id=np.asarray(particle_ids)),
+        )
+        self._pclass = pclass
+        names = [v.name for v in pclass.variables]
+        for kwvar, kwval in kwargs.items():
+            if kwvar not in names:
+                raise RuntimeError(f"Particle class does not have Variable {kwvar}")
+            self._data[kwvar][:] = kwval
+
+    # -- container protocol (particleset.py:140-190) ---------------------------------------------------------------
+    def __getattr__(self, name):
+        data = self.__dict__.get("_data")
+        if data is not None and name in data:
+            return data[name]
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        data = self.__dict__.get("_data")
+        if name != "_data" and isinstance(data, dict) and name in data:
+            data[name][:] = value
+        else:
+            object.__setattr__(self, name, value)
+
+    def __len__(self):
+        return len(self._data["particle_id"])
+
+    @property
+    def size(self):
+        return len(self)
+
+    def remove_indices(self, indices):  # particleset.py:247-250
+        for d in self._data:
+            self._data[d] = np.delete(self._data[d], indices, axis=0)
+
+    def _engine(self):
+        return self.fieldset._engine_or_create()
+
+    def populate_indices(self):
+        """Pre-populate the ``ei`` guesses (particleset.py:252-262) with a device search."""
+        eng = self._engine()
+        for i, grid in enumerate(self.fieldset.gridset):
+            f = next(fl for fl in self.fieldset.fields.values() if getattr(fl, "grid", None) is grid and hasattr(fl, "model"))
+            eng.sample(f.name, np.zeros(len(self)), self._data["z"], self._data["y"], self._data["x"])
+            raise NotImplementedError("populate_indices: device search kernel lands with the ei-returning pk_eval")
+
+    # -- the outer time loop (particleset.py:355-470) ------------------------------------------------------------
+    def execute(self, kernels, dt, endtime=None, runtime=None, output_file=None, verbose_progress=False):
+        if len(self) == 0:
+            return
+        if isinstance(kernels, types.FunctionType):
+            kernels = [kernels]
+        self._kernel = Kernel(kernels, self)
+        dt, sign_dt = _convert_dt_to_float(dt)
+        self._data["dt"][:] = dt
+        if runtime is not None and isinstance(runtime, (datetime.timedelta, np.timedelta64)):
+            runtime = to_seconds(runtime)
+        start_time, end_time = self._start_and_end_times(runtime, endtime, sign_dt)
+        if np.isnan(self._data["t"]).any():
+            self._data["t"][:] = start_time
+        outputdt = output_file.outputdt if output_file else None
+        next_output = None
+        if output_file:
+            output_file.write(self, start_time)
+            next_output = start_time + outputdt * sign_dt
+        time = start_time
+        while sign_dt * (time - end_time) < 0:
+            if next_output is not None:
+                next_time = (min if sign_dt > 0 else max)(next_output, end_time)
+            else:
+                next_time = end_time
+            self._kernel.execute(self, endtime=next_time, dt=dt)
+            if next_output is not None and np.abs(next_time - next_output) < 0.001:
+                output_file.write(self, next_output)
+                if np.isfinite(outputdt):
+                    next_output += outputdt * sign_dt
+            time = next_time
+
+    def _start_and_end_times(self, runtime, endtime, sign_dt):  # particleset.py:523-585
+        ti = self.fieldset.time_interval
+        if runtime is not None and endtime is not None:
+            raise ValueError(f"runtime and endtime are mutually exclusive. Got {runtime=!r}, {endtime=!r}")
+        if runtime is None and ti is None:
+            raise ValueError("The runtime must be provided when the time_interval is not defined for a fieldset.")
+        if runtime is None and endtime is None:
+            raise ValueError("Either runtime or endtime must be provided.")
+        rel = self._data["t"]
+        first = np.nanmin(rel) if sign_dt == 1 and not np.all(np.isnan(rel)) else (np.nanmax(rel) if not np.all(np.isnan(rel)) else np.nan)
+        if endtime is not None:
+            if isinstance(endtime, np.datetime64) and ti is not None:
+                if not (ti.left <= endtime <= ti.right):
+                    raise ValueError(f"end time {endtime!r} is not in fieldset time interval {ti!r}")
+                endtime = to_seconds(endtime - ti.left)
+            elif isinstance(endtime, (np.timedelta64, datetime.timedelta)):
+                endtime = to_seconds(endtime)
+            else:
+                endtime = float(endtime)
+        if sign_dt == 1:
+            fieldset_start = 0.0
+        else:
+            fieldset_start = ti.time_length_as_flt if ti is not None else float(runtime)
+        start_time = first if not np.isnan(first) else fieldset_start
+        if endtime is None:
+            endtime = start_time + sign_dt * float(runtime)
+        return float(start_time), float(endtime)

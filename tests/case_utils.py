@@ -1,0 +1,187 @@
+"""Helpers shared by the parity tests: turn a neutral case dict (oracle/cases.py, tests/golden/*.npz) into
+parcels_amd objects, run it through the HIP path, and compare particle SoA dicts."""
+
+from __future__ import annotations
+
+import glob
+import os
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_names():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def load_golden(name):
+    from oracle import make_golden as mg
+
+    return mg.load_case(os.path.join(GOLDEN_DIR, name + ".npz"))
+
+
+def is_curvilinear(case):
+    return np.asarray(case["lon"]).ndim == 2
+
+
+def attach_hash_table(case):
+    """Build the spatial hash with the framework's own host builder and pin it to the reference's checksum."""
+    from parcels_amd import spatialhash as sh
+
+    h = sh.SpatialHash(case["lon"], case["lat"], case["mesh"] == "spherical")
+    if "hash_checksum" in case:
+        assert h.checksum() == case["hash_checksum"], "spatial-hash table differs from the reference's"
+    case["hash_table"] = h.table()
+    return case
+
+
+def stop_time_of_reference(case, out, err):
+    """The batch reference stops at the iteration of the first error; per-particle engines are compared there."""
+    if err is None or err == "OutsideTimeInterval" or len(out["t"]) == 0:
+        return None
+    return float(np.max(out["t"]) if case["dt"] > 0 else np.min(out["t"]))
+
+
+def build_fieldset(case):
+    import parcels_amd as pa
+
+    pad = {"low": pa.Padding.LOW, "high": pa.Padding.HIGH, "both": pa.Padding.BOTH, "none": pa.Padding.NONE}
+    depth = case.get("depth")
+    md = pa.SGrid2DMetadata(
+        node_dimensions=("XG", "YG"),
+        node_coordinates=("lon", "lat"),
+        face_dimensions=(
+            pa.FaceNodePadding("XC", "XG", pad[case.get("x_pad", "low")]),
+            pa.FaceNodePadding("YC", "YG", pad[case.get("y_pad", "low")]),
+        ),
+        vertical_dimensions=(pa.FaceNodePadding("ZC", "depth", pad[case.get("z_pad", "both")]),) if depth is not None else None,
+    )
+    lon, lat = np.asarray(case["lon"]), np.asarray(case["lat"])
+    coords = {}
+    if lon.ndim == 1:
+        coords["lon"] = (("XG",), lon)
+        coords["lat"] = (("YG",), lat)
+    else:
+        coords["lon"] = (("YG", "XG"), lon)
+        coords["lat"] = (("YG", "XG"), lat)
+    if depth is not None:
+        coords["depth"] = (("depth",), np.asarray(depth))
+    ts = case.get("time_s")
+    if ts is not None and len(ts) > 1:
+        coords["time"] = (("time",), np.asarray(ts, dtype=np.float64))
+    data_vars = {}
+    for name, arr in case["fields"].items():
+        dims = tuple(case["field_dims"][name])
+        a = np.asarray(arr)
+        keep = [i for i, d in enumerate(dims) if not d.startswith("mock")]
+        a = a.reshape([a.shape[i] for i in keep])
+        data_vars[name] = (tuple(dims[i] for i in keep), a)
+    ds = pa.Dataset(data_vars, coords, sgrid=md)
+    fs = pa.FieldSet.from_sgrid_conventions(ds, mesh=case["mesh"])
+    for name, val in (case.get("constants") or {}).items():
+        fs.add_constant_field(name, val, mesh=case.get("const_mesh", "flat"))
+    for k, v in (case.get("context") or {}).items():
+        fs.add_context(k, v)
+    return fs
+
+
+def build_pset(case, fs, **kw):
+    import parcels_amd as pa
+
+    sdt = np.dtype(case.get("spatial_dtype", "float64")).type
+    pclass = pa.get_default_particle(sdt)
+    if "AdvectionRK45" in case["kernels"]:
+        pclass = pclass.add_variable(pa.Variable("next_dt", dtype=np.float64, initial=float(case.get("next_dt0", case["dt"]))))
+    n = len(np.atleast_1d(case["x"]))
+    t0 = case.get("t0")
+    t = np.zeros(n) if t0 is None else np.broadcast_to(np.asarray(t0, dtype=np.float64), (n,)).copy()
+    return pa.ParticleSet(fs, pclass=pclass, x=np.asarray(case["x"]), y=np.asarray(case["y"]), z=case.get("z"), t=t,
+                          seed=int(case.get("seed", 0)), **kw)
+
+
+def run_hip(case, endtime=None, **pset_kw):
+    """Run a case through parcels_amd (HIP). Returns (soa dict, error name or None, stats)."""
+    import parcels_amd as pa
+
+    fs = build_fieldset(case)
+    pset = build_pset(case, fs, **pset_kw)
+    kernels = [getattr(pa.kernels, k) for k in case["kernels"]]
+    kw = {}
+    if endtime is not None:
+        kw["endtime"] = float(endtime)
+    elif case.get("endtime") is not None:
+        kw["endtime"] = float(case["endtime"])
+    else:
+        kw["runtime"] = float(case["runtime"])
+    err = None
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        try:
+            pset.execute(kernels, dt=float(case["dt"]), **kw)
+        except (pa.FieldOutOfBoundError, pa.FieldOutOfBoundSurfaceError, pa.FieldInterpolationError, pa.GridSearchingError,
+                pa.OutsideTimeInterval, pa.GeneralError) as e:
+            err = type(e).__name__
+    return {k: np.array(v) for k, v in pset._data.items()}, err, pset._last_stats
+
+
+def run_oracle(case, endtime=None, nthreads=1):
+    from oracle import c_oracle as co
+
+    c = dict(case)
+    if endtime is not None:
+        c["endtime"] = float(endtime)
+        c["runtime"] = None
+    if is_curvilinear(c) and "hash_table" not in c:
+        attach_hash_table(c)
+    return co.run_case(c, nthreads=nthreads)
+
+
+def max_rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if a.size == 0:
+        return 0.0
+    d = np.abs(a - b)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        r = np.where(d == 0, 0.0, d / np.maximum(np.abs(b), 1e-300))
+    return float(np.nanmax(r))
+
+
+def compare(got, ref, *, rtol, atol_pos=0.0, check_state="all", err_mask=None, skip=("dt",), label=""):
+    """Compare two particle SoA dicts. Positions to rtol (relative to |ref|) or atol_pos; t, ei, ids exactly."""
+    assert len(got["x"]) == len(ref["x"]), f"{label}: particle count {len(got['x'])} != {len(ref['x'])}"
+    assert np.array_equal(got["particle_id"], ref["particle_id"]), f"{label}: particle order differs"
+    report = {}
+    for k in ("x", "y", "z", "dx", "dy", "dz", "next_dt", "dt"):
+        if k in skip or k not in ref or k not in got:
+            continue
+        a, b = np.asarray(got[k], dtype=np.float64), np.asarray(ref[k], dtype=np.float64)
+        ok = np.isclose(a, b, rtol=rtol, atol=atol_pos, equal_nan=True)
+        report[k] = max_rel(a, b)
+        assert ok.all(), f"{label}: {k} differs: max rel {report[k]:.3e} (rtol {rtol:g}) at {np.flatnonzero(~ok)[:5]}"
+    assert np.array_equal(got["t"], ref["t"]), f"{label}: t differs"
+    if check_state == "all":
+        assert np.array_equal(got["state"], ref["state"]), f"{label}: state differs: {np.flatnonzero(got['state'] != ref['state'])[:8]}"
+    elif check_state == "errors":
+        m = ref["state"] >= 50 if err_mask is None else err_mask
+        assert np.array_equal(got["state"][m], ref["state"][m]), f"{label}: error states differ"
+    assert np.array_equal(got["ei"], ref["ei"]), f"{label}: ei differs at {np.flatnonzero((got['ei'] != ref['ei']).any(axis=1))[:8]}"
+    return report
+
+
+# tolerance class of every golden case (see DESIGN.md "Parity")
+def tolerance_for(name, case):
+    f32_part = case.get("spatial_dtype", "float64") == "float32"
+    f32_coord = np.asarray(case["lon"]).dtype == np.float32
+    if f32_part and f32_coord:
+        return 2e-6  # NumPy keeps f32 x f32 interpolation weights in f32 for the first RK stage; not emulated
+    if f32_part:
+        return 5e-7  # one float32 ulp of the stored position (float32 cos() of the first stage differs by <= 1 ulp)
+    if is_curvilinear(case) and not case.get("populate"):
+        return 1e-7  # the reference's unguessed first evaluation carries float32 weights (spatialhash.py:505)
+    if any(k.startswith("AdvectionDiffusion") or k == "DiffusionUniformKh" for k in case["kernels"]):
+        return 1e-11  # log/sin/cos of the Box-Muller transform differ by an ulp between libm implementations
+    return 1e-12

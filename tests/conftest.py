@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+
+
+def _gpu_available() -> bool:
+    try:
+        import torch
+
+        return bool(torch.cuda.is_available())
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    if not _gpu_available():
+        pytest.skip("no GPU visible")
+    return 0

@@ -1,0 +1,155 @@
+"""CPU: host-side logic of parcels_amd (no GPU, no compute calls)."""
+
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import parcels_amd as pa
+from case_utils import build_fieldset, build_pset, golden_names, is_curvilinear, load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from parcels_amd import _hip
+
+    lib = _hip.load()
+    header = open(os.path.join(ROOT, "include", "parcels_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(pk_[a-z0-9_]+)\s*\(", header)))
+    assert declared, "no declarations found in include/parcels_hip.h"
+    assert sorted(_hip.ABI_SYMBOLS) == declared
+    for sym in declared:
+        assert hasattr(lib, sym), f"libparcels_hip.so does not export {sym}"
+    assert lib.pk_abi_version() == 1
+
+
+def test_ctypes_structs_match_header_layout():
+    from parcels_amd import _hip
+
+    # sizes computed from the C declarations (all members naturally aligned)
+    assert C.sizeof(_hip.GridDesc) == 18 * 4 + 8 + 7 * 8 + 2 * 8 + 2 * 4 + 6 * 8
+    assert C.sizeof(_hip.FieldDesc) == 14 * 4 + 8
+    assert C.sizeof(_hip.ParticlesDesc) == 8 + 2 * 4 + 12 * 8
+    assert C.sizeof(_hip.ExecParams) == (1 + 8 + 11) * 4 + 6 * 8 + 8
+    assert C.sizeof(_hip.ExecStats) == 3 * 8 + 80 * 8 + 4 * 8 + 2 * 4
+
+
+def test_no_gpu_fails_loudly():
+    """The product path has no CPU fallback: without a device the engine must raise, not compute."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    case, _, _ = load_golden("agrid_flat_rk4_f64")
+    fs = build_fieldset(case)
+    pset = build_pset(case, fs)
+    with pytest.raises(pa._hip.HipLibraryError):
+        pset.execute(pa.AdvectionRK4, dt=3600.0, runtime=3600.0)
+
+
+def test_python_kernels_are_rejected():
+    case, _, _ = load_golden("agrid_flat_rk4_f64")
+    fs = build_fieldset(case)
+    pset = build_pset(case, fs)
+
+    def MyKernel(particles, fieldset):
+        particles.dx += 1
+
+    with pytest.raises(NotImplementedError):
+        pset.execute([pa.AdvectionRK4, MyKernel], dt=3600.0, runtime=3600.0)
+
+    def BadSignature(p):
+        pass
+
+    with pytest.raises(ValueError):
+        pset.execute(BadSignature, dt=3600.0, runtime=3600.0)
+    with pytest.raises(RuntimeError):
+        pa.AdvectionRK4(None, None)  # device kernels cannot run on the host
+
+
+@pytest.mark.parametrize("name", ["agrid_sph_rk4_3d_f64", "cgrid_rect_sph_rk4_3d", "peninsula_C_flat", "cgrid_curv_flat_rk4", "diff_uniform_sph"])
+def test_grid_metadata_matches_oracle_marshalling(name):
+    """axes / ravel dims / C-grid offsets derived by XGrid agree with the oracle's independent derivation."""
+    from oracle import c_oracle as co
+
+    case, _, _ = load_golden(name)
+    fs = build_fieldset(case)
+    g = fs.gridset[0]
+    meta = co.grid_meta(case)
+    assert [int(a in g.axes) for a in "XYZ"] == [meta["has_x"], meta["has_y"], meta["has_z"]]
+    for ax in g.axes:
+        assert g.get_axis_dim(ax) == meta[ax.lower() + "dim"]
+    off = g.offsets()
+    assert (off["X"], off["Y"]) == (meta["off_x"], meta["off_y"])
+    if "Z" in g.axes:
+        assert off["Z"] == meta["off_z"]
+    assert g.is_curvilinear == is_curvilinear(case)
+    uv = fs.UV
+    assert isinstance(uv.interp_method, pa.CGrid_Velocity if case.get("cgrid") else pa.XLinear_Velocity)
+    assert len(fs.gridset) == (2 if case.get("constants") else 1)
+
+
+def test_tzyx_transposition_and_nan_fill():
+    from parcels_amd.field import transpose_to_tzyx
+
+    md = pa.SGrid2DMetadata(node_dimensions=("XG", "YG"),
+                            face_dimensions=(pa.FaceNodePadding("XC", "XG", pa.Padding.LOW), pa.FaceNodePadding("YC", "YG", pa.Padding.LOW)),
+                            vertical_dimensions=(pa.FaceNodePadding("ZC", "depth", pa.Padding.BOTH),))
+    a = np.arange(2 * 3 * 4.0).reshape(4, 3, 2)  # (XG, YG, time)
+    da = transpose_to_tzyx(pa.DataArray(("XG", "YG", "time"), a), md)
+    assert da.dims == ("time", "mockZ", "YG", "XG") and da.shape == (2, 1, 3, 4)
+    assert da.data[1, 0, 2, 3] == a[3, 2, 1]
+    u = np.ones((3, 4))
+    u[1, 1] = np.nan
+    ds = pa.Dataset({"U": (("YG", "XG"), u), "V": (("YG", "XG"), np.ones((3, 4)))},
+                    {"lon": (("XG",), np.arange(4.0)), "lat": (("YG",), np.arange(3.0))}, sgrid=md)
+    fs = pa.FieldSet.from_sgrid_conventions(ds, mesh="flat")
+    assert fs.U.data.data[0, 0, 1, 1] == 0.0  # model.py:135-143 fillna(0)
+    assert fs.time_interval is None
+    with pytest.raises(AttributeError):
+        fs.nonexistent
+    fs.add_context("dres", 0.1)
+    assert fs.dres == 0.1
+    with pytest.raises(AttributeError):
+        fs.dres = 3
+
+
+def test_rk45_context_defaults_follow_reference():
+    """kernel.py:134-159: defaults are installed on Kernel construction, tol divided by deg2m on a spherical mesh."""
+    case, _, _ = load_golden("agrid_sph_rk45")
+    fs = build_fieldset(case)
+    pset = build_pset(case, fs)
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pa.Kernel([pa.AdvectionRK45], pset)
+    assert fs.RK45_min_dt == 1 and fs.RK45_max_dt == 86400
+    assert fs.RK45_tol == pytest.approx(10 / (6366707.019493707 * np.pi / 180))
+    pclass = pa.get_default_particle(np.float64)
+    p2 = pa.ParticleSet(fs, pclass=pclass, x=[1.0], y=[1.0], z=[1.0], t=[0.0])
+    with pytest.raises(ValueError):
+        pa.Kernel([pa.AdvectionRK45], p2)  # needs next_dt
+
+
+def test_default_particle_schema():
+    p = pa.Particle
+    d = {v.name: v for v in p.variables}
+    assert d["x"].dtype == np.float32 and d["t"].dtype == np.float64 and d["state"].dtype == np.int32
+    assert d["dt"].initial == 1.0 and d["state"].initial == pa.StatusCode.Evaluate
+    assert [v.name for v in p.variables if not v.to_write] == ["dz", "dy", "dx", "dt", "state"]
+
+
+def test_spatial_hash_build_pinned_to_reference():
+    from case_utils import attach_hash_table
+
+    for name in golden_names():
+        case, _, _ = load_golden(name)
+        if is_curvilinear(case) and "hash_checksum" in case:
+            attach_hash_table(case)  # asserts the SHA-256 of keys/starts/counts/faces and bitwidth/bbox
+            break
+    else:
+        pytest.fail("no curvilinear fixture")
