@@ -198,6 +198,10 @@ int32_t pk_execute(pk_ctx* ctx, const pk_exec_params* params, pk_exec_stats* sta
 int32_t pk_eval(pk_ctx* ctx, const pk_exec_params* params, int32_t what, int64_t m, const double* t, const double* z,
                 const double* y, const double* x, double* out_u, double* out_v, double* out_w, int32_t* out_state);
 
+/* XGrid.search + ravel_index with no guess: ei_out[i] = ravel(search(z, y, x)) on grid `grid_id`
+ * (ParticleSet.populate_indices, particleset.py:252-262).  Host arrays of length m. */
+int32_t pk_search(pk_ctx* ctx, int32_t grid_id, int64_t m, const double* z, const double* y, const double* x, int32_t* ei_out);
+
 /* achieved copy bandwidth probe (device-to-device float4 copy), GB/s; used as a measured roofline denominator */
 int32_t pk_measure_copy_bandwidth(pk_ctx* ctx, int64_t bytes, int32_t iters, double* gbps);
 

@@ -168,6 +168,7 @@ ABI_SYMBOLS = [
     "pk_particles_device",
     "pk_execute",
     "pk_eval",
+    "pk_search",
     "pk_measure_copy_bandwidth",
 ]
 
@@ -213,6 +214,7 @@ def load():
     lib.pk_particles_device.argtypes = [C.c_void_p, C.POINTER(ParticlesDesc), C.POINTER(C.c_void_p)]
     lib.pk_execute.argtypes = [C.c_void_p, C.POINTER(ExecParams), C.POINTER(ExecStats)]
     lib.pk_eval.argtypes = [C.c_void_p, C.POINTER(ExecParams), C.c_int32, C.c_int64] + [C.c_void_p] * 8
+    lib.pk_search.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pk_measure_copy_bandwidth.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_double)]
     if lib.pk_abi_version() != 1:
         raise HipLibraryError(f"ABI version mismatch: library {lib.pk_abi_version()}, binding 1")

@@ -12,6 +12,8 @@
 #include <string>
 #include <vector>
 
+#include <rocprim/rocprim.hpp>
+
 #include "pk_kernels.h"
 
 using namespace pk;
@@ -51,7 +53,14 @@ struct pk_ctx {
     int64_t capacity = 0;
     bool bound = false;
     // sorted-order bookkeeping
-    int64_t* d_perm = nullptr;  // device row -> original row (nullptr: identity)
+    int64_t* d_perm = nullptr;      // device row -> host row (valid when has_perm)
+    bool has_perm = false;
+    int64_t* d_perm_alt = nullptr;
+    DParticles alt{};               // second set of columns (ping-pong target of the cell sort, staging of d2h)
+    unsigned long long *d_keys = nullptr, *d_keys_alt = nullptr;
+    uint32_t *d_idx = nullptr, *d_idx_alt = nullptr;
+    void* d_sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
     // scratch
     DCounters* d_counters = nullptr;
     unsigned long long* d_summary = nullptr;  // PK_NUM_STATE_CODES counts + 2 ordered-double slots
@@ -140,6 +149,67 @@ __global__ void __launch_bounds__(256) eval_kernel(const KArgs a, int what, int6
     if (ost) ost[i] = c.state;
 }
 
+// XGrid.search + ravel_index without a guess (ParticleSet.populate_indices, particleset.py:252-262)
+__global__ void __launch_bounds__(256) search_kernel(const DGrid g, int64_t m, const double* z, const double* y, const double* x,
+                                                     int32_t* ei_out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    PCtx c;
+    c.state = PK_EVALUATE;
+    c.pf = false;
+    c.hz = c.hy = c.hx = c.ht = 0;
+    GPos p;
+    int32_t ei = 0;
+    grid_search<-1>(g, nullptr, z[i], y[i], x[i], false, &ei, c, false, p);
+    ei_out[i] = ei;
+}
+
+// ---- cell sort ----------------------------------------------------------------------------------------
+// key = linear cell index of the particle's current position on the main grid (z-major like the field layout),
+// so that the 64 lanes of a wavefront gather from neighbouring cells (coalesced, L2-friendly).
+__global__ void __launch_bounds__(256) sort_key_kernel(const DGrid g, const DParticles P, unsigned long long* keys, uint32_t* idx) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P.n) return;
+    const bool pf = P.spatial_f32 != 0;
+    const double z = pf ? (double)((const float*)P.z)[i] : ((const double*)P.z)[i];
+    const double y = pf ? (double)((const float*)P.y)[i] : ((const double*)P.y)[i];
+    const double x = pf ? (double)((const float*)P.x)[i] : ((const double*)P.x)[i];
+    unsigned long long zi = 0, h = 0;
+    if (g.has_z && g.nz >= 2) zi = (unsigned long long)cell_index(g.depth, g.nz, z, 0);
+    if (g.kind == 1) {
+        h = morton_code(g, y, x);  // 30-bit Morton code of the hash grid: neighbouring codes = neighbouring cells
+        keys[i] = (zi << 30) | h;
+    } else {
+        unsigned long long yi = (g.has_y && g.ny >= 2) ? (unsigned long long)cell_index(g.lat, g.ny, y, 0) : 0;
+        unsigned long long xi = (g.has_x && g.nx >= 2) ? (unsigned long long)cell_index(g.lon, g.nx, x, 0) : 0;
+        keys[i] = (zi * (unsigned long long)g.ny + yi) * (unsigned long long)g.nx + xi;
+    }
+    idx[i] = (uint32_t)i;
+}
+
+template <class T>
+__global__ void __launch_bounds__(256) gather_rows_kernel(const T* __restrict__ in, T* __restrict__ out,
+                                                          const uint32_t* __restrict__ perm, int64_t n, int width) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t src = perm[i];
+    for (int k = 0; k < width; k++) out[i * width + k] = in[src * width + k];
+}
+template <class T>
+__global__ void __launch_bounds__(256) scatter_rows_kernel(const T* __restrict__ in, T* __restrict__ out,
+                                                           const int64_t* __restrict__ perm, int64_t n, int width) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t dst = perm[i];
+    for (int k = 0; k < width; k++) out[dst * width + k] = in[i * width + k];
+}
+__global__ void __launch_bounds__(256) compose_perm_kernel(const int64_t* __restrict__ old_perm, const uint32_t* __restrict__ perm,
+                                                           int64_t* __restrict__ new_perm, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    new_perm[i] = old_perm ? old_perm[perm[i]] : (int64_t)perm[i];
+}
+
 __global__ void __launch_bounds__(256) copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
 }
@@ -202,9 +272,18 @@ static void free_particles(pk_ctx* ctx) {
                     ctx->dev.dx, ctx->dev.dt, ctx->dev.next_dt, ctx->dev.state, ctx->dev.ei, ctx->dev.particle_id};
     for (void* p : cols)
         if (p) (void)hipFree(p);
-    if (ctx->d_perm) (void)hipFree(ctx->d_perm);
-    ctx->d_perm = nullptr;
+    void* alts[] = {ctx->alt.t,  ctx->alt.z,  ctx->alt.y,       ctx->alt.x,     ctx->alt.dz, ctx->alt.dy,
+                    ctx->alt.dx, ctx->alt.dt, ctx->alt.next_dt, ctx->alt.state, ctx->alt.ei, ctx->alt.particle_id,
+                    ctx->d_perm, ctx->d_perm_alt, ctx->d_keys, ctx->d_keys_alt, ctx->d_idx, ctx->d_idx_alt, ctx->d_sort_tmp};
+    for (void* p : alts)
+        if (p) (void)hipFree(p);
+    ctx->d_perm = ctx->d_perm_alt = nullptr;
+    ctx->d_keys = ctx->d_keys_alt = nullptr;
+    ctx->d_idx = ctx->d_idx_alt = nullptr;
+    ctx->d_sort_tmp = nullptr;
+    ctx->sort_tmp_bytes = 0;
     ctx->dev = DParticles{};
+    ctx->alt = DParticles{};
     ctx->capacity = 0;
 }
 
@@ -430,10 +509,120 @@ int32_t pk_particles_bind(pk_ctx* ctx, const pk_particles_desc* host) {
         PK_HIP(ctx, hipMalloc((void**)&ctx->dev.particle_id, cap * 8));
         ctx->capacity = cap;
     }
+    ctx->has_perm = false;
     ctx->dev.n = host->n;
     ctx->dev.ngrids = host->ngrids;
     ctx->dev.spatial_f32 = host->spatial_dtype == PK_F32;
     ctx->bound = true;
+    return 0;
+}
+
+}  // extern "C" (helpers with C++ linkage follow)
+
+struct ColRef {
+    void* h;
+    void* d;
+    void* a;  // alt/staging device column
+    size_t elem;
+    int width;
+};
+
+static std::vector<ColRef> particle_columns(pk_ctx* ctx) {
+    const size_t ss = spatial_size(ctx);
+    const int ng = ctx->host.ngrids;
+    return {
+        {ctx->host.t, ctx->dev.t, ctx->alt.t, 8, 1},          {ctx->host.z, ctx->dev.z, ctx->alt.z, ss, 1},
+        {ctx->host.y, ctx->dev.y, ctx->alt.y, ss, 1},          {ctx->host.x, ctx->dev.x, ctx->alt.x, ss, 1},
+        {ctx->host.dz, ctx->dev.dz, ctx->alt.dz, ss, 1},       {ctx->host.dy, ctx->dev.dy, ctx->alt.dy, ss, 1},
+        {ctx->host.dx, ctx->dev.dx, ctx->alt.dx, ss, 1},       {ctx->host.dt, ctx->dev.dt, ctx->alt.dt, 8, 1},
+        {ctx->host.next_dt, ctx->dev.next_dt, ctx->alt.next_dt, 8, 1},
+        {ctx->host.state, ctx->dev.state, ctx->alt.state, 4, 1},
+        {ctx->host.ei, ctx->dev.ei, ctx->alt.ei, 4, ng},
+        {ctx->host.particle_id, ctx->dev.particle_id, ctx->alt.particle_id, 8, 1},
+    };
+}
+
+// second column set + permutation buffers, allocated on first use (only when cell sorting is requested)
+static int32_t ensure_alt(pk_ctx* ctx) {
+    if (ctx->alt.t) return 0;
+    const int64_t cap = ctx->capacity;
+    const size_t ss = spatial_size(ctx);
+    PK_HIP(ctx, hipMalloc((void**)&ctx->alt.t, cap * 8));
+    PK_HIP(ctx, hipMalloc(&ctx->alt.z, cap * ss));
+    PK_HIP(ctx, hipMalloc(&ctx->alt.y, cap * ss));
+    PK_HIP(ctx, hipMalloc(&ctx->alt.x, cap * ss));
+    PK_HIP(ctx, hipMalloc(&ctx->alt.dz, cap * ss));
+    PK_HIP(ctx, hipMalloc(&ctx->alt.dy, cap * ss));
+    PK_HIP(ctx, hipMalloc(&ctx->alt.dx, cap * ss));
+    PK_HIP(ctx, hipMalloc((void**)&ctx->alt.dt, cap * 8));
+    if (ctx->dev.next_dt) PK_HIP(ctx, hipMalloc((void**)&ctx->alt.next_dt, cap * 8));
+    PK_HIP(ctx, hipMalloc((void**)&ctx->alt.state, cap * 4));
+    PK_HIP(ctx, hipMalloc((void**)&ctx->alt.ei, cap * 4 * ctx->host.ngrids));
+    PK_HIP(ctx, hipMalloc((void**)&ctx->alt.particle_id, cap * 8));
+    PK_HIP(ctx, hipMalloc((void**)&ctx->d_perm, cap * 8));
+    PK_HIP(ctx, hipMalloc((void**)&ctx->d_perm_alt, cap * 8));
+    PK_HIP(ctx, hipMalloc((void**)&ctx->d_keys, cap * 8));
+    PK_HIP(ctx, hipMalloc((void**)&ctx->d_keys_alt, cap * 8));
+    PK_HIP(ctx, hipMalloc((void**)&ctx->d_idx, cap * 4));
+    PK_HIP(ctx, hipMalloc((void**)&ctx->d_idx_alt, cap * 4));
+    return 0;
+}
+
+template <class T>
+static void launch_gather(pk_ctx* ctx, const void* in, void* out, const uint32_t* perm, int64_t n, int width) {
+    hipLaunchKernelGGL((gather_rows_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->compute, (const T*)in, (T*)out, perm, n, width);
+}
+template <class T>
+static void launch_scatter(pk_ctx* ctx, const void* in, void* out, const int64_t* perm, int64_t n, int width) {
+    hipLaunchKernelGGL((scatter_rows_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->compute, (const T*)in, (T*)out, perm, n, width);
+}
+
+static int bits_for(unsigned long long v) {
+    int b = 1;
+    while (b < 64 && (v >> b)) b++;
+    return b;
+}
+
+// Reorder the device rows by cell key (host row order is restored by pk_particles_d2h through d_perm).
+static int32_t sort_particles(pk_ctx* ctx, int main_grid) {
+    const int64_t n = ctx->dev.n;
+    if (n < 2) return 0;
+    if (n >= (1ll << 32)) return ctx->fail("cell sort supports < 2^32 particles per device");
+    int32_t rc = ensure_alt(ctx);
+    if (rc) return rc;
+    const DGrid& g = ctx->grids[main_grid].d;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    hipLaunchKernelGGL(sort_key_kernel, grid, dim3(256), 0, ctx->compute, g, ctx->dev, ctx->d_keys, ctx->d_idx);
+    PK_HIP(ctx, hipGetLastError());
+    unsigned long long kmax;
+    const unsigned long long nzc = (g.has_z && g.nz >= 2) ? (unsigned long long)g.nz : 1ull;
+    if (g.kind == 1) kmax = (nzc << 30) | 0x3FFFFFFFull;
+    else kmax = nzc * (unsigned long long)std::max(g.ny, 1) * (unsigned long long)std::max(g.nx, 1);
+    const unsigned end_bit = (unsigned)bits_for(kmax);
+    size_t tmp_bytes = 0;
+    PK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, ctx->d_keys, ctx->d_keys_alt, ctx->d_idx, ctx->d_idx_alt, (size_t)n, 0u, end_bit, ctx->compute));
+    if (tmp_bytes > ctx->sort_tmp_bytes) {
+        if (ctx->d_sort_tmp) PK_HIP(ctx, hipFree(ctx->d_sort_tmp));
+        PK_HIP(ctx, hipMalloc(&ctx->d_sort_tmp, tmp_bytes));
+        ctx->sort_tmp_bytes = tmp_bytes;
+    }
+    PK_HIP(ctx, rocprim::radix_sort_pairs(ctx->d_sort_tmp, tmp_bytes, ctx->d_keys, ctx->d_keys_alt, ctx->d_idx, ctx->d_idx_alt, (size_t)n, 0u, end_bit, ctx->compute));
+    const uint32_t* perm = ctx->d_idx_alt;
+    for (const ColRef& c : particle_columns(ctx)) {
+        if (!c.d || !c.a) continue;
+        if (c.elem == 8) launch_gather<unsigned long long>(ctx, c.d, c.a, perm, n, c.width);
+        else launch_gather<uint32_t>(ctx, c.d, c.a, perm, n, c.width);
+    }
+    hipLaunchKernelGGL(compose_perm_kernel, grid, dim3(256), 0, ctx->compute, ctx->has_perm ? ctx->d_perm : nullptr, perm, ctx->d_perm_alt, n);
+    PK_HIP(ctx, hipGetLastError());
+    // swap column sets (sizes/flags stay)
+    DParticles d = ctx->dev, a = ctx->alt;
+    ctx->dev.t = a.t; ctx->dev.z = a.z; ctx->dev.y = a.y; ctx->dev.x = a.x; ctx->dev.dz = a.dz; ctx->dev.dy = a.dy; ctx->dev.dx = a.dx;
+    ctx->dev.dt = a.dt; ctx->dev.next_dt = a.next_dt; ctx->dev.state = a.state; ctx->dev.ei = a.ei; ctx->dev.particle_id = a.particle_id;
+    ctx->alt.t = d.t; ctx->alt.z = d.z; ctx->alt.y = d.y; ctx->alt.x = d.x; ctx->alt.dz = d.dz; ctx->alt.dy = d.dy; ctx->alt.dx = d.dx;
+    ctx->alt.dt = d.dt; ctx->alt.next_dt = d.next_dt; ctx->alt.state = d.state; ctx->alt.ei = d.ei; ctx->alt.particle_id = d.particle_id;
+    std::swap(ctx->d_perm, ctx->d_perm_alt);
+    ctx->has_perm = true;
     return 0;
 }
 
@@ -442,25 +631,25 @@ static int32_t copy_particles(pk_ctx* ctx, bool to_device) {
     PK_HIP(ctx, hipSetDevice(ctx->device));
     const int64_t n = ctx->host.n;
     if (n == 0) return 0;
-    const size_t ss = spatial_size(ctx);
-    struct Col { void* h; void* d; size_t bytes; };
-    const Col cols[] = {
-        {ctx->host.t, ctx->dev.t, (size_t)n * 8},         {ctx->host.z, ctx->dev.z, (size_t)n * ss},
-        {ctx->host.y, ctx->dev.y, (size_t)n * ss},        {ctx->host.x, ctx->dev.x, (size_t)n * ss},
-        {ctx->host.dz, ctx->dev.dz, (size_t)n * ss},      {ctx->host.dy, ctx->dev.dy, (size_t)n * ss},
-        {ctx->host.dx, ctx->dev.dx, (size_t)n * ss},      {ctx->host.dt, ctx->dev.dt, (size_t)n * 8},
-        {ctx->host.next_dt, ctx->dev.next_dt, (size_t)n * 8}, {ctx->host.state, ctx->dev.state, (size_t)n * 4},
-        {ctx->host.ei, ctx->dev.ei, (size_t)n * 4 * ctx->host.ngrids},
-        {ctx->host.particle_id, ctx->dev.particle_id, (size_t)n * 8},
-    };
-    for (const Col& c : cols) {
+    if (to_device) ctx->has_perm = false;  // host order
+    for (const ColRef& c : particle_columns(ctx)) {
         if (!c.h || !c.d) continue;
-        if (to_device) PK_HIP(ctx, hipMemcpyAsync(c.d, c.h, c.bytes, hipMemcpyHostToDevice, ctx->compute));
-        else PK_HIP(ctx, hipMemcpyAsync(c.h, c.d, c.bytes, hipMemcpyDeviceToHost, ctx->compute));
+        const size_t bytes = (size_t)n * c.elem * c.width;
+        if (to_device) {
+            PK_HIP(ctx, hipMemcpyAsync(c.d, c.h, bytes, hipMemcpyHostToDevice, ctx->compute));
+        } else if (ctx->has_perm) {  // undo the cell sort: host row perm[i] <- device row i
+            if (c.elem == 8) launch_scatter<unsigned long long>(ctx, c.d, c.a, ctx->d_perm, n, c.width);
+            else launch_scatter<uint32_t>(ctx, c.d, c.a, ctx->d_perm, n, c.width);
+            PK_HIP(ctx, hipMemcpyAsync(c.h, c.a, bytes, hipMemcpyDeviceToHost, ctx->compute));
+        } else {
+            PK_HIP(ctx, hipMemcpyAsync(c.h, c.d, bytes, hipMemcpyDeviceToHost, ctx->compute));
+        }
     }
     PK_HIP(ctx, hipStreamSynchronize(ctx->compute));
     return 0;
 }
+
+extern "C" {
 
 int32_t pk_particles_h2d(pk_ctx* ctx) {
     if (!ctx) return -2;
@@ -485,7 +674,7 @@ int32_t pk_particles_device(pk_ctx* ctx, pk_particles_desc* dev, int64_t** perm)
     dev->state = ctx->dev.state;
     dev->ei = ctx->dev.ei;
     dev->particle_id = ctx->dev.particle_id;
-    if (perm) *perm = ctx->d_perm;
+    if (perm) *perm = ctx->has_perm ? ctx->d_perm : nullptr;
     return 0;
 }
 
@@ -567,12 +756,20 @@ int32_t pk_execute(pk_ctx* ctx, const pk_exec_params* prm, pk_exec_stats* stats)
     const unsigned long long init_mm[2] = {~0ull, 0ull};
     PK_HIP(ctx, hipMemcpyAsync(ctx->d_summary + PK_NUM_STATE_CODES, init_mm, sizeof(init_mm), hipMemcpyHostToDevice, ctx->compute));
     int launches = 0;
+    bool sorted = false;
     if (n > 0) {
         const dim3 grid((unsigned)((n + 255) / 256));
         int prog = PROG_GENERIC;
         if (prm->nk == 1 && use_lds) {
             if (prm->kernels[0] == PK_KERNEL_ADVECTION_RK4) prog = PROG_RK4;
             if (prm->kernels[0] == PK_KERNEL_ADVECTION_RK4_3D) prog = PROG_RK4_3D;
+        }
+        if (prm->sort_by_cell) {
+            PK_HIP(ctx, hipEventRecord(ctx->ev2, ctx->compute));
+            rc = sort_particles(ctx, a.main_grid);
+            if (rc) return rc;
+            a.p = ctx->dev;  // the column pointers were swapped
+            sorted = true;
         }
         PK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->compute));
         switch (prog) {
@@ -609,7 +806,9 @@ int32_t pk_execute(pk_ctx* ctx, const pk_exec_params* prm, pk_exec_stats* stats)
         float ms = 0.f;
         if (launches) PK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
         stats->kernel_ms = ms;
-        stats->sort_ms = 0.0;
+        float sms = 0.f;
+        if (sorted) PK_HIP(ctx, hipEventElapsedTime(&sms, ctx->ev2, ctx->ev0));
+        stats->sort_ms = sms;
         stats->launches = launches;
     }
     return 0;
@@ -665,6 +864,27 @@ int32_t pk_eval(pk_ctx* ctx, const pk_exec_params* prm, int32_t what, int64_t m,
     PK_HIP(ctx, hipStreamSynchronize(ctx->compute));
     PK_HIP(ctx, hipFree(d));
     PK_HIP(ctx, hipFree(ds));
+    return 0;
+}
+
+int32_t pk_search(pk_ctx* ctx, int32_t grid_id, int64_t m, const double* z, const double* y, const double* x, int32_t* ei_out) {
+    if (!ctx || !z || !y || !x || !ei_out) return -2;
+    if (grid_id < 0 || grid_id >= (int)ctx->grids.size()) return ctx->fail("unknown grid id");
+    PK_HIP(ctx, hipSetDevice(ctx->device));
+    if (m <= 0) return 0;
+    double* d = nullptr;
+    int32_t* de = nullptr;
+    PK_HIP(ctx, hipMalloc((void**)&d, sizeof(double) * m * 3));
+    PK_HIP(ctx, hipMalloc((void**)&de, sizeof(int32_t) * m));
+    PK_HIP(ctx, hipMemcpyAsync(d, z, sizeof(double) * m, hipMemcpyHostToDevice, ctx->compute));
+    PK_HIP(ctx, hipMemcpyAsync(d + m, y, sizeof(double) * m, hipMemcpyHostToDevice, ctx->compute));
+    PK_HIP(ctx, hipMemcpyAsync(d + 2 * m, x, sizeof(double) * m, hipMemcpyHostToDevice, ctx->compute));
+    hipLaunchKernelGGL(search_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->compute, ctx->grids[grid_id].d, m, d, d + m, d + 2 * m, de);
+    PK_HIP(ctx, hipGetLastError());
+    PK_HIP(ctx, hipMemcpyAsync(ei_out, de, sizeof(int32_t) * m, hipMemcpyDeviceToHost, ctx->compute));
+    PK_HIP(ctx, hipStreamSynchronize(ctx->compute));
+    PK_HIP(ctx, hipFree(d));
+    PK_HIP(ctx, hipFree(de));
     return 0;
 }
 

@@ -347,6 +347,16 @@ class DeviceEngine:
         return u, v, w
 
 
+def _engine_search(self, igrid, z, y, x):
+    z, y, x = (np.ascontiguousarray(np.atleast_1d(v), dtype=np.float64) for v in (z, y, x))
+    ei = np.zeros(x.shape[0], np.int32)
+    self.ctx.check(self.lib.pk_search(self.ctx.handle, int(self.grid_ids[igrid]), x.shape[0], _ptr(z), _ptr(y), _ptr(x), _ptr(ei)), "pk_search")
+    return ei
+
+
+DeviceEngine.search = _engine_search
+
+
 def raise_particle_errors(data: dict):
     """kernel.py:236-245: raise for the first error code present, in ErrorsToThrow order."""
     from .statuscodes import ErrorsToThrow

@@ -114,12 +114,10 @@ class ParticleSet:
         return self.fieldset._engine_or_create()
 
     def populate_indices(self):
-        """Pre-populate the ``ei`` guesses (particleset.py:252-262) with a device search."""
+        """Pre-populate the ``ei`` guesses (particleset.py:252-262) with a device search (pk_search)."""
         eng = self._engine()
-        for i, grid in enumerate(self.fieldset.gridset):
-            f = next(fl for fl in self.fieldset.fields.values() if getattr(fl, "grid", None) is grid and hasattr(fl, "model"))
-            eng.sample(f.name, np.zeros(len(self)), self._data["z"], self._data["y"], self._data["x"])
-            raise NotImplementedError("populate_indices: device search kernel lands with the ei-returning pk_eval")
+        for i in range(len(self.fieldset.gridset)):
+            self._data["ei"][:, i] = eng.search(i, self._data["z"], self._data["y"], self._data["x"])
 
     # -- the outer time loop (particleset.py:355-470) ------------------------------------------------------------
     def execute(self, kernels, dt, endtime=None, runtime=None, output_file=None, verbose_progress=False):

@@ -117,6 +117,8 @@ def run_hip(case, endtime=None, **pset_kw):
     err = None
     import warnings
 
+    if case.get("populate"):
+        pset.populate_indices()
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         try:
