@@ -128,6 +128,9 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    # measured device-to-device copy bandwidth: the practical HBM ceiling used as a second roofline denominator
+    copy_gbps = eng.ctx.copy_bandwidth(1 << 30, 5) if rank == 0 else 0.0
+
     # warmup: W steps (also pays the one-off cell sort)
     if W > 0:
         eng.execute(kern.kernel_ids, endtime=W * dt, dt0=dt, sort_by_cell=int(args.sort), t_start=0.0)
@@ -176,8 +179,19 @@ def main():
                        "all_states_endofloop": ok},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": None, "kernel": "advect_kernel<double,0,0,RK4,lds>", "kernel_ms_per_launch": float(kms.item()),
-                         "algorithmic_bytes_per_particle_step": ALGO_BYTES_PER_STEP_C2_RK4},
+                         "algorithmic_bytes_per_particle_step": ALGO_BYTES_PER_STEP_C2_RK4,
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_STEP_C2_RK4 * per_gpu_steps,
+                         "measured_copy_gbps": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps if copy_gbps else None},
         }
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):  # HBM bytes per launch from the rocprofv3 PMC passes (tools/pmc_summary.py), same command line
+            try:
+                pj = json.load(open(pmc))
+                if pj.get("particles_per_gpu") == npart and pj.get("steps") == K:
+                    out["roofline"]["traffic"] = pj["traffic_bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = pj.get("source")
+            except Exception:
+                pass
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(case, steps=K, sample=min(args.cpu_sample, npart))
         print(json.dumps(out))

@@ -130,21 +130,21 @@ __global__ void __launch_bounds__(256) eval_kernel(const KArgs a, int what, int6
     if (i >= m) return;
     const DField& mf = a.fields[a.main_field];
     const DGrid& mg = a.grids[a.main_grid];
-    Coords mc{mf.time, mg.depth, mg.lat, mg.lon};
+    Coords mc{mf.time, mg.depth, mg.lat, mg.lon, mf.tfirst, mf.tlast, mg.zfirst, mg.zlast, mg.yfirst, mg.ylast, mg.xfirst, mg.xlast};
     PCtx c;
     c.state = PK_EVALUATE;
     c.pf = false;
     c.hz = c.hy = c.hx = c.ht = 0;
-    for (int g = 0; g < PK_MAX_GRIDS; g++) c.first_eval[g] = true;
-    int32_t ei[PK_MAX_GRIDS] = {0, 0, 0, 0};
+    c.first_eval = 0xFu;
+    c.ei0 = c.ei1 = c.ei2 = c.ei3 = 0;
     if (what < 0) {
         double u, v, w;
-        eval_uvw<FT, -1, INTERP>(a, mc, c, ei, what == -2, t[i], z[i], y[i], x[i], false, u, v, w);
+        eval_uvw<FT, -1, INTERP>(a, mc, c, what == -2, t[i], z[i], y[i], x[i], false, u, v, w);
         ou[i] = u;
         if (ov) ov[i] = v;
         if (ow) ow[i] = w;
     } else {
-        ou[i] = eval_scalar<FT>(a, mc, c, ei, what, t[i], z[i], y[i], x[i], false);
+        ou[i] = eval_scalar<FT>(a, mc, c, what, t[i], z[i], y[i], x[i], false);
     }
     if (ost) ost[i] = c.state;
 }
@@ -349,6 +349,11 @@ int32_t pk_grid_create(pk_ctx* ctx, const pk_grid_desc* desc, int32_t* grid_id) 
     d.off_x = desc->off_x; d.off_y = desc->off_y; d.off_z = desc->off_z;
     d.lon_f32 = desc->lon_f32; d.lat_f32 = desc->lat_f32; d.depth_f32 = desc->depth_f32;
     d.deg2m = desc->deg2m;
+    if (desc->depth && desc->nz > 0) { d.zfirst = desc->depth[0]; d.zlast = desc->depth[desc->nz - 1]; }
+    if (desc->kind == 0) {
+        if (desc->lat && desc->ny > 0) { d.yfirst = desc->lat[0]; d.ylast = desc->lat[desc->ny - 1]; }
+        if (desc->lon && desc->nx > 0) { d.xfirst = desc->lon[0]; d.xlast = desc->lon[desc->nx - 1]; }
+    }
     const size_t nlon = desc->kind == 1 ? (size_t)desc->ny * desc->nx : (size_t)desc->nx;
     const size_t nlat = desc->kind == 1 ? (size_t)desc->ny * desc->nx : (size_t)desc->ny;
     int32_t rc;
@@ -409,6 +414,9 @@ int32_t pk_field_create(pk_ctx* ctx, const pk_field_desc* desc, int32_t* field_i
     d.data = f.dev_data;
     d.time = f.dev_time;
     d.tlen = f.time.back() - f.time.front();
+    d.tfirst = f.time.front();
+    d.tlast = f.time.back();
+    if (level_elems >= (1ull << 31)) return ctx->fail("a field time level must hold < 2^31 elements");
     *field_id = (int32_t)ctx->fields.size() - 1;
     return 0;
 }

@@ -34,6 +34,7 @@ struct DGrid {
     const uint32_t* h_faces;
     int64_t h_nkeys;
     double h_bbox[6];
+    double zfirst, zlast, yfirst, ylast, xfirst, xlast;  // first/last of the 1-D coordinate vectors (rectilinear; depth always)
 };
 
 struct DField {
@@ -45,6 +46,7 @@ struct DField {
     const void* data;                // nslots * st_t elements (ring of time levels)
     const double* time;              // nt
     double tlen;                     // time[nt-1] - time[0]
+    double tfirst, tlast;            // time[0], time[nt-1]
 };
 
 struct DParticles {
@@ -90,6 +92,35 @@ static constexpr int GRID_SEARCH_ERROR = -3;                                // i
 static constexpr int LEFT_OUT_OF_BOUNDS = -2;
 static constexpr int RIGHT_OUT_OF_BOUNDS = -1;
 
+// cos() for latitudes.  |x| <= 1.5 rad (86 deg): Cody-Waite reduction by pi/2 + the classic minimax kernels
+// (error < 0.82 ulp, checked against long-double cosl over 2e7 samples); beyond that the library cos.  The reference's
+// cos is NumPy/libm (<= 1 ulp): any <= 1 ulp cosine is as close to it as another libm would be.  ~20 fp64 ops
+// instead of the generic routine's range reduction.
+PK_DEV double cos_lat(double x) {
+    const double ax = fabs(x);
+    if (ax > 1.5) return cos(x);
+    if (ax <= 0.78539816339744830962) {
+        const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                     C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+        const double z = ax * ax;
+        const double r = z * fma(z, fma(z, fma(z, fma(z, fma(z, C6, C5), C4), C3), C2), C1);
+        if (ax < 0.3) return 1.0 - (0.5 * z - z * r);
+        double qx = ax > 0.78125 ? 0.28125 : ax * 0.25;
+        qx = __longlong_as_double(__double_as_longlong(qx) & 0xffffffff00000000ll);
+        const double hz = 0.5 * z - qx, a_ = 1.0 - qx;
+        return a_ - (hz - z * r);
+    }
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double pio2_1 = 1.57079632673412561417e+00, pio2_1t = 6.07710050650619224932e-11;
+    const double zz = ax - pio2_1;
+    const double y0 = zz - pio2_1t;
+    const double y1 = (zz - y0) - pio2_1t;
+    const double z = y0 * y0, v = z * y0;
+    const double r = fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2);
+    return -(y0 - ((z * (0.5 * y1 - v * r) - y1) - v * S1));
+}
+
 struct GPos {
     int ti, zi, yi, xi;
     double tau, zeta, eta, xsi;
@@ -101,6 +132,8 @@ struct Coords {
     const double* depth;
     const double* lat;
     const double* lon;
+    // first/last value of each vector, read once through the scalar unit (uniform) instead of per lane from LDS
+    double t0, t1, z0, z1, y0, y1, x0, x1;
 };
 
 // clip(searchsorted(arr, x, "left") - 1, 0, n-2) (index_search.py:47), found by walking from `hint`
@@ -142,7 +175,8 @@ PK_DEV int cell_index(const double* arr, int n, double x, int hint) {
 }
 
 // _search_1d_array (index_search.py:20-62)
-PK_DEV void search_1d(const double* arr, int n, double x, bool arr_f32, bool x_f32, int hint, int& idx, double& bc) {
+PK_DEV void search_1d(const double* arr, int n, double first, double last, double x, bool arr_f32, bool x_f32, int hint, int& idx,
+                      double& bc) {
     if (n < 2) {  // :45-46, no out-of-bounds codes in this branch
         idx = 0;
         bc = 0.0;
@@ -156,8 +190,8 @@ PK_DEV void search_1d(const double* arr, int n, double x, bool arr_f32, bool x_f
     } else {
         bc = (x - a0) / (a1 - a0);
     }
-    if (x < arr[0]) i = LEFT_OUT_OF_BOUNDS;        // :59
-    if (x > arr[n - 1]) i = RIGHT_OUT_OF_BOUNDS;   // :60
+    if (x < first) i = LEFT_OUT_OF_BOUNDS;   // :59
+    if (x > last) i = RIGHT_OUT_OF_BOUNDS;   // :60
     idx = i;
 }
 
@@ -336,8 +370,22 @@ struct PCtx {
     int state;
     bool pf;             // particle positions are stored as float32 (default Particle, particle.py:123-178)
     int hz, hy, hx, ht;  // search hints of the main grid (indices of the previous evaluation)
-    bool first_eval[PK_MAX_GRIDS];
+    unsigned first_eval;  // bit g: no evaluation on grid g yet in this execute() call
+    int32_t ei0, ei1, ei2, ei3;  // the particle's `ei` row, one register per grid (no dynamic indexing -> no scratch)
 };
+
+PK_DEV int32_t ei_get(const PCtx& c, int g) { return g == 0 ? c.ei0 : (g == 1 ? c.ei1 : (g == 2 ? c.ei2 : c.ei3)); }
+PK_DEV void ei_set(PCtx& c, int g, int32_t v) {  // value selects only: PCtx must stay in registers
+    c.ei0 = g == 0 ? v : c.ei0;
+    c.ei1 = g == 1 ? v : c.ei1;
+    c.ei2 = g == 2 ? v : c.ei2;
+    c.ei3 = g == 3 ? v : c.ei3;
+}
+PK_DEV bool take_first_eval(PCtx& c, int g) {
+    const bool f = (c.first_eval >> g) & 1u;
+    c.first_eval &= ~(1u << g);
+    return f;
+}
 
 // XGrid.search (xgrid.py:316-356) + ei write + state update (field.py:307-356)
 // KIND: 0 rectilinear, 1 curvilinear, -1 decide at run time (scalar fields on secondary grids)
@@ -349,7 +397,7 @@ PK_DEV void grid_search(const DGrid& g, const Coords* mc, double z, double y, do
     const double* lat = mc ? mc->lat : g.lat;
     const double* lon = mc ? mc->lon : g.lon;
     const bool hint = mc != nullptr;
-    if (g.has_z) search_1d(depth, g.nz, z, g.depth_f32, pos_f32, hint ? c.hz : 0, p.zi, p.zeta);
+    if (g.has_z) search_1d(depth, g.nz, mc ? mc->z0 : g.depth[0], mc ? mc->z1 : g.depth[g.nz - 1], z, g.depth_f32, pos_f32, hint ? c.hz : 0, p.zi, p.zeta);
     else { p.zi = 0; p.zeta = 0.0; }
     if (curv) {
         bool found = false;
@@ -364,9 +412,9 @@ PK_DEV void grid_search(const DGrid& g, const Coords* mc, double z, double y, do
         }
         if (!found) hash_query(g, y, x, p.yi, p.xi, p.xsi, p.eta);
     } else {
-        if (g.has_y) search_1d(lat, g.ny, y, g.lat_f32, pos_f32, hint ? c.hy : 0, p.yi, p.eta);
+        if (g.has_y) search_1d(lat, g.ny, mc ? mc->y0 : g.lat[0], mc ? mc->y1 : g.lat[g.ny - 1], y, g.lat_f32, pos_f32, hint ? c.hy : 0, p.yi, p.eta);
         else { p.yi = 0; p.eta = 0.0; }
-        if (g.has_x) search_1d(lon, g.nx, x, g.lon_f32, pos_f32, hint ? c.hx : 0, p.xi, p.xsi);
+        if (g.has_x) search_1d(lon, g.nx, mc ? mc->x0 : g.lon[0], mc ? mc->x1 : g.lon[g.nx - 1], x, g.lon_f32, pos_f32, hint ? c.hx : 0, p.xi, p.xsi);
         else { p.xi = 0; p.xsi = 0.0; }
     }
     if (hint) { c.hz = p.zi; c.hy = p.yi; c.hx = p.xi; }
@@ -385,7 +433,7 @@ PK_DEV void grid_search(const DGrid& g, const Coords* mc, double z, double y, do
 PK_DEV bool time_search(const DField& f, const double* time, double t, int hint, GPos& p) {
     if (!f.has_time_interval) { p.ti = 0; p.tau = 0.0; return true; }
     if (!(0 <= t) || !(t <= f.tlen)) return false;  // utils/time.py:60-62
-    search_1d(time, f.nt, t, false, false, hint, p.ti, p.tau);
+    search_1d(time, f.nt, f.tfirst, f.tlast, t, false, false, hint, p.ti, p.tau);
     return true;
 }
 
@@ -393,43 +441,88 @@ PK_DEV bool time_search(const DField& f, const double* time, double t, int hint,
 template <class FT>
 PK_DEV double ldv(const FT* p, int64_t off) { return (double)p[off]; }
 
+// The two x-corners of a cell are adjacent in memory (x is the fastest axis): fetch them with ONE 16-byte (fp64) /
+// 8-byte (fp32) load.  Element alignment is enough: gfx950 global loads handle unaligned dwordx4.
+typedef double pk_double2 __attribute__((ext_vector_type(2), aligned(8)));
+typedef float pk_float2 __attribute__((ext_vector_type(2), aligned(4)));
+PK_DEV void ldpair(const double* p, double& a, double& b) {
+    const pk_double2 v = *reinterpret_cast<const pk_double2*>(p);
+    a = v.x;
+    b = v.y;
+}
+PK_DEV void ldpair(const float* p, double& a, double& b) {
+    const pk_float2 v = *reinterpret_cast<const pk_float2*>(p);
+    a = (double)v.x;
+    b = (double)v.y;
+}
+
 PK_DEV int64_t slot_off(const DField& f, int ti) {
     int s = (f.nslots >= f.nt) ? ti : (ti % f.nslots);
     return (int64_t)s * f.st_t;
 }
 
-// XLinear.interp (_xinterpolators.py:112-153) on the corners of _gather_corners (:25-96)
+// Element offsets of the 16 bracketing corners (_gather_corners / _get_corner_data_Agrid, _xinterpolators.py:25-96),
+// computed once per evaluation and shared by every field with the same array layout (U, V, W of an A-grid).
+struct Corners {
+    int64_t ot0, ot1;   // slot offsets of the two time levels
+    int o[2][2];        // [z][y] in-level offset of the x0 corner (a level holds < 2^31 elements)
+    int dx;             // offset of the x1 corner relative to x0 (1, or 0 when clipped / no x dimension)
+    bool lenT, lenZ;
+    bool pairs;         // uniform: x-corners are adjacent elements -> one wide load per corner pair
+};
+PK_DEV Corners make_corners(const DField& f, const GPos& p) {
+    Corners k;
+    k.lenT = p.tau > 0;
+    k.lenZ = p.zeta > 0;
+    k.ot0 = slot_off(f, p.ti);
+    k.ot1 = slot_off(f, mini(p.ti + 1, f.nt - 1));
+    const int sz = (int)f.st_z, sy = (int)f.st_y, sx = (int)f.st_x;
+    const int oz0 = p.zi * sz, oz1 = mini(p.zi + 1, f.nz - 1) * sz;
+    const int oy0 = p.yi * sy, oy1 = mini(p.yi + 1, f.ny - 1) * sy;
+    const int ox0 = p.xi * sx;
+    k.dx = mini(p.xi + 1, f.nx - 1) * sx - ox0;
+    k.pairs = (f.st_x == 1) && (f.nx >= 2);  // then xi <= nx-2 for every in-bounds lane, so x1 == x0 + 1
+    k.o[0][0] = oz0 + oy0 + ox0;
+    k.o[0][1] = oz0 + oy1 + ox0;
+    k.o[1][0] = oz1 + oy0 + ox0;
+    k.o[1][1] = oz1 + oy1 + ox0;
+    return k;
+}
+PK_DEV bool same_layout(const DField& a, const DField& b) {
+    return a.st_t == b.st_t && a.st_z == b.st_z && a.st_y == b.st_y && a.st_x == b.st_x && a.nt == b.nt && a.nz == b.nz &&
+           a.ny == b.ny && a.nx == b.nx && a.nslots == b.nslots;
+}
 template <class FT>
-PK_DEV double xlinear(const DField& f, const GPos& p) {
-    const FT* d = (const FT*)f.data;
-    const bool lenT = p.tau > 0, lenZ = p.zeta > 0;
-    const int64_t ot0 = slot_off(f, p.ti), ot1 = slot_off(f, mini(p.ti + 1, f.nt - 1));
-    const int64_t oz0 = (int64_t)p.zi * f.st_z, oz1 = (int64_t)mini(p.zi + 1, f.nz - 1) * f.st_z;
-    const int64_t oy0 = (int64_t)p.yi * f.st_y, oy1 = (int64_t)mini(p.yi + 1, f.ny - 1) * f.st_y;
-    const int64_t ox0 = (int64_t)p.xi * f.st_x, ox1 = (int64_t)mini(p.xi + 1, f.nx - 1) * f.st_x;
-    // issue every load of this field first (independent), combine afterwards
+PK_DEV void ld2(const FT* p, int off, int dx, bool pairs, double& a, double& b) {
+    if (pairs) {
+        ldpair(p + off, a, b);
+    } else {  // a field without an x dimension (or of extent 1)
+        a = (double)p[off];
+        b = (double)p[off + dx];
+    }
+}
+
+// XLinear.interp (_xinterpolators.py:112-153)
+template <class FT>
+PK_DEV double xlinear(const DField& f, const Corners& k, const GPos& p) {
+    const FT* d0 = (const FT*)f.data + k.ot0;
+    const FT* d1 = (const FT*)f.data + k.ot1;
+    const bool lenT = k.lenT, lenZ = k.lenZ;
+    // issue every load of this field first (independent), combine afterwards; x-pairs are single wide loads
     double a[2][2][2];   // [z][y][x] at t0
     double b[2][2][2];   // at t1
-    a[0][0][0] = ldv(d, ot0 + oz0 + oy0 + ox0);
-    a[0][0][1] = ldv(d, ot0 + oz0 + oy0 + ox1);
-    a[0][1][0] = ldv(d, ot0 + oz0 + oy1 + ox0);
-    a[0][1][1] = ldv(d, ot0 + oz0 + oy1 + ox1);
+    ld2(d0, k.o[0][0], k.dx, k.pairs, a[0][0][0], a[0][0][1]);
+    ld2(d0, k.o[0][1], k.dx, k.pairs, a[0][1][0], a[0][1][1]);
     if (lenZ) {
-        a[1][0][0] = ldv(d, ot0 + oz1 + oy0 + ox0);
-        a[1][0][1] = ldv(d, ot0 + oz1 + oy0 + ox1);
-        a[1][1][0] = ldv(d, ot0 + oz1 + oy1 + ox0);
-        a[1][1][1] = ldv(d, ot0 + oz1 + oy1 + ox1);
+        ld2(d0, k.o[1][0], k.dx, k.pairs, a[1][0][0], a[1][0][1]);
+        ld2(d0, k.o[1][1], k.dx, k.pairs, a[1][1][0], a[1][1][1]);
     }
     if (lenT) {
-        b[0][0][0] = ldv(d, ot1 + oz0 + oy0 + ox0);
-        b[0][0][1] = ldv(d, ot1 + oz0 + oy0 + ox1);
-        b[0][1][0] = ldv(d, ot1 + oz0 + oy1 + ox0);
-        b[0][1][1] = ldv(d, ot1 + oz0 + oy1 + ox1);
+        ld2(d1, k.o[0][0], k.dx, k.pairs, b[0][0][0], b[0][0][1]);
+        ld2(d1, k.o[0][1], k.dx, k.pairs, b[0][1][0], b[0][1][1]);
         if (lenZ) {
-            b[1][0][0] = ldv(d, ot1 + oz1 + oy0 + ox0);
-            b[1][0][1] = ldv(d, ot1 + oz1 + oy0 + ox1);
-            b[1][1][0] = ldv(d, ot1 + oz1 + oy1 + ox0);
-            b[1][1][1] = ldv(d, ot1 + oz1 + oy1 + ox1);
+            ld2(d1, k.o[1][0], k.dx, k.pairs, b[1][0][0], b[1][0][1]);
+            ld2(d1, k.o[1][1], k.dx, k.pairs, b[1][1][0], b[1][1][1]);
         }
     }
     const double tau = p.tau, zeta = p.zeta, xsi = p.xsi, eta = p.eta;
@@ -449,6 +542,8 @@ PK_DEV double xlinear(const DField& f, const GPos& p) {
         }
     return (1 - xsi) * (1 - eta) * c[0][0] + xsi * (1 - eta) * c[0][1] + (1 - xsi) * eta * c[1][0] + xsi * eta * c[1][1];
 }
+template <class FT>
+PK_DEV double xlinear(const DField& f, const GPos& p) { return xlinear<FT>(f, make_corners(f, p), p); }
 
 // _geodetic_distance (utils/interpolation.py:178-185), including NumPy's float32 behaviour for f32 coordinates
 PK_DEV double geodetic_distance(const DGrid& g, double lat1, double lat2, double lon1, double lon2, double lat, bool cf32) {
@@ -456,11 +551,11 @@ PK_DEV double geodetic_distance(const DGrid& g, double lat1, double lat2, double
         if (cf32) {
             double dl = (double)(((float)lon2 - (float)lon1) * (float)g.deg2m);
             float dlaf = ((float)lat2 - (float)lat1) * (float)g.deg2m;
-            double a = dl * cos(DEG2RAD * lat);
+            double a = dl * cos_lat(DEG2RAD * lat);
             return sqrt(a * a + (double)(dlaf * dlaf));
         }
         double dl = (lon2 - lon1) * g.deg2m, dla = (lat2 - lat1) * g.deg2m;
-        double a = dl * cos(DEG2RAD * lat);
+        double a = dl * cos_lat(DEG2RAD * lat);
         return sqrt(a * a + dla * dla);
     }
     if (cf32) {
@@ -577,7 +672,7 @@ PK_DEV void cgrid_velocity(const DGrid& g, const Coords* mc, const DField& U, co
     if (g.spherical) {  // :311-314 (both components divided by deg2m*cos(lat))
         double conv;
         if (ypos_f32) conv = (double)((float)g.deg2m * cosf((float)ypos * DEG2RADF));
-        else conv = g.deg2m * cos(ypos * DEG2RAD);
+        else conv = g.deg2m * cos_lat(ypos * DEG2RAD);
         uu /= conv;
         vv /= conv;
     }
@@ -603,7 +698,7 @@ PK_DEV double finish_value(PCtx& c, const GPos& p, double v) {
 // VectorField.eval (field.py:250-304). INTERP: 0 XLinear_Velocity, 1 CGrid_Velocity. pos_f32: z,y,x come
 // straight from float32 particle storage (NumPy then evaluates cos(lat) in float32).
 template <class FT, int KIND, int INTERP>
-PK_DEV void eval_uvw(const KArgs& a, const Coords& mc, PCtx& c, int32_t* ei_row, bool want_w, double t, double z, double y,
+PK_DEV void eval_uvw(const KArgs& a, const Coords& mc, PCtx& c, bool want_w, double t, double z, double y,
                      double x, bool pos_f32, double& u, double& v, double& w) {
     const DField& U = a.fields[a.prm.fU];
     const DField& V = a.fields[a.prm.fV];
@@ -615,9 +710,10 @@ PK_DEV void eval_uvw(const KArgs& a, const Coords& mc, PCtx& c, int32_t* ei_row,
         return;
     }
     c.ht = p.ti;
-    const bool use_guess = c.first_eval[U.grid] ? (a.prm.have_guess0 != 0) : true;
-    c.first_eval[U.grid] = false;
-    grid_search<KIND>(g, &mc, z, y, x, pos_f32, &ei_row[U.grid], c, use_guess, p);
+    const bool use_guess = take_first_eval(c, U.grid) ? (a.prm.have_guess0 != 0) : true;
+    int32_t ei = ei_get(c, U.grid);
+    grid_search<KIND>(g, &mc, z, y, x, pos_f32, &ei, c, use_guess, p);
+    ei_set(c, U.grid, ei);
     const bool oob = (p.xi < 0 || p.yi < 0 || p.zi < 0);
     double uu = 0, vv = 0, ww = 0;
     if (!oob) {
@@ -625,13 +721,14 @@ PK_DEV void eval_uvw(const KArgs& a, const Coords& mc, PCtx& c, int32_t* ei_row,
         if (INTERP == 1) {
             cgrid_velocity<FT, KIND>(g, &mc, U, V, W, p, y, pos_f32, uu, vv, ww);
         } else {  // XLinear_Velocity.interp (_xinterpolators.py:169-190)
-            uu = xlinear<FT>(U, p);
-            vv = xlinear<FT>(V, p);
-            if (W) ww = xlinear<FT>(*W, p);
+            const Corners k = make_corners(U, p);
+            uu = xlinear<FT>(U, k, p);
+            vv = same_layout(U, V) ? xlinear<FT>(V, k, p) : xlinear<FT>(V, p);
+            if (W) ww = same_layout(U, *W) ? xlinear<FT>(*W, k, p) : xlinear<FT>(*W, p);
             if (g.spherical) {
                 double conv;
                 if (pos_f32) conv = (double)((float)g.deg2m * cosf((float)y * DEG2RADF));
-                else conv = g.deg2m * cos(y * DEG2RAD);
+                else conv = g.deg2m * cos_lat(y * DEG2RAD);
                 uu /= conv;
                 vv /= g.deg2m;
             }
@@ -644,7 +741,7 @@ PK_DEV void eval_uvw(const KArgs& a, const Coords& mc, PCtx& c, int32_t* ei_row,
 
 // Field.eval for a scalar field (field.py:145-195): XLinear or XConstantField
 template <class FT>
-PK_DEV double eval_scalar(const KArgs& a, const Coords& mc, PCtx& c, int32_t* ei_row, int fidx, double t, double z, double y,
+PK_DEV double eval_scalar(const KArgs& a, const Coords& mc, PCtx& c, int fidx, double t, double z, double y,
                           double x, bool pos_f32) {
     const DField& f = a.fields[fidx];
     const DGrid& g = a.grids[f.grid];
@@ -655,9 +752,10 @@ PK_DEV double eval_scalar(const KArgs& a, const Coords& mc, PCtx& c, int32_t* ei
         c.state = PK_ERROROUTSIDETIMEINTERVAL;
         return 0.0;
     }
-    const bool use_guess = c.first_eval[f.grid] ? (a.prm.have_guess0 != 0) : true;
-    c.first_eval[f.grid] = false;
-    grid_search<-1>(g, on_main ? &mc : nullptr, z, y, x, pos_f32, &ei_row[f.grid], c, use_guess, p);
+    const bool use_guess = take_first_eval(c, f.grid) ? (a.prm.have_guess0 != 0) : true;
+    int32_t ei = ei_get(c, f.grid);
+    grid_search<-1>(g, on_main ? &mc : nullptr, z, y, x, pos_f32, &ei, c, use_guess, p);
+    ei_set(c, f.grid, ei);
     double v = 0.0;
     if (!(p.xi < 0 || p.yi < 0 || p.zi < 0)) {
         if (f.is_const) v = (f.dtype == PK_F64) ? ((const double*)f.data)[0] : (double)((const float*)f.data)[0];

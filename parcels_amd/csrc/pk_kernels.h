@@ -328,8 +328,11 @@ PK_DEV unsigned xcd_swizzle(unsigned bid, unsigned nb) {
 }
 
 // KID: compile-time kernel id of a single-kernel program, or -1 for the kernel-list interpreter
+#ifndef PK_MIN_WAVES
+#define PK_MIN_WAVES 1
+#endif
 template <class FT, int KIND, int INTERP, int KID, bool LDS>
-__global__ void __launch_bounds__(256) advect_kernel(const KArgs a) {
+__global__ void __launch_bounds__(256, PK_MIN_WAVES) advect_kernel(const KArgs a) {
     extern __shared__ double smem[];
     const DField& mf = a.fields[a.main_field];
     const DGrid& mg = a.grids[a.main_grid];
@@ -359,6 +362,11 @@ __global__ void __launch_bounds__(256) advect_kernel(const KArgs a) {
         mc.lat = mg.lat;
         mc.lon = mg.lon;
     }
+    mc.t0 = mf.tfirst;
+    mc.t1 = mf.tlast;
+    mc.z0 = mg.zfirst; mc.z1 = mg.zlast;
+    mc.y0 = mg.yfirst; mc.y1 = mg.ylast;
+    mc.x0 = mg.xfirst; mc.x1 = mg.xlast;
 
     const int64_t i = (int64_t)xcd_swizzle(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     unsigned long long steps = 0, attempts = 0, paused = 0;
@@ -371,8 +379,7 @@ __global__ void __launch_bounds__(256) advect_kernel(const KArgs a) {
         c.state = prm.reset_state ? PK_EVALUATE : P.state[i];  // kernel.py:188
         if (c.state == PK_EVALUATE) {
             c.hz = c.hy = c.hx = c.ht = 0;
-#pragma unroll
-            for (int g = 0; g < PK_MAX_GRIDS; g++) c.first_eval[g] = (prm.reset_state != 0);
+            c.first_eval = prm.reset_state ? 0xFu : 0u;
             PState p;
             p.t = P.t[i];
             p.z = ldp(P.z, i, pf);
@@ -384,9 +391,11 @@ __global__ void __launch_bounds__(256) advect_kernel(const KArgs a) {
             p.dt = P.dt[i];
             p.next_dt = P.next_dt ? P.next_dt[i] : 0.0;
             p.id = P.particle_id[i];
-            int32_t ei[PK_MAX_GRIDS];
-#pragma unroll
-            for (int g = 0; g < PK_MAX_GRIDS; g++) ei[g] = g < P.ngrids ? P.ei[i * P.ngrids + g] : 0;
+            const int ng = P.ngrids;
+            c.ei0 = P.ei[i * ng];
+            c.ei1 = ng > 1 ? P.ei[i * ng + 1] : 0;
+            c.ei2 = ng > 2 ? P.ei[i * ng + 2] : 0;
+            c.ei3 = ng > 3 ? P.ei[i * ng + 3] : 0;
             const double endtime = prm.endtime;
             const int sign = prm.dt0 > 0 ? 1 : -1;  // kernel.py:186
             const bool windowed = mf.has_time_interval != 0;
@@ -414,9 +423,9 @@ __global__ void __launch_bounds__(256) advect_kernel(const KArgs a) {
                         for (int stage = 0; !prepare(a, kid, stage, k, c, p, L, rq); stage++) {
                             double u, v = 0.0, w = 0.0;
                             if (rq.kind == RQ_SCALAR) {
-                                u = eval_scalar<FT>(a, mc, c, ei, rq.fidx, rq.t, rq.z, rq.y, rq.x, rq.f32);
+                                u = eval_scalar<FT>(a, mc, c, rq.fidx, rq.t, rq.z, rq.y, rq.x, rq.f32);
                             } else {
-                                eval_uvw<FT, KIND, INTERP>(a, mc, c, ei, rq.kind == RQ_UVW, rq.t, rq.z, rq.y, rq.x, rq.f32, u, v, w);
+                                eval_uvw<FT, KIND, INTERP>(a, mc, c, rq.kind == RQ_UVW, rq.t, rq.z, rq.y, rq.x, rq.f32, u, v, w);
                             }
                             consume(kid, stage, L, u, v, w);
                         }
@@ -444,9 +453,10 @@ __global__ void __launch_bounds__(256) advect_kernel(const KArgs a) {
             P.dt[i] = p.dt;
             if (P.next_dt) P.next_dt[i] = p.next_dt;
             P.state[i] = c.state;
-#pragma unroll
-            for (int g = 0; g < PK_MAX_GRIDS; g++)
-                if (g < P.ngrids) P.ei[i * P.ngrids + g] = ei[g];
+            P.ei[i * ng] = c.ei0;
+            if (ng > 1) P.ei[i * ng + 1] = c.ei1;
+            if (ng > 2) P.ei[i * ng + 2] = c.ei2;
+            if (ng > 3) P.ei[i * ng + 3] = c.ei3;
         }
     }
     steps = wave_sum(steps);
