@@ -413,6 +413,12 @@ __global__ void __launch_bounds__(256, PK_MIN_WAVES) advect_kernel(const KArgs a
                     const double lo = fmin(p.t, t1), hi = fmax(p.t, t1);
                     if (lo < a.win_lo || hi > a.win_hi) { paused = 1; break; }
                 }
+                if (tte > 0 && p.t + dtc == p.t) {
+                    // dt == 0 (or below the resolution of t) before endtime: the reference's while-loop would spin
+                    // forever (kernel.py:190); a GPU must not -- flag the particle instead
+                    c.state = PK_ERROR;
+                    break;
+                }
                 p.dt = dtc;
                 for (int k = 0; k < nk; k++) {  // :206-216
                     const int kid = KID >= 0 ? KID : prm.kernels[k];

@@ -101,6 +101,9 @@ class Kernel:
             return StatusCode.Success
         engine = pset._engine()
         data = pset._data
+        if "RK45_tol" in self.fieldset.context and "next_dt" not in data:
+            # kernel.py:118-120: `particles.dt = particles.next_dt` runs whenever the fieldset has RK45_tol
+            raise KeyError("next_dt: fieldset.context has RK45_tol (RK45 mode) but the ParticleClass has no next_dt Variable")
         sign = 1 if dt > 0 else -1
         t = data["t"]
         t_start = float(np.nanmin(t) if sign > 0 else np.nanmax(t))

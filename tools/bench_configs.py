@@ -1,0 +1,141 @@
+#!/usr/bin/env python
+"""Measure the non-headline BASELINE.json configurations on one MI355X (not the bench.py contract line):
+
+  c3  3-D NEMO-like curvilinear C-grid nx=4322, ny=3059, nz=75, fp32 U,V,W, 1e7 particles, AdvectionRK4_3D,
+      field-slab ring (nslots < nt) with asynchronous prefetch of the next level
+  c5  same grid, AdvectionRK45 (adaptive, divergent dt) and AdvectionDiffusionM1 (per-particle counter RNG)
+
+`--scale s` shrinks nx, ny by s (default 1.0 = the BASELINE size).  Prints one JSON object per measured kernel list.
+Synthetic data: smooth analytic patterns on a smoothly warped lon/lat mesh.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def nemo_like_dataset(nx, ny, nz, nt, with_kh=False, seed=0):
+    import parcels_amd as pa
+
+    t0 = time.perf_counter()
+    i = np.arange(nx, dtype=np.float64)[None, :] / (nx - 1)
+    j = np.arange(ny, dtype=np.float64)[:, None] / (ny - 1)
+    lon = -170.0 + 340.0 * i + 2.0 * np.sin(2 * np.pi * j) * (0.3 + i) + 3.0 * j
+    lat = -75.0 + 150.0 * j + 1.5 * np.sin(2 * np.pi * i) * (0.5 + 0.5 * j) - 2.0 * i
+    depth = np.concatenate([[0.0], np.cumsum(np.linspace(5.0, 150.0, nz - 1))])
+    time_s = np.arange(nt) * 86400.0
+    zprof = np.exp(-depth / 1500.0).astype(np.float32)[:, None, None]
+    ii = i.astype(np.float32)
+    jj = j.astype(np.float32)
+    pu = (0.5 * np.cos(6 * np.pi * jj) * (1.0 + 0.3 * np.sin(10 * np.pi * ii))).astype(np.float32)
+    pv = (0.3 * np.sin(8 * np.pi * ii) * np.cos(4 * np.pi * jj)).astype(np.float32)
+    pw = (1e-4 * np.sin(12 * np.pi * ii) * np.sin(12 * np.pi * jj)).astype(np.float32)
+    U = np.empty((nt, nz, ny, nx), np.float32)
+    V = np.empty((nt, nz, ny, nx), np.float32)
+    W = np.empty((nt, nz, ny, nx), np.float32)
+    for k in range(nt):
+        f = np.float32(1.0 + 0.2 * np.sin(2 * np.pi * k / max(nt, 2)))
+        np.multiply(zprof, pu[None] * f, out=U[k])
+        np.multiply(zprof, pv[None] * f, out=V[k])
+        np.multiply(zprof, pw[None] * f, out=W[k])
+    md = pa.SGrid2DMetadata(
+        node_dimensions=("XG", "YG"), node_coordinates=("lon", "lat"),
+        face_dimensions=(pa.FaceNodePadding("XC", "XG", pa.Padding.LOW), pa.FaceNodePadding("YC", "YG", pa.Padding.LOW)),
+        vertical_dimensions=(pa.FaceNodePadding("ZC", "depth", pa.Padding.HIGH),),
+    )
+    dv = {"U": (("time", "ZC", "YC", "XG"), U), "V": (("time", "ZC", "YG", "XC"), V), "W": (("time", "depth", "YC", "XC"), W)}
+    if with_kh:
+        kh = (10.0 * (1.0 + 0.5 * np.tanh(3 * (2 * ii - 1))) * np.ones_like(jj)).astype(np.float32)
+        dv["Kh_zonal"] = (("YG", "XG"), kh)
+        dv["Kh_meridional"] = (("YG", "XG"), (10.0 * (1.0 + 0.3 * np.tanh(2 * (2 * jj - 1))) * np.ones_like(ii)).astype(np.float32))
+    ds = pa.Dataset(dv, {"lon": (("YG", "XG"), lon), "lat": (("YG", "XG"), lat), "depth": (("depth",), depth),
+                         "time": (("time",), time_s)}, sgrid=md)
+    gen_s = time.perf_counter() - t0
+    return ds, lon, lat, depth, gen_s
+
+
+def seed_particles(lon, lat, depth, n, seed):
+    rng = np.random.default_rng(seed)
+    ny, nx = lon.shape
+    ci = rng.uniform(0.1, 0.9, n) * (nx - 1)
+    cj = rng.uniform(0.1, 0.9, n) * (ny - 1)
+    i0, j0 = ci.astype(np.int64), cj.astype(np.int64)
+    fi, fj = ci - i0, cj - j0
+
+    def blend(a):
+        return (a[j0, i0] * (1 - fi) * (1 - fj) + a[j0, i0 + 1] * fi * (1 - fj) + a[j0 + 1, i0] * (1 - fi) * fj + a[j0 + 1, i0 + 1] * fi * fj)
+
+    return blend(lon), blend(lat), rng.uniform(5.0, 0.6 * depth[-1], n)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="c3", choices=["c3", "c5"])
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--particles", type=float, default=1e7)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--nt", type=int, default=4)
+    ap.add_argument("--nslots", type=int, default=3)
+    ap.add_argument("--nz", type=int, default=75)
+    args = ap.parse_args()
+
+    import parcels_amd as pa
+
+    nx, ny = max(int(4322 * args.scale), 32), max(int(3059 * args.scale), 32)
+    n = int(args.particles)
+    ds, lon, lat, depth, gen_s = nemo_like_dataset(nx, ny, args.nz, args.nt, with_kh=(args.config == "c5"))
+    t0 = time.perf_counter()
+    fs = pa.FieldSet.from_sgrid_conventions(ds, mesh="spherical", skip_field_data_validation=True)
+    if args.config == "c5":
+        fs.add_context("dres", 0.01)
+    fs.gridset[0].get_spatial_hash()
+    hash_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    fs.to_device(0, nslots=args.nslots)
+    upload_s = time.perf_counter() - t0
+    x, y, z = seed_particles(lon, lat, depth, n, seed=3)
+    dt = 3600.0
+    runs = [("AdvectionRK4_3D", [pa.AdvectionRK4_3D, pa.DeleteParticle], None)] if args.config == "c3" else [
+        ("AdvectionRK45", [pa.AdvectionRK45, pa.DeleteParticle], "rk45"),
+        ("AdvectionDiffusionM1", [pa.AdvectionDiffusionM1, pa.DeleteParticle], "m1"),
+    ]
+    for label, kernels, kind in runs:
+        if kind != "rk45":  # RK45 mode is keyed on the context (kernel.py:118): do not leak it into the other runs
+            for key in ("RK45_tol", "RK45_min_dt", "RK45_max_dt"):
+                fs.context.pop(key, None)
+        pclass = pa.get_default_particle(np.float64)
+        if kind == "rk45":
+            pclass = pclass.add_variable(pa.Variable("next_dt", dtype=np.float64, initial=dt))
+        pset = pa.ParticleSet(fs, pclass=pclass, x=x, y=y, z=z, t=np.zeros(n), sort_by_cell=True)
+        pset.populate_indices()
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            t0 = time.perf_counter()
+            pset.execute(kernels, dt=dt, runtime=args.steps * dt)
+            wall = time.perf_counter() - t0
+        st = pset._last_stats
+        out = {
+            "config": args.config, "kernels": label, "grid": [nx, ny, args.nz, args.nt], "nslots": args.nslots, "particles": n,
+            "steps_requested": args.steps, "particle_steps": int(st["steps"]), "attempts": int(st["attempts"]),
+            "kernel_ms": st["kernel_ms"], "sort_ms": st["sort_ms"], "launches": st["launches"],
+            "particle_steps_per_s_kernel": st["steps"] / (st["kernel_ms"] * 1e-3) if st["kernel_ms"] else None,
+            "particle_steps_per_s_wall_incl_h2d_d2h": st["steps"] / wall, "wall_s": wall,
+            "remaining_particles": len(pset), "state_counts": st["state_counts"],
+            "dataset_generation_s": gen_s, "hash_build_s": hash_s, "device_upload_s": upload_s,
+        }
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
