@@ -768,7 +768,10 @@ int32_t pk_execute(pk_ctx* ctx, const pk_exec_params* prm, pk_exec_stats* stats)
     if (n > 0) {
         const dim3 grid((unsigned)((n + 255) / 256));
         int prog = PROG_GENERIC;
-        if (prm->nk == 1 && use_lds) {
+        bool rest_policy = true;  // entries after the first are the sampling-free recovery kernels
+        for (int k = 1; k < prm->nk; k++)
+            rest_policy = rest_policy && (prm->kernels[k] == PK_KERNEL_DELETE_ON_ERROR || prm->kernels[k] == PK_KERNEL_DELETE_OUT_OF_BOUNDS);
+        if (rest_policy && use_lds) {
             if (prm->kernels[0] == PK_KERNEL_ADVECTION_RK4) prog = PROG_RK4;
             if (prm->kernels[0] == PK_KERNEL_ADVECTION_RK4_3D) prog = PROG_RK4_3D;
         }

@@ -79,6 +79,11 @@ struct KArgs {
 
 // ---- small helpers ------------------------------------------------------------------------------------
 #define PK_DEV __device__ __forceinline__
+// Scheduling fence between the gathers of two fields: without it the compiler hoists all 16 (32, 48) corner loads of
+// U, V (and W) above the first interpolation, which costs ~64 VGPRs per field and caps occupancy at 2 waves/SIMD.
+#ifndef PK_FIELD_FENCE
+#define PK_FIELD_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 
 PK_DEV int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 PK_DEV int mini(int a, int b) { return a < b ? a : b; }
@@ -502,44 +507,41 @@ PK_DEV void ld2(const FT* p, int off, int dx, bool pairs, double& a, double& b) 
     }
 }
 
-// XLinear.interp (_xinterpolators.py:112-153)
+// One depth level of XLinear: the 4 (y, x) corners at both time levels -> time-interpolated corner values.
+template <class FT>
+PK_DEV void xlinear_level(const FT* d0, const FT* d1, const Corners& k, int iz, double tau, double c[2][2]) {
+    double a[2][2], b[2][2];
+    ld2(d0, k.o[iz][0], k.dx, k.pairs, a[0][0], a[0][1]);
+    ld2(d0, k.o[iz][1], k.dx, k.pairs, a[1][0], a[1][1]);
+    if (k.lenT) {
+        ld2(d1, k.o[iz][0], k.dx, k.pairs, b[0][0], b[0][1]);
+        ld2(d1, k.o[iz][1], k.dx, k.pairs, b[1][0], b[1][1]);
+    }
+#pragma unroll
+    for (int iy = 0; iy < 2; iy++)
+#pragma unroll
+        for (int ix = 0; ix < 2; ix++) c[iy][ix] = k.lenT ? a[iy][ix] * (1 - tau) + b[iy][ix] * tau : a[iy][ix];
+}
+
+// XLinear.interp (_xinterpolators.py:112-153): lerp in t, then z, then bilinear in (eta, xsi).
+// The gather is issued in two batches (depth level z0, then z1) of up to 4 wide loads each: all 8 (16 scalar) loads at
+// once would hold ~64 VGPRs of data + addresses per field and cap the kernel at 2 waves/SIMD.
 template <class FT>
 PK_DEV double xlinear(const DField& f, const Corners& k, const GPos& p) {
     const FT* d0 = (const FT*)f.data + k.ot0;
     const FT* d1 = (const FT*)f.data + k.ot1;
-    const bool lenT = k.lenT, lenZ = k.lenZ;
-    // issue every load of this field first (independent), combine afterwards; x-pairs are single wide loads
-    double a[2][2][2];   // [z][y][x] at t0
-    double b[2][2][2];   // at t1
-    ld2(d0, k.o[0][0], k.dx, k.pairs, a[0][0][0], a[0][0][1]);
-    ld2(d0, k.o[0][1], k.dx, k.pairs, a[0][1][0], a[0][1][1]);
-    if (lenZ) {
-        ld2(d0, k.o[1][0], k.dx, k.pairs, a[1][0][0], a[1][0][1]);
-        ld2(d0, k.o[1][1], k.dx, k.pairs, a[1][1][0], a[1][1][1]);
-    }
-    if (lenT) {
-        ld2(d1, k.o[0][0], k.dx, k.pairs, b[0][0][0], b[0][0][1]);
-        ld2(d1, k.o[0][1], k.dx, k.pairs, b[0][1][0], b[0][1][1]);
-        if (lenZ) {
-            ld2(d1, k.o[1][0], k.dx, k.pairs, b[1][0][0], b[1][0][1]);
-            ld2(d1, k.o[1][1], k.dx, k.pairs, b[1][1][0], b[1][1][1]);
-        }
-    }
     const double tau = p.tau, zeta = p.zeta, xsi = p.xsi, eta = p.eta;
     double c[2][2];
+    xlinear_level<FT>(d0, d1, k, 0, tau, c);
+    if (k.lenZ) {
+        PK_FIELD_FENCE();
+        double c1[2][2];
+        xlinear_level<FT>(d0, d1, k, 1, tau, c1);
 #pragma unroll
-    for (int iy = 0; iy < 2; iy++)
+        for (int iy = 0; iy < 2; iy++)
 #pragma unroll
-        for (int ix = 0; ix < 2; ix++) {
-            double v0 = a[0][iy][ix];
-            if (lenT) v0 = v0 * (1 - tau) + b[0][iy][ix] * tau;
-            if (lenZ) {
-                double v1 = a[1][iy][ix];
-                if (lenT) v1 = v1 * (1 - tau) + b[1][iy][ix] * tau;
-                v0 = v0 * (1 - zeta) + v1 * zeta;
-            }
-            c[iy][ix] = v0;
-        }
+            for (int ix = 0; ix < 2; ix++) c[iy][ix] = c[iy][ix] * (1 - zeta) + c1[iy][ix] * zeta;
+    }
     return (1 - xsi) * (1 - eta) * c[0][0] + xsi * (1 - eta) * c[0][1] + (1 - xsi) * eta * c[1][0] + xsi * eta * c[1][1];
 }
 template <class FT>
@@ -723,7 +725,9 @@ PK_DEV void eval_uvw(const KArgs& a, const Coords& mc, PCtx& c, bool want_w, dou
         } else {  // XLinear_Velocity.interp (_xinterpolators.py:169-190)
             const Corners k = make_corners(U, p);
             uu = xlinear<FT>(U, k, p);
+            PK_FIELD_FENCE();
             vv = same_layout(U, V) ? xlinear<FT>(V, k, p) : xlinear<FT>(V, p);
+            PK_FIELD_FENCE();
             if (W) ww = same_layout(U, *W) ? xlinear<FT>(*W, k, p) : xlinear<FT>(*W, p);
             if (g.spherical) {
                 double conv;

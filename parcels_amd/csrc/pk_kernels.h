@@ -437,6 +437,18 @@ __global__ void __launch_bounds__(256, PK_MIN_WAVES) advect_kernel(const KArgs a
                         }
                     } while (c.state == PK_REPEAT);
                 }
+                if (KID >= 0) {
+                    // single-kernel programs may be followed by the sampling-free recovery kernels (Delete*)
+                    for (int k = 1; k < prm.nk; k++) {
+                        const int kid = prm.kernels[k];
+                        attempts++;
+                        if (kid == PK_KERNEL_DELETE_ON_ERROR) {
+                            if (c.state >= PK_ERROR) c.state = PK_DELETE;
+                        } else if (c.state == PK_ERROROUTOFBOUNDS || c.state == PK_ERRORTHROUGHSURFACE) {
+                            c.state = PK_DELETE;  // PK_KERNEL_DELETE_OUT_OF_BOUNDS
+                        }
+                    }
+                }
                 if (c.state == PK_EVALUATE || c.state == PK_SUCCESS) {  // :219-222 -> _position_update :108-120
                     p.x = padd(pf, p.x, p.dx);
                     p.y = padd(pf, p.y, p.dy);

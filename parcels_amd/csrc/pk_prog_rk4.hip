@@ -1,7 +1,9 @@
 // Instantiations of the fused advection kernel for program PROG_RK4 (one TU per program: parallel build).
-// 3 waves per SIMD: measured +25% on MI355X over the unconstrained allocation (the kernel is VALU-issue bound and
+// 4 waves per SIMD (128 VGPRs): measured on MI355X, C2: 8.4e9 (2 waves) / 1.15e10 (3) / 1.24e10 (4) particle-steps/s. The kernel is VALU-issue bound and
 // needs the extra wave to cover gather latency; the few spills this forces cost less than the lost occupancy)
-#define PK_MIN_WAVES 3
+#ifndef PK_MIN_WAVES
+#define PK_MIN_WAVES 4
+#endif
 #include "pk_kernels.h"
 namespace pk {
 PK_DEFINE_LAUNCH_PROGRAM(PROG_RK4, PK_KERNEL_ADVECTION_RK4, 0)
