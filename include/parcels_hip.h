@@ -102,6 +102,9 @@ typedef struct pk_grid_desc {
     const double* lon; /* nx, or ny*nx row-major; exact widening of the dataset's values           */
     const double* lat; /* ny, or ny*nx                                                             */
     const double* depth; /* nz (may be NULL when nz == 0)                                          */
+    const double* node_xyz; /* spherical curvilinear grids: unit-sphere coordinates of every node, three (ny, nx)
+                               planes X = cos(lon)cos(lat), Y = sin(lon)cos(lat), Z = sin(lat) (index_search.py:439-450);
+                               NULL otherwise.  Computed once on the host instead of 8 sin/cos pairs per evaluation. */
     /* CSR Morton hash, curvilinear only (all NULL/0 otherwise) */
     const uint32_t* h_keys;
     const int64_t* h_starts;

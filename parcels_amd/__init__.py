@@ -26,6 +26,7 @@ from .kernels import (
     SubmergeParticle,
 )
 from .particle import Particle, ParticleClass, Variable, get_default_particle
+from .particlefile import ParticleFile, read_particlefile
 from .particleset import ParticleSet
 from .sgrid import FaceNodePadding, Padding, SGrid2DMetadata
 from .statuscodes import (

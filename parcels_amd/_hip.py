@@ -58,6 +58,7 @@ class GridDesc(C.Structure):
         ("lon", C.c_void_p),
         ("lat", C.c_void_p),
         ("depth", C.c_void_p),
+        ("node_xyz", C.c_void_p),
         ("h_keys", C.c_void_p),
         ("h_starts", C.c_void_p),
         ("h_counts", C.c_void_p),

@@ -360,6 +360,10 @@ int32_t pk_grid_create(pk_ctx* ctx, const pk_grid_desc* desc, int32_t* grid_id) 
     if ((rc = upload(ctx, g, desc->lon, nlon, &d.lon))) return rc;
     if ((rc = upload(ctx, g, desc->lat, nlat, &d.lat))) return rc;
     if ((rc = upload(ctx, g, desc->depth, (size_t)desc->nz, &d.depth))) return rc;
+    if (desc->kind == 1 && desc->spherical) {
+        if (!desc->node_xyz) return ctx->fail("spherical curvilinear grid needs node_xyz (unit-sphere node coordinates)");
+        if ((rc = upload(ctx, g, desc->node_xyz, 3 * nlon, &d.node_xyz))) return rc;
+    }
     if (desc->kind == 1) {
         if (!desc->h_keys || desc->h_nkeys <= 0) return ctx->fail("curvilinear grid needs a spatial-hash table");
         if ((rc = upload(ctx, g, desc->h_keys, (size_t)desc->h_nkeys, &d.h_keys))) return rc;

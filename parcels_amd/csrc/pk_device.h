@@ -28,6 +28,7 @@ struct DGrid {
     const double* lon;
     const double* lat;
     const double* depth;
+    const double* node_xyz;  // curvilinear spherical: unit-sphere (X, Y, Z) of every node, 3 planes of ny*nx
     const uint32_t* h_keys;
     const int64_t* h_starts;
     const int64_t* h_counts;
@@ -200,6 +201,21 @@ PK_DEV void search_1d(const double* arr, int n, double first, double last, doubl
     idx = i;
 }
 
+// The two x-corners of a cell are adjacent in memory (x is the fastest axis): fetch them with ONE 16-byte (fp64) /
+// 8-byte (fp32) load.  Element alignment is enough: gfx950 global loads handle unaligned dwordx4.
+typedef double pk_double2 __attribute__((ext_vector_type(2), aligned(8)));
+typedef float pk_float2 __attribute__((ext_vector_type(2), aligned(4)));
+PK_DEV void ldpair(const double* p, double& a, double& b) {
+    const pk_double2 v = *reinterpret_cast<const pk_double2*>(p);
+    a = v.x;
+    b = v.y;
+}
+PK_DEV void ldpair(const float* p, double& a, double& b) {
+    const pk_float2 v = *reinterpret_cast<const pk_float2*>(p);
+    a = (double)v.x;
+    b = (double)v.y;
+}
+
 // ---- curvilinear point-in-cell (index_search.py:94-239, 439-450) -------------------------------------
 // np.dot(_invA, p): the integer matrix is promoted to float and every product is formed, also 0*p and 1*p
 // (exact for finite p), accumulated left to right.
@@ -236,11 +252,12 @@ PK_DEV void latlon_rad_to_xyz(double lat, double lon, double& X, double& Y, doub
     Z = sl;
 }
 
-PK_DEV void spherical_project(const double clon[4], const double clat[4], double x, double y, double pu[4], double pv[4],
-                              double& xq, double& yq) {
-    double cX[4], cY[4], cZ[4], qX, qY, qZ;
-#pragma unroll
-    for (int k = 0; k < 4; k++) latlon_rad_to_xyz(clat[k] * DEG2RAD, clon[k] * DEG2RAD, cX[k], cY[k], cZ[k]);
+// cX,cY,cZ: unit-sphere coordinates of the 4 corners (index_search.py:197-198), read from the per-node table that the
+// host computed once with the reference's own expression (cos(lon)cos(lat), sin(lon)cos(lat), sin(lat)) instead of
+// 8 sin/cos pairs per evaluation.
+PK_DEV void spherical_project(const double cX[4], const double cY[4], const double cZ[4], double x, double y, double pu[4],
+                              double pv[4], double& xq, double& yq) {
+    double qX, qY, qZ;
     latlon_rad_to_xyz(y * DEG2RAD, x * DEG2RAD, qX, qY, qZ);
     double ux = (cX[1] + cX[2]) - (cX[0] + cX[3]);
     double uy = (cY[1] + cY[2]) - (cY[0] + cY[3]);
@@ -270,13 +287,21 @@ PK_DEV void spherical_project(const double clon[4], const double clat[4], double
 // curvilinear_point_in_cell (index_search.py:94-120); (yi, xi) must be a valid cell
 PK_DEV bool point_in_cell(const DGrid& g, double y, double x, int yi, int xi, double& xsi, double& eta) {
     const int64_t i00 = (int64_t)yi * g.nx + xi, i10 = i00 + g.nx;
-    double clon[4] = {g.lon[i00], g.lon[i00 + 1], g.lon[i10 + 1], g.lon[i10]};
-    double clat[4] = {g.lat[i00], g.lat[i00 + 1], g.lat[i10 + 1], g.lat[i10]};
     if (g.spherical) {
-        double pu[4], pv[4], xq, yq;
-        spherical_project(clon, clat, x, y, pu, pv, xq, yq);
+        const int64_t plane = (int64_t)g.ny * g.nx;
+        const double* X = g.node_xyz;
+        const double* Y = X + plane;
+        const double* Z = Y + plane;
+        double cX[4], cY[4], cZ[4], pu[4], pv[4], xq, yq;
+        ldpair(X + i00, cX[0], cX[1]); ldpair(X + i10, cX[3], cX[2]);
+        ldpair(Y + i00, cY[0], cY[1]); ldpair(Y + i10, cY[3], cY[2]);
+        ldpair(Z + i00, cZ[0], cZ[1]); ldpair(Z + i10, cZ[3], cZ[2]);
+        spherical_project(cX, cY, cZ, x, y, pu, pv, xq, yq);
         bilinear_inverse(pu, pv, xq, yq, xsi, eta);
     } else {
+        double clon[4], clat[4];
+        ldpair(g.lon + i00, clon[0], clon[1]); ldpair(g.lon + i10, clon[3], clon[2]);
+        ldpair(g.lat + i00, clat[0], clat[1]); ldpair(g.lat + i10, clat[3], clat[2]);
         bilinear_inverse(clon, clat, x, y, xsi, eta);
     }
     return (xsi >= 0) && (xsi <= 1) && (eta >= 0) && (eta <= 1);
@@ -446,21 +471,6 @@ PK_DEV bool time_search(const DField& f, const double* time, double t, int hint,
 template <class FT>
 PK_DEV double ldv(const FT* p, int64_t off) { return (double)p[off]; }
 
-// The two x-corners of a cell are adjacent in memory (x is the fastest axis): fetch them with ONE 16-byte (fp64) /
-// 8-byte (fp32) load.  Element alignment is enough: gfx950 global loads handle unaligned dwordx4.
-typedef double pk_double2 __attribute__((ext_vector_type(2), aligned(8)));
-typedef float pk_float2 __attribute__((ext_vector_type(2), aligned(4)));
-PK_DEV void ldpair(const double* p, double& a, double& b) {
-    const pk_double2 v = *reinterpret_cast<const pk_double2*>(p);
-    a = v.x;
-    b = v.y;
-}
-PK_DEV void ldpair(const float* p, double& a, double& b) {
-    const pk_float2 v = *reinterpret_cast<const pk_float2*>(p);
-    a = (double)v.x;
-    b = (double)v.y;
-}
-
 PK_DEV int64_t slot_off(const DField& f, int ti) {
     int s = (f.nslots >= f.nt) ? ti : (ti % f.nslots);
     return (int64_t)s * f.st_t;
@@ -614,8 +624,8 @@ PK_DEV void cgrid_velocity(const DGrid& g, const Coords* mc, const DField& U, co
         py[0] = lat[yi]; py[1] = py[0]; py[2] = lat[yi + 1]; py[3] = py[2];
     } else {
         const int64_t i00 = (int64_t)yi * g.nx + xi, i10 = i00 + g.nx;
-        px[0] = g.lon[i00]; px[1] = g.lon[i00 + 1]; px[2] = g.lon[i10 + 1]; px[3] = g.lon[i10];
-        py[0] = g.lat[i00]; py[1] = g.lat[i00 + 1]; py[2] = g.lat[i10 + 1]; py[3] = g.lat[i10];
+        ldpair(g.lon + i00, px[0], px[1]); ldpair(g.lon + i10, px[3], px[2]);
+        ldpair(g.lat + i00, py[0], py[1]); ldpair(g.lat + i10, py[3], py[2]);
     }
     const bool cf32x = g.lon_f32, cf32 = g.lon_f32 && g.lat_f32;
     if (g.spherical) {  // :230-233

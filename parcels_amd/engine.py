@@ -76,6 +76,12 @@ class DeviceEngine:
         dep64 = np.ascontiguousarray(depth, dtype=np.float64) if depth is not None else None
         d.lon, d.lat, d.depth = _ptr(lon64), _ptr(lat64), _ptr(dep64)
         keep = [lon64, lat64, dep64]
+        if d.kind == 1 and d.spherical:
+            # the reference's own expression (index_search.py:439-450 on deg2rad of the corner lon/lat)
+            lonr, latr = np.deg2rad(lon64), np.deg2rad(lat64)
+            xyz = np.ascontiguousarray(np.stack((np.cos(lonr) * np.cos(latr), np.sin(lonr) * np.cos(latr), np.sin(latr))))
+            keep.append(xyz)
+            d.node_xyz = _ptr(xyz)
         if d.kind == 1:
             t = g.get_spatial_hash().table()
             keys = np.ascontiguousarray(t["keys"], dtype=np.uint32)

@@ -136,20 +136,25 @@ class ParticleSet:
         outputdt = output_file.outputdt if output_file else None
         next_output = None
         if output_file:
+            output_file.set_metadata(self.fieldset.gridset[0]._mesh)
+            output_file.metadata["parcels_kernels"] = self._kernel.funcname
             output_file.write(self, start_time)
             next_output = start_time + outputdt * sign_dt
         time = start_time
-        while sign_dt * (time - end_time) < 0:
-            if next_output is not None:
-                next_time = (min if sign_dt > 0 else max)(next_output, end_time)
-            else:
-                next_time = end_time
-            self._kernel.execute(self, endtime=next_time, dt=dt)
-            if next_output is not None and np.abs(next_time - next_output) < 0.001:
-                output_file.write(self, next_output)
-                if np.isfinite(outputdt):
-                    next_output += outputdt * sign_dt
-            time = next_time
+        from contextlib import nullcontext
+
+        with output_file if output_file is not None else nullcontext():  # the Parquet footer is written on error too
+            while sign_dt * (time - end_time) < 0:
+                if next_output is not None:
+                    next_time = (min if sign_dt > 0 else max)(next_output, end_time)
+                else:
+                    next_time = end_time
+                self._kernel.execute(self, endtime=next_time, dt=dt)
+                if next_output is not None and np.abs(next_time - next_output) < 0.001:
+                    output_file.write(self, next_output)
+                    if np.isfinite(outputdt):
+                        next_output += outputdt * sign_dt
+                time = next_time
 
     def _start_and_end_times(self, runtime, endtime, sign_dt):  # particleset.py:523-585
         ti = self.fieldset.time_interval

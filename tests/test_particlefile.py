@@ -1,0 +1,61 @@
+"""ParticleFile (Parquet) -- host-side write-out (mirrors the reference's tests/test_particlefile.py patterns)."""
+
+import numpy as np
+import pytest
+
+import parcels_amd as pa
+from case_utils import build_fieldset, build_pset, load_golden
+
+
+def _pset():
+    case, _, _ = load_golden("agrid_sph_rk4_f64")
+    fs = build_fieldset(case)
+    return case, fs, build_pset(case, fs)
+
+
+def test_validation(tmp_path):
+    with pytest.raises(ValueError):
+        pa.ParticleFile(tmp_path / "a.zarr", outputdt=3600.0)
+    with pytest.raises(ValueError):
+        pa.ParticleFile(tmp_path / "a.parquet", outputdt=0.0)
+    with pytest.raises(ValueError):
+        pa.ParticleFile(tmp_path / "a.parquet", outputdt=3600)  # int is rejected like the reference
+    (tmp_path / "b.parquet").write_bytes(b"x")
+    with pytest.raises(ValueError):
+        pa.ParticleFile(tmp_path / "b.parquet", outputdt=3600.0)
+    pa.ParticleFile(tmp_path / "b.parquet", outputdt=3600.0, mode="w")
+
+
+def test_write_filter_and_schema(tmp_path):
+    case, fs, pset = _pset()
+    n = len(pset)
+    pset._data["dt"][:] = 3600.0
+    pset._data["t"][: n // 2] = 7200.0  # half of the particles are at the output time
+    pset._data["t"][n // 2 :] = 0.0
+    with pa.ParticleFile(tmp_path / "out.parquet", outputdt=3600.0) as pf:
+        pf.write(pset, 7200.0)
+        pf.write(pset, 0.0)
+        pf.write(pset, 3600.0 * 5)  # nobody
+    df = pa.read_particlefile(tmp_path / "out.parquet")
+    assert list(df.columns) == ["t", "z", "y", "x", "particle_id"]  # to_write variables only (particle.py:129-175)
+    assert len(df) == n
+    first = df.iloc[: n // 2]
+    assert np.all(first["t"] == 7200.0) and np.array_equal(first["particle_id"], np.arange(n // 2))
+    assert df["x"].dtype == np.float64 and df["particle_id"].dtype == np.int64
+
+
+@pytest.mark.gpu
+def test_execute_with_output_file(gpu, tmp_path):
+    case, fs, pset = _pset()
+    n = len(pset)
+    pf = pa.ParticleFile(tmp_path / "traj.parquet", outputdt=6 * 3600.0)
+    pset.execute(pa.AdvectionRK4, dt=3600.0, runtime=24 * 3600.0, output_file=pf)
+    df = pa.read_particlefile(tmp_path / "traj.parquet")
+    assert len(df) == 5 * n  # t = 0, 6, 12, 18, 24 h
+    assert sorted(df["t"].unique()) == [0.0, 21600.0, 43200.0, 64800.0, 86400.0]
+    last = df[df["t"] == 86400.0].sort_values("particle_id")
+    np.testing.assert_array_equal(last["x"].to_numpy(), pset.x)
+    # same trajectory as one uninterrupted execute
+    _, _, p2 = _pset()
+    p2.execute(pa.AdvectionRK4, dt=3600.0, runtime=24 * 3600.0)
+    np.testing.assert_array_equal(p2.x, pset.x)
