@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(256) sort_key_kernel(const DGrid g, const DPar
     unsigned long long zi = 0, h = 0;
     if (g.has_z && g.nz >= 2) zi = (unsigned long long)cell_index(g.depth, g.nz, z, 0);
     if (g.kind == 1) {
-        h = morton_code(g, y, x);  // 30-bit Morton code of the hash grid: neighbouring codes = neighbouring cells
+        h = morton_code(g, make_qpoint(g, y, x));  // 30-bit Morton code of the hash grid: neighbouring codes = neighbouring cells
         keys[i] = (zi << 30) | h;
     } else {
         unsigned long long yi = (g.has_y && g.ny >= 2) ? (unsigned long long)cell_index(g.lat, g.ny, y, 0) : 0;

@@ -99,12 +99,17 @@ static constexpr int LEFT_OUT_OF_BOUNDS = -2;
 static constexpr int RIGHT_OUT_OF_BOUNDS = -1;
 
 // cos() for latitudes.  |x| <= 1.5 rad (86 deg): Cody-Waite reduction by pi/2 + the classic minimax kernels
-// (error < 0.82 ulp, checked against long-double cosl over 2e7 samples); beyond that the library cos.  The reference's
+// (error < 0.82 ulp, checked against long-double cosl over 2e7 samples); beyond that sincos_geo.  The reference's
 // cos is NumPy/libm (<= 1 ulp): any <= 1 ulp cosine is as close to it as another libm would be.  ~20 fp64 ops
 // instead of the generic routine's range reduction.
+PK_DEV void sincos_geo(double x, double& s, double& c);
 PK_DEV double cos_lat(double x) {
     const double ax = fabs(x);
-    if (ax > 1.5) return cos(x);
+    if (ax > 1.5) {  // beyond +-86 degrees (or a stray particle): general reduction, still no library call
+        double s_, c_;
+        sincos_geo(x, s_, c_);
+        return c_;
+    }
     if (ax <= 0.78539816339744830962) {
         const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
                      C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
@@ -243,22 +248,78 @@ PK_DEV void bilinear_inverse(const double px[4], const double py[4], double xq, 
     eta = e;
 }
 
+// sin and cos for angles of geographic size (|x| up to ~1e6 rad): Cody-Waite reduction by n*pi/2 with an 86-bit pi/2
+// (n*pio2_1 is exact for |n| < 2^20) + the classic minimax kernels; < 1 ulp like cos_lat.  The library sincos drags
+// a Payne-Hanek large-argument path (v_trig_preop) into the kernel that longitudes and latitudes never need.
+PK_DEV void sincos_geo(double x, double& s, double& c) {
+    const double pio2_1 = 1.57079632673412561417e+00, pio2_1t = 6.07710050650619224932e-11;
+    const double fn = rint(x * 6.36619772367581382433e-01);
+    double z0 = x - fn * pio2_1;
+    double w = fn * pio2_1t;
+    double r = z0 - w;
+    if (fabs(fn) > 4.0) {  // second Cody-Waite step (119-bit pi/2) once n*pio2_1t is no longer negligible
+        const double pio2_2 = 6.07710050630396597660e-11, pio2_2t = 2.02226624879595063154e-21;
+        const double t2 = z0;
+        w = fn * pio2_2;
+        z0 = t2 - w;
+        w = fn * pio2_2t - ((t2 - z0) - w);
+        r = z0 - w;
+    }
+    const double t = (z0 - r) - w;  // tail
+    const int n = (int)fn;
+    const double z = r * r;
+    // __kernel_sin(r, t)
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double v = z * r;
+    const double rs = fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2);
+    const double ks = r - ((z * (0.5 * t - v * rs) - t) - v * S1);
+    // __kernel_cos(r, t)
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double rc = z * fma(z, fma(z, fma(z, fma(z, fma(z, C6, C5), C4), C3), C2), C1);
+    const double ar = fabs(r);
+    double qx = ar > 0.78125 ? 0.28125 : ar * 0.25;
+    qx = __longlong_as_double(__double_as_longlong(qx) & 0xffffffff00000000ll);
+    if (ar < 0.3) qx = 0.0;
+    const double hz = 0.5 * z - qx, a_ = 1.0 - qx;
+    const double kc = a_ - (hz - (z * rc - r * t));
+    switch (n & 3) {
+        case 0: s = ks; c = kc; break;
+        case 1: s = kc; c = -ks; break;
+        case 2: s = -ks; c = -kc; break;
+        default: s = -kc; c = ks; break;
+    }
+}
+
 PK_DEV void latlon_rad_to_xyz(double lat, double lon, double& X, double& Y, double& Z) {
     double sl, cl, so, co;
-    sincos(lat, &sl, &cl);
-    sincos(lon, &so, &co);
+    sincos_geo(lat, sl, cl);
+    sincos_geo(lon, so, co);
     X = co * cl;
     Y = so * cl;
     Z = sl;
 }
 
-// cX,cY,cZ: unit-sphere coordinates of the 4 corners (index_search.py:197-198), read from the per-node table that the
-// host computed once with the reference's own expression (cos(lon)cos(lat), sin(lon)cos(lat), sin(lat)) instead of
-// 8 sin/cos pairs per evaluation.
-PK_DEV void spherical_project(const double cX[4], const double cY[4], const double cZ[4], double x, double y, double pu[4],
+// query point on the unit sphere (spherical) or in the plane (flat), computed once per evaluation
+struct QPoint {
+    double y, x;        // degrees / metres as given
+    double qX, qY, qZ;  // unit-sphere coordinates (spherical mesh); (x, y, 0) on a flat mesh
+};
+PK_DEV QPoint make_qpoint(const DGrid& g, double y, double x) {
+    QPoint q;
+    q.y = y;
+    q.x = x;
+    if (g.spherical) latlon_rad_to_xyz(y * DEG2RAD, x * DEG2RAD, q.qX, q.qY, q.qZ);
+    else { q.qX = x; q.qY = y; q.qZ = 0.0; }
+    return q;
+}
+
+// _spherical_project_cell_and_query (index_search.py:180-239).  cX,cY,cZ: unit-sphere coordinates of the 4 corners
+// (index_search.py:197-198), read from the per-node table that the host computed once with the reference's own
+// expression (cos(lon)cos(lat), sin(lon)cos(lat), sin(lat)) instead of 8 sin/cos pairs per evaluation.
+PK_DEV void spherical_project(const double cX[4], const double cY[4], const double cZ[4], const QPoint& q, double pu[4],
                               double pv[4], double& xq, double& yq) {
-    double qX, qY, qZ;
-    latlon_rad_to_xyz(y * DEG2RAD, x * DEG2RAD, qX, qY, qZ);
     double ux = (cX[1] + cX[2]) - (cX[0] + cX[3]);
     double uy = (cY[1] + cY[2]) - (cY[0] + cY[3]);
     double uz = (cZ[1] + cZ[2]) - (cZ[0] + cZ[3]);
@@ -280,12 +341,12 @@ PK_DEV void spherical_project(const double cX[4], const double cY[4], const doub
         pu[k] = cX[k] * eux + cY[k] * euy + cZ[k] * euz;
         pv[k] = cX[k] * evx + cY[k] * evy + cZ[k] * evz;
     }
-    xq = qX * eux + qY * euy + qZ * euz;
-    yq = qX * evx + qY * evy + qZ * evz;
+    xq = q.qX * eux + q.qY * euy + q.qZ * euz;
+    yq = q.qX * evx + q.qY * evy + q.qZ * evz;
 }
 
 // curvilinear_point_in_cell (index_search.py:94-120); (yi, xi) must be a valid cell
-PK_DEV bool point_in_cell(const DGrid& g, double y, double x, int yi, int xi, double& xsi, double& eta) {
+PK_DEV bool point_in_cell(const DGrid& g, const QPoint& q, int yi, int xi, double& xsi, double& eta) {
     const int64_t i00 = (int64_t)yi * g.nx + xi, i10 = i00 + g.nx;
     if (g.spherical) {
         const int64_t plane = (int64_t)g.ny * g.nx;
@@ -296,13 +357,13 @@ PK_DEV bool point_in_cell(const DGrid& g, double y, double x, int yi, int xi, do
         ldpair(X + i00, cX[0], cX[1]); ldpair(X + i10, cX[3], cX[2]);
         ldpair(Y + i00, cY[0], cY[1]); ldpair(Y + i10, cY[3], cY[2]);
         ldpair(Z + i00, cZ[0], cZ[1]); ldpair(Z + i10, cZ[3], cZ[2]);
-        spherical_project(cX, cY, cZ, x, y, pu, pv, xq, yq);
+        spherical_project(cX, cY, cZ, q, pu, pv, xq, yq);
         bilinear_inverse(pu, pv, xq, yq, xsi, eta);
     } else {
         double clon[4], clat[4];
         ldpair(g.lon + i00, clon[0], clon[1]); ldpair(g.lon + i10, clon[3], clon[2]);
         ldpair(g.lat + i00, clat[0], clat[1]); ldpair(g.lat + i10, clat[3], clat[2]);
-        bilinear_inverse(clon, clat, x, y, xsi, eta);
+        bilinear_inverse(clon, clat, q.x, q.y, xsi, eta);
     }
     return (xsi >= 0) && (xsi <= 1) && (eta >= 0) && (eta <= 1);
 }
@@ -324,40 +385,55 @@ PK_DEV uint32_t quantize(double v, double vmin, double vmax, int bitwidth) {
     if (q > bitwidth) q = bitwidth;
     return (uint32_t)q;
 }
-PK_DEV uint32_t morton_code(const DGrid& g, double y, double x) {
-    double qx, qy, qz;
-    if (g.spherical) latlon_rad_to_xyz(y * DEG2RAD, x * DEG2RAD, qx, qy, qz);
-    else { qx = x; qy = y; qz = 0.0; }
-    return (dilate_bits(quantize(qz, g.h_bbox[4], g.h_bbox[5], g.h_bitwidth)) << 2) |
-           (dilate_bits(quantize(qy, g.h_bbox[2], g.h_bbox[3], g.h_bitwidth)) << 1) |
-           dilate_bits(quantize(qx, g.h_bbox[0], g.h_bbox[1], g.h_bitwidth));
+PK_DEV uint32_t morton_code(const DGrid& g, const QPoint& q) {
+    return (dilate_bits(quantize(q.qZ, g.h_bbox[4], g.h_bbox[5], g.h_bitwidth)) << 2) |
+           (dilate_bits(quantize(q.qY, g.h_bbox[2], g.h_bbox[3], g.h_bitwidth)) << 1) |
+           dilate_bits(quantize(q.qX, g.h_bbox[0], g.h_bbox[1], g.h_bitwidth));
 }
-// first candidate (table order) whose cell contains the point; coords rounded to float32 like the
-// reference's float32 coords_best buffer (spatialhash.py:505)
-PK_DEV void hash_query(const DGrid& g, double y, double x, int& yi, int& xi, double& xsi, double& eta) {
+
+// _search_indices_curvilinear_2d (index_search.py:242-295) + SpatialHash.query (spatialhash.py:389-535) for one point:
+// candidate -1 is the cell guessed from `ei` (if any), candidates 0.. are the faces of the query's hash cell in table
+// order; the first candidate whose cell contains the point wins.  Hash hits return (xsi, eta) rounded to float32 like the
+// reference's float32 coords_best buffer (spatialhash.py:505).  ONE point-in-cell call site serves both paths.
+PK_DEV void curvilinear_search(const DGrid& g, double y, double x, bool use_guess, int gy, int gx, int& yi, int& xi, double& xsi,
+                               double& eta) {
     yi = GRID_SEARCH_ERROR;
     xi = GRID_SEARCH_ERROR;
     xsi = -1.0;
     eta = -1.0;
-    if (!(isfinite(x) && isfinite(y)) || g.h_nkeys <= 0) return;
-    const uint32_t code = morton_code(g, y, x);
-    int64_t lo = 0, hi = g.h_nkeys;
-    while (lo < hi) {
-        int64_t mid = (lo + hi) >> 1;
-        if (g.h_keys[mid] < code) lo = mid + 1; else hi = mid;
-    }
-    if (lo >= g.h_nkeys || g.h_keys[lo] != code) return;
-    const int64_t s = g.h_starts[lo], c = g.h_counts[lo];
+    const QPoint q = make_qpoint(g, y, x);
+    const bool guess_ok = use_guess && gy >= 0 && gy < g.ny - 1 && gx >= 0 && gx < g.nx - 1;
     const uint32_t ncx = (uint32_t)(g.nx - 1);
-    for (int64_t k = 0; k < c; k++) {
-        uint32_t face = g.h_faces[s + k];
-        int j = (int)(face / ncx), i = (int)(face % ncx);
+    int64_t s = 0, c = -1;  // CSR range of the hash cell, looked up lazily (c < 0: not yet)
+    for (int64_t k = guess_ok ? -1 : 0;; k++) {
+        int j, i;
+        if (k < 0) {
+            j = gy;
+            i = gx;
+        } else {
+            if (c < 0) {  // first hash candidate: locate the query's Morton code in the key table
+                c = 0;
+                if (isfinite(x) && isfinite(y) && g.h_nkeys > 0) {
+                    const uint32_t code = morton_code(g, q);
+                    int64_t lo = 0, hi = g.h_nkeys;
+                    while (lo < hi) {
+                        const int64_t mid = (lo + hi) >> 1;
+                        if (g.h_keys[mid] < code) lo = mid + 1; else hi = mid;
+                    }
+                    if (lo < g.h_nkeys && g.h_keys[lo] == code) { s = g.h_starts[lo]; c = g.h_counts[lo]; }
+                }
+            }
+            if (k >= c) return;
+            const uint32_t face = g.h_faces[s + k];
+            j = (int)(face / ncx);
+            i = (int)(face % ncx);
+        }
         double xs, et;
-        if (point_in_cell(g, y, x, j, i, xs, et)) {
+        if (point_in_cell(g, q, j, i, xs, et)) {
             yi = j;
             xi = i;
-            xsi = (double)(float)xs;
-            eta = (double)(float)et;
+            xsi = k < 0 ? xs : (double)(float)xs;
+            eta = k < 0 ? et : (double)(float)et;
             return;
         }
     }
@@ -430,17 +506,9 @@ PK_DEV void grid_search(const DGrid& g, const Coords* mc, double z, double y, do
     if (g.has_z) search_1d(depth, g.nz, mc ? mc->z0 : g.depth[0], mc ? mc->z1 : g.depth[g.nz - 1], z, g.depth_f32, pos_f32, hint ? c.hz : 0, p.zi, p.zeta);
     else { p.zi = 0; p.zeta = 0.0; }
     if (curv) {
-        bool found = false;
-        if (use_guess) {  // index_search.py:269-274
-            int gy, gx;
-            unravel_yx(g, (int64_t)*ei, gy, gx);
-            double xs = -1.0, et = -1.0;
-            if (gy >= 0 && gy < g.ny - 1 && gx >= 0 && gx < g.nx - 1 && point_in_cell(g, y, x, gy, gx, xs, et)) {
-                p.yi = gy; p.xi = gx; p.xsi = xs; p.eta = et;
-                found = true;
-            }
-        }
-        if (!found) hash_query(g, y, x, p.yi, p.xi, p.xsi, p.eta);
+        int gy = 0, gx = 0;
+        if (use_guess) unravel_yx(g, (int64_t)*ei, gy, gx);  // index_search.py:269-274
+        curvilinear_search(g, y, x, use_guess, gy, gx, p.yi, p.xi, p.xsi, p.eta);
     } else {
         if (g.has_y) search_1d(lat, g.ny, mc ? mc->y0 : g.lat[0], mc ? mc->y1 : g.lat[g.ny - 1], y, g.lat_f32, pos_f32, hint ? c.hy : 0, p.yi, p.eta);
         else { p.yi = 0; p.eta = 0.0; }

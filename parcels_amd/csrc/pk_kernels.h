@@ -331,8 +331,12 @@ PK_DEV unsigned xcd_swizzle(unsigned bid, unsigned nb) {
 #ifndef PK_MIN_WAVES
 #define PK_MIN_WAVES 1
 #endif
+// curvilinear search / C-grid interpolation need more registers: fewer waves, fewer spills
+#ifndef PK_MIN_WAVES_HEAVY
+#define PK_MIN_WAVES_HEAVY 2
+#endif
 template <class FT, int KIND, int INTERP, int KID, bool LDS>
-__global__ void __launch_bounds__(256, PK_MIN_WAVES) advect_kernel(const KArgs a) {
+__global__ void __launch_bounds__(256, (KIND == 1 || INTERP == 1) ? PK_MIN_WAVES_HEAVY : PK_MIN_WAVES) advect_kernel(const KArgs a) {
     extern __shared__ double smem[];
     const DField& mf = a.fields[a.main_field];
     const DGrid& mg = a.grids[a.main_grid];
