@@ -86,7 +86,7 @@ def main():
     ap.add_argument("--particles", type=float, default=1e7, help="particles per GPU")
     ap.add_argument("--sort", type=int, default=1, help="cell-sort the device copy of the particles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=400_000)
+    ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="particles of the CPU-baseline sample (~10-20 s on the host cores)")
     args = ap.parse_args()
 
     import torch
