@@ -127,6 +127,10 @@ typedef struct pk_field_desc {
     int32_t has_time_interval; /* Field.time_interval is not None (field.py:111-116)                */
     int32_t is_const;   /* XConstantField (_xinterpolators.py:156-166): value = data[0,0,0,0]       */
     int32_t nslots;     /* device-resident time levels: >= nt keeps all, else a ring (>= 2)         */
+    int32_t pack_count; /* > 1: this field leads a group of pack_count same-shaped fields (U,V,W of a C-grid)
+                           stored interleaved, one {U,V,W} struct per cell, so that the staggered corner values
+                           of one evaluation share cache lines; 0/1: plain array                            */
+    int32_t pack_leader; /* field id of the group leader this field joins, or -1                            */
     int32_t reserved0;
     const double* time; /* nt level times, seconds since time_interval.left (index_search.py:88)    */
 } pk_field_desc;

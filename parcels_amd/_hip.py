@@ -86,6 +86,8 @@ class FieldDesc(C.Structure):
         ("has_time_interval", C.c_int32),
         ("is_const", C.c_int32),
         ("nslots", C.c_int32),
+        ("pack_count", C.c_int32),
+        ("pack_leader", C.c_int32),
         ("reserved0", C.c_int32),
         ("time", C.c_void_p),
     ]

@@ -35,6 +35,8 @@ struct HostField {
     double* dev_time = nullptr;
     size_t level_bytes = 0;
     std::vector<double> time;
+    bool owns_data = true;   // false for followers of a packed group (the leader owns the interleaved buffer)
+    int pack_used = 1;       // leader: components handed out so far
     std::vector<int32_t> slot_level;    // committed (usable) level per ring slot, -1 = empty
     std::vector<int32_t> slot_pending;  // level being copied into the slot (async upload), -1 = none
 };
@@ -61,6 +63,8 @@ struct pk_ctx {
     uint32_t *d_idx = nullptr, *d_idx_alt = nullptr;
     void* d_sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
+    void* d_pack_tmp = nullptr;  // device staging of one field level before it is interleaved into a packed group
+    size_t pack_tmp_bytes = 0;
     // scratch
     DCounters* d_counters = nullptr;
     unsigned long long* d_summary = nullptr;  // PK_NUM_STATE_CODES counts + 2 ordered-double slots
@@ -210,6 +214,12 @@ __global__ void __launch_bounds__(256) compose_perm_kernel(const int64_t* __rest
     new_perm[i] = old_perm ? old_perm[perm[i]] : (int64_t)perm[i];
 }
 
+// scatter one contiguous field level into its component slot of a packed (array-of-structs) group buffer
+template <class T>
+__global__ void __launch_bounds__(256) interleave_kernel(const T* __restrict__ src, T* __restrict__ dst, int64_t n, int ncomp) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i * ncomp] = src[i];
+}
+
 __global__ void __launch_bounds__(256) copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
 }
@@ -294,10 +304,11 @@ int32_t pk_destroy(pk_ctx* ctx) {
     for (auto& g : ctx->grids)
         for (void* p : g.allocs) (void)hipFree(p);
     for (auto& f : ctx->fields) {
-        if (f.dev_data) (void)hipFree(f.dev_data);
+        if (f.dev_data && f.owns_data) (void)hipFree(f.dev_data);
         if (f.dev_time) (void)hipFree(f.dev_time);
     }
     free_particles(ctx);
+    if (ctx->d_pack_tmp) (void)hipFree(ctx->d_pack_tmp);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_summary) (void)hipFree(ctx->d_summary);
     for (int k = 0; k < 2; k++) {
@@ -357,13 +368,23 @@ int32_t pk_grid_create(pk_ctx* ctx, const pk_grid_desc* desc, int32_t* grid_id) 
     const size_t nlon = desc->kind == 1 ? (size_t)desc->ny * desc->nx : (size_t)desc->nx;
     const size_t nlat = desc->kind == 1 ? (size_t)desc->ny * desc->nx : (size_t)desc->ny;
     int32_t rc;
-    if ((rc = upload(ctx, g, desc->lon, nlon, &d.lon))) return rc;
-    if ((rc = upload(ctx, g, desc->lat, nlat, &d.lat))) return rc;
-    if ((rc = upload(ctx, g, desc->depth, (size_t)desc->nz, &d.depth))) return rc;
-    if (desc->kind == 1 && desc->spherical) {
-        if (!desc->node_xyz) return ctx->fail("spherical curvilinear grid needs node_xyz (unit-sphere node coordinates)");
-        if ((rc = upload(ctx, g, desc->node_xyz, 3 * nlon, &d.node_xyz))) return rc;
+    if (desc->kind == 1) {
+        // array-of-structs node table {lon, lat, X, Y, Z}: one or two cache lines per cell row instead of five planes
+        if (desc->spherical && !desc->node_xyz) return ctx->fail("spherical curvilinear grid needs node_xyz (unit-sphere node coordinates)");
+        std::vector<double> tab(nlon * 5);
+        for (size_t k = 0; k < nlon; k++) {
+            tab[5 * k + 0] = desc->lon[k];
+            tab[5 * k + 1] = desc->lat[k];
+            tab[5 * k + 2] = desc->spherical ? desc->node_xyz[k] : 0.0;
+            tab[5 * k + 3] = desc->spherical ? desc->node_xyz[nlon + k] : 0.0;
+            tab[5 * k + 4] = desc->spherical ? desc->node_xyz[2 * nlon + k] : 0.0;
+        }
+        if ((rc = upload(ctx, g, (const double*)tab.data(), tab.size(), &d.node_tab))) return rc;
+    } else {
+        if ((rc = upload(ctx, g, desc->lon, nlon, &d.lon))) return rc;
+        if ((rc = upload(ctx, g, desc->lat, nlat, &d.lat))) return rc;
     }
+    if ((rc = upload(ctx, g, desc->depth, (size_t)desc->nz, &d.depth))) return rc;
     if (desc->kind == 1) {
         if (!desc->h_keys || desc->h_nkeys <= 0) return ctx->fail("curvilinear grid needs a spatial-hash table");
         if ((rc = upload(ctx, g, desc->h_keys, (size_t)desc->h_nkeys, &d.h_keys))) return rc;
@@ -397,8 +418,23 @@ int32_t pk_field_create(pk_ctx* ctx, const pk_field_desc* desc, int32_t* field_i
     if (nslots < desc->nt && nslots < 2) nslots = 2;
     f.slot_level.assign(nslots, -1);
     f.slot_pending.assign(nslots, -1);
-    PK_HIP(ctx, hipMalloc(&f.dev_data, f.level_bytes * nslots));
-    PK_HIP(ctx, hipMemset(f.dev_data, 0, f.level_bytes * nslots));  // never expose NaN garbage (weight-0 reads)
+    int ncomp = 1, comp = 0;
+    if (desc->pack_leader >= 0) {  // follower: share the leader's interleaved buffer
+        if (desc->pack_leader >= (int)ctx->fields.size() - 1) return ctx->fail("pack_leader must be an existing field");
+        HostField& L = ctx->fields[desc->pack_leader];
+        if (L.d.ncomp <= 1 || L.pack_used >= L.d.ncomp) return ctx->fail("pack leader has no free component");
+        if (L.desc.dtype != desc->dtype || L.desc.nt != desc->nt || L.desc.nz != desc->nz || L.desc.ny != desc->ny ||
+            L.desc.nx != desc->nx || L.d.nslots != nslots)
+            return ctx->fail("packed fields must share dtype, extents and nslots");
+        ncomp = L.d.ncomp;
+        comp = L.pack_used++;
+        f.dev_data = L.dev_data;
+        f.owns_data = false;
+    } else {
+        ncomp = desc->pack_count > 1 ? desc->pack_count : 1;
+        PK_HIP(ctx, hipMalloc(&f.dev_data, f.level_bytes * nslots * ncomp));
+        PK_HIP(ctx, hipMemset(f.dev_data, 0, f.level_bytes * nslots * ncomp));  // never expose NaN garbage (weight-0 reads)
+    }
     f.time.assign(desc->nt, 0.0);
     if (desc->time) std::copy(desc->time, desc->time + desc->nt, f.time.begin());
     PK_HIP(ctx, hipMalloc((void**)&f.dev_time, sizeof(double) * desc->nt));
@@ -411,6 +447,8 @@ int32_t pk_field_create(pk_ctx* ctx, const pk_field_desc* desc, int32_t* field_i
     d.has_time_interval = desc->has_time_interval && desc->nt > 1;
     d.is_const = desc->is_const;
     d.nslots = nslots;
+    d.ncomp = ncomp;
+    d.comp = comp;
     d.st_t = desc->has_t ? (int64_t)level_elems : 0;
     d.st_z = desc->has_z ? (int64_t)desc->ny * desc->nx : 0;
     d.st_y = desc->has_y ? (int64_t)desc->nx : 0;
@@ -432,9 +470,31 @@ int32_t pk_field_upload_level(pk_ctx* ctx, int32_t field_id, int32_t level, cons
     if (level < 0 || level >= f.desc.nt) return ctx->fail("time level out of range");
     PK_HIP(ctx, hipSetDevice(ctx->device));
     const int slot = level % f.d.nslots;
-    char* dst = (char*)f.dev_data + (size_t)slot * f.level_bytes;
+    const int ncomp = f.d.ncomp;
+    const size_t esz = f.desc.dtype == PK_F64 ? 8 : 4;
+    const int64_t level_elems = (int64_t)(f.level_bytes / esz);
+    char* dst = (char*)f.dev_data + ((size_t)slot * f.level_bytes * ncomp) + (size_t)f.d.comp * esz;
+    char* h2d_dst = dst;
+    if (ncomp > 1) {  // packed group: land in a device staging buffer, then interleave on the copy stream
+        if (ctx->pack_tmp_bytes < f.level_bytes) {
+            PK_HIP(ctx, hipStreamSynchronize(ctx->copy));
+            if (ctx->d_pack_tmp) PK_HIP(ctx, hipFree(ctx->d_pack_tmp));
+            PK_HIP(ctx, hipMalloc(&ctx->d_pack_tmp, f.level_bytes));
+            ctx->pack_tmp_bytes = f.level_bytes;
+        }
+        h2d_dst = (char*)ctx->d_pack_tmp;
+    }
+    auto interleave = [&]() -> int32_t {
+        if (ncomp <= 1) return 0;
+        const unsigned grid = (unsigned)std::min<int64_t>((level_elems + 255) / 256, 256 * 32);
+        if (esz == 8) hipLaunchKernelGGL((interleave_kernel<double>), dim3(grid), dim3(256), 0, ctx->copy, (const double*)ctx->d_pack_tmp, (double*)dst, level_elems, ncomp);
+        else hipLaunchKernelGGL((interleave_kernel<float>), dim3(grid), dim3(256), 0, ctx->copy, (const float*)ctx->d_pack_tmp, (float*)dst, level_elems, ncomp);
+        PK_HIP(ctx, hipGetLastError());
+        return 0;
+    };
     if (!async) {
-        PK_HIP(ctx, hipMemcpyAsync(dst, host_data, f.level_bytes, hipMemcpyHostToDevice, ctx->copy));
+        PK_HIP(ctx, hipMemcpyAsync(h2d_dst, host_data, f.level_bytes, hipMemcpyHostToDevice, ctx->copy));
+        if (int32_t rc = interleave()) return rc;
         PK_HIP(ctx, hipStreamSynchronize(ctx->copy));
     } else {
         // pageable NumPy memory cannot be DMA'd asynchronously: bounce through a pinned staging ring (2 buffers)
@@ -452,8 +512,9 @@ int32_t pk_field_upload_level(pk_ctx* ctx, int32_t field_id, int32_t level, cons
             PK_HIP(ctx, hipEventSynchronize(ctx->stage_ev[k]));  // previous DMA out of this buffer finished
         }
         memcpy(ctx->stage[k], host_data, f.level_bytes);
-        PK_HIP(ctx, hipMemcpyAsync(dst, ctx->stage[k], f.level_bytes, hipMemcpyHostToDevice, ctx->copy));
+        PK_HIP(ctx, hipMemcpyAsync(h2d_dst, ctx->stage[k], f.level_bytes, hipMemcpyHostToDevice, ctx->copy));
         PK_HIP(ctx, hipEventRecord(ctx->stage_ev[k], ctx->copy));
+        if (int32_t rc = interleave()) return rc;
     }
     if (async) {  // usable only after pk_field_sync(); the level that lived in this slot is gone as of now
         f.slot_level[slot] = -1;

@@ -28,7 +28,8 @@ struct DGrid {
     const double* lon;
     const double* lat;
     const double* depth;
-    const double* node_xyz;  // curvilinear spherical: unit-sphere (X, Y, Z) of every node, 3 planes of ny*nx
+    const double* node_tab;  // curvilinear: array-of-structs {lon, lat, X, Y, Z} per node (X,Y,Z unit sphere; 0 on a flat mesh):
+                             // the 2 nodes of a cell row are 80 contiguous bytes -> 2 rows = 2-4 cache lines instead of 10
     const uint32_t* h_keys;
     const int64_t* h_starts;
     const int64_t* h_counts;
@@ -43,6 +44,7 @@ struct DField {
     int32_t nt, nz, ny, nx;
     int32_t has_time_interval, is_const;
     int32_t nslots, pad;
+    int32_t ncomp, comp;             // component packing: element (slot, z, y, x) of this field lives at (off * ncomp + comp)
     int64_t st_t, st_z, st_y, st_x;  // element strides (0 for axes the field does not have)
     const void* data;                // nslots * st_t elements (ring of time levels)
     const double* time;              // nt
@@ -347,22 +349,22 @@ PK_DEV void spherical_project(const double cX[4], const double cY[4], const doub
 
 // curvilinear_point_in_cell (index_search.py:94-120); (yi, xi) must be a valid cell
 PK_DEV bool point_in_cell(const DGrid& g, const QPoint& q, int yi, int xi, double& xsi, double& eta) {
-    const int64_t i00 = (int64_t)yi * g.nx + xi, i10 = i00 + g.nx;
+    // node table rows: {lon, lat, X, Y, Z} of node (yi, xi) followed by node (yi, xi+1): 10 contiguous doubles
+    const double* r0 = g.node_tab + ((int64_t)yi * g.nx + xi) * 5;
+    const double* r1 = r0 + (int64_t)g.nx * 5;
     if (g.spherical) {
-        const int64_t plane = (int64_t)g.ny * g.nx;
-        const double* X = g.node_xyz;
-        const double* Y = X + plane;
-        const double* Z = Y + plane;
-        double cX[4], cY[4], cZ[4], pu[4], pv[4], xq, yq;
-        ldpair(X + i00, cX[0], cX[1]); ldpair(X + i10, cX[3], cX[2]);
-        ldpair(Y + i00, cY[0], cY[1]); ldpair(Y + i10, cY[3], cY[2]);
-        ldpair(Z + i00, cZ[0], cZ[1]); ldpair(Z + i10, cZ[3], cZ[2]);
+        double cX[4], cY[4], cZ[4], pu[4], pv[4], xq, yq, t0_, t1_;
+        // corner order c0=(yi,xi) c1=(yi,xi+1) c2=(yi+1,xi+1) c3=(yi+1,xi)
+        ldpair(r0 + 2, cX[0], cY[0]); ldpair(r0 + 4, cZ[0], t0_);  // t0_ = lon of the next node (unused)
+        ldpair(r0 + 6, t1_, cX[1]);   ldpair(r0 + 8, cY[1], cZ[1]);
+        ldpair(r1 + 2, cX[3], cY[3]); ldpair(r1 + 4, cZ[3], t0_);
+        ldpair(r1 + 6, t1_, cX[2]);   ldpair(r1 + 8, cY[2], cZ[2]);
         spherical_project(cX, cY, cZ, q, pu, pv, xq, yq);
         bilinear_inverse(pu, pv, xq, yq, xsi, eta);
     } else {
         double clon[4], clat[4];
-        ldpair(g.lon + i00, clon[0], clon[1]); ldpair(g.lon + i10, clon[3], clon[2]);
-        ldpair(g.lat + i00, clat[0], clat[1]); ldpair(g.lat + i10, clat[3], clat[2]);
+        ldpair(r0, clon[0], clat[0]); ldpair(r0 + 5, clon[1], clat[1]);
+        ldpair(r1, clon[3], clat[3]); ldpair(r1 + 5, clon[2], clat[2]);
         bilinear_inverse(clon, clat, q.x, q.y, xsi, eta);
     }
     return (xsi >= 0) && (xsi <= 1) && (eta >= 0) && (eta <= 1);
@@ -539,9 +541,10 @@ PK_DEV bool time_search(const DField& f, const double* time, double t, int hint,
 template <class FT>
 PK_DEV double ldv(const FT* p, int64_t off) { return (double)p[off]; }
 
+// element offset of time level `ti` inside the field's (possibly component-packed) buffer, including the component
 PK_DEV int64_t slot_off(const DField& f, int ti) {
     int s = (f.nslots >= f.nt) ? ti : (ti % f.nslots);
-    return (int64_t)s * f.st_t;
+    return (int64_t)s * f.st_t * f.ncomp + f.comp;
 }
 
 // Element offsets of the 16 bracketing corners (_gather_corners / _get_corner_data_Agrid, _xinterpolators.py:25-96),
@@ -559,12 +562,13 @@ PK_DEV Corners make_corners(const DField& f, const GPos& p) {
     k.lenZ = p.zeta > 0;
     k.ot0 = slot_off(f, p.ti);
     k.ot1 = slot_off(f, mini(p.ti + 1, f.nt - 1));
-    const int sz = (int)f.st_z, sy = (int)f.st_y, sx = (int)f.st_x;
+    const int nc = f.ncomp;
+    const int sz = (int)f.st_z * nc, sy = (int)f.st_y * nc, sx = (int)f.st_x * nc;
     const int oz0 = p.zi * sz, oz1 = mini(p.zi + 1, f.nz - 1) * sz;
     const int oy0 = p.yi * sy, oy1 = mini(p.yi + 1, f.ny - 1) * sy;
     const int ox0 = p.xi * sx;
     k.dx = mini(p.xi + 1, f.nx - 1) * sx - ox0;
-    k.pairs = (f.st_x == 1) && (f.nx >= 2);  // then xi <= nx-2 for every in-bounds lane, so x1 == x0 + 1
+    k.pairs = (f.st_x == 1) && (f.nx >= 2) && (nc == 1);  // then xi <= nx-2 for every in-bounds lane, so x1 == x0 + 1
     k.o[0][0] = oz0 + oy0 + ox0;
     k.o[0][1] = oz0 + oy1 + ox0;
     k.o[1][0] = oz1 + oy0 + ox0;
@@ -572,7 +576,7 @@ PK_DEV Corners make_corners(const DField& f, const GPos& p) {
     return k;
 }
 PK_DEV bool same_layout(const DField& a, const DField& b) {
-    return a.st_t == b.st_t && a.st_z == b.st_z && a.st_y == b.st_y && a.st_x == b.st_x && a.nt == b.nt && a.nz == b.nz &&
+    return a.ncomp == 1 && b.ncomp == 1 && a.st_t == b.st_t && a.st_z == b.st_z && a.st_y == b.st_y && a.st_x == b.st_x && a.nt == b.nt && a.nz == b.nz &&
            a.ny == b.ny && a.nx == b.nx && a.nslots == b.nslots;
 }
 template <class FT>
@@ -652,8 +656,8 @@ PK_DEV void cgrid_pair(const DField& f, const GPos& p, int zA, int yA, int xA, i
     const FT* d = (const FT*)f.data;
     const bool lenT = p.tau > 0;
     const int64_t ot0 = slot_off(f, p.ti);
-    const int64_t offA = (int64_t)zA * f.st_z + (int64_t)yA * f.st_y + (int64_t)xA * f.st_x;
-    const int64_t offB = (int64_t)zB * f.st_z + (int64_t)yB * f.st_y + (int64_t)xB * f.st_x;
+    const int64_t offA = ((int64_t)zA * f.st_z + (int64_t)yA * f.st_y + (int64_t)xA * f.st_x) * f.ncomp;
+    const int64_t offB = ((int64_t)zB * f.st_z + (int64_t)yB * f.st_y + (int64_t)xB * f.st_x) * f.ncomp;
     double a = ldv(d, ot0 + offA), b = ldv(d, ot0 + offB);
     if (lenT) {
         const int64_t ot1 = slot_off(f, mini(p.ti + 1, f.nt - 1));
@@ -691,9 +695,10 @@ PK_DEV void cgrid_velocity(const DGrid& g, const Coords* mc, const DField& U, co
         px[0] = lon[xi]; px[1] = lon[xi + 1]; px[2] = px[1]; px[3] = px[0];
         py[0] = lat[yi]; py[1] = py[0]; py[2] = lat[yi + 1]; py[3] = py[2];
     } else {
-        const int64_t i00 = (int64_t)yi * g.nx + xi, i10 = i00 + g.nx;
-        ldpair(g.lon + i00, px[0], px[1]); ldpair(g.lon + i10, px[3], px[2]);
-        ldpair(g.lat + i00, py[0], py[1]); ldpair(g.lat + i10, py[3], py[2]);
+        const double* r0 = g.node_tab + ((int64_t)yi * g.nx + xi) * 5;  // same lines the point-in-cell test just read
+        const double* r1 = r0 + (int64_t)g.nx * 5;
+        ldpair(r0, px[0], py[0]); ldpair(r0 + 5, px[1], py[1]);
+        ldpair(r1, px[3], py[3]); ldpair(r1 + 5, px[2], py[2]);
     }
     const bool cf32x = g.lon_f32, cf32 = g.lon_f32 && g.lat_f32;
     if (g.spherical) {  // :230-233
@@ -840,7 +845,7 @@ PK_DEV double eval_scalar(const KArgs& a, const Coords& mc, PCtx& c, int fidx, d
     ei_set(c, f.grid, ei);
     double v = 0.0;
     if (!(p.xi < 0 || p.yi < 0 || p.zi < 0)) {
-        if (f.is_const) v = (f.dtype == PK_F64) ? ((const double*)f.data)[0] : (double)((const float*)f.data)[0];
+        if (f.is_const) v = (f.dtype == PK_F64) ? ((const double*)f.data)[f.comp] : (double)((const float*)f.data)[f.comp];
         else v = (f.dtype == PK_F64) ? xlinear<double>(f, p) : xlinear<float>(f, p);
     }
     return finish_value(c, p, v);

@@ -133,10 +133,30 @@ class DeviceEngine:
                 ns = max(4, min(nt, int(budget // max(level_bytes, 1))))
                 ns = nt if h.shape[0] == 1 else min(ns, nt)
             self.field_nslots[f.name] = ns
+        # C-grid velocity components are stored interleaved ({U,V,W} per cell): the staggered corner values of one
+        # evaluation then share cache lines, which is what bounds the sparse NEMO-size configuration
+        pack: dict[str, tuple[str, int]] = {}  # field name -> (leader name, group size)
+        for vf in fs.fields.values():
+            if isinstance(vf, VectorField) and isinstance(vf.interp_method, CGrid_Velocity):
+                comps = [c for c in (vf.U, vf.V, vf.W) if c is not None]
+                same = all(hosts[c.name].shape == hosts[comps[0].name].shape and hosts[c.name].dtype == hosts[comps[0].name].dtype
+                           and self.field_nslots[c.name] == self.field_nslots[comps[0].name] for c in comps)
+                if same and len(comps) >= len([1 for c in comps if pack.get(c.name, (None, 0))[1] >= len(comps)]) and len(comps) > 1:
+                    if all(pack.get(c.name, (None, 0))[1] < len(comps) for c in comps):
+                        order = [f.name for f in self.scalar_fields if f.name in {c.name for c in comps}]
+                        for nme in order:
+                            pack[nme] = (order[0], len(order))
         for f in self.scalar_fields:
             h = hosts[f.name]
             dims = f.data.dims
             d = _hip.FieldDesc()
+            d.pack_leader = -1
+            if f.name in pack:
+                leader, cnt = pack[f.name]
+                if leader == f.name:
+                    d.pack_count = cnt
+                else:
+                    d.pack_leader = self.field_ids[leader]
             d.grid = self.grid_ids[self.grids.index(f.grid)]
             d.dtype = _hip.PK_F64 if h.dtype == np.float64 else _hip.PK_F32
             d.nt, d.nz, d.ny, d.nx = h.shape

@@ -31,7 +31,7 @@ def test_ctypes_structs_match_header_layout():
 
     # sizes computed from the C declarations (all members naturally aligned)
     assert C.sizeof(_hip.GridDesc) == 18 * 4 + 8 + 8 * 8 + 2 * 8 + 2 * 4 + 6 * 8
-    assert C.sizeof(_hip.FieldDesc) == 14 * 4 + 8
+    assert C.sizeof(_hip.FieldDesc) == 16 * 4 + 8
     assert C.sizeof(_hip.ParticlesDesc) == 8 + 2 * 4 + 12 * 8
     assert C.sizeof(_hip.ExecParams) == (1 + 8 + 11) * 4 + 6 * 8 + 8
     assert C.sizeof(_hip.ExecStats) == 3 * 8 + 80 * 8 + 4 * 8 + 2 * 4
