@@ -181,7 +181,9 @@ __global__ void __launch_bounds__(256) sort_key_kernel(const DGrid g, const DPar
     unsigned long long zi = 0, h = 0;
     if (g.has_z && g.nz >= 2) zi = (unsigned long long)cell_index(g.depth, g.nz, z, 0);
     if (g.kind == 1) {
-        h = morton_code(g, make_qpoint(g, y, x));  // 30-bit Morton code of the hash grid: neighbouring codes = neighbouring cells
+        // depth-major like the field layout, then the 30-bit Morton code of the hash grid (neighbouring codes = neighbouring
+        // cells).  Measured on C3: depth-major 295 ms vs horizontal-major 308 ms per 3.6e8 particle-steps.
+        h = morton_code(g, make_qpoint(g, y, x));
         keys[i] = (zi << 30) | h;
     } else {
         unsigned long long yi = (g.has_y && g.ny >= 2) ? (unsigned long long)cell_index(g.lat, g.ny, y, 0) : 0;
