@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -74,6 +75,8 @@ struct pk_ctx {
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
     int stage_next = 0;
     hipDeviceProp_t prop;
+    int sort_horizontal_major = -1;  // tuning knobs (environment: PK_SORT_HORIZONTAL = 0/1 forces, PK_NO_SPECIAL)
+    int no_special = 0;
 
     int32_t fail(const char* where, hipError_t e) {
         err = std::string(where) + ": " + hipGetErrorString(e);
@@ -171,7 +174,8 @@ __global__ void __launch_bounds__(256) search_kernel(const DGrid g, int64_t m, c
 // ---- cell sort ----------------------------------------------------------------------------------------
 // key = linear cell index of the particle's current position on the main grid (z-major like the field layout),
 // so that the 64 lanes of a wavefront gather from neighbouring cells (coalesced, L2-friendly).
-__global__ void __launch_bounds__(256) sort_key_kernel(const DGrid g, const DParticles P, unsigned long long* keys, uint32_t* idx) {
+__global__ void __launch_bounds__(256) sort_key_kernel(const DGrid g, const DParticles P, unsigned long long* keys, uint32_t* idx,
+                                                       int horizontal_major) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= P.n) return;
     const bool pf = P.spatial_f32 != 0;
@@ -184,7 +188,7 @@ __global__ void __launch_bounds__(256) sort_key_kernel(const DGrid g, const DPar
         // depth-major like the field layout, then the 30-bit Morton code of the hash grid (neighbouring codes = neighbouring
         // cells).  Measured on C3: depth-major 295 ms vs horizontal-major 308 ms per 3.6e8 particle-steps.
         h = morton_code(g, make_qpoint(g, y, x));
-        keys[i] = (zi << 30) | h;
+        keys[i] = horizontal_major ? ((h << 12) | (zi & 0xFFFull)) : ((zi << 30) | h);
     } else {
         unsigned long long yi = (g.has_y && g.ny >= 2) ? (unsigned long long)cell_index(g.lat, g.ny, y, 0) : 0;
         unsigned long long xi = (g.has_x && g.nx >= 2) ? (unsigned long long)cell_index(g.lon, g.nx, x, 0) : 0;
@@ -263,6 +267,8 @@ int32_t pk_init(int32_t device, pk_ctx** out) {
     }
     pk_ctx* ctx = new pk_ctx();
     ctx->device = device;
+    if (const char* e = getenv("PK_SORT_HORIZONTAL")) ctx->sort_horizontal_major = atoi(e);
+    if (const char* e = getenv("PK_NO_SPECIAL")) ctx->no_special = atoi(e);
     *out = ctx;
     PK_HIP(ctx, hipSetDevice(device));
     PK_HIP(ctx, hipGetDeviceProperties(&ctx->prop, device));
@@ -659,7 +665,7 @@ static int bits_for(unsigned long long v) {
 }
 
 // Reorder the device rows by cell key (host row order is restored by pk_particles_d2h through d_perm).
-static int32_t sort_particles(pk_ctx* ctx, int main_grid) {
+static int32_t sort_particles(pk_ctx* ctx, int main_grid, int horizontal_major) {
     const int64_t n = ctx->dev.n;
     if (n < 2) return 0;
     if (n >= (1ll << 32)) return ctx->fail("cell sort supports < 2^32 particles per device");
@@ -667,11 +673,11 @@ static int32_t sort_particles(pk_ctx* ctx, int main_grid) {
     if (rc) return rc;
     const DGrid& g = ctx->grids[main_grid].d;
     const dim3 grid((unsigned)((n + 255) / 256));
-    hipLaunchKernelGGL(sort_key_kernel, grid, dim3(256), 0, ctx->compute, g, ctx->dev, ctx->d_keys, ctx->d_idx);
+    hipLaunchKernelGGL(sort_key_kernel, grid, dim3(256), 0, ctx->compute, g, ctx->dev, ctx->d_keys, ctx->d_idx, horizontal_major);
     PK_HIP(ctx, hipGetLastError());
     unsigned long long kmax;
     const unsigned long long nzc = (g.has_z && g.nz >= 2) ? (unsigned long long)g.nz : 1ull;
-    if (g.kind == 1) kmax = (nzc << 30) | 0x3FFFFFFFull;
+    if (g.kind == 1) kmax = horizontal_major ? ((0x3FFFFFFFull << 12) | 0xFFFull) : ((nzc << 30) | 0x3FFFFFFFull);
     else kmax = nzc * (unsigned long long)std::max(g.ny, 1) * (unsigned long long)std::max(g.nx, 1);
     const unsigned end_bit = (unsigned)bits_for(kmax);
     size_t tmp_bytes = 0;
@@ -841,10 +847,18 @@ int32_t pk_execute(pk_ctx* ctx, const pk_exec_params* prm, pk_exec_stats* stats)
         if (rest_policy && use_lds) {
             if (prm->kernels[0] == PK_KERNEL_ADVECTION_RK4) prog = PROG_RK4;
             if (prm->kernels[0] == PK_KERNEL_ADVECTION_RK4_3D) prog = PROG_RK4_3D;
+            if (prm->kernels[0] == PK_KERNEL_ADVECTION_RK45 && !ctx->no_special) prog = PROG_RK45;
+            if (prm->kernels[0] == PK_KERNEL_ADVECTIONDIFFUSION_M1 && !ctx->no_special) prog = PROG_M1;
         }
         if (prm->sort_by_cell) {
             PK_HIP(ctx, hipEventRecord(ctx->ev2, ctx->compute));
-            rc = sort_particles(ctx, a.main_grid);
+            // curvilinear sort order (measured on the NEMO-size grid): depth-major for 3-D advection (+4 %), horizontal-major
+            // (water columns share node-table lines) for 2-D kernels (RK45 +18 %, M1 +28 %); PK_SORT_HORIZONTAL overrides
+            int horizontal = 1;
+            for (int k = 0; k < prm->nk; k++)
+                if (prm->kernels[k] == PK_KERNEL_ADVECTION_RK4_3D || prm->kernels[k] == PK_KERNEL_ADVECTION_RK2_3D) horizontal = 0;
+            if (ctx->sort_horizontal_major >= 0) horizontal = ctx->sort_horizontal_major;
+            rc = sort_particles(ctx, a.main_grid, horizontal);
             if (rc) return rc;
             a.p = ctx->dev;  // the column pointers were swapped
             sorted = true;
@@ -853,6 +867,8 @@ int32_t pk_execute(pk_ctx* ctx, const pk_exec_params* prm, pk_exec_stats* stats)
         switch (prog) {
             case PROG_RK4: launch_program<PROG_RK4>(field_f32, curv, prm->interp_uv, use_lds, a, grid, lds_bytes, ctx->compute); break;
             case PROG_RK4_3D: launch_program<PROG_RK4_3D>(field_f32, curv, prm->interp_uv, use_lds, a, grid, lds_bytes, ctx->compute); break;
+            case PROG_RK45: launch_program<PROG_RK45>(field_f32, curv, prm->interp_uv, use_lds, a, grid, lds_bytes, ctx->compute); break;
+            case PROG_M1: launch_program<PROG_M1>(field_f32, curv, prm->interp_uv, use_lds, a, grid, lds_bytes, ctx->compute); break;
             default: launch_program<PROG_GENERIC>(field_f32, curv, prm->interp_uv, use_lds, a, grid, lds_bytes, ctx->compute); break;
         }
         PK_HIP(ctx, hipGetLastError());

@@ -17,7 +17,7 @@
 namespace pk {
 
 // programs: a single built-in kernel fixed at compile time, or the generic kernel-list interpreter
-enum Program { PROG_RK4 = 0, PROG_RK4_3D = 1, PROG_GENERIC = 2 };
+enum Program { PROG_RK4 = 0, PROG_RK4_3D = 1, PROG_GENERIC = 2, PROG_RK45 = 3, PROG_M1 = 4 };
 
 struct PState {
     double t, z, y, x, dz, dy, dx, dt, next_dt;
