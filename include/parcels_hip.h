@@ -162,6 +162,21 @@ typedef struct pk_particles_desc {
 int32_t pk_particles_bind(pk_ctx* ctx, const pk_particles_desc* host); /* remember host columns, size device columns */
 int32_t pk_particles_h2d(pk_ctx* ctx);
 int32_t pk_particles_d2h(pk_ctx* ctx);
+/* copy back only the selected columns (bit k = k-th column in the order t,z,y,x,dz,dy,dx,dt,next_dt,state,ei,particle_id):
+ * the periodic write-out needs the to_write columns only (particlefile.py:142-180), the rest stays device-resident */
+#define PK_COL_T 0x001u
+#define PK_COL_Z 0x002u
+#define PK_COL_Y 0x004u
+#define PK_COL_X 0x008u
+#define PK_COL_DZ 0x010u
+#define PK_COL_DY 0x020u
+#define PK_COL_DX 0x040u
+#define PK_COL_DT 0x080u
+#define PK_COL_NEXT_DT 0x100u
+#define PK_COL_STATE 0x200u
+#define PK_COL_EI 0x400u
+#define PK_COL_PARTICLE_ID 0x800u
+int32_t pk_particles_d2h_columns(pk_ctx* ctx, uint32_t column_mask);
 /* device pointers of the bound columns in CURRENT device order (for RCCL all-gather of the output
  * columns at write-out; see parcels_amd/distributed.py).  perm (int64*, may be NULL when the particles
  * have not been cell-sorted) maps device row -> original row. */

@@ -15,6 +15,8 @@ LIB_PATH = os.environ.get("PARCELS_HIP_LIB", os.path.join(_HERE, "libparcels_hip
 
 PK_F32, PK_F64 = 0, 1
 PK_MAX_GRIDS, PK_MAX_FIELDS, PK_MAX_KERNELS, PK_NUM_STATE_CODES = 4, 8, 8, 80
+COLUMN_BITS = {n: 1 << i for i, n in enumerate(
+    ["t", "z", "y", "x", "dz", "dy", "dx", "dt", "next_dt", "state", "ei", "particle_id"])}
 
 
 class HipLibraryError(RuntimeError):
@@ -168,6 +170,7 @@ ABI_SYMBOLS = [
     "pk_particles_bind",
     "pk_particles_h2d",
     "pk_particles_d2h",
+    "pk_particles_d2h_columns",
     "pk_particles_device",
     "pk_execute",
     "pk_eval",
@@ -214,6 +217,7 @@ def load():
     lib.pk_particles_bind.argtypes = [C.c_void_p, C.POINTER(ParticlesDesc)]
     lib.pk_particles_h2d.argtypes = [C.c_void_p]
     lib.pk_particles_d2h.argtypes = [C.c_void_p]
+    lib.pk_particles_d2h_columns.argtypes = [C.c_void_p, C.c_uint32]
     lib.pk_particles_device.argtypes = [C.c_void_p, C.POINTER(ParticlesDesc), C.POINTER(C.c_void_p)]
     lib.pk_execute.argtypes = [C.c_void_p, C.POINTER(ExecParams), C.POINTER(ExecStats)]
     lib.pk_eval.argtypes = [C.c_void_p, C.POINTER(ExecParams), C.c_int32, C.c_int64] + [C.c_void_p] * 8

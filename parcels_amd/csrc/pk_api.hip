@@ -707,14 +707,16 @@ static int32_t sort_particles(pk_ctx* ctx, int main_grid, int horizontal_major) 
     return 0;
 }
 
-static int32_t copy_particles(pk_ctx* ctx, bool to_device) {
+static int32_t copy_particles(pk_ctx* ctx, bool to_device, uint32_t mask = 0xFFFFFFFFu) {
     if (!ctx->bound) return ctx->fail("no particles bound");
     PK_HIP(ctx, hipSetDevice(ctx->device));
     const int64_t n = ctx->host.n;
     if (n == 0) return 0;
     if (to_device) ctx->has_perm = false;  // host order
+    int bit = 0;
     for (const ColRef& c : particle_columns(ctx)) {
-        if (!c.h || !c.d) continue;
+        const bool selected = (mask >> bit++) & 1u;
+        if (!c.h || !c.d || !selected) continue;
         const size_t bytes = (size_t)n * c.elem * c.width;
         if (to_device) {
             PK_HIP(ctx, hipMemcpyAsync(c.d, c.h, bytes, hipMemcpyHostToDevice, ctx->compute));
@@ -739,6 +741,10 @@ int32_t pk_particles_h2d(pk_ctx* ctx) {
 int32_t pk_particles_d2h(pk_ctx* ctx) {
     if (!ctx) return -2;
     return copy_particles(ctx, false);
+}
+int32_t pk_particles_d2h_columns(pk_ctx* ctx, uint32_t mask) {
+    if (!ctx) return -2;
+    return copy_particles(ctx, false, mask);
 }
 
 int32_t pk_particles_device(pk_ctx* ctx, pk_particles_desc* dev, int64_t** perm) {

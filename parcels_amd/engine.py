@@ -270,8 +270,15 @@ class DeviceEngine:
     def h2d(self):
         self.ctx.check(self.lib.pk_particles_h2d(self.ctx.handle), "pk_particles_h2d")
 
-    def d2h(self):
-        self.ctx.check(self.lib.pk_particles_d2h(self.ctx.handle), "pk_particles_d2h")
+    def d2h(self, columns=None):
+        """Copy the particle columns back to the bound NumPy arrays (all, or only the named ones)."""
+        if columns is None:
+            self.ctx.check(self.lib.pk_particles_d2h(self.ctx.handle), "pk_particles_d2h")
+            return
+        mask = 0
+        for name in columns:
+            mask |= _hip.COLUMN_BITS[name]
+        self.ctx.check(self.lib.pk_particles_d2h_columns(self.ctx.handle, mask), "pk_particles_d2h_columns")
 
     # ---- execution -------------------------------------------------------------------------------------------
     def make_params(self, kernel_ids, *, endtime, dt0, context=None, seed=0, reset_state=1, have_guess0=0, sort_by_cell=0):

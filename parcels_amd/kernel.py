@@ -95,32 +95,51 @@ class Kernel:
         if kernel in (_k.AdvectionRK4_3D, _k.AdvectionRK2_3D) and "UVW" not in fs.fields:
             raise ValueError(f"{kernel.__name__} needs a W field (UVW)")
 
-    def execute(self, pset, endtime, dt):
-        """Advance every particle to ``endtime`` on the device (kernel.py:174-247)."""
-        if len(pset) == 0:
-            return StatusCode.Success
+    def _have_guess0(self, data) -> int:
+        g0 = self.fieldset.gridset[0]
+        if g0.is_curvilinear and "X" in g0.axes:  # np.any(xi) over the guesses (index_search.py:269)
+            xdim = max(g0.xdim, 1)
+            return int(np.any(np.mod(data["ei"][:, 0].astype(np.int64), xdim) != 0))
+        return 0
+
+    def launch(self, pset, endtime, dt, have_guess0=0):
+        """Device part of Kernel.execute: advance the BOUND, device-resident particle columns to ``endtime``.
+        No host<->device copies; returns the engine statistics (steps, state histogram, kernel time)."""
         engine = pset._engine()
         data = pset._data
         if "RK45_tol" in self.fieldset.context and "next_dt" not in data:
             # kernel.py:118-120: `particles.dt = particles.next_dt` runs whenever the fieldset has RK45_tol
             raise KeyError("next_dt: fieldset.context has RK45_tol (RK45 mode) but the ParticleClass has no next_dt Variable")
         sign = 1 if dt > 0 else -1
-        t = data["t"]
-        t_start = float(np.nanmin(t) if sign > 0 else np.nanmax(t))
-        have_guess0 = 0
-        g0 = self.fieldset.gridset[0]
-        if g0.is_curvilinear and "X" in g0.axes:  # np.any(xi) over the guesses (index_search.py:269)
-            xdim = max(g0.xdim, 1)
-            have_guess0 = int(np.any(np.mod(data["ei"][:, 0].astype(np.int64), xdim) != 0))
-        engine.bind_particles(data)
-        engine.h2d()
+        t_start = pset._t_live if getattr(pset, "_t_live", None) is not None else float(np.nanmin(data["t"]) if sign > 0 else np.nanmax(data["t"]))
         stats = engine.execute(self.kernel_ids, endtime=endtime, dt0=dt, context=self.fieldset.context, seed=pset.seed,
                                have_guess0=have_guess0, sort_by_cell=int(pset.sort_by_cell), t_start=t_start)
-        engine.d2h()
         pset._last_stats = stats
-        # delete particles that signalled deletion (kernel.py:98-106); relative order is preserved
+        return stats
+
+    @staticmethod
+    def needs_host_pass(stats) -> bool:
+        """Deletions must be compacted and error codes raised on the host (kernel.py:233-245)."""
+        sc = stats["state_counts"]
+        return any(code in sc for code in (StatusCode.Delete, StatusCode.StopAllExecution, *[c for c in sc if c >= StatusCode.Error]))
+
+    def finish_on_host(self, pset):
+        """kernel.py:233-245 after the columns are back on the host: compact deleted particles, raise error codes."""
+        data = pset._data
         deleted = data["state"] == StatusCode.Delete
         if np.any(deleted):
             pset.remove_indices(np.where(deleted)[0])
         raise_particle_errors(pset._data)
+
+    def execute(self, pset, endtime, dt):
+        """Advance every particle to ``endtime`` on the device (kernel.py:174-247), host columns in, host columns out."""
+        if len(pset) == 0:
+            return StatusCode.Success
+        engine = pset._engine()
+        pset._t_live = None
+        engine.bind_particles(pset._data)
+        engine.h2d()
+        self.launch(pset, endtime, dt, have_guess0=self._have_guess0(pset._data))
+        engine.d2h()
+        self.finish_on_host(pset)
         return pset

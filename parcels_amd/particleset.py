@@ -42,6 +42,7 @@ class ParticleSet:
         self.seed = int(seed)
         self.sort_by_cell = bool(sort_by_cell)
         self._last_stats = None
+        self._t_live = None
         t = np.empty(shape=0) if t is None else np.array(t).flatten()
         y = np.empty(shape=0) if y is None else np.array(y).flatten()
         x = np.empty(shape=0) if x is None else np.array(x).flatten()
@@ -143,18 +144,49 @@ class ParticleSet:
         time = start_time
         from contextlib import nullcontext
 
-        with output_file if output_file is not None else nullcontext():  # the Parquet footer is written on error too
-            while sign_dt * (time - end_time) < 0:
-                if next_output is not None:
-                    next_time = (min if sign_dt > 0 else max)(next_output, end_time)
-                else:
-                    next_time = end_time
-                self._kernel.execute(self, endtime=next_time, dt=dt)
-                if next_output is not None and np.abs(next_time - next_output) < 0.001:
-                    output_file.write(self, next_output)
-                    if np.isfinite(outputdt):
-                        next_output += outputdt * sign_dt
-                time = next_time
+        # The particle columns stay DEVICE-RESIDENT for the whole call: one upload here, one download at the end; an
+        # output interval copies back only the columns the ParticleFile writes.  (The reference re-reads every column
+        # through ParticleSetView on every step, particlesetview.py:97-301.)
+        engine = self._engine()
+        kern = self._kernel
+        self._t_live = None
+        engine.bind_particles(self._data)
+        engine.h2d()
+        have_guess0 = kern._have_guess0(self._data)
+        out_cols = None
+        if output_file is not None:
+            out_cols = sorted({v.name for v in self._pclass.variables if v.to_write is not False} | {"t", "dt", "state", "particle_id"})
+        synced = True
+        try:
+            with output_file if output_file is not None else nullcontext():  # the Parquet footer is written on error too
+                while sign_dt * (time - end_time) < 0:
+                    if next_output is not None:
+                        next_time = (min if sign_dt > 0 else max)(next_output, end_time)
+                    else:
+                        next_time = end_time
+                    stats = kern.launch(self, next_time, dt, have_guess0=have_guess0)
+                    have_guess0 = 1
+                    synced = False
+                    self._t_live = next_time if not np.isnan(next_time) else None
+                    if kern.needs_host_pass(stats):
+                        engine.d2h()
+                        synced = True
+                        kern.finish_on_host(self)  # compacts / raises
+                        if len(self) == 0:
+                            break
+                        engine.bind_particles(self._data)
+                        engine.h2d()
+                    if next_output is not None and np.abs(next_time - next_output) < 0.001:
+                        if not synced:
+                            engine.d2h(out_cols)
+                        output_file.write(self, next_output)
+                        if np.isfinite(outputdt):
+                            next_output += outputdt * sign_dt
+                    time = next_time
+        finally:
+            if not synced and len(self) > 0:
+                engine.d2h()
+            self._t_live = None
 
     def _start_and_end_times(self, runtime, endtime, sign_dt):  # particleset.py:523-585
         ti = self.fieldset.time_interval

@@ -59,3 +59,29 @@ def test_execute_with_output_file(gpu, tmp_path):
     _, _, p2 = _pset()
     p2.execute(pa.AdvectionRK4, dt=3600.0, runtime=24 * 3600.0)
     np.testing.assert_array_equal(p2.x, pset.x)
+
+
+@pytest.mark.gpu
+def test_output_with_deletions_matches_uninterrupted_run(gpu, tmp_path):
+    """Device-resident loop + write-out + deletions: the file holds the survivors of each output time and the final
+    positions equal a run without output (tests/test_particlefile.py delete+write pattern of the reference)."""
+    case, _, _ = load_golden("agrid_flat_rk4_3d_escape_delete")
+    kernels = [pa.AdvectionRK4_3D, pa.DeleteParticle]
+    fs = build_fieldset(case)
+    a = build_pset(case, fs)
+    a.execute(kernels, dt=case["dt"], runtime=case["runtime"])
+    fs2 = build_fieldset(case)
+    b = build_pset(case, fs2)
+    pf = pa.ParticleFile(tmp_path / "del.parquet", outputdt=float(2 * case["dt"]))
+    b.execute(kernels, dt=case["dt"], runtime=case["runtime"], output_file=pf)
+    assert len(a) == len(b) < len(np.atleast_1d(case["x"]))
+    np.testing.assert_array_equal(a.particle_id, b.particle_id)
+    np.testing.assert_array_equal(a.x, b.x)
+    np.testing.assert_array_equal(a.z, b.z)
+    df = pa.read_particlefile(tmp_path / "del.parquet")
+    counts = df.groupby("t").size()
+    assert counts.iloc[0] == len(np.atleast_1d(case["x"])) and counts.iloc[-1] == len(b)
+    assert np.all(np.diff(counts.to_numpy()) <= 0)  # particles only ever disappear
+    last = df[df["t"] == df["t"].max()].sort_values("particle_id")
+    np.testing.assert_array_equal(last["particle_id"].to_numpy(), b.particle_id)
+    np.testing.assert_array_equal(last["x"].to_numpy(), b.x)
