@@ -213,6 +213,11 @@ typedef struct pk_exec_stats {
     int32_t reserved0;
 } pk_exec_stats;
 int32_t pk_execute(pk_ctx* ctx, const pk_exec_params* params, pk_exec_stats* stats);
+/* The same in two halves: _begin enqueues the sort + advection kernel + statistics on the compute stream and returns;
+ * the host can then stage and enqueue the NEXT field level (pk_field_upload_level async) while the RK sub-steps run;
+ * _end waits and fills the statistics.  pk_execute == begin + end. */
+int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* params);
+int32_t pk_execute_end(pk_ctx* ctx, pk_exec_stats* stats);
 
 /* ---- sampling: Field.eval / VectorField.eval at explicit points (field.py:145-195, 250-304) ------ */
 /* what = field id, or -1 for UV, -2 for UVW (fields taken from params).  All pointers are host

@@ -173,6 +173,8 @@ ABI_SYMBOLS = [
     "pk_particles_d2h_columns",
     "pk_particles_device",
     "pk_execute",
+    "pk_execute_begin",
+    "pk_execute_end",
     "pk_eval",
     "pk_search",
     "pk_measure_copy_bandwidth",
@@ -220,6 +222,8 @@ def load():
     lib.pk_particles_d2h_columns.argtypes = [C.c_void_p, C.c_uint32]
     lib.pk_particles_device.argtypes = [C.c_void_p, C.POINTER(ParticlesDesc), C.POINTER(C.c_void_p)]
     lib.pk_execute.argtypes = [C.c_void_p, C.POINTER(ExecParams), C.POINTER(ExecStats)]
+    lib.pk_execute_begin.argtypes = [C.c_void_p, C.POINTER(ExecParams)]
+    lib.pk_execute_end.argtypes = [C.c_void_p, C.POINTER(ExecStats)]
     lib.pk_eval.argtypes = [C.c_void_p, C.POINTER(ExecParams), C.c_int32, C.c_int64] + [C.c_void_p] * 8
     lib.pk_search.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pk_measure_copy_bandwidth.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_double)]

@@ -75,6 +75,13 @@ struct pk_ctx {
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
     int stage_next = 0;
     hipDeviceProp_t prop;
+    // an advection launch in flight (pk_execute_begin .. pk_execute_end)
+    bool in_flight = false;
+    int fl_launches = 0;
+    bool fl_sorted = false;
+    int64_t fl_n = 0;
+    DCounters* h_counters = nullptr;          // pinned: the async D2H of the counters must not block the host
+    unsigned long long* h_summary = nullptr;  // pinned
     int sort_horizontal_major = -1;  // tuning knobs (environment: PK_SORT_HORIZONTAL = 0/1 forces, PK_NO_SPECIAL)
     int no_special = 0;
 
@@ -282,6 +289,8 @@ int32_t pk_init(int32_t device, pk_ctx** out) {
     PK_HIP(ctx, hipEventCreateWithFlags(&ctx->stage_ev[1], hipEventDisableTiming));
     PK_HIP(ctx, hipMalloc((void**)&ctx->d_counters, sizeof(DCounters)));
     PK_HIP(ctx, hipMalloc((void**)&ctx->d_summary, sizeof(unsigned long long) * (PK_NUM_STATE_CODES + 2)));
+    PK_HIP(ctx, hipHostMalloc((void**)&ctx->h_counters, sizeof(DCounters), hipHostMallocDefault));
+    PK_HIP(ctx, hipHostMalloc((void**)&ctx->h_summary, sizeof(unsigned long long) * (PK_NUM_STATE_CODES + 2), hipHostMallocDefault));
     return 0;
 }
 
@@ -319,6 +328,8 @@ int32_t pk_destroy(pk_ctx* ctx) {
     if (ctx->d_pack_tmp) (void)hipFree(ctx->d_pack_tmp);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_summary) (void)hipFree(ctx->d_summary);
+    if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+    if (ctx->h_summary) (void)hipHostFree(ctx->h_summary);
     for (int k = 0; k < 2; k++) {
         if (ctx->stage[k]) (void)hipHostFree(ctx->stage[k]);
         if (ctx->stage_ev[k]) (void)hipEventDestroy(ctx->stage_ev[k]);
@@ -811,12 +822,12 @@ static int32_t fill_args(pk_ctx* ctx, const pk_exec_params* prm, KArgs& a, size_
     return 0;
 }
 
-int32_t pk_execute(pk_ctx* ctx, const pk_exec_params* prm, pk_exec_stats* stats) {
+int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
     if (!ctx || !prm) return -2;
     if (!ctx->bound) return ctx->fail("no particles bound");
+    if (ctx->in_flight) return ctx->fail("pk_execute_begin: a launch is already in flight (call pk_execute_end)");
     if (prm->nk < 1 || prm->nk > PK_MAX_KERNELS) return ctx->fail("params.nk out of range");
     PK_HIP(ctx, hipSetDevice(ctx->device));
-    if (stats) memset(stats, 0, sizeof(*stats));
     KArgs a;
     size_t lds_bytes = 0;
     int use_lds = 0;
@@ -884,12 +895,25 @@ int32_t pk_execute(pk_ctx* ctx, const pk_exec_params* prm, pk_exec_stats* stats)
         hipLaunchKernelGGL(summarize_kernel, dim3(sgrid), dim3(256), 0, ctx->compute, ctx->dev.state, ctx->dev.t, n, ctx->d_summary);
         PK_HIP(ctx, hipGetLastError());
     }
-    DCounters hc{};
-    unsigned long long hs[PK_NUM_STATE_CODES + 2];
-    PK_HIP(ctx, hipMemcpyAsync(&hc, ctx->d_counters, sizeof(hc), hipMemcpyDeviceToHost, ctx->compute));
-    PK_HIP(ctx, hipMemcpyAsync(hs, ctx->d_summary, sizeof(hs), hipMemcpyDeviceToHost, ctx->compute));
+    PK_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(DCounters), hipMemcpyDeviceToHost, ctx->compute));
+    PK_HIP(ctx, hipMemcpyAsync(ctx->h_summary, ctx->d_summary, sizeof(unsigned long long) * (PK_NUM_STATE_CODES + 2), hipMemcpyDeviceToHost, ctx->compute));
+    ctx->in_flight = true;
+    ctx->fl_launches = launches;
+    ctx->fl_sorted = sorted;
+    ctx->fl_n = n;
+    return 0;
+}
+
+int32_t pk_execute_end(pk_ctx* ctx, pk_exec_stats* stats) {
+    if (!ctx) return -2;
+    if (!ctx->in_flight) return ctx->fail("pk_execute_end: no launch in flight");
+    PK_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->in_flight = false;
     PK_HIP(ctx, hipStreamSynchronize(ctx->compute));
     if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        const DCounters& hc = *ctx->h_counters;
+        const unsigned long long* hs = ctx->h_summary;
         stats->steps = (int64_t)hc.steps;
         stats->attempts = (int64_t)hc.attempts;
         stats->paused = (int64_t)hc.paused;
@@ -900,18 +924,24 @@ int32_t pk_execute(pk_ctx* ctx, const pk_exec_params* prm, pk_exec_stats* stats)
             memcpy(&v, &b, 8);
             return v;
         };
-        const bool any_live = n > 0 && hs[PK_EVALUATE] > 0;
+        const bool any_live = ctx->fl_n > 0 && hs[PK_EVALUATE] > 0;
         stats->t_min_live = any_live ? unorder(hs[PK_NUM_STATE_CODES]) : NAN;
         stats->t_max_live = any_live ? unorder(hs[PK_NUM_STATE_CODES + 1]) : NAN;
         float ms = 0.f;
-        if (launches) PK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        if (ctx->fl_launches) PK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
         stats->kernel_ms = ms;
         float sms = 0.f;
-        if (sorted) PK_HIP(ctx, hipEventElapsedTime(&sms, ctx->ev2, ctx->ev0));
+        if (ctx->fl_sorted) PK_HIP(ctx, hipEventElapsedTime(&sms, ctx->ev2, ctx->ev0));
         stats->sort_ms = sms;
-        stats->launches = launches;
+        stats->launches = ctx->fl_launches;
     }
     return 0;
+}
+
+int32_t pk_execute(pk_ctx* ctx, const pk_exec_params* prm, pk_exec_stats* stats) {
+    int32_t rc = pk_execute_begin(ctx, prm);
+    if (rc) return rc;
+    return pk_execute_end(ctx, stats);
 }
 
 // ---- sampling ------------------------------------------------------------------------------------------

@@ -207,16 +207,13 @@ class DeviceEngine:
     def _windowed_fields(self):
         return [f for f in self.scalar_fields if self.field_nslots[f.name] < self.field_host[f.name].shape[0]]
 
-    def _ensure_window(self, t_live: float, sign: int, prefetch: bool = True):
-        """Make levels [k0, k0 + ncommit) resident (forward; mirrored backward), k0 = level bracket of t_live,
-        and start the asynchronous copy of the next level into the spare slot."""
+    def _plan_window(self, t_live: float, sign: int):
+        """Levels that must be committed for the next launch and the level to prefetch behind it."""
         wf = self._windowed_fields()
-        if not wf:
-            return
         time = wf[0].model.time_flt
         nt = len(time)
         ns = min(self.field_nslots[f.name] for f in wf)
-        ncommit = ns - 1 if prefetch and ns > 2 else ns
+        ncommit = ns - 1 if ns > 2 else ns
         if sign > 0:
             k0 = int(np.clip(np.searchsorted(time, t_live, side="right") - 1, 0, nt - 1))
             want = list(range(k0, min(k0 + ncommit, nt)))
@@ -225,17 +222,30 @@ class DeviceEngine:
             k1 = int(np.clip(np.searchsorted(time, t_live, side="left"), 0, nt - 1))
             want = list(range(max(k1 - ncommit + 1, 0), k1 + 1))
             nxt = k1 - ncommit if k1 - ncommit >= 0 else None
+        if ncommit >= ns:
+            nxt = None  # no spare slot to prefetch into
+        return wf, want, nxt
+
+    def _commit_window(self, t_live: float, sign: int):
+        """Make the wanted levels resident (normally they were prefetched during the previous launch)."""
+        wf, want, nxt = self._plan_window(t_live, sign)
         self.ctx.check(self.lib.pk_field_sync(self.ctx.handle), "pk_field_sync")  # commit earlier prefetches
         for f in wf:
             have = set(self._slots(f.name))
             for lv in want:
                 if lv not in have:
                     self._upload(f.name, lv, asynchronous=False)
-        if prefetch and nxt is not None and ncommit < ns:
-            for f in wf:
-                if nxt not in set(self._slots(f.name)):
-                    self._upload(f.name, nxt, asynchronous=True)
         self._window = (want[0], want[-1])
+        return nxt
+
+    def _prefetch(self, nxt):
+        """Stage and enqueue the next level on the copy stream WHILE the advection kernel runs (the host-side staging
+        memcpy -- or the page-ins of a memory-mapped file -- and the DMA both overlap the RK sub-steps)."""
+        if nxt is None:
+            return
+        for f in self._windowed_fields():
+            if nxt not in set(self._slots(f.name)):
+                self._upload(f.name, nxt, asynchronous=True)
 
     # ---- particles -------------------------------------------------------------------------------------------
     def bind_particles(self, data: dict):
@@ -321,14 +331,19 @@ class DeviceEngine:
         t_live = t_start
         last_live = None
         while True:
+            nxt = None
             if self.windowed:
                 if t_live is None or not np.isfinite(t_live):
                     t_live = 0.0 if sign > 0 else float(self._windowed_fields()[0].model.time_flt[-1])
-                self._ensure_window(float(t_live), sign)
+                nxt = self._commit_window(float(t_live), sign)
             prm = self.make_params(kernel_ids, endtime=endtime, dt0=dt0, context=context, seed=seed, reset_state=reset,
                                    have_guess0=(have_guess0 if reset else 1), sort_by_cell=sort_by_cell)
             st = _hip.ExecStats()
-            self.ctx.check(self.lib.pk_execute(self.ctx.handle, C.byref(prm), C.byref(st)), "pk_execute")
+            self.ctx.check(self.lib.pk_execute_begin(self.ctx.handle, C.byref(prm)), "pk_execute_begin")
+            try:
+                self._prefetch(nxt)  # overlaps the kernel that was just launched
+            finally:
+                self.ctx.check(self.lib.pk_execute_end(self.ctx.handle, C.byref(st)), "pk_execute_end")
             reset = 0
             total["steps"] += st.steps
             total["attempts"] += st.attempts

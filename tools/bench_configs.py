@@ -132,7 +132,7 @@ def main():
             "particle_steps_per_s_kernel": st["steps"] / (st["kernel_ms"] * 1e-3) if st["kernel_ms"] else None,
             "particle_steps_per_s_wall_incl_h2d_d2h": st["steps"] / wall, "wall_s": wall,
             "remaining_particles": len(pset), "state_counts": st["state_counts"],
-            "dataset_generation_s": gen_s, "hash_build_s": hash_s, "device_upload_s": upload_s,
+            "dataset_generation_s": gen_s, "hash_build_s": hash_s, "device_create_s": upload_s,
         }
         print(json.dumps(out), flush=True)
 
