@@ -186,7 +186,8 @@ int32_t pk_particles_device(pk_ctx* ctx, pk_particles_desc* dev, int64_t** perm)
 typedef struct pk_exec_params {
     int32_t nk;
     int32_t kernels[PK_MAX_KERNELS]; /* PK_KERNEL_*, applied in order to every evaluated particle   */
-    int32_t interp_uv;  /* 0 XLinear_Velocity (A-grid), 1 CGrid_Velocity                            */
+    int32_t interp_uv;  /* 0 XLinear_Velocity (A-grid), 1 CGrid_Velocity, 2 XFreeslip, 3 XPartialslip
+                           (_xinterpolators.py:169-190, 193-332, 386-502)                           */
     int32_t rk45_mode;  /* hasattr(fieldset, "RK45_tol") (kernel.py:118,225)                        */
     int32_t reset_state; /* 1: state[:] = Evaluate first (kernel.py:188); 0: continue a paused call */
     int32_t have_guess0; /* a particle had a non-zero xi guess at entry (index_search.py:269)       */

@@ -323,7 +323,7 @@ class MarshalledCase:
         p.nk = len(kernels)
         for i, k in enumerate(kernels):
             p.kernels[i] = KERNEL_IDS[k]
-        p.cgrid = int(bool(case.get("cgrid")))
+        p.cgrid = {"free": 2, "partial": 3}.get(case.get("slip"), int(bool(case.get("cgrid"))))
         p.rk45_mode = int("RK45_tol" in context)
         p.have_guess0 = int(have_guess0)
         fi = self.field_index

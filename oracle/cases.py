@@ -461,6 +461,23 @@ def diffusion_case(name, *, mesh, kernels, seed=0, npart=200, const_kh=None, spa
     )
 
 
+def slip_case(name, *, slip, mesh, kernels, seed=0, with_w=False, npart=300, spatial_dtype="float64", field_dtype=np.float64):
+    """A-grid flow around rectangular "land" blocks (U = V = 0 there) sampled with XFreeslip / XPartialslip
+    (tests/test_interpolation.py:119-154 pattern, turned into an advection run)."""
+    case = rect_agrid_case(name, mesh=mesh, kernels=kernels, seed=seed, nx=30, ny=20, nz=4, nt=3, npart=npart, with_w=with_w,
+                           spatial_dtype=spatial_dtype, field_dtype=field_dtype, runtime=20 * 3600.0, wscale=0.002)
+    rng = _rng(1000 + seed)
+    land = np.zeros((20, 30), bool)
+    for _ in range(14):
+        j, i = rng.integers(1, 17), rng.integers(1, 26)
+        land[j : j + rng.integers(1, 4), i : i + rng.integers(1, 5)] = True
+    for f in case["fields"].values():
+        f[:, :, land] = 0.0
+        f[:, 2:, land | np.roll(land, 1, axis=1)] = 0.0  # wider below: the z1 level is land where z0 is
+    case["slip"] = slip
+    return case
+
+
 def all_cases() -> dict:
     """name -> case.  Keep every case small: the fixtures are committed."""
     c = {}
@@ -500,6 +517,14 @@ def all_cases() -> dict:
     c["agrid_flat_rk45"]["context"] = {"RK45_tol": 0.5, "RK45_min_dt": 10.0, "RK45_max_dt": 7200.0}
     add(rect_agrid_case("agrid_sph_rk4_outside_time", mesh="spherical", kernels=["AdvectionRK4"], seed=19, nt=2,
                         runtime=30 * 3600.0))
+
+    # --- slip boundary conditions (XFreeslip / XPartialslip velocity interpolators) -------------------------------
+    add(slip_case("slip_free_flat_rk4", slip="free", mesh="flat", kernels=["AdvectionRK4"], seed=51))
+    add(slip_case("slip_partial_sph_rk4", slip="partial", mesh="spherical", kernels=["AdvectionRK4"], seed=52))
+    add(slip_case("slip_partial_sph_rk4_3d", slip="partial", mesh="spherical", kernels=["AdvectionRK4_3D", "DeleteParticle"], seed=53,
+                  with_w=True))
+    add(slip_case("slip_free_sph_rk4_f32", slip="free", mesh="spherical", kernels=["AdvectionRK4"], seed=54,
+                  spatial_dtype="float32", field_dtype=np.float32))
 
     # --- restated analytic datasets (BASELINE config 1) --------------------------------------------------------
     add(peninsula_case("peninsula_A_flat", mesh="flat", grid_type="A"))

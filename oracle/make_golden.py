@@ -114,7 +114,8 @@ def build_ref_fieldset(case):
                          sizes_extra=sizes_extra)
     fields = {n: (np.asarray(a), tuple(case["field_dims"][n])) for n, a in case["fields"].items()}
     fs = rs.make_ref_fieldset(grid=g, fields=fields, time_s=case.get("time_s"), cgrid=bool(case.get("cgrid")),
-                              constants=case.get("constants") or None, const_mesh=case.get("const_mesh", "flat"))
+                              constants=case.get("constants") or None, const_mesh=case.get("const_mesh", "flat"),
+                              slip=case.get("slip"))
     for k, v in (case.get("context") or {}).items():
         fs.add_context(k, v)
     return fs, g

@@ -287,7 +287,7 @@ def make_ref_grid(*, lon, lat, depth, mesh, x_pad="low", y_pad="low", z_pad="bot
     return g
 
 
-def make_ref_fieldset(*, grid, fields: dict, time_s=None, cgrid=False, constants=None, const_mesh="flat"):
+def make_ref_fieldset(*, grid, fields: dict, time_s=None, cgrid=False, constants=None, const_mesh="flat", slip=None):
     """Assemble reference Field/VectorField objects.
 
     fields : name -> (ndarray TZYX, dims tuple of 4 names).  Use "mockT"/"mockZ" style names for
@@ -320,6 +320,8 @@ def make_ref_fieldset(*, grid, fields: dict, time_s=None, cgrid=False, constants
         f.interp_method = xi.XLinear()
         fobjs[name] = f
     vinterp = xi.CGrid_Velocity if cgrid else xi.XLinear_Velocity
+    if slip is not None:
+        vinterp = {"free": xi.XFreeslip, "partial": xi.XPartialslip}[slip]
     if "U" in fobjs and "V" in fobjs:
         fobjs["UV"] = VectorField("UV", fobjs["U"], fobjs["V"], interp_method=vinterp())
         if "W" in fobjs:

@@ -1000,13 +1000,14 @@ int32_t pk_eval(pk_ctx* ctx, const pk_exec_params* prm, int32_t what, int64_t m,
     const dim3 grid((unsigned)((m + 255) / 256));
     const int fsel = what >= 0 ? what : p2.fU;
     const bool f32 = ctx->fields[fsel].d.dtype == PK_F32;
+#define PK_EVAL(FT, IN) hipLaunchKernelGGL((eval_kernel<FT, IN>), grid, dim3(256), 0, ctx->compute, a, what, m, dt_, dz, dy, dx, du, dv, dw, ds)
+    const int ik = p2.interp_uv >= 2 ? 2 : p2.interp_uv;
     if (f32) {
-        if (p2.interp_uv) hipLaunchKernelGGL((eval_kernel<float, 1>), grid, dim3(256), 0, ctx->compute, a, what, m, dt_, dz, dy, dx, du, dv, dw, ds);
-        else hipLaunchKernelGGL((eval_kernel<float, 0>), grid, dim3(256), 0, ctx->compute, a, what, m, dt_, dz, dy, dx, du, dv, dw, ds);
+        if (ik == 2) PK_EVAL(float, 2); else if (ik == 1) PK_EVAL(float, 1); else PK_EVAL(float, 0);
     } else {
-        if (p2.interp_uv) hipLaunchKernelGGL((eval_kernel<double, 1>), grid, dim3(256), 0, ctx->compute, a, what, m, dt_, dz, dy, dx, du, dv, dw, ds);
-        else hipLaunchKernelGGL((eval_kernel<double, 0>), grid, dim3(256), 0, ctx->compute, a, what, m, dt_, dz, dy, dx, du, dv, dw, ds);
+        if (ik == 2) PK_EVAL(double, 2); else if (ik == 1) PK_EVAL(double, 1); else PK_EVAL(double, 0);
     }
+#undef PK_EVAL
     PK_HIP(ctx, hipGetLastError());
     PK_HIP(ctx, hipMemcpyAsync(out_u, du, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->compute));
     if (out_v) PK_HIP(ctx, hipMemcpyAsync(out_v, dv, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->compute));

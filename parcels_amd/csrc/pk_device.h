@@ -629,6 +629,66 @@ PK_DEV double xlinear(const DField& f, const Corners& k, const GPos& p) {
 template <class FT>
 PK_DEV double xlinear(const DField& f, const GPos& p) { return xlinear<FT>(f, make_corners(f, p), p); }
 
+// _Spatialslip (_xinterpolators.py:386-477): XFreeslip (a = 1, b = 0) and XPartialslip (a = b = 0.5).  A corner is "land"
+// when np.isclose(U, 0) & np.isclose(V, 0) at the first bracketing time level; a cell row / column that is all land scales
+// the tangential velocity by (a + b*eta)/eta etc.  lenZ is evaluated per particle (zeta > 0), the W factors always use
+// both depth levels like the reference.
+template <class FT>
+PK_DEV void slip_velocity(const DGrid& g, const DField& U, const DField& V, const DField* W, const GPos& p, double ypos,
+                          bool ypos_f32, double a_, double b_, double& u, double& v, double& w) {
+    const Corners ku = make_corners(U, p);
+    const bool same_v = same_layout(U, V);
+    const Corners kv = same_v ? ku : make_corners(V, p);
+    double uu = xlinear<FT>(U, ku, p);
+    double vv = xlinear<FT>(V, kv, p);
+    double ww = 0.0;
+    if (W) ww = same_layout(U, *W) ? xlinear<FT>(*W, ku, p) : xlinear<FT>(*W, p);
+    const double zero_tol = sizeof(FT) == 4 ? (double)(float)1e-8 : 1e-8;  // np.isclose(v, 0.0): |v| <= atol
+    const FT* du = (const FT*)U.data + ku.ot0;
+    const FT* dv = (const FT*)V.data + kv.ot0;
+    bool land[2][2][2];
+#pragma unroll
+    for (int iz = 0; iz < 2; iz++)
+#pragma unroll
+        for (int iy = 0; iy < 2; iy++) {
+            double u0, u1, v0, v1;
+            ld2(du, ku.o[iz][iy], ku.dx, ku.pairs, u0, u1);
+            ld2(dv, kv.o[iz][iy], kv.dx, kv.pairs, v0, v1);
+            land[iz][iy][0] = fabs(u0) <= zero_tol && fabs(v0) <= zero_tol;
+            land[iz][iy][1] = fabs(u1) <= zero_tol && fabs(v1) <= zero_tol;
+        }
+    const double xsi = p.xsi, eta = p.eta;
+    const bool z2 = p.zeta > 0;
+    const bool row0 = land[0][0][0] && land[0][0][1], row0z = land[1][0][0] && land[1][0][1];
+    const bool row1 = land[0][1][0] && land[0][1][1], row1z = land[1][1][0] && land[1][1][1];
+    const bool col0 = land[0][0][0] && land[0][1][0], col0z = land[1][0][0] && land[1][1][0];
+    const bool col1 = land[0][0][1] && land[0][1][1], col1z = land[1][0][1] && land[1][1][1];
+    double f_u = 1.0;
+    if (row0 && (!z2 || row0z) && eta > 0) f_u = f_u * (a_ + b_ * eta) / eta;
+    if (row1 && (!z2 || row1z) && eta < 1) f_u = f_u * (1 - b_ * eta) / (1 - eta);
+    uu = uu * f_u;
+    if (g.spherical) {  // the reference hard-codes 1852*60 here (== deg2m of the default sphere)
+        if (ypos_f32) uu /= (double)(111120.0f * cosf((float)ypos * DEG2RADF));
+        else uu /= 111120 * cos_lat(ypos * DEG2RAD);
+    }
+    double f_v = 1.0;
+    if (col0 && (!z2 || col0z) && xsi > 0) f_v = f_v * (a_ + b_ * xsi) / xsi;
+    if (col1 && (!z2 || col1z) && xsi < 1) f_v = f_v * (1 - b_ * xsi) / (1 - xsi);
+    vv = vv * f_v;
+    if (g.spherical) vv /= 111120;
+    if (W) {
+        double f_w = 1.0;
+        if (row0 && row0z && eta > 0) f_w = f_w * (a_ + b_ * eta) / eta;
+        if (row1 && row1z && eta < 1) f_w = f_w * (1 - b_ * eta) / (1 - eta);
+        if (col0 && col0z && xsi > 0) f_w = f_w * (a_ + b_ * xsi) / xsi;
+        if (col1 && col1z && xsi < 1) f_w = f_w * (1 - b_ * xsi) / (1 - xsi);
+        ww = ww * f_w;
+    }
+    u = uu;
+    v = vv;
+    w = ww;
+}
+
 // _geodetic_distance (utils/interpolation.py:178-185), including NumPy's float32 behaviour for f32 coordinates
 PK_DEV double geodetic_distance(const DGrid& g, double lat1, double lat2, double lon1, double lon2, double lat, bool cf32) {
     if (g.spherical) {
@@ -805,6 +865,9 @@ PK_DEV void eval_uvw(const KArgs& a, const Coords& mc, PCtx& c, bool want_w, dou
         const DField* W = (want_w && a.prm.fW >= 0) ? &a.fields[a.prm.fW] : nullptr;
         if (INTERP == 1) {
             cgrid_velocity<FT, KIND>(g, &mc, U, V, W, p, y, pos_f32, uu, vv, ww);
+        } else if (INTERP == 2) {  // XFreeslip (interp_uv == 2) / XPartialslip (3)
+            const bool freeslip = a.prm.interp_uv == 2;
+            slip_velocity<FT>(g, U, V, W, p, y, pos_f32, freeslip ? 1.0 : 0.5, freeslip ? 0.0 : 0.5, uu, vv, ww);
         } else {  // XLinear_Velocity.interp (_xinterpolators.py:169-190)
             const Corners k = make_corners(U, p);
             uu = xlinear<FT>(U, k, p);

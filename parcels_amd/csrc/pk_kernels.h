@@ -336,7 +336,7 @@ PK_DEV unsigned xcd_swizzle(unsigned bid, unsigned nb) {
 #define PK_MIN_WAVES_HEAVY 2
 #endif
 template <class FT, int KIND, int INTERP, int KID, bool LDS>
-__global__ void __launch_bounds__(256, (KIND == 1 || INTERP == 1) ? PK_MIN_WAVES_HEAVY : PK_MIN_WAVES) advect_kernel(const KArgs a) {
+__global__ void __launch_bounds__(256, (KIND == 1 || INTERP != 0) ? PK_MIN_WAVES_HEAVY : PK_MIN_WAVES) advect_kernel(const KArgs a) {
     extern __shared__ double smem[];
     const DField& mf = a.fields[a.main_field];
     const DGrid& mg = a.grids[a.main_grid];
@@ -501,34 +501,34 @@ void launch_program(int field_f32, int curvilinear, int interp, int lds, const K
     hipLaunchKernelGGL((advect_kernel<FT, KD, IN, KIDV, LD>), grid, dim3(256), lds_bytes, stream, a)
 
 // single-kernel programs require LDS staging (the host falls back to the generic program otherwise)
+// interp: 0 XLinear_Velocity, 1 CGrid_Velocity, 2 slip (XFreeslip / XPartialslip, told apart by prm.interp_uv)
+#define PK_LAUNCH_KEYS(LD)                                     \
+    switch (key) {                                             \
+        case 0: PK_LAUNCH_CASE(double, 0, 0, LD); break;       \
+        case 1: PK_LAUNCH_CASE(double, 0, 1, LD); break;       \
+        case 2: PK_LAUNCH_CASE(double, 0, 2, LD); break;       \
+        case 3: PK_LAUNCH_CASE(double, 1, 0, LD); break;       \
+        case 4: PK_LAUNCH_CASE(double, 1, 1, LD); break;       \
+        case 5: PK_LAUNCH_CASE(double, 1, 2, LD); break;       \
+        case 6: PK_LAUNCH_CASE(float, 0, 0, LD); break;        \
+        case 7: PK_LAUNCH_CASE(float, 0, 1, LD); break;        \
+        case 8: PK_LAUNCH_CASE(float, 0, 2, LD); break;        \
+        case 9: PK_LAUNCH_CASE(float, 1, 0, LD); break;        \
+        case 10: PK_LAUNCH_CASE(float, 1, 1, LD); break;       \
+        case 11: PK_LAUNCH_CASE(float, 1, 2, LD); break;       \
+    }
+
 #define PK_DEFINE_LAUNCH_PROGRAM(PROGV, KID_, WITH_NOLDS)                                                            \
     template <>                                                                                                      \
     void launch_program<PROGV>(int field_f32, int curvilinear, int interp, int lds, const KArgs& a, dim3 grid,       \
                                size_t lds_bytes, hipStream_t stream) {                                               \
         constexpr int KIDV = KID_;                                                                                   \
-        const int key = (field_f32 ? 4 : 0) | (curvilinear ? 2 : 0) | (interp ? 1 : 0);                              \
+        const int ik = interp >= 2 ? 2 : interp;                                                                     \
+        const int key = (field_f32 ? 6 : 0) + (curvilinear ? 3 : 0) + ik;                                            \
         if (lds || !(WITH_NOLDS)) {                                                                                  \
-            switch (key) {                                                                                           \
-                case 0: PK_LAUNCH_CASE(double, 0, 0, true); break;                                                   \
-                case 1: PK_LAUNCH_CASE(double, 0, 1, true); break;                                                   \
-                case 2: PK_LAUNCH_CASE(double, 1, 0, true); break;                                                   \
-                case 3: PK_LAUNCH_CASE(double, 1, 1, true); break;                                                   \
-                case 4: PK_LAUNCH_CASE(float, 0, 0, true); break;                                                    \
-                case 5: PK_LAUNCH_CASE(float, 0, 1, true); break;                                                    \
-                case 6: PK_LAUNCH_CASE(float, 1, 0, true); break;                                                    \
-                case 7: PK_LAUNCH_CASE(float, 1, 1, true); break;                                                    \
-            }                                                                                                        \
+            PK_LAUNCH_KEYS(true)                                                                                     \
         } else if (WITH_NOLDS) {                                                                                     \
-            switch (key) {                                                                                           \
-                case 0: PK_LAUNCH_CASE(double, 0, 0, !(WITH_NOLDS)); break;                                          \
-                case 1: PK_LAUNCH_CASE(double, 0, 1, !(WITH_NOLDS)); break;                                          \
-                case 2: PK_LAUNCH_CASE(double, 1, 0, !(WITH_NOLDS)); break;                                          \
-                case 3: PK_LAUNCH_CASE(double, 1, 1, !(WITH_NOLDS)); break;                                          \
-                case 4: PK_LAUNCH_CASE(float, 0, 0, !(WITH_NOLDS)); break;                                           \
-                case 5: PK_LAUNCH_CASE(float, 0, 1, !(WITH_NOLDS)); break;                                           \
-                case 6: PK_LAUNCH_CASE(float, 1, 0, !(WITH_NOLDS)); break;                                           \
-                case 7: PK_LAUNCH_CASE(float, 1, 1, !(WITH_NOLDS)); break;                                           \
-            }                                                                                                        \
+            PK_LAUNCH_KEYS(!(WITH_NOLDS))                                                                            \
         }                                                                                                            \
     }
 

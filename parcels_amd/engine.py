@@ -303,7 +303,7 @@ class DeviceEngine:
         uv = fs.fields.get("UV")
         uvw = fs.fields.get("UVW")
         vec = uvw if uvw is not None else uv
-        p.interp_uv = int(isinstance(vec.interp_method, CGrid_Velocity)) if vec is not None else 0
+        p.interp_uv = int(vec.interp_method.kind) if vec is not None else 0
         fid = self.field_ids
         p.fU = fid.get(vec.U.name, -1) if vec is not None else -1
         p.fV = fid.get(vec.V.name, -1) if vec is not None else -1
@@ -379,7 +379,7 @@ class DeviceEngine:
         st = np.zeros(m, np.int32)
         prm = self.make_params([4], endtime=0.0, dt0=1.0)
         if isinstance(f, VectorField):
-            prm.interp_uv = int(isinstance(f.interp_method, CGrid_Velocity))
+            prm.interp_uv = int(f.interp_method.kind)
             prm.fU, prm.fV = self.field_ids[f.U.name], self.field_ids[f.V.name]
             prm.fW = self.field_ids[f.W.name] if f.W is not None else -1
             what = -2 if f.W is not None else -1

@@ -13,6 +13,8 @@ from .dataset import DataArray, Dataset
 from .interpolators import (
     CGrid_Velocity,
     ScalarInterpolator,
+    XFreeslip,
+    XPartialslip,
     VectorInterpolator,
     XConstantField,
     XLinear,
@@ -227,7 +229,7 @@ class VectorField:
     def interp_method(self, method):
         if not isinstance(method, VectorInterpolator):
             raise ValueError(f"method must be a `VectorInterpolator` object. Got {type(method)=!r}")
-        if not isinstance(method, (XLinear_Velocity, CGrid_Velocity)):
+        if not isinstance(method, (XLinear_Velocity, CGrid_Velocity, XFreeslip, XPartialslip)):
             raise NotImplementedError(f"{type(method).__name__} has no HIP implementation yet")
         self._interp_method = method
 

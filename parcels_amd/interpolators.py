@@ -27,3 +27,11 @@ class XLinear_Velocity(VectorInterpolator):  # noqa: N801  _xinterpolators.py:16
 
 class CGrid_Velocity(VectorInterpolator):  # noqa: N801  _xinterpolators.py:193-332
     kind = 1
+
+
+class XFreeslip(VectorInterpolator):  # _xinterpolators.py:480-490 (free-slip boundary condition, a = 1, b = 0)
+    kind = 2
+
+
+class XPartialslip(VectorInterpolator):  # _xinterpolators.py:493-502 (partial slip, a = b = 0.5)
+    kind = 3

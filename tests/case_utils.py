@@ -80,6 +80,11 @@ def build_fieldset(case):
         data_vars[name] = (tuple(dims[i] for i in keep), a)
     ds = pa.Dataset(data_vars, coords, sgrid=md)
     fs = pa.FieldSet.from_sgrid_conventions(ds, mesh=case["mesh"])
+    if case.get("slip"):
+        interp = {"free": pa.XFreeslip, "partial": pa.XPartialslip}[case["slip"]]()
+        for vname in ("UV", "UVW"):
+            if vname in fs.fields:
+                fs.fields[vname].interp_method = interp
     for name, val in (case.get("constants") or {}).items():
         fs.add_constant_field(name, val, mesh=case.get("const_mesh", "flat"))
     for k, v in (case.get("context") or {}).items():
