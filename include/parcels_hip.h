@@ -125,7 +125,9 @@ typedef struct pk_field_desc {
     int32_t nt, nz, ny, nx; /* TZYX extents; size 1 for axes the field does not have               */
     int32_t has_t, has_z, has_y, has_x; /* the field has a dimension on that axis                   */
     int32_t has_time_interval; /* Field.time_interval is not None (field.py:111-116)                */
-    int32_t is_const;   /* XConstantField (_xinterpolators.py:156-166): value = data[0,0,0,0]       */
+    int32_t is_const;   /* scalar interpolator of this field: 0 XLinear, 1 XConstantField (value = data[0,0,0,0]),
+                           2 XNearest, 3 CGrid_Tracer, 4 XLinearInvdistLandTracer
+                           (_xinterpolators.py:112-166, 335-383, 505-613)                            */
     int32_t nslots;     /* device-resident time levels: >= nt keeps all, else a ring (>= 2)         */
     int32_t pack_count; /* > 1: this field leads a group of pack_count same-shaped fields (U,V,W of a C-grid)
                            stored interleaved, one {U,V,W} struct per cell, so that the staggered corner values

@@ -31,6 +31,8 @@ KERNEL_IDS = {
     "SubmergeParticle": 22,
 }
 
+SCALAR_INTERP = {"XLinear": 0, "XConstantField": 1, "XNearest": 2, "CGrid_Tracer": 3, "XLinearInvdistLandTracer": 4}
+
 EARTH_RADIUS = 6366707.019493707  # mesh.py:6
 
 
@@ -294,7 +296,7 @@ class MarshalledCase:
             f.has_y = int(dims[2] in ("YG", "YC"))
             f.has_x = int(dims[3] in ("XG", "XC"))
             f.has_time_interval = int(has_ti and dims[0] == "time")
-            f.is_const = 0
+            f.is_const = SCALAR_INTERP[(case.get("scalar_interp") or {}).get(name, "XLinear")]
             f.data = _ptr(a)
             f.time = _ptr(time64)
             self.field_index[name] = len(flds)
@@ -457,6 +459,21 @@ def populate_indices(mc: MarshalledCase, data: dict):
             ei += idx.astype(np.int64) * stride
             stride *= dim
     data["ei"][:, 0] = ei.astype(np.int32)
+
+
+def sample_case(case: dict):
+    """Field.eval at explicit points through po_eval (scalar field ``case['sample_field']``)."""
+    mc = MarshalledCase(case)
+    fidx = mc.field_index[case["sample_field"]]
+    t, z, y, x = (np.ascontiguousarray(case[k], dtype=np.float64) for k in ("t0", "z", "y", "x"))
+    m = x.shape[0]
+    out = np.zeros(m)
+    st = np.zeros(m, np.int32)
+    prm = mc.params(kernels=[], endtime=0.0, dt0=1.0)
+    rc = lib().po_eval(mc.grids, mc.fields, C.byref(prm), C.c_int32(fidx), C.c_int64(m), _ptr(t), _ptr(z), _ptr(y), _ptr(x), _ptr(out),
+                       None, None, _ptr(st))
+    assert rc == 0
+    return {"value": out, "state": st}
 
 
 ERRORS_TO_THROW = [  # kernel.py:31-38 (order matters)

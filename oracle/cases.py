@@ -478,6 +478,45 @@ def slip_case(name, *, slip, mesh, kernels, seed=0, with_w=False, npart=300, spa
     return case
 
 
+def sample_case(name, *, interp, mesh="flat", seed=0, npts=400, field_dtype=np.float64, zpad="both", uniform_batch=None):
+    """Field.eval of a scalar field P with one of the scalar interpolators at explicit points (no particles):
+    random interior points, exact node hits, points on land blocks (zeros) and points outside the domain."""
+    rng = _rng(seed)
+    nx, ny, nz, nt = 12, 10, 4, 3
+    lon = np.linspace(0, 11, nx) if mesh == "flat" else np.linspace(-20, 24, nx)
+    lat = np.linspace(0, 9, ny) if mesh == "flat" else np.linspace(-18, 18, ny)
+    depth = np.array([0.0, 10.0, 30.0, 70.0])
+    time_s = np.array([0.0, 100.0, 250.0])
+    P = (rng.standard_normal((nt, nz, ny, nx)) + 3.0).astype(field_dtype)
+    P[:, :, 3:6, 4:7] = 0.0
+    P[:, 2:, 6:8, 1:3] = 0.0
+    P[1:, :, 1, 9] = 0.0
+    t = rng.uniform(0, 250, npts)
+    z = rng.uniform(0, 70, npts)
+    y = rng.uniform(lat[0], lat[-1], npts)
+    x = rng.uniform(lon[0], lon[-1], npts)
+    k = npts // 8
+    x[:k] = lon[rng.integers(0, nx, k)]          # exact nodes
+    y[:k] = lat[rng.integers(0, ny, k)]
+    z[k : 2 * k] = depth[rng.integers(0, nz, k)]
+    t[2 * k : 3 * k] = time_s[rng.integers(0, nt, k)]
+    x[3 * k : 3 * k + 6] = lon[-1] + 0.5          # out of bounds (-> 0)
+    y[3 * k + 6 : 3 * k + 12] = lat[0] - 0.5
+    if uniform_batch == "interior":
+        # XLinearInvdistLandTracer weights ALL gathered corners alike, so its value depends on the batch-global lenT/lenZ
+        # (_xinterpolators.py:575-576); keep the batch uniform: no particle exactly on the first time level / depth
+        t[t == 0.0] = time_s[-1]
+        z[z == 0.0] = depth[-1]
+    elif uniform_batch == "t0":
+        t[:] = 0.0  # every particle on the first time level: lenT == 1 for the whole batch
+        z[z == 0.0] = depth[-1]
+    return dict(
+        name=name, kind="sample", mesh=mesh, lon=lon, lat=lat, depth=depth, x_pad="low", y_pad="low", z_pad=zpad, time_s=time_s,
+        fields={"P": P}, field_dims={"P": TZYX_NODE}, cgrid=False, scalar_interp={"P": interp}, sample_field="P",
+        kernels=[], spatial_dtype="float64", x=x, y=y, z=z, t0=t, dt=1.0, runtime=None, seed=seed,
+    )
+
+
 def all_cases() -> dict:
     """name -> case.  Keep every case small: the fixtures are committed."""
     c = {}
@@ -517,6 +556,15 @@ def all_cases() -> dict:
     c["agrid_flat_rk45"]["context"] = {"RK45_tol": 0.5, "RK45_min_dt": 10.0, "RK45_max_dt": 7200.0}
     add(rect_agrid_case("agrid_sph_rk4_outside_time", mesh="spherical", kernels=["AdvectionRK4"], seed=19, nt=2,
                         runtime=30 * 3600.0))
+
+    # --- scalar interpolators sampled through Field.eval ------------------------------------------------------------
+    add(sample_case("sample_xlinear", interp="XLinear", seed=61))
+    add(sample_case("sample_xnearest", interp="XNearest", seed=62))
+    add(sample_case("sample_cgrid_tracer", interp="CGrid_Tracer", seed=63, zpad="high"))
+    add(sample_case("sample_invdist_land", interp="XLinearInvdistLandTracer", seed=64, uniform_batch="interior"))
+    add(sample_case("sample_invdist_land_f32", interp="XLinearInvdistLandTracer", seed=65, field_dtype=np.float32, mesh="spherical",
+                    uniform_batch="interior"))
+    add(sample_case("sample_invdist_land_t0", interp="XLinearInvdistLandTracer", seed=66, uniform_batch="t0"))
 
     # --- slip boundary conditions (XFreeslip / XPartialslip velocity interpolators) -------------------------------
     add(slip_case("slip_free_flat_rk4", slip="free", mesh="flat", kernels=["AdvectionRK4"], seed=51))

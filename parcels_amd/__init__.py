@@ -9,7 +9,17 @@ from . import kernels
 from .dataset import DataArray, Dataset
 from .field import Field, TimeInterval, VectorField
 from .fieldset import FieldSet
-from .interpolators import CGrid_Velocity, XConstantField, XFreeslip, XLinear, XLinear_Velocity, XPartialslip
+from .interpolators import (
+    CGrid_Tracer,
+    CGrid_Velocity,
+    XConstantField,
+    XFreeslip,
+    XLinear,
+    XLinear_Velocity,
+    XLinearInvdistLandTracer,
+    XNearest,
+    XPartialslip,
+)
 from .kernel import Kernel, KernelWarning
 from .kernels import (
     AdvectionDiffusionEM,

@@ -42,7 +42,7 @@ struct DGrid {
 struct DField {
     int32_t grid, dtype;
     int32_t nt, nz, ny, nx;
-    int32_t has_time_interval, is_const;
+    int32_t has_time_interval, is_const;  // is_const: scalar interpolator 0 XLinear 1 XConstantField 2 XNearest 3 CGrid_Tracer 4 InvdistLandTracer
     int32_t nslots, pad;
     int32_t ncomp, comp;             // component packing: element (slot, z, y, x) of this field lives at (off * ncomp + comp)
     int64_t st_t, st_z, st_y, st_x;  // element strides (0 for axes the field does not have)
@@ -833,6 +833,67 @@ PK_DEV void cgrid_velocity(const DGrid& g, const Coords* mc, const DField& U, co
     }
 }
 
+// one value of a (possibly packed) field at integer indices, linear in time (shared by XNearest / CGrid_Tracer)
+template <class FT>
+PK_DEV double point_value(const DField& f, const GPos& p, int zf, int yf, int xf) {
+    const FT* d = (const FT*)f.data;
+    const int64_t off = ((int64_t)zf * f.st_z + (int64_t)yf * f.st_y + (int64_t)xf * f.st_x) * f.ncomp;
+    double v = ldv(d, slot_off(f, p.ti) + off);
+    if (p.tau > 0) v = v * (1 - p.tau) + ldv(d, slot_off(f, mini(p.ti + 1, f.nt - 1)) + off) * p.tau;
+    return v;
+}
+// XNearest.interp (_xinterpolators.py:505-553)
+template <class FT>
+PK_DEV double xnearest(const DField& f, const GPos& p) {
+    const int zf = p.zeta <= 0.5 ? p.zi : mini(p.zi + 1, f.nz - 1);
+    const int yf = p.eta <= 0.5 ? p.yi : mini(p.yi + 1, f.ny - 1);
+    const int xf = p.xsi <= 0.5 ? p.xi : mini(p.xi + 1, f.nx - 1);
+    return point_value<FT>(f, p, zf, yf, xf);
+}
+// CGrid_Tracer.interp (_xinterpolators.py:335-383)
+template <class FT>
+PK_DEV double cgrid_tracer(const DGrid& g, const DField& f, const GPos& p) {
+    return point_value<FT>(f, p, clampi(p.zi + g.off_z, 0, f.nz - 1), clampi(p.yi + g.off_y, 0, f.ny - 1), clampi(p.xi + g.off_x, 0, f.nx - 1));
+}
+// XLinearInvdistLandTracer.interp (_xinterpolators.py:556-613); lenT/lenZ per particle (the reference's batch-global
+// choice changes the value here)
+template <class FT>
+PK_DEV double xlinear_invdist(const DField& f, const GPos& p) {
+    double value = xlinear<FT>(f, p);
+    const FT* d = (const FT*)f.data;
+    const int lenT = p.tau > 0 ? 2 : 1, lenZ = p.zeta > 0 ? 2 : 1;
+    const double zero_tol = sizeof(FT) == 4 ? (double)(float)1e-8 : 1e-8;
+    double val = 0.0, w_sum = 0.0, exact_vals = 0.0;
+    int nb_land = 0;
+    bool has_exact = false;
+    for (int it = 0; it < lenT; it++)
+        for (int iz = 0; iz < lenZ; iz++)
+            for (int iy = 0; iy < 2; iy++)
+                for (int ix = 0; ix < 2; ix++) {
+                    const int tt = it ? mini(p.ti + 1, f.nt - 1) : p.ti;
+                    const int zz = iz ? mini(p.zi + 1, f.nz - 1) : p.zi;
+                    const int yy = iy ? mini(p.yi + 1, f.ny - 1) : p.yi;
+                    const int xx = ix ? mini(p.xi + 1, f.nx - 1) : p.xi;
+                    const double c = ldv(d, slot_off(f, tt) + ((int64_t)zz * f.st_z + (int64_t)yy * f.st_y + (int64_t)xx * f.st_x) * f.ncomp);
+                    const bool land = fabs(c) <= zero_tol;
+                    nb_land += land;
+                    const double dist2 = (p.eta - iy) * (p.eta - iy) + (p.xsi - ix) * (p.xsi - ix);
+                    const double inv = 1.0 / dist2;
+                    val += land ? 0.0 : c * inv;
+                    w_sum += land ? 0.0 : inv;
+                    if (dist2 == 0 && !land) {
+                        exact_vals = sizeof(FT) == 4 ? (double)((float)exact_vals + (float)c) : exact_vals + c;
+                        has_exact = true;
+                    }
+                }
+    if (nb_land == 4 * lenZ * lenT) return 0.0;
+    if (nb_land > 0) {
+        value = val / w_sum;
+        if (has_exact) value = exact_vals;
+    }
+    return value;
+}
+
 // NaN -> ErrorInterpolation (field.py:373-378) then out-of-bounds -> 0 (field.py:359-370)
 PK_DEV double finish_value(PCtx& c, const GPos& p, double v) {
     if (v != v && c.state < PK_ERRORINTERPOLATION) c.state = PK_ERRORINTERPOLATION;
@@ -908,8 +969,14 @@ PK_DEV double eval_scalar(const KArgs& a, const Coords& mc, PCtx& c, int fidx, d
     ei_set(c, f.grid, ei);
     double v = 0.0;
     if (!(p.xi < 0 || p.yi < 0 || p.zi < 0)) {
-        if (f.is_const) v = (f.dtype == PK_F64) ? ((const double*)f.data)[f.comp] : (double)((const float*)f.data)[f.comp];
-        else v = (f.dtype == PK_F64) ? xlinear<double>(f, p) : xlinear<float>(f, p);
+        const bool f64 = f.dtype == PK_F64;
+        switch (f.is_const) {
+            case 1: v = f64 ? ((const double*)f.data)[f.comp] : (double)((const float*)f.data)[f.comp]; break;
+            case 2: v = f64 ? xnearest<double>(f, p) : xnearest<float>(f, p); break;
+            case 3: v = f64 ? cgrid_tracer<double>(g, f, p) : cgrid_tracer<float>(g, f, p); break;
+            case 4: v = f64 ? xlinear_invdist<double>(f, p) : xlinear_invdist<float>(f, p); break;
+            default: v = f64 ? xlinear<double>(f, p) : xlinear<float>(f, p); break;
+        }
     }
     return finish_value(c, p, v);
 }

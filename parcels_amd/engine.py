@@ -169,11 +169,12 @@ class DeviceEngine:
             has_ti = f.time_interval is not None and tflt is not None
             d.has_time_interval = int(has_ti)
             is_const = False
+            d.is_const = 0
             try:
                 is_const = isinstance(f.interp_method, XConstantField)
+                d.is_const = int(f.interp_method.kind)  # scalar interpolator code (include/parcels_hip.h)
             except AttributeError:
                 pass
-            d.is_const = int(is_const)
             if is_const:
                 d.has_y = d.has_x = 1
             d.nslots = self.field_nslots[f.name]

@@ -20,6 +20,7 @@ from .interpolators import (
     XLinear,
     XLinear_Velocity,
 )
+from .interpolators import CGrid_Tracer, XLinearInvdistLandTracer, XNearest  # noqa: E402
 from .xgrid import XGrid
 
 _FIELD_DATA_ORDERING = ("T", "Z", "Y", "X")
@@ -184,8 +185,8 @@ class Field:
     def interp_method(self, value):
         if not isinstance(value, ScalarInterpolator):
             raise ValueError(f"interp_method must be a `ScalarInterpolator` object. Got {type(value)=!r}")
-        if not isinstance(value, (XLinear, XConstantField)):
-            raise NotImplementedError(f"{type(value).__name__} has no HIP implementation yet (XLinear, XConstantField do)")
+        if not isinstance(value, (XLinear, XConstantField, XNearest, CGrid_Tracer, XLinearInvdistLandTracer)):
+            raise NotImplementedError(f"{type(value).__name__} has no HIP implementation")
         self.model.field_to_interpolator[self.name] = value
 
     def eval(self, t, z, y, x, particles=None):

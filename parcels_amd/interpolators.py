@@ -14,11 +14,23 @@ class VectorInterpolator:
 
 
 class XLinear(ScalarInterpolator):  # _xinterpolators.py:112-153
-    kind = "xlinear"
+    kind = 0
 
 
 class XConstantField(ScalarInterpolator):  # _xinterpolators.py:156-166
-    kind = "constant"
+    kind = 1
+
+
+class XNearest(ScalarInterpolator):  # _xinterpolators.py:505-553
+    kind = 2
+
+
+class CGrid_Tracer(ScalarInterpolator):  # noqa: N801  _xinterpolators.py:335-383
+    kind = 3
+
+
+class XLinearInvdistLandTracer(ScalarInterpolator):  # _xinterpolators.py:556-613
+    kind = 4
 
 
 class XLinear_Velocity(VectorInterpolator):  # noqa: N801  _xinterpolators.py:169-190

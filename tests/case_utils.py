@@ -12,8 +12,10 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def golden_names():
-    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+def golden_names(kind="advect"):
+    """Fixture names: "advect" = ParticleSet.execute trajectories, "sample" = Field.eval at explicit points."""
+    names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    return [n for n in names if n.startswith("sample_") == (kind == "sample")]
 
 
 def load_golden(name):
@@ -79,7 +81,7 @@ def build_fieldset(case):
         a = a.reshape([a.shape[i] for i in keep])
         data_vars[name] = (tuple(dims[i] for i in keep), a)
     ds = pa.Dataset(data_vars, coords, sgrid=md)
-    fs = pa.FieldSet.from_sgrid_conventions(ds, mesh=case["mesh"])
+    fs = pa.FieldSet.from_sgrid_conventions(ds, mesh=case["mesh"], vector_fields={} if case.get("kind") == "sample" else None)
     if case.get("slip"):
         interp = {"free": pa.XFreeslip, "partial": pa.XPartialslip}[case["slip"]]()
         for vname in ("UV", "UVW"):
@@ -90,6 +92,18 @@ def build_fieldset(case):
     for k, v in (case.get("context") or {}).items():
         fs.add_context(k, v)
     return fs
+
+
+def sample_hip(case):
+    """Field.eval through pk_eval with the requested scalar interpolator."""
+    import parcels_amd as pa
+
+    fs = build_fieldset(case)
+    name = case["sample_field"]
+    fs.fields[name].interp_method = getattr(pa, case["scalar_interp"][name])()
+    fs._engine = None  # the interpolator is part of the device field descriptor
+    val = fs.fields[name].eval(case["t0"], case["z"], case["y"], case["x"])
+    return {"value": np.asarray(val)}
 
 
 def build_pset(case, fs, **kw):
