@@ -44,6 +44,7 @@ def gather_output_columns(columns: dict, group=None) -> dict:
     dist.all_gather_into_tensor(counts, torch.tensor([n_local], dtype=torch.int64, device=dev), group=group)
     counts = counts.cpu().tolist()
     nmax = max(counts) if counts else 0
+    ragged = any(c != nmax for c in counts)
     out = {}
     for name in names:
         col = columns[name]
@@ -52,7 +53,8 @@ def gather_output_columns(columns: dict, group=None) -> dict:
             col = torch.cat([col, pad])
         buf = torch.empty(world * nmax, dtype=col.dtype, device=col.device)
         dist.all_gather_into_tensor(buf, col.contiguous(), group=group)
-        out[name] = torch.cat([buf[r * nmax : r * nmax + counts[r]] for r in range(world)])
+        # equal shards (the common case): the gathered buffer IS the result, no second pass over the data
+        out[name] = torch.cat([buf[r * nmax : r * nmax + counts[r]] for r in range(world)]) if ragged else buf
     return out
 
 
