@@ -46,7 +46,7 @@ struct HostField {
 struct pk_ctx {
     int device = 0;
     hipStream_t compute = nullptr, copy = nullptr;
-    hipEvent_t copy_done = nullptr, ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     bool copy_pending = false;
     std::string err;
     std::vector<HostGrid> grids;
@@ -302,7 +302,6 @@ int32_t pk_init(int32_t device, pk_ctx** out) {
     PK_HIP(ctx, hipGetDeviceProperties(&ctx->prop, device));
     PK_HIP(ctx, hipStreamCreateWithFlags(&ctx->compute, hipStreamNonBlocking));
     PK_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
-    PK_HIP(ctx, hipEventCreateWithFlags(&ctx->copy_done, hipEventDisableTiming));
     PK_HIP(ctx, hipEventCreate(&ctx->ev0));
     PK_HIP(ctx, hipEventCreate(&ctx->ev1));
     PK_HIP(ctx, hipEventCreate(&ctx->ev2));
@@ -355,7 +354,6 @@ int32_t pk_destroy(pk_ctx* ctx) {
         if (ctx->stage[k]) (void)hipHostFree(ctx->stage[k]);
         if (ctx->stage_ev[k]) (void)hipEventDestroy(ctx->stage_ev[k]);
     }
-    if (ctx->copy_done) (void)hipEventDestroy(ctx->copy_done);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);

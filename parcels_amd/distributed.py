@@ -18,7 +18,6 @@ from __future__ import annotations
 
 import ctypes as C
 
-import numpy as np
 
 
 def shard_slice(n_total: int, rank: int, world: int) -> slice:

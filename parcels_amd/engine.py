@@ -136,16 +136,19 @@ class DeviceEngine:
         # C-grid velocity components are stored interleaved ({U,V,W} per cell): the staggered corner values of one
         # evaluation then share cache lines, which is what bounds the sparse NEMO-size configuration
         pack: dict[str, tuple[str, int]] = {}  # field name -> (leader name, group size)
-        for vf in fs.fields.values():
-            if isinstance(vf, VectorField) and isinstance(vf.interp_method, CGrid_Velocity):
-                comps = [c for c in (vf.U, vf.V, vf.W) if c is not None]
-                same = all(hosts[c.name].shape == hosts[comps[0].name].shape and hosts[c.name].dtype == hosts[comps[0].name].dtype
-                           and self.field_nslots[c.name] == self.field_nslots[comps[0].name] for c in comps)
-                if same and len(comps) >= len([1 for c in comps if pack.get(c.name, (None, 0))[1] >= len(comps)]) and len(comps) > 1:
-                    if all(pack.get(c.name, (None, 0))[1] < len(comps) for c in comps):
-                        order = [f.name for f in self.scalar_fields if f.name in {c.name for c in comps}]
-                        for nme in order:
-                            pack[nme] = (order[0], len(order))
+        cgrid_vectors = [vf for vf in fs.fields.values() if isinstance(vf, VectorField) and isinstance(vf.interp_method, CGrid_Velocity)]
+        cgrid_vectors.sort(key=lambda vf: -(3 if vf.W is not None else 2))  # UVW before UV: the larger group wins
+        for vf in cgrid_vectors:
+            comps = [c for c in (vf.U, vf.V, vf.W) if c is not None]
+            if any(c.name in pack for c in comps):
+                continue  # already part of a (larger) group
+            ref = hosts[comps[0].name]
+            same = all(hosts[c.name].shape == ref.shape and hosts[c.name].dtype == ref.dtype
+                       and self.field_nslots[c.name] == self.field_nslots[comps[0].name] for c in comps)
+            if same:
+                order = [f.name for f in self.scalar_fields if f.name in {c.name for c in comps}]  # creation order
+                for nme in order:
+                    pack[nme] = (order[0], len(order))
         for f in self.scalar_fields:
             h = hosts[f.name]
             dims = f.data.dims

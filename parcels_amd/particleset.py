@@ -4,7 +4,6 @@ from __future__ import annotations
 
 import datetime
 import types
-import warnings
 
 import numpy as np
 
