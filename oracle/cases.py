@@ -616,4 +616,18 @@ def all_cases() -> dict:
     add(diffusion_case("diff_m1_constkh_flat", mesh="flat", kernels=["AdvectionDiffusionM1"], seed=45, const_kh=5.0))
     add(diffusion_case("diff_m1_sph_f32part", mesh="spherical", kernels=["AdvectionDiffusionM1"], seed=46,
                        spatial_dtype="float32"))
+    # --- non-finite release positions (tests/test_spatialhash.py:50-56: NaN/inf -> GRID_SEARCH_ERROR) ---------------
+    for nm, base, kern in (("agrid_sph_rk4_nonfinite", "agrid_sph_rk4_f64", ["AdvectionRK4", "DeleteParticle"]),
+                           ("cgrid_curv_sph_rk4_nonfinite", "cgrid_curv_sph_rk4_3d", ["AdvectionRK4_3D", "DeleteParticle"])):
+        nf = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in c[base].items()}
+        nf["name"] = nm
+        nf["kernels"] = kern
+        nf["x"][3], nf["y"][7], nf["z"][11] = np.nan, np.nan, np.nan
+        nf["x"][13], nf["y"][17], nf["z"][19] = np.inf, -np.inf, np.inf
+        add(nf)
+    nf = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in c["agrid_sph_rk4_f64"].items()}
+    nf["name"] = "agrid_sph_rk4_nan_raises"
+    nf["x"][5] = np.nan
+    add(nf)
+
     return c

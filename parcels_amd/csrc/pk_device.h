@@ -559,7 +559,7 @@ struct Corners {
 PK_DEV Corners make_corners(const DField& f, const GPos& p) {
     Corners k;
     k.lenT = p.tau > 0;
-    k.lenZ = p.zeta > 0;
+    k.lenZ = !(p.zeta <= 0);  // also for a NaN zeta: it must poison the value like in a batch whose lenZ is 2
     k.ot0 = slot_off(f, p.ti);
     k.ot1 = slot_off(f, mini(p.ti + 1, f.nt - 1));
     const int nc = f.ncomp;
@@ -896,8 +896,12 @@ PK_DEV double xlinear_invdist(const DField& f, const GPos& p) {
 
 // NaN -> ErrorInterpolation (field.py:373-378) then out-of-bounds -> 0 (field.py:359-370)
 PK_DEV double finish_value(PCtx& c, const GPos& p, double v) {
+    const bool oob = p.xi < 0 || p.yi < 0 || p.zi < 0;
+    // the reference interpolates wrapped-around garbage for out-of-bounds lanes before zeroing it: finite, unless a
+    // barycentric coordinate is non-finite (position +-inf / NaN) -> NaN -> ErrorInterpolation
+    if (oob && !(isfinite(p.xsi) && isfinite(p.eta) && isfinite(p.zeta) && isfinite(p.tau))) v = NAN;
     if (v != v && c.state < PK_ERRORINTERPOLATION) c.state = PK_ERRORINTERPOLATION;
-    if (p.xi < 0 || p.yi < 0 || p.zi < 0) v = 0.0;
+    if (oob) v = 0.0;
     return v;
 }
 
