@@ -105,7 +105,9 @@ typedef struct pk_grid_desc {
     const double* node_xyz; /* spherical curvilinear grids: unit-sphere coordinates of every node, three (ny, nx)
                                planes X = cos(lon)cos(lat), Y = sin(lon)cos(lat), Z = sin(lat) (index_search.py:439-450);
                                NULL otherwise.  Computed once on the host instead of 8 sin/cos pairs per evaluation. */
-    /* CSR Morton hash, curvilinear only (all NULL/0 otherwise) */
+    /* CSR Morton hash, curvilinear only (all NULL/0 otherwise).  Pass the four arrays to reuse a table built by the
+       caller (the reference's SpatialHash._hash_table, spatialhash.py:269-387); leave h_keys NULL and the library
+       builds the same table on the device from lon/lat/node_xyz (bit-identical; pk_grid_hash_download reads it back). */
     const uint32_t* h_keys;
     const int64_t* h_starts;
     const int64_t* h_counts;
@@ -117,6 +119,19 @@ typedef struct pk_grid_desc {
     double h_bbox[6]; /* xmin,xmax,ymin,ymax,zmin,zmax of the hash grid                             */
 } pk_grid_desc;
 int32_t pk_grid_create(pk_ctx* ctx, const pk_grid_desc* desc, int32_t* grid_id);
+
+/* The spatial-hash table of a curvilinear grid as resident on the device (SpatialHash._hash_table, _bitwidth and the
+   hash-grid bounds, spatialhash.py:60-108,214-228,269-387). */
+typedef struct pk_hash_info {
+    int64_t nkeys;
+    int64_t nentries;
+    int32_t bitwidth;
+    int32_t reserved;
+    double bbox[6];
+} pk_hash_info;
+int32_t pk_grid_hash_info(pk_ctx* ctx, int32_t grid, pk_hash_info* out);
+/* keys[nkeys], starts[nkeys], counts[nkeys], faces[nentries]; any pointer may be NULL to skip that array. */
+int32_t pk_grid_hash_download(pk_ctx* ctx, int32_t grid, uint32_t* keys, int64_t* starts, int64_t* counts, uint32_t* faces);
 
 /* ---- fields: Field data backend (model.py:67-113, _windowed_array.py:25-113) --------------------- */
 typedef struct pk_field_desc {

@@ -156,6 +156,10 @@ class ExecStats(C.Structure):
 
 
 # every symbol include/parcels_hip.h declares (tests/test_abi.py checks the library exports all of them)
+class HashInfo(C.Structure):
+    _fields_ = [("nkeys", C.c_int64), ("nentries", C.c_int64), ("bitwidth", C.c_int32), ("reserved", C.c_int32), ("bbox", C.c_double * 6)]
+
+
 ABI_SYMBOLS = [
     "pk_abi_version",
     "pk_init",
@@ -163,6 +167,8 @@ ABI_SYMBOLS = [
     "pk_last_error",
     "pk_get_device_info",
     "pk_grid_create",
+    "pk_grid_hash_info",
+    "pk_grid_hash_download",
     "pk_field_create",
     "pk_field_upload_level",
     "pk_field_sync",
@@ -212,6 +218,8 @@ def load():
     lib.pk_destroy.argtypes = [C.c_void_p]
     lib.pk_get_device_info.argtypes = [C.c_void_p, C.POINTER(DeviceInfo)]
     lib.pk_grid_create.argtypes = [C.c_void_p, C.POINTER(GridDesc), C.POINTER(C.c_int32)]
+    lib.pk_grid_hash_info.argtypes = [C.c_void_p, C.c_int32, C.POINTER(HashInfo)]
+    lib.pk_grid_hash_download.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 4
     lib.pk_field_create.argtypes = [C.c_void_p, C.POINTER(FieldDesc), C.POINTER(C.c_int32)]
     lib.pk_field_upload_level.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
     lib.pk_field_sync.argtypes = [C.c_void_p]

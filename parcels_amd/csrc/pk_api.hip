@@ -16,6 +16,7 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include "pk_hashbuild.h"
 #include "pk_kernels.h"
 
 using namespace pk;
@@ -28,6 +29,7 @@ struct HostGrid {
     pk_grid_desc desc;
     DGrid d;
     std::vector<void*> allocs;
+    int64_t h_nentries = 0;
 };
 
 struct HostField {
@@ -424,16 +426,56 @@ int32_t pk_grid_create(pk_ctx* ctx, const pk_grid_desc* desc, int32_t* grid_id) 
     }
     if ((rc = upload(ctx, g, desc->depth, (size_t)desc->nz, &d.depth))) return rc;
     if (desc->kind == 1) {
-        if (!desc->h_keys || desc->h_nkeys <= 0) return ctx->fail("curvilinear grid needs a spatial-hash table");
-        if ((rc = upload(ctx, g, desc->h_keys, (size_t)desc->h_nkeys, &d.h_keys))) return rc;
-        if ((rc = upload(ctx, g, desc->h_starts, (size_t)desc->h_nkeys, &d.h_starts))) return rc;
-        if ((rc = upload(ctx, g, desc->h_counts, (size_t)desc->h_nkeys, &d.h_counts))) return rc;
-        if ((rc = upload(ctx, g, desc->h_faces, (size_t)desc->h_nentries, &d.h_faces))) return rc;
-        d.h_nkeys = desc->h_nkeys;
-        d.h_bitwidth = desc->h_bitwidth;
-        for (int k = 0; k < 6; k++) d.h_bbox[k] = desc->h_bbox[k];
+        if (desc->h_keys && desc->h_nkeys > 0) {  // table built by the caller (e.g. the reference's own SpatialHash)
+            if ((rc = upload(ctx, g, desc->h_keys, (size_t)desc->h_nkeys, &d.h_keys))) return rc;
+            if ((rc = upload(ctx, g, desc->h_starts, (size_t)desc->h_nkeys, &d.h_starts))) return rc;
+            if ((rc = upload(ctx, g, desc->h_counts, (size_t)desc->h_nkeys, &d.h_counts))) return rc;
+            if ((rc = upload(ctx, g, desc->h_faces, (size_t)desc->h_nentries, &d.h_faces))) return rc;
+            d.h_nkeys = desc->h_nkeys;
+            g.h_nentries = desc->h_nentries;
+            d.h_bitwidth = desc->h_bitwidth;
+            for (int k = 0; k < 6; k++) d.h_bbox[k] = desc->h_bbox[k];
+        } else {  // built here, on the device, from the node table
+            HashBuildResult hb;
+            std::string msg;
+            hipError_t e = build_spatial_hash(ctx->compute, d.node_tab, desc->ny, desc->nx, desc->spherical, &hb, &msg);
+            if (e != hipSuccess) return ctx->fail("spatial hash build: " + msg);
+            g.allocs.push_back(hb.keys); g.allocs.push_back(hb.starts); g.allocs.push_back(hb.counts); g.allocs.push_back(hb.faces);
+            d.h_keys = hb.keys; d.h_starts = hb.starts; d.h_counts = hb.counts; d.h_faces = hb.faces;
+            d.h_nkeys = hb.nkeys;
+            g.h_nentries = hb.nentries;
+            d.h_bitwidth = hb.bitwidth;
+            for (int k = 0; k < 6; k++) d.h_bbox[k] = hb.bbox[k];
+        }
     }
     *grid_id = (int32_t)ctx->grids.size() - 1;
+    return 0;
+}
+
+int32_t pk_grid_hash_info(pk_ctx* ctx, int32_t grid, pk_hash_info* out) {
+    if (!ctx || !out) return -2;
+    if (grid < 0 || grid >= (int)ctx->grids.size()) return ctx->fail("unknown grid");
+    const HostGrid& g = ctx->grids[grid];
+    out->nkeys = g.d.h_nkeys;
+    out->nentries = g.h_nentries;
+    out->bitwidth = g.d.h_bitwidth;
+    out->reserved = 0;
+    for (int k = 0; k < 6; k++) out->bbox[k] = g.d.h_bbox[k];
+    return 0;
+}
+
+int32_t pk_grid_hash_download(pk_ctx* ctx, int32_t grid, uint32_t* keys, int64_t* starts, int64_t* counts, uint32_t* faces) {
+    if (!ctx) return -2;
+    if (grid < 0 || grid >= (int)ctx->grids.size()) return ctx->fail("unknown grid");
+    const HostGrid& g = ctx->grids[grid];
+    if (g.d.kind != 1 || g.d.h_nkeys <= 0) return ctx->fail("grid has no spatial-hash table");
+    PK_HIP(ctx, hipSetDevice(ctx->device));
+    PK_HIP(ctx, hipStreamSynchronize(ctx->compute));
+    const size_t nk = (size_t)g.d.h_nkeys, ne = (size_t)g.h_nentries;
+    if (keys) PK_HIP(ctx, hipMemcpy(keys, g.d.h_keys, nk * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (starts) PK_HIP(ctx, hipMemcpy(starts, g.d.h_starts, nk * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (counts) PK_HIP(ctx, hipMemcpy(counts, g.d.h_counts, nk * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (faces) PK_HIP(ctx, hipMemcpy(faces, g.d.h_faces, ne * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -15,6 +15,7 @@ Replaces the body of the reference's ``Kernel.execute`` (src/parcels/_core/kerne
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -29,7 +30,13 @@ def _ptr(a):
 
 
 class DeviceEngine:
-    def __init__(self, fieldset, device: int = 0, nslots: int | None = None, memory_fraction: float = 0.6):
+    def __init__(self, fieldset, device: int = 0, nslots: int | None = None, memory_fraction: float = 0.6,
+                 hash_build: str | None = None):
+        # hash_build: "device" (default) builds the Morton table of a curvilinear grid on the GPU (csrc/pk_hashbuild.hip);
+        # "host" uploads parcels_amd.spatialhash.SpatialHash's table.  A grid whose host table already exists uploads it.
+        self.hash_build = hash_build or os.environ.get("PARCELS_AMD_HASH_BUILD", "device")
+        if self.hash_build not in ("device", "host"):
+            raise ValueError("hash_build must be 'device' or 'host'")
         self.fieldset = fieldset
         self.device = int(device)
         self.ctx = _hip.Context(self.device)
@@ -82,7 +89,7 @@ class DeviceEngine:
             xyz = np.ascontiguousarray(np.stack((np.cos(lonr) * np.cos(latr), np.sin(lonr) * np.cos(latr), np.sin(latr))))
             keep.append(xyz)
             d.node_xyz = _ptr(xyz)
-        if d.kind == 1:
+        if d.kind == 1 and (self.hash_build == "host" or g._spatialhash is not None):
             t = g.get_spatial_hash().table()
             keys = np.ascontiguousarray(t["keys"], dtype=np.uint32)
             starts = np.ascontiguousarray(t["starts"], dtype=np.int64)
@@ -99,6 +106,20 @@ class DeviceEngine:
         self.ctx.check(self.lib.pk_grid_create(self.ctx.handle, C.byref(d), C.byref(gid)), "pk_grid_create")
         del keep  # copied on call
         return gid.value
+
+    def hash_table(self, igrid: int = 0) -> dict:
+        """The spatial-hash table resident on the device for grid ``igrid`` (same dict layout as SpatialHash.table())."""
+        info = _hip.HashInfo()
+        gid = self.grid_ids[igrid]
+        self.ctx.check(self.lib.pk_grid_hash_info(self.ctx.handle, gid, C.byref(info)), "pk_grid_hash_info")
+        keys = np.empty(info.nkeys, np.uint32)
+        starts = np.empty(info.nkeys, np.int64)
+        counts = np.empty(info.nkeys, np.int64)
+        faces = np.empty(info.nentries, np.uint32)
+        self.ctx.check(self.lib.pk_grid_hash_download(self.ctx.handle, gid, _ptr(keys), _ptr(starts), _ptr(counts), _ptr(faces)),
+                       "pk_grid_hash_download")
+        return dict(keys=keys, starts=starts, counts=counts, faces=faces, bitwidth=int(info.bitwidth),
+                    bbox=np.array(list(info.bbox), dtype=np.float64))
 
     # ---- fields ----------------------------------------------------------------------------------------------
     def _plan_and_create_fields(self, nslots, memory_fraction):
