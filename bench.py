@@ -131,6 +131,7 @@ def main():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
+            torch.cuda.synchronize()
 
     # measured device-to-device copy bandwidth: the practical HBM ceiling used as a second roofline denominator
     copy_gbps = eng.ctx.copy_bandwidth(1 << 30, 5) if rank == 0 else 0.0
@@ -214,7 +215,7 @@ def main():
                     out["roofline"]["traffic_source"] = pj.get("source")
             except Exception:
                 pass
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg is reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(case, steps=K, sample=min(args.cpu_sample, npart))
         print(json.dumps(out))
     if dist is not None:
