@@ -275,7 +275,9 @@ def make_ref_grid(*, lon, lat, depth, mesh, x_pad="low", y_pad="low", z_pad="bot
         sizes = {"XG": lon.shape[1], "YG": lon.shape[0]}
         coords = {"lon": DA(lon, dims=("YG", "XG")), "lat": DA(lat, dims=("YG", "XG"))}
     if has_z:
-        depth = np.asarray(depth, dtype=float)
+        depth = np.asarray(depth)
+        if not np.issubdtype(depth.dtype, np.floating):
+            depth = depth.astype(float)
         sizes["depth"] = depth.shape[0]
         coords["depth"] = DA(depth, dims=("depth",))
     sizes.update(sizes_extra or {})

@@ -76,10 +76,12 @@ def device_output_columns(engine) -> dict:
     n = d.n
     sp = "<f4" if d.spatial_dtype == _hip.PK_F32 else "<f8"
     cols = {}
-    if n == 0:
-        return cols
+    dev = f"cuda:{engine.device}"
     for name, ptr, ts in (("t", d.t, "<f8"), ("z", d.z, sp), ("y", d.y, sp), ("x", d.x, sp), ("particle_id", d.particle_id, "<i8")):
-        cols[name] = torch.as_tensor(_DeviceColumn(ptr, n, ts), device=f"cuda:{engine.device}")
+        if n == 0:  # an empty shard still takes part in the all-gather
+            cols[name] = torch.empty(0, dtype={"<f8": torch.float64, "<f4": torch.float32, "<i8": torch.int64}[ts], device=dev)
+        else:
+            cols[name] = torch.as_tensor(_DeviceColumn(ptr, n, ts), device=dev)
     return cols
 
 

@@ -13,8 +13,11 @@ ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def golden_names(kind="advect"):
-    """Fixture names: "advect" = ParticleSet.execute trajectories, "sample" = Field.eval at explicit points."""
+    """Fixture names: "advect" = ParticleSet.execute trajectories (all of them), "sample" = Field.eval at explicit points,
+    "v3jit" = the subset of "advect" built from the reference's v3-JIT regression data (oracle/make_v3_golden.py)."""
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    if kind == "v3jit":
+        return [n for n in names if n.startswith("v3jit_")]
     return [n for n in names if n.startswith("sample_") == (kind == "sample")]
 
 
@@ -82,6 +85,10 @@ def build_fieldset(case):
         data_vars[name] = (tuple(dims[i] for i in keep), a)
     ds = pa.Dataset(data_vars, coords, sgrid=md)
     fs = pa.FieldSet.from_sgrid_conventions(ds, mesh=case["mesh"], vector_fields={} if case.get("kind") == "sample" else None)
+    if case.get("cgrid"):  # node-dimensioned fields read as a C-grid (the reference's v3 regression test, test_interpolation.py:346-347)
+        for vname in ("UV", "UVW"):
+            if vname in fs.fields and not isinstance(fs.fields[vname].interp_method, pa.CGrid_Velocity):
+                fs.fields[vname].interp_method = pa.CGrid_Velocity()
     if case.get("slip"):
         interp = {"free": pa.XFreeslip, "partial": pa.XPartialslip}[case["slip"]]()
         for vname in ("UV", "UVW"):
@@ -207,3 +214,29 @@ def tolerance_for(name, case):
     if any(k.startswith("AdvectionDiffusion") or k == "DiffusionUniformKh" for k in case["kernels"]):
         return 1e-11  # log/sin/cos of the Box-Muller transform differ by an ulp between libm implementations
     return 1e-12
+
+
+# ---- the reference's v3-JIT regression trajectories (tests/test_interpolation.py:297-378) ---------------------------
+V3_ATOL = 1e-6  # the reference's own bar for v4-vs-v3 (np.testing.assert_allclose(..., atol=1e-6), :376-378)
+
+
+def v3_observations(run, case):
+    """lon/lat/z (n, 4) at t = 0, 1, 2, 3 s from `run(case, endtime) -> soa dict`; deleted particles are NaN like in the v3 file."""
+    n = len(case["x"])
+    sdt = np.dtype(case["spatial_dtype"])
+    obs = {k: np.full((n, 4), np.nan) for k in ("x", "y", "z")}
+    for k in obs:
+        obs[k][:, 0] = np.asarray(case[k]).astype(sdt)
+    for step in (1, 2, 3):
+        out = run(case, float(step))
+        ids = np.asarray(out["particle_id"])
+        for k in obs:
+            obs[k][ids, step] = out[k]
+    return obs
+
+
+def assert_matches_v3(obs, case, label):
+    for k, ref in (("x", "v3_lon"), ("y", "v3_lat"), ("z", "v3_z")):
+        v3 = np.asarray(case[ref])
+        assert np.array_equal(np.isnan(obs[k]), np.isnan(v3)), f"{label}: the set of deleted particles differs from v3 ({k})"
+        np.testing.assert_allclose(obs[k], v3, atol=V3_ATOL, rtol=0, equal_nan=True, err_msg=f"{label}: {k}")
