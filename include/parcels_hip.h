@@ -211,7 +211,9 @@ typedef struct pk_exec_params {
     int32_t fU, fV, fW, fKh_zonal, fKh_meridional; /* field ids, -1 if absent                       */
     int32_t sort_by_cell; /* 1: reorder device rows by cell key before stepping (row order on the
                               host is unaffected)                                                  */
-    int32_t reserved0;
+    int32_t next_dt_f32; /* the particle class declares next_dt as float32 (the default dtype of Variable, particle.py:36-60;
+                            tests/utils.py:24-25): AdvectionRK45's store into it rounds to f32, and `dt = next_dt`
+                            (kernel.py:118-120) then carries the rounded value.  The bound column itself stays f64.   */
     double endtime; /* seconds; every live particle is advanced from its own t to endtime           */
     double dt0;     /* execute()'s dt (sign gives the time direction)                               */
     double rk45_tol, rk45_min_dt, rk45_max_dt; /* fieldset.context (kernel.py:134-159)              */

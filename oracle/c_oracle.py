@@ -125,7 +125,7 @@ class PoParams(C.Structure):
         ("fW", C.c_int32),
         ("fKhz", C.c_int32),
         ("fKhm", C.c_int32),
-        ("pad", C.c_int32),
+        ("next_dt_f32", C.c_int32),
         ("endtime", C.c_double),
         ("dt0", C.c_double),
         ("rk45_tol", C.c_double),
@@ -328,6 +328,7 @@ class MarshalledCase:
         p.cgrid = {"free": 2, "partial": 3}.get(case.get("slip"), int(bool(case.get("cgrid"))))
         p.rk45_mode = int("RK45_tol" in context)
         p.have_guess0 = int(have_guess0)
+        p.next_dt_f32 = int(np.dtype(case.get("next_dt_dtype", "float64")) == np.float32)
         fi = self.field_index
         p.fU, p.fV, p.fW = fi.get("U", -1), fi.get("V", -1), fi.get("W", -1)
         p.fKhz, p.fKhm = fi.get("Kh_zonal", -1), fi.get("Kh_meridional", -1)
@@ -386,7 +387,7 @@ def initial_particles(case: dict, ngrids: int) -> dict:
         "ei": np.zeros((n, ngrids), np.int32),
     }
     if "AdvectionRK45" in case["kernels"]:
-        d["next_dt"] = np.full(n, float(case.get("next_dt0", case["dt"])), np.float64)
+        d["next_dt"] = np.full(n, float(case.get("next_dt0", case["dt"])), np.dtype(case.get("next_dt_dtype", "float64")))
     return d
 
 
@@ -419,7 +420,7 @@ def execute(mc: MarshalledCase, data: dict, *, kernels, endtime, dt0, context=No
         data[k] = w[k].astype(sdt)
     data["t"], data["dt"] = w["t"], w["dt"]
     if nd is not None:
-        data["next_dt"] = nd
+        data["next_dt"] = nd.astype(data["next_dt"].dtype)  # exact: the C code already rounded f32 columns
     data["state"], data["ei"], data["particle_id"] = state, ei, pid
     keep = data["state"] != 30
     if not keep.all():
@@ -507,8 +508,23 @@ def run_case(case: dict, nthreads: int = 1):
     if case.get("populate"):  # ParticleSet.populate_indices (particleset.py:252-262)
         populate_indices(mc, data)
         have_guess0 = 1
-    stats = execute(mc, data, kernels=case["kernels"], endtime=end, dt0=dt, context=ctx, seed=case.get("seed", 0),
-                    have_guess0=have_guess0, nthreads=nthreads)
+    # output intervals (particleset.py:440-462): one Kernel.execute per interval, dt is NOT reset in between
+    stops = [end]
+    if case.get("outputdt"):  # next_output accumulates (particleset.py:441,455): k * outputdt would round differently
+        stops = []
+        next_output = start + float(case["outputdt"]) * sign
+        time = start
+        while sign * (time - end) < 0:
+            time = (min if sign > 0 else max)(next_output, end)
+            stops.append(time)
+            if abs(time - next_output) < 0.001:
+                next_output += float(case["outputdt"]) * sign
+    for stop in stops:
+        stats = execute(mc, data, kernels=case["kernels"], endtime=stop, dt0=dt, context=ctx, seed=case.get("seed", 0),
+                        have_guess0=have_guess0, nthreads=nthreads)
+        have_guess0 = 1
+        if len(data["state"]) == 0 or np.any(data["state"] >= 50):
+            break
     err = None
     for code, name in ERRORS_TO_THROW:
         if np.any(data["state"] == code):

@@ -630,4 +630,32 @@ def all_cases() -> dict:
     nf["x"][5] = np.nan
     add(nf)
 
+    # --- output intervals + the float32 `next_dt` Variable of the reference's tests (tests/utils.py:24-25) -----------
+    # outputdt = 2.3 dt: the last step of every interval is clipped to a dt that float32 cannot hold, AdvectionRK45 copies
+    # it into next_dt and `dt = next_dt` (kernel.py:118-120) carries the rounded value into the next interval.
+    for nm, nd in (("agrid_sph_rk45_outputdt_f64nextdt", "float64"), ("agrid_sph_rk45_outputdt_f32nextdt", "float32")):
+        oc = rect_agrid_case(nm, mesh="spherical", kernels=["AdvectionRK45"], seed=62, npart=100, runtime=14 * 3600.0)
+        oc["outputdt"] = 2.3 * 3600.0 + 0.7
+        oc["next_dt_dtype"] = nd
+        oc["context"] = {"RK45_tol": 500.0, "RK45_min_dt": 10.0, "RK45_max_dt": 4 * 3600.0}
+        add(oc)
+    oc = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in c["agrid_sph_rk45_outputdt_f32nextdt"].items()}
+    oc["name"] = "agrid_sph_rk45_outputdt_f32nextdt_maxdt"  # max_dt = dt: the clipped, f32-rounded dt IS the next interval's first step
+    oc["context"] = {"RK45_tol": 500.0, "RK45_min_dt": 10.0, "RK45_max_dt": 3600.0}
+    add(oc)
+    oc = rect_agrid_case("agrid_flat_rk4_3d_outputdt", mesh="flat", kernels=["AdvectionRK4_3D"], seed=63, with_w=True, npart=100,
+                         runtime=9 * 3600.0)
+    oc["outputdt"] = 2.5 * 3600.0
+    add(oc)
+
+    # --- length-1 dimensions (tests/test_advection.py:207-234 test_length1dimensions; index_search.py:45-46) -----
+    # A coordinate of one node: index 0, bcoord 0 and no out-of-bounds test on that axis, wherever the particle is.
+    for nm, axes in (("agrid_flat_len1_x", "x"), ("agrid_flat_len1_y", "y"), ("agrid_flat_len1_z", "z"), ("agrid_flat_len1_xyz", "xyz")):
+        lc = rect_agrid_case(nm, mesh="flat", kernels=["AdvectionRK4_3D"], seed=61, with_w=True, npart=60, runtime=6 * 3600.0)
+        for ax, key, axis in (("x", "lon", 3), ("y", "lat", 2), ("z", "depth", 1)):
+            if ax in axes:
+                lc[key] = lc[key][:1].copy()
+                lc["fields"] = {k: np.ascontiguousarray(np.take(v, [0], axis=axis)) for k, v in lc["fields"].items()}
+        add(lc)
+
     return c

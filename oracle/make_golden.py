@@ -165,7 +165,7 @@ def ref_run_case(case):
     extra_vars = None
     pkw = None
     if "AdvectionRK45" in case["kernels"]:
-        extra_vars = [("next_dt", np.float64, float(case.get("next_dt0", case["dt"])))]
+        extra_vars = [("next_dt", np.dtype(case.get("next_dt_dtype", "float64")).type, float(case.get("next_dt0", case["dt"])))]
     n = len(np.atleast_1d(case["x"]))
     z = case.get("z")
     if z is not None and np.ndim(z) == 0:
@@ -176,7 +176,7 @@ def ref_run_case(case):
         out, err = rs.run_reference(
             fs, klist, x=np.asarray(case["x"]), y=np.asarray(case["y"]), z=z, t=case.get("t0"), dt=float(case["dt"]),
             runtime=case.get("runtime"), endtime_s=case.get("endtime"), spatial_dtype=np.dtype(case.get("spatial_dtype", "float64")).type,
-            extra_vars=extra_vars, particle_kwargs=pkw, populate=bool(case.get("populate")),
+            extra_vars=extra_vars, particle_kwargs=pkw, populate=bool(case.get("populate")), outputdt=case.get("outputdt"),
         )
     finally:
         np.random.normal = old_normal

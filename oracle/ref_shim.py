@@ -343,8 +343,31 @@ def make_ref_fieldset(*, grid, fields: dict, time_s=None, cgrid=False, constants
     return RefFieldSet(fobjs, gridset, tint)
 
 
+class _OutputStub:
+    """What ParticleSet.execute touches of a ParticleFile (particleset.py:401-403,419-462): it splits the run into
+    output intervals, i.e. one Kernel.execute per interval."""
+
+    def __init__(self, outputdt_s):
+        self.outputdt = outputdt_s
+        self.metadata = {}
+        self.path = "<memory>"
+        self.times = []
+
+    def set_metadata(self, mesh):
+        pass
+
+    def write(self, pset, time):
+        self.times.append(float(time))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 def run_reference(fieldset, kernels, *, x, y, z, t=None, dt, runtime=None, endtime_s=None, spatial_dtype=np.float64,
-                  extra_vars=None, particle_kwargs=None, populate=False):
+                  extra_vars=None, particle_kwargs=None, populate=False, outputdt=None):
     """Run the reference's own ParticleSet.execute and return a copy of its SoA dict (+ raised exception name)."""
     m = load_reference()
     P = m["particle"]
@@ -365,6 +388,8 @@ def run_reference(fieldset, kernels, *, x, y, z, t=None, dt, runtime=None, endti
         kw["runtime"] = runtime
     if endtime_s is not None:
         kw["endtime"] = np.timedelta64(int(round(endtime_s * 1e9)), "ns")
+    if outputdt is not None:  # particlefile.py needs real pyarrow/xarray: only the loop's use of it is reproduced
+        kw["output_file"] = _OutputStub(float(outputdt))
     import warnings
 
     with warnings.catch_warnings():

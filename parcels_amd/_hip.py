@@ -129,7 +129,7 @@ class ExecParams(C.Structure):
         ("fKh_zonal", C.c_int32),
         ("fKh_meridional", C.c_int32),
         ("sort_by_cell", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("next_dt_f32", C.c_int32),
         ("endtime", C.c_double),
         ("dt0", C.c_double),
         ("rk45_tol", C.c_double),

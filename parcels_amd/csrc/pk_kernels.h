@@ -164,7 +164,7 @@ PK_DEV bool prepare(const KArgs& a, int kid, int stage, int kslot, PCtx& c, PSta
             const bool increase = good && (kappa <= prm.rk45_tol / 10) && (fabs(dt * 2) <= fabs(prm.rk45_max_dt));
             double next_dt = increase ? dt * 2 : dt;
             if (fabs(next_dt) > fabs(prm.rk45_max_dt)) next_dt = prm.rk45_max_dt * sign_dt;
-            p.next_dt = next_dt;
+            p.next_dt = prm.next_dt_f32 ? (double)(float)next_dt : next_dt;  // assignment into an f32 column
             if (good) c.state = PK_EVALUATE;  // :146 overwrites any sampling error code
             double ndt = good ? dt : dt / 2;
             if (fabs(ndt) < fabs(prm.rk45_min_dt)) ndt = prm.rk45_min_dt * sign_dt;

@@ -69,6 +69,10 @@ class Dataset:
             return self.data_vars[k]
         return self.coords[k]
 
+    def __setitem__(self, k, v):
+        """ds["W"] = (dims, array) or a DataArray: adds / replaces a data variable (a coordinate if the name is one)."""
+        (self.coords if k in self.coords else self.data_vars)[k] = _as_da(v)
+
     def __contains__(self, k):
         return k in self.data_vars or k in self.coords
 

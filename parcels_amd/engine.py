@@ -55,6 +55,7 @@ class DeviceEngine:
         self.field_nslots: dict[str, int] = {}
         self._plan_and_create_fields(nslots, memory_fraction)
         self._bound_sig = None
+        self._next_dt_f32 = None
         self.last_stats: dict | None = None
 
     # ---- grids -----------------------------------------------------------------------------------------------
@@ -295,25 +296,35 @@ class DeviceEngine:
         d.dz, d.dy, d.dx = _ptr(data["dz"]), _ptr(data["dy"]), _ptr(data["dx"])
         d.dt = _ptr(data["dt"])
         nd = data.get("next_dt")
-        if nd is not None and nd.dtype != np.float64:
-            raise TypeError("next_dt must be float64")
+        self._next_dt_f32 = None
+        if nd is not None and nd.dtype == np.float32:
+            # Variable("next_dt") defaults to float32 (particle.py:36-60).  The device column is f64; the kernel rounds every
+            # store to f32 (pk_exec_params.next_dt_f32), so this f64 shadow converts back exactly.
+            self._next_dt_f32 = (nd, nd.astype(np.float64))
+            nd = self._next_dt_f32[1]
+        elif nd is not None and nd.dtype != np.float64:
+            raise TypeError("next_dt must be float32 or float64")
         d.next_dt = _ptr(nd) if nd is not None else None
         d.state, d.ei, d.particle_id = _ptr(data["state"]), _ptr(data["ei"]), _ptr(data["particle_id"])
         self.ctx.check(self.lib.pk_particles_bind(self.ctx.handle, C.byref(d)), "pk_particles_bind")
         self._bound = data
 
     def h2d(self):
+        if self._next_dt_f32 is not None:
+            self._next_dt_f32[1][:] = self._next_dt_f32[0]
         self.ctx.check(self.lib.pk_particles_h2d(self.ctx.handle), "pk_particles_h2d")
 
     def d2h(self, columns=None):
         """Copy the particle columns back to the bound NumPy arrays (all, or only the named ones)."""
         if columns is None:
             self.ctx.check(self.lib.pk_particles_d2h(self.ctx.handle), "pk_particles_d2h")
-            return
-        mask = 0
-        for name in columns:
-            mask |= _hip.COLUMN_BITS[name]
-        self.ctx.check(self.lib.pk_particles_d2h_columns(self.ctx.handle, mask), "pk_particles_d2h_columns")
+        else:
+            mask = 0
+            for name in columns:
+                mask |= _hip.COLUMN_BITS.get(name, 0)  # other user Variables live on the host only (no kernel writes them)
+            self.ctx.check(self.lib.pk_particles_d2h_columns(self.ctx.handle, mask), "pk_particles_d2h_columns")
+        if self._next_dt_f32 is not None and (columns is None or "next_dt" in columns):
+            self._next_dt_f32[0][:] = self._next_dt_f32[1]
 
     # ---- execution -------------------------------------------------------------------------------------------
     def make_params(self, kernel_ids, *, endtime, dt0, context=None, seed=0, reset_state=1, have_guess0=0, sort_by_cell=0):
@@ -336,6 +347,7 @@ class DeviceEngine:
         p.fKh_zonal = fid.get("Kh_zonal", -1)
         p.fKh_meridional = fid.get("Kh_meridional", -1)
         p.rk45_mode = int("RK45_tol" in context)
+        p.next_dt_f32 = int(getattr(self, "_next_dt_f32", None) is not None)
         p.reset_state = int(reset_state)
         p.have_guess0 = int(have_guess0)
         p.sort_by_cell = int(sort_by_cell)

@@ -119,12 +119,36 @@ def build_pset(case, fs, **kw):
     sdt = np.dtype(case.get("spatial_dtype", "float64")).type
     pclass = pa.get_default_particle(sdt)
     if "AdvectionRK45" in case["kernels"]:
-        pclass = pclass.add_variable(pa.Variable("next_dt", dtype=np.float64, initial=float(case.get("next_dt0", case["dt"]))))
+        pclass = pclass.add_variable(pa.Variable("next_dt", dtype=np.dtype(case.get("next_dt_dtype", "float64")).type,
+                                                 initial=float(case.get("next_dt0", case["dt"]))))
     n = len(np.atleast_1d(case["x"]))
     t0 = case.get("t0")
     t = np.zeros(n) if t0 is None else np.broadcast_to(np.asarray(t0, dtype=np.float64), (n,)).copy()
     return pa.ParticleSet(fs, pclass=pclass, x=np.asarray(case["x"]), y=np.asarray(case["y"]), z=case.get("z"), t=t,
                           seed=int(case.get("seed", 0)), **kw)
+
+
+class OutputRecorder:
+    """Duck-typed ParticleFile: makes ParticleSet.execute split the run into output intervals (particleset.py:419-462) and
+    records the observations in memory."""
+
+    def __init__(self, outputdt):
+        self.outputdt = outputdt
+        self.metadata = {}
+        self.obs = []
+
+    def set_metadata(self, mesh):
+        pass
+
+    def write(self, pset, time):
+        self.obs.append((float(time), np.array(pset._data["particle_id"]), np.array(pset._data["x"]), np.array(pset._data["y"]),
+                         np.array(pset._data["z"]), np.array(pset._data["t"])))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
 
 
 def run_hip(case, endtime=None, **pset_kw):
@@ -141,6 +165,8 @@ def run_hip(case, endtime=None, **pset_kw):
         kw["endtime"] = float(case["endtime"])
     else:
         kw["runtime"] = float(case["runtime"])
+    if case.get("outputdt"):
+        kw["output_file"] = OutputRecorder(float(case["outputdt"]))
     err = None
     import warnings
 

@@ -182,3 +182,125 @@ def test_statistics_of_uniform_diffusion(gpu):
     assert abs(pset.x.std() / expected_std - 1) < 0.01 and abs(pset.y.std() / expected_std - 1) < 0.01
     assert abs(pset.x.mean()) < 4 * expected_std / np.sqrt(n)
     assert abs(np.corrcoef(pset.x, pset.y)[0, 1]) < 0.01
+
+
+@pytest.mark.parametrize("mesh", ["spherical", "flat"])
+def test_advection_meridional(gpu, mesh, npart=10):
+    """tests/test_advection.py:110-128: uniform V moves every particle the same dlat, whatever its latitude."""
+    fs = pa.FieldSet.from_sgrid_conventions(simple_uv_dataset(mesh=mesh, v=1.0), mesh=mesh)
+    runtime = 7200
+    startlat = np.linspace(0, 80, npart)
+    startlon = 20.0 + np.zeros(npart)
+    pset = pa.ParticleSet(fs, x=startlon, y=startlat, t=np.zeros(npart))
+    pset.execute(pa.AdvectionRK4, runtime=runtime, dt=np.timedelta64(15, "m"))
+    expected_dlat = runtime / (1852 * 60) if mesh == "spherical" else runtime
+    np.testing.assert_allclose(pset.x, startlon, atol=1e-5)
+    np.testing.assert_allclose(pset.y - startlat, expected_dlat, atol=1e-4)
+
+
+@pytest.mark.parametrize("mesh", ["spherical", "flat"])
+def test_horizontal_advection_in_3d_flow(gpu, mesh, npart=10):
+    """tests/test_advection.py:131-145: zonal flow growing linearly with depth from 0 to 1 m/s (vertical interpolation)."""
+    ds = simple_uv_dataset(mesh=mesh, u=1.0)
+    ds["U"].data[:, 0, :, :] = 0.0
+    fs = pa.FieldSet.from_sgrid_conventions(ds, mesh=mesh)
+    pset = pa.ParticleSet(fs, x=np.zeros(npart), y=np.zeros(npart), z=np.linspace(0.1, 0.9, npart), t=np.zeros(npart))
+    pset.execute(pa.AdvectionRK4, runtime=np.timedelta64(2, "h"), dt=np.timedelta64(15, "m"))
+    expected_lon = pset.z * pset.t
+    if mesh == "spherical":
+        expected_lon = expected_lon / (1852 * 60 * np.cos(np.deg2rad(pset.y)))
+    np.testing.assert_allclose(pset.x, expected_lon, atol=1.0e-1)
+
+
+@pytest.mark.parametrize("direction", ["up", "down"])
+@pytest.mark.parametrize("resubmerge_particle", [True, False])
+def test_advection_3d_outofbounds(gpu, direction, resubmerge_particle):
+    """tests/test_advection.py:148-191: a particle leaving through the surface is resubmerged by SubmergeParticle (dz = 0,
+    z = 0, horizontal displacement kept) or deleted; leaving through the bottom it is always deleted."""
+    ds = simple_uv_dataset(mesh="flat", u=0.01)
+    ds["W"] = (ds["V"].dims, np.full(ds["V"].data.shape, -1.0 if direction == "up" else 1.0))
+    fs = pa.FieldSet.from_sgrid_conventions(ds, mesh="flat")
+    kernels = [pa.AdvectionRK4_3D]
+    if resubmerge_particle:
+        kernels.append(pa.SubmergeParticle)
+    kernels.append(pa.DeleteOutOfBounds)
+    pset = pa.ParticleSet(fs, x=0.5, y=0.5, z=0.9, t=0.0)
+    pset.execute(kernels, runtime=np.timedelta64(10, "s"), dt=np.timedelta64(1, "s"))
+    if direction == "up" and resubmerge_particle:
+        np.testing.assert_allclose(pset.x[0], 0.6, atol=1e-5)
+        np.testing.assert_allclose(pset.z[0], 0, atol=1e-5)
+    else:
+        assert len(pset) == 0
+
+
+def test_radial_rotation_with_staggered_release(gpu, npart=10):
+    """tests/test_advection.py:237-251 + generated.py:42-91: solid-body rotation (period 1 day), particle k released at
+    k*dt; every particle ends at the common endtime on its own circle (atol 5e-2)."""
+    xdim = ydim = 200
+    lon = np.linspace(0, 60, xdim, dtype=np.float32)
+    lat = np.linspace(0, 60, ydim, dtype=np.float32)
+    omega = 2 * np.pi / 86400.0
+    r = np.sqrt((lon[None, :] - 30.0) ** 2 + (lat[:, None] - 30.0) ** 2)
+    theta = np.arctan2(lat[:, None] - 30.0, lon[None, :] - 30.0)
+    U = np.broadcast_to((r * np.sin(theta) * omega).astype(np.float32), (2, 1, ydim, xdim)).copy()
+    V = np.broadcast_to((-r * np.cos(theta) * omega).astype(np.float32), (2, 1, ydim, xdim)).copy()
+    md = pa.SGrid2DMetadata(
+        node_dimensions=("XG", "YG"), node_coordinates=("lon", "lat"),
+        face_dimensions=(pa.FaceNodePadding("XC", "XG", pa.Padding.LOW), pa.FaceNodePadding("YC", "YG", pa.Padding.HIGH)),
+        vertical_dimensions=(pa.FaceNodePadding("ZC", "depth", pa.Padding.BOTH),),
+    )
+    ds = pa.Dataset({"U": (("time", "depth", "YG", "XG"), U), "V": (("time", "depth", "YG", "XG"), V)},
+                    {"time": (("time",), np.array([0.0, 10 * 86400.0])), "depth": (("depth",), np.array([0.0])),
+                     "lat": (("YG",), lat), "lon": (("XG",), lon)}, sgrid=md)
+    fs = pa.FieldSet.from_sgrid_conventions(ds, mesh="flat")
+    dt = 30.0
+    x0 = np.linspace(32, 50, npart)
+    y0 = np.ones(npart) * 30
+    starttime = np.arange(npart) * dt
+    pset = pa.ParticleSet(fs, x=x0, y=y0, t=starttime)
+    pset.execute(pa.AdvectionRK4, endtime=np.timedelta64(10, "m"), dt=np.timedelta64(30, "s"))
+    assert np.all(pset.t == 600.0)
+    th = 2 * np.pi * (pset.t - starttime) / 86400.0
+    np.testing.assert_allclose(pset.x, (x0 - 30.0) * np.cos(th) + 30.0, atol=5e-2)
+    np.testing.assert_allclose(pset.y, -(x0 - 30.0) * np.sin(th) + 30.0, atol=5e-2)
+
+
+@pytest.mark.parametrize("kernel,rtol", [("AdvectionEE", 1e-1), ("AdvectionRK2", 3e-3), ("AdvectionRK4", 1e-5), ("AdvectionRK45", 1e-4)])
+def test_decaying_moving_eddy_closed_form(gpu, kernel, rtol):
+    """tests/test_advection.py:310-351 + generated.py:143-203 (Fabbroni 2009): decaying inertial oscillation on a geostrophic
+    current sampled every 2 minutes for 25 h; closed-form position after 23 h."""
+    u_g, u_0, gamma, gamma_g, f = 0.04, 0.3, 1.0 / (2.89 * 86400), 1.0 / (28.9 * 86400), 1.0e-4
+    tt = np.arange(0.0, 86400.0 + 3600.0, 120.0)
+    lon = np.linspace(0, 20000, 2, dtype=np.float32)
+    lat = np.linspace(5000, 12000, 2, dtype=np.float32)
+    U = np.zeros((tt.size, 1, 2, 2), np.float32)
+    V = np.zeros((tt.size, 1, 2, 2), np.float32)
+    U[:] = (u_g * np.exp(-gamma_g * tt) + (u_0 - u_g) * np.exp(-gamma * tt) * np.cos(f * tt))[:, None, None, None]
+    V[:] = (-(u_0 - u_g) * np.exp(-gamma * tt) * np.sin(f * tt))[:, None, None, None]
+    md = pa.SGrid2DMetadata(
+        node_dimensions=("XG", "YG"), node_coordinates=("lon", "lat"),
+        face_dimensions=(pa.FaceNodePadding("XC", "XG", pa.Padding.LOW), pa.FaceNodePadding("YC", "YG", pa.Padding.HIGH)),
+        vertical_dimensions=(pa.FaceNodePadding("ZC", "depth", pa.Padding.BOTH),),
+    )
+    ds = pa.Dataset({"U": (("time", "depth", "YG", "XG"), U), "V": (("time", "depth", "YG", "XG"), V)},
+                    {"time": (("time",), tt), "depth": (("depth",), np.array([0.0])), "lat": (("YG",), lat), "lon": (("XG",), lon)}, sgrid=md)
+    fs = pa.FieldSet.from_sgrid_conventions(ds, mesh="flat")
+    pclass = pa.Particle
+    if kernel == "AdvectionRK45":
+        fs.add_context("RK45_tol", rtol)
+        fs.add_context("RK45_min_dt", 10 * 60)
+        fs.add_context("RK45_max_dt", 24 * 60 * 60)
+        pclass = pa.Particle.add_variable(pa.Variable("next_dt", dtype=np.float32, initial=3600.0))
+    x0, y0, T = 10000.0, 10000.0, 23 * 3600.0
+    pset = pa.ParticleSet(fs, pclass=pclass, x=x0, y=y0, t=0.0)
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pset.execute(getattr(pa.kernels, kernel), dt=np.timedelta64(60, "m"), endtime=np.timedelta64(23, "h"))
+    den = f**2 + gamma**2
+    exp_lon = (x0 + (u_g / gamma_g) * (1 - np.exp(-gamma_g * T))
+               + f * ((u_0 - u_g) / den) * ((gamma / f) + np.exp(-gamma * T) * (np.sin(f * T) - (gamma / f) * np.cos(f * T))))
+    exp_lat = y0 - ((u_0 - u_g) / den) * f * (1 - np.exp(-gamma * T) * (np.cos(f * T) + (gamma / f) * np.sin(f * T)))
+    np.testing.assert_allclose(pset.x, exp_lon, rtol=rtol)
+    np.testing.assert_allclose(pset.y, exp_lat, rtol=rtol)
