@@ -352,12 +352,14 @@ class _OutputStub:
         self.metadata = {}
         self.path = "<memory>"
         self.times = []
+        self.obs = []
 
     def set_metadata(self, mesh):
         pass
 
     def write(self, pset, time):
         self.times.append(float(time))
+        self.obs.append({k: np.array(pset._data[k], copy=True) for k in ("particle_id", "t", "z", "y", "x")})
 
     def __enter__(self):
         return self
@@ -399,4 +401,10 @@ def run_reference(fieldset, kernels, *, x, y, z, t=None, dt, runtime=None, endti
         except Exception as e:  # per-particle error codes surface as exceptions (kernel.py:239-245)
             err = type(e).__name__
     out = {k: np.array(v, copy=True) for k, v in pset._data.items()}
+    stub = kw.get("output_file")
+    if stub is not None and stub.obs and all(len(o["x"]) == len(stub.obs[0]["x"]) for o in stub.obs):
+        # what the ParticleFile would have been handed at every output time (no deletions: rectangular arrays)
+        out["obs_time"] = np.array(stub.times)
+        for k in ("particle_id", "t", "z", "y", "x"):
+            out["obs_" + k] = np.stack([o[k] for o in stub.obs])
     return out, err

@@ -85,8 +85,9 @@ struct pk_ctx {
     int64_t fl_n = 0;
     DCounters* h_counters = nullptr;          // pinned: the async D2H of the counters must not block the host
     unsigned long long* h_summary = nullptr;  // pinned
-    int sort_horizontal_major = -1;  // tuning knobs (environment: PK_SORT_HORIZONTAL = 0/1 forces, PK_NO_SPECIAL)
+    int sort_horizontal_major = -1;  // tuning knobs (environment: PK_SORT_HORIZONTAL = 0/1 forces, PK_NO_SPECIAL, PK_NO_CELL_CACHE)
     int no_special = 0;
+    int no_cell_cache = 0;
 
     int32_t fail(const char* where, hipError_t e) {
         err = std::string(where) + ": " + hipGetErrorString(e);
@@ -147,11 +148,12 @@ __global__ void __launch_bounds__(256) eval_kernel(const KArgs a, int what, int6
     if (i >= m) return;
     const DField& mf = a.fields[a.main_field];
     const DGrid& mg = a.grids[a.main_grid];
-    Coords mc{mf.time, mg.depth, mg.lat, mg.lon, mf.tfirst, mf.tlast, mg.zfirst, mg.zlast, mg.yfirst, mg.ylast, mg.xfirst, mg.xlast};
+    Coords mc{CellCache{nullptr, nullptr, nullptr}, mf.time, mg.depth, mg.lat, mg.lon, mf.tfirst, mf.tlast, mg.zfirst, mg.zlast, mg.yfirst, mg.ylast, mg.xfirst, mg.xlast};
     PCtx c;
     c.state = PK_EVALUATE;
     c.pf = false;
     c.hz = c.hy = c.hx = c.ht = 0;
+    c.hyx_valid = false;
     c.first_eval = 0xFu;
     c.ei0 = c.ei1 = c.ei2 = c.ei3 = 0;
     if (what < 0) {
@@ -175,6 +177,7 @@ __global__ void __launch_bounds__(256) search_kernel(const DGrid g, int64_t m, c
     c.state = PK_EVALUATE;
     c.pf = false;
     c.hz = c.hy = c.hx = c.ht = 0;
+    c.hyx_valid = false;
     GPos p;
     int32_t ei = 0;
     grid_search<-1>(g, nullptr, z[i], y[i], x[i], false, &ei, c, false, p);
@@ -299,6 +302,7 @@ int32_t pk_init(int32_t device, pk_ctx** out) {
     ctx->device = device;
     if (const char* e = getenv("PK_SORT_HORIZONTAL")) ctx->sort_horizontal_major = atoi(e);
     if (const char* e = getenv("PK_NO_SPECIAL")) ctx->no_special = atoi(e);
+    if (const char* e = getenv("PK_NO_CELL_CACHE")) ctx->no_cell_cache = atoi(e);
     *out = ctx;
     PK_HIP(ctx, hipSetDevice(device));
     PK_HIP(ctx, hipGetDeviceProperties(&ctx->prop, device));
@@ -880,6 +884,24 @@ static int32_t fill_args(pk_ctx* ctx, const pk_exec_params* prm, KArgs& a, size_
     lds_bytes = (size_t)std::max(a.lds_total, 1) * sizeof(double);
     use_lds = lds_bytes <= 64 * 1024;
     if (!use_lds) lds_bytes = 0;
+    // per-lane cell cache of curvilinear grids (pk_device.h: CellCache): 20 node doubles + 4 key ints per lane, plus the
+    // 12 staggered field values of a C-grid evaluation when they still fit the 64 KiB of a workgroup
+    a.lds_cc_nodes = a.lds_cc_keys = a.lds_cc_fvals = -1;
+    const bool want_cc = use_lds && mg.d.kind == 1 && !ctx->no_cell_cache && (int64_t)mg.d.ny * mg.d.nx < INT32_MAX;
+    if (want_cc) {
+        const size_t node_b = 20 * 256 * sizeof(double), key_b = 4 * 256 * sizeof(int32_t);
+        const size_t fval_b = 12 * 256 * (size_t)(mf.desc.dtype == PK_F32 ? 4 : 8);
+        if (lds_bytes + node_b + key_b <= 64 * 1024) {
+            a.lds_cc_nodes = a.lds_total;
+            a.lds_cc_keys = a.lds_cc_nodes + 20 * 256;
+            int32_t end = a.lds_cc_keys + (int32_t)(key_b / sizeof(double));
+            if (prm->interp_uv == 1 && (size_t)end * sizeof(double) + fval_b <= 64 * 1024) {
+                a.lds_cc_fvals = end;
+                end += (int32_t)(fval_b / sizeof(double));
+            }
+            lds_bytes = (size_t)end * sizeof(double);
+        }
+    }
     return 0;
 }
 

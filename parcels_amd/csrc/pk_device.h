@@ -77,6 +77,7 @@ struct KArgs {
     DCounters* counters;
     // LDS layout of the main grid's 1-D arrays (element offsets into the dynamic shared array, -1 = global)
     int32_t lds_time, lds_depth, lds_lat, lds_lon, lds_total;
+    int32_t lds_cc_nodes, lds_cc_keys, lds_cc_fvals;  // cell cache (CellCache) offsets in doubles from the LDS base, -1 = off
     int32_t main_grid, main_field;
 };
 
@@ -139,8 +140,23 @@ struct GPos {
     double tau, zeta, eta, xsi;
 };
 
+// Per-lane LDS cache of the curvilinear cell a particle sits in: its 4 corner nodes {lon, lat, X, Y, Z} and the raw
+// staggered field values of one C-grid evaluation at both time levels.  A particle moves a fraction of a cell per RK
+// stage, so stages 2..4 and most following steps of the fused loop find their cell here instead of re-fetching ~9
+// cache lines per evaluation through L2 (the 1e7 particles of BASELINE config 3 touch ~150 MB per stage, far more
+// than the 4 MB L2 of an XCD keeps between stages).  Layout: structure-of-arrays over the 256 lanes of the workgroup
+// (element k of lane l at [k * 256 + l]) -> conflict-free ds_read/ds_write.  Cached bits are the global ones, so
+// results are unchanged.  All pointers NULL = disabled.
+constexpr int CC_LANES = 256;
+struct CellCache {
+    double* nodes;  // [20][256]: corner c (0 (yi,xi), 1 (yi,xi+1), 2 (yi+1,xi+1), 3 (yi+1,xi)), component m -> (c*5+m)
+    int* key;       // [4][256]: node cell yi*nx+xi | field cell yi*nx+xi | zi | 2*ti + (level ti+1 cached);  -1 = empty
+    void* fvals;    // [12][256] of the field dtype: Ua,Ub,Va,Vb,Wa,Wb at level ti, then at level ti+1 (NULL: not cached)
+};
+
 // Coordinate vectors of the main grid, either LDS-staged or global (address space is inferred after inlining).
 struct Coords {
+    CellCache cc;
     const double* time;
     const double* depth;
     const double* lat;
@@ -348,26 +364,60 @@ PK_DEV void spherical_project(const double cX[4], const double cY[4], const doub
 }
 
 // curvilinear_point_in_cell (index_search.py:94-120); (yi, xi) must be a valid cell
-PK_DEV bool point_in_cell(const DGrid& g, const QPoint& q, int yi, int xi, double& xsi, double& eta) {
+PK_DEV bool point_in_cell(const DGrid& g, const QPoint& q, int yi, int xi, double& xsi, double& eta, const CellCache* cc = nullptr) {
     // node table rows: {lon, lat, X, Y, Z} of node (yi, xi) followed by node (yi, xi+1): 10 contiguous doubles
     const double* r0 = g.node_tab + ((int64_t)yi * g.nx + xi) * 5;
     const double* r1 = r0 + (int64_t)g.nx * 5;
+    const bool use_cc = cc && cc->key;
+    const int cell = yi * g.nx + xi;
+    const bool hit = use_cc && cc->key[0] == cell;
+    double* nd = use_cc ? cc->nodes : nullptr;
+#define PK_ND(c_, m_) nd[((c_) * 5 + (m_)) * CC_LANES]
     if (g.spherical) {
-        double cX[4], cY[4], cZ[4], pu[4], pv[4], xq, yq, t0_, t1_;
+        double cX[4], cY[4], cZ[4], pu[4], pv[4], xq, yq;
         // corner order c0=(yi,xi) c1=(yi,xi+1) c2=(yi+1,xi+1) c3=(yi+1,xi)
-        ldpair(r0 + 2, cX[0], cY[0]); ldpair(r0 + 4, cZ[0], t0_);  // t0_ = lon of the next node (unused)
-        ldpair(r0 + 6, t1_, cX[1]);   ldpair(r0 + 8, cY[1], cZ[1]);
-        ldpair(r1 + 2, cX[3], cY[3]); ldpair(r1 + 4, cZ[3], t0_);
-        ldpair(r1 + 6, t1_, cX[2]);   ldpair(r1 + 8, cY[2], cZ[2]);
+        if (hit) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) { cX[k] = PK_ND(k, 2); cY[k] = PK_ND(k, 3); cZ[k] = PK_ND(k, 4); }
+        } else {
+            double lon1, lat1, lon2, lat2;
+            ldpair(r0 + 2, cX[0], cY[0]); ldpair(r0 + 4, cZ[0], lon1);
+            ldpair(r0 + 6, lat1, cX[1]);  ldpair(r0 + 8, cY[1], cZ[1]);
+            ldpair(r1 + 2, cX[3], cY[3]); ldpair(r1 + 4, cZ[3], lon2);
+            ldpair(r1 + 6, lat2, cX[2]);  ldpair(r1 + 8, cY[2], cZ[2]);
+            if (use_cc) {  // the cached cell (the failed guess) is replaced; the key is set once the point is inside
+                double lon0, lat0, lon3, lat3;
+                ldpair(r0, lon0, lat0);
+                ldpair(r1, lon3, lat3);
+                cc->key[0] = -1;
+                PK_ND(0, 0) = lon0; PK_ND(0, 1) = lat0; PK_ND(1, 0) = lon1; PK_ND(1, 1) = lat1;
+                PK_ND(2, 0) = lon2; PK_ND(2, 1) = lat2; PK_ND(3, 0) = lon3; PK_ND(3, 1) = lat3;
+#pragma unroll
+                for (int k = 0; k < 4; k++) { PK_ND(k, 2) = cX[k]; PK_ND(k, 3) = cY[k]; PK_ND(k, 4) = cZ[k]; }
+            }
+        }
         spherical_project(cX, cY, cZ, q, pu, pv, xq, yq);
         bilinear_inverse(pu, pv, xq, yq, xsi, eta);
     } else {
         double clon[4], clat[4];
-        ldpair(r0, clon[0], clat[0]); ldpair(r0 + 5, clon[1], clat[1]);
-        ldpair(r1, clon[3], clat[3]); ldpair(r1 + 5, clon[2], clat[2]);
+        if (hit) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) { clon[k] = PK_ND(k, 0); clat[k] = PK_ND(k, 1); }
+        } else {
+            ldpair(r0, clon[0], clat[0]); ldpair(r0 + 5, clon[1], clat[1]);
+            ldpair(r1, clon[3], clat[3]); ldpair(r1 + 5, clon[2], clat[2]);
+            if (use_cc) {
+                cc->key[0] = -1;
+#pragma unroll
+                for (int k = 0; k < 4; k++) { PK_ND(k, 0) = clon[k]; PK_ND(k, 1) = clat[k]; }
+            }
+        }
         bilinear_inverse(clon, clat, q.x, q.y, xsi, eta);
     }
-    return (xsi >= 0) && (xsi <= 1) && (eta >= 0) && (eta <= 1);
+#undef PK_ND
+    const bool inside = (xsi >= 0) && (xsi <= 1) && (eta >= 0) && (eta <= 1);
+    if (use_cc && !hit && inside) cc->key[0] = cell;
+    return inside;
 }
 
 // ---- Morton spatial hash query (spatialhash.py:389-535, 554-597, 647-765) ------------------------------
@@ -398,7 +448,7 @@ PK_DEV uint32_t morton_code(const DGrid& g, const QPoint& q) {
 // order; the first candidate whose cell contains the point wins.  Hash hits return (xsi, eta) rounded to float32 like the
 // reference's float32 coords_best buffer (spatialhash.py:505).  ONE point-in-cell call site serves both paths.
 PK_DEV void curvilinear_search(const DGrid& g, double y, double x, bool use_guess, int gy, int gx, int& yi, int& xi, double& xsi,
-                               double& eta) {
+                               double& eta, const CellCache* cc = nullptr) {
     yi = GRID_SEARCH_ERROR;
     xi = GRID_SEARCH_ERROR;
     xsi = -1.0;
@@ -431,7 +481,7 @@ PK_DEV void curvilinear_search(const DGrid& g, double y, double x, bool use_gues
             i = (int)(face % ncx);
         }
         double xs, et;
-        if (point_in_cell(g, q, j, i, xs, et)) {
+        if (point_in_cell(g, q, j, i, xs, et, cc)) {
             yi = j;
             xi = i;
             xsi = k < 0 ? xs : (double)(float)xs;
@@ -478,6 +528,7 @@ struct PCtx {
     int state;
     bool pf;             // particle positions are stored as float32 (default Particle, particle.py:123-178)
     int hz, hy, hx, ht;  // search hints of the main grid (indices of the previous evaluation)
+    bool hyx_valid;      // (hy, hx) is an in-range cell whose ravelled index is the particle's ei on the main grid
     unsigned first_eval;  // bit g: no evaluation on grid g yet in this execute() call
     int32_t ei0, ei1, ei2, ei3;  // the particle's `ei` row, one register per grid (no dynamic indexing -> no scratch)
 };
@@ -509,16 +560,24 @@ PK_DEV void grid_search(const DGrid& g, const Coords* mc, double z, double y, do
     else { p.zi = 0; p.zeta = 0.0; }
     if (curv) {
         int gy = 0, gx = 0;
-        if (use_guess) unravel_yx(g, (int64_t)*ei, gy, gx);  // index_search.py:269-274
-        curvilinear_search(g, y, x, use_guess, gy, gx, p.yi, p.xi, p.xsi, p.eta);
+        if (use_guess) {  // index_search.py:269-274
+            // unravel(ei) of the cell the previous evaluation found is that cell: skip the 64-bit div/mod chain
+            if (hint && c.hyx_valid) { gy = c.hy; gx = c.hx; }
+            else unravel_yx(g, (int64_t)*ei, gy, gx);
+        }
+        curvilinear_search(g, y, x, use_guess, gy, gx, p.yi, p.xi, p.xsi, p.eta, mc ? &mc->cc : nullptr);
     } else {
         if (g.has_y) search_1d(lat, g.ny, mc ? mc->y0 : g.lat[0], mc ? mc->y1 : g.lat[g.ny - 1], y, g.lat_f32, pos_f32, hint ? c.hy : 0, p.yi, p.eta);
         else { p.yi = 0; p.eta = 0.0; }
         if (g.has_x) search_1d(lon, g.nx, mc ? mc->x0 : g.lon[0], mc ? mc->x1 : g.lon[g.nx - 1], x, g.lon_f32, pos_f32, hint ? c.hx : 0, p.xi, p.xsi);
         else { p.xi = 0; p.xsi = 0.0; }
     }
-    if (hint) { c.hz = p.zi; c.hy = p.yi; c.hx = p.xi; }
-    *ei = (int32_t)ravel_ei(g, p.zi, p.yi, p.xi);
+    const int64_t rav = ravel_ei(g, p.zi, p.yi, p.xi);
+    *ei = (int32_t)rav;
+    if (hint) {
+        c.hz = p.zi; c.hy = p.yi; c.hx = p.xi;
+        c.hyx_valid = curv && p.zi >= 0 && p.yi >= 0 && p.xi >= 0 && rav == (int64_t)*ei;
+    }
     int s = c.state;
     if (p.xi == -1 && s < PK_ERROROUTOFBOUNDS) s = PK_ERROROUTOFBOUNDS;
     if (p.xi == GRID_SEARCH_ERROR && s < PK_ERRORGRIDSEARCHING) s = PK_ERRORGRIDSEARCHING;
@@ -711,30 +770,18 @@ PK_DEV double geodetic_distance(const DGrid& g, double lat1, double lat2, double
 }
 
 // two bracketing face values, reduced over time (_xinterpolators.py:249-270)
-template <class FT>
-PK_DEV void cgrid_pair(const DField& f, const GPos& p, int zA, int yA, int xA, int zB, int yB, int xB, double& oa, double& ob) {
-    const FT* d = (const FT*)f.data;
-    const bool lenT = p.tau > 0;
-    const int64_t ot0 = slot_off(f, p.ti);
-    const int64_t offA = ((int64_t)zA * f.st_z + (int64_t)yA * f.st_y + (int64_t)xA * f.st_x) * f.ncomp;
-    const int64_t offB = ((int64_t)zB * f.st_z + (int64_t)yB * f.st_y + (int64_t)xB * f.st_x) * f.ncomp;
-    double a = ldv(d, ot0 + offA), b = ldv(d, ot0 + offB);
-    if (lenT) {
-        const int64_t ot1 = slot_off(f, mini(p.ti + 1, f.nt - 1));
-        double a1 = ldv(d, ot1 + offA), b1 = ldv(d, ot1 + offB);
-        a = a * (1 - p.tau) + a1 * p.tau;
-        b = b * (1 - p.tau) + b1 * p.tau;
-    }
-    oa = a;
-    ob = b;
+PK_DEV int64_t cgrid_off(const DField& f, int z, int y, int x) {
+    return ((int64_t)z * f.st_z + (int64_t)y * f.st_y + (int64_t)x * f.st_x) * f.ncomp;
 }
 
 PK_DEV double pymod360(double v) {  // Python/NumPy % with a positive divisor
+    if (v >= 0.0 && v < 360.0) return v;  // fmod is exact, so this IS its result on the common path (no 50-instruction fmod)
     double q = fmod(v, 360.0);
     if (q < 0) q += 360.0;
     return q;
 }
 PK_DEV float pymod360f(float v) {
+    if (v >= 0.0f && v < 360.0f) return v;
     float q = fmodf(v, 360.0f);
     if (q < 0) q += 360.0f;
     return q;
@@ -749,11 +796,17 @@ PK_DEV void cgrid_velocity(const DGrid& g, const Coords* mc, const DField& U, co
     const int ydim = U.ny, xdim = U.nx, zdim = U.nz;
     double px[4], py[4];
     const bool rect = (KIND < 0) ? (g.kind == 0) : (KIND == 0);
+    const bool cc_on = !rect && mc && mc->cc.key;
+    const int cell = yi * g.nx + xi;
     if (rect) {
         const double* lon = mc ? mc->lon : g.lon;
         const double* lat = mc ? mc->lat : g.lat;
         px[0] = lon[xi]; px[1] = lon[xi + 1]; px[2] = px[1]; px[3] = px[0];
         py[0] = lat[yi]; py[1] = py[0]; py[2] = lat[yi + 1]; py[3] = py[2];
+    } else if (cc_on && mc->cc.key[0] == cell) {  // the search that found (yi, xi) left its corner nodes in the lane's LDS cache
+        const double* nd = mc->cc.nodes;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { px[k] = nd[(k * 5 + 0) * CC_LANES]; py[k] = nd[(k * 5 + 1) * CC_LANES]; }
     } else {
         const double* r0 = g.node_tab + ((int64_t)yi * g.nx + xi) * 5;  // same lines the point-in-cell test just read
         const double* r1 = r0 + (int64_t)g.nx * 5;
@@ -792,9 +845,57 @@ PK_DEV void cgrid_velocity(const DGrid& g, const Coords* mc, const DField& U, co
 #undef PK_PHI_DOT
     const int yi_o = clampi(yi + g.off_y, 0, ydim - 1), xi_1 = clampi(xi + 1, 0, xdim - 1);
     const int yi_1 = clampi(yi + 1, 0, ydim - 1), xi_o = clampi(xi + g.off_x, 0, xdim - 1);
-    double ua, ub, va, vb;
-    cgrid_pair<FT>(U, p, zi, yi_o, xi, zi, yi_o, xi_1, ua, ub);   // :272-279
-    cgrid_pair<FT>(V, p, zi, yi, xi_o, zi, yi_1, xi_o, va, vb);   // :281-288
+    // the six staggered values of this cell at level ti (and ti+1): U at the x-faces (:272-279), V at the y-faces
+    // (:281-288), W at the two z-faces (:316-328, clipped with U's z extent like the reference)
+    const bool lenT = p.tau > 0;
+    const int zi_0 = clampi(zi + g.off_z, 0, zdim - 1), zi_1 = clampi(zi + g.off_z + 1, 0, zdim - 1);
+    double raw[12];
+    FT* fv = cc_on ? (FT*)mc->cc.fvals : nullptr;
+    const bool fhit = fv && mc->cc.key[1 * CC_LANES] == cell && mc->cc.key[2 * CC_LANES] == zi &&
+                      (mc->cc.key[3 * CC_LANES] >> 1) == p.ti && (!lenT || (mc->cc.key[3 * CC_LANES] & 1));
+    if (fhit) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) raw[k] = (double)fv[k * CC_LANES];
+        if (lenT) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) raw[6 + k] = (double)fv[(6 + k) * CC_LANES];
+        }
+    } else {
+        int64_t off[6];
+        const FT* dat[6] = {(const FT*)U.data, (const FT*)U.data, (const FT*)V.data, (const FT*)V.data,
+                            W ? (const FT*)W->data : nullptr, W ? (const FT*)W->data : nullptr};
+        const DField* fl[6] = {&U, &U, &V, &V, W, W};
+        off[0] = cgrid_off(U, zi, yi_o, xi);
+        off[1] = cgrid_off(U, zi, yi_o, xi_1);
+        off[2] = cgrid_off(V, zi, yi, xi_o);
+        off[3] = cgrid_off(V, zi, yi_1, xi_o);
+        off[4] = W ? cgrid_off(*W, zi_0, yi_o, xi_o) : 0;
+        off[5] = W ? cgrid_off(*W, zi_1, yi_o, xi_o) : 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) raw[k] = (k < 4 || W) ? ldv(dat[k], slot_off(*fl[k], p.ti) + off[k]) : 0.0;
+        if (lenT) {
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+                raw[6 + k] = (k < 4 || W) ? ldv(dat[k], slot_off(*fl[k], mini(p.ti + 1, fl[k]->nt - 1)) + off[k]) : 0.0;
+        }
+        if (fv) {  // values widened exactly from FT, so the narrowing store is exact
+            mc->cc.key[1 * CC_LANES] = -1;
+#pragma unroll
+            for (int k = 0; k < 6; k++) fv[k * CC_LANES] = (FT)raw[k];
+            if (lenT) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) fv[(6 + k) * CC_LANES] = (FT)raw[6 + k];
+            }
+            mc->cc.key[2 * CC_LANES] = zi;
+            mc->cc.key[3 * CC_LANES] = 2 * p.ti + (lenT ? 1 : 0);
+            mc->cc.key[1 * CC_LANES] = cell;
+        }
+    }
+    if (lenT) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) raw[k] = raw[k] * (1 - p.tau) + raw[6 + k] * p.tau;
+    }
+    const double ua = raw[0], ub = raw[1], va = raw[2], vb = raw[3];
     const double U0 = ua * c4, U1 = ub * c2;
     const double Uvel = (1 - xsi) * U0 + xsi * U1;
     const double V0 = va * c1, V1 = vb * c3;
@@ -823,11 +924,8 @@ PK_DEV void cgrid_velocity(const DGrid& g, const Coords* mc, const DField& U, co
     }
     u = uu;
     v = vv;
-    if (W) {  // :316-328 (clipped with U's z extent, like the reference)
-        const int zi_0 = clampi(zi + g.off_z, 0, zdim - 1), zi_1 = clampi(zi + g.off_z + 1, 0, zdim - 1);
-        double wa, wb;
-        cgrid_pair<FT>(*W, p, zi_0, yi_o, xi_o, zi_1, yi_o, xi_o, wa, wb);
-        w = wa * (1 - zeta) + wb * zeta;
+    if (W) {  // :316-328
+        w = raw[4] * (1 - zeta) + raw[5] * zeta;
     } else {
         w = 0.0;
     }

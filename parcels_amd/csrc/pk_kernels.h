@@ -366,6 +366,16 @@ __global__ void __launch_bounds__(256, (KIND == 1 || INTERP != 0) ? PK_MIN_WAVES
         mc.lat = mg.lat;
         mc.lon = mg.lon;
     }
+    mc.cc.nodes = nullptr;
+    mc.cc.key = nullptr;
+    mc.cc.fvals = nullptr;
+    if (LDS && KIND == 1 && a.lds_cc_nodes >= 0) {  // lane-private slots: no barrier needed
+        mc.cc.nodes = smem + a.lds_cc_nodes + threadIdx.x;
+        mc.cc.key = (int*)(smem + a.lds_cc_keys) + threadIdx.x;
+        if (INTERP == 1 && a.lds_cc_fvals >= 0) mc.cc.fvals = (void*)((FT*)(smem + a.lds_cc_fvals) + threadIdx.x);
+        mc.cc.key[0] = -1;
+        mc.cc.key[CC_LANES] = -1;
+    }
     mc.t0 = mf.tfirst;
     mc.t1 = mf.tlast;
     mc.z0 = mg.zfirst; mc.z1 = mg.zlast;
@@ -383,6 +393,7 @@ __global__ void __launch_bounds__(256, (KIND == 1 || INTERP != 0) ? PK_MIN_WAVES
         c.state = prm.reset_state ? PK_EVALUATE : P.state[i];  // kernel.py:188
         if (c.state == PK_EVALUATE) {
             c.hz = c.hy = c.hx = c.ht = 0;
+            c.hyx_valid = false;
             c.first_eval = prm.reset_state ? 0xFu : 0u;
             PState p;
             p.t = P.t[i];

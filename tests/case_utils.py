@@ -165,8 +165,9 @@ def run_hip(case, endtime=None, **pset_kw):
         kw["endtime"] = float(case["endtime"])
     else:
         kw["runtime"] = float(case["runtime"])
+    run_hip.last_recorder = None
     if case.get("outputdt"):
-        kw["output_file"] = OutputRecorder(float(case["outputdt"]))
+        kw["output_file"] = run_hip.last_recorder = OutputRecorder(float(case["outputdt"]))
     err = None
     import warnings
 
