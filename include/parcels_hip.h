@@ -115,7 +115,12 @@ typedef struct pk_grid_desc {
     int64_t h_nkeys;
     int64_t h_nentries;
     int32_t h_bitwidth;
-    int32_t reserved1;
+    int32_t neighbour_probe; /* curvilinear search when a particle has left its guessed cell: 0 = automatic (default): on
+                                a mesh WITHOUT coincident nodes (no cyclic halo / fold rows, so cells cannot overlap) the
+                                neighbour cell the barycentric coordinates point at is tested before the hash-cell faces
+                                -- same answer as the reference's table-order walk (spatialhash.py:389-535), found in one
+                                probe instead of ~10; on a mesh WITH coincident nodes the table order is kept.
+                                1 = always probe the neighbour first, -1 = never.                                        */
     double h_bbox[6]; /* xmin,xmax,ymin,ymax,zmin,zmax of the hash grid                             */
 } pk_grid_desc;
 int32_t pk_grid_create(pk_ctx* ctx, const pk_grid_desc* desc, int32_t* grid_id);
@@ -126,7 +131,7 @@ typedef struct pk_hash_info {
     int64_t nkeys;
     int64_t nentries;
     int32_t bitwidth;
-    int32_t reserved;
+    int32_t neighbour_probe; /* 1: the search probes the neighbour cell first on this grid (pk_grid_desc.neighbour_probe) */
     double bbox[6];
 } pk_hash_info;
 int32_t pk_grid_hash_info(pk_ctx* ctx, int32_t grid, pk_hash_info* out);

@@ -68,7 +68,7 @@ class GridDesc(C.Structure):
         ("h_nkeys", C.c_int64),
         ("h_nentries", C.c_int64),
         ("h_bitwidth", C.c_int32),
-        ("reserved1", C.c_int32),
+        ("neighbour_probe", C.c_int32),
         ("h_bbox", C.c_double * 6),
     ]
 
@@ -157,7 +157,7 @@ class ExecStats(C.Structure):
 
 # every symbol include/parcels_hip.h declares (tests/test_abi.py checks the library exports all of them)
 class HashInfo(C.Structure):
-    _fields_ = [("nkeys", C.c_int64), ("nentries", C.c_int64), ("bitwidth", C.c_int32), ("reserved", C.c_int32), ("bbox", C.c_double * 6)]
+    _fields_ = [("nkeys", C.c_int64), ("nentries", C.c_int64), ("bitwidth", C.c_int32), ("neighbour_probe", C.c_int32), ("bbox", C.c_double * 6)]
 
 
 ABI_SYMBOLS = [

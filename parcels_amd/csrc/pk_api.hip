@@ -88,6 +88,7 @@ struct pk_ctx {
     int sort_horizontal_major = -1;  // tuning knobs (environment: PK_SORT_HORIZONTAL = 0/1 forces, PK_NO_SPECIAL, PK_NO_CELL_CACHE)
     int no_special = 0;
     int no_cell_cache = 0;
+    int no_hash_dir = 0;
 
     int32_t fail(const char* where, hipError_t e) {
         err = std::string(where) + ": " + hipGetErrorString(e);
@@ -303,6 +304,7 @@ int32_t pk_init(int32_t device, pk_ctx** out) {
     if (const char* e = getenv("PK_SORT_HORIZONTAL")) ctx->sort_horizontal_major = atoi(e);
     if (const char* e = getenv("PK_NO_SPECIAL")) ctx->no_special = atoi(e);
     if (const char* e = getenv("PK_NO_CELL_CACHE")) ctx->no_cell_cache = atoi(e);
+    if (const char* e = getenv("PK_NO_HASH_DIR")) ctx->no_hash_dir = atoi(e);
     *out = ctx;
     PK_HIP(ctx, hipSetDevice(device));
     PK_HIP(ctx, hipGetDeviceProperties(&ctx->prop, device));
@@ -451,6 +453,27 @@ int32_t pk_grid_create(pk_ctx* ctx, const pk_grid_desc* desc, int32_t* grid_id) 
             d.h_bitwidth = hb.bitwidth;
             for (int k = 0; k < 6; k++) d.h_bbox[k] = hb.bbox[k];
         }
+        // neighbour-first probing (pk_device.h: curvilinear_search) is exact only where cells cannot overlap
+        int probe = desc->neighbour_probe;
+        if (const char* e = getenv("PK_NEIGHBOUR_PROBE")) probe = atoi(e);
+        if (probe == 0) {
+            bool coincident = true;
+            std::string msg;
+            if (mesh_has_coincident_nodes(ctx->compute, d.node_tab, desc->ny, desc->nx, desc->spherical, d.h_bbox, &coincident, &msg) != hipSuccess)
+                return ctx->fail("coincident-node scan: " + msg);
+            d.walk_ok = coincident ? 0 : 1;
+        } else {
+            d.walk_ok = probe > 0 ? 1 : 0;
+        }
+        if (!ctx->no_hash_dir) {
+            int32_t* dir = nullptr;
+            int32_t shift = 0;
+            std::string msg;
+            if (build_hash_directory(ctx->compute, d.h_keys, d.h_nkeys, &dir, &shift, &msg) != hipSuccess) return ctx->fail(msg);
+            if (dir) g.allocs.push_back(dir);
+            d.h_dir = dir;
+            d.h_dir_shift = shift;
+        }
     }
     *grid_id = (int32_t)ctx->grids.size() - 1;
     return 0;
@@ -463,7 +486,7 @@ int32_t pk_grid_hash_info(pk_ctx* ctx, int32_t grid, pk_hash_info* out) {
     out->nkeys = g.d.h_nkeys;
     out->nentries = g.h_nentries;
     out->bitwidth = g.d.h_bitwidth;
-    out->reserved = 0;
+    out->neighbour_probe = g.d.walk_ok;
     for (int k = 0; k < 6; k++) out->bbox[k] = g.d.h_bbox[k];
     return 0;
 }

@@ -35,6 +35,9 @@ struct DGrid {
     const int64_t* h_counts;
     const uint32_t* h_faces;
     int64_t h_nkeys;
+    int32_t walk_ok;       // the mesh has no coincident nodes: neighbour-first probing is exact (curvilinear_search)
+    const int32_t* h_dir;  // directory over h_keys by the top bits of the code (pk_hashbuild.h), NULL = none
+    int32_t h_dir_shift;
     double h_bbox[6];
     double zfirst, zlast, yfirst, ylast, xfirst, xlast;  // first/last of the 1-D coordinate vectors (rectilinear; depth always)
 };
@@ -468,6 +471,11 @@ PK_DEV void curvilinear_search(const DGrid& g, double y, double x, bool use_gues
                 if (isfinite(x) && isfinite(y) && g.h_nkeys > 0) {
                     const uint32_t code = morton_code(g, q);
                     int64_t lo = 0, hi = g.h_nkeys;
+                    if (g.h_dir) {  // keys with the same top bits: a handful instead of all of them
+                        const uint32_t b = code >> g.h_dir_shift;
+                        lo = g.h_dir[b];
+                        hi = g.h_dir[b + 1];
+                    }
                     while (lo < hi) {
                         const int64_t mid = (lo + hi) >> 1;
                         if (g.h_keys[mid] < code) lo = mid + 1; else hi = mid;
@@ -487,6 +495,25 @@ PK_DEV void curvilinear_search(const DGrid& g, double y, double x, bool use_gues
             xsi = k < 0 ? xs : (double)(float)xs;
             eta = k < 0 ? et : (double)(float)et;
             return;
+        }
+        if (k < 0 && g.walk_ok) {
+            // The particle left the guessed cell.  On a mesh without coincident nodes (cells cannot overlap) exactly one cell
+            // holds it, almost always the neighbour the barycentric coordinates point at: test that one before walking the
+            // ~10-20 faces of the hash cell in table order.  Accepted only well inside (no tie with an adjacent cell, which
+            // the table order would have to break); the coordinates are rounded like a hash hit (spatialhash.py:505).
+            const int dj = et < 0 ? -1 : (et > 1 ? 1 : 0), di = xs < 0 ? -1 : (xs > 1 ? 1 : 0);
+            const int nj = gy + dj, ni = gx + di;
+            if ((dj | di) != 0 && nj >= 0 && nj < g.ny - 1 && ni >= 0 && ni < g.nx - 1) {
+                double xs2, et2;
+                const double m = 1e-9;
+                if (point_in_cell(g, q, nj, ni, xs2, et2, cc) && xs2 > m && xs2 < 1 - m && et2 > m && et2 < 1 - m) {
+                    yi = nj;
+                    xi = ni;
+                    xsi = (double)(float)xs2;
+                    eta = (double)(float)et2;
+                    return;
+                }
+            }
         }
     }
 }

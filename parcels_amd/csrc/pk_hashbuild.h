@@ -23,4 +23,16 @@ struct HashBuildResult {
 hipError_t build_spatial_hash(hipStream_t stream, const double* node_tab, int ny, int nx, int spherical, HashBuildResult* out,
                               std::string* err);
 
+// Directory over the sorted key array: dir[b] = index of the first key whose top `bits` bits (of the 30-bit Morton code)
+// are >= b, for b in [0, 2^bits].  A query then binary-searches keys[dir[b], dir[b+1]) -- a handful of keys -- instead of
+// all of them (23 dependent loads for the 5e6 keys of a 1/12-degree grid).  Same result as the full search.
+hipError_t build_hash_directory(hipStream_t stream, const uint32_t* keys, int64_t nkeys, int32_t** dir, int32_t* shift, std::string* err);
+
+// Does the mesh have coincident nodes (cyclic halo columns, a north-fold row, a degenerate pole row)?  Then two distinct
+// cells can hold the same point and only the reference's table order decides between them.  Nodes count as coincident when
+// they fall into the same cell of a 2^-20-spaced lattice of the unit sphere (~6 m on Earth; 2^-30 of the bbox on a flat
+// mesh) in either of two lattices offset by half a cell.  NaN (masked) nodes never coincide.
+hipError_t mesh_has_coincident_nodes(hipStream_t stream, const double* node_tab, int ny, int nx, int spherical, const double bbox[6],
+                                     bool* coincident, std::string* err);
+
 }  // namespace pk

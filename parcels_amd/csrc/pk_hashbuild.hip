@@ -197,6 +197,110 @@ inline unsigned grid_for(int64_t n, int64_t cap = 1 << 16) {
 
 }  // namespace
 
+namespace {
+__global__ void __launch_bounds__(HB_BLOCK) hb_directory_kernel(const uint32_t* __restrict__ keys, int64_t nkeys, int shift, int64_t nbuckets,
+                                                                int32_t* __restrict__ dir) {
+    const int64_t b = (int64_t)blockIdx.x * HB_BLOCK + threadIdx.x;
+    if (b > nbuckets) return;
+    const uint64_t first = (uint64_t)b << shift;  // smallest code of bucket b (b == nbuckets: one past the last code)
+    int64_t lo = 0, hi = nkeys;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((uint64_t)keys[mid] < first) lo = mid + 1; else hi = mid;
+    }
+    dir[b] = (int32_t)lo;
+}
+}  // namespace
+
+namespace {
+__global__ void __launch_bounds__(HB_BLOCK) hb_node_key_kernel(const double* __restrict__ tab, int64_t nnodes, int spherical, DBox bb, double offset,
+                                                               unsigned long long* __restrict__ keys) {
+    const int64_t i = (int64_t)blockIdx.x * HB_BLOCK + threadIdx.x;
+    if (i >= nnodes) return;
+    const double* r = tab + 5 * i;
+    unsigned long long key;
+    if (spherical) {
+        const double X = r[2], Y = r[3], Z = r[4];
+        if (X != X || Y != Y || Z != Z) key = 0x8000000000000000ull | (unsigned long long)i;  // masked: unique
+        else {
+            const double s = 1048576.0;  // 2^20 cells per unit
+            const unsigned long long qx = (unsigned long long)((X + 1.0) * s + offset), qy = (unsigned long long)((Y + 1.0) * s + offset),
+                                     qz = (unsigned long long)((Z + 1.0) * s + offset);
+            key = (qx << 42) | (qy << 21) | qz;  // each < 2^21 + 1
+        }
+    } else {
+        const double x = r[0], y = r[1];
+        if (x != x || y != y) key = 0x8000000000000000ull | (unsigned long long)i;
+        else {
+            const double s = 1073741824.0;  // 2^30 cells across the bbox
+            const double dx = bb.v[1] - bb.v[0], dy = bb.v[3] - bb.v[2];
+            const unsigned long long qx = (unsigned long long)((dx != 0 ? (x - bb.v[0]) / dx : 0.0) * s + offset),
+                                     qy = (unsigned long long)((dy != 0 ? (y - bb.v[2]) / dy : 0.0) * s + offset);
+            key = (qx << 31) | qy;
+        }
+    }
+    keys[i] = key;
+}
+
+__global__ void __launch_bounds__(HB_BLOCK) hb_adjacent_equal_kernel(const unsigned long long* __restrict__ sorted, int64_t n, int* __restrict__ flag) {
+    const int64_t i = (int64_t)blockIdx.x * HB_BLOCK + threadIdx.x;
+    if (i + 1 < n && sorted[i] == sorted[i + 1]) *flag = 1;
+}
+}  // namespace
+
+hipError_t mesh_has_coincident_nodes(hipStream_t stream, const double* node_tab, int ny, int nx, int spherical, const double bbox[6],
+                                     bool* coincident, std::string* err) {
+    *coincident = true;  // the safe answer if anything fails
+    const int64_t n = (int64_t)ny * nx;
+    Scratch tmp;
+    unsigned long long *d_keys, *d_sorted;
+    int* d_flag;
+    HB_TRY(tmp.alloc(&d_keys, (size_t)n));
+    HB_TRY(tmp.alloc(&d_sorted, (size_t)n));
+    HB_TRY(tmp.alloc(&d_flag, 1));
+    HB_TRY(hipMemsetAsync(d_flag, 0, sizeof(int), stream));
+    DBox bb;
+    for (int k = 0; k < 6; k++) bb.v[k] = bbox[k];
+    size_t tb = 0;
+    void* d_tmp = nullptr;
+    HB_TRY(rocprim::radix_sort_keys(nullptr, tb, d_keys, d_sorted, (size_t)n, 0u, 64u, stream));
+    HB_TRY(tmp.alloc((char**)&d_tmp, tb));
+    const unsigned nb = (unsigned)((n + HB_BLOCK - 1) / HB_BLOCK);
+    for (int pass = 0; pass < 2; pass++) {
+        hipLaunchKernelGGL(hb_node_key_kernel, dim3(nb), dim3(HB_BLOCK), 0, stream, node_tab, n, spherical, bb, pass ? 0.5 : 0.0, d_keys);
+        HB_TRY(rocprim::radix_sort_keys(d_tmp, tb, d_keys, d_sorted, (size_t)n, 0u, 64u, stream));
+        hipLaunchKernelGGL(hb_adjacent_equal_kernel, dim3(nb), dim3(HB_BLOCK), 0, stream, d_sorted, n, d_flag);
+    }
+    int flag = 1;
+    HB_TRY(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HB_TRY(hipStreamSynchronize(stream));
+    HB_TRY(hipGetLastError());
+    *coincident = flag != 0;
+    return hipSuccess;
+}
+
+hipError_t build_hash_directory(hipStream_t stream, const uint32_t* keys, int64_t nkeys, int32_t** dir, int32_t* shift, std::string* err) {
+    *dir = nullptr;
+    *shift = 0;
+    if (nkeys <= 0 || nkeys >= INT32_MAX) return hipSuccess;  // no directory: the query searches the whole array
+    int bits = 1;
+    while (bits < 26 && ((int64_t)1 << bits) < 2 * nkeys) bits++;  // ~0.5 keys per bucket, at most 256 MiB
+    const int64_t nbuckets = (int64_t)1 << bits;
+    int32_t* d = nullptr;
+    HB_TRY(hipMalloc((void**)&d, (size_t)(nbuckets + 1) * sizeof(int32_t)));
+    hipLaunchKernelGGL(hb_directory_kernel, dim3((unsigned)((nbuckets + 1 + HB_BLOCK - 1) / HB_BLOCK)), dim3(HB_BLOCK), 0, stream, keys, nkeys,
+                       30 - bits, nbuckets, d);
+    hipError_t e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        if (err) *err = std::string("hash directory: ") + hipGetErrorString(e);
+        return e;
+    }
+    *dir = d;
+    *shift = 30 - bits;
+    return hipSuccess;
+}
+
 hipError_t build_spatial_hash(hipStream_t stream, const double* node_tab, int ny, int nx, int spherical, HashBuildResult* out,
                               std::string* err) {
     *out = HashBuildResult();

@@ -31,12 +31,14 @@ def _ptr(a):
 
 class DeviceEngine:
     def __init__(self, fieldset, device: int = 0, nslots: int | None = None, memory_fraction: float = 0.6,
-                 hash_build: str | None = None):
+                 hash_build: str | None = None, neighbour_probe: int = 0):
         # hash_build: "device" (default) builds the Morton table of a curvilinear grid on the GPU (csrc/pk_hashbuild.hip);
         # "host" uploads parcels_amd.spatialhash.SpatialHash's table.  A grid whose host table already exists uploads it.
         self.hash_build = hash_build or os.environ.get("PARCELS_AMD_HASH_BUILD", "device")
         if self.hash_build not in ("device", "host"):
             raise ValueError("hash_build must be 'device' or 'host'")
+        # neighbour_probe: pk_grid_desc.neighbour_probe (0 automatic, 1 always, -1 never; include/parcels_hip.h)
+        self.neighbour_probe = int(neighbour_probe)
         self.fieldset = fieldset
         self.device = int(device)
         self.ctx = _hip.Context(self.device)
@@ -103,6 +105,7 @@ class DeviceEngine:
             d.h_bitwidth = int(t["bitwidth"])
             for i, v in enumerate(np.asarray(t["bbox"], dtype=np.float64)):
                 d.h_bbox[i] = float(v)
+        d.neighbour_probe = self.neighbour_probe
         gid = C.c_int32(-1)
         self.ctx.check(self.lib.pk_grid_create(self.ctx.handle, C.byref(d), C.byref(gid)), "pk_grid_create")
         del keep  # copied on call
@@ -120,7 +123,7 @@ class DeviceEngine:
         self.ctx.check(self.lib.pk_grid_hash_download(self.ctx.handle, gid, _ptr(keys), _ptr(starts), _ptr(counts), _ptr(faces)),
                        "pk_grid_hash_download")
         return dict(keys=keys, starts=starts, counts=counts, faces=faces, bitwidth=int(info.bitwidth),
-                    bbox=np.array(list(info.bbox), dtype=np.float64))
+                    bbox=np.array(list(info.bbox), dtype=np.float64), neighbour_probe=int(info.neighbour_probe))
 
     # ---- fields ----------------------------------------------------------------------------------------------
     def _plan_and_create_fields(self, nslots, memory_fraction):
