@@ -1020,15 +1020,21 @@ PK_DEV double xlinear_invdist(const DField& f, const GPos& p) {
 }
 
 // NaN -> ErrorInterpolation (field.py:373-378) then out-of-bounds -> 0 (field.py:359-370)
-PK_DEV double finish_value(PCtx& c, const GPos& p, double v) {
+// The reference interpolates wrapped-around garbage for out-of-bounds lanes before zeroing it: finite, unless a barycentric
+// coordinate is non-finite (position +-inf / NaN) -> NaN -> ErrorInterpolation.  `oob_flags`: bit 0 out of bounds, bit 1 that
+// non-finite case; computed once right after the search so that the coordinates need not stay live.
+PK_DEV int oob_flags(const GPos& p) {
     const bool oob = p.xi < 0 || p.yi < 0 || p.zi < 0;
-    // the reference interpolates wrapped-around garbage for out-of-bounds lanes before zeroing it: finite, unless a
-    // barycentric coordinate is non-finite (position +-inf / NaN) -> NaN -> ErrorInterpolation
-    if (oob && !(isfinite(p.xsi) && isfinite(p.eta) && isfinite(p.zeta) && isfinite(p.tau))) v = NAN;
+    const bool bad = oob && !(isfinite(p.xsi) && isfinite(p.eta) && isfinite(p.zeta) && isfinite(p.tau));
+    return (oob ? 1 : 0) | (bad ? 2 : 0);
+}
+PK_DEV double finish_value(PCtx& c, int flags, double v) {
+    if (flags & 2) v = NAN;
     if (v != v && c.state < PK_ERRORINTERPOLATION) c.state = PK_ERRORINTERPOLATION;
-    if (oob) v = 0.0;
+    if (flags & 1) v = 0.0;
     return v;
 }
+PK_DEV double finish_value(PCtx& c, const GPos& p, double v) { return finish_value(c, oob_flags(p), v); }
 
 // VectorField.eval (field.py:250-304). INTERP: 0 XLinear_Velocity, 1 CGrid_Velocity. pos_f32: z,y,x come
 // straight from float32 particle storage (NumPy then evaluates cos(lat) in float32).
@@ -1049,7 +1055,8 @@ PK_DEV void eval_uvw(const KArgs& a, const Coords& mc, PCtx& c, bool want_w, dou
     int32_t ei = ei_get(c, U.grid);
     grid_search<KIND>(g, &mc, z, y, x, pos_f32, &ei, c, use_guess, p);
     ei_set(c, U.grid, ei);
-    const bool oob = (p.xi < 0 || p.yi < 0 || p.zi < 0);
+    const int flags = oob_flags(p);
+    const bool oob = flags & 1;
     double uu = 0, vv = 0, ww = 0;
     if (!oob) {
         const DField* W = (want_w && a.prm.fW >= 0) ? &a.fields[a.prm.fW] : nullptr;
@@ -1074,9 +1081,9 @@ PK_DEV void eval_uvw(const KArgs& a, const Coords& mc, PCtx& c, bool want_w, dou
             }
         }
     }
-    u = finish_value(c, p, uu);
-    v = finish_value(c, p, vv);
-    w = finish_value(c, p, ww);
+    u = finish_value(c, flags, uu);
+    v = finish_value(c, flags, vv);
+    w = finish_value(c, flags, ww);
 }
 
 // Field.eval for a scalar field (field.py:145-195): XLinear or XConstantField
