@@ -246,11 +246,20 @@ __global__ void __launch_bounds__(256) copy_kernel(const float4* __restrict__ sr
 
 }  // namespace pk
 
-// pageable -> pinned staging copy of one field level, split over a few host threads (a single core moves ~10 GB/s,
-// which would otherwise bound the slab stream well below the PCIe rate)
+// pageable -> pinned staging copy of one field level, split over host threads (a single core moves ~10 GB/s, which would
+// otherwise bound the slab stream well below the PCIe rate).  PK_COPY_THREADS overrides the thread count.
+constexpr size_t PK_STAGE_CHUNK_BYTES = (size_t)256 << 20;
+static unsigned copy_threads() {
+    static const unsigned n = [] {
+        if (const char* e = getenv("PK_COPY_THREADS")) return (unsigned)std::max(1, atoi(e));
+        const unsigned hw = std::thread::hardware_concurrency();
+        return std::max(8u, std::min(32u, hw / 4));
+    }();
+    return n;
+}
 static void parallel_memcpy(void* dst, const void* src, size_t bytes) {
-    const size_t min_chunk = 32u << 20;
-    unsigned nthr = (unsigned)std::min<size_t>(8, std::max<size_t>(1, bytes / min_chunk));
+    const size_t min_chunk = 4u << 20;
+    unsigned nthr = (unsigned)std::min<size_t>(copy_threads(), std::max<size_t>(1, bytes / min_chunk));
     if (nthr <= 1) {
         memcpy(dst, src, bytes);
         return;
@@ -604,23 +613,23 @@ int32_t pk_field_upload_level(pk_ctx* ctx, int32_t field_id, int32_t level, cons
         if (int32_t rc = interleave()) return rc;
         PK_HIP(ctx, hipStreamSynchronize(ctx->copy));
     } else {
-        // pageable NumPy memory cannot be DMA'd asynchronously: bounce through a pinned staging ring (2 buffers)
-        const int k = ctx->stage_next;
-        ctx->stage_next ^= 1;
-        if (ctx->stage_bytes[k] < f.level_bytes) {
-            if (ctx->stage[k]) {
-                PK_HIP(ctx, hipEventSynchronize(ctx->stage_ev[k]));
-                PK_HIP(ctx, hipHostFree(ctx->stage[k]));
-                ctx->stage[k] = nullptr;
+        // pageable NumPy memory cannot be DMA'd asynchronously: bounce it through a ring of two fixed-size pinned chunks
+        // (allocated once; pinning a whole 4 GB level costs ~1 s) -- the host fills chunk k+1 while chunk k is on the wire
+        const size_t chunk = PK_STAGE_CHUNK_BYTES;
+        for (size_t off = 0; off < f.level_bytes; off += chunk) {
+            const size_t len = std::min(chunk, f.level_bytes - off);
+            const int k = ctx->stage_next;
+            ctx->stage_next ^= 1;
+            if (!ctx->stage[k]) {
+                PK_HIP(ctx, hipHostMalloc(&ctx->stage[k], chunk, hipHostMallocDefault));
+                ctx->stage_bytes[k] = chunk;
+            } else {
+                PK_HIP(ctx, hipEventSynchronize(ctx->stage_ev[k]));  // previous DMA out of this buffer finished
             }
-            PK_HIP(ctx, hipHostMalloc(&ctx->stage[k], f.level_bytes, hipHostMallocDefault));
-            ctx->stage_bytes[k] = f.level_bytes;
-        } else {
-            PK_HIP(ctx, hipEventSynchronize(ctx->stage_ev[k]));  // previous DMA out of this buffer finished
+            parallel_memcpy(ctx->stage[k], (const char*)host_data + off, len);
+            PK_HIP(ctx, hipMemcpyAsync(h2d_dst + off, ctx->stage[k], len, hipMemcpyHostToDevice, ctx->copy));
+            PK_HIP(ctx, hipEventRecord(ctx->stage_ev[k], ctx->copy));
         }
-        parallel_memcpy(ctx->stage[k], host_data, f.level_bytes);
-        PK_HIP(ctx, hipMemcpyAsync(h2d_dst, ctx->stage[k], f.level_bytes, hipMemcpyHostToDevice, ctx->copy));
-        PK_HIP(ctx, hipEventRecord(ctx->stage_ev[k], ctx->copy));
         if (int32_t rc = interleave()) return rc;
     }
     if (async) {  // usable only after pk_field_sync(); the level that lived in this slot is gone as of now
