@@ -203,6 +203,12 @@ int32_t pk_particles_d2h_columns(pk_ctx* ctx, uint32_t column_mask);
  * columns at write-out; see parcels_amd/distributed.py).  perm (int64*, may be NULL when the particles
  * have not been cell-sorted) maps device row -> original row. */
 int32_t pk_particles_device(pk_ctx* ctx, pk_particles_desc* dev, int64_t** perm);
+/* Kernel.remove_deleted (kernel.py:98-106) on the device-resident columns: rows whose state is Delete are removed (the
+ * survivors keep their relative order, in device order and in host order), no column crosses PCIe.  `new_host` describes
+ * the caller's host arrays of the surviving length (same schema as the bound ones); later pk_particles_d2h* calls fill
+ * THOSE.  The caller learns the survivors from the `state` column (pk_particles_d2h_columns(PK_COL_STATE)) beforehand.
+ * *n_new = number of surviving particles (must equal new_host->n). */
+int32_t pk_particles_compact(pk_ctx* ctx, const pk_particles_desc* new_host, int64_t* n_new);
 
 /* ---- execution: Kernel.execute (kernel.py:174-247) ----------------------------------------------- */
 typedef struct pk_exec_params {

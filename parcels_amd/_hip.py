@@ -178,6 +178,7 @@ ABI_SYMBOLS = [
     "pk_particles_d2h",
     "pk_particles_d2h_columns",
     "pk_particles_device",
+    "pk_particles_compact",
     "pk_execute",
     "pk_execute_begin",
     "pk_execute_end",
@@ -229,6 +230,7 @@ def load():
     lib.pk_particles_d2h.argtypes = [C.c_void_p]
     lib.pk_particles_d2h_columns.argtypes = [C.c_void_p, C.c_uint32]
     lib.pk_particles_device.argtypes = [C.c_void_p, C.POINTER(ParticlesDesc), C.POINTER(C.c_void_p)]
+    lib.pk_particles_compact.argtypes = [C.c_void_p, C.POINTER(ParticlesDesc), C.POINTER(C.c_int64)]
     lib.pk_execute.argtypes = [C.c_void_p, C.POINTER(ExecParams), C.POINTER(ExecStats)]
     lib.pk_execute_begin.argtypes = [C.c_void_p, C.POINTER(ExecParams)]
     lib.pk_execute_end.argtypes = [C.c_void_p, C.POINTER(ExecStats)]

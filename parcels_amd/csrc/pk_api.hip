@@ -234,6 +234,32 @@ __global__ void __launch_bounds__(256) compose_perm_kernel(const int64_t* __rest
     new_perm[i] = old_perm ? old_perm[perm[i]] : (int64_t)perm[i];
 }
 
+// ---- device-side removal of deleted particles (Kernel.remove_deleted, kernel.py:98-106) ----------------------------------
+__global__ void __launch_bounds__(256) keep_flags_kernel(const int32_t* __restrict__ state, const int64_t* __restrict__ perm, int64_t n,
+                                                         unsigned long long* __restrict__ keep_dev, uint32_t* __restrict__ keep_host) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned k = state[i] != PK_DELETE;
+    keep_dev[i] = k;
+    keep_host[perm ? perm[i] : i] = k;
+}
+template <class T>
+__global__ void __launch_bounds__(256) compact_rows_kernel(const T* __restrict__ in, T* __restrict__ out, const unsigned long long* __restrict__ keep,
+                                                           const unsigned long long* __restrict__ pos, int64_t n, int width) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !keep[i]) return;
+    const int64_t dst = (int64_t)pos[i];
+    for (int k = 0; k < width; k++) out[dst * width + k] = in[i * width + k];
+}
+// new_perm[new device row] = new host row of the old host row this device row mapped to
+__global__ void __launch_bounds__(256) compact_perm_kernel(const int64_t* __restrict__ perm, const unsigned long long* __restrict__ keep,
+                                                           const unsigned long long* __restrict__ pos, const uint32_t* __restrict__ host_pos,
+                                                           int64_t n, int64_t* __restrict__ new_perm) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !keep[i]) return;
+    new_perm[pos[i]] = (int64_t)host_pos[perm[i]];
+}
+
 // scatter one contiguous field level into its component slot of a packed (array-of-structs) group buffer
 template <class T>
 __global__ void __launch_bounds__(256) interleave_kernel(const T* __restrict__ src, T* __restrict__ dst, int64_t n, int ncomp) {
@@ -870,6 +896,66 @@ int32_t pk_particles_device(pk_ctx* ctx, pk_particles_desc* dev, int64_t** perm)
     dev->ei = ctx->dev.ei;
     dev->particle_id = ctx->dev.particle_id;
     if (perm) *perm = ctx->has_perm ? ctx->d_perm : nullptr;
+    return 0;
+}
+
+// Remove the rows whose state is Delete from the DEVICE-RESIDENT columns (order of the survivors kept, in device order and
+// in host order) and re-point the host side at `new_host`, the caller's arrays of the surviving length: no column crosses
+// PCIe.  Kernel.remove_deleted (kernel.py:98-106) without the round trip through NumPy.
+int32_t pk_particles_compact(pk_ctx* ctx, const pk_particles_desc* new_host, int64_t* n_new) {
+    if (!ctx || !new_host || !n_new) return -2;
+    if (!ctx->bound) return ctx->fail("no particles bound");
+    if (ctx->in_flight) return ctx->fail("pk_particles_compact: a launch is in flight");
+    PK_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t n = ctx->dev.n;
+    if (n >= (1ll << 32)) return ctx->fail("device compaction supports < 2^32 particles per device");
+    if (new_host->ngrids != ctx->host.ngrids || new_host->spatial_dtype != ctx->host.spatial_dtype ||
+        (new_host->next_dt != nullptr) != (ctx->host.next_dt != nullptr))
+        return ctx->fail("pk_particles_compact: the new host columns must have the bound schema");
+    int64_t kept = 0;
+    if (n > 0) {
+        int32_t rc = ensure_alt(ctx);
+        if (rc) return rc;
+        const dim3 grid((unsigned)((n + 255) / 256));
+        unsigned long long *keep = ctx->d_keys, *pos = ctx->d_keys_alt;
+        uint32_t *keep_host = ctx->d_idx, *host_pos = ctx->d_idx_alt;
+        const int64_t* perm = ctx->has_perm ? ctx->d_perm : nullptr;
+        hipLaunchKernelGGL(keep_flags_kernel, grid, dim3(256), 0, ctx->compute, ctx->dev.state, perm, n, keep, keep_host);
+        size_t tb1 = 0, tb2 = 0;
+        PK_HIP(ctx, rocprim::exclusive_scan(nullptr, tb1, keep, pos, 0ull, (size_t)n, rocprim::plus<unsigned long long>(), ctx->compute));
+        PK_HIP(ctx, rocprim::exclusive_scan(nullptr, tb2, keep_host, host_pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), ctx->compute));
+        const size_t tb = std::max(tb1, tb2);
+        if (tb > ctx->sort_tmp_bytes) {
+            if (ctx->d_sort_tmp) PK_HIP(ctx, hipFree(ctx->d_sort_tmp));
+            PK_HIP(ctx, hipMalloc(&ctx->d_sort_tmp, tb));
+            ctx->sort_tmp_bytes = tb;
+        }
+        PK_HIP(ctx, rocprim::exclusive_scan(ctx->d_sort_tmp, tb1, keep, pos, 0ull, (size_t)n, rocprim::plus<unsigned long long>(), ctx->compute));
+        PK_HIP(ctx, rocprim::exclusive_scan(ctx->d_sort_tmp, tb2, keep_host, host_pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), ctx->compute));
+        unsigned long long last_pos = 0, last_keep = 0;
+        PK_HIP(ctx, hipMemcpyAsync(&last_pos, pos + (n - 1), 8, hipMemcpyDeviceToHost, ctx->compute));
+        PK_HIP(ctx, hipMemcpyAsync(&last_keep, keep + (n - 1), 8, hipMemcpyDeviceToHost, ctx->compute));
+        for (const ColRef& c : particle_columns(ctx)) {
+            if (!c.d || !c.a) continue;
+            if (c.elem == 8) hipLaunchKernelGGL((compact_rows_kernel<unsigned long long>), grid, dim3(256), 0, ctx->compute, (const unsigned long long*)c.d, (unsigned long long*)c.a, keep, pos, n, c.width);
+            else hipLaunchKernelGGL((compact_rows_kernel<uint32_t>), grid, dim3(256), 0, ctx->compute, (const uint32_t*)c.d, (uint32_t*)c.a, keep, pos, n, c.width);
+        }
+        if (perm) hipLaunchKernelGGL(compact_perm_kernel, grid, dim3(256), 0, ctx->compute, perm, keep, pos, host_pos, n, ctx->d_perm_alt);
+        PK_HIP(ctx, hipGetLastError());
+        PK_HIP(ctx, hipStreamSynchronize(ctx->compute));
+        kept = (int64_t)(last_pos + last_keep);
+        DParticles d = ctx->dev, a = ctx->alt;
+        ctx->dev.t = a.t; ctx->dev.z = a.z; ctx->dev.y = a.y; ctx->dev.x = a.x; ctx->dev.dz = a.dz; ctx->dev.dy = a.dy; ctx->dev.dx = a.dx;
+        ctx->dev.dt = a.dt; ctx->dev.next_dt = a.next_dt; ctx->dev.state = a.state; ctx->dev.ei = a.ei; ctx->dev.particle_id = a.particle_id;
+        ctx->alt.t = d.t; ctx->alt.z = d.z; ctx->alt.y = d.y; ctx->alt.x = d.x; ctx->alt.dz = d.dz; ctx->alt.dy = d.dy; ctx->alt.dx = d.dx;
+        ctx->alt.dt = d.dt; ctx->alt.next_dt = d.next_dt; ctx->alt.state = d.state; ctx->alt.ei = d.ei; ctx->alt.particle_id = d.particle_id;
+        if (perm) std::swap(ctx->d_perm, ctx->d_perm_alt);
+    }
+    if (new_host->n != kept) return ctx->fail("pk_particles_compact: new host columns hold " + std::to_string(new_host->n) + " rows, " +
+                                              std::to_string(kept) + " particles survive");
+    ctx->dev.n = kept;
+    ctx->host = *new_host;
+    *n_new = kept;
     return 0;
 }
 

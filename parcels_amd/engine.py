@@ -277,7 +277,8 @@ class DeviceEngine:
                 self._upload(f.name, nxt, asynchronous=True)
 
     # ---- particles -------------------------------------------------------------------------------------------
-    def bind_particles(self, data: dict):
+    def _particles_desc(self, data: dict):
+        """Validate the SoA dict (particle.py:182-222) and describe it for the library (pk_particles_desc)."""
         n = data["x"].shape[0]
         for k in ("t", "z", "y", "x", "dz", "dy", "dx", "dt", "state", "ei", "particle_id"):
             a = data[k]
@@ -309,8 +310,33 @@ class DeviceEngine:
             raise TypeError("next_dt must be float32 or float64")
         d.next_dt = _ptr(nd) if nd is not None else None
         d.state, d.ei, d.particle_id = _ptr(data["state"]), _ptr(data["ei"]), _ptr(data["particle_id"])
+        return d
+
+    def bind_particles(self, data: dict):
+        d = self._particles_desc(data)
         self.ctx.check(self.lib.pk_particles_bind(self.ctx.handle, C.byref(d)), "pk_particles_bind")
         self._bound = data
+
+    def compact_deleted(self, data: dict) -> dict:
+        """Kernel.remove_deleted (kernel.py:98-106) without moving the columns: the rows in state Delete are removed from
+        the device-resident columns (pk_particles_compact); only the `state` column comes back, to tell the host which rows
+        survive.  Returns the new SoA dict: `state` and host-only user Variables are compacted here, the device-bound columns
+        are fresh arrays of the surviving length that the next d2h() fills."""
+        self.d2h(["state"])
+        keep = data["state"] != StatusCode.Delete
+        n_new = int(np.count_nonzero(keep))
+        new = {}
+        for name, arr in data.items():
+            if name != "state" and name in _hip.COLUMN_BITS:
+                new[name] = np.empty((n_new,) + arr.shape[1:], dtype=arr.dtype)
+            else:
+                new[name] = np.ascontiguousarray(arr[keep])
+        d = self._particles_desc(new)
+        got = C.c_int64(-1)
+        self.ctx.check(self.lib.pk_particles_compact(self.ctx.handle, C.byref(d), C.byref(got)), "pk_particles_compact")
+        assert got.value == n_new
+        self._bound = new
+        return new
 
     def h2d(self):
         if self._next_dt_f32 is not None:

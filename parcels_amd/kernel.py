@@ -123,6 +123,12 @@ class Kernel:
         sc = stats["state_counts"]
         return any(code in sc for code in (StatusCode.Delete, StatusCode.StopAllExecution, *[c for c in sc if c >= StatusCode.Error]))
 
+    @staticmethod
+    def only_deletions(stats) -> bool:
+        """The launch left particles in state Delete and nothing to raise: the compaction can stay on the device."""
+        sc = stats["state_counts"]
+        return StatusCode.Delete in sc and StatusCode.StopAllExecution not in sc and not any(c >= StatusCode.Error for c in sc)
+
     def finish_on_host(self, pset):
         """kernel.py:233-245 after the columns are back on the host: compact deleted particles, raise error codes."""
         data = pset._data

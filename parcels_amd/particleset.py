@@ -33,6 +33,7 @@ class ParticleSet:
     ``seed`` keys the counter-based RNG of the stochastic kernels; ``sort_by_cell`` lets the engine reorder the
     device copy by grid cell for gather locality (host row order is never affected)."""
 
+
     def __init__(self, fieldset, pclass=Particle, *, t=None, z=None, y=None, x=None, particle_ids=None, seed=0,
                  sort_by_cell=False, **kwargs):
         object.__setattr__(self, "_data", None)
@@ -40,6 +41,7 @@ class ParticleSet:
         self._kernel = None
         self.seed = int(seed)
         self.sort_by_cell = bool(sort_by_cell)
+        self.device_compaction = True  # deleted particles are removed on the device (False: through NumPy on the host)
         self._last_stats = None
         self._t_live = None
         t = np.empty(shape=0) if t is None else np.array(t).flatten()
@@ -167,7 +169,14 @@ class ParticleSet:
                     have_guess0 = 1
                     synced = False
                     self._t_live = next_time if not np.isnan(next_time) else None
-                    if kern.needs_host_pass(stats):
+                    if kern.only_deletions(stats) and self.device_compaction:
+                        # Kernel.remove_deleted on the device: the columns do not leave HBM (pk_particles_compact)
+                        self._data = engine.compact_deleted(self._data)
+                        synced = False
+                        if len(self) == 0:
+                            synced = True
+                            break
+                    elif kern.needs_host_pass(stats):
                         engine.d2h()
                         synced = True
                         kern.finish_on_host(self)  # compacts / raises

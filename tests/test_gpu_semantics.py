@@ -304,3 +304,35 @@ def test_decaying_moving_eddy_closed_form(gpu, kernel, rtol):
     exp_lat = y0 - ((u_0 - u_g) / den) * f * (1 - np.exp(-gamma * T) * (np.cos(f * T) + (gamma / f) * np.sin(f * T)))
     np.testing.assert_allclose(pset.x, exp_lon, rtol=rtol)
     np.testing.assert_allclose(pset.y, exp_lat, rtol=rtol)
+
+
+@pytest.mark.parametrize("sort_by_cell", [False, True])
+def test_device_side_removal_of_deleted_particles(gpu, sort_by_cell):
+    """Kernel.remove_deleted (kernel.py:98-106) runs on the device-resident columns (pk_particles_compact): same particle
+    set, same order, same observations at every output time as the host (NumPy) compaction, with and without the cell sort
+    permutation, including a host-only user Variable."""
+    from case_utils import OutputRecorder
+
+    fs = pa.FieldSet.from_sgrid_conventions(simple_uv_dataset(mesh="flat", u=5.0, v=2.5, dims=(4, 2, 30, 40)), mesh="flat")
+    rng = np.random.default_rng(5)
+    n = 20000
+    x0, y0 = rng.uniform(-9e5, 9e5, n), rng.uniform(-9e5, 9e5, n)
+    pclass = pa.get_default_particle(np.float64).add_variable(pa.Variable("tag", dtype=np.int32, initial=0))
+    runs = []
+    for device in (True, False):
+        pset = pa.ParticleSet(fs, pclass=pclass, x=x0, y=y0, t=np.zeros(n), sort_by_cell=sort_by_cell, tag=np.arange(n, dtype=np.int32))
+        pset.device_compaction = device
+        rec = OutputRecorder(3 * 3600.0)
+        pset.execute([pa.AdvectionRK4, pa.DeleteOutOfBounds], runtime=30 * 3600.0, dt=3600.0, output_file=rec)
+        runs.append((pset, rec))
+    (a, ra), (b, rb) = runs
+    assert 0 < len(a) < n and len(a) == len(b)
+    for k in a._data:
+        assert np.array_equal(a._data[k], b._data[k]), k
+    assert np.array_equal(a._data["tag"], a._data["particle_id"].astype(np.int32))  # the host-only column followed the rows
+    assert len(ra.obs) == len(rb.obs) > 5
+    counts = [len(o[1]) for o in ra.obs]
+    assert counts[0] == n and counts[-1] < counts[0] and len(set(counts)) > 3  # particles leave in several intervals
+    for oa, ob in zip(ra.obs, rb.obs):
+        for u, v in zip(oa, ob):
+            assert np.array_equal(u, v)
