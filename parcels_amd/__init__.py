@@ -5,7 +5,7 @@ time loop, cell search and interpolation run in hand-written HIP kernels (csrc/)
 include/parcels_hip.h.  There is no NumPy/CPU execution path.
 """
 
-from . import kernels
+from . import convert, kernels
 from .dataset import DataArray, Dataset
 from .field import Field, TimeInterval, VectorField
 from .fieldset import FieldSet

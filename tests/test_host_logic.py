@@ -153,3 +153,43 @@ def test_spatial_hash_build_pinned_to_reference():
             break
     else:
         pytest.fail("no curvilinear fixture")
+
+
+def test_nemo_to_sgrid_names_dims_offsets_and_w_sign():
+    """parcels_amd.convert.nemo_to_sgrid against what the reference's converter produces (convert.py:308-408; expectations
+    of tests/test_convert.py:26-104): SGRID topology, U on (y_center, x), V on (y, x_center), offsets X=1, Y=1, Z=0, W negated,
+    NEMO names mapped."""
+    from parcels_amd import convert
+
+    nt, nz, ny, nx = 2, 3, 6, 7
+    rng = np.random.default_rng(0)
+    glamf = np.linspace(0, 6, nx)[None, :] + np.zeros((ny, 1))
+    gphif = np.linspace(40, 45, ny)[:, None] + np.zeros((1, nx))
+    uo, vo, wo = (rng.standard_normal((nt, nz, ny, nx)).astype(np.float32) for _ in range(3))
+    coords = pa.Dataset({}, {"glamf": (("t", "y", "x"), glamf[None]), "gphif": (("t", "y", "x"), gphif[None]),
+                             "depthw": (("depthw",), np.array([0.0, 10.0, 30.0])), "time_counter": (("time_counter",), np.array([0.0, 86400.0]))})
+    ds = convert.nemo_to_sgrid(
+        fields={"uo": (("time_counter", "depthu", "y", "x"), uo), "vo": (("time_counter", "depthv", "y", "x"), vo),
+                "wo": (("time_counter", "depthw", "y", "x"), wo)}, coords=coords)
+    md = ds.sgrid
+    assert md.node_dimensions == ("x", "y") and md.node_coordinates == ("lon", "lat")
+    assert [(f.face, f.node, f.padding) for f in md.face_dimensions] == [("x_center", "x", pa.Padding.LOW), ("y_center", "y", pa.Padding.LOW)]
+    assert [(f.face, f.node, f.padding) for f in md.vertical_dimensions] == [("depth_center", "depth", pa.Padding.HIGH)]
+    assert ds["U"].dims == ("time", "depth_center", "y_center", "x")
+    assert ds["V"].dims == ("time", "depth_center", "y", "x_center")
+    assert ds["W"].dims == ("time", "depth", "y", "x")
+    assert np.array_equal(ds["W"].data, -wo) and np.array_equal(ds["U"].data, uo)
+    assert ds["lon"].dims == ("y", "x") and ds["lon"].attrs["units"] == "degrees"
+    fs = pa.FieldSet.from_sgrid_conventions(ds)  # mesh from the units attribute: spherical
+    assert fs.gridset[0]._mesh.is_spherical()
+    assert fs.gridset[0].offsets() == {"X": 1, "Y": 1, "Z": 0}
+    assert isinstance(fs.UVW.interp_method, pa.CGrid_Velocity)
+
+    # surface-only data: a single depth level is added (convert.py:150-154); a missing coordinate is an error
+    ds2 = convert.nemo_to_sgrid(fields={"U": (("time_counter", "y", "x"), uo[:, 0]), "V": (("time_counter", "y", "x"), vo[:, 0])},
+                                coords=pa.Dataset({}, {"glamf": (("y", "x"), glamf), "gphif": (("y", "x"), gphif),
+                                                       "time_counter": (("time_counter",), np.array([0.0, 86400.0]))}))
+    assert ds2["U"].dims == ("time", "depth", "y_center", "x") and ds2["depth"].data.tolist() == [0.0]
+    pa.FieldSet.from_sgrid_conventions(ds2, mesh="spherical")
+    with pytest.raises(ValueError, match="glamf"):
+        convert.nemo_to_sgrid(fields={}, coords=pa.Dataset({}, {"gphif": (("y", "x"), gphif)}))
