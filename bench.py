@@ -97,12 +97,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    # rehearsal knob for a 1-GPU box: all ranks share cuda:0 and talk over gloo (RCCL refuses two ranks on one device); the
+    # line it prints is marked and is not a measurement
+    rehearsal = os.environ.get("PARCELS_AMD_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import parcels_amd as pa
     from tests.case_utils import build_fieldset, build_pset
@@ -194,7 +202,7 @@ def main():
             "config": {"workload": "C2: 3D rectilinear A-grid 360x180x50x24 fp64 U,V (spherical), AdvectionRK4, dt=3600 s",
                        "particles_per_gpu": npart, "particle_dtype": "f64", "cell_sorted": bool(args.sort),
                        "parallelism": f"particles sharded by id x{world}, fields replicated",
-                       "all_states_endofloop": ok},
+                       "all_states_endofloop": ok, **({"rehearsal_shared_gpu_gloo": True} if rehearsal else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": None, "kernel": "advect_kernel<double,0,0,RK4,lds>", "kernel_ms_per_launch": float(kms.item()),
                          "algorithmic_bytes_per_particle_step": ALGO_BYTES_PER_STEP_C2_RK4,

@@ -153,7 +153,7 @@ struct GPos {
 constexpr int CC_LANES = 256;
 struct CellCache {
     double* nodes;  // [20][256]: corner c (0 (yi,xi), 1 (yi,xi+1), 2 (yi+1,xi+1), 3 (yi+1,xi)), component m -> (c*5+m)
-    int* key;       // [4][256]: node cell yi*nx+xi | field cell yi*nx+xi | zi | 2*ti + (level ti+1 cached);  -1 = empty
+    int* key;       // [4][256]: node cell yi*nx+xi | field cell yi*nx+xi | zi | 4*ti + 2*(W cached) + (level ti+1 cached);  -1 = empty
     void* fvals;    // [12][256] of the field dtype: Ua,Ub,Va,Vb,Wa,Wb at level ti, then at level ti+1 (NULL: not cached)
 };
 
@@ -878,8 +878,10 @@ PK_DEV void cgrid_velocity(const DGrid& g, const Coords* mc, const DField& U, co
     const int zi_0 = clampi(zi + g.off_z, 0, zdim - 1), zi_1 = clampi(zi + g.off_z + 1, 0, zdim - 1);
     double raw[12];
     FT* fv = cc_on ? (FT*)mc->cc.fvals : nullptr;
+    // key[3] = 4*ti + 2*(W values cached) + (level ti+1 cached)
     const bool fhit = fv && mc->cc.key[1 * CC_LANES] == cell && mc->cc.key[2 * CC_LANES] == zi &&
-                      (mc->cc.key[3 * CC_LANES] >> 1) == p.ti && (!lenT || (mc->cc.key[3 * CC_LANES] & 1));
+                      (mc->cc.key[3 * CC_LANES] >> 2) == p.ti && (!lenT || (mc->cc.key[3 * CC_LANES] & 1)) &&
+                      (!W || (mc->cc.key[3 * CC_LANES] & 2));
     if (fhit) {
 #pragma unroll
         for (int k = 0; k < 6; k++) raw[k] = (double)fv[k * CC_LANES];
@@ -914,7 +916,7 @@ PK_DEV void cgrid_velocity(const DGrid& g, const Coords* mc, const DField& U, co
                 for (int k = 0; k < 6; k++) fv[(6 + k) * CC_LANES] = (FT)raw[6 + k];
             }
             mc->cc.key[2 * CC_LANES] = zi;
-            mc->cc.key[3 * CC_LANES] = 2 * p.ti + (lenT ? 1 : 0);
+            mc->cc.key[3 * CC_LANES] = 4 * p.ti + (W ? 2 : 0) + (lenT ? 1 : 0);
             mc->cc.key[1 * CC_LANES] = cell;
         }
     }
