@@ -1,0 +1,104 @@
+"""GPU: seeded differential fuzzing of the HIP path against the CPU oracle.
+
+Every seed draws a grid type (rectilinear A-grid / rectilinear C-grid / curvilinear A- or C-grid), mesh, field / particle /
+coordinate dtypes, a kernel list (Euler .. RK45, Milstein / Euler-Maruyama diffusion, recovery kernels), time direction,
+staggered releases, release margins that push particles out of the domain, output intervals and the device cell sort, and
+demands what the fixed cases demand: same raised error, same `t`, `state`, `ei` and particle order exactly, positions to the
+tolerance class of the configuration (tests/case_utils.py).  The oracle itself is pinned to the reference bit for bit
+(tests/test_oracle_golden.py), so this widens the reference-parity net to configurations no fixture holds.
+"""
+
+import os
+
+import numpy as np
+import pytest
+
+from case_utils import compare, run_hip, run_oracle
+
+pytestmark = pytest.mark.gpu
+
+ADVECTION_2D = ["AdvectionEE", "AdvectionRK2", "AdvectionRK4", "AdvectionRK45"]
+ADVECTION_3D = ["AdvectionRK2_3D", "AdvectionRK4_3D"]
+RECOVERY = [None, "DeleteParticle", "DeleteOutOfBounds", "SubmergeParticle"]
+
+
+def draw_case(seed):
+    from oracle import cases
+
+    rng = np.random.default_rng(1000 + seed)
+    kind = rng.choice(["agrid", "agrid", "cgrid", "curv_c", "curv_a", "diffusion"])
+    mesh = str(rng.choice(["spherical", "flat"]))
+    backward = bool(rng.random() < 0.25)
+    npart = int(rng.integers(200, 1500))
+    three_d = bool(rng.random() < 0.5)
+    kernel = str(rng.choice(ADVECTION_3D if three_d else ADVECTION_2D))
+    kernels = [kernel]
+    if rng.random() < 0.3 and kernel != "AdvectionRK45":
+        kernels.append(str(rng.choice(ADVECTION_2D[:3] + (ADVECTION_3D if three_d else []))))
+    rec = RECOVERY[int(rng.integers(0, len(RECOVERY)))]
+    if rec == "SubmergeParticle":
+        kernels += ["SubmergeParticle", "DeleteOutOfBounds"]
+    elif rec:
+        kernels.append(rec)
+    sdt = str(rng.choice(["float64", "float64", "float32"]))
+    fdt = np.float32 if rng.random() < 0.5 else np.float64
+    dt = float(rng.choice([600.0, 1800.0, 3600.0])) * (-1 if backward else 1)
+    nsteps = int(rng.integers(5, 30))
+    common = dict(mesh=mesh, kernels=kernels, seed=int(seed), npart=npart)
+    if kind == "agrid":
+        cdt = np.float32 if (rng.random() < 0.25) else np.float64
+        case = cases.rect_agrid_case(f"fuzz{seed}", **common, nx=int(rng.integers(8, 40)), ny=int(rng.integers(6, 30)),
+                                     nz=int(rng.integers(2, 8)), nt=int(rng.integers(2, 5)), field_dtype=fdt, spatial_dtype=sdt,
+                                     coord_dtype=cdt, with_w=three_d, dt=dt, runtime=nsteps * abs(dt),
+                                     margin=float(rng.choice([0.15, 0.05, 0.01])), vel=float(rng.choice([0.5, 2.0, 6.0])),
+                                     stagger=bool(rng.random() < 0.3))
+    elif kind == "cgrid":
+        case = cases.rect_cgrid_case(f"fuzz{seed}", **common, field_dtype=fdt, spatial_dtype=sdt)
+        case["dt"], case["runtime"] = dt, nsteps * abs(dt)
+    elif kind in ("curv_c", "curv_a"):
+        case = cases.curv_cgrid_case(f"fuzz{seed}", **common, nx=int(rng.integers(20, 60)), ny=int(rng.integers(16, 45)),
+                                     field_dtype=fdt, spatial_dtype=sdt, with_w=True, dt=dt, runtime=nsteps * abs(dt),
+                                     vel=float(rng.choice([0.3, 1.0, 3.0])), cgrid=(kind == "curv_c"))
+        case["populate"] = bool(rng.random() < 0.5)
+    else:
+        dk = str(rng.choice(["AdvectionDiffusionM1", "AdvectionDiffusionEM"]))
+        case = cases.diffusion_case(f"fuzz{seed}", mesh=mesh, kernels=[dk] + ([rec] if rec in ("DeleteParticle", "DeleteOutOfBounds") else []),
+                                    seed=int(seed), npart=npart, spatial_dtype=sdt, const_kh=(5.0 if rng.random() < 0.3 else None))
+        case["dt"] = abs(case["dt"])
+        backward = False
+    if "AdvectionRK45" in case["kernels"]:
+        scale = 1.0 if mesh == "flat" else 1.0
+        case["context"] = {"RK45_tol": float(rng.choice([0.5, 50.0, 5000.0])) * scale, "RK45_min_dt": 10.0, "RK45_max_dt": 4 * 3600.0}
+        if rng.random() < 0.5:
+            case["next_dt_dtype"] = "float32"
+    if backward and case.get("time_s") is not None:
+        case["t0"] = np.full(len(case["x"]), float(case["time_s"][-1]))
+        case["dt"] = -abs(case["dt"])
+    if rng.random() < 0.3 and kind != "diffusion":
+        case["outputdt"] = float(abs(case["dt"]) * rng.choice([2.0, 2.5, 3.7]))
+    if not three_d and kind != "diffusion":
+        pass
+    return case, bool(rng.random() < 0.5)
+
+
+def tolerance(case):
+    f32_part = case.get("spatial_dtype", "float64") == "float32"
+    f32_coord = np.asarray(case["lon"]).dtype == np.float32
+    if f32_part and f32_coord:
+        return 2e-6
+    if f32_part:
+        return 5e-7
+    if np.asarray(case["lon"]).ndim == 2 and not case.get("populate"):
+        return 1e-7
+    return 1e-10
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PARCELS_FUZZ_SEEDS", "96"))))
+def test_random_configuration_matches_oracle(gpu, seed):
+    case, sort_by_cell = draw_case(seed)
+    ref, oerr, ostats = run_oracle(case)
+    got, gerr, stats = run_hip(case, sort_by_cell=sort_by_cell)
+    label = f"seed {seed}: {case['kernels']} mesh={case['mesh']} lon{np.asarray(case['lon']).shape} dt={case['dt']} sort={sort_by_cell} " \
+            f"outputdt={case.get('outputdt')} sdt={case.get('spatial_dtype')}"
+    assert gerr == oerr, label
+    compare(got, ref, rtol=tolerance(case), check_state="all", label=label)
