@@ -428,12 +428,6 @@ __global__ void __launch_bounds__(256, (KIND == 1 || INTERP != 0) ? PK_MIN_WAVES
                     const double lo = fmin(p.t, t1), hi = fmax(p.t, t1);
                     if (lo < a.win_lo || hi > a.win_hi) { paused = 1; break; }
                 }
-                if (tte > 0 && p.t + dtc == p.t) {
-                    // dt == 0 (or below the resolution of t) before endtime: the reference's while-loop would spin
-                    // forever (kernel.py:190); a GPU must not -- flag the particle instead
-                    c.state = PK_ERROR;
-                    break;
-                }
                 p.dt = dtc;
                 for (int k = 0; k < nk; k++) {  // :206-216
                     const int kid = KID >= 0 ? KID : prm.kernels[k];
@@ -465,6 +459,14 @@ __global__ void __launch_bounds__(256, (KIND == 1 || INTERP != 0) ? PK_MIN_WAVES
                     }
                 }
                 if (c.state == PK_EVALUATE || c.state == PK_SUCCESS) {  // :219-222 -> _position_update :108-120
+                    if (tte > 0 && p.t + p.dt == p.t) {
+                        // The step would not advance t before endtime (dt == 0 -- e.g. RK45 after a particle was released
+                        // exactly at an output time -- or below the resolution of t, after AdvectionRK45's own clamp to
+                        // RK45_min_dt): the reference's while-loop spins forever here (kernel.py:190).  A GPU must not:
+                        // flag the particle (StatusCode.Error) instead.
+                        c.state = PK_ERROR;
+                        break;
+                    }
                     p.x = padd(pf, p.x, p.dx);
                     p.y = padd(pf, p.y, p.dy);
                     p.z = padd(pf, p.z, p.dz);

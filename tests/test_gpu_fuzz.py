@@ -67,8 +67,7 @@ def draw_case(seed):
         case["dt"] = abs(case["dt"])
         backward = False
     if "AdvectionRK45" in case["kernels"]:
-        scale = 1.0 if mesh == "flat" else 1.0
-        case["context"] = {"RK45_tol": float(rng.choice([0.5, 50.0, 5000.0])) * scale, "RK45_min_dt": 10.0, "RK45_max_dt": 4 * 3600.0}
+        case["context"] = {"RK45_tol": float(rng.choice([0.5, 50.0, 5000.0])), "RK45_min_dt": 10.0, "RK45_max_dt": 4 * 3600.0}
         if rng.random() < 0.5:
             case["next_dt_dtype"] = "float32"
     if backward and case.get("time_s") is not None:
@@ -76,8 +75,6 @@ def draw_case(seed):
         case["dt"] = -abs(case["dt"])
     if rng.random() < 0.3 and kind != "diffusion":
         case["outputdt"] = float(abs(case["dt"]) * rng.choice([2.0, 2.5, 3.7]))
-    if not three_d and kind != "diffusion":
-        pass
     return case, bool(rng.random() < 0.5)
 
 
@@ -101,4 +98,7 @@ def test_random_configuration_matches_oracle(gpu, seed):
     label = f"seed {seed}: {case['kernels']} mesh={case['mesh']} lon{np.asarray(case['lon']).shape} dt={case['dt']} sort={sort_by_cell} " \
             f"outputdt={case.get('outputdt')} sdt={case.get('spatial_dtype')}"
     assert gerr == oerr, label
-    compare(got, ref, rtol=tolerance(case), check_state="all", label=label)
+    # positions near 0 (a longitude crossing the Greenwich meridian) carry the absolute rounding noise of the coordinate scale
+    tol = tolerance(case)
+    scale = float(max(np.nanmax(np.abs(case["lon"])), np.nanmax(np.abs(case["lat"]))))
+    compare(got, ref, rtol=tol, atol_pos=tol * scale, check_state="all", label=label)
