@@ -366,8 +366,41 @@ PK_DEV void spherical_project(const double cX[4], const double cY[4], const doub
     yq = q.qX * evx + q.qY * evy + q.qZ * evz;
 }
 
+// ---- Morton spatial hash query (spatialhash.py:389-535, 554-597, 647-765) ------------------------------
+PK_DEV uint32_t dilate_bits(uint32_t n) {
+    n &= 0x000003FFu;
+    n = (n | (n << 16)) & 0xFF0000FFu;
+    n = (n | (n << 8)) & 0x0300F00Fu;
+    n = (n | (n << 4)) & 0x030C30C3u;
+    n = (n | (n << 2)) & 0x09249249u;
+    return n;
+}
+PK_DEV uint32_t quantize(double v, double vmin, double vmax, int bitwidth) {
+    double d = vmax - vmin;
+    double vn = (d != 0) ? (v - vmin) / d : 0.0;
+    double q = vn * bitwidth;
+    if (!(q >= 0)) q = 0;  // also NaN (rejected by the finite mask anyway)
+    if (q > bitwidth) q = bitwidth;
+    return (uint32_t)q;
+}
+// quantised [min, max] of the four corner values of a face along one axis vs the quantised query coordinate
+PK_DEV bool in_quantised_box(const DGrid& g, const double c[4], double v, int axis2) {
+    const double lo = fmin(fmin(c[0], c[1]), fmin(c[2], c[3])), hi = fmax(fmax(c[0], c[1]), fmax(c[2], c[3]));
+    const uint32_t qv = quantize(v, g.h_bbox[axis2], g.h_bbox[axis2 + 1], g.h_bitwidth);
+    return quantize(lo, g.h_bbox[axis2], g.h_bbox[axis2 + 1], g.h_bitwidth) <= qv && qv <= quantize(hi, g.h_bbox[axis2], g.h_bbox[axis2 + 1], g.h_bitwidth);
+}
+PK_DEV uint32_t morton_code(const DGrid& g, const QPoint& q) {
+    return (dilate_bits(quantize(q.qZ, g.h_bbox[4], g.h_bbox[5], g.h_bitwidth)) << 2) |
+           (dilate_bits(quantize(q.qY, g.h_bbox[2], g.h_bbox[3], g.h_bitwidth)) << 1) |
+           dilate_bits(quantize(q.qX, g.h_bbox[0], g.h_bbox[1], g.h_bitwidth));
+}
+
 // curvilinear_point_in_cell (index_search.py:94-120); (yi, xi) must be a valid cell
-PK_DEV bool point_in_cell(const DGrid& g, const QPoint& q, int yi, int xi, double& xsi, double& eta, const CellCache* cc = nullptr) {
+// `listed` (optional): does the spatial-hash table list this face in the query's hash cell?  By construction of the table
+// (spatialhash.py:269-387: a face is entered into every hash cell its quantised corner box overlaps) that is the case iff
+// the query's quantised coordinates lie inside that box -- computed here from the corners already in registers.
+PK_DEV bool point_in_cell(const DGrid& g, const QPoint& q, int yi, int xi, double& xsi, double& eta, const CellCache* cc = nullptr,
+                          bool* listed = nullptr) {
     // node table rows: {lon, lat, X, Y, Z} of node (yi, xi) followed by node (yi, xi+1): 10 contiguous doubles
     const double* r0 = g.node_tab + ((int64_t)yi * g.nx + xi) * 5;
     const double* r1 = r0 + (int64_t)g.nx * 5;
@@ -399,6 +432,7 @@ PK_DEV bool point_in_cell(const DGrid& g, const QPoint& q, int yi, int xi, doubl
                 for (int k = 0; k < 4; k++) { PK_ND(k, 2) = cX[k]; PK_ND(k, 3) = cY[k]; PK_ND(k, 4) = cZ[k]; }
             }
         }
+        if (listed) *listed = in_quantised_box(g, cX, q.qX, 0) && in_quantised_box(g, cY, q.qY, 2) && in_quantised_box(g, cZ, q.qZ, 4);
         spherical_project(cX, cY, cZ, q, pu, pv, xq, yq);
         bilinear_inverse(pu, pv, xq, yq, xsi, eta);
     } else {
@@ -415,35 +449,13 @@ PK_DEV bool point_in_cell(const DGrid& g, const QPoint& q, int yi, int xi, doubl
                 for (int k = 0; k < 4; k++) { PK_ND(k, 0) = clon[k]; PK_ND(k, 1) = clat[k]; }
             }
         }
+        if (listed) *listed = in_quantised_box(g, clon, q.x, 0) && in_quantised_box(g, clat, q.y, 2);  // z is 0 for face and query
         bilinear_inverse(clon, clat, q.x, q.y, xsi, eta);
     }
 #undef PK_ND
     const bool inside = (xsi >= 0) && (xsi <= 1) && (eta >= 0) && (eta <= 1);
     if (use_cc && !hit && inside) cc->key[0] = cell;
     return inside;
-}
-
-// ---- Morton spatial hash query (spatialhash.py:389-535, 554-597, 647-765) ------------------------------
-PK_DEV uint32_t dilate_bits(uint32_t n) {
-    n &= 0x000003FFu;
-    n = (n | (n << 16)) & 0xFF0000FFu;
-    n = (n | (n << 8)) & 0x0300F00Fu;
-    n = (n | (n << 4)) & 0x030C30C3u;
-    n = (n | (n << 2)) & 0x09249249u;
-    return n;
-}
-PK_DEV uint32_t quantize(double v, double vmin, double vmax, int bitwidth) {
-    double d = vmax - vmin;
-    double vn = (d != 0) ? (v - vmin) / d : 0.0;
-    double q = vn * bitwidth;
-    if (!(q >= 0)) q = 0;  // also NaN (rejected by the finite mask anyway)
-    if (q > bitwidth) q = bitwidth;
-    return (uint32_t)q;
-}
-PK_DEV uint32_t morton_code(const DGrid& g, const QPoint& q) {
-    return (dilate_bits(quantize(q.qZ, g.h_bbox[4], g.h_bbox[5], g.h_bitwidth)) << 2) |
-           (dilate_bits(quantize(q.qY, g.h_bbox[2], g.h_bbox[3], g.h_bitwidth)) << 1) |
-           dilate_bits(quantize(q.qX, g.h_bbox[0], g.h_bbox[1], g.h_bitwidth));
 }
 
 // _search_indices_curvilinear_2d (index_search.py:242-295) + SpatialHash.query (spatialhash.py:389-535) for one point:
@@ -459,30 +471,31 @@ PK_DEV void curvilinear_search(const DGrid& g, double y, double x, bool use_gues
     const QPoint q = make_qpoint(g, y, x);
     const bool guess_ok = use_guess && gy >= 0 && gy < g.ny - 1 && gx >= 0 && gx < g.nx - 1;
     const uint32_t ncx = (uint32_t)(g.nx - 1);
-    int64_t s = 0, c = -1;  // CSR range of the hash cell, looked up lazily (c < 0: not yet)
+    int64_t s = 0, c = -1;  // CSR range of the query's hash cell, looked up lazily (c < 0: not yet)
+    auto lookup = [&]() {   // locate the query's Morton code in the key table (spatialhash.py:430-470)
+        c = 0;
+        if (isfinite(x) && isfinite(y) && g.h_nkeys > 0) {
+            const uint32_t code = morton_code(g, q);
+            int64_t lo = 0, hi = g.h_nkeys;
+            if (g.h_dir) {  // keys with the same top bits: a handful instead of all of them
+                const uint32_t b = code >> g.h_dir_shift;
+                lo = g.h_dir[b];
+                hi = g.h_dir[b + 1];
+            }
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (g.h_keys[mid] < code) lo = mid + 1; else hi = mid;
+            }
+            if (lo < g.h_nkeys && g.h_keys[lo] == code) { s = g.h_starts[lo]; c = g.h_counts[lo]; }
+        }
+    };
     for (int64_t k = guess_ok ? -1 : 0;; k++) {
         int j, i;
         if (k < 0) {
             j = gy;
             i = gx;
         } else {
-            if (c < 0) {  // first hash candidate: locate the query's Morton code in the key table
-                c = 0;
-                if (isfinite(x) && isfinite(y) && g.h_nkeys > 0) {
-                    const uint32_t code = morton_code(g, q);
-                    int64_t lo = 0, hi = g.h_nkeys;
-                    if (g.h_dir) {  // keys with the same top bits: a handful instead of all of them
-                        const uint32_t b = code >> g.h_dir_shift;
-                        lo = g.h_dir[b];
-                        hi = g.h_dir[b + 1];
-                    }
-                    while (lo < hi) {
-                        const int64_t mid = (lo + hi) >> 1;
-                        if (g.h_keys[mid] < code) lo = mid + 1; else hi = mid;
-                    }
-                    if (lo < g.h_nkeys && g.h_keys[lo] == code) { s = g.h_starts[lo]; c = g.h_counts[lo]; }
-                }
-            }
+            if (c < 0) lookup();
             if (k >= c) return;
             const uint32_t face = g.h_faces[s + k];
             j = (int)(face / ncx);
@@ -497,21 +510,27 @@ PK_DEV void curvilinear_search(const DGrid& g, double y, double x, bool use_gues
             return;
         }
         if (k < 0 && g.walk_ok) {
-            // The particle left the guessed cell.  On a mesh without coincident nodes (cells cannot overlap) exactly one cell
+            // The particle left the guessed cell.  On a mesh without coincident nodes (cells cannot overlap) at most one cell
             // holds it, almost always the neighbour the barycentric coordinates point at: test that one before walking the
-            // ~10-20 faces of the hash cell in table order.  Accepted only well inside (no tie with an adjacent cell, which
-            // the table order would have to break); the coordinates are rounded like a hash hit (spatialhash.py:505).
+            // ~10-20 faces of the hash cell in table order (one point-in-cell test + two dependent loads each).  Accepted only
+            // (a) well inside -- no tie with an adjacent cell, which the table order would have to break -- and (b) if that
+            // face is listed in the query's hash cell, because a face the table does not list there is one the reference
+            // cannot find (it answers GRID_SEARCH_ERROR: the xyz box of the four corners does not cover the whole curved
+            // cell).  The coordinates are rounded like a hash hit (spatialhash.py:505).
             const int dj = et < 0 ? -1 : (et > 1 ? 1 : 0), di = xs < 0 ? -1 : (xs > 1 ? 1 : 0);
             const int nj = gy + dj, ni = gx + di;
             if ((dj | di) != 0 && nj >= 0 && nj < g.ny - 1 && ni >= 0 && ni < g.nx - 1) {
                 double xs2, et2;
                 const double m = 1e-9;
-                if (point_in_cell(g, q, nj, ni, xs2, et2, cc) && xs2 > m && xs2 < 1 - m && et2 > m && et2 < 1 - m) {
-                    yi = nj;
-                    xi = ni;
-                    xsi = (double)(float)xs2;
-                    eta = (double)(float)et2;
-                    return;
+                bool listed = false;
+                if (point_in_cell(g, q, nj, ni, xs2, et2, cc, &listed) && xs2 > m && xs2 < 1 - m && et2 > m && et2 < 1 - m) {
+                    if (listed) {
+                        yi = nj;
+                        xi = ni;
+                        xsi = (double)(float)xs2;
+                        eta = (double)(float)et2;
+                        return;
+                    }
                 }
             }
         }
