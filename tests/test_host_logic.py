@@ -193,3 +193,32 @@ def test_nemo_to_sgrid_names_dims_offsets_and_w_sign():
     pa.FieldSet.from_sgrid_conventions(ds2, mesh="spherical")
     with pytest.raises(ValueError, match="glamf"):
         convert.nemo_to_sgrid(fields={}, coords=pa.Dataset({}, {"gphif": (("y", "x"), gphif)}))
+
+
+@pytest.mark.parametrize("mesh,nx,ny", [("spherical", 60, 45), ("flat", 60, 45), ("spherical", 24, 18)])
+def test_spatial_hash_build_equals_reference_on_masked_meshes(mesh, nx, ny):
+    """Warped meshes with NaN (masked) nodes, fine and coarse (bit width bisected): parcels_amd.spatialhash builds the table
+    the reference's SpatialHash builds (spatialhash.py:45-387), array for array.  The GPU build is compared with this one in
+    tests/test_gpu_parity.py.  Needs the reference tree (build container only)."""
+    from oracle import ref_shim as rs
+
+    if not rs.reference_available():
+        pytest.skip("the reference tree is not available on this machine")
+    from parcels_amd import spatialhash as sh
+
+    i = np.arange(nx, dtype=np.float64)[None, :] / (nx - 1)
+    j = np.arange(ny, dtype=np.float64)[:, None] / (ny - 1)
+    lon = -170.0 + 340.0 * i + 2.0 * np.sin(2 * np.pi * j) * (0.3 + i) + 3.0 * j
+    lat = -75.0 + 150.0 * j + 1.5 * np.sin(2 * np.pi * i) * (0.5 + 0.5 * j) - 2.0 * i
+    js, is_ = slice(ny // 5, ny // 5 + max(ny // 50, 1)), slice(nx // 5, nx // 5 + max(nx // 40, 1))
+    lon[js, is_] = np.nan
+    lat[js, is_] = np.nan
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = rs.make_ref_grid(lon=lon, lat=lat, depth=None, mesh=mesh).get_spatial_hash()
+        mine = sh.SpatialHash(lon, lat, mesh == "spherical").table()
+    assert int(ref._bitwidth) == mine["bitwidth"]
+    for k in ("keys", "starts", "counts", "faces"):
+        assert np.array_equal(np.asarray(ref._hash_table[k]).astype(mine[k].dtype), mine[k]), k
