@@ -336,3 +336,49 @@ def test_device_side_removal_of_deleted_particles(gpu, sort_by_cell):
     for oa, ob in zip(ra.obs, rb.obs):
         for u, v in zip(oa, ob):
             assert np.array_equal(u, v)
+
+
+def test_trajectory_independent_of_other_particles_release_times(gpu):
+    """tests/test_particleset_execute.py:48-95: U varies in time only (cos, 1-day period, 3-hourly levels); a particle's
+    trajectory must not depend on when its batch-mates were released."""
+    nt = 25
+    ds = simple_uv_dataset(dims=(nt, 2, 6, 6), mesh="flat")
+    times = 3.0 * 3600.0 * np.arange(nt)
+    ds["time"] = (("time",), times)
+    ds["U"].data[:] = np.cos(2 * np.pi * times / 86400.0)[:, None, None, None]
+    fs = pa.FieldSet.from_sgrid_conventions(ds, mesh="flat")
+
+    def run(release_times):
+        n = len(release_times)
+        pset = pa.ParticleSet(fs, pclass=pa.Particle, t=np.array(release_times, dtype=np.float64), z=np.zeros(n), y=np.zeros(n), x=np.zeros(n))
+        pset.execute(pa.AdvectionRK4, dt=np.timedelta64(1, "h"), endtime=np.timedelta64(48, "h"))
+        return pset.x[0], pset.y[0]
+
+    alone = run([0.0])
+    uniform = run([0.0] * 4)
+    staggered = run([0.0] + [3 * 3600.0] * 3)
+    assert uniform == alone and staggered == alone  # the reference asserts approx; per-particle lanes give equality
+    assert abs(alone[0]) < 1.0 and alone[1] == 0.0  # two full periods of the oscillation bring the particle back
+
+
+@pytest.mark.parametrize("kernel", ["AdvectionEE", "AdvectionRK2", "AdvectionRK4", "AdvectionRK45"])
+@pytest.mark.parametrize("dt_days", [10, 1])
+def test_run_rk_to_endtime_forward_and_backward(gpu, kernel, dt_days):
+    """tests/test_particleset_execute.py:207-232: the kernels can be run to the very end of the fieldset's time interval and
+    back to its start without raising OutsideTimeInterval (the sub-stages at t + dt/2, t + dt touch the last level exactly)."""
+    ds = simple_uv_dataset(mesh="flat")  # U = V = 0, 360 levels over 366 days
+    fs = pa.FieldSet.from_sgrid_conventions(ds, mesh="flat")
+    pclass = pa.Particle
+    if kernel == "AdvectionRK45":
+        fs.add_context("RK45_tol", 10)
+        fs.add_context("RK45_min_dt", 1)
+        fs.add_context("RK45_max_dt", 24 * 60 * 60)
+        pclass = pa.Particle.add_variable(pa.Variable("next_dt"))
+    T = 366 * 86400.0
+    pset = pa.ParticleSet(fs, pclass=pclass, x=[0.2], y=[5.0], t=[0.0])
+    k = getattr(pa.kernels, kernel)
+    pset.execute(k, endtime=T, dt=np.timedelta64(dt_days, "D"))
+    assert pset.t[0] == T
+    pset.execute(k, endtime=0.0, dt=-np.timedelta64(dt_days, "D"))
+    assert pset.t[0] == 0.0
+    assert pset.x[0] == np.float32(0.2) and pset.y[0] == np.float32(5.0)
