@@ -141,6 +141,9 @@ PK_DEV double cos_lat(double x) {
 struct GPos {
     int ti, zi, yi, xi;
     double tau, zeta, eta, xsi;
+    bool w32;  // xsi, eta are float32 ARRAYS in the reference: a curvilinear evaluation without any guess takes them straight from
+               // the hash query's float32 buffer (spatialhash.py:505), so NumPy forms every expression made of xsi, eta and
+               // Python scalars alone in float32 (1 - xsi, (1 - xsi) * (1 - eta), ...) before it meets float64 data
 };
 
 // Per-lane LDS cache of the curvilinear cell a particle sits in: its 4 corner nodes {lon, lat, X, Y, Z} and the raw
@@ -604,6 +607,7 @@ PK_DEV void grid_search(const DGrid& g, const Coords* mc, double z, double y, do
     const bool hint = mc != nullptr;
     if (g.has_z) search_1d(depth, g.nz, mc ? mc->z0 : g.depth[0], mc ? mc->z1 : g.depth[g.nz - 1], z, g.depth_f32, pos_f32, hint ? c.hz : 0, p.zi, p.zeta);
     else { p.zi = 0; p.zeta = 0.0; }
+    p.w32 = curv && !use_guess;
     if (curv) {
         int gy = 0, gx = 0;
         if (use_guess) {  // index_search.py:269-274
@@ -728,6 +732,13 @@ PK_DEV double xlinear(const DField& f, const Corners& k, const GPos& p) {
         for (int iy = 0; iy < 2; iy++)
 #pragma unroll
             for (int ix = 0; ix < 2; ix++) c[iy][ix] = c[iy][ix] * (1 - zeta) + c1[iy][ix] * zeta;
+    }
+    if (p.w32) {  // float32 xsi/eta arrays: the four weights are float32 products (_xinterpolators.py:146-151)
+        const float a = (float)xsi, b = (float)eta;
+        const float w00 = (1.0f - a) * (1.0f - b), w01 = a * (1.0f - b), w10 = (1.0f - a) * b, w11 = a * b;
+        if (sizeof(FT) == 4 && !k.lenT && !k.lenZ)  // float32 data untouched by a float64 lerp: the expression stays float32
+            return (double)(((w00 * (float)c[0][0] + w01 * (float)c[0][1]) + w10 * (float)c[1][0]) + w11 * (float)c[1][1]);
+        return (double)w00 * c[0][0] + (double)w01 * c[0][1] + (double)w10 * c[1][0] + (double)w11 * c[1][1];
     }
     return (1 - xsi) * (1 - eta) * c[0][0] + xsi * (1 - eta) * c[0][1] + (1 - xsi) * eta * c[1][0] + xsi * eta * c[1][1];
 }
@@ -881,13 +892,24 @@ PK_DEV void cgrid_velocity(const DGrid& g, const Coords* mc, const DField& U, co
                 if (-px[k] + px[0] > 180) px[k] = px[k] + 360;
         }
     }
-    // einsum("ij,ji->i", phi2D_lin(eta, xsi), py): products formed for all four corners, summed in corner order
-#define PK_PHI_DOT(e, x_) \
+    // einsum("ij,ji->i", phi2D_lin(eta, xsi), py): products formed for all four corners, summed in corner order.  With
+    // float32 xsi/eta arrays (p.w32) the phi entries and 1 - xsi, 1 - eta, eta - 1, xsi - 1 are float32 results.
+    const bool w32 = p.w32;
+    const float xf = (float)xsi, ef = (float)eta;
+    const double omx = w32 ? (double)(1.0f - xf) : 1 - xsi;
+    const double ome = w32 ? (double)(1.0f - ef) : 1 - eta;
+#define PK_PHI_DOT64(e, x_) \
     (((((1 - (x_)) * (1 - (e))) * py[0] + ((x_) * (1 - (e))) * py[1]) + ((x_) * (e)) * py[2]) + ((1 - (x_)) * (e)) * py[3])
+#define PK_PHI_DOT32(e, x_)                                                                                     \
+    (((((double)((1.0f - (x_)) * (1.0f - (e)))) * py[0] + ((double)((x_) * (1.0f - (e)))) * py[1]) +              \
+      ((double)((x_) * (e))) * py[2]) + ((double)((1.0f - (x_)) * (e))) * py[3])
+#define PK_PHI_DOT(e, x_) (w32 ? PK_PHI_DOT32((float)(e), (float)(x_)) : PK_PHI_DOT64(e, x_))
     const double c1 = geodetic_distance(g, py[0], py[1], px[0], px[1], PK_PHI_DOT(0.0, xsi), cf32);
     const double c2 = geodetic_distance(g, py[1], py[2], px[1], px[2], PK_PHI_DOT(eta, 1.0), cf32);
     const double c3 = geodetic_distance(g, py[2], py[3], px[2], px[3], PK_PHI_DOT(1.0, xsi), cf32);
     const double c4 = geodetic_distance(g, py[3], py[0], px[3], px[0], PK_PHI_DOT(eta, 0.0), cf32);
+#undef PK_PHI_DOT64
+#undef PK_PHI_DOT32
 #undef PK_PHI_DOT
     const int yi_o = clampi(yi + g.off_y, 0, ydim - 1), xi_1 = clampi(xi + 1, 0, xdim - 1);
     const int yi_1 = clampi(yi + 1, 0, ydim - 1), xi_o = clampi(xi + g.off_x, 0, xdim - 1);
@@ -945,22 +967,22 @@ PK_DEV void cgrid_velocity(const DGrid& g, const Coords* mc, const DField& U, co
     }
     const double ua = raw[0], ub = raw[1], va = raw[2], vb = raw[3];
     const double U0 = ua * c4, U1 = ub * c2;
-    const double Uvel = (1 - xsi) * U0 + xsi * U1;
+    const double Uvel = omx * U0 + xsi * U1;
     const double V0 = va * c1, V1 = vb * c3;
-    const double Vvel = (1 - eta) * V0 + eta * V1;
+    const double Vvel = ome * V0 + eta * V1;
     // _compute_jacobian_determinant (utils/interpolation.py:188-198)
-    const double dxs0 = eta - 1, dxs1 = 1 - eta, dxs2 = eta, dxs3 = -eta;
-    const double det0 = xsi - 1, det1 = -xsi, det2 = xsi, det3 = 1 - xsi;
+    const double dxs0 = w32 ? (double)(ef - 1.0f) : eta - 1, dxs1 = ome, dxs2 = eta, dxs3 = -eta;
+    const double det0 = w32 ? (double)(xf - 1.0f) : xsi - 1, det1 = -xsi, det2 = xsi, det3 = omx;
     const double dxdxsi = ((dxs0 * px[0] + dxs1 * px[1]) + dxs2 * px[2]) + dxs3 * px[3];
     const double dxdeta = ((det0 * px[0] + det1 * px[1]) + det2 * px[2]) + det3 * px[3];
     const double dydxsi = ((dxs0 * py[0] + dxs1 * py[1]) + dxs2 * py[2]) + dxs3 * py[3];
     const double dydeta = ((det0 * py[0] + det1 * py[1]) + det2 * py[2]) + det3 * py[3];
     double jac = dxdxsi * dydeta - dxdeta * dydxsi;
     if (g.spherical) jac = jac * g.deg2m;
-    const double A = -(1 - eta) * Uvel - (1 - xsi) * Vvel;
-    const double B = (1 - eta) * Uvel - xsi * Vvel;
+    const double A = -ome * Uvel - omx * Vvel;
+    const double B = ome * Uvel - xsi * Vvel;
     const double C = eta * Uvel + xsi * Vvel;
-    const double D = -eta * Uvel + (1 - xsi) * Vvel;
+    const double D = -eta * Uvel + omx * Vvel;
     double uu = (A * px[0] + B * px[1] + C * px[2] + D * px[3]) / jac;
     double vv = (A * py[0] + B * py[1] + C * py[2] + D * py[3]) / jac;
     if (g.spherical) {  // :311-314 (both components divided by deg2m*cos(lat))

@@ -85,8 +85,6 @@ def tolerance(case):
         return 2e-6
     if f32_part:
         return 5e-7
-    if np.asarray(case["lon"]).ndim == 2 and not case.get("populate"):
-        return 1e-7
     return 1e-10
 
 
