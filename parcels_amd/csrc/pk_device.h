@@ -144,7 +144,19 @@ struct GPos {
     bool w32;  // xsi, eta are float32 ARRAYS in the reference: a curvilinear evaluation without any guess takes them straight from
                // the hash query's float32 buffer (spatialhash.py:505), so NumPy forms every expression made of xsi, eta and
                // Python scalars alone in float32 (1 - xsi, (1 - xsi) * (1 - eta), ...) before it meets float64 data
+    bool x32, e32, z32;  // the bcoord ARRAY of that axis is float32 in the reference: w32, or a float32 coordinate searched with
+                         // float32 particle positions (index_search.py:51: f32 - f32 stays f32)
 };
+
+// NumPy dtype propagation for the expressions in which float32 arrays meet: float32 op float32 -> float32 (rounded),
+// anything with a float64 array -> float64; Python scalars adapt to the array.  (value, is-float32-array) pairs.
+struct TV {
+    double v;
+    bool f32;
+};
+PK_DEV TV tv_mul(TV a, TV b) { const bool f = a.f32 && b.f32; return TV{f ? (double)((float)a.v * (float)b.v) : a.v * b.v, f}; }
+PK_DEV TV tv_add(TV a, TV b) { const bool f = a.f32 && b.f32; return TV{f ? (double)((float)a.v + (float)b.v) : a.v + b.v, f}; }
+PK_DEV TV tv_one_minus(TV a) { return TV{a.f32 ? (double)(1.0f - (float)a.v) : 1 - a.v, a.f32}; }
 
 // Per-lane LDS cache of the curvilinear cell a particle sits in: its 4 corner nodes {lon, lat, X, Y, Z} and the raw
 // staggered field values of one C-grid evaluation at both time levels.  A particle moves a fraction of a cell per RK
@@ -608,6 +620,9 @@ PK_DEV void grid_search(const DGrid& g, const Coords* mc, double z, double y, do
     if (g.has_z) search_1d(depth, g.nz, mc ? mc->z0 : g.depth[0], mc ? mc->z1 : g.depth[g.nz - 1], z, g.depth_f32, pos_f32, hint ? c.hz : 0, p.zi, p.zeta);
     else { p.zi = 0; p.zeta = 0.0; }
     p.w32 = curv && !use_guess;
+    p.z32 = g.has_z && g.depth_f32 && pos_f32 && g.nz >= 2;
+    p.x32 = curv ? p.w32 : (g.has_x && g.lon_f32 && pos_f32 && g.nx >= 2);
+    p.e32 = curv ? p.w32 : (g.has_y && g.lat_f32 && pos_f32 && g.ny >= 2);
     if (curv) {
         int gy = 0, gx = 0;
         if (use_guess) {  // index_search.py:269-274
@@ -718,28 +733,42 @@ PK_DEV void xlinear_level(const FT* d0, const FT* d1, const Corners& k, int iz, 
 // The gather is issued in two batches (depth level z0, then z1) of up to 4 wide loads each: all 8 (16 scalar) loads at
 // once would hold ~64 VGPRs of data + addresses per field and cap the kernel at 2 waves/SIMD.
 template <class FT>
-PK_DEV double xlinear(const DField& f, const Corners& k, const GPos& p) {
+PK_DEV double xlinear(const DField& f, const Corners& k, const GPos& p, bool* out32 = nullptr) {
     const FT* d0 = (const FT*)f.data + k.ot0;
     const FT* d1 = (const FT*)f.data + k.ot1;
     const double tau = p.tau, zeta = p.zeta, xsi = p.xsi, eta = p.eta;
     double c[2][2];
     xlinear_level<FT>(d0, d1, k, 0, tau, c);
+    const bool typed = p.x32 || p.e32 || p.z32;  // some bcoord array is float32 in the reference (uniform across the wave)
+    const bool c32 = sizeof(FT) == 4 && !k.lenT;  // corner values are float32 data untouched by the float64 time lerp
     if (k.lenZ) {
         PK_FIELD_FENCE();
         double c1[2][2];
         xlinear_level<FT>(d0, d1, k, 1, tau, c1);
+        if (typed) {
+            const TV z = TV{zeta, p.z32}, omz = tv_one_minus(z);
 #pragma unroll
-        for (int iy = 0; iy < 2; iy++)
+            for (int iy = 0; iy < 2; iy++)
 #pragma unroll
-            for (int ix = 0; ix < 2; ix++) c[iy][ix] = c[iy][ix] * (1 - zeta) + c1[iy][ix] * zeta;
+                for (int ix = 0; ix < 2; ix++) c[iy][ix] = tv_add(tv_mul(TV{c[iy][ix], c32}, omz), tv_mul(TV{c1[iy][ix], c32}, z)).v;
+        } else {
+#pragma unroll
+            for (int iy = 0; iy < 2; iy++)
+#pragma unroll
+                for (int ix = 0; ix < 2; ix++) c[iy][ix] = c[iy][ix] * (1 - zeta) + c1[iy][ix] * zeta;
+        }
     }
-    if (p.w32) {  // float32 xsi/eta arrays: the four weights are float32 products (_xinterpolators.py:146-151)
-        const float a = (float)xsi, b = (float)eta;
-        const float w00 = (1.0f - a) * (1.0f - b), w01 = a * (1.0f - b), w10 = (1.0f - a) * b, w11 = a * b;
-        if (sizeof(FT) == 4 && !k.lenT && !k.lenZ)  // float32 data untouched by a float64 lerp: the expression stays float32
-            return (double)(((w00 * (float)c[0][0] + w01 * (float)c[0][1]) + w10 * (float)c[1][0]) + w11 * (float)c[1][1]);
-        return (double)w00 * c[0][0] + (double)w01 * c[0][1] + (double)w10 * c[1][0] + (double)w11 * c[1][1];
+    if (typed) {  // _xinterpolators.py:146-151 with NumPy's dtype propagation
+        const bool cz32 = c32 && (!k.lenZ || p.z32);
+        const TV x = TV{xsi, p.x32}, e = TV{eta, p.e32}, omx = tv_one_minus(x), ome = tv_one_minus(e);
+        TV r = tv_mul(tv_mul(omx, ome), TV{c[0][0], cz32});
+        r = tv_add(r, tv_mul(tv_mul(x, ome), TV{c[0][1], cz32}));
+        r = tv_add(r, tv_mul(tv_mul(omx, e), TV{c[1][0], cz32}));
+        r = tv_add(r, tv_mul(tv_mul(x, e), TV{c[1][1], cz32}));
+        if (out32) *out32 = r.f32;
+        return r.v;
     }
+    if (out32) *out32 = false;
     return (1 - xsi) * (1 - eta) * c[0][0] + xsi * (1 - eta) * c[0][1] + (1 - xsi) * eta * c[1][0] + xsi * eta * c[1][1];
 }
 template <class FT>
@@ -1110,17 +1139,20 @@ PK_DEV void eval_uvw(const KArgs& a, const Coords& mc, PCtx& c, bool want_w, dou
             slip_velocity<FT>(g, U, V, W, p, y, pos_f32, freeslip ? 1.0 : 0.5, freeslip ? 0.0 : 0.5, uu, vv, ww);
         } else {  // XLinear_Velocity.interp (_xinterpolators.py:169-190)
             const Corners k = make_corners(U, p);
-            uu = xlinear<FT>(U, k, p);
+            bool u32 = false, v32 = false;
+            uu = xlinear<FT>(U, k, p, &u32);
             PK_FIELD_FENCE();
-            vv = same_layout(U, V) ? xlinear<FT>(V, k, p) : xlinear<FT>(V, p);
+            vv = same_layout(U, V) ? xlinear<FT>(V, k, p, &v32) : xlinear<FT>(V, make_corners(V, p), p, &v32);
             PK_FIELD_FENCE();
             if (W) ww = same_layout(U, *W) ? xlinear<FT>(*W, k, p) : xlinear<FT>(*W, p);
-            if (g.spherical) {
+            if (g.spherical) {  // in-place /= : a float32 u / v array is divided and stored in float32
                 double conv;
                 if (pos_f32) conv = (double)((float)g.deg2m * cosf((float)y * DEG2RADF));
                 else conv = g.deg2m * cos_lat(y * DEG2RAD);
-                uu /= conv;
-                vv /= g.deg2m;
+                if (u32) uu = pos_f32 ? (double)((float)uu / (float)conv) : (double)(float)(uu / conv);
+                else uu /= conv;
+                if (v32) vv = (double)((float)vv / (float)g.deg2m);
+                else vv /= g.deg2m;
             }
         }
     }
