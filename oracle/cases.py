@@ -397,6 +397,35 @@ def curv_cgrid_case(name, *, mesh, kernels, seed=0, nx=40, ny=30, nz=5, nt=3, np
     )
 
 
+def curv_cgrid_diffusion_case(name, *, mesh, kernels, seed=0, npart=300, spatial_dtype="float64", kh="node4d", dt=1800.0,
+                              runtime=None, nx=40, ny=30, field_dtype=np.float32, kh_dtype=np.float32):
+    """BASELINE config 5 in small: AdvectionDiffusionM1 / EM (and RK45 lists) on the 3-D curvilinear C-grid, U/V/W staggered,
+    Kh_zonal / Kh_meridional with a tanh profile (tests/test_diffusion.py:60-67) living on the NODES of the same grid and
+    sampled with XLinear -- either full (time, depth, YG, XG) arrays or 2-D (YG, XG) ones like tools/bench_configs.py."""
+    case = curv_cgrid_case(name, mesh=mesh, kernels=kernels, seed=seed, nx=nx, ny=ny, npart=npart, field_dtype=field_dtype,
+                           spatial_dtype=spatial_dtype, with_w=True, dt=dt, runtime=runtime, vel=0.3, cgrid=True)
+    nt, nz = case["fields"]["U"].shape[:2]
+    ii = (np.arange(nx)[None, :] / (nx - 1)) * np.ones((ny, 1))
+    jj = (np.arange(ny)[:, None] / (ny - 1)) * np.ones((1, nx))
+    scale = 100.0 if mesh == "spherical" else 10.0
+    khz = (scale * (1.0 + 0.5 * np.tanh(3 * (2 * ii - 1)))).astype(kh_dtype)
+    khm = (scale * (1.0 + 0.3 * np.tanh(2 * (2 * jj - 1)))).astype(kh_dtype)
+    if kh == "node4d":
+        tz = (1.0 + 0.1 * np.arange(nt))[:, None, None, None] * (1.0 - 0.05 * np.arange(nz))[None, :, None, None]
+        case["fields"]["Kh_zonal"] = (tz * khz[None, None]).astype(kh_dtype)
+        case["fields"]["Kh_meridional"] = (tz * khm[None, None]).astype(kh_dtype)
+        case["field_dims"]["Kh_zonal"] = TZYX_NODE
+        case["field_dims"]["Kh_meridional"] = TZYX_NODE
+    else:
+        case["fields"]["Kh_zonal"] = khz[None, None]
+        case["fields"]["Kh_meridional"] = khm[None, None]
+        case["field_dims"]["Kh_zonal"] = ("mockT", "mockZ", "YG", "XG")
+        case["field_dims"]["Kh_meridional"] = ("mockT", "mockZ", "YG", "XG")
+    case["context"] = {"dres": 0.01 if mesh == "spherical" else 100.0}
+    case["seed"] = 4321 + seed
+    return case
+
+
 def diffusion_case(name, *, mesh, kernels, seed=0, npart=200, const_kh=None, spatial_dtype="float64", dt=600.0,
                    runtime=6 * 3600.0):
     """Kh fields like tests/test_diffusion.py:49-78 (tanh profile) or constant Kh (:19-46)."""
@@ -616,6 +645,34 @@ def all_cases() -> dict:
     add(diffusion_case("diff_m1_constkh_flat", mesh="flat", kernels=["AdvectionDiffusionM1"], seed=45, const_kh=5.0))
     add(diffusion_case("diff_m1_sph_f32part", mesh="spherical", kernels=["AdvectionDiffusionM1"], seed=46,
                        spatial_dtype="float32"))
+
+    # --- BASELINE config 5: stochastic + adaptive kernels on the 3-D curvilinear C-grid -------------------------------
+    add(curv_cgrid_diffusion_case("cgrid_curv_sph_m1", mesh="spherical", kernels=["AdvectionDiffusionM1", "DeleteParticle"], seed=71))
+    add(curv_cgrid_diffusion_case("cgrid_curv_flat_m1", mesh="flat", kernels=["AdvectionDiffusionM1", "DeleteParticle"], seed=72))
+    add(curv_cgrid_diffusion_case("cgrid_curv_sph_m1_kh2d", mesh="spherical", kernels=["AdvectionDiffusionM1", "DeleteParticle"], seed=73,
+                                  kh="2d"))
+    add(curv_cgrid_diffusion_case("cgrid_curv_sph_m1_f32part", mesh="spherical", kernels=["AdvectionDiffusionM1", "DeleteParticle"],
+                                  seed=74, spatial_dtype="float32"))
+    add(curv_cgrid_diffusion_case("cgrid_curv_sph_em", mesh="spherical", kernels=["AdvectionDiffusionEM", "DeleteParticle"], seed=75,
+                                  kh_dtype=np.float64, field_dtype=np.float64))
+    pc = dict(curv_cgrid_diffusion_case("cgrid_curv_sph_m1_populated", mesh="spherical", kernels=["AdvectionDiffusionM1", "DeleteParticle"],
+                                        seed=76))
+    pc["populate"] = True
+    add(pc)
+    rc = curv_cgrid_case("cgrid_curv_sph_rk45_w", mesh="spherical", kernels=["AdvectionRK45", "DeleteParticle"], seed=77, with_w=True,
+                         runtime=8 * 3600.0)
+    rc["context"] = {"RK45_tol": 10.0, "RK45_min_dt": 1.0, "RK45_max_dt": 86400.0}  # kernel.py:137-159 defaults, as in config 5
+    rc["populate"] = True
+    add(rc)
+    rc = curv_cgrid_case("cgrid_curv_flat_rk45_f32part", mesh="flat", kernels=["AdvectionRK45", "DeleteParticle"], seed=78, with_w=True,
+                         runtime=8 * 3600.0, spatial_dtype="float32")
+    rc["context"] = {"RK45_tol": 0.5, "RK45_min_dt": 10.0, "RK45_max_dt": 7200.0}
+    add(rc)
+    rc = curv_cgrid_case("cgrid_curv_sph_rk45_f32part", mesh="spherical", kernels=["AdvectionRK45", "DeleteParticle"], seed=79, with_w=True,
+                         runtime=8 * 3600.0, spatial_dtype="float32")
+    rc["context"] = {"RK45_tol": 50.0, "RK45_min_dt": 10.0, "RK45_max_dt": 7200.0}
+    rc["next_dt_dtype"] = "float32"
+    add(rc)
     # --- non-finite release positions (tests/test_spatialhash.py:50-56: NaN/inf -> GRID_SEARCH_ERROR) ---------------
     for nm, base, kern in (("agrid_sph_rk4_nonfinite", "agrid_sph_rk4_f64", ["AdvectionRK4", "DeleteParticle"]),
                            ("cgrid_curv_sph_rk4_nonfinite", "cgrid_curv_sph_rk4_3d", ["AdvectionRK4_3D", "DeleteParticle"])):

@@ -26,7 +26,7 @@ def draw_case(seed):
     from oracle import cases
 
     rng = np.random.default_rng(1000 + seed)
-    kind = rng.choice(["agrid", "agrid", "cgrid", "curv_c", "curv_a", "diffusion"])
+    kind = rng.choice(["agrid", "agrid", "cgrid", "curv_c", "curv_a", "diffusion", "curv_diffusion", "slip"])
     mesh = str(rng.choice(["spherical", "flat"]))
     backward = bool(rng.random() < 0.25)
     npart = int(rng.integers(200, 1500))
@@ -60,6 +60,19 @@ def draw_case(seed):
                                      field_dtype=fdt, spatial_dtype=sdt, with_w=True, dt=dt, runtime=nsteps * abs(dt),
                                      vel=float(rng.choice([0.3, 1.0, 3.0])), cgrid=(kind == "curv_c"))
         case["populate"] = bool(rng.random() < 0.5)
+    elif kind == "curv_diffusion":  # BASELINE config 5: Milstein / Euler-Maruyama on the 3-D curvilinear C-grid, Kh on its nodes
+        dk = str(rng.choice(["AdvectionDiffusionM1", "AdvectionDiffusionM1", "AdvectionDiffusionEM"]))
+        case = cases.curv_cgrid_diffusion_case(f"fuzz{seed}", mesh=mesh, kernels=[dk] + ([rec] if rec in ("DeleteParticle", "DeleteOutOfBounds") else []),
+                                               seed=int(seed), npart=npart, spatial_dtype=sdt, kh=str(rng.choice(["node4d", "2d"])),
+                                               nx=int(rng.integers(20, 60)), ny=int(rng.integers(16, 45)), field_dtype=fdt,
+                                               kh_dtype=np.float32 if rng.random() < 0.5 else np.float64, dt=abs(dt), runtime=nsteps * abs(dt))
+        case["populate"] = bool(rng.random() < 0.5)
+        backward = False
+    elif kind == "slip":  # XFreeslip / XPartialslip around land blocks
+        k2 = [str(rng.choice(["AdvectionRK4_3D", "AdvectionRK2_3D"] if three_d else ["AdvectionEE", "AdvectionRK2", "AdvectionRK4"]))]
+        case = cases.slip_case(f"fuzz{seed}", slip=str(rng.choice(["free", "partial"])), mesh=mesh, kernels=k2 + (["DeleteParticle"] if three_d else []),
+                               seed=int(seed), with_w=three_d, npart=npart, spatial_dtype=sdt, field_dtype=fdt)
+        case["dt"], case["runtime"] = dt, nsteps * abs(dt)
     else:
         dk = str(rng.choice(["AdvectionDiffusionM1", "AdvectionDiffusionEM"]))
         case = cases.diffusion_case(f"fuzz{seed}", mesh=mesh, kernels=[dk] + ([rec] if rec in ("DeleteParticle", "DeleteOutOfBounds") else []),
@@ -73,7 +86,7 @@ def draw_case(seed):
     if backward and case.get("time_s") is not None:
         case["t0"] = np.full(len(case["x"]), float(case["time_s"][-1]))
         case["dt"] = -abs(case["dt"])
-    if rng.random() < 0.3 and kind != "diffusion":
+    if rng.random() < 0.3 and kind not in ("diffusion", "curv_diffusion"):
         case["outputdt"] = float(abs(case["dt"]) * rng.choice([2.0, 2.5, 3.7]))
     return case, bool(rng.random() < 0.5)
 
