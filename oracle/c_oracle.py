@@ -126,6 +126,9 @@ class PoParams(C.Structure):
         ("fKhz", C.c_int32),
         ("fKhm", C.c_int32),
         ("next_dt_f32", C.c_int32),
+        ("force_lent", C.c_int32),
+        ("force_lenz", C.c_int32),
+        ("pad2", C.c_int32),
         ("endtime", C.c_double),
         ("dt0", C.c_double),
         ("rk45_tol", C.c_double),

@@ -490,11 +490,12 @@ def diffusion_case(name, *, mesh, kernels, seed=0, npart=200, const_kh=None, spa
     )
 
 
-def slip_case(name, *, slip, mesh, kernels, seed=0, with_w=False, npart=300, spatial_dtype="float64", field_dtype=np.float64):
+def slip_case(name, *, slip, mesh, kernels, seed=0, with_w=False, npart=300, spatial_dtype="float64", field_dtype=np.float64,
+              coord_dtype=np.float64):
     """A-grid flow around rectangular "land" blocks (U = V = 0 there) sampled with XFreeslip / XPartialslip
     (tests/test_interpolation.py:119-154 pattern, turned into an advection run)."""
     case = rect_agrid_case(name, mesh=mesh, kernels=kernels, seed=seed, nx=30, ny=20, nz=4, nt=3, npart=npart, with_w=with_w,
-                           spatial_dtype=spatial_dtype, field_dtype=field_dtype, runtime=20 * 3600.0, wscale=0.002)
+                           spatial_dtype=spatial_dtype, field_dtype=field_dtype, coord_dtype=coord_dtype, runtime=20 * 3600.0, wscale=0.002)
     rng = _rng(1000 + seed)
     land = np.zeros((20, 30), bool)
     for _ in range(14):
@@ -507,7 +508,26 @@ def slip_case(name, *, slip, mesh, kernels, seed=0, with_w=False, npart=300, spa
     return case
 
 
-def sample_case(name, *, interp, mesh="flat", seed=0, npts=400, field_dtype=np.float64, zpad="both", uniform_batch=None):
+def slip_curv_case(name, *, slip, mesh, kernels, seed=0, with_w=False, npart=300, spatial_dtype="float64", field_dtype=np.float64,
+                   populate=False):
+    """XFreeslip / XPartialslip on a CURVILINEAR A-grid with land blocks.  Unpopulated, the first evaluation of the reference
+    carries float32 xsi / eta arrays (spatialhash.py:505): f_u = ones_like(xsi) and the slip factors are float32 then."""
+    case = curv_cgrid_case(name, mesh=mesh, kernels=kernels, seed=seed, nx=30, ny=20, nz=4, nt=3, npart=npart, field_dtype=field_dtype,
+                           spatial_dtype=spatial_dtype, with_w=with_w, dt=1800.0, runtime=12 * 3600.0, vel=0.3, cgrid=False)
+    rng = _rng(2000 + seed)
+    land = np.zeros((20, 30), bool)
+    for _ in range(16):
+        j, i = rng.integers(1, 17), rng.integers(1, 26)
+        land[j : j + rng.integers(1, 4), i : i + rng.integers(1, 5)] = True
+    for f in case["fields"].values():
+        f[:, :, land] = 0.0
+        f[:, 2:, land | np.roll(land, 1, axis=1)] = 0.0
+    case["slip"] = slip
+    case["populate"] = populate
+    return case
+
+
+def sample_case(name, *, interp, mesh="flat", seed=0, npts=400, field_dtype=np.float64, zpad="both", uniform_batch=None, curv=False):
     """Field.eval of a scalar field P with one of the scalar interpolators at explicit points (no particles):
     random interior points, exact node hits, points on land blocks (zeros) and points outside the domain."""
     rng = _rng(seed)
@@ -531,6 +551,18 @@ def sample_case(name, *, interp, mesh="flat", seed=0, npts=400, field_dtype=np.f
     t[2 * k : 3 * k] = time_s[rng.integers(0, nt, k)]
     x[3 * k : 3 * k + 6] = lon[-1] + 0.5          # out of bounds (-> 0)
     y[3 * k + 6 : 3 * k + 12] = lat[0] - 0.5
+    if curv:  # the same logical mesh, smoothly warped: Field.eval has no `ei` guess, so xsi / eta come back as float32 arrays
+        lon2, lat2 = curvilinear_grid(nx, ny, mesh=mesh, seed=seed)
+        ci, cj = rng.uniform(0.02, 0.98, npts) * (nx - 1), rng.uniform(0.02, 0.98, npts) * (ny - 1)
+        if mesh == "flat":  # exact nodes (on a spherical mesh the tangent-plane test of a node hit is decided by the last bit of sin/cos)
+            ci[:k], cj[:k] = np.round(ci[:k]), np.round(cj[:k])
+        i0, j0 = np.minimum(ci.astype(int), nx - 2), np.minimum(cj.astype(int), ny - 2)
+        fi, fj = ci - i0, cj - j0
+        blend = lambda a: (a[j0, i0] * (1 - fi) * (1 - fj) + a[j0, i0 + 1] * fi * (1 - fj) + a[j0 + 1, i0] * (1 - fi) * fj  # noqa: E731
+                           + a[j0 + 1, i0 + 1] * fi * fj)
+        x, y = blend(lon2), blend(lat2)
+        x[3 * k : 3 * k + 6] = lon2.max() + 5.0  # outside the mesh
+        lon, lat = lon2, lat2
     if uniform_batch == "interior":
         # XLinearInvdistLandTracer weights ALL gathered corners alike, so its value depends on the batch-global lenT/lenZ
         # (_xinterpolators.py:575-576); keep the batch uniform: no particle exactly on the first time level / depth
@@ -673,6 +705,28 @@ def all_cases() -> dict:
     rc["context"] = {"RK45_tol": 50.0, "RK45_min_dt": 10.0, "RK45_max_dt": 7200.0}
     rc["next_dt_dtype"] = "float32"
     add(rc)
+
+    # --- float32 ARRAYS meeting in the slip interpolators, XLinearInvdistLandTracer and AdvectionRK45 -----
+    add(slip_curv_case("slip_free_curv_sph_f32", slip="free", mesh="spherical", kernels=["AdvectionRK4", "DeleteParticle"], seed=81,
+                       spatial_dtype="float32", field_dtype=np.float32))
+    add(slip_curv_case("slip_partial_curv_flat_3d", slip="partial", mesh="flat", kernels=["AdvectionRK4_3D", "DeleteParticle"], seed=82,
+                       with_w=True))
+    add(slip_curv_case("slip_partial_curv_sph_ee", slip="partial", mesh="spherical", kernels=["AdvectionEE", "DeleteParticle"], seed=83,
+                       field_dtype=np.float32))
+    add(slip_case("slip_partial_sph_f32all_3d", slip="partial", mesh="spherical", kernels=["AdvectionRK4_3D", "DeleteParticle"], seed=84,
+                  with_w=True, spatial_dtype="float32", field_dtype=np.float32, coord_dtype=np.float32))
+    add(slip_case("slip_free_flat_f32all_ee", slip="free", mesh="flat", kernels=["AdvectionEE"], seed=85, spatial_dtype="float32",
+                  field_dtype=np.float32, coord_dtype=np.float32))
+    add(sample_case("sample_invdist_land_mixed", interp="XLinearInvdistLandTracer", seed=67))  # nodes at t = 0 and z = 0 among interior points
+    add(sample_case("sample_invdist_land_curv_f32", interp="XLinearInvdistLandTracer", seed=68, field_dtype=np.float32, mesh="spherical",
+                    curv=True))
+    add(sample_case("sample_xlinear_curv_f32", interp="XLinear", seed=69, field_dtype=np.float32, mesh="flat", curv=True))
+    add(peninsula_case("peninsula_A_flat_rk45", mesh="flat", grid_type="A", kernels=("AdvectionRK45",), runtime=6 * 3600.0))
+    c["peninsula_A_flat_rk45"]["context"] = {"RK45_tol": 1.0, "RK45_min_dt": 10.0, "RK45_max_dt": 3600.0}
+    add(stommel_case("stommel_A_rk45", grid_type="A", kernels=("AdvectionRK45",), runtime=5 * 86400.0))
+    c["stommel_A_rk45"]["context"] = {"RK45_tol": 100.0, "RK45_min_dt": 60.0, "RK45_max_dt": 86400.0}
+    add(peninsula_case("peninsula_C_spherical_rk45", mesh="spherical", grid_type="C", kernels=("AdvectionRK45",), runtime=6 * 3600.0))
+    c["peninsula_C_spherical_rk45"]["context"] = {"RK45_tol": 1.0, "RK45_min_dt": 10.0, "RK45_max_dt": 3600.0}
     # --- non-finite release positions (tests/test_spatialhash.py:50-56: NaN/inf -> GRID_SEARCH_ERROR) ---------------
     for nm, base, kern in (("agrid_sph_rk4_nonfinite", "agrid_sph_rk4_f64", ["AdvectionRK4", "DeleteParticle"]),
                            ("cgrid_curv_sph_rk4_nonfinite", "cgrid_curv_sph_rk4_3d", ["AdvectionRK4_3D", "DeleteParticle"])):
