@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PK_ABI_VERSION 1
+#define PK_ABI_VERSION 2
 #define PK_MAX_GRIDS 4
 #define PK_MAX_FIELDS 8
 #define PK_MAX_KERNELS 8
@@ -222,6 +222,10 @@ typedef struct pk_exec_params {
     int32_t fU, fV, fW, fKh_zonal, fKh_meridional; /* field ids, -1 if absent                       */
     int32_t sort_by_cell; /* 1: reorder device rows by cell key before stepping (row order on the
                               host is unaffected)                                                  */
+    int32_t force_lent, force_lenz; /* lenT / lenZ of XLinearInvdistLandTracer and the slip interpolators, which the reference takes over
+                            the WHOLE batch (`2 if np.any(tau > 0) else 1`, _xinterpolators.py:130-131,401-402,575-576) and which
+                            change values there: 0 = per particle (pk_execute: a fused multi-step launch has no batch), 1 / 2 =
+                            that value for every particle.  pk_eval (one call == one batch) fills them in itself.            */
     int32_t next_dt_f32; /* the particle class declares next_dt as float32 (the default dtype of Variable, particle.py:36-60;
                             tests/utils.py:24-25): AdvectionRK45's store into it rounds to f32, and `dt = next_dt`
                             (kernel.py:118-120) then carries the rounded value.  The bound column itself stays f64.   */

@@ -13,6 +13,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PARCELS_HIP_LIB", os.path.join(_HERE, "libparcels_hip.so"))  # override: A/B builds
 
+PK_ABI_VERSION = 2
 PK_F32, PK_F64 = 0, 1
 PK_MAX_GRIDS, PK_MAX_FIELDS, PK_MAX_KERNELS, PK_NUM_STATE_CODES = 4, 8, 8, 80
 COLUMN_BITS = {n: 1 << i for i, n in enumerate(
@@ -129,6 +130,8 @@ class ExecParams(C.Structure):
         ("fKh_zonal", C.c_int32),
         ("fKh_meridional", C.c_int32),
         ("sort_by_cell", C.c_int32),
+        ("force_lent", C.c_int32),
+        ("force_lenz", C.c_int32),
         ("next_dt_f32", C.c_int32),
         ("endtime", C.c_double),
         ("dt0", C.c_double),
@@ -237,8 +240,8 @@ def load():
     lib.pk_eval.argtypes = [C.c_void_p, C.POINTER(ExecParams), C.c_int32, C.c_int64] + [C.c_void_p] * 8
     lib.pk_search.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pk_measure_copy_bandwidth.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_double)]
-    if lib.pk_abi_version() != 1:
-        raise HipLibraryError(f"ABI version mismatch: library {lib.pk_abi_version()}, binding 1")
+    if lib.pk_abi_version() != PK_ABI_VERSION:
+        raise HipLibraryError(f"ABI version mismatch: library {lib.pk_abi_version()}, binding {PK_ABI_VERSION}")
     _lib = lib
     return lib
 

@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(256) summarize_kernel(const int32_t* state, co
 }
 
 // Field.eval / VectorField.eval at explicit points (no particles): what >= 0 scalar field, -1 UV, -2 UVW
-template <class FT, int INTERP>
+template <class FT, int INTERP, bool TYPED>
 __global__ void __launch_bounds__(256) eval_kernel(const KArgs a, int what, int64_t m, const double* t, const double* z,
                                                    const double* y, const double* x, double* ou, double* ov, double* ow,
                                                    int32_t* ost) {
@@ -156,17 +156,35 @@ __global__ void __launch_bounds__(256) eval_kernel(const KArgs a, int what, int6
     c.hz = c.hy = c.hx = c.ht = 0;
     c.hyx_valid = false;
     c.first_eval = 0xFu;
+    c.u32 = c.v32 = false;
     c.ei0 = c.ei1 = c.ei2 = c.ei3 = 0;
     if (what < 0) {
         double u, v, w;
-        eval_uvw<FT, -1, INTERP>(a, mc, c, what == -2, t[i], z[i], y[i], x[i], false, u, v, w);
+        eval_uvw<FT, -1, INTERP, TYPED>(a, mc, c, what == -2, t[i], z[i], y[i], x[i], false, u, v, w);
         ou[i] = u;
         if (ov) ov[i] = v;
         if (ow) ow[i] = w;
     } else {
-        ou[i] = eval_scalar<FT>(a, mc, c, what, t[i], z[i], y[i], x[i], false);
+        ou[i] = eval_scalar<FT, TYPED>(a, mc, c, what, t[i], z[i], y[i], x[i], false);
     }
     if (ost) ost[i] = c.state;
+}
+
+// One pk_eval call is one batch of the reference: lenT = 2 if np.any(tau > 0) else 1, lenZ likewise over the WHOLE batch
+// (_xinterpolators.py:130-131,401-402,575-576).  flags: bit 0 any(tau > 0), bit 1 any(zeta > 0).
+__global__ void __launch_bounds__(256) batch_len_kernel(const DField f, const DGrid g, int64_t m, const double* t, const double* z, unsigned* flags) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned fl = 0;
+    if (i < m) {
+        GPos p;
+        if (time_search(f, f.time, t[i], 0, p) && p.tau > 0) fl |= 1u;
+        if (g.has_z) {
+            search_1d(g.depth, g.nz, g.depth[0], g.depth[g.nz - 1], z[i], g.depth_f32 != 0, false, 0, p.zi, p.zeta);
+            if (p.zeta > 0) fl |= 2u;
+        }
+    }
+    if (__any(fl & 1u) && (threadIdx.x & 63) == 0) atomicOr(flags, 1u);
+    if (__any(fl & 2u) && (threadIdx.x & 63) == 0) atomicOr(flags, 2u);
 }
 
 // XGrid.search + ravel_index without a guess (ParticleSet.populate_indices, particleset.py:252-262)
@@ -181,7 +199,7 @@ __global__ void __launch_bounds__(256) search_kernel(const DGrid g, int64_t m, c
     c.hyx_valid = false;
     GPos p;
     int32_t ei = 0;
-    grid_search<-1>(g, nullptr, z[i], y[i], x[i], false, &ei, c, false, p);
+    grid_search<-1, false>(g, nullptr, z[i], y[i], x[i], false, &ei, c, false, p);  // indices only: dtype emulation of the bcoords is irrelevant
     ei_out[i] = ei;
 }
 
@@ -960,6 +978,14 @@ int32_t pk_particles_compact(pk_ctx* ctx, const pk_particles_desc* new_host, int
 }
 
 // ---- execution -----------------------------------------------------------------------------------------
+// Some grid stores a coordinate as float32: NumPy's float32 arithmetic on coordinate / barycentric arrays has to be reproduced
+// (pk_device.h: TYPED), which only the PROG_TYPED program and the typed sampling kernels carry.
+static bool ctx_is_typed(const pk_ctx* ctx) {
+    for (const HostGrid& g : ctx->grids)
+        if (g.d.lon_f32 || g.d.lat_f32 || g.d.depth_f32) return true;
+    return false;
+}
+
 static int32_t fill_args(pk_ctx* ctx, const pk_exec_params* prm, KArgs& a, size_t& lds_bytes, int& use_lds) {
     memset(&a, 0, sizeof(a));
     for (size_t g = 0; g < ctx->grids.size(); g++) a.grids[g] = ctx->grids[g].d;
@@ -1068,6 +1094,7 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
             if (prm->kernels[0] == PK_KERNEL_ADVECTION_RK45 && !ctx->no_special) prog = PROG_RK45;
             if (prm->kernels[0] == PK_KERNEL_ADVECTIONDIFFUSION_M1 && !ctx->no_special) prog = PROG_M1;
         }
+        if (ctx_is_typed(ctx)) prog = PROG_TYPED;
         if (prm->sort_by_cell) {
             PK_HIP(ctx, hipEventRecord(ctx->ev2, ctx->compute));
             // curvilinear sort order (measured on the NEMO-size grid): depth-major for 3-D advection (+4 %), horizontal-major
@@ -1087,6 +1114,7 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
             case PROG_RK4_3D: launch_program<PROG_RK4_3D>(field_f32, curv, prm->interp_uv, use_lds, a, grid, lds_bytes, ctx->compute); break;
             case PROG_RK45: launch_program<PROG_RK45>(field_f32, curv, prm->interp_uv, use_lds, a, grid, lds_bytes, ctx->compute); break;
             case PROG_M1: launch_program<PROG_M1>(field_f32, curv, prm->interp_uv, use_lds, a, grid, lds_bytes, ctx->compute); break;
+            case PROG_TYPED: launch_program<PROG_TYPED>(field_f32, curv, prm->interp_uv, use_lds, a, grid, lds_bytes, ctx->compute); break;
             default: launch_program<PROG_GENERIC>(field_f32, curv, prm->interp_uv, use_lds, a, grid, lds_bytes, ctx->compute); break;
         }
         PK_HIP(ctx, hipGetLastError());
@@ -1180,13 +1208,26 @@ int32_t pk_eval(pk_ctx* ctx, const pk_exec_params* prm, int32_t what, int64_t m,
     const dim3 grid((unsigned)((m + 255) / 256));
     const int fsel = what >= 0 ? what : p2.fU;
     const bool f32 = ctx->fields[fsel].d.dtype == PK_F32;
-#define PK_EVAL(FT, IN) hipLaunchKernelGGL((eval_kernel<FT, IN>), grid, dim3(256), 0, ctx->compute, a, what, m, dt_, dz, dy, dx, du, dv, dw, ds)
+    if ((what >= 0 && ctx->fields[fsel].d.is_const == 4) || (what < 0 && p2.interp_uv >= 2)) {  // batch-global lenT / lenZ
+        unsigned* dflags = (unsigned*)ds;  // reused as the state output afterwards
+        PK_HIP(ctx, hipMemsetAsync(dflags, 0, sizeof(unsigned), ctx->compute));
+        hipLaunchKernelGGL(batch_len_kernel, grid, dim3(256), 0, ctx->compute, ctx->fields[fsel].d, ctx->grids[ctx->fields[fsel].d.grid].d, m, dt_, dz, dflags);
+        unsigned hflags = 0;
+        PK_HIP(ctx, hipMemcpyAsync(&hflags, dflags, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->compute));
+        PK_HIP(ctx, hipStreamSynchronize(ctx->compute));
+        a.prm.force_lent = (hflags & 1u) ? 2 : 1;
+        a.prm.force_lenz = (hflags & 2u) ? 2 : 1;
+    }
+    const bool typed = ctx_is_typed(ctx);
+#define PK_EVAL(FT, IN, TY) hipLaunchKernelGGL((eval_kernel<FT, IN, TY>), grid, dim3(256), 0, ctx->compute, a, what, m, dt_, dz, dy, dx, du, dv, dw, ds)
+#define PK_EVAL_T(FT, IN) do { if (typed) PK_EVAL(FT, IN, true); else PK_EVAL(FT, IN, false); } while (0)
     const int ik = p2.interp_uv >= 2 ? 2 : p2.interp_uv;
     if (f32) {
-        if (ik == 2) PK_EVAL(float, 2); else if (ik == 1) PK_EVAL(float, 1); else PK_EVAL(float, 0);
+        if (ik == 2) PK_EVAL_T(float, 2); else if (ik == 1) PK_EVAL_T(float, 1); else PK_EVAL_T(float, 0);
     } else {
-        if (ik == 2) PK_EVAL(double, 2); else if (ik == 1) PK_EVAL(double, 1); else PK_EVAL(double, 0);
+        if (ik == 2) PK_EVAL_T(double, 2); else if (ik == 1) PK_EVAL_T(double, 1); else PK_EVAL_T(double, 0);
     }
+#undef PK_EVAL_T
 #undef PK_EVAL
     PK_HIP(ctx, hipGetLastError());
     PK_HIP(ctx, hipMemcpyAsync(out_u, du, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->compute));

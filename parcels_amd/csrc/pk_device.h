@@ -158,6 +158,23 @@ PK_DEV TV tv_mul(TV a, TV b) { const bool f = a.f32 && b.f32; return TV{f ? (dou
 PK_DEV TV tv_add(TV a, TV b) { const bool f = a.f32 && b.f32; return TV{f ? (double)((float)a.v + (float)b.v) : a.v + b.v, f}; }
 PK_DEV TV tv_one_minus(TV a) { return TV{a.f32 ? (double)(1.0f - (float)a.v) : 1 - a.v, a.f32}; }
 
+// The same for whole interpolators (CGrid_Velocity, the slip factors): a value plus the dtype tag of the NumPy array it is in the
+// reference -- 0 float64 array, 1 float32 array, 2 Python scalar (adapts to the other operand).  float32 op float32 is a float32
+// operation (rounded), anything with a float64 array is float64.
+struct NV {
+    double v;
+    int dt;
+};
+PK_DEV NV nvv(double v, int dt) { return NV{v, dt}; }
+PK_DEV int nv_res(int a, int b) { return a == 2 ? b : (b == 2 ? a : ((a == 1 && b == 1) ? 1 : 0)); }
+PK_DEV NV nv_add(NV a, NV b) { const int d = nv_res(a.dt, b.dt); return NV{d == 1 ? (double)((float)a.v + (float)b.v) : a.v + b.v, d}; }
+PK_DEV NV nv_sub(NV a, NV b) { const int d = nv_res(a.dt, b.dt); return NV{d == 1 ? (double)((float)a.v - (float)b.v) : a.v - b.v, d}; }
+PK_DEV NV nv_mul(NV a, NV b) { const int d = nv_res(a.dt, b.dt); return NV{d == 1 ? (double)((float)a.v * (float)b.v) : a.v * b.v, d}; }
+PK_DEV NV nv_div(NV a, NV b) { const int d = nv_res(a.dt, b.dt); return NV{d == 1 ? (double)((float)a.v / (float)b.v) : a.v / b.v, d}; }
+PK_DEV NV nv_neg(NV a) { return NV{-a.v, a.dt}; }
+PK_DEV NV nv_cast(NV a, int dt) { return NV{dt == 1 ? (double)(float)a.v : a.v, dt}; }
+PK_DEV NV nv_sqrt(NV a) { return a.dt == 1 ? NV{(double)sqrtf((float)a.v), 1} : NV{sqrt(a.v), a.dt}; }
+
 // Per-lane LDS cache of the curvilinear cell a particle sits in: its 4 corner nodes {lon, lat, X, Y, Z} and the raw
 // staggered field values of one C-grid evaluation at both time levels.  A particle moves a fraction of a cell per RK
 // stage, so stages 2..4 and most following steps of the fused loop find their cell here instead of re-fetching ~9
@@ -592,6 +609,7 @@ struct PCtx {
     bool hyx_valid;      // (hy, hx) is an in-range cell whose ravelled index is the particle's ei on the main grid
     unsigned first_eval;  // bit g: no evaluation on grid g yet in this execute() call
     int32_t ei0, ei1, ei2, ei3;  // the particle's `ei` row, one register per grid (no dynamic indexing -> no scratch)
+    bool u32, v32;  // the u / v ARRAYS of the last eval_uvw are float32 in the reference (AdvectionRK45's stage-1 products)
 };
 
 PK_DEV int32_t ei_get(const PCtx& c, int g) { return g == 0 ? c.ei0 : (g == 1 ? c.ei1 : (g == 2 ? c.ei2 : c.ei3)); }
@@ -609,7 +627,11 @@ PK_DEV bool take_first_eval(PCtx& c, int g) {
 
 // XGrid.search (xgrid.py:316-356) + ei write + state update (field.py:307-356)
 // KIND: 0 rectilinear, 1 curvilinear, -1 decide at run time (scalar fields on secondary grids)
-template <int KIND>
+// TYPED: some grid of the fieldset stores a coordinate as float32, so NumPy's float32 arithmetic on coordinate / barycentric
+// arrays has to be reproduced (GPos::x32 / e32 / z32, the f32 paths of search_1d).  false: those are compile-time constants
+// (only the float32 (xsi, eta) of an unguessed curvilinear evaluation, GPos::w32, remains a run-time property) and the
+// programs built for float64 coordinates carry none of the emulation.
+template <int KIND, bool TYPED>
 PK_DEV void grid_search(const DGrid& g, const Coords* mc, double z, double y, double x, bool pos_f32, int32_t* ei,
                         PCtx& c, bool use_guess, GPos& p) {
     const bool curv = (KIND < 0) ? (g.kind == 1) : (KIND == 1);
@@ -617,12 +639,13 @@ PK_DEV void grid_search(const DGrid& g, const Coords* mc, double z, double y, do
     const double* lat = mc ? mc->lat : g.lat;
     const double* lon = mc ? mc->lon : g.lon;
     const bool hint = mc != nullptr;
-    if (g.has_z) search_1d(depth, g.nz, mc ? mc->z0 : g.depth[0], mc ? mc->z1 : g.depth[g.nz - 1], z, g.depth_f32, pos_f32, hint ? c.hz : 0, p.zi, p.zeta);
+    const bool zf32 = TYPED && g.depth_f32, yf32 = TYPED && g.lat_f32, xf32 = TYPED && g.lon_f32;
+    if (g.has_z) search_1d(depth, g.nz, mc ? mc->z0 : g.depth[0], mc ? mc->z1 : g.depth[g.nz - 1], z, zf32, pos_f32, hint ? c.hz : 0, p.zi, p.zeta);
     else { p.zi = 0; p.zeta = 0.0; }
     p.w32 = curv && !use_guess;
-    p.z32 = g.has_z && g.depth_f32 && pos_f32 && g.nz >= 2;
-    p.x32 = curv ? p.w32 : (g.has_x && g.lon_f32 && pos_f32 && g.nx >= 2);
-    p.e32 = curv ? p.w32 : (g.has_y && g.lat_f32 && pos_f32 && g.ny >= 2);
+    p.z32 = g.has_z && zf32 && pos_f32 && g.nz >= 2;
+    p.x32 = curv ? p.w32 : (g.has_x && xf32 && pos_f32 && g.nx >= 2);
+    p.e32 = curv ? p.w32 : (g.has_y && yf32 && pos_f32 && g.ny >= 2);
     if (curv) {
         int gy = 0, gx = 0;
         if (use_guess) {  // index_search.py:269-274
@@ -632,9 +655,9 @@ PK_DEV void grid_search(const DGrid& g, const Coords* mc, double z, double y, do
         }
         curvilinear_search(g, y, x, use_guess, gy, gx, p.yi, p.xi, p.xsi, p.eta, mc ? &mc->cc : nullptr);
     } else {
-        if (g.has_y) search_1d(lat, g.ny, mc ? mc->y0 : g.lat[0], mc ? mc->y1 : g.lat[g.ny - 1], y, g.lat_f32, pos_f32, hint ? c.hy : 0, p.yi, p.eta);
+        if (g.has_y) search_1d(lat, g.ny, mc ? mc->y0 : g.lat[0], mc ? mc->y1 : g.lat[g.ny - 1], y, yf32, pos_f32, hint ? c.hy : 0, p.yi, p.eta);
         else { p.yi = 0; p.eta = 0.0; }
-        if (g.has_x) search_1d(lon, g.nx, mc ? mc->x0 : g.lon[0], mc ? mc->x1 : g.lon[g.nx - 1], x, g.lon_f32, pos_f32, hint ? c.hx : 0, p.xi, p.xsi);
+        if (g.has_x) search_1d(lon, g.nx, mc ? mc->x0 : g.lon[0], mc ? mc->x1 : g.lon[g.nx - 1], x, xf32, pos_f32, hint ? c.hx : 0, p.xi, p.xsi);
         else { p.xi = 0; p.xsi = 0.0; }
     }
     const int64_t rav = ravel_ei(g, p.zi, p.yi, p.xi);
@@ -776,18 +799,24 @@ PK_DEV double xlinear(const DField& f, const GPos& p) { return xlinear<FT>(f, ma
 
 // _Spatialslip (_xinterpolators.py:386-477): XFreeslip (a = 1, b = 0) and XPartialslip (a = b = 0.5).  A corner is "land"
 // when np.isclose(U, 0) & np.isclose(V, 0) at the first bracketing time level; a cell row / column that is all land scales
-// the tangential velocity by (a + b*eta)/eta etc.  lenZ is evaluated per particle (zeta > 0), the W factors always use
-// both depth levels like the reference.
+// the tangential velocity by (a + b*eta)/eta etc.  lenZ (does the z1 level take part in the u / v land tests) is batch-global
+// in the reference, `2 if np.any(zeta > 0) else 1`: here per particle (zeta > 0) unless `force_lenz` (1 / 2) gives the value of
+// the batch (pk_eval: one call is one batch); the W factors always use both depth levels like the reference.
+// NumPy dtypes: f_u = ones_like(xsi), f_v = ones_like(eta), f_w = ones_like(zeta) take the dtype of THAT barycentric array, the
+// factor expressions the dtype of the coordinate they are made of (product first, then the quotient), `f[land] = ...` casts
+// back to f's dtype, and the in-place `u /= ...`, `v /= ...` keep the dtype XLinear returned.
 template <class FT>
 PK_DEV void slip_velocity(const DGrid& g, const DField& U, const DField& V, const DField* W, const GPos& p, double ypos,
-                          bool ypos_f32, double a_, double b_, double& u, double& v, double& w) {
+                          bool ypos_f32, double a_, double b_, int force_lenz, double& u, double& v, double& w, bool& u32o, bool& v32o) {
     const Corners ku = make_corners(U, p);
     const bool same_v = same_layout(U, V);
     const Corners kv = same_v ? ku : make_corners(V, p);
-    double uu = xlinear<FT>(U, ku, p);
-    double vv = xlinear<FT>(V, kv, p);
-    double ww = 0.0;
-    if (W) ww = same_layout(U, *W) ? xlinear<FT>(*W, ku, p) : xlinear<FT>(*W, p);
+    bool u32 = false, v32 = false, w32 = false;
+    NV uu = nvv(xlinear<FT>(U, ku, p, &u32), 0);
+    NV vv = nvv(xlinear<FT>(V, kv, p, &v32), 0);
+    NV ww = nvv(0.0, 0);
+    if (W) ww.v = same_layout(U, *W) ? xlinear<FT>(*W, ku, p, &w32) : xlinear<FT>(*W, make_corners(*W, p), p, &w32);
+    uu.dt = u32; vv.dt = v32; ww.dt = w32;
     const double zero_tol = sizeof(FT) == 4 ? (double)(float)1e-8 : 1e-8;  // np.isclose(v, 0.0): |v| <= atol
     const FT* du = (const FT*)U.data + ku.ot0;
     const FT* dv = (const FT*)V.data + kv.ot0;
@@ -802,36 +831,42 @@ PK_DEV void slip_velocity(const DGrid& g, const DField& U, const DField& V, cons
             land[iz][iy][0] = fabs(u0) <= zero_tol && fabs(v0) <= zero_tol;
             land[iz][iy][1] = fabs(u1) <= zero_tol && fabs(v1) <= zero_tol;
         }
-    const double xsi = p.xsi, eta = p.eta;
-    const bool z2 = p.zeta > 0;
+    const NV xsi = nvv(p.xsi, p.x32), eta = nvv(p.eta, p.e32);
+    const NV one = nvv(1.0, 2), na = nvv(a_, 2), nb = nvv(b_, 2);
+    const bool z2 = force_lenz ? force_lenz == 2 : p.zeta > 0;
     const bool row0 = land[0][0][0] && land[0][0][1], row0z = land[1][0][0] && land[1][0][1];
     const bool row1 = land[0][1][0] && land[0][1][1], row1z = land[1][1][0] && land[1][1][1];
     const bool col0 = land[0][0][0] && land[0][1][0], col0z = land[1][0][0] && land[1][1][0];
     const bool col1 = land[0][0][1] && land[0][1][1], col1z = land[1][0][1] && land[1][1][1];
-    double f_u = 1.0;
-    if (row0 && (!z2 || row0z) && eta > 0) f_u = f_u * (a_ + b_ * eta) / eta;
-    if (row1 && (!z2 || row1z) && eta < 1) f_u = f_u * (1 - b_ * eta) / (1 - eta);
-    uu = uu * f_u;
+    // f[land] = f[land] * (a + b*c) / c   and   f[land] * (1 - b*c) / (1 - c)
+    auto fac_lo = [&](NV f, NV c) { return nv_cast(nv_div(nv_mul(f, nv_add(na, nv_mul(nb, c))), c), f.dt); };
+    auto fac_hi = [&](NV f, NV c) { return nv_cast(nv_div(nv_mul(f, nv_sub(one, nv_mul(nb, c))), nv_sub(one, c)), f.dt); };
+    NV f_u = nvv(1.0, p.x32);
+    if (row0 && (!z2 || row0z) && p.eta > 0) f_u = fac_lo(f_u, eta);
+    if (row1 && (!z2 || row1z) && p.eta < 1) f_u = fac_hi(f_u, eta);
+    uu = nv_mul(uu, f_u);
     if (g.spherical) {  // the reference hard-codes 1852*60 here (== deg2m of the default sphere)
-        if (ypos_f32) uu /= (double)(111120.0f * cosf((float)ypos * DEG2RADF));
-        else uu /= 111120 * cos_lat(ypos * DEG2RAD);
+        const NV conv = ypos_f32 ? NV{(double)(111120.0f * cosf((float)ypos * DEG2RADF)), 1} : NV{111120 * cos_lat(ypos * DEG2RAD), 0};
+        uu = nv_cast(nv_div(uu, conv), uu.dt);
     }
-    double f_v = 1.0;
-    if (col0 && (!z2 || col0z) && xsi > 0) f_v = f_v * (a_ + b_ * xsi) / xsi;
-    if (col1 && (!z2 || col1z) && xsi < 1) f_v = f_v * (1 - b_ * xsi) / (1 - xsi);
-    vv = vv * f_v;
-    if (g.spherical) vv /= 111120;
+    NV f_v = nvv(1.0, p.e32);
+    if (col0 && (!z2 || col0z) && p.xsi > 0) f_v = fac_lo(f_v, xsi);
+    if (col1 && (!z2 || col1z) && p.xsi < 1) f_v = fac_hi(f_v, xsi);
+    vv = nv_mul(vv, f_v);
+    if (g.spherical) vv = nv_cast(nv_div(vv, nvv(111120.0, 2)), vv.dt);
     if (W) {
-        double f_w = 1.0;
-        if (row0 && row0z && eta > 0) f_w = f_w * (a_ + b_ * eta) / eta;
-        if (row1 && row1z && eta < 1) f_w = f_w * (1 - b_ * eta) / (1 - eta);
-        if (col0 && col0z && xsi > 0) f_w = f_w * (a_ + b_ * xsi) / xsi;
-        if (col1 && col1z && xsi < 1) f_w = f_w * (1 - b_ * xsi) / (1 - xsi);
-        ww = ww * f_w;
+        NV f_w = nvv(1.0, p.z32);
+        if (row0 && row0z && p.eta > 0) f_w = fac_lo(f_w, eta);
+        if (row1 && row1z && p.eta < 1) f_w = fac_hi(f_w, eta);
+        if (col0 && col0z && p.xsi > 0) f_w = fac_lo(f_w, xsi);
+        if (col1 && col1z && p.xsi < 1) f_w = fac_hi(f_w, xsi);
+        ww = nv_mul(ww, f_w);
     }
-    u = uu;
-    v = vv;
-    w = ww;
+    u = uu.v;
+    v = vv.v;
+    w = ww.v;
+    u32o = uu.dt == 1;
+    v32o = vv.dt == 1;
 }
 
 // _geodetic_distance (utils/interpolation.py:178-185), including NumPy's float32 behaviour for f32 coordinates
@@ -873,10 +908,132 @@ PK_DEV float pymod360f(float v) {
     return q;
 }
 
+// np.column_stack of four entries followed by einsum("ij,ji->i", ., q) (phi2D_lin and the Jacobian rows, utils/interpolation.py:
+// 25-31,188-198): the entries are cast to their common dtype, products and running sum take the promoted dtype of both operands.
+// float64 entries against float32 coordinates run through einsum's buffered two-accumulator loop, (p0 + p2) + (p1 + p3); every
+// other combination adds left to right (batches of two or more particles; measured on NumPy 2.2).
+PK_DEV NV nv_dot4(const NV e[4], const NV q[4]) {
+    int dt = 2;
+#pragma unroll
+    for (int k = 0; k < 4; k++) dt = nv_res(dt, e[k].dt);
+    if (dt == 2) dt = 0;
+    const int odt = nv_res(dt, q[0].dt);
+    if (dt == 0 && q[0].dt == 1) {
+        const double p0 = e[0].v * q[0].v, p1 = e[1].v * q[1].v, p2 = e[2].v * q[2].v, p3 = e[3].v * q[3].v;
+        return NV{(p0 + p2) + (p1 + p3), odt};
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const double a = dt == 1 ? (double)(float)e[k].v : e[k].v;
+        if (odt == 1) acc = (double)((float)acc + (float)a * (float)q[k].v);
+        else acc = acc + a * q[k].v;
+    }
+    return NV{acc, odt};
+}
+PK_DEV void nv_phi2d(NV eta, NV xsi, NV out[4]) {  // utils/interpolation.py:25-31
+    const NV one = nvv(1.0, 2);
+    const NV omx = nv_sub(one, xsi), ome = nv_sub(one, eta);
+    out[0] = nv_mul(omx, ome);
+    out[1] = nv_mul(xsi, ome);
+    out[2] = nv_mul(xsi, eta);
+    out[3] = nv_mul(omx, eta);
+}
+PK_DEV NV nv_cos_deg(NV lat) {  // np.cos(np.pi / 180.0 * lat)
+    const NV r = nv_mul(nvv(3.14159265358979323846 / 180.0, 2), lat);
+    return r.dt == 1 ? NV{(double)cosf((float)r.v), 1} : NV{cos_lat(r.v), r.dt};
+}
+PK_DEV NV nv_geodetic(const DGrid& g, NV lat1, NV lat2, NV lon1, NV lon2, NV lat) {  // utils/interpolation.py:178-185
+    if (g.spherical) {
+        const NV a = nv_mul(nv_mul(nv_sub(lon2, lon1), nvv(g.deg2m, 2)), nv_cos_deg(lat));
+        const NV b = nv_mul(nv_sub(lat2, lat1), nvv(g.deg2m, 2));
+        return nv_sqrt(nv_add(nv_mul(a, a), nv_mul(b, b)));
+    }
+    const NV a = nv_sub(lon2, lon1), b = nv_sub(lat2, lat1);
+    return nv_sqrt(nv_add(nv_mul(a, a), nv_mul(b, b)));
+}
+// two bracketing face values reduced over time, with their dtype (_xinterpolators.py:249-270): tau is a float64 array
+template <class FT>
+PK_DEV void cgrid_pair_t(const DField& f, const GPos& p, int64_t offA, int64_t offB, NV out[2]) {
+    const FT* d = (const FT*)f.data;
+    const int64_t s0 = slot_off(f, p.ti);
+    double a = ldv(d, s0 + offA), b = ldv(d, s0 + offB);
+    int dt = sizeof(FT) == 4 ? 1 : 0;
+    if (p.tau > 0) {
+        const int64_t s1 = slot_off(f, mini(p.ti + 1, f.nt - 1));
+        a = a * (1 - p.tau) + ldv(d, s1 + offA) * p.tau;
+        b = b * (1 - p.tau) + ldv(d, s1 + offB) * p.tau;
+        dt = 0;
+    }
+    out[0] = nvv(a, dt);
+    out[1] = nvv(b, dt);
+}
+// CGrid_Velocity.interp with every operation carrying its NumPy dtype: float32 coordinate arrays (lon_f32 / lat_f32), float32
+// barycentric arrays (GPos::x32 / e32 / z32) and float32 field data that no float64 time lerp has touched.  Used by the programs
+// built for fieldsets with float32 coordinates (TYPED); pxv / pyv: corner coordinates after the antimeridian unwrapping.
+template <class FT>
+PK_DEV void cgrid_velocity_typed(const DGrid& g, const DField& U, const DField& V, const DField* W, const GPos& p, const double pxv[4],
+                                 const double pyv[4], double ypos, bool ypos_f32, double& u, double& v, double& w, bool& u32, bool& v32) {
+    const int xi = p.xi, yi = p.yi, zi = p.zi;
+    const int ydim = U.ny, xdim = U.nx, zdim = U.nz;
+    const NV xsi = nvv(p.xsi, p.x32), eta = nvv(p.eta, p.e32), zeta = nvv(p.zeta, p.z32);
+    const NV one = nvv(1.0, 2), zero = nvv(0.0, 2);
+    NV px[4], py[4], phi[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { px[k] = nvv(pxv[k], g.lon_f32 ? 1 : 0); py[k] = nvv(pyv[k], g.lat_f32 ? 1 : 0); }
+    nv_phi2d(zero, xsi, phi);
+    const NV c1 = nv_geodetic(g, py[0], py[1], px[0], px[1], nv_dot4(phi, py));
+    nv_phi2d(eta, one, phi);
+    const NV c2 = nv_geodetic(g, py[1], py[2], px[1], px[2], nv_dot4(phi, py));
+    nv_phi2d(one, xsi, phi);
+    const NV c3 = nv_geodetic(g, py[2], py[3], px[2], px[3], nv_dot4(phi, py));
+    nv_phi2d(eta, zero, phi);
+    const NV c4 = nv_geodetic(g, py[3], py[0], px[3], px[0], nv_dot4(phi, py));
+    NV cd[2];
+    const int yi_o = clampi(yi + g.off_y, 0, ydim - 1), xi_1 = clampi(xi + 1, 0, xdim - 1);
+    cgrid_pair_t<FT>(U, p, cgrid_off(U, zi, yi_o, xi), cgrid_off(U, zi, yi_o, xi_1), cd);
+    const NV U0 = nv_mul(cd[0], c4), U1 = nv_mul(cd[1], c2);
+    const NV omx = nv_sub(one, xsi), ome = nv_sub(one, eta);
+    const NV Uvel = nv_add(nv_mul(omx, U0), nv_mul(xsi, U1));
+    const int yi_1 = clampi(yi + 1, 0, ydim - 1), xi_o = clampi(xi + g.off_x, 0, xdim - 1);
+    cgrid_pair_t<FT>(V, p, cgrid_off(V, zi, yi, xi_o), cgrid_off(V, zi, yi_1, xi_o), cd);
+    const NV V0 = nv_mul(cd[0], c1), V1 = nv_mul(cd[1], c3);
+    const NV Vvel = nv_add(nv_mul(ome, V0), nv_mul(eta, V1));
+    // _compute_jacobian_determinant (utils/interpolation.py:188-198)
+    const NV dxs[4] = {nv_sub(eta, one), ome, eta, nv_neg(eta)};
+    const NV det[4] = {nv_sub(xsi, one), nv_neg(xsi), xsi, omx};
+    const NV dxdxsi = nv_dot4(dxs, px), dxdeta = nv_dot4(det, px), dydxsi = nv_dot4(dxs, py), dydeta = nv_dot4(det, py);
+    NV jac = nv_sub(nv_mul(dxdxsi, dydeta), nv_mul(dxdeta, dydxsi));
+    if (g.spherical) jac = nv_mul(jac, nvv(g.deg2m, 2));
+    const NV A = nv_sub(nv_mul(nv_neg(ome), Uvel), nv_mul(omx, Vvel));
+    const NV B = nv_sub(nv_mul(ome, Uvel), nv_mul(xsi, Vvel));
+    const NV C = nv_add(nv_mul(eta, Uvel), nv_mul(xsi, Vvel));
+    const NV D = nv_add(nv_mul(nv_neg(eta), Uvel), nv_mul(omx, Vvel));
+    NV uu = nv_div(nv_add(nv_add(nv_add(nv_mul(A, px[0]), nv_mul(B, px[1])), nv_mul(C, px[2])), nv_mul(D, px[3])), jac);
+    NV vv = nv_div(nv_add(nv_add(nv_add(nv_mul(A, py[0]), nv_mul(B, py[1])), nv_mul(C, py[2])), nv_mul(D, py[3])), jac);
+    if (g.spherical) {  // :311-314, in place: u and v keep their dtype
+        const NV conv = nv_mul(nvv(g.deg2m, 2), ypos_f32 ? NV{(double)cosf((float)ypos * DEG2RADF), 1} : NV{cos_lat(ypos * DEG2RAD), 0});
+        uu = nv_cast(nv_div(uu, conv), uu.dt);
+        vv = nv_cast(nv_div(vv, conv), vv.dt);
+    }
+    u = uu.v;
+    v = vv.v;
+    u32 = uu.dt == 1;
+    v32 = vv.dt == 1;
+    if (W) {  // :316-328
+        const int zi_0 = clampi(zi + g.off_z, 0, zdim - 1), zi_1 = clampi(zi + g.off_z + 1, 0, zdim - 1);
+        cgrid_pair_t<FT>(*W, p, cgrid_off(*W, zi_0, yi_o, xi_o), cgrid_off(*W, zi_1, yi_o, xi_o), cd);
+        w = nv_add(nv_mul(cd[0], nv_sub(one, zeta)), nv_mul(cd[1], zeta)).v;
+    } else {
+        w = 0.0;
+    }
+}
+
 // CGrid_Velocity.interp (_xinterpolators.py:193-332)
-template <class FT, int KIND>
+template <class FT, int KIND, bool TYPED>
 PK_DEV void cgrid_velocity(const DGrid& g, const Coords* mc, const DField& U, const DField& V, const DField* W, const GPos& p,
-                           double ypos, bool ypos_f32, double& u, double& v, double& w) {
+                           double ypos, bool ypos_f32, double& u, double& v, double& w, bool& u32, bool& v32) {
+    u32 = v32 = false;
     const int xi = p.xi, yi = p.yi, zi = p.zi;
     const double xsi = p.xsi, eta = p.eta, zeta = p.zeta;
     const int ydim = U.ny, xdim = U.nx, zdim = U.nz;
@@ -899,7 +1056,7 @@ PK_DEV void cgrid_velocity(const DGrid& g, const Coords* mc, const DField& U, co
         ldpair(r0, px[0], py[0]); ldpair(r0 + 5, px[1], py[1]);
         ldpair(r1, px[3], py[3]); ldpair(r1 + 5, px[2], py[2]);
     }
-    const bool cf32x = g.lon_f32, cf32 = g.lon_f32 && g.lat_f32;
+    const bool cf32x = TYPED && g.lon_f32;
     if (g.spherical) {  // :230-233
         if (cf32x) {
 #pragma unroll
@@ -921,6 +1078,11 @@ PK_DEV void cgrid_velocity(const DGrid& g, const Coords* mc, const DField& U, co
                 if (-px[k] + px[0] > 180) px[k] = px[k] + 360;
         }
     }
+    if (TYPED) {  // float32 coordinate arrays somewhere in the fieldset: carry NumPy's dtype through every operation
+        cgrid_velocity_typed<FT>(g, U, V, W, p, px, py, ypos, ypos_f32, u, v, w, u32, v32);
+        return;
+    }
+    constexpr bool cf32 = false;  // float64 coordinates from here on
     // einsum("ij,ji->i", phi2D_lin(eta, xsi), py): products formed for all four corners, summed in corner order.  With
     // float32 xsi/eta arrays (p.w32) the phi entries and 1 - xsi, 1 - eta, eta - 1, xsi - 1 are float32 results.
     const bool w32 = p.w32;
@@ -1052,13 +1214,15 @@ template <class FT>
 PK_DEV double cgrid_tracer(const DGrid& g, const DField& f, const GPos& p) {
     return point_value<FT>(f, p, clampi(p.zi + g.off_z, 0, f.nz - 1), clampi(p.yi + g.off_y, 0, f.ny - 1), clampi(p.xi + g.off_x, 0, f.nx - 1));
 }
-// XLinearInvdistLandTracer.interp (_xinterpolators.py:556-613); lenT/lenZ per particle (the reference's batch-global
-// choice changes the value here)
+// XLinearInvdistLandTracer.interp (_xinterpolators.py:556-613).  lenT / lenZ are batch-global in the reference and, unlike in
+// XLinear, every gathered corner takes part: per particle here unless force_lent / force_lenz (1 / 2) give the value of the
+// batch (pk_eval: one call is one batch).  `values` keeps XLinear's dtype: its assignments cast to it.
 template <class FT>
-PK_DEV double xlinear_invdist(const DField& f, const GPos& p) {
-    double value = xlinear<FT>(f, p);
+PK_DEV double xlinear_invdist(const DField& f, const GPos& p, int force_lent, int force_lenz) {
+    bool v32 = false;
+    double value = xlinear<FT>(f, make_corners(f, p), p, &v32);
     const FT* d = (const FT*)f.data;
-    const int lenT = p.tau > 0 ? 2 : 1, lenZ = p.zeta > 0 ? 2 : 1;
+    const int lenT = force_lent ? force_lent : (p.tau > 0 ? 2 : 1), lenZ = force_lenz ? force_lenz : (p.zeta > 0 ? 2 : 1);
     const double zero_tol = sizeof(FT) == 4 ? (double)(float)1e-8 : 1e-8;
     double val = 0.0, w_sum = 0.0, exact_vals = 0.0;
     int nb_land = 0;
@@ -1087,6 +1251,7 @@ PK_DEV double xlinear_invdist(const DField& f, const GPos& p) {
     if (nb_land > 0) {
         value = val / w_sum;
         if (has_exact) value = exact_vals;
+        if (v32) value = (double)(float)value;
     }
     return value;
 }
@@ -1110,7 +1275,7 @@ PK_DEV double finish_value(PCtx& c, const GPos& p, double v) { return finish_val
 
 // VectorField.eval (field.py:250-304). INTERP: 0 XLinear_Velocity, 1 CGrid_Velocity. pos_f32: z,y,x come
 // straight from float32 particle storage (NumPy then evaluates cos(lat) in float32).
-template <class FT, int KIND, int INTERP>
+template <class FT, int KIND, int INTERP, bool TYPED>
 PK_DEV void eval_uvw(const KArgs& a, const Coords& mc, PCtx& c, bool want_w, double t, double z, double y,
                      double x, bool pos_f32, double& u, double& v, double& w) {
     const DField& U = a.fields[a.prm.fU];
@@ -1118,6 +1283,7 @@ PK_DEV void eval_uvw(const KArgs& a, const Coords& mc, PCtx& c, bool want_w, dou
     const DGrid& g = a.grids[U.grid];
     GPos p;
     u = v = w = 0.0;
+    c.u32 = c.v32 = false;
     if (!time_search(U, mc.time, t, c.ht, p)) {  // field.py:303-304 -> _deal_with_errors: state := 70, zeros
         c.state = PK_ERROROUTSIDETIMEINTERVAL;
         return;
@@ -1125,7 +1291,7 @@ PK_DEV void eval_uvw(const KArgs& a, const Coords& mc, PCtx& c, bool want_w, dou
     c.ht = p.ti;
     const bool use_guess = take_first_eval(c, U.grid) ? (a.prm.have_guess0 != 0) : true;
     int32_t ei = ei_get(c, U.grid);
-    grid_search<KIND>(g, &mc, z, y, x, pos_f32, &ei, c, use_guess, p);
+    grid_search<KIND, TYPED>(g, &mc, z, y, x, pos_f32, &ei, c, use_guess, p);
     ei_set(c, U.grid, ei);
     const int flags = oob_flags(p);
     const bool oob = flags & 1;
@@ -1133,10 +1299,10 @@ PK_DEV void eval_uvw(const KArgs& a, const Coords& mc, PCtx& c, bool want_w, dou
     if (!oob) {
         const DField* W = (want_w && a.prm.fW >= 0) ? &a.fields[a.prm.fW] : nullptr;
         if (INTERP == 1) {
-            cgrid_velocity<FT, KIND>(g, &mc, U, V, W, p, y, pos_f32, uu, vv, ww);
+            cgrid_velocity<FT, KIND, TYPED>(g, &mc, U, V, W, p, y, pos_f32, uu, vv, ww, c.u32, c.v32);
         } else if (INTERP == 2) {  // XFreeslip (interp_uv == 2) / XPartialslip (3)
             const bool freeslip = a.prm.interp_uv == 2;
-            slip_velocity<FT>(g, U, V, W, p, y, pos_f32, freeslip ? 1.0 : 0.5, freeslip ? 0.0 : 0.5, uu, vv, ww);
+            slip_velocity<FT>(g, U, V, W, p, y, pos_f32, freeslip ? 1.0 : 0.5, freeslip ? 0.0 : 0.5, a.prm.force_lenz, uu, vv, ww, c.u32, c.v32);
         } else {  // XLinear_Velocity.interp (_xinterpolators.py:169-190)
             const Corners k = make_corners(U, p);
             bool u32 = false, v32 = false;
@@ -1154,6 +1320,8 @@ PK_DEV void eval_uvw(const KArgs& a, const Coords& mc, PCtx& c, bool want_w, dou
                 if (v32) vv = (double)((float)vv / (float)g.deg2m);
                 else vv /= g.deg2m;
             }
+            c.u32 = u32;
+            c.v32 = v32;
         }
     }
     u = finish_value(c, flags, uu);
@@ -1162,7 +1330,7 @@ PK_DEV void eval_uvw(const KArgs& a, const Coords& mc, PCtx& c, bool want_w, dou
 }
 
 // Field.eval for a scalar field (field.py:145-195): XLinear or XConstantField
-template <class FT>
+template <class FT, bool TYPED>
 PK_DEV double eval_scalar(const KArgs& a, const Coords& mc, PCtx& c, int fidx, double t, double z, double y,
                           double x, bool pos_f32) {
     const DField& f = a.fields[fidx];
@@ -1176,7 +1344,7 @@ PK_DEV double eval_scalar(const KArgs& a, const Coords& mc, PCtx& c, int fidx, d
     }
     const bool use_guess = take_first_eval(c, f.grid) ? (a.prm.have_guess0 != 0) : true;
     int32_t ei = ei_get(c, f.grid);
-    grid_search<-1>(g, on_main ? &mc : nullptr, z, y, x, pos_f32, &ei, c, use_guess, p);
+    grid_search<-1, TYPED>(g, on_main ? &mc : nullptr, z, y, x, pos_f32, &ei, c, use_guess, p);
     ei_set(c, f.grid, ei);
     double v = 0.0;
     if (!(p.xi < 0 || p.yi < 0 || p.zi < 0)) {
@@ -1185,7 +1353,7 @@ PK_DEV double eval_scalar(const KArgs& a, const Coords& mc, PCtx& c, int fidx, d
             case 1: v = f64 ? ((const double*)f.data)[f.comp] : (double)((const float*)f.data)[f.comp]; break;
             case 2: v = f64 ? xnearest<double>(f, p) : xnearest<float>(f, p); break;
             case 3: v = f64 ? cgrid_tracer<double>(g, f, p) : cgrid_tracer<float>(g, f, p); break;
-            case 4: v = f64 ? xlinear_invdist<double>(f, p) : xlinear_invdist<float>(f, p); break;
+            case 4: v = f64 ? xlinear_invdist<double>(f, p, a.prm.force_lent, a.prm.force_lenz) : xlinear_invdist<float>(f, p, a.prm.force_lent, a.prm.force_lenz); break;
             default: v = f64 ? xlinear<double>(f, p) : xlinear<float>(f, p); break;
         }
     }

@@ -17,7 +17,8 @@
 namespace pk {
 
 // programs: a single built-in kernel fixed at compile time, or the generic kernel-list interpreter
-enum Program { PROG_RK4 = 0, PROG_RK4_3D = 1, PROG_GENERIC = 2, PROG_RK45 = 3, PROG_M1 = 4 };
+enum Program { PROG_RK4 = 0, PROG_RK4_3D = 1, PROG_GENERIC = 2, PROG_RK45 = 3, PROG_M1 = 4, PROG_TYPED = 5 };  // PROG_TYPED: the kernel-list
+// interpreter with NumPy's float32 dtype propagation (fieldsets with float32 coordinate arrays; pk_device.h: TYPED)
 
 struct PState {
     double t, z, y, x, dz, dy, dx, dt, next_dt;
@@ -44,6 +45,7 @@ struct Request {
 // kernel-local registers (all indices are compile-time constants -> scalar-replaced into VGPRs)
 struct KLocal {
     double r[14];
+    bool u1f, v1f;  // AdvectionRK45: u1 / v1 are float32 ARRAYS in the reference (PCtx::u32 / v32 of the stage-0 sample)
 };
 
 // meters_to_degrees_zonal / _meridional (_advectiondiffusion.py:11-18); `particles.y * np.pi / 180` is float32
@@ -125,37 +127,42 @@ PK_DEV bool prepare(const KArgs& a, int kid, int stage, int kslot, PCtx& c, PSta
             using namespace rk45c;
             const double dt = p.dt;
             const double *u = &L.r[0], *v = &L.r[6];
+            // u1 / v1 may be float32 ARRAYS in the reference (float32 data on float32 coordinates sampled at float32 positions, or
+            // the unguessed first evaluation on a curvilinear A-grid): their product with a Python float is a float32 product
+            // (NEP 50).  Every later sample point is float64, so only the stage-1 terms are affected.
+            auto U1 = [&](double k) { return L.u1f ? (double)((float)u[0] * (float)k) : u[0] * k; };
+            auto V1 = [&](double k) { return L.v1f ? (double)((float)v[0] * (float)k) : v[0] * k; };
             switch (stage) {
                 case 0: rq.f32 = pf; return false;
                 case 1:
-                    rq.x = p.x + u[0] * A00 * dt; rq.y = p.y + v[0] * A00 * dt; rq.t = p.t + c0 * dt;
+                    rq.x = p.x + U1(A00) * dt; rq.y = p.y + V1(A00) * dt; rq.t = p.t + c0 * dt;
                     return false;
                 case 2:
-                    rq.x = p.x + (u[0] * A10 + u[1] * A11) * dt; rq.y = p.y + (v[0] * A10 + v[1] * A11) * dt;
+                    rq.x = p.x + (U1(A10) + u[1] * A11) * dt; rq.y = p.y + (V1(A10) + v[1] * A11) * dt;
                     rq.t = p.t + c1 * dt;
                     return false;
                 case 3:
-                    rq.x = p.x + (u[0] * A20 + u[1] * A21 + u[2] * A22) * dt;
-                    rq.y = p.y + (v[0] * A20 + v[1] * A21 + v[2] * A22) * dt;
+                    rq.x = p.x + (U1(A20) + u[1] * A21 + u[2] * A22) * dt;
+                    rq.y = p.y + (V1(A20) + v[1] * A21 + v[2] * A22) * dt;
                     rq.t = p.t + c2 * dt;
                     return false;
                 case 4:
-                    rq.x = p.x + (u[0] * A30 + u[1] * A31 + u[2] * A32 + u[3] * A33) * dt;
-                    rq.y = p.y + (v[0] * A30 + v[1] * A31 + v[2] * A32 + v[3] * A33) * dt;
+                    rq.x = p.x + (U1(A30) + u[1] * A31 + u[2] * A32 + u[3] * A33) * dt;
+                    rq.y = p.y + (V1(A30) + v[1] * A31 + v[2] * A32 + v[3] * A33) * dt;
                     rq.t = p.t + c3 * dt;
                     return false;
                 case 5:
-                    rq.x = p.x + (u[0] * A40 + u[1] * A41 + u[2] * A42 + u[3] * A43 + u[4] * A44) * dt;
-                    rq.y = p.y + (v[0] * A40 + v[1] * A41 + v[2] * A42 + v[3] * A43 + v[4] * A44) * dt;
+                    rq.x = p.x + (U1(A40) + u[1] * A41 + u[2] * A42 + u[3] * A43 + u[4] * A44) * dt;
+                    rq.y = p.y + (V1(A40) + v[1] * A41 + v[2] * A42 + v[3] * A43 + v[4] * A44) * dt;
                     rq.t = p.t + c4 * dt;
                     return false;
                 default: break;
             }
             const double sign_dt = (dt > 0) ? 1.0 : ((dt < 0) ? -1.0 : dt);  // np.sign
-            const double x_4th = (u[0] * b40 + u[1] * b41 + u[2] * b42 + u[3] * b43 + u[4] * b44) * dt;
-            const double y_4th = (v[0] * b40 + v[1] * b41 + v[2] * b42 + v[3] * b43 + v[4] * b44) * dt;
-            const double x_5th = (u[0] * b50 + u[1] * b51 + u[2] * b52 + u[3] * b53 + u[4] * b54 + u[5] * b55) * dt;
-            const double y_5th = (v[0] * b50 + v[1] * b51 + v[2] * b52 + v[3] * b53 + v[4] * b54 + v[5] * b55) * dt;
+            const double x_4th = (U1(b40) + u[1] * b41 + u[2] * b42 + u[3] * b43 + u[4] * b44) * dt;
+            const double y_4th = (V1(b40) + v[1] * b41 + v[2] * b42 + v[3] * b43 + v[4] * b44) * dt;
+            const double x_5th = (U1(b50) + u[1] * b51 + u[2] * b52 + u[3] * b53 + u[4] * b54 + u[5] * b55) * dt;
+            const double y_5th = (V1(b50) + v[1] * b51 + v[2] * b52 + v[3] * b53 + v[4] * b54 + v[5] * b55) * dt;
             const double ex = x_5th - x_4th, ey = y_5th - y_4th;
             const double kappa = sqrt(ex * ex + ey * ey);
             const bool good = (kappa <= prm.rk45_tol) || (fabs(dt) <= fabs(prm.rk45_min_dt));
@@ -262,7 +269,7 @@ PK_DEV bool prepare(const KArgs& a, int kid, int stage, int kslot, PCtx& c, PSta
 }
 
 // consume(): fold the sampled (u, v, w) of `stage` into the kernel's registers
-PK_DEV void consume(int kid, int stage, KLocal& L, double u, double v, double w) {
+PK_DEV void consume(int kid, int stage, const PCtx& c, KLocal& L, double u, double v, double w) {
     switch (kid) {
         case PK_KERNEL_ADVECTION_RK4:
         case PK_KERNEL_ADVECTION_RK4_3D:
@@ -274,7 +281,7 @@ PK_DEV void consume(int kid, int stage, KLocal& L, double u, double v, double w)
             break;
         case PK_KERNEL_ADVECTION_RK45:
             switch (stage) {
-                case 0: L.r[0] = u; L.r[6] = v; break;
+                case 0: L.r[0] = u; L.r[6] = v; L.u1f = c.u32; L.v1f = c.v32; break;
                 case 1: L.r[1] = u; L.r[7] = v; break;
                 case 2: L.r[2] = u; L.r[8] = v; break;
                 case 3: L.r[3] = u; L.r[9] = v; break;
@@ -335,7 +342,7 @@ PK_DEV unsigned xcd_swizzle(unsigned bid, unsigned nb) {
 #ifndef PK_MIN_WAVES_HEAVY
 #define PK_MIN_WAVES_HEAVY 2
 #endif
-template <class FT, int KIND, int INTERP, int KID, bool LDS>
+template <class FT, int KIND, int INTERP, int KID, bool LDS, bool TYPED>
 __global__ void __launch_bounds__(256, (KIND == 1 || INTERP != 0) ? PK_MIN_WAVES_HEAVY : PK_MIN_WAVES) advect_kernel(const KArgs a) {
     extern __shared__ double smem[];
     const DField& mf = a.fields[a.main_field];
@@ -395,6 +402,7 @@ __global__ void __launch_bounds__(256, (KIND == 1 || INTERP != 0) ? PK_MIN_WAVES
             c.hz = c.hy = c.hx = c.ht = 0;
             c.hyx_valid = false;
             c.first_eval = prm.reset_state ? 0xFu : 0u;
+            c.u32 = c.v32 = false;
             PState p;
             p.t = P.t[i];
             p.z = ldp(P.z, i, pf);
@@ -433,16 +441,17 @@ __global__ void __launch_bounds__(256, (KIND == 1 || INTERP != 0) ? PK_MIN_WAVES
                     const int kid = KID >= 0 ? KID : prm.kernels[k];
                     do {
                         KLocal L;
+                        L.u1f = L.v1f = false;
                         Request rq;
                         attempts++;
                         for (int stage = 0; !prepare(a, kid, stage, k, c, p, L, rq); stage++) {
                             double u, v = 0.0, w = 0.0;
                             if (rq.kind == RQ_SCALAR) {
-                                u = eval_scalar<FT>(a, mc, c, rq.fidx, rq.t, rq.z, rq.y, rq.x, rq.f32);
+                                u = eval_scalar<FT, TYPED>(a, mc, c, rq.fidx, rq.t, rq.z, rq.y, rq.x, rq.f32);
                             } else {
-                                eval_uvw<FT, KIND, INTERP>(a, mc, c, rq.kind == RQ_UVW, rq.t, rq.z, rq.y, rq.x, rq.f32, u, v, w);
+                                eval_uvw<FT, KIND, INTERP, TYPED>(a, mc, c, rq.kind == RQ_UVW, rq.t, rq.z, rq.y, rq.x, rq.f32, u, v, w);
                             }
-                            consume(kid, stage, L, u, v, w);
+                            consume(kid, stage, c, L, u, v, w);
                         }
                     } while (c.state == PK_REPEAT);
                 }
@@ -511,7 +520,7 @@ void launch_program(int field_f32, int curvilinear, int interp, int lds, const K
                     hipStream_t stream);
 
 #define PK_LAUNCH_CASE(FT, KD, IN, LD) \
-    hipLaunchKernelGGL((advect_kernel<FT, KD, IN, KIDV, LD>), grid, dim3(256), lds_bytes, stream, a)
+    hipLaunchKernelGGL((advect_kernel<FT, KD, IN, KIDV, LD, TYPEDV>), grid, dim3(256), lds_bytes, stream, a)
 
 // single-kernel programs require LDS staging (the host falls back to the generic program otherwise)
 // interp: 0 XLinear_Velocity, 1 CGrid_Velocity, 2 slip (XFreeslip / XPartialslip, told apart by prm.interp_uv)
@@ -531,11 +540,12 @@ void launch_program(int field_f32, int curvilinear, int interp, int lds, const K
         case 11: PK_LAUNCH_CASE(float, 1, 2, LD); break;       \
     }
 
-#define PK_DEFINE_LAUNCH_PROGRAM(PROGV, KID_, WITH_NOLDS)                                                            \
+#define PK_DEFINE_LAUNCH_PROGRAM(PROGV, KID_, WITH_NOLDS, TYPED_)                                                    \
     template <>                                                                                                      \
     void launch_program<PROGV>(int field_f32, int curvilinear, int interp, int lds, const KArgs& a, dim3 grid,       \
                                size_t lds_bytes, hipStream_t stream) {                                               \
         constexpr int KIDV = KID_;                                                                                   \
+        constexpr bool TYPEDV = TYPED_;                                                                              \
         const int ik = interp >= 2 ? 2 : interp;                                                                     \
         const int key = (field_f32 ? 6 : 0) + (curvilinear ? 3 : 0) + ik;                                            \
         if (lds || !(WITH_NOLDS)) {                                                                                  \

@@ -5,5 +5,5 @@
 #endif
 #include "pk_kernels.h"
 namespace pk {
-PK_DEFINE_LAUNCH_PROGRAM(PROG_GENERIC, -1, 1)
+PK_DEFINE_LAUNCH_PROGRAM(PROG_GENERIC, -1, 1, false)
 }

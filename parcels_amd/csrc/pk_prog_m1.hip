@@ -4,5 +4,5 @@
 #endif
 #include "pk_kernels.h"
 namespace pk {
-PK_DEFINE_LAUNCH_PROGRAM(PROG_M1, PK_KERNEL_ADVECTIONDIFFUSION_M1, 0)
+PK_DEFINE_LAUNCH_PROGRAM(PROG_M1, PK_KERNEL_ADVECTIONDIFFUSION_M1, 0, false)
 }

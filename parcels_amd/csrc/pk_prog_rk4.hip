@@ -6,5 +6,5 @@
 #endif
 #include "pk_kernels.h"
 namespace pk {
-PK_DEFINE_LAUNCH_PROGRAM(PROG_RK4, PK_KERNEL_ADVECTION_RK4, 0)
+PK_DEFINE_LAUNCH_PROGRAM(PROG_RK4, PK_KERNEL_ADVECTION_RK4, 0, false)
 }

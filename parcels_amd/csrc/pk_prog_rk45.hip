@@ -4,5 +4,5 @@
 #endif
 #include "pk_kernels.h"
 namespace pk {
-PK_DEFINE_LAUNCH_PROGRAM(PROG_RK45, PK_KERNEL_ADVECTION_RK45, 0)
+PK_DEFINE_LAUNCH_PROGRAM(PROG_RK45, PK_KERNEL_ADVECTION_RK45, 0, false)
 }

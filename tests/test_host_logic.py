@@ -23,7 +23,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert sorted(_hip.ABI_SYMBOLS) == declared
     for sym in declared:
         assert hasattr(lib, sym), f"libparcels_hip.so does not export {sym}"
-    assert lib.pk_abi_version() == 1
+    assert lib.pk_abi_version() == _hip.PK_ABI_VERSION == 2
 
 
 def test_ctypes_structs_match_header_layout():
@@ -33,7 +33,7 @@ def test_ctypes_structs_match_header_layout():
     assert C.sizeof(_hip.GridDesc) == 18 * 4 + 8 + 8 * 8 + 2 * 8 + 2 * 4 + 6 * 8
     assert C.sizeof(_hip.FieldDesc) == 16 * 4 + 8
     assert C.sizeof(_hip.ParticlesDesc) == 8 + 2 * 4 + 12 * 8
-    assert C.sizeof(_hip.ExecParams) == (1 + 8 + 11) * 4 + 6 * 8 + 8
+    assert C.sizeof(_hip.ExecParams) == (1 + 8 + 13) * 4 + 6 * 8 + 8
     assert C.sizeof(_hip.ExecStats) == 3 * 8 + 80 * 8 + 4 * 8 + 2 * 4
 
 
