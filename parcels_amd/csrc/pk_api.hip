@@ -89,6 +89,13 @@ struct pk_ctx {
     int no_special = 0;
     int no_cell_cache = 0;
     int no_hash_dir = 0;
+    int no_fast = 0;
+    // {a, 1/width} coordinate tables of the fast A-grid path (pk_fast_agrid.h), cached per (main grid, main field)
+    double* d_fast_tab = nullptr;
+    size_t fast_tab_cap = 0;
+    int fast_tab_grid = -1, fast_tab_field = -1;
+    bool fast_tab_ok = false;
+    int32_t fast_tab_off[5] = {0, 0, 0, 0, 0};
 
     int32_t fail(const char* where, hipError_t e) {
         err = std::string(where) + ": " + hipGetErrorString(e);
@@ -358,6 +365,7 @@ int32_t pk_init(int32_t device, pk_ctx** out) {
     if (const char* e = getenv("PK_NO_SPECIAL")) ctx->no_special = atoi(e);
     if (const char* e = getenv("PK_NO_CELL_CACHE")) ctx->no_cell_cache = atoi(e);
     if (const char* e = getenv("PK_NO_HASH_DIR")) ctx->no_hash_dir = atoi(e);
+    if (const char* e = getenv("PK_NO_FAST")) ctx->no_fast = atoi(e);
     *out = ctx;
     PK_HIP(ctx, hipSetDevice(device));
     PK_HIP(ctx, hipGetDeviceProperties(&ctx->prop, device));
@@ -407,6 +415,7 @@ int32_t pk_destroy(pk_ctx* ctx) {
     }
     free_particles(ctx);
     if (ctx->d_pack_tmp) (void)hipFree(ctx->d_pack_tmp);
+    if (ctx->d_fast_tab) (void)hipFree(ctx->d_fast_tab);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_summary) (void)hipFree(ctx->d_summary);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
@@ -1049,6 +1058,121 @@ static int32_t fill_args(pk_ctx* ctx, const pk_exec_params* prm, KArgs& a, size_
     return 0;
 }
 
+// Fold the descriptors of the velocity fields and their grid into the wave-uniform constants of the fast A-grid path
+// (pk_device.h: FastA, pk_fast_agrid.h) when its preconditions hold: rectilinear grid with float64 coordinates, XLinear_Velocity,
+// U / V (/ W) plain arrays of one layout with adjacent x-corners, a time level below 4 GiB (32-bit lane offsets), and coordinate
+// vectors whose cell widths have well-scaled reciprocals.  a.fast.ok == 0 otherwise (the general program runs).
+static int32_t fill_fast(pk_ctx* ctx, const pk_exec_params* prm, KArgs& a, bool want_w) {
+    FastA& F = a.fast;
+    memset(&F, 0, sizeof(F));
+    if (ctx->no_fast || prm->interp_uv != 0 || prm->rk45_mode) return 0;  // rk45_mode: dt follows the next_dt column (kernel.py:118-120)
+    const HostField& U = ctx->fields[prm->fU];
+    const HostField& V = ctx->fields[prm->fV];
+    const HostField* W = (want_w && prm->fW >= 0) ? &ctx->fields[prm->fW] : nullptr;
+    if (want_w && !W) return 0;
+    const HostGrid& g = ctx->grids[U.d.grid];
+    if (g.d.kind != 0 || g.d.lon_f32 || g.d.lat_f32 || g.d.depth_f32) return 0;
+    if (V.d.grid != U.d.grid || (W && W->d.grid != U.d.grid)) return 0;
+    auto same = [](const DField& x, const DField& y) {
+        return x.ncomp == 1 && y.ncomp == 1 && x.dtype == y.dtype && x.st_t == y.st_t && x.st_z == y.st_z && x.st_y == y.st_y && x.st_x == y.st_x &&
+               x.nt == y.nt && x.nz == y.nz && x.ny == y.ny && x.nx == y.nx && x.nslots == y.nslots && x.has_time_interval == y.has_time_interval;
+    };
+    if (!same(U.d, V.d) || (W && !same(U.d, W->d))) return 0;
+    if (V.time != U.time || (W && W->time != U.time)) return 0;
+    const DField& f = U.d;
+    const size_t esz = f.dtype == PK_F64 ? 8 : 4;
+    if (!g.d.has_x || f.st_x != 1 || f.nx < 2 || f.nx != g.d.nx) return 0;
+    // an axis the fields extend over must be the grid's axis (then an in-bounds cell index + 1 never needs clipping)
+    const bool fy = f.ny >= 2 && f.st_y > 0, fz = f.nz >= 2 && f.st_z > 0;
+    if (fy && !(g.d.has_y && f.ny == g.d.ny)) return 0;
+    if (fz && !(g.d.has_z && f.nz == g.d.nz)) return 0;
+    if (f.has_time_interval && (f.nt < 2 || U.time.front() != 0.0)) return 0;
+    const uint64_t lvl_b = (uint64_t)f.st_t * esz;
+    const uint64_t last_b = ((uint64_t)f.nz * (uint64_t)f.st_z + (uint64_t)f.ny * (uint64_t)f.st_y + (uint64_t)f.nx) * esz;
+    if (lvl_b >= (1ull << 32) || last_b >= (1ull << 32)) return 0;
+    // coordinate tables, built once per (grid, field)
+    if (ctx->fast_tab_grid != U.d.grid || ctx->fast_tab_field != prm->fU) {
+        ctx->fast_tab_grid = U.d.grid;
+        ctx->fast_tab_field = prm->fU;
+        ctx->fast_tab_ok = false;
+        std::vector<double> tab;
+        bool ok = true;
+        auto push = [&](const double* arr, int n) {
+            for (int i = 0; i < n; i++) {
+                double r = 0.0;
+                if (i + 1 < n) {
+                    const double d = arr[i + 1] - arr[i];
+                    r = 1.0 / d;
+                    if (!(d > 1e-100 && d < 1e100) || !std::isfinite(r)) ok = false;
+                }
+                tab.push_back(arr[i]);
+                tab.push_back(r);
+            }
+        };
+        const int nt = f.has_time_interval ? f.nt : 0;
+        const int nz = g.d.has_z ? g.d.nz : 0, ny = g.d.has_y ? g.d.ny : 0, nx = g.d.nx;
+        ctx->fast_tab_off[0] = 0;
+        push(U.time.data(), nt);
+        ctx->fast_tab_off[1] = (int32_t)(tab.size() / 2);
+        std::vector<double> tmp;
+        auto fetch = [&](const double* dev, int n) -> int32_t {
+            tmp.assign((size_t)std::max(n, 0), 0.0);
+            if (n > 0) PK_HIP(ctx, hipMemcpy(tmp.data(), dev, sizeof(double) * n, hipMemcpyDeviceToHost));
+            return 0;
+        };
+        if (int32_t rc = fetch(g.d.depth, nz)) return rc;
+        push(tmp.data(), nz);
+        ctx->fast_tab_off[2] = (int32_t)(tab.size() / 2);
+        if (int32_t rc = fetch(g.d.lat, ny)) return rc;
+        push(tmp.data(), ny);
+        ctx->fast_tab_off[3] = (int32_t)(tab.size() / 2);
+        if (int32_t rc = fetch(g.d.lon, nx)) return rc;
+        push(tmp.data(), nx);
+        ctx->fast_tab_off[4] = (int32_t)(tab.size() / 2);
+        if (tab.size() * sizeof(double) > 60 * 1024) ok = false;  // must fit the LDS of a workgroup
+        if (ok) {
+            if (tab.size() > ctx->fast_tab_cap) {
+                PK_HIP(ctx, hipStreamSynchronize(ctx->compute));
+                if (ctx->d_fast_tab) PK_HIP(ctx, hipFree(ctx->d_fast_tab));
+                PK_HIP(ctx, hipMalloc((void**)&ctx->d_fast_tab, tab.size() * sizeof(double)));
+                ctx->fast_tab_cap = tab.size();
+            }
+            PK_HIP(ctx, hipStreamSynchronize(ctx->compute));
+            PK_HIP(ctx, hipMemcpy(ctx->d_fast_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+        ctx->fast_tab_ok = ok;
+    }
+    if (!ctx->fast_tab_ok) return 0;
+    const double inv_deg2m = 1.0 / g.d.deg2m;
+    if (!(g.d.deg2m > 1e-100 && g.d.deg2m < 1e100) || !std::isfinite(inv_deg2m)) return 0;
+    F.grid = U.d.grid;
+    F.has_ti = f.has_time_interval;
+    F.has_z = g.d.has_z; F.has_y = g.d.has_y; F.has_x = g.d.has_x;
+    F.spherical = g.d.spherical;
+    F.nt = f.nt;
+    F.nslots = f.nslots;
+    F.gnz = g.d.nz; F.gny = g.d.ny; F.gnx = g.d.nx;
+    uint32_t stride = 1;
+    if (g.d.has_x) { F.ex = stride; stride *= (uint32_t)g.d.xdim; }
+    if (g.d.has_y) { F.ey = stride; stride *= (uint32_t)g.d.ydim; }
+    if (g.d.has_z) { F.ez = stride; }
+    F.st_z = (uint32_t)f.st_z;
+    F.st_y = (uint32_t)f.st_y;
+    F.dyb = fy ? (uint32_t)(f.st_y * esz) : 0u;
+    F.dzb = fz ? (uint32_t)(f.st_z * esz) : 0u;
+    F.lds_time = ctx->fast_tab_off[0]; F.lds_depth = ctx->fast_tab_off[1]; F.lds_lat = ctx->fast_tab_off[2]; F.lds_lon = ctx->fast_tab_off[3];
+    F.lds_n = ctx->fast_tab_off[4];
+    F.lvl_b = (int64_t)lvl_b;
+    F.U = (const char*)U.d.data; F.V = (const char*)V.d.data; F.W = W ? (const char*)W->d.data : nullptr;
+    F.tab = ctx->d_fast_tab;
+    F.tlen = f.tlen; F.t0 = f.tfirst; F.t1 = f.tlast;
+    F.z0 = g.d.zfirst; F.z1 = g.d.zlast; F.y0 = g.d.yfirst; F.y1 = g.d.ylast; F.x0 = g.d.xfirst; F.x1 = g.d.xlast;
+    F.deg2m = g.d.deg2m;
+    F.inv_deg2m = inv_deg2m;
+    F.ok = 1;
+    return 0;
+}
+
 int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
     if (!ctx || !prm) return -2;
     if (!ctx->bound) return ctx->fail("no particles bound");
@@ -1095,6 +1219,10 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
             if (prm->kernels[0] == PK_KERNEL_ADVECTIONDIFFUSION_M1 && !ctx->no_special) prog = PROG_M1;
         }
         if (ctx_is_typed(ctx)) prog = PROG_TYPED;
+        if ((prog == PROG_RK4 || prog == PROG_RK4_3D) && !curv) {
+            rc = fill_fast(ctx, prm, a, prog == PROG_RK4_3D);
+            if (rc) return rc;
+        }
         if (prm->sort_by_cell) {
             PK_HIP(ctx, hipEventRecord(ctx->ev2, ctx->compute));
             // curvilinear sort order (measured on the NEMO-size grid): depth-major for 3-D advection (+4 %), horizontal-major
@@ -1109,7 +1237,11 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
             sorted = true;
         }
         PK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->compute));
-        switch (prog) {
+        const size_t fast_lds = (size_t)a.fast.lds_n * 2 * sizeof(double);
+        const int pf32 = ctx->dev.spatial_f32;
+        if (a.fast.ok && prog == PROG_RK4) launch_fast<PROG_RK4>(field_f32, pf32, a, grid, fast_lds, ctx->compute);
+        else if (a.fast.ok && prog == PROG_RK4_3D) launch_fast<PROG_RK4_3D>(field_f32, pf32, a, grid, fast_lds, ctx->compute);
+        else switch (prog) {
             case PROG_RK4: launch_program<PROG_RK4>(field_f32, curv, prm->interp_uv, use_lds, a, grid, lds_bytes, ctx->compute); break;
             case PROG_RK4_3D: launch_program<PROG_RK4_3D>(field_f32, curv, prm->interp_uv, use_lds, a, grid, lds_bytes, ctx->compute); break;
             case PROG_RK45: launch_program<PROG_RK45>(field_f32, curv, prm->interp_uv, use_lds, a, grid, lds_bytes, ctx->compute); break;

@@ -71,6 +71,25 @@ struct DCounters {
     unsigned long long steps, attempts, paused;
 };
 
+// Wave-uniform constants of the fast path for XLinear_Velocity on a rectilinear A-grid with float64 coordinates
+// (pk_fast_agrid.h), folded from the grid / field descriptors by the host (pk_api.hip: fill_fast).
+struct FastA {
+    int32_t ok, grid;                           // preconditions hold; grid id (column of `ei`)
+    int32_t has_ti, has_z, has_y, has_x, spherical;
+    int32_t nt, nslots;                         // time levels of U / V / W and their ring
+    int32_t gnz, gny, gnx;                      // node counts of the grid axes
+    uint32_t ex, ey, ez;                        // ravel strides of `ei` (basegrid.py:83-152), 0 for an axis the grid lacks
+    uint32_t st_z, st_y;                        // element strides of the fields inside a level (st_x == 1)
+    uint32_t dyb, dzb;                          // byte strides to the yi+1 row / zi+1 plane, 0 if the fields have no such neighbour
+    int32_t lds_time, lds_depth, lds_lat, lds_lon, lds_n;  // offsets (in pairs) of the {a, 1/width} tables inside `tab`
+    int32_t pad0;
+    int64_t lvl_b;                              // bytes per time level (< 2^32)
+    const char *U, *V, *W;                      // level rings (W may be NULL)
+    const double* tab;                          // global copy of the interleaved coordinate tables: time | depth | lat | lon
+    double tlen, t0, t1, z0, z1, y0, y1, x0, x1;
+    double deg2m, inv_deg2m;
+};
+
 struct KArgs {
     DGrid grids[PK_MAX_GRIDS];
     DField fields[PK_MAX_FIELDS];
@@ -82,6 +101,7 @@ struct KArgs {
     int32_t lds_time, lds_depth, lds_lat, lds_lon, lds_total;
     int32_t lds_cc_nodes, lds_cc_keys, lds_cc_fvals;  // cell cache (CellCache) offsets in doubles from the LDS base, -1 = off
     int32_t main_grid, main_field;
+    FastA fast;
 };
 
 // ---- small helpers ------------------------------------------------------------------------------------

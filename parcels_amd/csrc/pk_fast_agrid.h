@@ -1,0 +1,312 @@
+// pk_fast_agrid.h -- VectorField.eval for the headline configuration: XLinear_Velocity on a rectilinear A-grid with
+// float64 coordinates (BASELINE config 2; field.py:250-304, index_search.py:20-91, _xinterpolators.py:25-190).
+//
+// Same arithmetic, expression by expression, as the general eval_uvw<FT, 0, 0, false> of pk_device.h -- the parity tests run
+// both against the same fixtures -- but laid out for the CDNA4 issue ports:
+//   * everything the general path re-derives per evaluation from the field / grid descriptors (strides, extents, slot
+//     arithmetic, layout comparisons) is folded into one small `FastA` block of wave-uniform values by the host;
+//   * the 1-D coordinate vectors are staged into LDS as {a[i], 1 / (a[i+1] - a[i])} pairs: the barycentric quotient
+//     (x - a[i]) / (a[i+1] - a[i]) is formed with the correctly rounded reciprocal and two fused residual steps (Markstein's
+//     theorem: identical to the IEEE quotient) -- 5 fp64 issue slots instead of the ~14 of v_div_scale / v_rcp / v_div_fmas;
+//   * the time level, and whether the second time / depth level takes part, is made wave-uniform with a readfirstlane
+//     waterfall (one pass unless particles of one wavefront sit on different time levels): level base addresses live in
+//     SGPRs, every corner-pair load is `global_load_dwordx4 v, v_off, s[base]` with ONE shared 32-bit lane offset, and the
+//     lenT / lenZ selects of the general path become scalar branches;
+//   * the particle storage dtype is a template parameter.
+#pragma once
+#include "pk_device.h"
+
+namespace pk {
+
+// interleaved coordinate table entry: node value and reciprocal of the width of the cell that starts there
+typedef double pk_tab2 __attribute__((ext_vector_type(2)));
+
+struct FastTabs {  // LDS-resident {a, 1/width} tables of the main grid and the velocity field's time axis
+    const pk_tab2* time;
+    const pk_tab2* depth;
+    const pk_tab2* lat;
+    const pk_tab2* lon;
+};
+
+// n / d with r = RN(1/d) (host, IEEE): q0 = RN(n r) is within a few ulp, the fused residual e0 = n - d q0 is exact up to a
+// relative 2^-53 of itself, q1 = RN(q0 + e0 r) is faithful; a second residual step then yields the correctly rounded quotient
+// (Markstein 1990, Thm. 8.5 of Muller et al.'s Handbook: y = RN(1/b), q faithful, r = RN(a - bq) exact => RN(q + r y) = RN(a/b)).
+// Quotients that come out zero, tiny or NaN take the hardware division (the exactness argument needs normal numbers; the widths
+// d are checked by the host to lie in [1e-100, 1e100], so a huge quotient means a huge numerator, which the residuals handle).
+PK_DEV double div_by_recip(double n, double d, double r) {
+    const double q0 = n * r;
+    const double e0 = __builtin_fma(-d, q0, n);
+    const double q1 = __builtin_fma(e0, r, q0);
+    const double e1 = __builtin_fma(-d, q1, n);
+    double q = __builtin_fma(e1, r, q1);
+    // zero, subnormal-range and NaN quotients (an infinite numerator or an overflowing product ends as NaN above)
+    if (__builtin_expect(!(fabs(q) >= 1e-250), 0)) {
+        // rare (a sample point exactly on a node, t exactly on a time level, non-finite input).  The empty volatile asm keeps the
+        // optimiser from if-converting this block: speculated, the 14-instruction hardware division would run on every call
+        double nn = n;
+        asm volatile("" : "+v"(nn));
+        q = nn / d;
+    }
+    return q;
+}
+
+// clip(searchsorted(arr, x, "left") - 1, 0, n-2) over the interleaved table (same walk + bisect as cell_index)
+PK_DEV int cell_index_tab(const pk_tab2* tab, int n, double x, int i) {
+    if (x != x) return n - 2;
+    if (tab[i].x < x) {
+        int k = 0;
+        while (i < n - 2 && tab[i + 1].x < x) {
+            ++i;
+            if (++k == 3) {
+                int lo = i + 1, hi = n;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (tab[mid].x < x) lo = mid + 1; else hi = mid;
+                }
+                i = clampi(lo - 1, 0, n - 2);
+                break;
+            }
+        }
+    } else {
+        int k = 0;
+        while (i > 0 && !(tab[i].x < x)) {
+            --i;
+            if (++k == 3) {
+                int lo = 0, hi = i + 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (tab[mid].x < x) lo = mid + 1; else hi = mid;
+                }
+                i = clampi(lo - 1, 0, n - 2);
+                break;
+            }
+        }
+    }
+    return i;
+}
+
+// _search_1d_array (index_search.py:20-62) for a float64 coordinate: the hinted cell is right for all but the lanes that just
+// crossed a cell edge.  `cell` (in / out): a valid cell index 0..n-2, the hint on entry and the cell found on exit; idx: that
+// cell or the out-of-bounds code.  The cell test is NaN-proof as written: a NaN fails it unless the hint already is the
+// last cell (NumPy sorts NaN last), and cell_index_tab answers n-2.
+PK_DEV void fast_search(const pk_tab2* tab, int n, double first, double last, double x, int& cell, int& idx, double& bc) {
+    if (n < 2) {  // :45-46
+        idx = 0;
+        bc = 0.0;
+        return;
+    }
+    int i = cell;
+    pk_tab2 e = tab[i];
+    double a1 = tab[i + 1].x;
+    const bool ok = (e.x < x || i == 0) && (x <= a1 || i == n - 2);
+    if (!ok) {
+        i = cell_index_tab(tab, n, x, i);
+        e = tab[i];
+        a1 = tab[i + 1].x;
+    }
+    bc = div_by_recip(x - e.x, a1 - e.x, e.y);
+    cell = i;
+    if (x < first) i = LEFT_OUT_OF_BOUNDS;
+    if (x > last) i = RIGHT_OUT_OF_BOUNDS;
+    idx = i;
+}
+
+// The two x-corners of one (level, z, y) row at byte offset `off` from a wave-uniform base: one wide load in saddr form.
+template <class FT>
+PK_DEV void ldrow(const char* base, uint32_t off, double& a, double& b) {
+    ldpair(reinterpret_cast<const FT*>(base + off), a, b);
+}
+
+// XLinear.interp (_xinterpolators.py:112-153) for one field; LT / LZ: the second time / depth level takes part (wave-uniform,
+// compile-time here so that the whole gather + interpolation of a field is ONE basic block of up to 8 wide loads).
+// l0 / l1: wave-uniform bases of the two time levels; b00: byte offset of corner (zi, yi, xi) inside a level; dyb / dzb: byte
+// strides to the yi+1 row / zi+1 plane (0 on an axis the field does not have).
+struct Rows {  // the (up to) 16 corner values of one field: [time level][z][y] rows of two x-neighbours
+    double c00, c01, c10, c11, t00, t01, t10, t11, d00, d01, d10, d11, e00, e01, e10, e11;
+};
+template <class FT, bool LT, bool LZ>
+PK_DEV void load_rows(Rows& r, const char* l0, const char* l1, uint32_t b00, uint32_t dyb, uint32_t dzb) {
+    ldrow<FT>(l0, b00, r.c00, r.c01);
+    ldrow<FT>(l0 + dyb, b00, r.c10, r.c11);
+    if (LT) {
+        ldrow<FT>(l1, b00, r.t00, r.t01);
+        ldrow<FT>(l1 + dyb, b00, r.t10, r.t11);
+    }
+    if (LZ) {
+        ldrow<FT>(l0 + dzb, b00, r.d00, r.d01);
+        ldrow<FT>(l0 + dzb + dyb, b00, r.d10, r.d11);
+        if (LT) {
+            ldrow<FT>(l1 + dzb, b00, r.e00, r.e01);
+            ldrow<FT>(l1 + dzb + dyb, b00, r.e10, r.e11);
+        }
+    }
+}
+// lerp in t, then z, then bilinear in (eta, xsi) with the weights (1-xsi)(1-eta), xsi(1-eta), (1-xsi)eta, xsi*eta shared by U, V, W
+template <bool LT, bool LZ>
+PK_DEV double interp_rows(const Rows& r, double tau, double omt, double zeta, double omz, double w00, double w01, double w10, double w11) {
+    double c00 = r.c00, c01 = r.c01, c10 = r.c10, c11 = r.c11;
+    if (LT) {
+        c00 = c00 * omt + r.t00 * tau; c01 = c01 * omt + r.t01 * tau;
+        c10 = c10 * omt + r.t10 * tau; c11 = c11 * omt + r.t11 * tau;
+    }
+    if (LZ) {
+        double d00 = r.d00, d01 = r.d01, d10 = r.d10, d11 = r.d11;
+        if (LT) {
+            d00 = d00 * omt + r.e00 * tau; d01 = d01 * omt + r.e01 * tau;
+            d10 = d10 * omt + r.e10 * tau; d11 = d11 * omt + r.e11 * tau;
+        }
+        c00 = c00 * omz + d00 * zeta; c01 = c01 * omz + d01 * zeta;
+        c10 = c10 * omz + d10 * zeta; c11 = c11 * omz + d11 * zeta;
+    }
+    return w00 * c00 + w01 * c01 + w10 * c10 + w11 * c11;
+}
+
+// U, V (and W) of one evaluation.  PK_FAST_BATCH: 8 = the corner rows of one field are requested back to back (one memory round
+// trip per field), 16 = those of U and V together (more registers), 4 = left to the scheduler.  The fences keep the machine
+// scheduler from sinking the loads back between the arithmetic.
+#ifndef PK_FAST_BATCH
+#define PK_FAST_BATCH 8
+#endif
+template <class FT, bool D3, bool LT, bool LZ>
+PK_DEV void uvw_fast(const FastA& F, int64_t o0, int64_t o1, uint32_t b00, double tau, double omt, double zeta, double omz, double w00,
+                     double w01, double w10, double w11, double& uu, double& vv, double& ww) {
+    // keep the 32-bit lane offset opaque up to here: its zero-extension must sit in the basic block of the loads for the
+    // instruction selector to fold it into the `saddr + voffset` addressing mode (otherwise one 64-bit VALU add per load)
+    uint32_t bo = b00;
+    asm volatile("" : "+v"(bo));
+    Rows ru, rv, rw;
+    load_rows<FT, LT, LZ>(ru, F.U + o0, F.U + o1, bo, F.dyb, F.dzb);
+#if PK_FAST_BATCH == 16
+    load_rows<FT, LT, LZ>(rv, F.V + o0, F.V + o1, bo, F.dyb, F.dzb);
+#endif
+#if PK_FAST_BATCH >= 8
+    PK_FIELD_FENCE();
+#endif
+    uu = interp_rows<LT, LZ>(ru, tau, omt, zeta, omz, w00, w01, w10, w11);
+#if PK_FAST_BATCH != 16
+    load_rows<FT, LT, LZ>(rv, F.V + o0, F.V + o1, bo, F.dyb, F.dzb);
+#if PK_FAST_BATCH >= 8
+    PK_FIELD_FENCE();
+#endif
+#endif
+    vv = interp_rows<LT, LZ>(rv, tau, omt, zeta, omz, w00, w01, w10, w11);
+    if (D3) {
+        load_rows<FT, LT, LZ>(rw, F.W + o0, F.W + o1, bo, F.dyb, F.dzb);
+#if PK_FAST_BATCH >= 8
+        PK_FIELD_FENCE();
+#endif
+        ww = interp_rows<LT, LZ>(rw, tau, omt, zeta, omz, w00, w01, w10, w11);
+    }
+}
+
+PK_DEV int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Per-particle evaluation context of the fast kernels.  Besides the status code and the `ei` entry of the velocity grid it holds
+// the cells of the previous evaluation (always valid cell indices: the search hints) and a memo of the last time and depth
+// searched: the search is a pure function of the coordinate, and the Runge-Kutta stages revisit t (stages 2 and 3 share
+// t + dt/2; stage 4 of one step and stage 1 of the next share t + dt) and, in the 2-D kernels, never move z.
+struct FCtx {
+    int state;
+    int32_t ei;
+    int ht, hz, hy, hx;
+    int zi;                      // memo: index (or out-of-bounds code) of the last depth searched
+    double mt, mtau, mz, mzeta;  // memo keys (bitwise-equal coordinate => same answer) and barycentric values
+};
+PK_DEV void fctx_init(FCtx& c, int state, int32_t ei) {
+    c.state = state;
+    c.ei = ei;
+    c.ht = c.hz = c.hy = c.hx = 0;
+    c.zi = 0;
+    c.mt = c.mz = __builtin_nan("");  // equal to nothing
+    c.mtau = c.mzeta = 0.0;
+}
+
+// VectorField.eval (field.py:250-304) + XLinear_Velocity.interp (_xinterpolators.py:169-190).  PF: the sample point may come
+// straight from float32 particle storage (pos_f32); D3: sample W as well.
+template <class FT, bool PF, bool D3>
+PK_DEV void eval_uvw_fast(const KArgs& a, const FastTabs& T, FCtx& c, double t, double z, double y, double x, bool pos_f32, double& u,
+                          double& v, double& w) {
+    const FastA& F = a.fast;
+    u = v = w = 0.0;
+    int ti = 0;
+    double tau = 0.0;
+    if (F.has_ti) {  // _search_time_index (index_search.py:65-91)
+        if (!(0 <= t) || !(t <= F.tlen)) {
+            c.state = PK_ERROROUTSIDETIMEINTERVAL;
+            return;
+        }
+        if (t != c.mt) {
+            int idx;
+            fast_search(T.time, F.nt, F.t0, F.t1, t, c.ht, idx, c.mtau);  // level times start at 0 (host check): idx == c.ht
+            c.mt = t;
+        }
+        ti = c.ht;
+        tau = c.mtau;
+    }
+    int zi = 0, yi = 0, xi = 0;
+    double zeta = 0.0, eta = 0.0, xsi = 0.0;
+    if (F.has_z) {
+        if (!(z == c.mz)) {
+            fast_search(T.depth, F.gnz, F.z0, F.z1, z, c.hz, c.zi, c.mzeta);
+            c.mz = z;
+        }
+        zi = c.zi;
+        zeta = c.mzeta;
+    }
+    if (F.has_y) fast_search(T.lat, F.gny, F.y0, F.y1, y, c.hy, yi, eta);
+    if (F.has_x) fast_search(T.lon, F.gnx, F.x0, F.x1, x, c.hx, xi, xsi);
+    // ravel_index (basegrid.py:83-152): the low 32 bits of the int64 sum are the wrapped 32-bit sum
+    c.ei = (int32_t)((uint32_t)xi * F.ex + (uint32_t)yi * F.ey + (uint32_t)zi * F.ez);
+    if (__builtin_expect((xi | yi | zi) < 0, 0)) {  // some index carries an out-of-bounds code (-1 right, -2 left)
+        int s = c.state;  // field.py:307-356
+        if ((xi == RIGHT_OUT_OF_BOUNDS || yi == RIGHT_OUT_OF_BOUNDS || zi == RIGHT_OUT_OF_BOUNDS) && s < PK_ERROROUTOFBOUNDS) s = PK_ERROROUTOFBOUNDS;
+        if (zi == LEFT_OUT_OF_BOUNDS && s < PK_ERRORTHROUGHSURFACE) s = PK_ERRORTHROUGHSURFACE;
+        // field.py:359-378: a non-finite barycentric coordinate makes the (wrapped-around) gather NaN, then everything is zeroed
+        const bool bad = !(isfinite(xsi) && isfinite(eta) && isfinite(zeta) && isfinite(tau));
+        if (bad && s < PK_ERRORINTERPOLATION) s = PK_ERRORINTERPOLATION;
+        c.state = s;
+        return;
+    }
+    const bool lenT = tau > 0, lenZ = !(zeta <= 0);
+    const int key = (ti << 2) | (lenT ? 2 : 0) | (lenZ ? 1 : 0);
+    const uint32_t b00 = ((uint32_t)zi * F.st_z + (uint32_t)yi * F.st_y + (uint32_t)xi) * (uint32_t)sizeof(FT);
+    const double omt = 1 - tau, omz = 1 - zeta, omx = 1 - xsi, ome = 1 - eta;
+    const double w00 = omx * ome, w01 = xsi * ome, w10 = omx * eta, w11 = xsi * eta;
+    double uu = 0.0, vv = 0.0, ww = 0.0;
+    for (bool done = false; !done;) {
+        // everything derived from the wave-uniform key is formed BEFORE the lane test: inside `if (key == uk)` the optimiser
+        // may substitute the (divergent) key for uk, which would move the level arithmetic back into vector registers
+        const int uk = uniform_i32(key);
+        const int uti = uk >> 2;
+        int s0 = uti, s1 = uti + 1;  // has_ti: 0 <= ti <= nt-2; otherwise ti == 0 and the second level is never read
+        if (F.nslots < F.nt) {       // ring of time levels: level L lives in slot L % nslots
+            s0 = (int)((uint32_t)s0 % (uint32_t)F.nslots);
+            s1 = (int)((uint32_t)s1 % (uint32_t)F.nslots);
+        }
+        int64_t o0 = (int64_t)s0 * F.lvl_b, o1 = (int64_t)s1 * F.lvl_b;
+        int lens = uk & 3;
+        asm volatile("" : "+s"(o0), "+s"(o1), "+s"(lens));  // opaque scalars: no path back to the divergent key
+        if (key == uk) {
+            if (lens == 3) uvw_fast<FT, D3, true, true>(F, o0, o1, b00, tau, omt, zeta, omz, w00, w01, w10, w11, uu, vv, ww);
+            else if (lens == 2) uvw_fast<FT, D3, true, false>(F, o0, o1, b00, tau, omt, zeta, omz, w00, w01, w10, w11, uu, vv, ww);
+            else if (lens == 1) uvw_fast<FT, D3, false, true>(F, o0, o1, b00, tau, omt, zeta, omz, w00, w01, w10, w11, uu, vv, ww);
+            else uvw_fast<FT, D3, false, false>(F, o0, o1, b00, tau, omt, zeta, omz, w00, w01, w10, w11, uu, vv, ww);
+            done = true;
+        }
+    }
+    if (F.spherical) {  // _xinterpolators.py:183-187
+        double conv;
+        if (PF && pos_f32) conv = (double)((float)F.deg2m * cosf((float)y * DEG2RADF));
+        else conv = F.deg2m * cos_lat(y * DEG2RAD);
+        uu /= conv;
+        vv = div_by_recip(vv, F.deg2m, F.inv_deg2m);
+    }
+    if (__builtin_expect(uu != uu || vv != vv || ww != ww, 0)) {  // field.py:373-378
+        if (c.state < PK_ERRORINTERPOLATION) c.state = PK_ERRORINTERPOLATION;
+    }
+    u = uu;
+    v = vv;
+    w = ww;
+}
+
+}  // namespace pk

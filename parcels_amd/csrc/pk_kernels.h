@@ -13,6 +13,7 @@
 // kernel-list program (KID = -1).
 #pragma once
 #include "pk_device.h"
+#include "pk_fast_agrid.h"
 
 namespace pk {
 
@@ -342,9 +343,10 @@ PK_DEV unsigned xcd_swizzle(unsigned bid, unsigned nb) {
 #ifndef PK_MIN_WAVES_HEAVY
 #define PK_MIN_WAVES_HEAVY 2
 #endif
-template <class FT, int KIND, int INTERP, int KID, bool LDS, bool TYPED>
+// PFM: particle storage dtype -- 0 float64, 1 float32, -1 decided at run time (P.spatial_f32).
+template <class FT, int KIND, int INTERP, int KID, bool LDS, bool TYPED, int PFM = -1>
 __global__ void __launch_bounds__(256, (KIND == 1 || INTERP != 0) ? PK_MIN_WAVES_HEAVY : PK_MIN_WAVES) advect_kernel(const KArgs a) {
-    extern __shared__ double smem[];
+    extern __shared__ __attribute__((aligned(16))) double smem[];
     const DField& mf = a.fields[a.main_field];
     const DGrid& mg = a.grids[a.main_grid];
     Coords mc;
@@ -395,7 +397,7 @@ __global__ void __launch_bounds__(256, (KIND == 1 || INTERP != 0) ? PK_MIN_WAVES
         const DParticles& P = a.p;
         const pk_exec_params& prm = a.prm;
         PCtx c;
-        const bool pf = P.spatial_f32 != 0;
+        const bool pf = PFM < 0 ? (P.spatial_f32 != 0) : (PFM == 1);
         c.pf = pf;
         c.state = prm.reset_state ? PK_EVALUATE : P.state[i];  // kernel.py:188
         if (c.state == PK_EVALUATE) {
@@ -513,11 +515,152 @@ __global__ void __launch_bounds__(256, (KIND == 1 || INTERP != 0) ? PK_MIN_WAVES
     }
 }
 
+// ---- the headline kernel: AdvectionRK4 / AdvectionRK4_3D on a rectilinear A-grid with float64 coordinates -----------------
+// Same step loop as advect_kernel (Kernel.execute, kernel.py:174-247) with the Runge-Kutta stages of _advection.py:42-75 written
+// out around ONE evaluation site (pk_fast_agrid.h) instead of the prepare / consume stage machine: fewer loop-carried values,
+// no kernel-local register array, particle dtype and dimensionality fixed at compile time.
+#ifndef PK_MIN_WAVES_FAST
+#define PK_MIN_WAVES_FAST 4
+#endif
+template <class FT, int PFM, bool D3>
+__global__ void __launch_bounds__(256, PK_MIN_WAVES_FAST) advect_fast_kernel(const KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    FastTabs ft;
+    {
+        // {a[i], 1 / (a[i+1] - a[i])} tables of time | depth | lat | lon, staged once per workgroup (coalesced 16-byte copies)
+        pk_tab2* s_tab = reinterpret_cast<pk_tab2*>(smem);
+        const pk_tab2* g_tab = reinterpret_cast<const pk_tab2*>(a.fast.tab);
+        for (int k = threadIdx.x; k < a.fast.lds_n; k += 256) s_tab[k] = g_tab[k];
+        __syncthreads();
+        ft.time = s_tab + a.fast.lds_time;
+        ft.depth = s_tab + a.fast.lds_depth;
+        ft.lat = s_tab + a.fast.lds_lat;
+        ft.lon = s_tab + a.fast.lds_lon;
+    }
+    // the row index is re-derived where it is needed (entry and exit) instead of living in two registers across the step loop
+    auto row = [&]() { return (int64_t)xcd_swizzle(blockIdx.x, gridDim.x) * 256 + threadIdx.x; };
+    unsigned steps = 0, attempts = 0, paused = 0;  // per lane and launch: 32 bits are plenty
+    if (row() < a.p.n) {
+        int64_t i = row();
+        const DParticles& P = a.p;
+        const pk_exec_params& prm = a.prm;
+        constexpr bool pf = PFM == 1;
+        FCtx c;
+        c.state = prm.reset_state ? PK_EVALUATE : P.state[i];  // kernel.py:188
+        if (c.state == PK_EVALUATE) {
+            fctx_init(c, PK_EVALUATE, P.ei[i * P.ngrids + a.fast.grid]);  // only the velocity grid's `ei` is touched
+            double pt = P.t[i];
+            double pz = ldp(P.z, i, pf), py = ldp(P.y, i, pf), px = ldp(P.x, i, pf);
+            double pdz = ldp(P.dz, i, pf), pdy = ldp(P.dy, i, pf), pdx = ldp(P.dx, i, pf);
+            double pdt = P.dt[i];
+            const double endtime = prm.endtime;
+            const int sign = prm.dt0 > 0 ? 1 : -1;  // kernel.py:186
+            const bool windowed = a.fast.has_ti != 0;
+            while (c.state == PK_EVALUATE) {  // :190 (no kernel of these programs sets Repeat)
+                const double tte = sign * (endtime - pt);
+                if (!(tte >= 0)) break;  // :193-197
+                double dtc;
+                if (sign == 1) dtc = fmax(fmin(pdt, tte), 0.0);  // :200-203
+                else dtc = fmin(fmax(pdt, -tte), 0.0);
+                if (windowed) {  // field-slab streaming: step only inside the resident time window (advect_kernel)
+                    const double t1 = pt + dtc;
+                    const double lo = fmin(pt, t1), hi = fmax(pt, t1);
+                    if (lo < a.win_lo || hi > a.win_hi) { paused = 1; break; }
+                }
+                pdt = dtc;
+                attempts++;
+                // AdvectionRK4(_3D), _advection.py:42-75: (u1 + 2*u2 + 2*u3 + u4) summed left to right
+                double su = 0.0, sv = 0.0, sw = 0.0, lu = 0.0, lv = 0.0, lw = 0.0;
+#pragma unroll 1
+                for (int stage = 0; stage < 4; stage++) {
+                    double st = pt, sz = pz, sy = py, sx = px;
+                    if (stage > 0) {
+                        const double cdt = stage == 3 ? 1.0 : 0.5;  // u*1.0 == u and 1.0*dt == dt exactly
+                        sx = px + lu * cdt * pdt;
+                        sy = py + lv * cdt * pdt;
+                        if (D3) sz = pz + lw * cdt * pdt;
+                        st = pt + cdt * pdt;
+                    }
+                    double u, v, w;
+                    eval_uvw_fast<FT, pf, D3>(a, ft, c, st, sz, sy, sx, pf && stage == 0, u, v, w);
+                    if (stage == 0) { su = u; sv = v; sw = w; }
+                    else if (stage == 3) { su = su + u; sv = sv + v; sw = sw + w; }
+                    else { su = su + 2 * u; sv = sv + 2 * v; sw = sw + 2 * w; }
+                    lu = u; lv = v; lw = w;
+                }
+                constexpr double sixth = 1.0 / 6.0;  // RN(1/6): su / 6.0 exactly (div_by_recip)
+                pdx = pstore(pf, pdx + div_by_recip(su, 6.0, sixth) * pdt);
+                pdy = pstore(pf, pdy + div_by_recip(sv, 6.0, sixth) * pdt);
+                if (D3) pdz = pstore(pf, pdz + div_by_recip(sw, 6.0, sixth) * pdt);
+                for (int k = 1; k < prm.nk; k++) {  // the sampling-free recovery kernels that may follow (Delete*)
+                    const int kid = prm.kernels[k];
+                    attempts++;
+                    if (kid == PK_KERNEL_DELETE_ON_ERROR) {
+                        if (c.state >= PK_ERROR) c.state = PK_DELETE;
+                    } else if (c.state == PK_ERROROUTOFBOUNDS || c.state == PK_ERRORTHROUGHSURFACE) {
+                        c.state = PK_DELETE;  // PK_KERNEL_DELETE_OUT_OF_BOUNDS
+                    }
+                }
+                if (c.state == PK_EVALUATE || c.state == PK_SUCCESS) {  // :219-222 -> _position_update :108-120
+                    if (tte > 0 && pt + pdt == pt) {  // dt == 0 before endtime: see advect_kernel
+                        c.state = PK_ERROR;
+                        break;
+                    }
+                    px = padd(pf, px, pdx);
+                    py = padd(pf, py, pdy);
+                    pz = padd(pf, pz, pdz);
+                    pt += pdt;
+                    pdx = pdy = pdz = 0.0;
+                    steps++;
+                }
+                pdt = prm.dt0;                                                        // :225-226 (not RK45 mode)
+                if (c.state == PK_EVALUATE && pt == endtime) c.state = PK_ENDOFLOOP;  // :229-230
+            }
+            i = row();
+            asm volatile("" : "+v"(i));  // keep it re-derived: not hoisted above the loop
+            P.t[i] = pt;
+            stp(P.z, i, pz, pf);
+            stp(P.y, i, py, pf);
+            stp(P.x, i, px, pf);
+            stp(P.dz, i, pdz, pf);
+            stp(P.dy, i, pdy, pf);
+            stp(P.dx, i, pdx, pf);
+            P.dt[i] = pdt;
+            P.state[i] = c.state;
+            P.ei[i * P.ngrids + a.fast.grid] = c.ei;
+        }
+    }
+    const unsigned long long wsteps = wave_sum((unsigned long long)steps), wattempts = wave_sum((unsigned long long)attempts),
+                             wpaused = wave_sum((unsigned long long)paused);
+    if ((threadIdx.x & 63) == 0) {
+        if (wsteps) atomicAdd(&a.counters->steps, wsteps);
+        if (wattempts) atomicAdd(&a.counters->attempts, wattempts);
+        if (wpaused) atomicAdd(&a.counters->paused, wpaused);
+    }
+}
+
 // One translation unit per program (compiled in parallel) defines launch_program<PROG>.
 // key bits: field f32 | curvilinear | C-grid ; lds: coordinate vectors staged in LDS
 template <int PROG>
 void launch_program(int field_f32, int curvilinear, int interp, int lds, const KArgs& a, dim3 grid, size_t lds_bytes,
                     hipStream_t stream);
+
+// fast single-kernel programs (pk_fast_agrid.h): one TU per program defines launch_fast<PROG>
+template <int PROG>
+void launch_fast(int field_f32, int particles_f32, const KArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream);
+
+#define PK_LAUNCH_FAST_CASE(FT, PF) \
+    hipLaunchKernelGGL((advect_fast_kernel<FT, PF, KIDV == PK_KERNEL_ADVECTION_RK4_3D>), grid, dim3(256), lds_bytes, stream, a)
+#define PK_DEFINE_LAUNCH_FAST(PROGV, KID_)                                                                              \
+    template <>                                                                                                         \
+    void launch_fast<PROGV>(int field_f32, int particles_f32, const KArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream) { \
+        constexpr int KIDV = KID_;                                                                                      \
+        if (field_f32) {                                                                                                \
+            if (particles_f32) PK_LAUNCH_FAST_CASE(float, 1); else PK_LAUNCH_FAST_CASE(float, 0);                       \
+        } else {                                                                                                        \
+            if (particles_f32) PK_LAUNCH_FAST_CASE(double, 1); else PK_LAUNCH_FAST_CASE(double, 0);                     \
+        }                                                                                                               \
+    }
 
 #define PK_LAUNCH_CASE(FT, KD, IN, LD) \
     hipLaunchKernelGGL((advect_kernel<FT, KD, IN, KIDV, LD, TYPEDV>), grid, dim3(256), lds_bytes, stream, a)
