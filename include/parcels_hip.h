@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PK_ABI_VERSION 2
+#define PK_ABI_VERSION 3
 #define PK_MAX_GRIDS 4
 #define PK_MAX_FIELDS 8
 #define PK_MAX_KERNELS 8
@@ -74,6 +74,16 @@ int32_t pk_abi_version(void);
 int32_t pk_init(int32_t device, pk_ctx** out);
 int32_t pk_destroy(pk_ctx* ctx);
 const char* pk_last_error(const pk_ctx* ctx); /* ctx may be NULL: error of the last failed pk_init */
+
+/* Tuning / A-B switches of the library (the reference has no counterpart; its behaviour is the same for every setting):
+ *   "fast_path"        1 (default) AdvectionRK4 / AdvectionRK4_3D with XLinear_Velocity on a rectilinear grid with float64
+ *                      coordinates run the dedicated kernels of csrc/pk_fast_agrid.h; 0 = the general program
+ *   "special_programs" 1 (default) single-kernel programs for AdvectionRK45 / AdvectionDiffusionM1; 0 = kernel-list interpreter
+ *   "cell_cache"       1 (default) per-lane LDS cache of the curvilinear cell;  "hash_directory" 1 (default) key directory;
+ *                      both take effect for grids created / launches made afterwards
+ *   "sort_horizontal"  -1 (default) automatic, 0 depth-major, 1 horizontal-major cell sort of curvilinear grids
+ * Environment variables PK_NO_FAST, PK_NO_SPECIAL, PK_NO_CELL_CACHE, PK_NO_HASH_DIR, PK_SORT_HORIZONTAL give the initial values. */
+int32_t pk_set_option(pk_ctx* ctx, const char* name, int32_t value);
 
 typedef struct pk_device_info {
     char name[128];
@@ -165,6 +175,10 @@ int32_t pk_field_create(pk_ctx* ctx, const pk_field_desc* desc, int32_t* field_i
  * overlaps the RK sub-steps running on level k.  Stands in for WindowedArray._ensure (_windowed_array.py:56-72). */
 int32_t pk_field_upload_level(pk_ctx* ctx, int32_t field_id, int32_t level, const void* host_data, int32_t async);
 int32_t pk_field_sync(pk_ctx* ctx); /* wait for the copy stream and commit every pending level */
+/* Drop every committed level of the field's ring outside [lo_level, hi_level] (WindowedArray's eviction behind the clock,
+ * _windowed_array.py:64-72, for either time direction or a jump): pk_execute requires the resident levels of a ring to be
+ * contiguous, and the particles pause at the edge of the intersection of all rings' windows. */
+int32_t pk_field_evict_outside(pk_ctx* ctx, int32_t field_id, int32_t lo_level, int32_t hi_level);
 /* which committed level each ring slot currently holds (-1 = empty/pending); `levels` has room for nslots ints */
 int32_t pk_field_slots(pk_ctx* ctx, int32_t field_id, int32_t* levels, int32_t* nslots);
 

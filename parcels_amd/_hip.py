@@ -13,7 +13,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PARCELS_HIP_LIB", os.path.join(_HERE, "libparcels_hip.so"))  # override: A/B builds
 
-PK_ABI_VERSION = 2
+PK_ABI_VERSION = 3
 PK_F32, PK_F64 = 0, 1
 PK_MAX_GRIDS, PK_MAX_FIELDS, PK_MAX_KERNELS, PK_NUM_STATE_CODES = 4, 8, 8, 80
 COLUMN_BITS = {n: 1 << i for i, n in enumerate(
@@ -176,6 +176,7 @@ ABI_SYMBOLS = [
     "pk_field_upload_level",
     "pk_field_sync",
     "pk_field_slots",
+    "pk_field_evict_outside",
     "pk_particles_bind",
     "pk_particles_h2d",
     "pk_particles_d2h",
@@ -188,6 +189,7 @@ ABI_SYMBOLS = [
     "pk_eval",
     "pk_search",
     "pk_measure_copy_bandwidth",
+    "pk_set_option",
 ]
 
 _lib = None
@@ -227,6 +229,7 @@ def load():
     lib.pk_field_create.argtypes = [C.c_void_p, C.POINTER(FieldDesc), C.POINTER(C.c_int32)]
     lib.pk_field_upload_level.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
     lib.pk_field_sync.argtypes = [C.c_void_p]
+    lib.pk_field_evict_outside.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     lib.pk_field_slots.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.pk_particles_bind.argtypes = [C.c_void_p, C.POINTER(ParticlesDesc)]
     lib.pk_particles_h2d.argtypes = [C.c_void_p]
@@ -240,6 +243,7 @@ def load():
     lib.pk_eval.argtypes = [C.c_void_p, C.POINTER(ExecParams), C.c_int32, C.c_int64] + [C.c_void_p] * 8
     lib.pk_search.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pk_measure_copy_bandwidth.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_double)]
+    lib.pk_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
     if lib.pk_abi_version() != PK_ABI_VERSION:
         raise HipLibraryError(f"ABI version mismatch: library {lib.pk_abi_version()}, binding {PK_ABI_VERSION}")
     _lib = lib
@@ -276,6 +280,10 @@ class Context:
             "total_mem": info.total_mem,
             "free_mem": info.free_mem,
         }
+
+    def set_option(self, name: str, value: int):
+        """Tuning / A-B switches (include/parcels_hip.h: pk_set_option), e.g. set_option("fast_path", 0)."""
+        self.check(self.lib.pk_set_option(self.handle, name.encode(), int(value)), f"pk_set_option({name})")
 
     def copy_bandwidth(self, nbytes: int = 1 << 30, iters: int = 10) -> float:
         g = C.c_double()

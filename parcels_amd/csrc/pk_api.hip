@@ -383,6 +383,18 @@ int32_t pk_init(int32_t device, pk_ctx** out) {
     return 0;
 }
 
+int32_t pk_set_option(pk_ctx* ctx, const char* name, int32_t value) {
+    if (!ctx || !name) return -2;
+    const std::string n(name);
+    if (n == "fast_path") ctx->no_fast = !value;
+    else if (n == "special_programs") ctx->no_special = !value;
+    else if (n == "cell_cache") ctx->no_cell_cache = !value;
+    else if (n == "hash_directory") ctx->no_hash_dir = !value;
+    else if (n == "sort_horizontal") ctx->sort_horizontal_major = value;
+    else return ctx->fail("pk_set_option: unknown option '" + n + "'");
+    return 0;
+}
+
 static void free_particles(pk_ctx* ctx) {
     void* cols[] = {ctx->dev.t,  ctx->dev.z,  ctx->dev.y,       ctx->dev.x,     ctx->dev.dz, ctx->dev.dy,
                     ctx->dev.dx, ctx->dev.dt, ctx->dev.next_dt, ctx->dev.state, ctx->dev.ei, ctx->dev.particle_id};
@@ -710,6 +722,17 @@ int32_t pk_field_sync(pk_ctx* ctx) {
     return 0;
 }
 
+int32_t pk_field_evict_outside(pk_ctx* ctx, int32_t field_id, int32_t lo_level, int32_t hi_level) {
+    if (!ctx) return -2;
+    if (field_id < 0 || field_id >= (int)ctx->fields.size()) return ctx->fail("unknown field id");
+    if (ctx->in_flight) return ctx->fail("pk_field_evict_outside: a launch is in flight");
+    HostField& f = ctx->fields[field_id];
+    if (f.d.nslots >= f.desc.nt) return 0;  // all levels resident: nothing to evict
+    for (size_t k = 0; k < f.slot_level.size(); k++)
+        if (f.slot_level[k] >= 0 && (f.slot_level[k] < lo_level || f.slot_level[k] > hi_level)) f.slot_level[k] = -1;
+    return 0;
+}
+
 int32_t pk_field_slots(pk_ctx* ctx, int32_t field_id, int32_t* levels, int32_t* nslots) {
     if (!ctx) return -2;
     if (field_id < 0 || field_id >= (int)ctx->fields.size()) return ctx->fail("unknown field id");
@@ -1010,19 +1033,20 @@ static int32_t fill_args(pk_ctx* ctx, const pk_exec_params* prm, KArgs& a, size_
     a.main_grid = ctx->fields[prm->fU].d.grid;
     const HostField& mf = ctx->fields[prm->fU];
     const HostGrid& mg = ctx->grids[a.main_grid];
-    // resident time window of the main field's ring (all time-varying fields are uploaded in lock step)
+    // resident time window: the intersection over every time-varying field that lives in a ring of slots (each on its own
+    // time axis).  A particle steps only while [t, t+dt] lies inside it, so no field is sampled on a level that is not there.
     a.win_lo = -INFINITY;
     a.win_hi = INFINITY;
-    if (mf.d.has_time_interval) {
+    for (const HostField& f : ctx->fields) {
+        if (!f.d.has_time_interval || f.d.nslots >= f.desc.nt) continue;
         int lo = 1 << 30, hi = -1, cnt = 0;
-        for (int lv : mf.slot_level)
+        for (int lv : f.slot_level)
             if (lv >= 0) { lo = std::min(lo, lv); hi = std::max(hi, lv); cnt++; }
-        if (cnt == 0) return ctx->fail("no time level of the velocity field is resident (pk_field_upload_level)");
-        if (hi - lo + 1 != cnt) return ctx->fail("resident time levels are not contiguous");
-        a.win_lo = mf.time[lo];
-        a.win_hi = mf.time[hi];
-        if (lo == 0) a.win_lo = -INFINITY;            // nothing earlier exists: let the kernels raise code 70
-        if (hi == mf.desc.nt - 1) a.win_hi = INFINITY;
+        if (cnt == 0) return ctx->fail("no time level of a streamed field is resident (pk_field_upload_level)");
+        if (hi - lo + 1 != cnt) return ctx->fail("resident time levels are not contiguous (pk_field_evict_outside)");
+        // nothing earlier / later exists at the ends of the axis: let the kernels raise code 70 there
+        if (lo > 0) a.win_lo = std::max(a.win_lo, f.time[lo]);
+        if (hi < f.desc.nt - 1) a.win_hi = std::min(a.win_hi, f.time[hi]);
     }
     // LDS staging of the main grid's 1-D vectors
     const int nt = mf.d.has_time_interval ? mf.d.nt : 0;

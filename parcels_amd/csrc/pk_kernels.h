@@ -423,7 +423,7 @@ __global__ void __launch_bounds__(256, (KIND == 1 || INTERP != 0) ? PK_MIN_WAVES
             c.ei3 = ng > 3 ? P.ei[i * ng + 3] : 0;
             const double endtime = prm.endtime;
             const int sign = prm.dt0 > 0 ? 1 : -1;  // kernel.py:186
-            const bool windowed = mf.has_time_interval != 0;
+            const bool windowed = a.win_lo > -INFINITY || a.win_hi < INFINITY;  // some field streams through a ring of levels
             const int nk = KID >= 0 ? 1 : prm.nk;
             while (c.state == PK_EVALUATE || c.state == PK_REPEAT) {  // :190
                 const double tte = sign * (endtime - p.t);
@@ -555,7 +555,7 @@ __global__ void __launch_bounds__(256, PK_MIN_WAVES_FAST) advect_fast_kernel(con
             double pdt = P.dt[i];
             const double endtime = prm.endtime;
             const int sign = prm.dt0 > 0 ? 1 : -1;  // kernel.py:186
-            const bool windowed = a.fast.has_ti != 0;
+            const bool windowed = a.win_lo > -INFINITY || a.win_hi < INFINITY;  // some field streams through a ring of levels
             while (c.state == PK_EVALUATE) {  // :190 (no kernel of these programs sets Repeat)
                 const double tte = sign * (endtime - pt);
                 if (!(tte >= 0)) break;  // :193-197

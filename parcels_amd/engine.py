@@ -236,12 +236,13 @@ class DeviceEngine:
     def _windowed_fields(self):
         return [f for f in self.scalar_fields if self.field_nslots[f.name] < self.field_host[f.name].shape[0]]
 
-    def _plan_window(self, t_live: float, sign: int):
-        """Levels that must be committed for the next launch and the level to prefetch behind it."""
-        wf = self._windowed_fields()
-        time = wf[0].model.time_flt
+    def _plan_window(self, f, t_live: float, sign: int):
+        """Levels of field ``f`` that must be committed for the next launch and the level to prefetch behind them.
+        Every windowed field is planned on ITS OWN time axis (fields of one FieldSet may come from models with different
+        level times); the library pauses a particle where the intersection of the fields' resident windows ends."""
+        time = f.model.time_flt
         nt = len(time)
-        ns = min(self.field_nslots[f.name] for f in wf)
+        ns = self.field_nslots[f.name]
         ncommit = ns - 1 if ns > 2 else ns
         if sign > 0:
             k0 = int(np.clip(np.searchsorted(time, t_live, side="right") - 1, 0, nt - 1))
@@ -253,28 +254,37 @@ class DeviceEngine:
             nxt = k1 - ncommit if k1 - ncommit >= 0 else None
         if ncommit >= ns:
             nxt = None  # no spare slot to prefetch into
-        return wf, want, nxt
+        return want, nxt
 
     def _commit_window(self, t_live: float, sign: int):
-        """Make the wanted levels resident (normally they were prefetched during the previous launch)."""
-        wf, want, nxt = self._plan_window(t_live, sign)
+        """Make the wanted levels resident (normally they were prefetched during the previous launch) and drop every other
+        level: what an earlier run / a far-away particle left in the ring would make the resident set non-contiguous."""
         self.ctx.check(self.lib.pk_field_sync(self.ctx.handle), "pk_field_sync")  # commit earlier prefetches
-        for f in wf:
+        plan = {}
+        for f in self._windowed_fields():
+            want, nxt = self._plan_window(f, t_live, sign)
+            # keep the wanted levels and the prefetch target (it usually arrived during the previous launch and is what lets a
+            # step that straddles the last wanted level proceed); everything else in the ring is stale
+            keep = want + ([nxt] if nxt is not None else [])
+            self.ctx.check(self.lib.pk_field_evict_outside(self.ctx.handle, self.field_ids[f.name], int(min(keep)), int(max(keep))),
+                           "pk_field_evict_outside")
             have = set(self._slots(f.name))
             for lv in want:
                 if lv not in have:
                     self._upload(f.name, lv, asynchronous=False)
-        self._window = (want[0], want[-1])
-        return nxt
+            plan[f.name] = nxt
+        return plan
 
-    def _prefetch(self, nxt):
-        """Stage and enqueue the next level on the copy stream WHILE the advection kernel runs (the host-side staging
-        memcpy -- or the page-ins of a memory-mapped file -- and the DMA both overlap the RK sub-steps)."""
-        if nxt is None:
-            return
-        for f in self._windowed_fields():
-            if nxt not in set(self._slots(f.name)):
+    def _prefetch(self, plan):
+        """Stage and enqueue the next level of every windowed field on the copy stream WHILE the advection kernel runs (the
+        host-side staging memcpy -- or the page-ins of a memory-mapped file -- and the DMA both overlap the RK sub-steps)."""
+        issued = False
+        for f in self._windowed_fields() if plan else ():
+            nxt = plan.get(f.name)
+            if nxt is not None and nxt not in set(self._slots(f.name)):
                 self._upload(f.name, nxt, asynchronous=True)
+                issued = True
+        return issued
 
     # ---- particles -------------------------------------------------------------------------------------------
     def _particles_desc(self, data: dict):
@@ -400,14 +410,15 @@ class DeviceEngine:
             nxt = None
             if self.windowed:
                 if t_live is None or not np.isfinite(t_live):
-                    t_live = 0.0 if sign > 0 else float(self._windowed_fields()[0].model.time_flt[-1])
+                    t_live = 0.0 if sign > 0 else max(float(f.model.time_flt[-1]) for f in self._windowed_fields())
                 nxt = self._commit_window(float(t_live), sign)
             prm = self.make_params(kernel_ids, endtime=endtime, dt0=dt0, context=context, seed=seed, reset_state=reset,
                                    have_guess0=(have_guess0 if reset else 1), sort_by_cell=sort_by_cell)
             st = _hip.ExecStats()
             self.ctx.check(self.lib.pk_execute_begin(self.ctx.handle, C.byref(prm)), "pk_execute_begin")
+            prefetched = False
             try:
-                self._prefetch(nxt)  # overlaps the kernel that was just launched
+                prefetched = self._prefetch(nxt)  # overlaps the kernel that was just launched
             finally:
                 self.ctx.check(self.lib.pk_execute_end(self.ctx.handle, C.byref(st)), "pk_execute_end")
             reset = 0
@@ -422,7 +433,9 @@ class DeviceEngine:
             if not self.windowed:
                 raise _hip.HipLibraryError("particles paused although all time levels are resident (internal error)")
             t_live = st.t_min_live if sign > 0 else st.t_max_live
-            if last_live is not None and t_live == last_live:
+            # no particle moved AND no new level is on its way (a small ring needs one launch per cycle just to bring in the
+            # level behind the window; the next commit makes it resident): the step itself does not fit
+            if last_live is not None and t_live == last_live and not prefetched:
                 raise RuntimeError(
                     "field window too small: a single step does not fit into the resident time levels; "
                     "increase nslots (FieldSet.to_device(nslots=...))"

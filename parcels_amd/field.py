@@ -188,6 +188,8 @@ class Field:
         if not isinstance(value, (XLinear, XConstantField, XNearest, CGrid_Tracer, XLinearInvdistLandTracer)):
             raise NotImplementedError(f"{type(value).__name__} has no HIP implementation")
         self.model.field_to_interpolator[self.name] = value
+        if self._fieldset is not None:  # the scalar interpolator code and the C-grid packing are part of the device descriptors
+            self._fieldset._engine = None
 
     def eval(self, t, z, y, x, particles=None):
         """Interpolate in space and time on the GPU (field.py:145-185). Returns the values as float64."""
@@ -233,6 +235,8 @@ class VectorField:
         if not isinstance(method, (XLinear_Velocity, CGrid_Velocity, XFreeslip, XPartialslip)):
             raise NotImplementedError(f"{type(method).__name__} has no HIP implementation yet")
         self._interp_method = method
+        if self._fieldset is not None:  # C-grid component packing is decided when the device copy is made
+            self._fieldset._engine = None
 
     def eval(self, t, z, y, x, particles=None):
         if self._fieldset is None:

@@ -4,6 +4,7 @@ from __future__ import annotations
 
 import datetime
 import types
+import warnings
 
 import numpy as np
 
@@ -25,6 +26,26 @@ def _convert_dt_to_float(dt):  # particleset.py:488-505
     if not np.isfinite(dt) or dt == 0:
         raise ValueError(f"dt must be a non-zero finite number of seconds. Got {dt!r}")
     return dt, (1 if dt > 0 else -1)
+
+
+def _warn_outputdt_release_desync(outputdt, starttime, release_times):  # particleset.py:473-482
+    if outputdt and np.isfinite(outputdt):
+        t = np.asarray(release_times, dtype=np.float64)
+        fin = np.isfinite(t)
+        if np.any(np.mod(t[fin] - starttime, outputdt) != 0):
+            warnings.warn(
+                "Some of the particles have a start time difference that is not a multiple of outputdt. "
+                "This could cause the first output of some of the particles that start later "
+                "in the simulation to be at a different time than expected.",
+                ParticleSetWarning, stacklevel=3)
+
+
+def _warn_particle_times_outside_fieldset_time_bounds(release_times, time_interval):  # particleset.py:485-494
+    t = np.asarray(release_times, dtype=np.float64)
+    if t.size == 0 or np.isnan(t).all():
+        return
+    if np.any(t < 0) or np.any(t > time_interval.time_length_as_flt):
+        warnings.warn("Some particles are set to be released outside the FieldSet's executable time domain.", ParticleSetWarning, stacklevel=3)
 
 
 class ParticleSet:
@@ -73,6 +94,8 @@ class ParticleSet:
             raise TypeError("particle t must be a datetime, timedelta, or float seconds")
         t = np.repeat(t, x.size) if np.size(t) == 1 else np.asarray(t)
         assert x.size == t.size, "t and positions (x, y, z) do not have the same lengths."
+        if self.fieldset.time_interval:  # particleset.py:108-110
+            _warn_particle_times_outside_fieldset_time_bounds(t, self.fieldset.time_interval)
         for kwvar in kwargs:
             kwargs[kwvar] = np.array(kwargs[kwvar]).flatten()
             assert x.size == kwargs[kwvar].size, f"{kwvar} and positions (x, y, z) don't have the same lengths."
@@ -130,12 +153,18 @@ class ParticleSet:
         self._kernel = Kernel(kernels, self)
         dt, sign_dt = _convert_dt_to_float(dt)
         self._data["dt"][:] = dt
-        if runtime is not None and isinstance(runtime, (datetime.timedelta, np.timedelta64)):
-            runtime = to_seconds(runtime)
+        if runtime is not None:  # _convert_runtime_to_float (particleset.py:508-520)
+            try:
+                runtime = to_seconds(runtime) if isinstance(runtime, (datetime.timedelta, np.timedelta64)) else float(runtime)
+            except (ValueError, TypeError) as e:
+                raise ValueError(f"The runtime must be a datetime.timedelta, np.timedelta64 or float object. Got {type(runtime)}") from e
+            if runtime < 0:
+                raise ValueError(f"The runtime must be a non-negative timedelta or float. Got {runtime=!r}")
         start_time, end_time = self._start_and_end_times(runtime, endtime, sign_dt)
         if np.isnan(self._data["t"]).any():
             self._data["t"][:] = start_time
         outputdt = output_file.outputdt if output_file else None
+        _warn_outputdt_release_desync(outputdt, start_time, self._data["t"])
         next_output = None
         if output_file:
             output_file.set_metadata(self.fieldset.gridset[0]._mesh)
@@ -205,7 +234,7 @@ class ParticleSet:
         if runtime is None and endtime is None:
             raise ValueError("Either runtime or endtime must be provided.")
         rel = self._data["t"]
-        first = np.nanmin(rel) if sign_dt == 1 and not np.all(np.isnan(rel)) else (np.nanmax(rel) if not np.all(np.isnan(rel)) else np.nan)
+        first = rel.min() if sign_dt == 1 else rel.max()  # NaN-propagating like the reference: one unset release time => fieldset start
         if endtime is not None:
             if isinstance(endtime, np.datetime64) and ti is not None:
                 if not (ti.left <= endtime <= ti.right):

@@ -23,7 +23,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert sorted(_hip.ABI_SYMBOLS) == declared
     for sym in declared:
         assert hasattr(lib, sym), f"libparcels_hip.so does not export {sym}"
-    assert lib.pk_abi_version() == _hip.PK_ABI_VERSION == 2
+    assert lib.pk_abi_version() == _hip.PK_ABI_VERSION == 3
 
 
 def test_ctypes_structs_match_header_layout():
@@ -222,3 +222,49 @@ def test_spatial_hash_build_equals_reference_on_masked_meshes(mesh, nx, ny):
     assert int(ref._bitwidth) == mine["bitwidth"]
     for k in ("keys", "starts", "counts", "faces"):
         assert np.array_equal(np.asarray(ref._hash_table[k]).astype(mine[k].dtype), mine[k]), k
+
+
+def test_start_and_end_times_follow_the_reference():
+    """_get_simulation_start_and_end_times (particleset.py:523-585): min()/max() of the release times propagate NaN (one unset
+    time => the run starts at the fieldset start), negative runtime raises, release times outside the time interval and output
+    intervals that do not divide the release offsets warn."""
+    import warnings
+
+    from parcels_amd.particleset import ParticleSetWarning, _warn_outputdt_release_desync
+
+    case, _, _ = load_golden("agrid_flat_rk4_f64")
+    fs = build_fieldset(case)
+    n = len(case["x"])
+    t = np.linspace(1000.0, 5000.0, n)
+    pset = pa.ParticleSet(fs, pclass=pa.get_default_particle(np.float64), x=case["x"], y=case["y"], z=case["z"], t=t)
+    assert pset._start_and_end_times(3600.0, None, 1) == (1000.0, 4600.0)
+    assert pset._start_and_end_times(3600.0, None, -1) == (5000.0, 1400.0)
+    pset._data["t"][3] = np.nan  # the reference: first_release_time = release_times.min() -> NaN -> fieldset start
+    tlen = fs.time_interval.time_length_as_flt
+    assert pset._start_and_end_times(3600.0, None, 1) == (0.0, 3600.0)
+    assert pset._start_and_end_times(3600.0, None, -1) == (tlen, tlen - 3600.0)
+    with pytest.raises(ValueError):
+        pset.execute(pa.AdvectionRK4, dt=3600.0, runtime=-1.0)
+    with pytest.raises(ValueError):
+        pset.execute(pa.AdvectionRK4, dt=3600.0, runtime=10.0, endtime=20.0)
+    with pytest.warns(ParticleSetWarning):
+        pa.ParticleSet(fs, x=case["x"], y=case["y"], z=case["z"], t=np.full(n, -5.0))
+    with pytest.warns(ParticleSetWarning):
+        _warn_outputdt_release_desync(600.0, 0.0, np.array([0.0, 900.0]))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        _warn_outputdt_release_desync(600.0, 0.0, np.array([0.0, 1200.0, np.nan]))
+        _warn_outputdt_release_desync(None, 0.0, np.array([0.0, 900.0]))
+
+
+def test_changing_an_interpolator_drops_the_device_copy():
+    """The scalar interpolator code and the C-grid packing are frozen into the device descriptors: a later assignment must not
+    be silently ignored (the FieldSet forgets its engine and rebuilds it on the next use)."""
+    case, _, _ = load_golden("agrid_flat_rk4_f64")
+    fs = build_fieldset(case)
+    fs.__dict__["_engine"] = object()
+    fs.U.interp_method = pa.XNearest()
+    assert fs._engine is None
+    fs.__dict__["_engine"] = object()
+    fs.UV.interp_method = pa.XFreeslip()
+    assert fs._engine is None
