@@ -9,20 +9,33 @@ interpolation).  Fields and particles are resident in HBM when the timed region 
     python bench.py --gpus 1 --steps 24 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Multi-GPU (weak scaling): particles are sharded by id, fields replicated, NO collective on the data path, so the timed K
-steps contain none.  The only exchange of the path -- the periodic trajectory write-out, one RCCL all-gather of the output
+Multi-GPU (weak scaling, 1e7 particles per GPU): ONE id space of N x 1e7 particles, generated in shard-independent blocks and
+sharded by id (parcels_amd.distributed.shard_slice), fields replicated, NO collective on the data path, so the timed K steps
+contain none.  The only exchange of the path -- the periodic trajectory write-out, one RCCL all-gather of the to-write
 columns (t, z, y, x, particle_id) over xGMI -- is executed once after the timed steps and reported separately
 (`writeout_allgather_ms`, and `value_incl_writeout` = throughput if a write-out followed every K steps).
 
-Prints ONE JSON line (rank 0).  `roofline`: achieved = algorithmic bytes per particle-step (1112 B for
-C2 RK4 = 4 stages x 2 fields x 16 corners x 8 B + 88 B state) x particle-steps / advection-kernel time measured with
-HIP events on the compute stream.  `cpu_baseline`: the scalar C oracle (oracle/parcels_oracle.c, "port") with OpenMP
-on the host cores, on a bounded sample of the same workload.
+Prints ONE JSON line (rank 0).  What the objects mean:
+
+`roofline` -- the advection kernel is bound by fp64-rate VALU issue, not by HBM (its gathers are served by L2 / Infinity Cache):
+  bound     "valu_fp64"
+  achieved  VALU-busy SIMD-cycles per second = (SQ_ACTIVE_INST_VALU x 4 per particle-step, from the rocprofv3 PMC pass summarised
+            in profiles/pmc_latest.json) x particle-steps of the timed launch / kernel time measured HERE with HIP events on the
+            compute stream;  peak = 1024 SIMDs x 2.4 GHz;  frac = VALU utilisation at peak clock
+  traffic   HBM bytes of the timed launch (FETCH_SIZE + WRITE_SIZE passes, calibrated on the 1 GiB copy kernel), scaled per
+            particle-step to this run;  `hbm` = that traffic over the kernel time against the 8 TB/s peak
+  algorithmic  SURVEY.md 8(d)'s byte model (1112 B per particle-step = 4 stages x 2 fields x 16 corners x 8 B + 88 B state) over
+            the kernel time.  It exceeds the HBM peak because those bytes come out of cache: it is NOT an HBM fraction.
+`cpu_baseline` -- the scalar C oracle (oracle/parcels_oracle.c, kind "port") with OpenMP on this box's host cores, bounded sample.
+`cpu_baseline_reference` -- the reference itself (Parcels under oracle/ref_shim.py) timed by tools/time_reference_cpu.py in the
+  build container (profiles/r02_cpu_reference.json): /root/reference does not exist on the GPU box.
 """
 
 from __future__ import annotations
 
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -35,10 +48,25 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_STEP_C2_RK4 = 4 * 2 * 16 * 8 + 88
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md
+N_SIMD, PEAK_CLOCK_GHZ = 1024, 2.4  # 256 CUs x 4 SIMDs; one fp64-rate VALU instruction occupies a SIMD for 4 cycles
+POS_BLOCK = 1 << 20  # particles per generator block (positions do not depend on how the id space is sharded)
 
 
-def c2_case(npart: int, seed: int, nx=360, ny=180, nz=50, nt=24):
-    """Synthetic C2 FieldSet: smooth analytic (Rossby-wave-like) U, V in m/s, |u| <= ~1 m/s, fp64."""
+def c2_positions(seed: int, lo: int, hi: int):
+    """x, y, z of particles lo..hi-1 of the global id space: block b of POS_BLOCK ids is drawn from default_rng([seed, b])."""
+    xs, ys, zs = [], [], []
+    for b in range(lo // POS_BLOCK, (max(hi, lo + 1) - 1) // POS_BLOCK + 1):
+        rng = np.random.default_rng([seed, b])
+        x = rng.uniform(5.0, 355.0, POS_BLOCK)
+        y = rng.uniform(-75.0, 75.0, POS_BLOCK)
+        z = rng.uniform(10.0, 4990.0, POS_BLOCK)
+        s = slice(max(lo - b * POS_BLOCK, 0), min(hi - b * POS_BLOCK, POS_BLOCK))
+        xs.append(x[s]); ys.append(y[s]); zs.append(z[s])
+    return np.concatenate(xs), np.concatenate(ys), np.concatenate(zs)
+
+
+def c2_case(seed: int = 1, lo: int = 0, hi: int = 10_000_000, nx=360, ny=180, nz=50, nt=24):
+    """Synthetic C2 FieldSet: smooth analytic (Rossby-wave-like) U, V in m/s, |u| <= ~1 m/s, fp64; particles lo..hi-1."""
     lon = np.linspace(0.0, 360.0, nx)
     lat = np.linspace(-80.0, 80.0, ny)
     depth = np.linspace(0.0, 5000.0, nz)
@@ -50,14 +78,12 @@ def c2_case(npart: int, seed: int, nx=360, ny=180, nz=50, nt=24):
     U = (0.6 * np.cos(phi) * (1 - 0.5 * zz) + 0.3 * np.sin(3 * lam + 2 * np.pi * tt) * np.cos(2 * phi) * np.exp(-2 * zz)
          + 0.1 * np.cos(5 * lam - 4 * np.pi * tt) * np.sin(4 * phi))
     V = (0.3 * np.cos(3 * lam + 2 * np.pi * tt) * np.sin(2 * phi) * np.exp(-2 * zz) + 0.1 * np.sin(5 * lam - 4 * np.pi * tt) * np.cos(phi))
-    rng = np.random.default_rng(seed)
+    x, y, z = c2_positions(seed, lo, hi)
     return dict(
         name="C2", mesh="spherical", lon=lon, lat=lat, depth=depth, x_pad="low", y_pad="low", z_pad="both", time_s=time_s,
         fields={"U": np.ascontiguousarray(U), "V": np.ascontiguousarray(V)},
         field_dims={"U": ("time", "depth", "YG", "XG"), "V": ("time", "depth", "YG", "XG")}, cgrid=False,
-        kernels=["AdvectionRK4"], spatial_dtype="float64",
-        x=rng.uniform(5.0, 355.0, npart), y=rng.uniform(-75.0, 75.0, npart), z=rng.uniform(10.0, 4990.0, npart),
-        t0=None, dt=3600.0, runtime=None, seed=seed,
+        kernels=["AdvectionRK4"], spatial_dtype="float64", x=x, y=y, z=z, t0=None, dt=3600.0, runtime=None, seed=seed,
     )
 
 
@@ -77,6 +103,13 @@ def cpu_baseline(case, steps: int, sample: int):
     el = time.perf_counter() - t0
     return {"value": st["steps"] / el, "unit": "particle-steps/s", "cores": cores, "kind": "port",
             "sample": f"{sample} particles x {steps} RK4 steps of the same FieldSet, oracle/parcels_oracle.c with OpenMP ({el:.1f} s)"}
+
+
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "parcels_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "parcels_amd", "csrc", "*.hip"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -113,18 +146,20 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import parcels_amd as pa
+    from parcels_amd.distributed import shard_slice
     from tests.case_utils import build_fieldset, build_pset
 
     npart = int(args.particles)
     K, W = args.steps, args.warmup
-    case = c2_case(npart, seed=1 + rank)
+    shard = shard_slice(world * npart, rank, world)  # one id space, sharded by id
+    case = c2_case(seed=1, lo=shard.start, hi=shard.stop)
     nt = len(case["time_s"])
     if (K + W) * case["dt"] > case["time_s"][-1]:
         raise SystemExit(f"steps+warmup must stay within the {nt}-level time interval")
     fs = build_fieldset(case)
     fs.to_device(device=local_rank)
     pset = build_pset(case, fs, sort_by_cell=bool(args.sort))
-    pset._data["particle_id"] += rank * npart  # shard by id
+    pset._data["particle_id"] += shard.start
     kern = pa.Kernel([pa.AdvectionRK4], pset)
     eng = fs._engine_or_create()
     dt = case["dt"]
@@ -141,12 +176,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # measured device-to-device copy bandwidth: the practical HBM ceiling used as a second roofline denominator
+    # measured device-to-device copy bandwidth (float4 copy of 1 GiB): the practical HBM ceiling, and the calibration dispatch of
+    # the FETCH_SIZE / WRITE_SIZE counter passes (tools/pmc_summary.py)
     copy_gbps = eng.ctx.copy_bandwidth(1 << 30, 5) if rank == 0 else 0.0
 
     # warmup: W steps (also pays the one-off cell sort)
+    sort_ms = 0.0
     if W > 0:
-        eng.execute(kern.kernel_ids, endtime=W * dt, dt0=dt, sort_by_cell=int(args.sort), t_start=0.0)
+        st_w = eng.execute(kern.kernel_ids, endtime=W * dt, dt0=dt, sort_by_cell=int(args.sort), t_start=0.0)
+        sort_ms = st_w["sort_ms"]
     sync()
     t0 = time.perf_counter()
     st = eng.execute(kern.kernel_ids, endtime=(W + K) * dt, dt0=dt, sort_by_cell=0, t_start=W * dt)
@@ -185,7 +223,34 @@ def main():
         value = total_steps / el
         kernel_s = float(kms.item()) * 1e-3
         per_gpu_steps = total_steps / world
-        achieved = ALGO_BYTES_PER_STEP_C2_RK4 * per_gpu_steps / kernel_s / 1e9 if kernel_s > 0 else 0.0
+        algo_gbps = ALGO_BYTES_PER_STEP_C2_RK4 * per_gpu_steps / kernel_s / 1e9 if kernel_s > 0 else 0.0
+        peak_cycles = N_SIMD * PEAK_CLOCK_GHZ  # G SIMD-cycles per second
+        roof = {"bound": "valu_fp64", "achieved": None, "peak": peak_cycles, "unit": "G VALU-busy SIMD-cycles/s", "frac": None, "traffic": None,
+                "kernel": "pk::advect_fast_kernel<double, 0, false> (csrc/pk_kernels.h, pk_fast_agrid.h)", "kernel_ms_per_launch": float(kms.item()),
+                "hbm": None,
+                "algorithmic": {"note": "SURVEY 8(d) byte model; these bytes are served by L2 / Infinity Cache, this is NOT an HBM fraction",
+                                "bytes_per_particle_step": ALGO_BYTES_PER_STEP_C2_RK4, "bytes_per_launch": ALGO_BYTES_PER_STEP_C2_RK4 * per_gpu_steps,
+                                "achieved_gbps": algo_gbps, "over_hbm_peak": algo_gbps / HBM_PEAK_GBPS},
+                "measured_copy_gbps": copy_gbps}
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):  # per-particle-step counters of the rocprofv3 PMC passes (tools/pmc_summary.py), scaled to THIS launch
+            try:
+                pj = json.load(open(pmc))
+                pp = pj["per_particle_step"]
+                busy = pp["valu_busy_simd_cycles"] * per_gpu_steps  # SIMD-cycles
+                roof["achieved"] = busy / kernel_s / 1e9
+                roof["frac"] = roof["achieved"] / peak_cycles
+                roof["valu_insts_per_wave_evaluation"] = pp["valu_insts_per_wave_eval"]
+                if pp.get("fetch_bytes") is not None and pp.get("write_bytes") is not None:
+                    traffic = (pp["fetch_bytes"] + pp["write_bytes"]) * per_gpu_steps
+                    roof["traffic"] = traffic
+                    roof["hbm"] = {"achieved": traffic / kernel_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                   "frac": traffic / kernel_s / 1e9 / HBM_PEAK_GBPS, "bytes_per_particle_step": pp["fetch_bytes"] + pp["write_bytes"]}
+                roof["counters_source"] = pj.get("source")
+                roof["counters_stale"] = pj.get("source_hash") != kernel_source_hash()  # kernels changed since the PMC passes
+            except Exception as e:  # a malformed summary must not kill the bench line
+                roof["counters_error"] = repr(e)
+        t_all = el + t_h2d + t_d2h + sort_ms * 1e-3
         out = {
             "metric": "RK4 particle-steps/sec",
             "value": value,
@@ -201,26 +266,24 @@ def main():
             "data": "synthetic",
             "config": {"workload": "C2: 3D rectilinear A-grid 360x180x50x24 fp64 U,V (spherical), AdvectionRK4, dt=3600 s",
                        "particles_per_gpu": npart, "particle_dtype": "f64", "cell_sorted": bool(args.sort),
-                       "parallelism": f"particles sharded by id x{world}, fields replicated",
+                       "parallelism": f"one id space of {world * npart} particles sharded by id x{world}, fields replicated",
                        "all_states_endofloop": ok, **({"rehearsal_shared_gpu_gloo": True} if rehearsal else {})},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": None, "kernel": "advect_kernel<double,0,0,RK4,lds>", "kernel_ms_per_launch": float(kms.item()),
-                         "algorithmic_bytes_per_particle_step": ALGO_BYTES_PER_STEP_C2_RK4,
-                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_STEP_C2_RK4 * per_gpu_steps,
-                         "measured_copy_gbps": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps if copy_gbps else None},
-            # boundary costs outside the timed steps (rank 0): host<->device copies of the particle columns, write-out exchange
-            "host_boundary": {"h2d_ms": t_h2d * 1e3, "d2h_ms": t_d2h * 1e3,
+            "roofline": roof,
+            # boundary costs outside the timed steps (rank 0): host<->device copies of the particle columns, the one-off cell sort
+            "host_boundary": {"h2d_ms": t_h2d * 1e3, "d2h_ms": t_d2h * 1e3, "cell_sort_ms": sort_ms,
                               "value_pcie_inclusive": total_steps / (el + t_h2d + t_d2h)},
+            "value_end_to_end": total_steps / t_all,  # H2D of the particle columns + cell sort + K steps + D2H
             "writeout_allgather_ms": t_ag * 1e3 if world > 1 else None,
             "value_incl_writeout": total_steps / (el + t_ag) if world > 1 else None,
         }
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):  # HBM bytes per launch from the rocprofv3 PMC passes (tools/pmc_summary.py), same command line
+        ref = os.path.join(ROOT, "profiles", "r02_cpu_reference.json")
+        if os.path.exists(ref):
             try:
-                pj = json.load(open(pmc))
-                if pj.get("particles_per_gpu") == npart and pj.get("steps") == K:
-                    out["roofline"]["traffic"] = pj["traffic_bytes_per_launch"]
-                    out["roofline"]["traffic_source"] = pj.get("source")
+                rj = json.load(open(ref))
+                out["cpu_baseline_reference"] = {"value": rj["all_cores"]["value"], "unit": rj["unit"], "cores": rj["all_cores"]["processes"],
+                                                 "kind": "reference", "single_process_value": rj["single_process"]["value"],
+                                                 "sample": f"{rj['all_cores']['particles']} particles x {rj['all_cores']['steps']} steps, {rj['what']}",
+                                                 "box": rj["box"], "source": "profiles/r02_cpu_reference.json (tools/time_reference_cpu.py)"}
             except Exception:
                 pass
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is reported at N = 1 only

@@ -291,8 +291,17 @@ __global__ void __launch_bounds__(256) interleave_kernel(const T* __restrict__ s
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i * ncomp] = src[i];
 }
 
+// device-to-device float4 copy used as the measured HBM ceiling: 4 independent 16-byte loads in flight per lane, one block
+// per 4 KiB-per-wave tile (no grid-stride tail), which is what reaches the ~6.3 TB/s of MI355X_MICROARCH.md
 __global__ void __launch_bounds__(256) copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+    const int64_t base = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    if (base + 768 < n) {
+        const float4 a = src[base], b = src[base + 256], c = src[base + 512], d = src[base + 768];
+        dst[base] = a; dst[base + 256] = b; dst[base + 512] = c; dst[base + 768] = d;
+    } else {
+        for (int k = 0; k < 4; k++)
+            if (base + 256 * k < n) dst[base + 256 * k] = src[base + 256 * k];
+    }
 }
 
 }  // namespace pk
@@ -1425,7 +1434,7 @@ int32_t pk_measure_copy_bandwidth(pk_ctx* ctx, int64_t bytes, int32_t iters, dou
     PK_HIP(ctx, hipMalloc(&src, n16 * 16));
     PK_HIP(ctx, hipMalloc(&dst, n16 * 16));
     PK_HIP(ctx, hipMemsetAsync(src, 1, n16 * 16, ctx->compute));
-    const unsigned grid = (unsigned)std::min<int64_t>((n16 + 255) / 256, 256 * 8 * 4);
+    const unsigned grid = (unsigned)((n16 + 1023) / 1024);
     hipLaunchKernelGGL(copy_kernel, dim3(grid), dim3(256), 0, ctx->compute, (const float4*)src, (float4*)dst, n16);
     PK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->compute));
     for (int k = 0; k < iters; k++)

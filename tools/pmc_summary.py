@@ -1,57 +1,149 @@
 #!/usr/bin/env python
-"""Turn the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, --kernel-trace only) of bench.py into
-profiles/<name>.md + profiles/pmc_latest.json.
+"""Summarise the rocprofv3 passes that tools/gpu_profile_c2.sh leaves under gpurun_out/ into profiles/<name>.md and
+profiles/pmc_latest.json (which bench.py folds into its `roofline` object).
 
-gfx950 corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE/WRITE_SIZE are in KiB of 64-B fabric requests;
-FETCH_SIZE reports exactly half of the bytes of a wide coalesced read on this rocprofv3, other access widths are
-uncalibrated.  We therefore calibrate on the float4 copy kernel that bench.py runs (pk::copy_kernel: exactly 1 GiB read and
-1 GiB written per dispatch) and scale the advection kernel's counters by the same factors.
+    python tools/pmc_summary.py TAG NAME [--particles 1e7 --steps 24]
+        reads  gpurun_out/TAG_pmc_{sq,sq2,fetch,write}/p_counter_collection.csv, gpurun_out/TAG_trace/, gpurun_out/TAG_bench.json
+        writes profiles/NAME_pmc.md, profiles/NAME_kernel_trace.md, profiles/NAME_bench.json, profiles/pmc_latest.json
+
+Counter conventions on gfx950 (MI355X_MICROARCH.md): the passes are separate runs with --kernel-trace only; SQ_ACTIVE_INST_* and
+SQ_WAVE_CYCLES / SQ_WAIT_* count QUAD-cycles (x4 = cycles); GRBM_GUI_ACTIVE is summed over the 8 XCDs; FETCH_SIZE / WRITE_SIZE
+are KiB of 64-byte fabric requests and FETCH_SIZE reports half the bytes of a wide coalesced read -- both are calibrated here on
+the float4 copy kernel bench.py runs first (pk::copy_kernel: exactly 1 GiB read + 1 GiB written per dispatch).
+Everything is reported PER PARTICLE-STEP as well, so that bench.py can scale it to any --steps / --particles.
 """
+import argparse
 import csv
 import glob
+import hashlib
 import json
+import os
+import sqlite3
 import sys
 
-
-def read_counter(d, counter):
-    rows = []
-    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
-        for r in csv.DictReader(open(f)):
-            if r.get("Counter_Name") == counter:
-                rows.append((r["Kernel_Name"], float(r["Counter_Value"])))
-    return rows
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_SIMD, N_XCD = 1024, 8
 
 
-def main(fetch_dir, write_dir, out_md, particles, steps):
-    res = {}
-    for name, d in (("FETCH_SIZE", fetch_dir), ("WRITE_SIZE", write_dir)):
-        rows = read_counter(d, name)
-        adv = [v for k, v in rows if "advect_kernel" in k]
-        cpy = [v for k, v in rows if "copy_kernel" in k]
-        res[name] = {"advect": adv, "copy": cpy}
-    GiB = float(1 << 30)
-    # calibration factors: true bytes / (counter * 1024)
-    f_cal = GiB / (1024.0 * (sum(res["FETCH_SIZE"]["copy"]) / max(len(res["FETCH_SIZE"]["copy"]), 1))) if res["FETCH_SIZE"]["copy"] else None
-    w_cal = GiB / (1024.0 * (sum(res["WRITE_SIZE"]["copy"]) / max(len(res["WRITE_SIZE"]["copy"]), 1))) if res["WRITE_SIZE"]["copy"] else None
-    fetch_adv = res["FETCH_SIZE"]["advect"][-1] if res["FETCH_SIZE"]["advect"] else None  # last dispatch = the timed launch
-    write_adv = res["WRITE_SIZE"]["advect"][-1] if res["WRITE_SIZE"]["advect"] else None
-    lines = ["# HBM traffic of the advection kernel from rocprofv3 PMC passes", "",
-             f"copy_kernel (1 GiB in, 1 GiB out per dispatch): FETCH_SIZE = {res['FETCH_SIZE']['copy']}, WRITE_SIZE = {res['WRITE_SIZE']['copy']} (KiB)",
-             f"calibration factors true/(counter*1024): fetch {f_cal}, write {w_cal}", "",
-             f"advect_kernel dispatches: FETCH_SIZE = {res['FETCH_SIZE']['advect']}, WRITE_SIZE = {res['WRITE_SIZE']['advect']} (KiB)"]
-    out = {"particles_per_gpu": particles, "steps": steps, "source": out_md}
-    if fetch_adv is not None and write_adv is not None:
-        fb = fetch_adv * 1024.0 * (f_cal or 1.0)
-        wb = write_adv * 1024.0 * (w_cal or 1.0)
-        out["traffic_bytes_per_launch"] = fb + wb
-        out["fetch_bytes"] = fb
-        out["write_bytes"] = wb
-        lines += ["", f"timed launch ({particles} particles x {steps} steps): fetch {fb/1e9:.3f} GB + write {wb/1e9:.3f} GB = {(fb+wb)/1e9:.3f} GB "
-                  f"= {(fb+wb)/(particles*steps):.1f} B per particle-step (algorithmic: 1112 B)"]
+def source_hash():
+    """sha256 over the kernel sources: bench.py marks the counters stale when the kernels changed since they were collected."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "parcels_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "parcels_amd", "csrc", "*.hip"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def read_pass(d):
+    """-> {kernel class: [ {counter: value, ...} per dispatch ]} for the advection and the copy kernel"""
+    out = {"advect": {}, "copy": {}}
+    meta = {}
+    f = os.path.join(d, "p_counter_collection.csv")
+    if not os.path.exists(f):
+        return out, meta
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        cls = "advect" if "advect" in k else ("copy" if "copy_kernel" in k else None)
+        if cls is None:
+            continue
+        disp = int(r["Dispatch_Id"])
+        out[cls].setdefault(disp, {})
+        out[cls][disp][r["Counter_Name"]] = out[cls][disp].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        if cls == "advect":
+            meta = {"kernel": k, "vgpr": int(r["VGPR_Count"]), "accum_vgpr": int(r["Accum_VGPR_Count"]), "sgpr": int(r["SGPR_Count"]),
+                    "lds": int(r["LDS_Block_Size"]), "scratch": int(r["Scratch_Size"])}
+    return out, meta
+
+
+def trace_summary(tag, out_md):
+    dbs = glob.glob(os.path.join(ROOT, "gpurun_out", tag + "_trace", "**", "*.db"), recursive=True)
+    if not dbs:
+        return None
+    cur = sqlite3.connect(dbs[0]).cursor()
+    lines = [f"# rocprofv3 --kernel-trace --stats of `python bench.py --no-cpu-baseline` ({tag})", "", "## top kernels (us)", "",
+             "| kernel | calls | total_us | avg_us | % |", "|---|---|---|---|---|"]
+    for name, calls, total, avg, pct in cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
+        short = name if len(name) < 110 else name[:70] + " ... " + name[-30:]
+        lines.append(f"| `{short}` | {calls} | {total / 1e3:.1f} | {avg / 1e3:.1f} | {pct:.2f} |")
+    lines += ["", "## dispatches of the advection / sort kernels (the LAST advect dispatch is the timed launch)", "",
+              "| kernel | duration_us | grid | wg | lds | scratch | vgpr | agpr | sgpr |", "|---|---|---|---|---|---|---|---|---|"]
+    q = ("select name,duration,grid_x,workgroup_x,lds_size,scratch_size,vgpr_count,accum_vgpr_count,sgpr_count from kernels "
+         "where name like '%pk::advect%' or name like '%pk::sort_key%' order by start")
+    last = None
+    for r in cur.execute(q):
+        lines.append(f"| `{r[0][:90]}` | {r[1] / 1e3:.1f} | {r[2]} | {r[3]} | {r[4]} | {r[5]} | {r[6]} | {r[7]} | {r[8]} |")
+        if "advect" in r[0]:
+            last = r[1] / 1e6
     open(out_md, "w").write("\n".join(lines) + "\n")
-    json.dump(out, open("profiles/pmc_latest.json", "w"), indent=1)
-    print("\n".join(lines))
+    return last
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("tag")
+    ap.add_argument("name")
+    ap.add_argument("--particles", type=float, default=1e7)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--evals-per-step", type=int, default=4)
+    a = ap.parse_args()
+    g = os.path.join(ROOT, "gpurun_out", a.tag + "_")
+    npart, K = int(a.particles), a.steps
+    psteps = npart * K
+    wave_evals = psteps * a.evals_per_step / 64
+    c = {}
+    meta = {}
+    copy = {}
+    for p in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
+        d, m = read_pass(g + p)
+        if d["advect"]:
+            c.update(d["advect"][max(d["advect"])])  # last dispatch = the timed launch
+            meta = m or meta
+        for disp in d["copy"].values():
+            for k, v in disp.items():
+                copy.setdefault(k, []).append(v)
+    GiB = float(1 << 30)
+    f_cal = GiB / (1024.0 * (sum(copy["FETCH_SIZE"]) / len(copy["FETCH_SIZE"]))) if copy.get("FETCH_SIZE") else None
+    w_cal = GiB / (1024.0 * (sum(copy["WRITE_SIZE"]) / len(copy["WRITE_SIZE"]))) if copy.get("WRITE_SIZE") else None
+    fetch_b = c["FETCH_SIZE"] * 1024.0 * (f_cal or 2.0) if "FETCH_SIZE" in c else None
+    write_b = c["WRITE_SIZE"] * 1024.0 * (w_cal or 1.0) if "WRITE_SIZE" in c else None
+    trace_ms = trace_summary(a.tag, os.path.join(ROOT, "profiles", a.name + "_kernel_trace.md"))
+    cyc_xcd = c.get("GRBM_GUI_ACTIVE", 0.0) / N_XCD
+    valu_busy_cyc = c.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0
+    out = {
+        "source": f"profiles/{a.name}_pmc.md", "source_hash": source_hash(), "particles_per_gpu": npart, "steps": K, **meta,
+        "per_particle_step": {
+            "valu_busy_simd_cycles": valu_busy_cyc / psteps,
+            "valu_insts_per_wave_eval": c.get("SQ_INSTS_VALU", 0.0) / wave_evals,
+            "salu_insts_per_wave_eval": c.get("SQ_INSTS_SALU", 0.0) / wave_evals,
+            "fetch_bytes": fetch_b / psteps if fetch_b is not None else None,
+            "write_bytes": write_b / psteps if write_b is not None else None,
+        },
+        "profiled_launch": {"gpu_cycles_per_xcd": cyc_xcd, "valu_utilisation_at_measured_clock": valu_busy_cyc / (N_SIMD * cyc_xcd) if cyc_xcd else None,
+                            "kernel_ms_in_trace_pass": trace_ms * 1e3 if trace_ms else None},
+        "counters": c,
+    }
+    if fetch_b is not None and write_b is not None:
+        out["traffic_bytes_per_launch"] = fetch_b + write_b
+    json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1)
+    L = [f"# PMC counters of the timed advection launch ({a.tag}): {npart} particles x {K} steps", "",
+         f"kernel `{meta.get('kernel', '?')[:120]}`: arch VGPR {meta.get('vgpr')} (+{meta.get('accum_vgpr')} acc), SGPR {meta.get('sgpr')}, LDS {meta.get('lds')} B, scratch {meta.get('scratch')} B/lane", "",
+         "| counter | value | per wave-evaluation |", "|---|---|---|"]
+    for k in sorted(c):
+        L.append(f"| {k} | {c[k]:.4g} | {c[k] / wave_evals:.2f} |")
+    L += ["", f"* VALU instructions per wave-evaluation: **{c.get('SQ_INSTS_VALU', 0) / wave_evals:.0f}** (SALU {c.get('SQ_INSTS_SALU', 0) / wave_evals:.0f}); "
+              f"VALU busy = SQ_ACTIVE_INST_VALU x 4 = {valu_busy_cyc:.4g} SIMD-cycles = {valu_busy_cyc / max(c.get('SQ_INSTS_VALU', 1), 1):.2f} cycles per instruction",
+          f"* GPU cycles of the launch (GRBM_GUI_ACTIVE / 8 XCDs): {cyc_xcd:.4g} -> VALU utilisation {valu_busy_cyc / (N_SIMD * cyc_xcd) if cyc_xcd else float('nan'):.3f} of {N_SIMD} SIMDs at the clock the profiled pass ran at",
+          f"* wave-cycle split: waiting on memory / LDS (SQ_WAIT_ANY) {c.get('SQ_WAIT_ANY', 0) / max(c.get('SQ_WAVE_CYCLES', 1), 1):.2f}, issue stall (SQ_WAIT_INST_ANY) "
+          f"{c.get('SQ_WAIT_INST_ANY', 0) / max(c.get('SQ_WAVE_CYCLES', 1), 1):.2f}, issuing (SQ_ACTIVE_INST_ANY) {c.get('SQ_ACTIVE_INST_ANY', 0) / max(c.get('SQ_WAVE_CYCLES', 1), 1):.2f}"]
+    if fetch_b is not None and write_b is not None:
+        L += [f"* copy_kernel calibration (1 GiB in + 1 GiB out per dispatch): FETCH_SIZE {copy.get('FETCH_SIZE')} KiB -> x{f_cal:.4f}, WRITE_SIZE {copy.get('WRITE_SIZE')} KiB -> x{w_cal:.4f}",
+              f"* HBM traffic of the launch: fetch {fetch_b / 1e9:.3f} GB + write {write_b / 1e9:.3f} GB = {(fetch_b + write_b) / 1e9:.3f} GB = "
+              f"**{(fetch_b + write_b) / psteps:.1f} B per particle-step** (algorithmic model of SURVEY 8d: 1112 B, served by L2 / Infinity Cache)"]
+    open(os.path.join(ROOT, "profiles", a.name + "_pmc.md"), "w").write("\n".join(L) + "\n")
+    bj = g + "bench.json"
+    if os.path.exists(bj):
+        open(os.path.join(ROOT, "profiles", a.name + "_bench.json"), "w").write(open(bj).read())
+    print("\n".join(L))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3], int(float(sys.argv[4])), int(sys.argv[5]))
+    main()
