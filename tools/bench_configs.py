@@ -6,6 +6,8 @@
   c5  same grid, AdvectionRK45 (adaptive, divergent dt) and AdvectionDiffusionM1 (per-particle counter RNG)
 
 `--scale s` shrinks nx, ny by s (default 1.0 = the BASELINE size).  Prints one JSON object per measured kernel list.
+`--check N` re-runs the first N particle ids of every measured run through the CPU oracle on the same arrays (parity AT bench
+size: deleted set, state, ei, t exact; positions 1e-12) and fails loudly on any difference.
 Synthetic data: smooth analytic patterns on a smoothly warped lon/lat mesh.
 """
 
@@ -77,40 +79,69 @@ def seed_particles(lon, lat, depth, n, seed):
     return blend(lon), blend(lat), rng.uniform(5.0, 0.6 * depth[-1], n)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--config", default="c3", choices=["c3", "c5"])
-    ap.add_argument("--scale", type=float, default=1.0)
-    ap.add_argument("--particles", type=float, default=1e7)
-    ap.add_argument("--steps", type=int, default=24)
-    ap.add_argument("--nt", type=int, default=4)
-    ap.add_argument("--nslots", type=int, default=3)
-    ap.add_argument("--nz", type=int, default=75)
-    ap.add_argument("--hash", default="device", choices=["device", "host"], help="where the Morton table of the grid is built")
-    args = ap.parse_args()
+def check_against_oracle(*, n_check, dsinfo, engine, pset, kernel_names, context, x, y, z, dt, runtime, nthreads=None):
+    """TEST INFRASTRUCTURE inside the measurement script: the first `n_check` particle ids of the run just finished are re-run
+    alone through the CPU oracle (oracle/parcels_oracle.c) on the SAME arrays and hash table -- particles are independent, so
+    the subset must reproduce: deleted set, state, ei, t exactly; positions to 1e-12 of the coordinate scale (1e-11 with the Box-Muller
+    draws of the stochastic kernels).  Raises AssertionError otherwise; returns the worst relative differences."""
+    import numpy as np
 
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from case_utils import compare
+    from oracle import c_oracle as co
+
+    ds, lon, lat, depth = dsinfo
+    fields, dims = {}, {}
+    for name, (fdims, arr) in ds.items():
+        if arr.ndim == 2:  # 2-D Kh fields: (YG, XG) -> (mockT, mockZ, YG, XG)
+            arr, fdims = arr[None, None], ("mockT", "mockZ") + tuple(fdims)
+        fields[name], dims[name] = arr, tuple(fdims)
+    case = dict(name="bench_check", mesh="spherical", lon=lon, lat=lat, depth=depth, x_pad="low", y_pad="low", z_pad="high",
+                time_s=np.arange(fields["U"].shape[0]) * 86400.0, fields=fields, field_dims=dims, cgrid=True, kernels=list(kernel_names),
+                spatial_dtype="float64", x=x[:n_check], y=y[:n_check], z=z[:n_check], t0=None, dt=dt, runtime=runtime, seed=0,
+                context={k: v for k, v in context.items() if k == "dres"}, populate=True, hash_table=engine.hash_table(0))
+    t0 = time.perf_counter()
+    ref, err, _ = co.run_case(case, nthreads=nthreads or (os.cpu_count() or 1))
+    oracle_s = time.perf_counter() - t0
+    assert err is None, f"oracle raised {err}"
+    sel = pset._data["particle_id"] < n_check
+    got = {k: np.asarray(v)[sel] for k, v in pset._data.items()}
+    stochastic = any(k.startswith("AdvectionDiffusion") for k in kernel_names)
+    rtol = 1e-11 if stochastic else 1e-12
+    # relative to the coordinate scale: longitudes run through 0 on this mesh, |x| itself is no yardstick there (tests/test_gpu_fuzz.py)
+    scale = float(max(np.abs(lon).max(), np.abs(lat).max()))
+    rep = compare(got, ref, rtol=rtol, atol_pos=rtol * scale, check_state="all", label="bench-size subset vs oracle",
+                  skip=("dt",) if "AdvectionRK45" in kernel_names else ())
+    worst_abs = {k: float(np.max(np.abs(np.asarray(got[k], dtype=np.float64) - np.asarray(ref[k], dtype=np.float64)))) if len(ref[k]) else 0.0
+                 for k in ("x", "y", "z")}
+    return {"n_check": int(n_check), "survivors": int(sel.sum()), "deleted": int(n_check - sel.sum()), "max_rel_diff": rep,
+            "max_abs_diff": worst_abs, "tolerance": f"|a-b| <= {rtol:g} * (|b| + {scale:.0f})",
+            "exact": ["particle ids of the survivors (= deleted set)", "state", "ei", "t"], "oracle_s": oracle_s}
+
+
+def run_config(config="c3", scale=1.0, particles=1e7, steps=24, nt=4, nslots=3, nz=75, hash="device", check=0, emit=print, dt=3600.0):
     import parcels_amd as pa
 
-    nx, ny = max(int(4322 * args.scale), 32), max(int(3059 * args.scale), 32)
-    n = int(args.particles)
-    ds, lon, lat, depth, gen_s = nemo_like_dataset(nx, ny, args.nz, args.nt, with_kh=(args.config == "c5"))
+    nx, ny = max(int(4322 * scale), 32), max(int(3059 * scale), 32)
+    n = int(particles)
+    ds, lon, lat, depth, gen_s = nemo_like_dataset(nx, ny, nz, nt, with_kh=(config == "c5"))
     t0 = time.perf_counter()
     fs = pa.FieldSet.from_sgrid_conventions(ds, mesh="spherical", skip_field_data_validation=True)
-    if args.config == "c5":
+    if config == "c5":
         fs.add_context("dres", 0.01)
     hash_s = 0.0
-    if args.hash == "host":
+    if hash == "host":
         fs.gridset[0].get_spatial_hash()
         hash_s = time.perf_counter() - t0
     t0 = time.perf_counter()
-    fs.to_device(0, nslots=args.nslots)  # builds the spatial hash on the device unless the host table exists
+    fs.to_device(0, nslots=nslots)  # builds the spatial hash on the device unless the host table exists
     upload_s = time.perf_counter() - t0
     x, y, z = seed_particles(lon, lat, depth, n, seed=3)
-    dt = 3600.0
-    runs = [("AdvectionRK4_3D", [pa.AdvectionRK4_3D, pa.DeleteParticle], None)] if args.config == "c3" else [
+    runs = [("AdvectionRK4_3D", [pa.AdvectionRK4_3D, pa.DeleteParticle], None)] if config == "c3" else [
         ("AdvectionRK45", [pa.AdvectionRK45, pa.DeleteParticle], "rk45"),
         ("AdvectionDiffusionM1", [pa.AdvectionDiffusionM1, pa.DeleteParticle], "m1"),
     ]
+    results = []
     for label, kernels, kind in runs:
         if kind != "rk45":  # RK45 mode is keyed on the context (kernel.py:118): do not leak it into the other runs
             for key in ("RK45_tol", "RK45_min_dt", "RK45_max_dt"):
@@ -125,19 +156,41 @@ def main():
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             t0 = time.perf_counter()
-            pset.execute(kernels, dt=dt, runtime=args.steps * dt)
+            pset.execute(kernels, dt=dt, runtime=steps * dt)
             wall = time.perf_counter() - t0
         st = pset._last_stats
         out = {
-            "config": args.config, "kernels": label, "grid": [nx, ny, args.nz, args.nt], "nslots": args.nslots, "particles": n,
-            "steps_requested": args.steps, "particle_steps": int(st["steps"]), "attempts": int(st["attempts"]),
+            "config": config, "kernels": label, "grid": [nx, ny, nz, nt], "nslots": nslots, "particles": n,
+            "steps_requested": steps, "particle_steps": int(st["steps"]), "attempts": int(st["attempts"]),
             "kernel_ms": st["kernel_ms"], "sort_ms": st["sort_ms"], "launches": st["launches"],
             "particle_steps_per_s_kernel": st["steps"] / (st["kernel_ms"] * 1e-3) if st["kernel_ms"] else None,
             "particle_steps_per_s_wall_incl_h2d_d2h": st["steps"] / wall, "wall_s": wall,
             "remaining_particles": len(pset), "state_counts": st["state_counts"],
-            "dataset_generation_s": gen_s, "hash_build": args.hash, "host_hash_build_s": hash_s, "device_create_s": upload_s,
+            "dataset_generation_s": gen_s, "hash_build": hash, "host_hash_build_s": hash_s, "device_create_s": upload_s,
         }
-        print(json.dumps(out), flush=True)
+        if check:
+            out["check"] = check_against_oracle(n_check=min(int(check), n), dsinfo=({k: (v.dims, v.data) for k, v in ds.data_vars.items()}, lon, lat, depth), engine=fs._engine,
+                                                pset=pset, kernel_names=[label, "DeleteParticle"], context=fs.context, x=x, y=y, z=z, dt=dt,
+                                                runtime=steps * dt)
+        emit(json.dumps(out), flush=True) if emit is print else emit(out)
+        results.append(out)
+    return results
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="c3", choices=["c3", "c5"])
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--particles", type=float, default=1e7)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--nt", type=int, default=4)
+    ap.add_argument("--nslots", type=int, default=3)
+    ap.add_argument("--nz", type=int, default=75)
+    ap.add_argument("--hash", default="device", choices=["device", "host"], help="where the Morton table of the grid is built")
+    ap.add_argument("--dt", type=float, default=3600.0)
+    ap.add_argument("--check", type=float, default=0, help="re-run the first N particles through the CPU oracle and compare (0 = off)")
+    a = ap.parse_args()
+    run_config(a.config, a.scale, a.particles, a.steps, a.nt, a.nslots, a.nz, a.hash, int(a.check), dt=a.dt)
 
 
 if __name__ == "__main__":
