@@ -27,6 +27,49 @@ def shard_slice(n_total: int, rank: int, world: int) -> slice:
     return slice(start, start + base + (1 if rank < rem else 0))
 
 
+def resolve_shard(shard) -> tuple[int, int]:
+    """(rank, world) from ``ParticleSet(shard=...)``: an explicit pair, or "auto" = the initialised torch.distributed group."""
+    if isinstance(shard, str):
+        if shard != "auto":
+            raise ValueError(f"shard must be (rank, world) or 'auto'. Got {shard!r}")
+        return dist_rank_world()
+    rank, world = (int(v) for v in shard)
+    if not (0 <= rank < world):
+        raise ValueError(f"shard rank {rank} out of range for world size {world}")
+    return rank, world
+
+
+def dist_rank_world(group=None) -> tuple[int, int]:
+    """(rank, world size) of the torch.distributed group, (0, 1) when none is initialised."""
+    try:
+        import torch.distributed as dist
+    except Exception:  # torch is plumbing: absent => single process
+        return 0, 1
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0, 1
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def gather_write_columns(columns: dict, group=None, device=None) -> dict | None:
+    """The write-out exchange of ParticleFile.write (particlefile.py:142-180) across ranks: every rank passes the NumPy columns of
+    ITS particles that pass the write filter; rank 0 receives the concatenation in rank order (= id order for contiguous
+    shards), the others None.  Over RCCL (backend "nccl") the columns travel as device tensors on ``device``; over gloo as
+    host tensors.  Ranks may contribute different, also zero, row counts."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    on_gpu = dist.get_backend(group) == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device() if device is None else int(device)) if on_gpu else torch.device("cpu")
+    tens = {}
+    for name, col in columns.items():
+        tens[name] = torch.from_numpy(np.ascontiguousarray(col)).to(dev)
+    out = gather_output_columns(tens, group)
+    if dist.get_rank(group) != 0:
+        return None
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
 def gather_output_columns(columns: dict, group=None) -> dict:
     """All-gather a dict of equally long 1-D torch tensors (one row per local particle) over the process group.
 

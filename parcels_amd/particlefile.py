@@ -44,7 +44,13 @@ def get_schema(pclass, file_metadata, fset_time_interval):
 
 
 class ParticleFile:
-    def __init__(self, path, outputdt, compression="zstd", mode=None):
+    """One Parquet file of trajectories.  With an initialised torch.distributed group of more than one rank (one process per GPU,
+    ParticleSet(shard=...)) every rank calls ``write`` collectively: the rows passing the write filter are gathered (RCCL
+    all-gather over xGMI under backend "nccl", gloo in the CPU tests -- parcels_amd.distributed.gather_write_columns) and rank 0
+    appends the one table; the file is byte-identical to the one a single process writes for the whole id space.
+    ``distributed=False`` keeps a ParticleFile rank-local."""
+
+    def __init__(self, path, outputdt, compression="zstd", mode=None, distributed=None, group=None):
         if not isinstance(outputdt, (np.timedelta64, timedelta, float)):
             raise ValueError(f"Expected outputdt to be a np.timedelta64, datetime.timedelta or float (in seconds), got {type(outputdt)}")
         self._compression = compression
@@ -59,13 +65,21 @@ class ParticleFile:
         self._writer = None
         if mode not in {None, "w"}:
             raise ValueError(f"Invalid mode value {mode!r}. Expected one of None or 'w'.")
-        if path.exists():
-            if mode is None:
-                raise ValueError(f"Path '{path}' already exists. Use mode='w' or use a new path.")
-            path.unlink()
-        if not path.parent.exists():
-            raise ValueError(f"Folder location for '{path} does not exist. Create the folder location first.")
+        from .distributed import dist_rank_world
+
+        self._group = group
+        self._rank, self._world = dist_rank_world(group) if distributed is not False else (0, 1)
+        if distributed and self._world == 1:
+            raise ValueError("ParticleFile(distributed=True) needs an initialised torch.distributed group")
+        if self._rank == 0:  # the file belongs to rank 0; the other ranks only contribute rows
+            if path.exists():
+                if mode is None:
+                    raise ValueError(f"Path '{path}' already exists. Use mode='w' or use a new path.")
+                path.unlink()
+            if not path.parent.exists():
+                raise ValueError(f"Folder location for '{path} does not exist. Create the folder location first.")
         self.metadata = {}
+        self.gather_seconds = 0.0  # time spent in the write-out exchange (multi-rank only)
 
     def set_metadata(self, parcels_grid_mesh):
         from . import __version__
@@ -101,8 +115,19 @@ class ParticleFile:
         data = pset._data
         if isinstance(t, (np.timedelta64, np.datetime64)):
             t = to_seconds(t - fieldset.time_interval.left)
-        idx = _to_write_particles(data, t) if indices is None else indices
+        idx = _to_write_particles(data, t) if indices is None else indices  # the reference's filter, applied BEFORE the exchange
         cols = {v.name: data[v.name][idx] for v in _get_vars_to_write(pset._pclass)}
+        if self._world > 1:
+            import time as _time
+
+            from .distributed import gather_write_columns
+
+            t0 = _time.perf_counter()
+            eng = getattr(fieldset, "_engine", None)
+            cols = gather_write_columns(cols, self._group, device=getattr(eng, "device", None))
+            self.gather_seconds += _time.perf_counter() - t0
+            if cols is None:
+                return
         self.write_columns(pset._pclass, cols, fieldset.time_interval)
 
     def close(self):

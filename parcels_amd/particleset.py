@@ -56,8 +56,13 @@ class ParticleSet:
 
 
     def __init__(self, fieldset, pclass=Particle, *, t=None, z=None, y=None, x=None, particle_ids=None, seed=0,
-                 sort_by_cell=False, **kwargs):
+                 sort_by_cell=False, shard=None, **kwargs):
+        """``shard``: None = all particles live here; ``(rank, world)`` or ``"auto"`` (rank / world size of the initialised
+        torch.distributed group) = every process is given the SAME arrays and keeps its contiguous block of the id space
+        (parcels_amd.distributed.shard_slice) -- fields are replicated, particles never migrate, and a ParticleFile gathers
+        the to-write columns of all ranks at every output time."""
         object.__setattr__(self, "_data", None)
+        object.__setattr__(self, "_shard", None)
         self.fieldset = fieldset
         self._kernel = None
         self.seed = int(seed)
@@ -99,6 +104,15 @@ class ParticleSet:
         for kwvar in kwargs:
             kwargs[kwvar] = np.array(kwargs[kwvar]).flatten()
             assert x.size == kwargs[kwvar].size, f"{kwvar} and positions (x, y, z) don't have the same lengths."
+        if shard is not None:
+            from .distributed import resolve_shard, shard_slice
+
+            rank, world = resolve_shard(shard)
+            sl = shard_slice(x.size, rank, world)
+            particle_ids = np.asarray(particle_ids)[sl]
+            t, z, y, x = t[sl], z[sl], y[sl], x[sl]
+            kwargs = {k: v[sl] for k, v in kwargs.items()}
+            self._shard = (rank, world)
         self._data = create_particle_data(
             pclass=pclass, nparticles=x.size, ngrids=len(fieldset.gridset),
             initial=dict(t=t, z=z, y=y, x=x, particle_id=np.asarray(particle_ids)),

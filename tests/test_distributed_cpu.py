@@ -68,3 +68,88 @@ def test_write_out_allgather_world2():
     assert np.array_equal(out["x"], expect_ids * 0.5)
     assert out["z"].dtype == np.float32 and np.array_equal(out["z"], expect_ids.astype(np.float32))
     assert np.all(out["t"] == 3600.0)
+
+
+# ---- the sharded ParticleSet + collective ParticleFile.write: two ranks produce the single-process file, byte for byte --------
+def _synthetic_run(pset, pf, times):
+    """Stand-in for ParticleSet.execute's output loop (particleset.py:436-459) on the host columns: positions are a function
+    of (particle_id, time); some particles lag behind the output time (filtered out by |t_p - t| <= |dt|/2), some are deleted on
+    the way, and one write finds nobody."""
+    import numpy as np
+
+    d = pset._data
+    d["dt"][:] = 600.0
+    for k, tm in enumerate(times):
+        ids = d["particle_id"].astype(np.float64)
+        d["x"][:] = (ids * 0.25 + tm * 1e-3).astype(d["x"].dtype)
+        d["y"][:] = (np.sin(ids) * 10 + k).astype(d["y"].dtype)
+        d["z"][:] = (ids % 7).astype(d["z"].dtype)
+        d["t"][:] = tm
+        d["t"][d["particle_id"] % 5 == k % 5] = tm - 1000.0  # outside dt/2: not written this time
+        if k == 2:
+            d["t"][:] = tm + 5000.0  # nobody passes the filter
+        pf.write(pset, tm)
+        gone = np.where(d["particle_id"] % 11 == k)[0]  # Kernel.remove_deleted between intervals
+        pset.remove_indices(gone)
+
+
+def _make_fieldset():
+    import parcels_amd as pa
+    from case_utils import build_fieldset
+    from oracle import cases
+
+    return build_fieldset(cases.rect_agrid_case("dist", mesh="spherical", kernels=["AdvectionRK4"], seed=1, npart=4))
+
+
+def _pf_worker(rank, world, port, n_total, path):
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import parcels_amd as pa
+
+        fs = _make_fieldset()
+        ids = np.arange(n_total)
+        pset = pa.ParticleSet(fs, x=ids * 0.1, y=ids * 0.0, z=ids * 0.0, t=np.zeros(n_total), shard="auto")
+        assert pset._shard == (rank, world) and len(pset) == shard_slice(n_total, rank, world).stop - shard_slice(n_total, rank, world).start
+        pf = pa.ParticleFile(path, outputdt=600.0)
+        pf.set_metadata("spherical")
+        with pf:
+            _synthetic_run(pset, pf, [0.0, 600.0, 1200.0, 1800.0, 2400.0])
+        assert (rank == 0) == os.path.exists(path) or rank != 0
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_write_the_single_process_file_byte_for_byte(tmp_path):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import parcels_amd as pa
+
+    n_total, world = 1003, 2
+    # single process, whole id space
+    fs = _make_fieldset()
+    ids = np.arange(n_total)
+    pset = pa.ParticleSet(fs, x=ids * 0.1, y=ids * 0.0, z=ids * 0.0, t=np.zeros(n_total))
+    one = tmp_path / "one.parquet"
+    pf = pa.ParticleFile(one, outputdt=600.0)
+    pf.set_metadata("spherical")
+    with pf:
+        _synthetic_run(pset, pf, [0.0, 600.0, 1200.0, 1800.0, 2400.0])
+    # two ranks over gloo
+    two = tmp_path / "two.parquet"
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_pf_worker, args=(r, world, port, n_total, str(two))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    assert one.read_bytes() == two.read_bytes()
+    df = pa.read_particlefile(two)
+    assert len(df) > n_total and df["particle_id"].max() == n_total - 1

@@ -22,3 +22,31 @@ def test_bench_config_subset_reproduces_through_the_oracle(gpu, config):
         c = r["check"]
         assert c["survivors"] > 0.9 * c["n_check"] and r["particle_steps"] > 0
         assert max(c["max_abs_diff"].values()) <= 1e-11 * 6000  # z in metres is the largest coordinate
+
+
+def test_c4_two_ranks_write_the_single_process_file(gpu, tmp_path):
+    """BASELINE config 4 end to end on ONE GPU (rehearsal: two ranks share cuda:0 and talk over gloo, because RCCL refuses two
+    ranks on one device): one id space sharded by id, fields from one shared memory-mapped copy, ParticleSet.execute with a
+    ParticleFile whose rows come from the all-gather of the to-write columns -- and the file equals, byte for byte, the one a
+    single process writes for the whole id space (deleted particles, cell sort and ring included)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    from case_utils import ROOT_DIR
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PARCELS_AMD_BENCH_REHEARSAL="1", PK_C4_DIR=str(tmp_path / "shared"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(port), os.path.join(ROOT_DIR, "tools", "bench_configs.py"), "--config", "c4", "--scale", "0.1", "--particles", "40000", "--steps", "11",
+           "--nz", "12", "--dt", "21600", "--output-every", "3", "--verify-single"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT_DIR, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["particles_total"] == 80000 and out["byte_identical_to_single_process_file"] is True
+    assert out["parquet_rows"] >= 4 * out["remaining_particles"]

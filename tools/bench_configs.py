@@ -3,6 +3,10 @@
 
   c3  3-D NEMO-like curvilinear C-grid nx=4322, ny=3059, nz=75, fp32 U,V,W, 1e7 particles, AdvectionRK4_3D,
       field-slab ring (nslots < nt) with asynchronous prefetch of the next level
+  c4  the c3 grid with `--particles` per GPU on every rank of one node: launch with
+        python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P tools/bench_configs.py --config c4
+      one id space sharded by id, fields replicated from ONE shared memory-mapped host copy, ParticleFile on rank 0 fed by the
+      RCCL all-gather of the to-write columns
   c5  same grid, AdvectionRK45 (adaptive, divergent dt) and AdvectionDiffusionM1 (per-particle counter RNG)
 
 `--scale s` shrinks nx, ny by s (default 1.0 = the BASELINE size).  Prints one JSON object per measured kernel list.
@@ -25,7 +29,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def nemo_like_dataset(nx, ny, nz, nt, with_kh=False, seed=0):
+def nemo_like_dataset(nx, ny, nz, nt, with_kh=False, seed=0, shared_dir=None, generate=True):
+    """shared_dir: U, V, W live in .npy files there and are memory-mapped (config c4: the ranks of one node share ONE copy of
+    the field levels through the page cache instead of holding a private 48 GB each); generate=False opens them read-only."""
     import parcels_amd as pa
 
     t0 = time.perf_counter()
@@ -41,10 +47,16 @@ def nemo_like_dataset(nx, ny, nz, nt, with_kh=False, seed=0):
     pu = (0.5 * np.cos(6 * np.pi * jj) * (1.0 + 0.3 * np.sin(10 * np.pi * ii))).astype(np.float32)
     pv = (0.3 * np.sin(8 * np.pi * ii) * np.cos(4 * np.pi * jj)).astype(np.float32)
     pw = (1e-4 * np.sin(12 * np.pi * ii) * np.sin(12 * np.pi * jj)).astype(np.float32)
-    U = np.empty((nt, nz, ny, nx), np.float32)
-    V = np.empty((nt, nz, ny, nx), np.float32)
-    W = np.empty((nt, nz, ny, nx), np.float32)
-    for k in range(nt):
+    if shared_dir is None:
+        U = np.empty((nt, nz, ny, nx), np.float32)
+        V = np.empty((nt, nz, ny, nx), np.float32)
+        W = np.empty((nt, nz, ny, nx), np.float32)
+    else:
+        os.makedirs(shared_dir, exist_ok=True)
+        mode = "w+" if generate else "r"
+        kw = dict(dtype=np.float32, shape=(nt, nz, ny, nx)) if generate else {}
+        U, V, W = (np.lib.format.open_memmap(os.path.join(shared_dir, f"{c}.npy"), mode=mode, **kw) for c in "UVW")
+    for k in range(nt if generate else 0):
         f = np.float32(1.0 + 0.2 * np.sin(2 * np.pi * k / max(nt, 2)))
         np.multiply(zprof, pu[None] * f, out=U[k])
         np.multiply(zprof, pv[None] * f, out=V[k])
@@ -77,6 +89,108 @@ def seed_particles(lon, lat, depth, n, seed):
         return (a[j0, i0] * (1 - fi) * (1 - fj) + a[j0, i0 + 1] * fi * (1 - fj) + a[j0 + 1, i0] * (1 - fi) * fj + a[j0 + 1, i0 + 1] * fi * fj)
 
     return blend(lon), blend(lat), rng.uniform(5.0, 0.6 * depth[-1], n)
+
+
+POS_BLOCK = 1 << 20
+
+
+def seed_particles_block(lon, lat, depth, lo, hi, seed):
+    """Particles lo..hi-1 of one global id space, drawn block-wise so that positions do not depend on the sharding."""
+    xs, ys, zs = [], [], []
+    for b in range(lo // POS_BLOCK, (max(hi, lo + 1) - 1) // POS_BLOCK + 1):
+        x, y, z = seed_particles(lon, lat, depth, POS_BLOCK, seed=[seed, b])
+        sl = slice(max(lo - b * POS_BLOCK, 0), min(hi - b * POS_BLOCK, POS_BLOCK))
+        xs.append(x[sl]); ys.append(y[sl]); zs.append(z[sl])
+    return np.concatenate(xs), np.concatenate(ys), np.concatenate(zs)
+
+
+def run_c4(scale=1.0, particles=1e7, steps=24, nt=4, nslots=3, nz=75, output_every=6, verify_single=False, dt=3600.0, shared_dir=None):
+    """BASELINE config 4: the C3 grid, `particles` per GPU over all ranks of one node (launch with torch.distributed.run, one
+    process per GPU), ONE id space sharded by id, fields replicated in HBM from one shared memory-mapped copy on the host, no
+    collective on the data path, and a ParticleFile on rank 0 fed by the RCCL all-gather of the to-write columns every
+    `output_every` steps.  verify_single: rank 0 re-runs the whole id space alone and compares the Parquet files byte for byte."""
+    import torch
+    import torch.distributed as dist
+
+    import parcels_amd as pa
+    from parcels_amd.distributed import shard_slice
+
+    rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
+    rehearsal = os.environ.get("PARCELS_AMD_BENCH_REHEARSAL") == "1"  # 1-GPU box: all ranks on cuda:0, gloo instead of RCCL
+    if rehearsal:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("gloo" if rehearsal else "nccl", **({} if rehearsal else {"device_id": torch.device("cuda", local_rank)}))
+    shared_dir = shared_dir or os.environ.get("PK_C4_DIR", f"/dev/shm/pk_c4_{os.environ.get('MASTER_PORT', '0')}")
+    nx, ny = max(int(4322 * scale), 32), max(int(3059 * scale), 32)
+    n = int(particles)
+    t0 = time.perf_counter()
+    if rank == 0:
+        nemo_like_dataset(nx, ny, nz, nt, shared_dir=shared_dir, generate=True)
+    if world > 1:
+        dist.barrier()
+    ds, lon, lat, depth, _ = nemo_like_dataset(nx, ny, nz, nt, shared_dir=shared_dir, generate=False)
+    gen_s = time.perf_counter() - t0
+    out_path = os.path.join(shared_dir, "c4.parquet")
+
+    def one_run(lo, hi, path, distributed):
+        fs = pa.FieldSet.from_sgrid_conventions(ds, mesh="spherical", skip_field_data_validation=True)
+        fs.to_device(local_rank, nslots=nslots)
+        x, y, z = seed_particles_block(lon, lat, depth, lo, hi, seed=3)
+        pset = pa.ParticleSet(fs, pclass=pa.get_default_particle(np.float64), x=x, y=y, z=z, t=np.zeros(hi - lo), particle_ids=np.arange(lo, hi),
+                              sort_by_cell=True)
+        pset.populate_indices()
+        pf = pa.ParticleFile(path, outputdt=float(output_every * dt), mode="w", distributed=None if distributed else False)
+        torch.cuda.synchronize()
+        if distributed and world > 1:
+            dist.barrier()
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            t1 = time.perf_counter()
+            pset.execute([pa.AdvectionRK4_3D, pa.DeleteParticle], dt=dt, runtime=steps * dt, output_file=pf)
+            torch.cuda.synchronize()
+            if distributed and world > 1:
+                dist.barrier()
+            wall = time.perf_counter() - t1
+        return pset, pf, wall
+
+    sl = shard_slice(world * n, rank, world)
+    pset, pf, wall = one_run(sl.start, sl.stop, out_path, True)
+    st = pset._last_stats
+    vals = torch.tensor([wall, float(len(pset)), pf.gather_seconds], dtype=torch.float64)
+    if world > 1:
+        mx = vals.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = vals.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        wall, remaining, gather_s = float(mx[0]), int(sm[1]), float(mx[2])
+    else:
+        remaining, gather_s = len(pset), pf.gather_seconds
+    if rank == 0:
+        import pyarrow.parquet as pq
+
+        rows = pq.ParquetFile(out_path).metadata.num_rows
+        out = {"config": "c4", "kernels": "AdvectionRK4_3D", "grid": [nx, ny, nz, nt], "nslots": nslots, "n_gpus": world, "particles_per_gpu": n,
+               "particles_total": world * n, "steps": steps, "output_every_steps": output_every, "wall_s_incl_writeout": wall,
+               "particle_steps_per_s_wall": world * n * steps / wall, "writeout_gather_s_max_rank": gather_s, "parquet_rows": rows,
+               "remaining_particles": remaining, "last_interval_kernel_ms_rank0": st["kernel_ms"], "dataset_generation_s": gen_s,
+               "shared_fields": shared_dir, **({"rehearsal_shared_gpu_gloo": True} if rehearsal else {})}
+        if verify_single:
+            single = os.path.join(shared_dir, "c4_single.parquet")
+            one_run(0, world * n, single, False)
+            out["byte_identical_to_single_process_file"] = open(single, "rb").read() == open(out_path, "rb").read()
+            assert out["byte_identical_to_single_process_file"], "the gathered Parquet differs from the single-process file"
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0 and os.environ.get("PK_C4_KEEP") != "1":
+        import shutil
+
+        shutil.rmtree(shared_dir, ignore_errors=True)
 
 
 def check_against_oracle(*, n_check, dsinfo, engine, pset, kernel_names, context, x, y, z, dt, runtime, nthreads=None):
@@ -179,7 +293,7 @@ def run_config(config="c3", scale=1.0, particles=1e7, steps=24, nt=4, nslots=3, 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", default="c3", choices=["c3", "c5"])
+    ap.add_argument("--config", default="c3", choices=["c3", "c4", "c5"])
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--particles", type=float, default=1e7)
     ap.add_argument("--steps", type=int, default=24)
@@ -189,7 +303,12 @@ def main():
     ap.add_argument("--hash", default="device", choices=["device", "host"], help="where the Morton table of the grid is built")
     ap.add_argument("--dt", type=float, default=3600.0)
     ap.add_argument("--check", type=float, default=0, help="re-run the first N particles through the CPU oracle and compare (0 = off)")
+    ap.add_argument("--output-every", type=int, default=6, help="c4: steps between write-outs")
+    ap.add_argument("--verify-single", action="store_true", help="c4: rank 0 re-runs the whole id space alone and compares the files")
     a = ap.parse_args()
+    if a.config == "c4":
+        run_c4(a.scale, a.particles, a.steps, a.nt, a.nslots, a.nz, a.output_every, a.verify_single, a.dt)
+        return
     run_config(a.config, a.scale, a.particles, a.steps, a.nt, a.nslots, a.nz, a.hash, int(a.check), dt=a.dt)
 
 
