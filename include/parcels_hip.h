@@ -174,6 +174,12 @@ int32_t pk_field_create(pk_ctx* ctx, const pk_field_desc* desc, int32_t* field_i
  * pk_execute only reads committed levels and never waits on the copy stream, so an async upload of level k+1
  * overlaps the RK sub-steps running on level k.  Stands in for WindowedArray._ensure (_windowed_array.py:56-72). */
 int32_t pk_field_upload_level(pk_ctx* ctx, int32_t field_id, int32_t level, const void* host_data, int32_t async);
+/* The same for a whole packed group (pack_count > 1): host_data[k] is the level of the k-th component in creation order (the
+ * leader first).  The components are interleaved into {U,V,W} structs by the host threads that fill the pinned staging chunks
+ * anyway, so the DMA lands the level in its final layout and no device-side repack runs (per-field uploads of a packed field
+ * go through a device staging buffer + an interleave kernel instead).  Slot bookkeeping as above, for every field of the group. */
+int32_t pk_field_upload_group_level(pk_ctx* ctx, int32_t leader_field_id, int32_t level, const void* const* host_data, int32_t ncomp,
+                                    int32_t async);
 int32_t pk_field_sync(pk_ctx* ctx); /* wait for the copy stream and commit every pending level */
 /* Drop every committed level of the field's ring outside [lo_level, hi_level] (WindowedArray's eviction behind the clock,
  * _windowed_array.py:64-72, for either time direction or a jump): pk_execute requires the resident levels of a ring to be
@@ -213,6 +219,14 @@ int32_t pk_particles_d2h(pk_ctx* ctx);
 #define PK_COL_EI 0x400u
 #define PK_COL_PARTICLE_ID 0x800u
 int32_t pk_particles_d2h_columns(pk_ctx* ctx, uint32_t column_mask);
+/* Asynchronous write-out (ParticleSet.execute's output step, particleset.py:452-459, overlapped with the next interval):
+ * _begin snapshots the selected columns -- un-sorted into host row order -- into one of two device staging sets on the compute
+ * stream and enqueues their copy into pinned host columns on the copy stream; it returns at once and the next pk_execute may
+ * start.  _wait blocks until the copy of that slot has landed and returns the pinned columns (NULL for columns outside the mask;
+ * valid until the next _begin on the slot).  _wait only waits on an event and may be called from a second host thread (the
+ * Parquet encoder) while the first thread drives the next launch. */
+int32_t pk_particles_snapshot_begin(pk_ctx* ctx, uint32_t column_mask, int32_t slot);
+int32_t pk_particles_snapshot_wait(pk_ctx* ctx, int32_t slot, pk_particles_desc* out_host_columns);
 /* device pointers of the bound columns in CURRENT device order (for RCCL all-gather of the output
  * columns at write-out; see parcels_amd/distributed.py).  perm (int64*, may be NULL when the particles
  * have not been cell-sorted) maps device row -> original row. */

@@ -174,6 +174,7 @@ ABI_SYMBOLS = [
     "pk_grid_hash_download",
     "pk_field_create",
     "pk_field_upload_level",
+    "pk_field_upload_group_level",
     "pk_field_sync",
     "pk_field_slots",
     "pk_field_evict_outside",
@@ -181,6 +182,8 @@ ABI_SYMBOLS = [
     "pk_particles_h2d",
     "pk_particles_d2h",
     "pk_particles_d2h_columns",
+    "pk_particles_snapshot_begin",
+    "pk_particles_snapshot_wait",
     "pk_particles_device",
     "pk_particles_compact",
     "pk_execute",
@@ -228,6 +231,7 @@ def load():
     lib.pk_grid_hash_download.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 4
     lib.pk_field_create.argtypes = [C.c_void_p, C.POINTER(FieldDesc), C.POINTER(C.c_int32)]
     lib.pk_field_upload_level.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
+    lib.pk_field_upload_group_level.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.c_int32, C.c_int32]
     lib.pk_field_sync.argtypes = [C.c_void_p]
     lib.pk_field_evict_outside.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     lib.pk_field_slots.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -235,6 +239,8 @@ def load():
     lib.pk_particles_h2d.argtypes = [C.c_void_p]
     lib.pk_particles_d2h.argtypes = [C.c_void_p]
     lib.pk_particles_d2h_columns.argtypes = [C.c_void_p, C.c_uint32]
+    lib.pk_particles_snapshot_begin.argtypes = [C.c_void_p, C.c_uint32, C.c_int32]
+    lib.pk_particles_snapshot_wait.argtypes = [C.c_void_p, C.c_int32, C.POINTER(ParticlesDesc)]
     lib.pk_particles_device.argtypes = [C.c_void_p, C.POINTER(ParticlesDesc), C.POINTER(C.c_void_p)]
     lib.pk_particles_compact.argtypes = [C.c_void_p, C.POINTER(ParticlesDesc), C.POINTER(C.c_int64)]
     lib.pk_execute.argtypes = [C.c_void_p, C.POINTER(ExecParams), C.POINTER(ExecStats)]

@@ -90,6 +90,19 @@ struct pk_ctx {
     int no_cell_cache = 0;
     int no_hash_dir = 0;
     int no_fast = 0;
+    // asynchronous write-out snapshots (pk_particles_snapshot_begin / _wait): two sets of device staging columns (host row order)
+    // + pinned host columns, so that the D2H and the encode of interval k overlap the launch of interval k+1
+    struct Snapshot {
+        void* dev[12] = {};
+        void* host[12] = {};
+        int64_t capacity = 0;  // rows the buffers were sized for
+        int64_t n = 0;         // rows of the snapshot in flight
+        uint32_t mask = 0;
+        int ngrids = 0;
+        size_t ss = 0;
+        hipEvent_t ready = nullptr, done = nullptr;
+        bool in_flight = false;
+    } snap[2];
     // {a, 1/width} coordinate tables of the fast A-grid path (pk_fast_agrid.h), cached per (main grid, main field)
     double* d_fast_tab = nullptr;
     size_t fast_tab_cap = 0;
@@ -335,6 +348,48 @@ static void parallel_memcpy(void* dst, const void* src, size_t bytes) {
     for (auto& t : pool) t.join();
 }
 
+// the same staging step for a packed group: elements [0, n) of `ncomp` separate host arrays -> one array of structs
+// {c0, c1, ...} in the pinned chunk, so that the DMA lands the level in its final layout (no device-side repack)
+template <class T>
+static void interleave_range(T* dst, const T* const* src, int ncomp, size_t lo, size_t hi) {
+    // non-temporal stores: the pinned chunk is written once and read by the DMA engine, never by this core -- no read-for-
+    // ownership of the destination lines, a third less memory traffic for the fill that has to keep up with the PCIe link
+    if (ncomp == 3) {
+        const T *a = src[0], *b = src[1], *c = src[2];
+        for (size_t i = lo; i < hi; i++) {
+            __builtin_nontemporal_store(a[i], &dst[3 * i]);
+            __builtin_nontemporal_store(b[i], &dst[3 * i + 1]);
+            __builtin_nontemporal_store(c[i], &dst[3 * i + 2]);
+        }
+    } else if (ncomp == 2) {
+        const T *a = src[0], *b = src[1];
+        for (size_t i = lo; i < hi; i++) {
+            __builtin_nontemporal_store(a[i], &dst[2 * i]);
+            __builtin_nontemporal_store(b[i], &dst[2 * i + 1]);
+        }
+    } else {
+        for (size_t i = lo; i < hi; i++)
+            for (int k = 0; k < ncomp; k++) dst[(size_t)ncomp * i + k] = src[k][i];
+    }
+}
+template <class T>
+static void parallel_interleave(T* dst, const T* const* src, int ncomp, size_t n) {
+    const size_t min_chunk = (size_t)1 << 18;
+    const unsigned nthr = (unsigned)std::min<size_t>(copy_threads(), std::max<size_t>(1, n / min_chunk));
+    if (nthr <= 1) {
+        interleave_range(dst, src, ncomp, 0, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    const size_t per = (n + nthr - 1) / nthr;
+    for (unsigned k = 0; k < nthr; k++) {
+        const size_t lo = (size_t)k * per, hi = std::min(n, lo + per);
+        if (lo >= hi) break;
+        pool.emplace_back([=]() { interleave_range(dst, src, ncomp, lo, hi); });
+    }
+    for (auto& t : pool) t.join();
+}
+
 template <class T>
 static int32_t upload(pk_ctx* ctx, HostGrid& g, const T* host, size_t n, const T** dev) {
     *dev = nullptr;
@@ -404,6 +459,19 @@ int32_t pk_set_option(pk_ctx* ctx, const char* name, int32_t value) {
     return 0;
 }
 
+static void free_snapshots(pk_ctx* ctx) {
+    for (auto& sn : ctx->snap) {
+        if (sn.in_flight && sn.done) (void)hipEventSynchronize(sn.done);
+        for (int k = 0; k < 12; k++) {
+            if (sn.dev[k]) (void)hipFree(sn.dev[k]);
+            if (sn.host[k]) (void)hipHostFree(sn.host[k]);
+            sn.dev[k] = sn.host[k] = nullptr;
+        }
+        sn.capacity = 0;
+        sn.in_flight = false;
+    }
+}
+
 static void free_particles(pk_ctx* ctx) {
     void* cols[] = {ctx->dev.t,  ctx->dev.z,  ctx->dev.y,       ctx->dev.x,     ctx->dev.dz, ctx->dev.dy,
                     ctx->dev.dx, ctx->dev.dt, ctx->dev.next_dt, ctx->dev.state, ctx->dev.ei, ctx->dev.particle_id};
@@ -435,6 +503,11 @@ int32_t pk_destroy(pk_ctx* ctx) {
         if (f.dev_time) (void)hipFree(f.dev_time);
     }
     free_particles(ctx);
+    free_snapshots(ctx);
+    for (auto& sn : ctx->snap) {
+        if (sn.ready) (void)hipEventDestroy(sn.ready);
+        if (sn.done) (void)hipEventDestroy(sn.done);
+    }
     if (ctx->d_pack_tmp) (void)hipFree(ctx->d_pack_tmp);
     if (ctx->d_fast_tab) (void)hipFree(ctx->d_fast_tab);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
@@ -625,6 +698,15 @@ int32_t pk_field_create(pk_ctx* ctx, const pk_field_desc* desc, int32_t* field_i
         PK_HIP(ctx, hipMalloc(&f.dev_data, f.level_bytes * nslots * ncomp));
         PK_HIP(ctx, hipMemset(f.dev_data, 0, f.level_bytes * nslots * ncomp));  // never expose NaN garbage (weight-0 reads)
     }
+    if (nslots < desc->nt) {
+        // a streamed field: pin the two staging chunks now (pinning 512 MiB costs ~0.15 s -- at creation, not inside the first run)
+        for (int k = 0; k < 2; k++)
+            if (!ctx->stage[k]) {
+                PK_HIP(ctx, hipHostMalloc(&ctx->stage[k], PK_STAGE_CHUNK_BYTES, hipHostMallocDefault));
+                ctx->stage_bytes[k] = PK_STAGE_CHUNK_BYTES;
+                PK_HIP(ctx, hipEventRecord(ctx->stage_ev[k], ctx->copy));
+            }
+    }
     f.time.assign(desc->nt, 0.0);
     if (desc->time) std::copy(desc->time, desc->time + desc->nt, f.time.begin());
     PK_HIP(ctx, hipMalloc((void**)&f.dev_time, sizeof(double) * desc->nt));
@@ -714,6 +796,57 @@ int32_t pk_field_upload_level(pk_ctx* ctx, int32_t field_id, int32_t level, cons
         f.slot_level[slot] = level;
         f.slot_pending[slot] = -1;
     }
+    return 0;
+}
+
+int32_t pk_field_upload_group_level(pk_ctx* ctx, int32_t leader_id, int32_t level, const void* const* host_data, int32_t ncomp_given,
+                                    int32_t async) {
+    if (!ctx || !host_data) return -2;
+    if (leader_id < 0 || leader_id >= (int)ctx->fields.size()) return ctx->fail("unknown field id");
+    HostField& L = ctx->fields[leader_id];
+    const int ncomp = L.d.ncomp;
+    if (ncomp <= 1 || !L.owns_data) return ctx->fail("pk_field_upload_group_level: the field does not lead a packed group");
+    if (ncomp_given != ncomp || L.pack_used != ncomp) return ctx->fail("pk_field_upload_group_level: one host level per component of the complete group is required");
+    if (ncomp > 8) return ctx->fail("pk_field_upload_group_level: at most 8 components");
+    if (level < 0 || level >= L.desc.nt) return ctx->fail("time level out of range");
+    for (int k = 0; k < ncomp; k++)
+        if (!host_data[k]) return -2;
+    PK_HIP(ctx, hipSetDevice(ctx->device));
+    const int slot = level % L.d.nslots;
+    const size_t esz = L.desc.dtype == PK_F64 ? 8 : 4;
+    const size_t level_elems = L.level_bytes / esz;
+    char* dst = (char*)L.dev_data + (size_t)slot * L.level_bytes * ncomp;
+    const size_t chunk_elems = PK_STAGE_CHUNK_BYTES / (esz * ncomp);
+    for (size_t off = 0; off < level_elems; off += chunk_elems) {
+        const size_t len = std::min(chunk_elems, level_elems - off);
+        const int k = ctx->stage_next;
+        ctx->stage_next ^= 1;
+        if (!ctx->stage[k]) {
+            PK_HIP(ctx, hipHostMalloc(&ctx->stage[k], PK_STAGE_CHUNK_BYTES, hipHostMallocDefault));
+            ctx->stage_bytes[k] = PK_STAGE_CHUNK_BYTES;
+        } else {
+            PK_HIP(ctx, hipEventSynchronize(ctx->stage_ev[k]));  // previous DMA out of this buffer finished
+        }
+        if (esz == 8) {
+            const double* src[8];
+            for (int c = 0; c < ncomp; c++) src[c] = (const double*)host_data[c] + off;
+            parallel_interleave((double*)ctx->stage[k], src, ncomp, len);
+        } else {
+            const float* src[8];
+            for (int c = 0; c < ncomp; c++) src[c] = (const float*)host_data[c] + off;
+            parallel_interleave((float*)ctx->stage[k], src, ncomp, len);
+        }
+        PK_HIP(ctx, hipMemcpyAsync(dst + off * esz * ncomp, ctx->stage[k], len * esz * ncomp, hipMemcpyHostToDevice, ctx->copy));
+        PK_HIP(ctx, hipEventRecord(ctx->stage_ev[k], ctx->copy));
+    }
+    if (!async) PK_HIP(ctx, hipStreamSynchronize(ctx->copy));
+    for (size_t f = 0; f < ctx->fields.size(); f++) {  // the leader and its followers change slot state together
+        HostField& F = ctx->fields[f];
+        if ((int)f != leader_id && F.desc.pack_leader != leader_id) continue;
+        F.slot_level[slot] = async ? -1 : level;
+        F.slot_pending[slot] = async ? level : -1;
+    }
+    if (async) ctx->copy_pending = true;
     return 0;
 }
 
@@ -938,6 +1071,87 @@ int32_t pk_particles_d2h(pk_ctx* ctx) {
 int32_t pk_particles_d2h_columns(pk_ctx* ctx, uint32_t mask) {
     if (!ctx) return -2;
     return copy_particles(ctx, false, mask);
+}
+
+// ---- asynchronous write-out (particleset.py:436-459 / particlefile.py:142-180 overlapped with the next interval) -------------
+int32_t pk_particles_snapshot_begin(pk_ctx* ctx, uint32_t mask, int32_t slot) {
+    if (!ctx) return -2;
+    if (slot < 0 || slot > 1) return ctx->fail("snapshot slot must be 0 or 1");
+    if (!ctx->bound) return ctx->fail("no particles bound");
+    if (ctx->in_flight) return ctx->fail("pk_particles_snapshot_begin: a launch is in flight");
+    PK_HIP(ctx, hipSetDevice(ctx->device));
+    pk_ctx::Snapshot& sn = ctx->snap[slot];
+    if (sn.in_flight) return ctx->fail("snapshot slot still in flight (pk_particles_snapshot_wait first)");
+    if (!sn.ready) {
+        PK_HIP(ctx, hipEventCreateWithFlags(&sn.ready, hipEventDisableTiming));
+        PK_HIP(ctx, hipEventCreateWithFlags(&sn.done, hipEventDisableTiming));
+    }
+    const int64_t n = ctx->dev.n;
+    const std::vector<ColRef> cols = particle_columns(ctx);
+    const size_t ss = spatial_size(ctx);
+    if (sn.capacity < n || sn.ngrids != ctx->host.ngrids || sn.ss != ss) {  // (re)size: all columns, so that any mask fits later
+        for (int k = 0; k < 12; k++) {
+            if (sn.dev[k]) PK_HIP(ctx, hipFree(sn.dev[k]));
+            if (sn.host[k]) PK_HIP(ctx, hipHostFree(sn.host[k]));
+            sn.dev[k] = sn.host[k] = nullptr;
+        }
+        const int64_t cap = std::max<int64_t>(n + n / 8, 1);
+        for (int k = 0; k < 12; k++) {
+            if (!cols[k].d) continue;
+            const size_t bytes = (size_t)cap * cols[k].elem * cols[k].width;
+            PK_HIP(ctx, hipMalloc(&sn.dev[k], bytes));
+            PK_HIP(ctx, hipHostMalloc(&sn.host[k], bytes, hipHostMallocDefault));
+        }
+        sn.capacity = cap;
+        sn.ngrids = ctx->host.ngrids;
+        sn.ss = ss;
+    }
+    sn.n = n;
+    sn.mask = mask;
+    if (n > 0) {
+        for (int k = 0; k < 12; k++) {
+            const ColRef& c = cols[k];
+            if (!((mask >> k) & 1u) || !c.d) continue;
+            const size_t bytes = (size_t)n * c.elem * c.width;
+            if (ctx->has_perm) {  // undo the cell sort: host row perm[i] <- device row i
+                if (c.elem == 8) launch_scatter<unsigned long long>(ctx, c.d, sn.dev[k], ctx->d_perm, n, c.width);
+                else launch_scatter<uint32_t>(ctx, c.d, sn.dev[k], ctx->d_perm, n, c.width);
+            } else {
+                PK_HIP(ctx, hipMemcpyAsync(sn.dev[k], c.d, bytes, hipMemcpyDeviceToDevice, ctx->compute));
+            }
+        }
+        PK_HIP(ctx, hipGetLastError());
+    }
+    PK_HIP(ctx, hipEventRecord(sn.ready, ctx->compute));  // the next launch may now overwrite the live columns
+    PK_HIP(ctx, hipStreamWaitEvent(ctx->copy, sn.ready, 0));
+    for (int k = 0; k < 12 && n > 0; k++) {
+        const ColRef& c = cols[k];
+        if (!((mask >> k) & 1u) || !c.d) continue;
+        PK_HIP(ctx, hipMemcpyAsync(sn.host[k], sn.dev[k], (size_t)n * c.elem * c.width, hipMemcpyDeviceToHost, ctx->copy));
+    }
+    PK_HIP(ctx, hipEventRecord(sn.done, ctx->copy));
+    sn.in_flight = true;
+    return 0;
+}
+
+// Wait for the snapshot in `slot` and hand out its pinned host columns (valid until the next snapshot_begin on that slot).
+// May be called from a second host thread while the first one drives the next launch: it only waits on an event.
+int32_t pk_particles_snapshot_wait(pk_ctx* ctx, int32_t slot, pk_particles_desc* out) {
+    if (!ctx || !out) return -2;
+    if (slot < 0 || slot > 1) return -2;
+    pk_ctx::Snapshot& sn = ctx->snap[slot];
+    if (!sn.in_flight) return -3;  // (no ctx->fail here: the error string belongs to the driving thread)
+    if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+    if (hipEventSynchronize(sn.done) != hipSuccess) return -1;
+    sn.in_flight = false;
+    memset(out, 0, sizeof(*out));
+    out->n = sn.n;
+    out->ngrids = sn.ngrids;
+    out->spatial_dtype = sn.ss == 4 ? PK_F32 : PK_F64;
+    void** dst[12] = {(void**)&out->t, &out->z, &out->y, &out->x, &out->dz, &out->dy, &out->dx, (void**)&out->dt, (void**)&out->next_dt,
+                      (void**)&out->state, (void**)&out->ei, (void**)&out->particle_id};
+    for (int k = 0; k < 12; k++) *dst[k] = ((sn.mask >> k) & 1u) ? sn.host[k] : nullptr;
+    return 0;
 }
 
 int32_t pk_particles_device(pk_ctx* ctx, pk_particles_desc* dev, int64_t** perm) {

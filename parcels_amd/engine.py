@@ -161,6 +161,8 @@ class DeviceEngine:
         # C-grid velocity components are stored interleaved ({U,V,W} per cell): the staggered corner values of one
         # evaluation then share cache lines, which is what bounds the sparse NEMO-size configuration
         pack: dict[str, tuple[str, int]] = {}  # field name -> (leader name, group size)
+        self.pack_groups: dict[str, list[str]] = {}  # leader name -> member names in component order
+        self.pack_leader_of: dict[str, str] = {}
         cgrid_vectors = [vf for vf in fs.fields.values() if isinstance(vf, VectorField) and isinstance(vf.interp_method, CGrid_Velocity)]
         cgrid_vectors.sort(key=lambda vf: -(3 if vf.W is not None else 2))  # UVW before UV: the larger group wins
         for vf in cgrid_vectors:
@@ -174,6 +176,7 @@ class DeviceEngine:
                 order = [f.name for f in self.scalar_fields if f.name in {c.name for c in comps}]  # creation order
                 for nme in order:
                     pack[nme] = (order[0], len(order))
+                self.pack_groups[order[0]] = order
         for f in self.scalar_fields:
             h = hosts[f.name]
             dims = f.data.dims
@@ -212,12 +215,29 @@ class DeviceEngine:
             self.ctx.check(self.lib.pk_field_create(self.ctx.handle, C.byref(d), C.byref(fid)), f"pk_field_create({f.name})")
             self.field_ids[f.name] = fid.value
             self.field_host[f.name] = h
-            if d.nslots >= d.nt:
-                for lv in range(d.nt):
+        for leader, members in self.pack_groups.items():
+            for m in members:
+                self.pack_leader_of[m] = leader
+        for f in self.scalar_fields:  # resident fields: all levels now (packed groups need every member created first)
+            if self.field_nslots[f.name] >= self.field_host[f.name].shape[0]:
+                for lv in range(self.field_host[f.name].shape[0]):
                     self._upload(f.name, lv, asynchronous=False)
         self.windowed = any(self.field_nslots[f.name] < self.field_host[f.name].shape[0] for f in self.scalar_fields)
 
     def _upload(self, name, level, asynchronous):
+        leader = self.pack_leader_of.get(name)
+        if leader is not None:
+            if leader != name:
+                return  # travels with its group leader
+            # packed {U,V,W} group: one call, interleaved by the host threads that stage the level for the DMA anyway
+            members = self.pack_groups[leader]
+            lvls = [self.field_host[m][level] for m in members]
+            ptrs = (C.c_void_p * len(members))(*[l.ctypes.data for l in lvls])
+            self.ctx.check(
+                self.lib.pk_field_upload_group_level(self.ctx.handle, self.field_ids[leader], int(level), ptrs, len(members), int(asynchronous)),
+                f"pk_field_upload_group_level({'+'.join(members)}, {level})",
+            )
+            return
         h = self.field_host[name]
         lvl = h[level]
         self.ctx.check(
@@ -365,6 +385,45 @@ class DeviceEngine:
         if self._next_dt_f32 is not None and (columns is None or "next_dt" in columns):
             self._next_dt_f32[0][:] = self._next_dt_f32[1]
 
+    # ---- asynchronous write-out snapshots ------------------------------------------------------------------------
+    _SNAP_COLS = ("t", "z", "y", "x", "dz", "dy", "dx", "dt", "next_dt", "state", "ei", "particle_id")
+
+    def snapshot_begin(self, columns, slot: int):
+        """Enqueue the copy of the named device columns (host row order) into the pinned host set ``slot``; returns at once."""
+        mask = 0
+        for name in columns:
+            mask |= _hip.COLUMN_BITS.get(name, 0)
+        self.ctx.check(self.lib.pk_particles_snapshot_begin(self.ctx.handle, mask, int(slot)), "pk_particles_snapshot_begin")
+        self._snap_dtypes = {k: self._bound[k].dtype for k in self._bound if k in _hip.COLUMN_BITS}
+
+    def snapshot_wait(self, slot: int) -> dict:
+        """Block until snapshot ``slot`` has landed; NumPy views of its pinned columns (valid until the slot is reused).  Callable
+        from a worker thread while the main thread drives the next launch."""
+        d = _hip.ParticlesDesc()
+        rc = self.lib.pk_particles_snapshot_wait(self.ctx.handle, int(slot), C.byref(d))
+        if rc != 0:
+            raise _hip.HipLibraryError(f"pk_particles_snapshot_wait(slot={slot}) failed ({rc})")
+        n = int(d.n)
+        sp = np.float32 if d.spatial_dtype == _hip.PK_F32 else np.float64
+        spec = {"t": np.float64, "z": sp, "y": sp, "x": sp, "dz": sp, "dy": sp, "dx": sp, "dt": np.float64, "next_dt": np.float64,
+                "state": np.int32, "ei": np.int32, "particle_id": np.int64}
+        out = {}
+        for name in self._SNAP_COLS:
+            ptr = getattr(d, name)
+            if not ptr:
+                continue
+            width = int(d.ngrids) if name == "ei" else 1
+            dt = np.dtype(spec[name])
+            buf = (C.c_char * (n * width * dt.itemsize)).from_address(ptr)
+            a = np.frombuffer(buf, dtype=dt, count=n * width)
+            if name == "ei":
+                a = a.reshape(n, width)
+            want = self._snap_dtypes.get(name)
+            if name == "next_dt" and want is not None and want != dt:  # float32 Variable shadowed by a float64 device column
+                a = a.astype(want)
+            out[name] = a
+        return out
+
     # ---- execution -------------------------------------------------------------------------------------------
     def make_params(self, kernel_ids, *, endtime, dt0, context=None, seed=0, reset_state=1, have_guess0=0, sort_by_cell=0):
         fs = self.fieldset
@@ -402,7 +461,11 @@ class DeviceEngine:
     def execute(self, kernel_ids, *, endtime, dt0, context=None, seed=0, have_guess0=0, sort_by_cell=0, t_start=None) -> dict:
         """One Kernel.execute(pset, endtime, dt) on the bound (device-resident) particle columns."""
         sign = 1 if dt0 > 0 else -1
-        total = {"steps": 0, "attempts": 0, "kernel_ms": 0.0, "sort_ms": 0.0, "launches": 0}
+        import time as _time
+
+        # host-side split of a streamed run: commit = synchronous level uploads before a launch, prefetch = staging + enqueueing
+        # the next level while the kernel runs, wait = pk_execute_end after the prefetch was enqueued
+        total = {"steps": 0, "attempts": 0, "kernel_ms": 0.0, "sort_ms": 0.0, "launches": 0, "commit_s": 0.0, "prefetch_s": 0.0, "wait_s": 0.0}
         reset = 1
         t_live = t_start
         last_live = None
@@ -411,16 +474,22 @@ class DeviceEngine:
             if self.windowed:
                 if t_live is None or not np.isfinite(t_live):
                     t_live = 0.0 if sign > 0 else max(float(f.model.time_flt[-1]) for f in self._windowed_fields())
+                _t = _time.perf_counter()
                 nxt = self._commit_window(float(t_live), sign)
+                total["commit_s"] += _time.perf_counter() - _t
             prm = self.make_params(kernel_ids, endtime=endtime, dt0=dt0, context=context, seed=seed, reset_state=reset,
                                    have_guess0=(have_guess0 if reset else 1), sort_by_cell=sort_by_cell)
             st = _hip.ExecStats()
             self.ctx.check(self.lib.pk_execute_begin(self.ctx.handle, C.byref(prm)), "pk_execute_begin")
             prefetched = False
             try:
+                _t = _time.perf_counter()
                 prefetched = self._prefetch(nxt)  # overlaps the kernel that was just launched
+                total["prefetch_s"] += _time.perf_counter() - _t
             finally:
+                _t = _time.perf_counter()
                 self.ctx.check(self.lib.pk_execute_end(self.ctx.handle, C.byref(st)), "pk_execute_end")
+                total["wait_s"] += _time.perf_counter() - _t
             reset = 0
             total["steps"] += st.steps
             total["attempts"] += st.attempts

@@ -130,6 +130,13 @@ class ParticleFile:
                 return
         self.write_columns(pset._pclass, cols, fieldset.time_interval)
 
+    def async_writer(self, pset, engine, out_cols):
+        """Writer that takes the output step off the critical path of ParticleSet.execute (None for a collective multi-rank file:
+        its all-gather must stay on the thread that drives the launches)."""
+        if self._world > 1:
+            return None
+        return _AsyncWriter(self, pset, engine, out_cols)
+
     def close(self):
         if self._writer is not None:
             self._writer.close()
@@ -140,6 +147,60 @@ class ParticleFile:
 
     def __exit__(self, *args):
         self.close()
+
+
+class _SnapshotView:
+    """What ParticleFile.write needs of a ParticleSet, over one snapshot of the columns."""
+
+    def __init__(self, data, pclass, fieldset):
+        self._data, self._pclass, self.fieldset = data, pclass, fieldset
+
+
+class _AsyncWriter:
+    """Double-buffered write-out: submit() snapshots the to-write device columns (pk_particles_snapshot_begin: device-side copy
+    in host row order + D2H on the copy stream into one of two pinned column sets) and returns; ONE writer thread waits for the
+    copy, applies the write filter and encodes the Parquet table while the caller launches the next interval.  Tables are written
+    in submission order; at most two snapshots are in flight (the third submit waits for the first encode)."""
+
+    def __init__(self, pfile, pset, engine, out_cols):
+        from concurrent.futures import ThreadPoolExecutor
+
+        self.pfile, self.pset, self.engine = pfile, pset, engine
+        self.cols = [c for c in out_cols if c in engine._SNAP_COLS]
+        self.pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="parcels-writeout")
+        self.pending = [None, None]
+        self.slot = 0
+        self.encode_seconds = 0.0
+
+    def submit(self, data, t):
+        slot = self.slot
+        self.slot ^= 1
+        if self.pending[slot] is not None:  # its pinned columns are about to be reused
+            self.pending[slot].result()
+        self.engine.snapshot_begin(self.cols, slot)
+        host_only = {k: v for k, v in data.items() if k not in self.engine._SNAP_COLS}  # replaced, never mutated, by later intervals
+        self.pending[slot] = self.pool.submit(self._task, slot, host_only, float(t))
+
+    def _task(self, slot, host_only, t):
+        import time as _time
+
+        cols = self.engine.snapshot_wait(slot)
+        t0 = _time.perf_counter()
+        cols.update(host_only)
+        self.pfile.write(_SnapshotView(cols, self.pset._pclass, self.pset.fieldset), t)
+        self.encode_seconds += _time.perf_counter() - t0
+
+    def drain(self):
+        for k in (self.slot, self.slot ^ 1):  # oldest first
+            if self.pending[k] is not None:
+                self.pending[k].result()
+                self.pending[k] = None
+
+    def close(self):
+        try:
+            self.drain()
+        finally:
+            self.pool.shutdown(wait=True)
 
 
 def read_particlefile(path):

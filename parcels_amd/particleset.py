@@ -68,6 +68,7 @@ class ParticleSet:
         self.seed = int(seed)
         self.sort_by_cell = bool(sort_by_cell)
         self.device_compaction = True  # deleted particles are removed on the device (False: through NumPy on the host)
+        self.async_output = True  # ParticleFile tables are encoded on a writer thread behind the next interval (False: inline)
         self._last_stats = None
         self._t_live = None
         t = np.empty(shape=0) if t is None else np.array(t).flatten()
@@ -198,8 +199,13 @@ class ParticleSet:
         engine.h2d()
         have_guess0 = kern._have_guess0(self._data)
         out_cols = None
+        writer = None
         if output_file is not None:
             out_cols = sorted({v.name for v in self._pclass.variables if v.to_write is not False} | {"t", "dt", "state", "particle_id"})
+            # the file's own rank-local write path can run behind the next interval (ParticleFile.async_writer); a duck-typed or
+            # collective (multi-rank) file is written synchronously
+            make = getattr(output_file, "async_writer", None)
+            writer = make(self, engine, out_cols) if make is not None and self.async_output else None
         synced = True
         try:
             with output_file if output_file is not None else nullcontext():  # the Parquet footer is written on error too
@@ -228,13 +234,24 @@ class ParticleSet:
                         engine.bind_particles(self._data)
                         engine.h2d()
                     if next_output is not None and np.abs(next_time - next_output) < 0.001:
-                        if not synced:
-                            engine.d2h(out_cols)
-                        output_file.write(self, next_output)
+                        if writer is not None and not synced:
+                            # snapshot on the device, D2H on the copy stream, filter + Parquet encode on the writer thread --
+                            # all of it overlaps the next interval's launch (particlefile.py:142-180 off the critical path)
+                            writer.submit(self._data, next_output)
+                        else:
+                            if writer is not None:
+                                writer.drain()  # keep the tables in time order
+                            if not synced:
+                                engine.d2h(out_cols)
+                            output_file.write(self, next_output)
                         if np.isfinite(outputdt):
                             next_output += outputdt * sign_dt
                     time = next_time
+                if writer is not None:
+                    writer.drain()
         finally:
+            if writer is not None:
+                writer.close()
             if not synced and len(self) > 0:
                 engine.d2h()
             self._t_live = None

@@ -85,3 +85,31 @@ def test_output_with_deletions_matches_uninterrupted_run(gpu, tmp_path):
     last = df[df["t"] == df["t"].max()].sort_values("particle_id")
     np.testing.assert_array_equal(last["particle_id"].to_numpy(), b.particle_id)
     np.testing.assert_array_equal(last["x"].to_numpy(), b.x)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sort", [False, True])
+def test_async_write_out_equals_the_inline_path(gpu, tmp_path, sort):
+    """The double-buffered write-out (device snapshot -> D2H on the copy stream -> filter + Parquet encode on a writer thread,
+    behind the next interval's launch) produces the file of the inline path byte for byte: deletions between intervals, the cell
+    sort, staggered releases (rows filtered out at some output times) and a host-only user Variable included."""
+    from oracle import cases
+
+    case = cases.rect_agrid_case("pf_async", mesh="flat", kernels=["AdvectionRK4", "DeleteParticle"], seed=5, nx=24, ny=16, nz=5, nt=4, npart=20000,
+                                 vel=2.5, margin=0.02, runtime=30 * 3600.0, stagger=True)
+    files = {}
+    for mode in ("inline", "async"):
+        fs = build_fieldset(case)
+        pclass = pa.get_default_particle(np.float64).add_variable(pa.Variable("tag", dtype=np.int32, initial=0))
+        n = len(case["x"])
+        pset = pa.ParticleSet(fs, pclass=pclass, x=case["x"], y=case["y"], z=case["z"], t=case["t0"], sort_by_cell=sort, tag=np.arange(n) % 13)
+        pset.async_output = mode == "async"
+        path = tmp_path / f"{mode}_{sort}.parquet"
+        pset.execute([pa.AdvectionRK4, pa.kernels.DeleteParticle], dt=3600.0, runtime=case["runtime"], output_file=pa.ParticleFile(path, outputdt=2 * 3600.0))
+        files[mode] = (path.read_bytes(), len(pset), {k: np.array(v) for k, v in pset._data.items()})
+    assert files["async"][1] == files["inline"][1] < 20000, "no deletions: the test does not test"
+    assert files["async"][0] == files["inline"][0]
+    for k, v in files["inline"][2].items():
+        assert np.array_equal(files["async"][2][k], v), k
+    df = pa.read_particlefile(tmp_path / f"async_{sort}.parquet")
+    assert "tag" in df.columns and len(df["t"].unique()) >= 16
