@@ -29,6 +29,7 @@ extern "C" {
 #define PK_MAX_GRIDS 4
 #define PK_MAX_FIELDS 8
 #define PK_MAX_KERNELS 8
+#define PK_MAX_EXTRA 4 /* user Variables that device kernels write (PK_KERNEL_SAMPLE_FIELD) */
 #define PK_NUM_STATE_CODES 80
 
 typedef struct pk_ctx pk_ctx;
@@ -65,6 +66,9 @@ typedef struct pk_ctx pk_ctx;
 #define PK_KERNEL_ADVECTIONDIFFUSION_M1 7
 #define PK_KERNEL_ADVECTIONDIFFUSION_EM 8
 #define PK_KERNEL_DIFFUSION_UNIFORM_KH 9
+#define PK_KERNEL_SAMPLE_FIELD 10 /* `particles.<var> = fieldset.<F>[particles]`: the user kernel every tutorial writes (kernel.py:206-216 runs
+                                   it as Python; tests/test_particleset_execute.py:182-205 SampleU / SampleUV).  Field and target
+                                   column per kernel-list slot: pk_exec_params.sample_field / sample_var */
 #define PK_KERNEL_DELETE_ON_ERROR 20
 #define PK_KERNEL_DELETE_OUT_OF_BOUNDS 21
 #define PK_KERNEL_SUBMERGE_THROUGH_SURFACE 22
@@ -200,6 +204,12 @@ typedef struct pk_particles_desc {
     int32_t* state;
     int32_t* ei; /* n * ngrids                                                                     */
     int64_t* particle_id;
+    /* user Variables that live on the device because a device kernel writes them (Particle.add_variable, particle.py:79-113):
+       n_extra columns of dtype PK_F32 / PK_F64; all other user Variables stay host-only */
+    int32_t n_extra;
+    int32_t extra_dtype[PK_MAX_EXTRA];
+    int32_t reserved1;
+    void* extra[PK_MAX_EXTRA];
 } pk_particles_desc;
 int32_t pk_particles_bind(pk_ctx* ctx, const pk_particles_desc* host); /* remember host columns, size device columns */
 int32_t pk_particles_h2d(pk_ctx* ctx);
@@ -218,6 +228,7 @@ int32_t pk_particles_d2h(pk_ctx* ctx);
 #define PK_COL_STATE 0x200u
 #define PK_COL_EI 0x400u
 #define PK_COL_PARTICLE_ID 0x800u
+#define PK_COL_EXTRA0 0x1000u /* extra column k: PK_COL_EXTRA0 << k */
 int32_t pk_particles_d2h_columns(pk_ctx* ctx, uint32_t column_mask);
 /* Asynchronous write-out (ParticleSet.execute's output step, particleset.py:452-459, overlapped with the next interval):
  * _begin snapshots the selected columns -- un-sorted into host row order -- into one of two device staging sets on the compute
@@ -254,6 +265,8 @@ typedef struct pk_exec_params {
                             the WHOLE batch (`2 if np.any(tau > 0) else 1`, _xinterpolators.py:130-131,401-402,575-576) and which
                             change values there: 0 = per particle (pk_execute: a fused multi-step launch has no batch), 1 / 2 =
                             that value for every particle.  pk_eval (one call == one batch) fills them in itself.            */
+    int32_t sample_field[PK_MAX_KERNELS]; /* PK_KERNEL_SAMPLE_FIELD in kernel-list slot k: id of the scalar field to sample ...   */
+    int32_t sample_var[PK_MAX_KERNELS];   /* ... and the extra particle column (0 .. n_extra-1) that receives the value           */
     int32_t next_dt_f32; /* the particle class declares next_dt as float32 (the default dtype of Variable, particle.py:36-60;
                             tests/utils.py:24-25): AdvectionRK45's store into it rounds to f32, and `dt = next_dt`
                             (kernel.py:118-120) then carries the rounded value.  The bound column itself stays f64.   */

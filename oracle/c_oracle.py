@@ -26,6 +26,7 @@ KERNEL_IDS = {
     "AdvectionDiffusionM1": 7,
     "AdvectionDiffusionEM": 8,
     "DiffusionUniformKh": 9,
+    "SampleField": 10,
     "DeleteParticle": 20,
     "DeleteOutOfBounds": 21,
     "SubmergeParticle": 22,
@@ -110,6 +111,8 @@ class PoParticles(C.Structure):
         ("state", C.c_void_p),
         ("ei", C.c_void_p),
         ("particle_id", C.c_void_p),
+        ("extra", C.c_void_p * 4),
+        ("extra_f32", C.c_int32 * 4),
     ]
 
 
@@ -129,6 +132,8 @@ class PoParams(C.Structure):
         ("force_lent", C.c_int32),
         ("force_lenz", C.c_int32),
         ("pad2", C.c_int32),
+        ("sample_field", C.c_int32 * 8),
+        ("sample_var", C.c_int32 * 8),
         ("endtime", C.c_double),
         ("dt0", C.c_double),
         ("rk45_tol", C.c_double),
@@ -326,8 +331,19 @@ class MarshalledCase:
         context = dict(context or {})
         p = PoParams()
         p.nk = len(kernels)
+        samples = case.get("sample_into") or {}
+        self.sample_vars = []
         for i, k in enumerate(kernels):
-            p.kernels[i] = KERNEL_IDS[k]
+            p.sample_field[i] = p.sample_var[i] = -1
+            if k in samples:  # the user kernel `particles.<var> = fieldset.<F>[particles]`
+                fname, vname, _ = samples[k]
+                if vname not in self.sample_vars:
+                    self.sample_vars.append(vname)
+                p.kernels[i] = KERNEL_IDS["SampleField"]
+                p.sample_field[i] = self.field_index[fname]
+                p.sample_var[i] = self.sample_vars.index(vname)
+            else:
+                p.kernels[i] = KERNEL_IDS[k]
         p.cgrid = {"free": 2, "partial": 3}.get(case.get("slip"), int(bool(case.get("cgrid"))))
         p.rk45_mode = int("RK45_tol" in context)
         p.have_guess0 = int(have_guess0)
@@ -391,6 +407,8 @@ def initial_particles(case: dict, ngrids: int) -> dict:
     }
     if "AdvectionRK45" in case["kernels"]:
         d["next_dt"] = np.full(n, float(case.get("next_dt0", case["dt"])), np.dtype(case.get("next_dt_dtype", "float64")))
+    for fname, vname, vdt in (case.get("sample_into") or {}).values():
+        d[vname] = np.zeros(n, np.dtype(vdt))
     return d
 
 
@@ -415,6 +433,11 @@ def execute(mc: MarshalledCase, data: dict, *, kernels, endtime, dt0, context=No
     P.next_dt = _ptr(nd)
     P.state, P.ei, P.particle_id = _ptr(state), _ptr(ei), _ptr(pid)
     prm = mc.params(kernels=kernels, endtime=endtime, dt0=dt0, context=context, seed=seed, have_guess0=have_guess0)
+    xw = {}
+    for k, vname in enumerate(getattr(mc, "sample_vars", [])):
+        xw[vname] = np.ascontiguousarray(data[vname], dtype=np.float64)
+        P.extra[k] = xw[vname].ctypes.data
+        P.extra_f32[k] = int(data[vname].dtype == np.float32)
     st = PoStats()
     rc = lib().po_execute(mc.grids, C.c_int32(mc.ngrids), mc.fields, C.c_int32(len(mc.fields)), C.byref(prm), C.byref(P),
                           C.byref(st), C.c_int32(nthreads))
@@ -425,6 +448,8 @@ def execute(mc: MarshalledCase, data: dict, *, kernels, endtime, dt0, context=No
     if nd is not None:
         data["next_dt"] = nd.astype(data["next_dt"].dtype)  # exact: the C code already rounded f32 columns
     data["state"], data["ei"], data["particle_id"] = state, ei, pid
+    for vname, w_ in xw.items():
+        data[vname] = w_.astype(data[vname].dtype)  # exact: the C code already rounded float32 Variables
     keep = data["state"] != 30
     if not keep.all():
         for k in list(data):

@@ -618,6 +618,16 @@ def all_cases() -> dict:
     add(rect_agrid_case("agrid_sph_rk4_outside_time", mesh="spherical", kernels=["AdvectionRK4"], seed=19, nt=2,
                         runtime=30 * 3600.0))
 
+    # --- the user kernel every tutorial writes: particles.p = fieldset.P[particles] after the advection kernel ----------------
+    for nm, kw, pd in (("agrid_sph_rk4_sample_p_f32", dict(mesh="spherical", seed=31), "float32"),
+                       ("agrid_flat_rk4_sample_p_f64_escape", dict(mesh="flat", seed=32, vel=6.0, margin=0.01, dt=1800.0, runtime=20 * 1800.0), "float64")):
+        cs = rect_agrid_case(nm, kernels=["AdvectionRK4", "SampleP"] + (["DeleteParticle"] if "escape" in nm else []), **kw)
+        rng = _rng(kw["seed"] + 1000)
+        cs["fields"]["P"] = smooth_random_field(rng, cs["fields"]["U"].shape, 5.0, np.float64)
+        cs["field_dims"]["P"] = TZYX_NODE
+        cs["sample_into"] = {"SampleP": ["P", "p", pd]}
+        add(cs)
+
     # --- scalar interpolators sampled through Field.eval ------------------------------------------------------------
     add(sample_case("sample_xlinear", interp="XLinear", seed=61))
     add(sample_case("sample_xnearest", interp="XNearest", seed=62))

@@ -147,9 +147,20 @@ def ref_run_case(case):
     rec = _recovery_kernels(m)
     patch = _NormalPatch(int(case.get("seed", 0)))
     klist = []
+    samples = case.get("sample_into") or {}
     for slot, name in enumerate(case["kernels"]):
         if name in rec:
             klist.append(rec[name])
+            continue
+        if name in samples:  # the user kernel of the tutorials, in Python, run by the reference's own kernel loop (kernel.py:206-216)
+            fname, vname, _ = samples[name]
+
+            def make_sample(fname=fname, vname=vname, name=name):
+                def sample(particles, fieldset):
+                    setattr(particles, vname, getattr(fieldset, fname)[particles])
+                sample.__name__ = name
+                return sample
+            klist.append(make_sample())
             continue
         f = getattr(K, name)
         if name in ("AdvectionDiffusionM1", "AdvectionDiffusionEM", "DiffusionUniformKh"):
@@ -166,6 +177,8 @@ def ref_run_case(case):
     pkw = None
     if "AdvectionRK45" in case["kernels"]:
         extra_vars = [("next_dt", np.dtype(case.get("next_dt_dtype", "float64")).type, float(case.get("next_dt0", case["dt"])))]
+    for fname, vname, vdt in samples.values():
+        extra_vars = (extra_vars or []) + [(vname, np.dtype(vdt).type, 0)]
     n = len(np.atleast_1d(case["x"]))
     z = case.get("z")
     if z is not None and np.ndim(z) == 0:

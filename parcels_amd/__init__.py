@@ -33,6 +33,7 @@ from .kernels import (
     DeleteOutOfBounds,
     DeleteParticle,
     DiffusionUniformKh,
+    SampleField,
     SubmergeParticle,
 )
 from .particle import Particle, ParticleClass, Variable, get_default_particle

@@ -16,6 +16,9 @@ LIB_PATH = os.environ.get("PARCELS_HIP_LIB", os.path.join(_HERE, "libparcels_hip
 PK_ABI_VERSION = 3
 PK_F32, PK_F64 = 0, 1
 PK_MAX_GRIDS, PK_MAX_FIELDS, PK_MAX_KERNELS, PK_NUM_STATE_CODES = 4, 8, 8, 80
+PK_MAX_EXTRA = 4
+PK_KERNEL_SAMPLE_FIELD = 10
+PK_COL_EXTRA0 = 0x1000
 COLUMN_BITS = {n: 1 << i for i, n in enumerate(
     ["t", "z", "y", "x", "dz", "dy", "dx", "dt", "next_dt", "state", "ei", "particle_id"])}
 
@@ -113,6 +116,10 @@ class ParticlesDesc(C.Structure):
         ("state", C.c_void_p),
         ("ei", C.c_void_p),
         ("particle_id", C.c_void_p),
+        ("n_extra", C.c_int32),
+        ("extra_dtype", C.c_int32 * PK_MAX_EXTRA),
+        ("reserved1", C.c_int32),
+        ("extra", C.c_void_p * PK_MAX_EXTRA),
     ]
 
 
@@ -132,6 +139,8 @@ class ExecParams(C.Structure):
         ("sort_by_cell", C.c_int32),
         ("force_lent", C.c_int32),
         ("force_lenz", C.c_int32),
+        ("sample_field", C.c_int32 * PK_MAX_KERNELS),
+        ("sample_var", C.c_int32 * PK_MAX_KERNELS),
         ("next_dt_f32", C.c_int32),
         ("endtime", C.c_double),
         ("dt0", C.c_double),

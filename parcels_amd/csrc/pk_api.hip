@@ -93,13 +93,14 @@ struct pk_ctx {
     // asynchronous write-out snapshots (pk_particles_snapshot_begin / _wait): two sets of device staging columns (host row order)
     // + pinned host columns, so that the D2H and the encode of interval k overlap the launch of interval k+1
     struct Snapshot {
-        void* dev[12] = {};
-        void* host[12] = {};
+        void* dev[12 + PK_MAX_EXTRA] = {};
+        void* host[12 + PK_MAX_EXTRA] = {};
         int64_t capacity = 0;  // rows the buffers were sized for
         int64_t n = 0;         // rows of the snapshot in flight
         uint32_t mask = 0;
         int ngrids = 0;
         size_t ss = 0;
+        size_t extra_elem[PK_MAX_EXTRA] = {};
         hipEvent_t ready = nullptr, done = nullptr;
         bool in_flight = false;
     } snap[2];
@@ -462,7 +463,7 @@ int32_t pk_set_option(pk_ctx* ctx, const char* name, int32_t value) {
 static void free_snapshots(pk_ctx* ctx) {
     for (auto& sn : ctx->snap) {
         if (sn.in_flight && sn.done) (void)hipEventSynchronize(sn.done);
-        for (int k = 0; k < 12; k++) {
+        for (int k = 0; k < 12 + PK_MAX_EXTRA; k++) {
             if (sn.dev[k]) (void)hipFree(sn.dev[k]);
             if (sn.host[k]) (void)hipHostFree(sn.host[k]);
             sn.dev[k] = sn.host[k] = nullptr;
@@ -482,6 +483,10 @@ static void free_particles(pk_ctx* ctx) {
                     ctx->d_perm, ctx->d_perm_alt, ctx->d_keys, ctx->d_keys_alt, ctx->d_idx, ctx->d_idx_alt, ctx->d_sort_tmp};
     for (void* p : alts)
         if (p) (void)hipFree(p);
+    for (int k = 0; k < PK_MAX_EXTRA; k++) {
+        if (ctx->dev.extra[k]) (void)hipFree(ctx->dev.extra[k]);
+        if (ctx->alt.extra[k]) (void)hipFree(ctx->alt.extra[k]);
+    }
     ctx->d_perm = ctx->d_perm_alt = nullptr;
     ctx->d_keys = ctx->d_keys_alt = nullptr;
     ctx->d_idx = ctx->d_idx_alt = nullptr;
@@ -895,7 +900,14 @@ int32_t pk_particles_bind(pk_ctx* ctx, const pk_particles_desc* host) {
                         !host->state || !host->ei || !host->particle_id))
         return ctx->fail("particle columns must not be NULL");
     PK_HIP(ctx, hipSetDevice(ctx->device));
-    const bool realloc_needed = !ctx->bound || host->n > ctx->capacity || host->ngrids != ctx->host.ngrids ||
+    if (host->n_extra < 0 || host->n_extra > PK_MAX_EXTRA) return ctx->fail("bad number of extra particle columns");
+    bool extra_changed = host->n_extra != ctx->host.n_extra;
+    for (int k = 0; k < host->n_extra && !extra_changed; k++) extra_changed = host->extra_dtype[k] != ctx->host.extra_dtype[k];
+    for (int k = 0; k < host->n_extra; k++) {
+        if (host->extra_dtype[k] != PK_F32 && host->extra_dtype[k] != PK_F64) return ctx->fail("extra particle columns must be PK_F32 or PK_F64");
+        if (host->n > 0 && !host->extra[k]) return ctx->fail("particle columns must not be NULL");
+    }
+    const bool realloc_needed = !ctx->bound || host->n > ctx->capacity || host->ngrids != ctx->host.ngrids || extra_changed ||
                                 host->spatial_dtype != ctx->host.spatial_dtype || (host->next_dt != nullptr) != (ctx->dev.next_dt != nullptr);
     ctx->host = *host;
     if (realloc_needed) {
@@ -914,8 +926,10 @@ int32_t pk_particles_bind(pk_ctx* ctx, const pk_particles_desc* host) {
         PK_HIP(ctx, hipMalloc((void**)&ctx->dev.state, cap * 4));
         PK_HIP(ctx, hipMalloc((void**)&ctx->dev.ei, cap * 4 * host->ngrids));
         PK_HIP(ctx, hipMalloc((void**)&ctx->dev.particle_id, cap * 8));
+        for (int k = 0; k < host->n_extra; k++) PK_HIP(ctx, hipMalloc(&ctx->dev.extra[k], cap * (host->extra_dtype[k] == PK_F32 ? 4 : 8)));
         ctx->capacity = cap;
     }
+    for (int k = 0; k < PK_MAX_EXTRA; k++) ctx->dev.extra_f32[k] = ctx->alt.extra_f32[k] = (k < host->n_extra && host->extra_dtype[k] == PK_F32);
     ctx->has_perm = false;
     ctx->dev.n = host->n;
     ctx->dev.ngrids = host->ngrids;
@@ -946,7 +960,22 @@ static std::vector<ColRef> particle_columns(pk_ctx* ctx) {
         {ctx->host.state, ctx->dev.state, ctx->alt.state, 4, 1},
         {ctx->host.ei, ctx->dev.ei, ctx->alt.ei, 4, ng},
         {ctx->host.particle_id, ctx->dev.particle_id, ctx->alt.particle_id, 8, 1},
+        {ctx->host.extra[0], ctx->dev.extra[0], ctx->alt.extra[0], (size_t)(ctx->dev.extra_f32[0] ? 4 : 8), 1},
+        {ctx->host.extra[1], ctx->dev.extra[1], ctx->alt.extra[1], (size_t)(ctx->dev.extra_f32[1] ? 4 : 8), 1},
+        {ctx->host.extra[2], ctx->dev.extra[2], ctx->alt.extra[2], (size_t)(ctx->dev.extra_f32[2] ? 4 : 8), 1},
+        {ctx->host.extra[3], ctx->dev.extra[3], ctx->alt.extra[3], (size_t)(ctx->dev.extra_f32[3] ? 4 : 8), 1},
     };
+}
+constexpr int PK_NCOLS = 12 + PK_MAX_EXTRA;
+static_assert(PK_MAX_EXTRA == 4, "particle_columns lists four extra columns");
+
+// exchange the two column sets (sizes / flags stay): after the cell sort and the compaction wrote the new order into `alt`
+static void swap_column_sets(pk_ctx* ctx) {
+    DParticles &d = ctx->dev, &a = ctx->alt;
+    std::swap(d.t, a.t); std::swap(d.z, a.z); std::swap(d.y, a.y); std::swap(d.x, a.x);
+    std::swap(d.dz, a.dz); std::swap(d.dy, a.dy); std::swap(d.dx, a.dx); std::swap(d.dt, a.dt);
+    std::swap(d.next_dt, a.next_dt); std::swap(d.state, a.state); std::swap(d.ei, a.ei); std::swap(d.particle_id, a.particle_id);
+    for (int k = 0; k < PK_MAX_EXTRA; k++) std::swap(d.extra[k], a.extra[k]);
 }
 
 // second column set + permutation buffers, allocated on first use (only when cell sorting is requested)
@@ -966,6 +995,8 @@ static int32_t ensure_alt(pk_ctx* ctx) {
     PK_HIP(ctx, hipMalloc((void**)&ctx->alt.state, cap * 4));
     PK_HIP(ctx, hipMalloc((void**)&ctx->alt.ei, cap * 4 * ctx->host.ngrids));
     PK_HIP(ctx, hipMalloc((void**)&ctx->alt.particle_id, cap * 8));
+    for (int k = 0; k < PK_MAX_EXTRA; k++)
+        if (ctx->dev.extra[k]) PK_HIP(ctx, hipMalloc(&ctx->alt.extra[k], cap * (ctx->dev.extra_f32[k] ? 4 : 8)));
     PK_HIP(ctx, hipMalloc((void**)&ctx->d_perm, cap * 8));
     PK_HIP(ctx, hipMalloc((void**)&ctx->d_perm_alt, cap * 8));
     PK_HIP(ctx, hipMalloc((void**)&ctx->d_keys, cap * 8));
@@ -1022,12 +1053,7 @@ static int32_t sort_particles(pk_ctx* ctx, int main_grid, int horizontal_major) 
     }
     hipLaunchKernelGGL(compose_perm_kernel, grid, dim3(256), 0, ctx->compute, ctx->has_perm ? ctx->d_perm : nullptr, perm, ctx->d_perm_alt, n);
     PK_HIP(ctx, hipGetLastError());
-    // swap column sets (sizes/flags stay)
-    DParticles d = ctx->dev, a = ctx->alt;
-    ctx->dev.t = a.t; ctx->dev.z = a.z; ctx->dev.y = a.y; ctx->dev.x = a.x; ctx->dev.dz = a.dz; ctx->dev.dy = a.dy; ctx->dev.dx = a.dx;
-    ctx->dev.dt = a.dt; ctx->dev.next_dt = a.next_dt; ctx->dev.state = a.state; ctx->dev.ei = a.ei; ctx->dev.particle_id = a.particle_id;
-    ctx->alt.t = d.t; ctx->alt.z = d.z; ctx->alt.y = d.y; ctx->alt.x = d.x; ctx->alt.dz = d.dz; ctx->alt.dy = d.dy; ctx->alt.dx = d.dx;
-    ctx->alt.dt = d.dt; ctx->alt.next_dt = d.next_dt; ctx->alt.state = d.state; ctx->alt.ei = d.ei; ctx->alt.particle_id = d.particle_id;
+    swap_column_sets(ctx);
     std::swap(ctx->d_perm, ctx->d_perm_alt);
     ctx->has_perm = true;
     return 0;
@@ -1089,14 +1115,16 @@ int32_t pk_particles_snapshot_begin(pk_ctx* ctx, uint32_t mask, int32_t slot) {
     const int64_t n = ctx->dev.n;
     const std::vector<ColRef> cols = particle_columns(ctx);
     const size_t ss = spatial_size(ctx);
-    if (sn.capacity < n || sn.ngrids != ctx->host.ngrids || sn.ss != ss) {  // (re)size: all columns, so that any mask fits later
-        for (int k = 0; k < 12; k++) {
+    bool extra_fit = true;
+    for (int k = 0; k < PK_MAX_EXTRA; k++) extra_fit = extra_fit && ((cols[12 + k].d != nullptr) == (sn.dev[12 + k] != nullptr)) && sn.extra_elem[k] == (cols[12 + k].d ? cols[12 + k].elem : 0);
+    if (sn.capacity < n || sn.ngrids != ctx->host.ngrids || sn.ss != ss || !extra_fit) {  // (re)size: all columns, so that any mask fits later
+        for (int k = 0; k < PK_NCOLS; k++) {
             if (sn.dev[k]) PK_HIP(ctx, hipFree(sn.dev[k]));
             if (sn.host[k]) PK_HIP(ctx, hipHostFree(sn.host[k]));
             sn.dev[k] = sn.host[k] = nullptr;
         }
         const int64_t cap = std::max<int64_t>(n + n / 8, 1);
-        for (int k = 0; k < 12; k++) {
+        for (int k = 0; k < PK_NCOLS; k++) {
             if (!cols[k].d) continue;
             const size_t bytes = (size_t)cap * cols[k].elem * cols[k].width;
             PK_HIP(ctx, hipMalloc(&sn.dev[k], bytes));
@@ -1105,11 +1133,12 @@ int32_t pk_particles_snapshot_begin(pk_ctx* ctx, uint32_t mask, int32_t slot) {
         sn.capacity = cap;
         sn.ngrids = ctx->host.ngrids;
         sn.ss = ss;
+        for (int k = 0; k < PK_MAX_EXTRA; k++) sn.extra_elem[k] = cols[12 + k].d ? cols[12 + k].elem : 0;
     }
     sn.n = n;
     sn.mask = mask;
     if (n > 0) {
-        for (int k = 0; k < 12; k++) {
+        for (int k = 0; k < PK_NCOLS; k++) {
             const ColRef& c = cols[k];
             if (!((mask >> k) & 1u) || !c.d) continue;
             const size_t bytes = (size_t)n * c.elem * c.width;
@@ -1124,7 +1153,7 @@ int32_t pk_particles_snapshot_begin(pk_ctx* ctx, uint32_t mask, int32_t slot) {
     }
     PK_HIP(ctx, hipEventRecord(sn.ready, ctx->compute));  // the next launch may now overwrite the live columns
     PK_HIP(ctx, hipStreamWaitEvent(ctx->copy, sn.ready, 0));
-    for (int k = 0; k < 12 && n > 0; k++) {
+    for (int k = 0; k < PK_NCOLS && n > 0; k++) {
         const ColRef& c = cols[k];
         if (!((mask >> k) & 1u) || !c.d) continue;
         PK_HIP(ctx, hipMemcpyAsync(sn.host[k], sn.dev[k], (size_t)n * c.elem * c.width, hipMemcpyDeviceToHost, ctx->copy));
@@ -1151,6 +1180,11 @@ int32_t pk_particles_snapshot_wait(pk_ctx* ctx, int32_t slot, pk_particles_desc*
     void** dst[12] = {(void**)&out->t, &out->z, &out->y, &out->x, &out->dz, &out->dy, &out->dx, (void**)&out->dt, (void**)&out->next_dt,
                       (void**)&out->state, (void**)&out->ei, (void**)&out->particle_id};
     for (int k = 0; k < 12; k++) *dst[k] = ((sn.mask >> k) & 1u) ? sn.host[k] : nullptr;
+    for (int k = 0; k < PK_MAX_EXTRA; k++) {
+        out->extra[k] = ((sn.mask >> (12 + k)) & 1u) ? sn.host[12 + k] : nullptr;
+        out->extra_dtype[k] = sn.extra_elem[k] == 4 ? PK_F32 : PK_F64;
+        if (sn.extra_elem[k]) out->n_extra = k + 1;
+    }
     return 0;
 }
 
@@ -1183,7 +1217,7 @@ int32_t pk_particles_compact(pk_ctx* ctx, const pk_particles_desc* new_host, int
     const int64_t n = ctx->dev.n;
     if (n >= (1ll << 32)) return ctx->fail("device compaction supports < 2^32 particles per device");
     if (new_host->ngrids != ctx->host.ngrids || new_host->spatial_dtype != ctx->host.spatial_dtype ||
-        (new_host->next_dt != nullptr) != (ctx->host.next_dt != nullptr))
+        (new_host->next_dt != nullptr) != (ctx->host.next_dt != nullptr) || new_host->n_extra != ctx->host.n_extra)
         return ctx->fail("pk_particles_compact: the new host columns must have the bound schema");
     int64_t kept = 0;
     if (n > 0) {
@@ -1217,11 +1251,7 @@ int32_t pk_particles_compact(pk_ctx* ctx, const pk_particles_desc* new_host, int
         PK_HIP(ctx, hipGetLastError());
         PK_HIP(ctx, hipStreamSynchronize(ctx->compute));
         kept = (int64_t)(last_pos + last_keep);
-        DParticles d = ctx->dev, a = ctx->alt;
-        ctx->dev.t = a.t; ctx->dev.z = a.z; ctx->dev.y = a.y; ctx->dev.x = a.x; ctx->dev.dz = a.dz; ctx->dev.dy = a.dy; ctx->dev.dx = a.dx;
-        ctx->dev.dt = a.dt; ctx->dev.next_dt = a.next_dt; ctx->dev.state = a.state; ctx->dev.ei = a.ei; ctx->dev.particle_id = a.particle_id;
-        ctx->alt.t = d.t; ctx->alt.z = d.z; ctx->alt.y = d.y; ctx->alt.x = d.x; ctx->alt.dz = d.dz; ctx->alt.dy = d.dy; ctx->alt.dx = d.dx;
-        ctx->alt.dt = d.dt; ctx->alt.next_dt = d.next_dt; ctx->alt.state = d.state; ctx->alt.ei = d.ei; ctx->alt.particle_id = d.particle_id;
+        swap_column_sets(ctx);
         if (perm) std::swap(ctx->d_perm, ctx->d_perm_alt);
     }
     if (new_host->n != kept) return ctx->fail("pk_particles_compact: new host columns hold " + std::to_string(new_host->n) + " rows, " +
@@ -1439,6 +1469,10 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
         if (id == PK_KERNEL_ADVECTION_RK45 && !ctx->dev.next_dt) return ctx->fail("AdvectionRK45 needs the next_dt column");
         if ((id == PK_KERNEL_ADVECTION_RK4_3D || id == PK_KERNEL_ADVECTION_RK2_3D) && prm->fW < 0)
             return ctx->fail("3-D advection needs the W field");
+        if (id == PK_KERNEL_SAMPLE_FIELD) {
+            if (prm->sample_field[k] < 0 || prm->sample_field[k] >= (int)ctx->fields.size()) return ctx->fail("PK_KERNEL_SAMPLE_FIELD: params.sample_field names no field");
+            if (prm->sample_var[k] < 0 || prm->sample_var[k] >= ctx->host.n_extra) return ctx->fail("PK_KERNEL_SAMPLE_FIELD: params.sample_var names no extra particle column");
+        }
     }
     if (need_kh && (prm->fKh_zonal < 0 || prm->fKh_meridional < 0)) return ctx->fail("diffusion kernels need Kh_zonal/Kh_meridional");
     const HostField& U = ctx->fields[prm->fU];

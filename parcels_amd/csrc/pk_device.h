@@ -65,6 +65,8 @@ struct DParticles {
     int32_t* state;
     int32_t* ei;
     int64_t* particle_id;
+    void* extra[PK_MAX_EXTRA];        // user Variables written by device kernels (PK_KERNEL_SAMPLE_FIELD)
+    int32_t extra_f32[PK_MAX_EXTRA];  // 1: float32 column, 0: float64
 };
 
 struct DCounters {
@@ -630,6 +632,7 @@ struct PCtx {
     unsigned first_eval;  // bit g: no evaluation on grid g yet in this execute() call
     int32_t ei0, ei1, ei2, ei3;  // the particle's `ei` row, one register per grid (no dynamic indexing -> no scratch)
     bool u32, v32;  // the u / v ARRAYS of the last eval_uvw are float32 in the reference (AdvectionRK45's stage-1 products)
+    int64_t row;    // device row of the particle (kernels that write user Variables)
 };
 
 PK_DEV int32_t ei_get(const PCtx& c, int g) { return g == 0 ? c.ei0 : (g == 1 ? c.ei1 : (g == 2 ? c.ei2 : c.ei3)); }

@@ -247,6 +247,18 @@ PK_DEV bool prepare(const KArgs& a, int kid, int stage, int kslot, PCtx& c, PSta
             p.dy = pstore(pf, p.dy + sqrt(2 * khm) * (s * z1));
             return true;
         }
+        case PK_KERNEL_SAMPLE_FIELD: {  // particles.<var> = fieldset.<F>[particles] (field.py:187-195: eval at the particle's t, z, y, x)
+            if (stage == 0) {
+                rq.kind = RQ_SCALAR;
+                rq.fidx = prm.sample_field[kslot];
+                rq.f32 = pf;
+                return false;
+            }
+            const int v = prm.sample_var[kslot];  // assignment into the Variable's dtype (particlesetview.py:202-205)
+            if (a.p.extra_f32[v]) ((float*)a.p.extra[v])[c.row] = (float)L.r[0];
+            else ((double*)a.p.extra[v])[c.row] = L.r[0];
+            return true;
+        }
         case PK_KERNEL_DELETE_ON_ERROR:  // tests/common_kernels.py:12-13
             if (c.state >= PK_ERROR) c.state = PK_DELETE;
             return true;
@@ -314,6 +326,9 @@ PK_DEV void consume(int kid, int stage, const PCtx& c, KLocal& L, double u, doub
             break;
         case PK_KERNEL_DIFFUSION_UNIFORM_KH:
             if (stage == 0) L.r[0] = u; else L.r[1] = u;
+            break;
+        case PK_KERNEL_SAMPLE_FIELD:
+            L.r[0] = u;
             break;
         default:  // RK2, RK2_3D, EE, Submerge: only the latest sample matters
             L.r[3] = u; L.r[4] = v; L.r[5] = w;
@@ -399,6 +414,7 @@ __global__ void __launch_bounds__(256, (KIND == 1 || INTERP != 0) ? PK_MIN_WAVES
         PCtx c;
         const bool pf = PFM < 0 ? (P.spatial_f32 != 0) : (PFM == 1);
         c.pf = pf;
+        c.row = i;
         c.state = prm.reset_state ? PK_EVALUATE : P.state[i];  // kernel.py:188
         if (c.state == PK_EVALUATE) {
             c.hz = c.hy = c.hx = c.ht = 0;

@@ -58,6 +58,7 @@ class DeviceEngine:
         self._plan_and_create_fields(nslots, memory_fraction)
         self._bound_sig = None
         self._next_dt_f32 = None
+        self.device_variables: list[str] = []  # user Variables bound as extra device columns (set by Kernel: SampleField targets)
         self.last_stats: dict | None = None
 
     # ---- grids -----------------------------------------------------------------------------------------------
@@ -340,7 +341,21 @@ class DeviceEngine:
             raise TypeError("next_dt must be float32 or float64")
         d.next_dt = _ptr(nd) if nd is not None else None
         d.state, d.ei, d.particle_id = _ptr(data["state"]), _ptr(data["ei"]), _ptr(data["particle_id"])
+        d.n_extra = len(self.device_variables)
+        for k, name in enumerate(self.device_variables):
+            a = data[name]
+            if not a.flags["C_CONTIGUOUS"]:
+                a = data[name] = np.ascontiguousarray(a)
+            if a.dtype not in (np.float32, np.float64) or a.shape != (n,):
+                raise TypeError(f"device Variable '{name}' must be a float32 / float64 column of length n")
+            d.extra_dtype[k] = _hip.PK_F32 if a.dtype == np.float32 else _hip.PK_F64
+            d.extra[k] = a.ctypes.data
         return d
+
+    def _column_bit(self, name):
+        if name in self.device_variables:
+            return _hip.PK_COL_EXTRA0 << self.device_variables.index(name)
+        return _hip.COLUMN_BITS.get(name, 0)  # other user Variables live on the host only (no kernel writes them)
 
     def bind_particles(self, data: dict):
         d = self._particles_desc(data)
@@ -357,7 +372,7 @@ class DeviceEngine:
         n_new = int(np.count_nonzero(keep))
         new = {}
         for name, arr in data.items():
-            if name != "state" and name in _hip.COLUMN_BITS:
+            if name != "state" and (name in _hip.COLUMN_BITS or name in self.device_variables):
                 new[name] = np.empty((n_new,) + arr.shape[1:], dtype=arr.dtype)
             else:
                 new[name] = np.ascontiguousarray(arr[keep])
@@ -380,7 +395,7 @@ class DeviceEngine:
         else:
             mask = 0
             for name in columns:
-                mask |= _hip.COLUMN_BITS.get(name, 0)  # other user Variables live on the host only (no kernel writes them)
+                mask |= self._column_bit(name)
             self.ctx.check(self.lib.pk_particles_d2h_columns(self.ctx.handle, mask), "pk_particles_d2h_columns")
         if self._next_dt_f32 is not None and (columns is None or "next_dt" in columns):
             self._next_dt_f32[0][:] = self._next_dt_f32[1]
@@ -392,7 +407,8 @@ class DeviceEngine:
         """Enqueue the copy of the named device columns (host row order) into the pinned host set ``slot``; returns at once."""
         mask = 0
         for name in columns:
-            mask |= _hip.COLUMN_BITS.get(name, 0)
+            mask |= self._column_bit(name)
+        self._snap_extra = list(self.device_variables)
         self.ctx.check(self.lib.pk_particles_snapshot_begin(self.ctx.handle, mask, int(slot)), "pk_particles_snapshot_begin")
         self._snap_dtypes = {k: self._bound[k].dtype for k in self._bound if k in _hip.COLUMN_BITS}
 
@@ -422,10 +438,16 @@ class DeviceEngine:
             if name == "next_dt" and want is not None and want != dt:  # float32 Variable shadowed by a float64 device column
                 a = a.astype(want)
             out[name] = a
+        for k, name in enumerate(self._snap_extra):
+            ptr = d.extra[k]
+            if not ptr:
+                continue
+            dt = np.dtype(np.float32 if d.extra_dtype[k] == _hip.PK_F32 else np.float64)
+            out[name] = np.frombuffer((C.c_char * (n * dt.itemsize)).from_address(ptr), dtype=dt, count=n)
         return out
 
     # ---- execution -------------------------------------------------------------------------------------------
-    def make_params(self, kernel_ids, *, endtime, dt0, context=None, seed=0, reset_state=1, have_guess0=0, sort_by_cell=0):
+    def make_params(self, kernel_ids, *, endtime, dt0, context=None, seed=0, reset_state=1, have_guess0=0, sort_by_cell=0, samples=None):
         fs = self.fieldset
         context = context or {}
         p = _hip.ExecParams()
@@ -456,9 +478,14 @@ class DeviceEngine:
         p.rk45_max_dt = float(context.get("RK45_max_dt", 0.0))
         p.dres = float(context.get("dres", 0.0))
         p.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        for slot in range(_hip.PK_MAX_KERNELS):
+            p.sample_field[slot] = p.sample_var[slot] = -1
+        for slot, (fname, var) in (samples or {}).items():
+            p.sample_field[slot] = self.field_ids[fname]
+            p.sample_var[slot] = int(var)
         return p
 
-    def execute(self, kernel_ids, *, endtime, dt0, context=None, seed=0, have_guess0=0, sort_by_cell=0, t_start=None) -> dict:
+    def execute(self, kernel_ids, *, endtime, dt0, context=None, seed=0, have_guess0=0, sort_by_cell=0, t_start=None, samples=None) -> dict:
         """One Kernel.execute(pset, endtime, dt) on the bound (device-resident) particle columns."""
         sign = 1 if dt0 > 0 else -1
         import time as _time
@@ -478,7 +505,7 @@ class DeviceEngine:
                 nxt = self._commit_window(float(t_live), sign)
                 total["commit_s"] += _time.perf_counter() - _t
             prm = self.make_params(kernel_ids, endtime=endtime, dt0=dt0, context=context, seed=seed, reset_state=reset,
-                                   have_guess0=(have_guess0 if reset else 1), sort_by_cell=sort_by_cell)
+                                   have_guess0=(have_guess0 if reset else 1), sort_by_cell=sort_by_cell, samples=samples)
             st = _hip.ExecStats()
             self.ctx.check(self.lib.pk_execute_begin(self.ctx.handle, C.byref(prm)), "pk_execute_begin")
             prefetched = False

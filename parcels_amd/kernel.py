@@ -20,6 +20,9 @@ from .engine import raise_particle_errors
 from .statuscodes import StatusCode
 
 
+_RESERVED_COLUMNS = {"t", "z", "y", "x", "dz", "dy", "dx", "dt", "next_dt", "state", "ei", "particle_id"}
+
+
 class KernelWarning(RuntimeWarning):
     pass
 
@@ -40,18 +43,43 @@ class Kernel:
                 raise ValueError(f"Kernel function {f.__name__} must have the signature (particles, fieldset)")
         if len(kernels) == 0:
             raise ValueError("List of `kernels` should have at least one function.")
-        unknown = [f.__name__ for f in kernels if f not in _k.KERNEL_IDS]
+        unknown = [f.__name__ for f in kernels if _k.kernel_id(f) is None]
         if unknown:
             raise NotImplementedError(
                 f"{unknown} are not built-in device kernels. parcels_amd executes kernels inside a HIP kernel and has "
-                f"no host (NumPy) path; supported: {sorted(f.__name__ for f in _k.KERNEL_IDS)}"
+                f"no host (NumPy) path; supported: {sorted(f.__name__ for f in _k.KERNEL_IDS)} and parcels_amd.SampleField(field, into=variable)"
             )
         self._fieldset = pset.fieldset
         self._pclass = pset._pclass
         for f in kernels:
             self.check_fieldsets_in_kernels(f)
         self._kernels = kernels
-        self.kernel_ids = [_k.KERNEL_IDS[f] for f in kernels]
+        self.kernel_ids = [_k.kernel_id(f) for f in kernels]
+        # SampleField tokens: the sampled scalar field and the particle Variable that receives the value, per kernel-list slot;
+        # those Variables become device columns (pk_particles_desc.extra), every other user Variable stays on the host
+        self.samples = {}
+        self.device_variables = []
+        names = {v.name: v for v in self._pclass.variables}
+        for slot, f in enumerate(kernels):
+            spec = getattr(f, "_pk_sample", None)
+            if spec is None:
+                continue
+            fname, vname = spec
+            fld = self._fieldset.fields.get(fname)
+            if fld is None or hasattr(fld, "U"):
+                raise ValueError(f"SampleField: '{fname}' is not a scalar field of the fieldset")
+            if vname not in names or vname in _RESERVED_COLUMNS:
+                raise ValueError(f"SampleField: the ParticleClass has no user Variable '{vname}' (Particle.add_variable)")
+            if np.dtype(names[vname].dtype) not in (np.dtype(np.float32), np.dtype(np.float64)):
+                raise TypeError(f"SampleField: Variable '{vname}' must be float32 or float64")
+            if fname in ("U", "V", "W"):  # field.py:187-190
+                warnings.warn("Sampling of velocities should normally be done using fieldset.UV or fieldset.UVW object; tread carefully",
+                              RuntimeWarning, stacklevel=3)
+            if vname not in self.device_variables:
+                self.device_variables.append(vname)
+            self.samples[slot] = (fname, self.device_variables.index(vname))
+        if len(self.device_variables) > 4:
+            raise ValueError("at most 4 particle Variables can be written by device kernels")
 
     @property
     def funcname(self):
@@ -113,7 +141,7 @@ class Kernel:
         sign = 1 if dt > 0 else -1
         t_start = pset._t_live if getattr(pset, "_t_live", None) is not None else float(np.nanmin(data["t"]) if sign > 0 else np.nanmax(data["t"]))
         stats = engine.execute(self.kernel_ids, endtime=endtime, dt0=dt, context=self.fieldset.context, seed=pset.seed,
-                               have_guess0=have_guess0, sort_by_cell=int(pset.sort_by_cell), t_start=t_start)
+                               have_guess0=have_guess0, sort_by_cell=int(pset.sort_by_cell), t_start=t_start, samples=self.samples)
         pset._last_stats = stats
         return stats
 
@@ -143,6 +171,7 @@ class Kernel:
             return StatusCode.Success
         engine = pset._engine()
         pset._t_live = None
+        engine.device_variables = list(self.device_variables)
         engine.bind_particles(pset._data)
         engine.h2d()
         self.launch(pset, endtime, dt, have_guess0=self._have_guess0(pset._data))

@@ -20,6 +20,7 @@ __all__ = [
     "DeleteOutOfBounds",
     "DeleteParticle",
     "DiffusionUniformKh",
+    "SampleField",
     "SubmergeParticle",
 ]
 
@@ -89,6 +90,35 @@ def DeleteOutOfBounds(particles, fieldset):  # tests/test_advection.py:157-161
 def SubmergeParticle(particles, fieldset):  # tests/test_advection.py:163-174
     """ErrorThroughSurface -> resample UV, dz = 0, z = 0, state = Evaluate."""
     _device_only("SubmergeParticle")
+
+
+def SampleField(field: str, into: str):
+    """The user kernel every Parcels tutorial writes,
+
+        def SampleP(particles, fieldset):
+            particles.p = fieldset.P[particles]
+
+    as a device kernel: ``pset.execute([AdvectionRK4, SampleField("P", into="p")], ...)`` samples scalar field ``field`` at every
+    particle's (t, z, y, x) in each step of the kernel loop (kernel.py:206-216) and stores it in the particle Variable ``into``
+    (float32 or float64, added with ``Particle.add_variable``), with the reference's status-code side effects of a failed
+    sample (field.py:307-378).  Returns a kernel token named ``Sample<field>``."""
+    if not (isinstance(field, str) and isinstance(into, str)):
+        raise TypeError("SampleField(field_name, into=variable_name)")
+
+    def token(particles, fieldset):
+        _device_only(token.__name__)
+
+    token.__name__ = token.__qualname__ = f"Sample{field}"
+    token.__doc__ = f"particles.{into} = fieldset.{field}[particles]"
+    token._pk_sample = (field, into)
+    return token
+
+
+def kernel_id(f):
+    """PK_KERNEL_* id of a kernel token, or None for a function this package cannot run."""
+    if getattr(f, "_pk_sample", None) is not None:
+        return 10  # PK_KERNEL_SAMPLE_FIELD
+    return KERNEL_IDS.get(f)
 
 
 KERNEL_IDS = {

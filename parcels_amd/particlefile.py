@@ -166,7 +166,7 @@ class _AsyncWriter:
         from concurrent.futures import ThreadPoolExecutor
 
         self.pfile, self.pset, self.engine = pfile, pset, engine
-        self.cols = [c for c in out_cols if c in engine._SNAP_COLS]
+        self.cols = [c for c in out_cols if c in engine._SNAP_COLS or c in engine.device_variables]
         self.pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="parcels-writeout")
         self.pending = [None, None]
         self.slot = 0
@@ -178,7 +178,8 @@ class _AsyncWriter:
         if self.pending[slot] is not None:  # its pinned columns are about to be reused
             self.pending[slot].result()
         self.engine.snapshot_begin(self.cols, slot)
-        host_only = {k: v for k, v in data.items() if k not in self.engine._SNAP_COLS}  # replaced, never mutated, by later intervals
+        # host-only Variables: replaced, never mutated, by later intervals
+        host_only = {k: v for k, v in data.items() if k not in self.engine._SNAP_COLS and k not in self.engine.device_variables}
         self.pending[slot] = self.pool.submit(self._task, slot, host_only, float(t))
 
     def _task(self, slot, host_only, t):

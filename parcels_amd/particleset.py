@@ -195,6 +195,7 @@ class ParticleSet:
         engine = self._engine()
         kern = self._kernel
         self._t_live = None
+        engine.device_variables = list(kern.device_variables)  # user Variables that device kernels write live on the device
         engine.bind_particles(self._data)
         engine.h2d()
         have_guess0 = kern._have_guess0(self._data)

@@ -121,6 +121,8 @@ def build_pset(case, fs, **kw):
     if "AdvectionRK45" in case["kernels"]:
         pclass = pclass.add_variable(pa.Variable("next_dt", dtype=np.dtype(case.get("next_dt_dtype", "float64")).type,
                                                  initial=float(case.get("next_dt0", case["dt"]))))
+    for fname, vname, vdt in (case.get("sample_into") or {}).values():
+        pclass = pclass.add_variable(pa.Variable(vname, dtype=np.dtype(vdt).type, initial=0))
     n = len(np.atleast_1d(case["x"]))
     t0 = case.get("t0")
     t = np.zeros(n) if t0 is None else np.broadcast_to(np.asarray(t0, dtype=np.float64), (n,)).copy()
@@ -157,7 +159,8 @@ def run_hip(case, endtime=None, **pset_kw):
 
     fs = build_fieldset(case)
     pset = build_pset(case, fs, **pset_kw)
-    kernels = [getattr(pa.kernels, k) for k in case["kernels"]]
+    samples = case.get("sample_into") or {}
+    kernels = [pa.SampleField(samples[k][0], into=samples[k][1]) if k in samples else getattr(pa.kernels, k) for k in case["kernels"]]
     kw = {}
     if endtime is not None:
         kw["endtime"] = float(endtime)
@@ -211,7 +214,8 @@ def compare(got, ref, *, rtol, atol_pos=0.0, check_state="all", err_mask=None, s
     assert len(got["x"]) == len(ref["x"]), f"{label}: particle count {len(got['x'])} != {len(ref['x'])}"
     assert np.array_equal(got["particle_id"], ref["particle_id"]), f"{label}: particle order differs"
     report = {}
-    for k in ("x", "y", "z", "dx", "dy", "dz", "next_dt", "dt"):
+    user = [k for k in ref if k not in ("x", "y", "z", "dx", "dy", "dz", "next_dt", "dt", "t", "state", "ei", "particle_id") and not k.startswith("obs_")]
+    for k in ["x", "y", "z", "dx", "dy", "dz", "next_dt", "dt"] + user:
         if k in skip or k not in ref or k not in got:
             continue
         a, b = np.asarray(got[k], dtype=np.float64), np.asarray(ref[k], dtype=np.float64)

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import parcels_amd as pa
-from case_utils import build_fieldset, build_pset, golden_names, is_curvilinear, load_golden
+from case_utils import ROOT_DIR, build_fieldset, build_pset, golden_names, is_curvilinear, load_golden
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -26,15 +26,24 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.pk_abi_version() == _hip.PK_ABI_VERSION == 3
 
 
-def test_ctypes_structs_match_header_layout():
+def test_ctypes_structs_match_header_layout(tmp_path):
+    """sizeof() of every struct of include/parcels_hip.h as gcc lays it out == the ctypes mirror in parcels_amd/_hip.py."""
+    import subprocess
+
     from parcels_amd import _hip
 
-    # sizes computed from the C declarations (all members naturally aligned)
-    assert C.sizeof(_hip.GridDesc) == 18 * 4 + 8 + 8 * 8 + 2 * 8 + 2 * 4 + 6 * 8
-    assert C.sizeof(_hip.FieldDesc) == 16 * 4 + 8
-    assert C.sizeof(_hip.ParticlesDesc) == 8 + 2 * 4 + 12 * 8
-    assert C.sizeof(_hip.ExecParams) == (1 + 8 + 13) * 4 + 6 * 8 + 8
-    assert C.sizeof(_hip.ExecStats) == 3 * 8 + 80 * 8 + 4 * 8 + 2 * 4
+    names = {"pk_grid_desc": _hip.GridDesc, "pk_field_desc": _hip.FieldDesc, "pk_particles_desc": _hip.ParticlesDesc,
+             "pk_exec_params": _hip.ExecParams, "pk_exec_stats": _hip.ExecStats, "pk_device_info": _hip.DeviceInfo, "pk_hash_info": _hip.HashInfo}
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "parcels_hip.h"\nint main(void){' +
+                   "".join(f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}\n")
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT_DIR, "include"), str(src), "-o", str(exe)])
+    out = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for n, cls in names.items():
+        assert C.sizeof(cls) == int(out[n]), n
+    # the members the kernels index by constant
+    assert _hip.PK_MAX_EXTRA == 4 and _hip.PK_MAX_KERNELS == 8
 
 
 def test_no_gpu_fails_loudly():
@@ -268,3 +277,30 @@ def test_changing_an_interpolator_drops_the_device_copy():
     fs.__dict__["_engine"] = object()
     fs.UV.interp_method = pa.XFreeslip()
     assert fs._engine is None
+
+
+def test_sample_field_token_validation():
+    """SampleField(field, into=variable): the device form of `particles.p = fieldset.P[particles]` (tests/test_particleset_execute.py:
+    182-205 pattern) -- checked at Kernel construction like the reference checks its kernels (kernel.py:67-70,122-159)."""
+    from parcels_amd.kernel import Kernel
+
+    case, _, _ = load_golden("agrid_sph_rk4_sample_p_f32")
+    fs = build_fieldset(case)
+    pset = build_pset(case, fs)
+    k = Kernel([pa.AdvectionRK4, pa.SampleField("P", into="p")], pset)
+    assert k.kernel_ids == [4, 10] and k.samples == {1: ("P", 0)} and k.device_variables == ["p"] and k.funcname == "AdvectionRK4SampleP"
+    with pytest.raises(ValueError):
+        Kernel([pa.SampleField("nope", into="p")], pset)
+    with pytest.raises(ValueError):
+        Kernel([pa.SampleField("P", into="q")], pset)  # no such Variable
+    with pytest.raises(ValueError):
+        Kernel([pa.SampleField("P", into="x")], pset)  # a built-in column is not a user Variable
+    with pytest.raises(ValueError):
+        Kernel([pa.SampleField("UV", into="p")], pset)  # vector fields are sampled by the advection kernels
+    with pytest.warns(RuntimeWarning, match="Sampling of velocities should normally be done using fieldset.UV"):
+        Kernel([pa.SampleField("U", into="p")], pset)  # field.py:187-190
+    ip = pa.ParticleSet(fs, pclass=pa.get_default_particle(np.float64).add_variable(pa.Variable("p", dtype=np.int32)), x=[1.0], y=[1.0], z=[1.0], t=[0.0])
+    with pytest.raises(TypeError):
+        Kernel([pa.SampleField("P", into="p")], ip)
+    with pytest.raises(RuntimeError):
+        pa.SampleField("P", into="p")(None, None)  # device kernels cannot run on the host
