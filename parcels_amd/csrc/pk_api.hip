@@ -1325,11 +1325,11 @@ static int32_t fill_args(pk_ctx* ctx, const pk_exec_params* prm, KArgs& a, size_
     a.lds_cc_nodes = a.lds_cc_keys = a.lds_cc_fvals = -1;
     const bool want_cc = use_lds && mg.d.kind == 1 && !ctx->no_cell_cache && (int64_t)mg.d.ny * mg.d.nx < INT32_MAX;
     if (want_cc) {
-        const size_t node_b = 20 * 256 * sizeof(double), key_b = 4 * 256 * sizeof(int32_t);
-        const size_t fval_b = 12 * 256 * (size_t)(mf.desc.dtype == PK_F32 ? 4 : 8);
+        const size_t node_b = 20 * CC_LANES * sizeof(double), key_b = 4 * CC_LANES * sizeof(int32_t);
+        const size_t fval_b = 12 * CC_LANES * (size_t)(mf.desc.dtype == PK_F32 ? 4 : 8);
         if (lds_bytes + node_b + key_b <= 64 * 1024) {
             a.lds_cc_nodes = a.lds_total;
-            a.lds_cc_keys = a.lds_cc_nodes + 20 * 256;
+            a.lds_cc_keys = a.lds_cc_nodes + 20 * CC_LANES;
             int32_t end = a.lds_cc_keys + (int32_t)(key_b / sizeof(double));
             if (prm->interp_uv == 1 && (size_t)end * sizeof(double) + fval_b <= 64 * 1024) {
                 a.lds_cc_fvals = end;

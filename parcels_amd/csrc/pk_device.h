@@ -260,7 +260,14 @@ PK_DEV NV nv_sqrt(NV a) { return a.dt == 1 ? NV{(double)sqrtf((float)a.v), 1} : 
 // than the 4 MB L2 of an XCD keeps between stages).  Layout: structure-of-arrays over the 256 lanes of the workgroup
 // (element k of lane l at [k * 256 + l]) -> conflict-free ds_read/ds_write.  Cached bits are the global ones, so
 // results are unchanged.  All pointers NULL = disabled.
-constexpr int CC_LANES = 256;
+// Workgroup size of the programs that carry the cell cache (curvilinear grids, LDS-staged): ONE wavefront.  The cache costs
+// 224 B of LDS per lane (f32 fields); 256-lane workgroups (57 KB) fit twice into the 160 KB of a CU = 2 waves / SIMD whatever the
+// register budget, 64-lane workgroups fit ten times, so the occupancy is decided by the registers again.
+#ifndef PK_WG_CURV
+#define PK_WG_CURV 64
+#endif
+constexpr int CC_LANES = PK_WG_CURV;
+__host__ __device__ constexpr inline int wg_size(int kind, bool lds) { return (kind == 1 && lds) ? PK_WG_CURV : 256; }
 struct CellCache {
     double* nodes;  // [20][256]: corner c (0 (yi,xi), 1 (yi,xi+1), 2 (yi+1,xi+1), 3 (yi+1,xi)), component m -> (c*5+m)
     int* key;       // [4][256]: node cell yi*nx+xi | field cell yi*nx+xi | zi | 4*ti + 2*(W cached) + (level ti+1 cached);  -1 = empty
@@ -1165,6 +1172,47 @@ PK_DEV void cgrid_velocity(const DGrid& g, const Coords* mc, const DField& U, co
         cgrid_velocity_typed<FT>(g, U, V, W, p, px, py, ypos, ypos_f32, u, v, w, u32, v32);
         return;
     }
+    // The staggered field values are requested FIRST and the edge-length geometry (4 cos + 4 sqrt, ~1000 cycles of fp64) is
+    // computed while they are in flight: on a cache miss the wave would otherwise sit out a second global round trip after the
+    // one of the cell search (the kernel waits on memory for a third of its wave cycles at 2 waves / SIMD).
+    const int yi_o = clampi(yi + g.off_y, 0, ydim - 1), xi_1 = clampi(xi + 1, 0, xdim - 1);
+    const int yi_1 = clampi(yi + 1, 0, ydim - 1), xi_o = clampi(xi + g.off_x, 0, xdim - 1);
+    // the six staggered values of this cell at level ti (and ti+1): U at the x-faces (:272-279), V at the y-faces
+    // (:281-288), W at the two z-faces (:316-328, clipped with U's z extent like the reference)
+    const bool lenT = p.tau > 0;
+    const int zi_0 = clampi(zi + g.off_z, 0, zdim - 1), zi_1 = clampi(zi + g.off_z + 1, 0, zdim - 1);
+    FT rawf[12];  // kept in the field dtype until the geometry is done: a conversion here would wait for the loads
+    FT* fv = cc_on ? (FT*)mc->cc.fvals : nullptr;
+    // key[3] = 4*ti + 2*(W values cached) + (level ti+1 cached)
+    const bool fhit = fv && mc->cc.key[1 * CC_LANES] == cell && mc->cc.key[2 * CC_LANES] == zi &&
+                      (mc->cc.key[3 * CC_LANES] >> 2) == p.ti && (!lenT || (mc->cc.key[3 * CC_LANES] & 1)) &&
+                      (!W || (mc->cc.key[3 * CC_LANES] & 2));
+    if (fhit) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) rawf[k] = fv[k * CC_LANES];
+        if (lenT) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) rawf[6 + k] = fv[(6 + k) * CC_LANES];
+        }
+    } else {
+        int64_t off[6];
+        const FT* dat[6] = {(const FT*)U.data, (const FT*)U.data, (const FT*)V.data, (const FT*)V.data,
+                            W ? (const FT*)W->data : nullptr, W ? (const FT*)W->data : nullptr};
+        const DField* fl[6] = {&U, &U, &V, &V, W, W};
+        off[0] = cgrid_off(U, zi, yi_o, xi);
+        off[1] = cgrid_off(U, zi, yi_o, xi_1);
+        off[2] = cgrid_off(V, zi, yi, xi_o);
+        off[3] = cgrid_off(V, zi, yi_1, xi_o);
+        off[4] = W ? cgrid_off(*W, zi_0, yi_o, xi_o) : 0;
+        off[5] = W ? cgrid_off(*W, zi_1, yi_o, xi_o) : 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) rawf[k] = (k < 4 || W) ? dat[k][slot_off(*fl[k], p.ti) + off[k]] : (FT)0;
+        if (lenT) {
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+                rawf[6 + k] = (k < 4 || W) ? dat[k][slot_off(*fl[k], mini(p.ti + 1, fl[k]->nt - 1)) + off[k]] : (FT)0;
+        }
+    }
     constexpr bool cf32 = false;  // float64 coordinates from here on
     // einsum("ij,ji->i", phi2D_lin(eta, xsi), py): products formed for all four corners, summed in corner order.  With
     // float32 xsi/eta arrays (p.w32) the phi entries and 1 - xsi, 1 - eta, eta - 1, xsi - 1 are float32 results.
@@ -1185,60 +1233,23 @@ PK_DEV void cgrid_velocity(const DGrid& g, const Coords* mc, const DField& U, co
 #undef PK_PHI_DOT64
 #undef PK_PHI_DOT32
 #undef PK_PHI_DOT
-    const int yi_o = clampi(yi + g.off_y, 0, ydim - 1), xi_1 = clampi(xi + 1, 0, xdim - 1);
-    const int yi_1 = clampi(yi + 1, 0, ydim - 1), xi_o = clampi(xi + g.off_x, 0, xdim - 1);
-    // the six staggered values of this cell at level ti (and ti+1): U at the x-faces (:272-279), V at the y-faces
-    // (:281-288), W at the two z-faces (:316-328, clipped with U's z extent like the reference)
-    const bool lenT = p.tau > 0;
-    const int zi_0 = clampi(zi + g.off_z, 0, zdim - 1), zi_1 = clampi(zi + g.off_z + 1, 0, zdim - 1);
-    double raw[12];
-    FT* fv = cc_on ? (FT*)mc->cc.fvals : nullptr;
-    // key[3] = 4*ti + 2*(W values cached) + (level ti+1 cached)
-    const bool fhit = fv && mc->cc.key[1 * CC_LANES] == cell && mc->cc.key[2 * CC_LANES] == zi &&
-                      (mc->cc.key[3 * CC_LANES] >> 2) == p.ti && (!lenT || (mc->cc.key[3 * CC_LANES] & 1)) &&
-                      (!W || (mc->cc.key[3 * CC_LANES] & 2));
-    if (fhit) {
-#pragma unroll
-        for (int k = 0; k < 6; k++) raw[k] = (double)fv[k * CC_LANES];
-        if (lenT) {
-#pragma unroll
-            for (int k = 0; k < 6; k++) raw[6 + k] = (double)fv[(6 + k) * CC_LANES];
-        }
-    } else {
-        int64_t off[6];
-        const FT* dat[6] = {(const FT*)U.data, (const FT*)U.data, (const FT*)V.data, (const FT*)V.data,
-                            W ? (const FT*)W->data : nullptr, W ? (const FT*)W->data : nullptr};
-        const DField* fl[6] = {&U, &U, &V, &V, W, W};
-        off[0] = cgrid_off(U, zi, yi_o, xi);
-        off[1] = cgrid_off(U, zi, yi_o, xi_1);
-        off[2] = cgrid_off(V, zi, yi, xi_o);
-        off[3] = cgrid_off(V, zi, yi_1, xi_o);
-        off[4] = W ? cgrid_off(*W, zi_0, yi_o, xi_o) : 0;
-        off[5] = W ? cgrid_off(*W, zi_1, yi_o, xi_o) : 0;
-#pragma unroll
-        for (int k = 0; k < 6; k++) raw[k] = (k < 4 || W) ? ldv(dat[k], slot_off(*fl[k], p.ti) + off[k]) : 0.0;
-        if (lenT) {
-#pragma unroll
-            for (int k = 0; k < 6; k++)
-                raw[6 + k] = (k < 4 || W) ? ldv(dat[k], slot_off(*fl[k], mini(p.ti + 1, fl[k]->nt - 1)) + off[k]) : 0.0;
-        }
-        if (fv) {  // values widened exactly from FT, so the narrowing store is exact
+    if (!fhit) {  // fill the lane's cache slot now that the geometry has covered the latency of the loads
+        if (fv) {
             mc->cc.key[1 * CC_LANES] = -1;
 #pragma unroll
-            for (int k = 0; k < 6; k++) fv[k * CC_LANES] = (FT)raw[k];
+            for (int k = 0; k < 6; k++) fv[k * CC_LANES] = rawf[k];
             if (lenT) {
 #pragma unroll
-                for (int k = 0; k < 6; k++) fv[(6 + k) * CC_LANES] = (FT)raw[6 + k];
+                for (int k = 0; k < 6; k++) fv[(6 + k) * CC_LANES] = rawf[6 + k];
             }
             mc->cc.key[2 * CC_LANES] = zi;
             mc->cc.key[3 * CC_LANES] = 4 * p.ti + (W ? 2 : 0) + (lenT ? 1 : 0);
             mc->cc.key[1 * CC_LANES] = cell;
         }
     }
-    if (lenT) {
+    double raw[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++) raw[k] = raw[k] * (1 - p.tau) + raw[6 + k] * p.tau;
-    }
+    for (int k = 0; k < 6; k++) raw[k] = lenT ? (double)rawf[k] * (1 - p.tau) + (double)rawf[6 + k] * p.tau : (double)rawf[k];
     const double ua = raw[0], ub = raw[1], va = raw[2], vb = raw[3];
     const double U0 = ua * c4, U1 = ub * c2;
     const double Uvel = omx * U0 + xsi * U1;

@@ -362,7 +362,8 @@ PK_DEV unsigned xcd_swizzle(unsigned bid, unsigned nb) {
 #endif
 // PFM: particle storage dtype -- 0 float64, 1 float32, -1 decided at run time (P.spatial_f32).
 template <class FT, int KIND, int INTERP, int KID, bool LDS, bool TYPED, int PFM = -1>
-__global__ void __launch_bounds__(256, (KIND == 1 || INTERP != 0) ? PK_MIN_WAVES_HEAVY : PK_MIN_WAVES) advect_kernel(const KArgs a) {
+__global__ void __launch_bounds__(wg_size(KIND, LDS), (KIND == 1 || INTERP != 0) ? PK_MIN_WAVES_HEAVY : PK_MIN_WAVES) advect_kernel(const KArgs a) {
+    constexpr int WG = wg_size(KIND, LDS);
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const DField& mf = a.fields[a.main_field];
     const DGrid& mg = a.grids[a.main_grid];
@@ -374,12 +375,12 @@ __global__ void __launch_bounds__(256, (KIND == 1 || INTERP != 0) ? PK_MIN_WAVES
         double* s_lat = smem + a.lds_lat;
         double* s_lon = smem + a.lds_lon;
         const int nt = mf.has_time_interval ? mf.nt : 0;
-        for (int k = threadIdx.x; k < nt; k += 256) s_time[k] = mf.time[k];
+        for (int k = threadIdx.x; k < nt; k += WG) s_time[k] = mf.time[k];
         const int nz = mg.has_z ? mg.nz : 0;
-        for (int k = threadIdx.x; k < nz; k += 256) s_depth[k] = mg.depth[k];
+        for (int k = threadIdx.x; k < nz; k += WG) s_depth[k] = mg.depth[k];
         if (KIND == 0) {
-            for (int k = threadIdx.x; k < mg.ny; k += 256) s_lat[k] = mg.lat[k];
-            for (int k = threadIdx.x; k < mg.nx; k += 256) s_lon[k] = mg.lon[k];
+            for (int k = threadIdx.x; k < mg.ny; k += WG) s_lat[k] = mg.lat[k];
+            for (int k = threadIdx.x; k < mg.nx; k += WG) s_lon[k] = mg.lon[k];
         }
         __syncthreads();
         mc.time = s_time;
@@ -408,7 +409,7 @@ __global__ void __launch_bounds__(256, (KIND == 1 || INTERP != 0) ? PK_MIN_WAVES
     mc.y0 = mg.yfirst; mc.y1 = mg.ylast;
     mc.x0 = mg.xfirst; mc.x1 = mg.xlast;
 
-    const int64_t i = (int64_t)xcd_swizzle(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    const int64_t i = (int64_t)xcd_swizzle(blockIdx.x, gridDim.x) * WG + threadIdx.x;
     unsigned long long steps = 0, attempts = 0, paused = 0;
     if (i < a.p.n) {
         const DParticles& P = a.p;
@@ -680,8 +681,9 @@ void launch_fast(int field_f32, int particles_f32, const KArgs& a, dim3 grid, si
         }                                                                                                               \
     }
 
-#define PK_LAUNCH_CASE(FT, KD, IN, LD) \
-    hipLaunchKernelGGL((advect_kernel<FT, KD, IN, KIDV, LD, TYPEDV>), grid, dim3(256), lds_bytes, stream, a)
+#define PK_LAUNCH_CASE(FT, KD, IN, LD)                                                                                          \
+    hipLaunchKernelGGL((advect_kernel<FT, KD, IN, KIDV, LD, TYPEDV>), dim3((unsigned)((a.p.n + wg_size(KD, LD) - 1) / wg_size(KD, LD))), \
+                       dim3(wg_size(KD, LD)), lds_bytes, stream, a)
 
 // single-kernel programs require LDS staging (the host falls back to the generic program otherwise)
 // interp: 0 XLinear_Velocity, 1 CGrid_Velocity, 2 slip (XFreeslip / XPartialslip, told apart by prm.interp_uv)
