@@ -27,7 +27,7 @@ extern "C" {
 
 #define PK_ABI_VERSION 3
 #define PK_MAX_GRIDS 4
-#define PK_MAX_FIELDS 8
+#define PK_MAX_FIELDS 16
 #define PK_MAX_KERNELS 8
 #define PK_MAX_EXTRA 4 /* user Variables that device kernels write (PK_KERNEL_SAMPLE_FIELD) */
 #define PK_NUM_STATE_CODES 80

@@ -548,8 +548,8 @@ class DeviceEngine:
         t, z, y, x = np.broadcast_arrays(*(np.atleast_1d(np.asarray(v, dtype=np.float64)) for v in (t, z, y, x)))
         t, z, y, x = (np.ascontiguousarray(v) for v in (t, z, y, x))
         m = x.shape[0]
-        if self.windowed:
-            raise NotImplementedError("host-driven sampling needs all time levels resident (use nslots >= nt)")
+        if self.windowed and m > 0:
+            return self._sample_streamed(name, t, z, y, x)
         u, v, w = np.zeros(m), np.zeros(m), np.zeros(m)
         st = np.zeros(m, np.int32)
         prm = self.make_params([4], endtime=0.0, dt0=1.0)
@@ -568,6 +568,46 @@ class DeviceEngine:
         )
         self.last_sample_state = st
         return u, v, w
+
+
+def _sample_streamed(self, name, t, z, y, x):
+    """Field.eval at explicit points when the field levels stream through a ring: the points are visited in time order, one
+    resident window at a time (what WindowedArray does for the reference's batches, _windowed_array.py:56-97)."""
+    m = x.shape[0]
+    order = np.argsort(t, kind="stable")  # NaN last
+    ts = t[order]
+    u, v, w = np.zeros(m), np.zeros(m), np.zeros(m)
+    st = np.zeros(m, np.int32)
+    wf = self._windowed_fields()
+    was = self.windowed
+    i = 0
+    try:
+        while i < m:
+            t0 = float(ts[i])
+            j = m
+            if np.isfinite(t0):
+                self._commit_window(t0, 1)
+                hi = np.inf
+                for f in wf:
+                    tf = np.asarray(f.model.time_flt, dtype=np.float64)
+                    lv = [l for l in self._slots(f.name) if l >= 0]
+                    if max(lv) < len(tf) - 1:
+                        hi = min(hi, float(tf[max(lv)]))
+                j = max(int(np.searchsorted(ts, hi, side="right")), i + 1)
+            sel = order[i:j]
+            self.windowed = False  # the chunk's levels are resident: evaluate it like a resident field
+            cu, cv, cw = self.sample(name, t[sel], z[sel], y[sel], x[sel])
+            self.windowed = was
+            u[sel], v[sel], w[sel] = cu, cv, cw
+            st[sel] = self.last_sample_state
+            i = j
+    finally:
+        self.windowed = was
+    self.last_sample_state = st
+    return u, v, w
+
+
+DeviceEngine._sample_streamed = _sample_streamed
 
 
 def _engine_search(self, igrid, z, y, x):

@@ -100,3 +100,25 @@ def test_streamed_scalar_fields_on_their_own_time_axis(gpu):
         if ns is not None:
             assert pset._last_stats["launches"] > 1, "the ring was not exercised"
     compare(res[4], res[None], rtol=0.0, check_state="all", label="own time axes", skip=())
+
+
+def test_field_eval_at_explicit_points_through_a_ring(gpu):
+    """Field.eval / VectorField.eval (field.py:145-195, 250-304) with the levels streaming through a ring of 3: the points are
+    served one resident window at a time and the values equal those of a fully resident FieldSet, bit for bit."""
+    from oracle import cases
+
+    case = cases.rect_agrid_case("ring_eval", mesh="spherical", kernels=["AdvectionRK4"], seed=9, nt=8, npart=2000, with_w=True, level_dt=86400.0)
+    rng = np.random.default_rng(3)
+    n = len(case["x"])
+    t = rng.uniform(-1000.0, 7 * 86400.0 + 1000.0, n)  # unsorted, a few outside the time interval
+    t[::50] = 86400.0 * rng.integers(0, 8, len(t[::50]))  # exactly on levels
+    res = {}
+    for ns in (None, 3):
+        fs = build_fieldset(case)
+        fs.to_device(nslots=ns)
+        uvw = fs.UVW.eval(t, case["z"], case["y"], case["x"])
+        usc = fs.U.eval(t, case["z"], case["y"], case["x"])
+        res[ns] = (np.array(uvw[0]), np.array(uvw[1]), np.array(uvw[2]), np.array(usc), np.array(fs._engine.last_sample_state))
+    for a, b in zip(res[3], res[None]):
+        assert np.array_equal(a, b, equal_nan=True) if a.dtype.kind == "f" else np.array_equal(a, b)
+    assert np.any(res[None][4] == 70) and np.any(res[None][0] != 0)
