@@ -40,6 +40,7 @@ from .particle import Particle, ParticleClass, Variable, get_default_particle
 from .particlefile import ParticleFile, read_particlefile
 from .particleset import ParticleSet
 from .sgrid import FaceNodePadding, Padding, SGrid2DMetadata
+from .sources import LevelSource, NpyLevels, ZarrLevels
 from .statuscodes import (
     AllParcelsErrorCodes,
     FieldInterpolationError,

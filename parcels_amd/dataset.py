@@ -14,9 +14,12 @@ from .sgrid import FaceNodePadding, Padding, SGrid2DMetadata
 
 class DataArray:
     def __init__(self, dims, data, attrs=None):
+        from .sources import is_level_source
+
         self.dims = (dims,) if isinstance(dims, str) else tuple(dims)
-        self.data = np.asarray(data)
-        if self.data.ndim != len(self.dims):
+        # a level source (parcels_amd.sources) stays what it is: its levels are read when the device asks for them
+        self.data = data if is_level_source(data) else np.asarray(data)
+        if len(self.data.shape) != len(self.dims):
             raise ValueError(f"dims {self.dims} do not match array of shape {self.data.shape}")
         self.attrs = dict(attrs or {})
 
@@ -30,7 +33,7 @@ class DataArray:
 
     @property
     def ndim(self):
-        return self.data.ndim
+        return len(self.data.shape)
 
 
 def _as_da(v) -> DataArray:

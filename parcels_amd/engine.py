@@ -29,6 +29,19 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
+class _LazyLevels:
+    """A level source (parcels_amd.sources) behind the `host[level]` indexing the engine uses for NumPy arrays."""
+
+    def __init__(self, src, dtype):
+        self.src, self.dtype = src, np.dtype(dtype)
+        self.shape = tuple(src.shape)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+
+    def __getitem__(self, level):
+        lvl = self.src.level(int(level), self.dtype) if hasattr(self.src, "level") else np.ascontiguousarray(self.src.read_level(int(level)), dtype=self.dtype)
+        return lvl
+
+
 class DeviceEngine:
     def __init__(self, fieldset, device: int = 0, nslots: int | None = None, memory_fraction: float = 0.6,
                  hash_build: str | None = None, neighbour_probe: int = 0):
@@ -134,15 +147,20 @@ class DeviceEngine:
         for f in fs.fields.values():
             if isinstance(f, VectorField):
                 comps = [c for c in (f.U, f.V, f.W) if c is not None]
-                dts = {np.asarray(c.data.data).dtype for c in comps}
+                dts = {np.dtype(c.data.data.dtype) for c in comps}
                 tgt = np.float32 if dts == {np.dtype(np.float32)} else np.float64
                 for c in comps:
                     share[c.name] = np.float64 if share.get(c.name) is np.float64 else tgt
         hosts = {}
+        from .sources import is_level_source
+
         for f in self.scalar_fields:
-            a = np.asarray(f.data.data)
-            tgt = share.get(f.name, np.float32 if a.dtype == np.float32 else np.float64)
-            hosts[f.name] = np.ascontiguousarray(a, dtype=tgt)
+            a = f.data.data
+            tgt = share.get(f.name, np.float32 if np.dtype(a.dtype) == np.float32 else np.float64)
+            if is_level_source(a):
+                hosts[f.name] = _LazyLevels(a, tgt)  # levels are read (and converted) when `_upload` asks for them
+            else:  # no copy for a C-contiguous array / np.memmap of the target dtype
+                hosts[f.name] = np.ascontiguousarray(np.asarray(a), dtype=tgt)
         # residency plan: keep all levels if they fit the budget, else a ring
         info = self.ctx.device_info()
         budget = memory_fraction * info["free_mem"]

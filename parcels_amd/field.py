@@ -99,7 +99,20 @@ class StructuredModelData:
             raise ValueError(f"Expected `ds` to be a parcels_amd.Dataset. Got {type(ds)}")
         ds = ds.copy()
         md = ds.sgrid
+        from .sources import is_level_source
+
         for name in list(ds.data_vars):
+            if is_level_source(ds.data_vars[name].data):  # read level by level later: must already be laid out (time, z, y, x)
+                da = ds.data_vars[name]
+                if len(da.dims) != 4 or da.dims[0] != "time":
+                    raise ValueError(f"level source '{name}' needs dims (time, <z>, <y>, <x>) naming its four axes; got {da.dims}")
+                d2a = dict(md.dim_to_axis())
+                axes = [d2a.get(d) for d in da.dims[1:]]
+                for want, got, d in zip("ZYX", axes, da.dims[1:]):
+                    if got not in (want, None) or (got is None and not str(d).startswith("mock")):
+                        raise ValueError(f"level source '{name}': dimension '{d}' is not the {want} axis of the grid (use 'mock{want}' for an absent axis)")
+                da.data.fill_nan = bool(getattr(da.data, "fill_nan", True)) and not skip_field_data_validation
+                continue
             da = transpose_to_tzyx(ds.data_vars[name], md)
             if not skip_field_data_validation and np.issubdtype(da.data.dtype, np.floating):
                 if np.isnan(da.data).any():  # model.py:135-143 fillna(0)

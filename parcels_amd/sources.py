@@ -1,0 +1,203 @@
+"""Level sources: field data that is read from disk one time level at a time.
+
+The reference hands the hot path dask-backed arrays and its ``WindowedArray`` reads each level once, on demand
+(src/parcels/_core/_windowed_array.py:56-97, _xarray.py:13-35).  The engine's counterpart of "a level is needed" is
+``DeviceEngine._upload(name, level)``: with a fully materialised NumPy array (or ``np.memmap``) it slices the level; with one of the
+sources below it asks the source -- for a streamed field during the previous launch (``_prefetch``), so the read, the decompression
+and the page-ins overlap the RK sub-steps, and a dataset larger than the host's memory never exists in it as a whole.
+
+A level source is anything with
+
+    .shape  (nt, nz, ny, nx) in T, Z, Y, X order (size 1 for absent axes: put the array in TZYX order when you write it)
+    .dtype  float32 or float64
+    .read_level(k) -> C-contiguous ndarray of shape[1:]
+
+``Dataset`` keeps such an object as it is (no ``np.asarray``).  NaN fill values are replaced by 0 per level at read time, like
+``StructuredModelData`` does for in-memory arrays (model.py:135-143).
+
+* ``NpyLevels``  -- a directory / list of ``.npy`` files, one per time level (memory-mapped).
+* ``ZarrLevels`` -- one array of a zarr v2 store on a local filesystem, chunked with ONE time level per chunk along the first axis
+  (chunks may split z / y / x), compressor null, zstd, lz4, or blosc (lz4 / zstd / zlib inner codec, byte shuffle) --
+  the formats pyarrow's codecs can decode; no zarr / numcodecs installation is needed.
+"""
+
+from __future__ import annotations
+
+import glob
+import json
+import os
+import struct
+
+import numpy as np
+
+__all__ = ["LevelSource", "NpyLevels", "ZarrLevels", "is_level_source"]
+
+
+class LevelSource:
+    """Base class / protocol marker."""
+
+    shape: tuple
+    dtype: np.dtype
+    fill_nan = True  # replace NaN by 0 when a level is read (model.py:135-143)
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    @property
+    def nbytes(self):
+        return int(np.prod(self.shape)) * np.dtype(self.dtype).itemsize
+
+    def read_level(self, k: int) -> np.ndarray:  # pragma: no cover - interface
+        raise NotImplementedError
+
+    def level(self, k: int, dtype=None) -> np.ndarray:
+        """Level ``k`` ready for the upload: C-contiguous, target dtype, NaN -> 0."""
+        a = self.read_level(int(k))
+        if tuple(a.shape) != tuple(self.shape[1:]):
+            raise ValueError(f"level {k} has shape {a.shape}, expected {self.shape[1:]}")
+        if self.fill_nan and np.issubdtype(a.dtype, np.floating) and np.isnan(a).any():
+            a = np.nan_to_num(a, nan=0.0)
+        return np.ascontiguousarray(a, dtype=dtype or self.dtype)
+
+    def __getitem__(self, k):
+        if isinstance(k, (int, np.integer)):
+            return self.level(int(k))
+        raise TypeError("a level source is indexed by one time level at a time")
+
+
+def is_level_source(obj) -> bool:
+    return isinstance(obj, LevelSource) or (hasattr(obj, "read_level") and hasattr(obj, "shape") and hasattr(obj, "dtype"))
+
+
+class NpyLevels(LevelSource):
+    """One ``.npy`` file per time level: ``NpyLevels("/data/U_*.npy")`` (sorted glob), a directory, or a list of paths.  Each file
+    holds one (nz, ny, nx) level -- or any shape that reshapes to ``level_shape``."""
+
+    def __init__(self, paths, level_shape=None):
+        if isinstance(paths, (str, os.PathLike)):
+            p = str(paths)
+            paths = sorted(glob.glob(os.path.join(p, "*.npy"))) if os.path.isdir(p) else sorted(glob.glob(p))
+        self.paths = [str(p) for p in paths]
+        if not self.paths:
+            raise ValueError("NpyLevels: no level files found")
+        first = np.load(self.paths[0], mmap_mode="r")
+        ls = tuple(level_shape) if level_shape is not None else tuple(first.shape)
+        ls = (1,) * (3 - len(ls)) + ls if len(ls) < 3 else ls
+        if int(np.prod(ls)) != int(np.prod(first.shape)) or len(ls) != 3:
+            raise ValueError(f"NpyLevels: a level of shape {first.shape} does not reshape to (nz, ny, nx) = {ls}")
+        self.shape = (len(self.paths),) + ls
+        self.dtype = np.dtype(first.dtype)
+
+    def read_level(self, k):
+        return np.load(self.paths[k], mmap_mode="r").reshape(self.shape[1:])
+
+
+# ---- zarr v2 ----------------------------------------------------------------------------------------------------------------
+def _blosc_decode(buf: bytes) -> bytes:
+    """One Blosc-1 frame (what numcodecs.Blosc writes): 16-byte header, block offsets, per-block [split] streams."""
+    import pyarrow as pa
+
+    version, versionlz, flags, typesize = struct.unpack_from("<BBBB", buf, 0)
+    nbytes, blocksize, cbytes = struct.unpack_from("<III", buf, 4)
+    if version != 2:
+        raise ValueError(f"unsupported blosc frame version {version}")
+    if flags & 0x2:  # memcpyed: the payload follows the header verbatim
+        return bytes(buf[16:16 + nbytes])
+    if flags & 0x4:
+        raise ValueError("blosc bit-shuffle is not supported (use byte shuffle or no shuffle)")
+    codec = {0: None, 1: "lz4", 2: "lz4", 4: "gzip", 5: "zstd"}.get(flags >> 5, "?")
+    if codec in (None, "?"):
+        raise ValueError(f"unsupported blosc inner codec {flags >> 5} (blosclz / snappy): re-encode with lz4, zstd or zlib")
+    shuffle = bool(flags & 0x1) and typesize > 1
+    dont_split = bool(flags & 0x10)
+    nblocks = (nbytes + blocksize - 1) // blocksize
+    offs = struct.unpack_from(f"<{nblocks}I", buf, 16)
+    out = bytearray(nbytes)
+    cod = pa.Codec("lz4_raw" if codec == "lz4" else codec)
+    for b in range(nblocks):
+        bsize = min(blocksize, nbytes - b * blocksize)
+        # blosc splits a full block into `typesize` byte-plane streams unless told not to; the short last block is never split
+        split = (not dont_split) and bsize == blocksize and 1 < typesize <= 16 and blocksize // typesize >= 128
+        nsplit = typesize if split else 1
+        pos = offs[b]
+        block = bytearray()
+        for _ in range(nsplit):
+            (cb,) = struct.unpack_from("<i", buf, pos)
+            pos += 4
+            neblock = bsize // nsplit
+            chunk = buf[pos:pos + cb]
+            block += chunk if cb == neblock else cod.decompress(chunk, decompressed_size=neblock).to_pybytes()  # cb == raw size: stored
+            pos += cb
+        if shuffle:
+            n = bsize // typesize
+            arr = np.frombuffer(bytes(block[: n * typesize]), dtype=np.uint8).reshape(typesize, n).T.reshape(-1)
+            block = bytearray(arr.tobytes()) + block[n * typesize:]
+        out[b * blocksize:b * blocksize + bsize] = block
+    return bytes(out)
+
+
+class ZarrLevels(LevelSource):
+    """``ZarrLevels("/data/model.zarr", "uo")``: the array ``uo`` of a zarr v2 directory store whose first axis is time with
+    chunk length 1.  ``shape_tzyx`` inserts size-1 axes when the array has fewer than four (e.g. a (time, y, x) surface field:
+    ``shape_tzyx=("t", None, "y", "x")`` is implied for 3-D arrays)."""
+
+    def __init__(self, store, array, fill_nan=True):
+        self.root = os.path.join(str(store), array)
+        meta_path = os.path.join(self.root, ".zarray")
+        if not os.path.exists(meta_path):
+            raise FileNotFoundError(f"{meta_path}: not a zarr v2 array (zarr v3 stores are not read)")
+        meta = json.load(open(meta_path))
+        if meta.get("zarr_format") != 2 or meta.get("order", "C") != "C" or meta.get("filters"):
+            raise ValueError("ZarrLevels reads zarr v2 arrays in C order without filters")
+        self.zshape = tuple(meta["shape"])
+        self.chunks = tuple(meta["chunks"])
+        if self.chunks[0] != 1:
+            raise ValueError(f"the time axis must be chunked one level per chunk, got chunks={self.chunks}")
+        self.zdtype = np.dtype(meta["dtype"])
+        self.dtype = np.dtype(np.float64 if self.zdtype.itemsize == 8 else np.float32) if self.zdtype.kind == "f" else np.dtype(np.float64)
+        self.compressor = meta.get("compressor")
+        self.fill_value = meta.get("fill_value")
+        self.sep = meta.get("dimension_separator", ".")
+        rest = self.zshape[1:]
+        if not (1 <= len(rest) <= 3):
+            raise ValueError(f"expected a (time, [z,] [y,] x) array, got shape {self.zshape}")
+        self.shape = (self.zshape[0],) + (1,) * (3 - len(rest)) + tuple(rest)
+        self.fill_nan = fill_nan
+
+    def _decode(self, raw: bytes) -> bytes:
+        c = self.compressor
+        if c is None:
+            return raw
+        cid = c.get("id")
+        if cid == "blosc":
+            return _blosc_decode(raw)
+        import pyarrow as pa
+
+        if cid == "zstd":
+            n = int(np.prod(self.chunks)) * self.zdtype.itemsize
+            return pa.Codec("zstd").decompress(raw, decompressed_size=n).to_pybytes()
+        if cid == "lz4":  # numcodecs.LZ4: 4-byte little-endian size + raw lz4 block
+            (n,) = struct.unpack_from("<I", raw, 0)
+            return pa.Codec("lz4_raw").decompress(raw[4:], decompressed_size=n).to_pybytes()
+        if cid in ("zlib", "gzip"):
+            import zlib
+
+            return zlib.decompress(raw) if cid == "zlib" else zlib.decompress(raw, 31)
+        raise ValueError(f"unsupported zarr compressor {cid!r}")
+
+    def read_level(self, k):
+        rest_shape, rest_chunks = self.zshape[1:], self.chunks[1:]
+        out = np.empty(rest_shape, dtype=self.zdtype)
+        grid = [range((s + c - 1) // c) for s, c in zip(rest_shape, rest_chunks)]
+        for idx in np.ndindex(*[len(g) for g in grid]):
+            key = self.sep.join(str(v) for v in (k,) + tuple(idx))
+            path = os.path.join(self.root, key)
+            sl = tuple(slice(i * c, min((i + 1) * c, s)) for i, c, s in zip(idx, rest_chunks, rest_shape))
+            if not os.path.exists(path):  # an unwritten chunk holds the fill value
+                out[sl] = np.nan if self.fill_value in (None, "NaN") else self.fill_value
+                continue
+            buf = self._decode(open(path, "rb").read())
+            chunk = np.frombuffer(buf, dtype=self.zdtype, count=int(np.prod(rest_chunks))).reshape(rest_chunks)
+            out[sl] = chunk[tuple(slice(0, s.stop - s.start) for s in sl)]
+        return out.reshape(self.shape[1:])

@@ -79,6 +79,9 @@ def build_fieldset(case):
     data_vars = {}
     for name, arr in case["fields"].items():
         dims = tuple(case["field_dims"][name])
+        if hasattr(arr, "read_level"):  # a level source (parcels_amd.sources): handed over as it is
+            data_vars[name] = (dims, arr)
+            continue
         a = np.asarray(arr)
         keep = [i for i, d in enumerate(dims) if not d.startswith("mock")]
         a = a.reshape([a.shape[i] for i in keep])

@@ -1,0 +1,143 @@
+"""Level sources (parcels_amd/sources.py): field data read from disk one time level at a time -- per-level .npy files and zarr v2
+arrays (null / zstd / lz4 / blosc chunks), the producer side of the device's level ring."""
+
+from __future__ import annotations
+
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import parcels_amd as pa
+from case_utils import build_fieldset, build_pset, compare
+
+
+def _write_zarr_v2(root, name, arr, chunks, compressor):
+    """A zarr v2 directory array written by hand (zarr / numcodecs are not installed): null, zstd, numcodecs-style lz4."""
+    import pyarrow as pyarrow
+
+    d = os.path.join(root, name)
+    os.makedirs(d, exist_ok=True)
+    meta = {"zarr_format": 2, "shape": list(arr.shape), "chunks": list(chunks), "dtype": arr.dtype.str, "order": "C", "filters": None,
+            "fill_value": "NaN", "compressor": None if compressor is None else {"id": compressor}}
+    json.dump(meta, open(os.path.join(d, ".zarray"), "w"))
+    grid = [range((s + c - 1) // c) for s, c in zip(arr.shape, chunks)]
+    for idx in np.ndindex(*[len(g) for g in grid]):
+        chunk = np.full(chunks, np.nan, arr.dtype)
+        sl = tuple(slice(i * c, min((i + 1) * c, s)) for i, c, s in zip(idx, chunks, arr.shape))
+        part = arr[sl]
+        chunk[tuple(slice(0, n) for n in part.shape)] = part
+        raw = chunk.tobytes()
+        if compressor == "zstd":
+            raw = pyarrow.Codec("zstd").compress(raw).to_pybytes()
+        elif compressor == "lz4":
+            raw = struct.pack("<I", len(raw)) + pyarrow.Codec("lz4_raw").compress(raw).to_pybytes()
+        open(os.path.join(d, ".".join(str(i) for i in idx)), "wb").write(raw)
+
+
+@pytest.mark.parametrize("compressor", [None, "zstd", "lz4"])
+def test_zarr_levels_reads_what_was_written(tmp_path, compressor):
+    rng = np.random.default_rng(1)
+    a = rng.standard_normal((5, 4, 13, 17)).astype(np.float32)
+    a[2, 1, 3, 4] = np.nan
+    _write_zarr_v2(str(tmp_path), "U", a, (1, 2, 8, 17), compressor)
+    src = pa.ZarrLevels(str(tmp_path), "U")
+    assert src.shape == a.shape and src.dtype == np.float32
+    for k in range(5):
+        assert np.array_equal(src.read_level(k), a[k], equal_nan=True)
+    assert src.level(2)[1, 3, 4] == 0.0  # NaN fill -> 0 like model.py:135-143
+    b = rng.standard_normal((3, 9, 11))  # (time, y, x) surface field -> (nt, 1, ny, nx)
+    _write_zarr_v2(str(tmp_path), "S", b, (1, 9, 11), compressor)
+    s2 = pa.ZarrLevels(str(tmp_path), "S")
+    assert s2.shape == (3, 1, 9, 11) and np.array_equal(s2.level(1)[0], b[1])
+    with pytest.raises(ValueError):
+        _write_zarr_v2(str(tmp_path), "bad", a, (2, 4, 13, 17), None)
+        pa.ZarrLevels(str(tmp_path), "bad")
+
+
+def test_zarr_levels_decodes_the_reference_s_blosc_stores():
+    """The zarr stores the reference ships (tests/test_data/*.zarr, numcodecs Blosc lz4 + byte shuffle) through the product's own
+    frame decoder, against oracle/mini_zarr.py (build container only)."""
+    root = "/root/reference/tests/test_data/test_interpolation_jit_linear.zarr"
+    if not os.path.isdir(root):
+        pytest.skip("reference test data not present")
+    from oracle import mini_zarr
+    from parcels_amd.sources import _blosc_decode
+
+    n = 0
+    for name in sorted(os.listdir(root)):
+        d = os.path.join(root, name)
+        if not os.path.exists(os.path.join(d, ".zarray")):
+            continue
+        meta = json.load(open(os.path.join(d, ".zarray")))
+        if (meta.get("compressor") or {}).get("id") != "blosc":
+            continue
+        for f in os.listdir(d):
+            if f.startswith("."):
+                continue
+            raw = open(os.path.join(d, f), "rb").read()
+            assert _blosc_decode(raw) == mini_zarr.blosc_decompress(raw)
+            n += 1
+    assert n > 0
+
+
+def test_npy_levels(tmp_path):
+    a = np.arange(4 * 3 * 5 * 6, dtype=np.float64).reshape(4, 3, 5, 6)
+    for k in range(4):
+        np.save(tmp_path / f"U_{k:03d}.npy", a[k])
+    src = pa.NpyLevels(str(tmp_path / "U_*.npy"))
+    assert src.shape == a.shape and src.dtype == np.float64
+    assert np.array_equal(src[2], a[2]) and src[2].flags["C_CONTIGUOUS"]
+    with pytest.raises(TypeError):
+        src[1:3]
+    with pytest.raises(ValueError):
+        pa.NpyLevels(str(tmp_path / "nothing_*.npy"))
+
+
+def _case_on_disk(tmp_path, kind):
+    from oracle import cases
+
+    case = cases.rect_agrid_case("src_" + kind, mesh="spherical", kernels=["AdvectionRK4_3D"], seed=17, nx=30, ny=20, nz=6, nt=7, npart=3000, with_w=True,
+                                 field_dtype=np.float32, level_dt=43200.0, dt=3600.0, runtime=2.9 * 86400.0)
+    lazy = dict(case)
+    lazy["fields"] = {}
+    for name, arr in case["fields"].items():
+        if kind == "npy":
+            d = tmp_path / name
+            d.mkdir()
+            for k in range(arr.shape[0]):
+                np.save(d / f"{k:04d}.npy", arr[k])
+            lazy["fields"][name] = pa.NpyLevels(str(d))
+        else:
+            _write_zarr_v2(str(tmp_path / "store.zarr"), name, arr, (1, 3, 20, 16), "zstd")
+            lazy["fields"][name] = pa.ZarrLevels(str(tmp_path / "store.zarr"), name)
+    return case, lazy
+
+
+def test_fieldset_accepts_level_sources(tmp_path):
+    case, lazy = _case_on_disk(tmp_path, "npy")
+    fs = build_fieldset(lazy)
+    assert isinstance(fs.U.data.data, pa.NpyLevels) and fs.U.data.shape == case["fields"]["U"].shape
+    assert fs.time_interval is not None and "UVW" in fs.fields
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["npy", "zarr"])
+def test_advection_from_level_sources_equals_in_memory_fields(gpu, tmp_path, kind):
+    """Levels read from disk on demand into a ring of 3 (and all at once into a resident device copy) give the trajectories of the
+    in-memory NumPy fields, bit for bit."""
+    case, lazy = _case_on_disk(tmp_path, kind)
+    ref_fs = build_fieldset(case)
+    ref = build_pset(case, ref_fs)
+    ref.execute([pa.AdvectionRK4_3D, pa.DeleteParticle], dt=case["dt"], runtime=case["runtime"])
+    want = {k: np.array(v) for k, v in ref._data.items()}
+    for ns in (3, None):
+        fs = build_fieldset(lazy)
+        fs.to_device(nslots=ns)
+        pset = build_pset(lazy, fs)
+        pset.execute([pa.AdvectionRK4_3D, pa.DeleteParticle], dt=case["dt"], runtime=case["runtime"])
+        if ns is not None:
+            assert pset._last_stats["launches"] > 1
+        compare({k: np.array(v) for k, v in pset._data.items()}, want, rtol=0.0, check_state="all", label=f"{kind} nslots={ns}", skip=())
