@@ -156,12 +156,17 @@ class OutputRecorder:
         return False
 
 
-def run_hip(case, endtime=None, **pset_kw):
-    """Run a case through parcels_amd (HIP). Returns (soa dict, error name or None, stats)."""
+def run_hip(case, endtime=None, nslots=None, async_output=None, **pset_kw):
+    """Run a case through parcels_amd (HIP). Returns (soa dict, error name or None, stats).  nslots: stream the field levels
+    through a ring of that many slots (None: the engine decides, i.e. resident for test-sized fields)."""
     import parcels_amd as pa
 
     fs = build_fieldset(case)
+    if nslots is not None:
+        fs.to_device(nslots=nslots)
     pset = build_pset(case, fs, **pset_kw)
+    if async_output is not None:
+        pset.async_output = bool(async_output)
     samples = case.get("sample_into") or {}
     kernels = [pa.SampleField(samples[k][0], into=samples[k][1]) if k in samples else getattr(pa.kernels, k) for k in case["kernels"]]
     kw = {}
