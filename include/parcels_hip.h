@@ -55,7 +55,7 @@ typedef struct pk_ctx pk_ctx;
 
 /* Built-in kernels, recognised by identity on the Python side like kernel.py:129-134 does.
  * 1-9: kernels/_advection.py:21-155, kernels/_advectiondiffusion.py:21-153.
- * 20-22: native forms of the recovery kernels the reference's tests interleave with them
+ * 20-25: native forms of the recovery / no-op kernels the reference's tests interleave with them
  *        (tests/common_kernels.py:12-13, tests/test_advection.py:157-174). */
 #define PK_KERNEL_ADVECTION_EE 1
 #define PK_KERNEL_ADVECTION_RK2 2
@@ -72,6 +72,9 @@ typedef struct pk_ctx pk_ctx;
 #define PK_KERNEL_DELETE_ON_ERROR 20
 #define PK_KERNEL_DELETE_OUT_OF_BOUNDS 21
 #define PK_KERNEL_SUBMERGE_THROUGH_SURFACE 22
+#define PK_KERNEL_DO_NOTHING 23 /* tests/common_kernels.py:8-9: the kernel of the reference's loop / output tests (time passes, nothing moves) */
+#define PK_KERNEL_MOVE_EAST 24  /* tests/common_kernels.py:16-17: particles.dx += 0.1 */
+#define PK_KERNEL_MOVE_NORTH 25 /* tests/common_kernels.py:20-21: particles.dy += 0.1 */
 
 /* ---- context ------------------------------------------------------------------------------------ */
 int32_t pk_abi_version(void);

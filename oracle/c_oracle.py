@@ -27,6 +27,9 @@ KERNEL_IDS = {
     "AdvectionDiffusionEM": 8,
     "DiffusionUniformKh": 9,
     "SampleField": 10,
+    "DoNothing": 23,
+    "MoveEast": 24,
+    "MoveNorth": 25,
     "DeleteParticle": 20,
     "DeleteOutOfBounds": 21,
     "SubmergeParticle": 22,

@@ -618,6 +618,15 @@ def all_cases() -> dict:
     add(rect_agrid_case("agrid_sph_rk4_outside_time", mesh="spherical", kernels=["AdvectionRK4"], seed=19, nt=2,
                         runtime=30 * 3600.0))
 
+    # --- the toy kernels of the reference's loop tests (tests/common_kernels.py): kernel-order invariance via dx (test_kernel.py:
+    #     167-202), misaligned outputdt with a moving particle (test_particlefile.py:331-398), default float32 particles ----------
+    add(rect_agrid_case("agrid_flat_move_east_north_f32", mesh="flat", kernels=["MoveEast", "AdvectionRK4", "MoveNorth", "DoNothing"], seed=33,
+                        spatial_dtype="float32", vel=0.0, dt=20.0, runtime=100.0))
+    c["agrid_flat_move_east_north_f32"]["outputdt"] = 50.0
+    add(rect_agrid_case("agrid_sph_do_nothing_backward", mesh="spherical", kernels=["DoNothing"], seed=34, dt=-300.0, runtime=7200.0))
+    c["agrid_sph_do_nothing_backward"]["t0"] = np.full(300, 86400.0)
+    c["agrid_sph_do_nothing_backward"]["outputdt"] = 3600.0
+
     # --- the user kernel every tutorial writes: particles.p = fieldset.P[particles] after the advection kernel ----------------
     for nm, kw, pd in (("agrid_sph_rk4_sample_p_f32", dict(mesh="spherical", seed=31), "float32"),
                        ("agrid_flat_rk4_sample_p_f64_escape", dict(mesh="flat", seed=32, vel=6.0, margin=0.01, dt=1800.0, runtime=20 * 1800.0), "float64")):

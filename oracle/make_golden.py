@@ -100,7 +100,17 @@ def _recovery_kernels(m):
         particles[inds].z = 0
         particles[inds].state = SC.Evaluate
 
-    return {"DeleteParticle": DeleteParticle, "DeleteOutOfBounds": DeleteOutOfBounds, "SubmergeParticle": SubmergeParticle}
+    def DoNothing(particles, fieldset):  # tests/common_kernels.py:8-9
+        pass
+
+    def MoveEast(particles, fieldset):  # tests/common_kernels.py:16-17
+        particles.dx += 0.1
+
+    def MoveNorth(particles, fieldset):  # tests/common_kernels.py:20-21
+        particles.dy += 0.1
+
+    return {"DeleteParticle": DeleteParticle, "DeleteOutOfBounds": DeleteOutOfBounds, "SubmergeParticle": SubmergeParticle,
+            "DoNothing": DoNothing, "MoveEast": MoveEast, "MoveNorth": MoveNorth}
 
 
 def build_ref_fieldset(case):

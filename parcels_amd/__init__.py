@@ -33,12 +33,15 @@ from .kernels import (
     DeleteOutOfBounds,
     DeleteParticle,
     DiffusionUniformKh,
+    DoNothing,
+    MoveEast,
+    MoveNorth,
     SampleField,
     SubmergeParticle,
 )
 from .particle import Particle, ParticleClass, Variable, get_default_particle
 from .particlefile import ParticleFile, read_particlefile
-from .particleset import ParticleSet
+from .particleset import ParticleSet, ParticleSetWarning
 from .sgrid import FaceNodePadding, Padding, SGrid2DMetadata
 from .sources import LevelSource, NpyLevels, ZarrLevels
 from .statuscodes import (

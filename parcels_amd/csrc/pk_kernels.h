@@ -261,6 +261,14 @@ PK_DEV bool prepare(const KArgs& a, int kid, int stage, int kslot, PCtx& c, PSta
             else ((double*)a.p.extra[v])[c.row] = L.r[0];
             return true;
         }
+        case PK_KERNEL_DO_NOTHING:  // tests/common_kernels.py:8-9
+            return true;
+        case PK_KERNEL_MOVE_EAST:  // tests/common_kernels.py:16-17: `particles.dx += 0.1` (an in-place add in the storage dtype)
+            p.dx = padd(pf, p.dx, 0.1);
+            return true;
+        case PK_KERNEL_MOVE_NORTH:  // tests/common_kernels.py:20-21
+            p.dy = padd(pf, p.dy, 0.1);
+            return true;
         case PK_KERNEL_DELETE_ON_ERROR:  // tests/common_kernels.py:12-13
             if (c.state >= PK_ERROR) c.state = PK_DELETE;
             return true;

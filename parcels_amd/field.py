@@ -52,6 +52,21 @@ class TimeInterval:
         start, end = max(self.left, other.left), min(self.right, other.right)
         return TimeInterval(start, end) if start < end else None
 
+    def get_cf_attrs(self) -> dict:
+        """CF attributes of "x seconds from the left edge" (utils/time.py:88-119).  The reference routes calendar dates through
+        cftime.datetime(calendar="gregorian"), whose strftime format is "%Y-%m-%d %H:%M:%S" and whose calendar attribute reads
+        back as "standard"; cftime-typed (non-standard calendar) intervals are outside the hot path's scope."""
+        import datetime as _dt
+
+        left = self.left
+        if isinstance(left, np.timedelta64):
+            return {"units": "seconds"}
+        if isinstance(left, np.datetime64):
+            left = left.astype("datetime64[us]").astype(_dt.datetime)
+        if isinstance(left, _dt.datetime):
+            return {"units": f"seconds since {left.strftime('%Y-%m-%d %H:%M:%S')}", "calendar": "standard"}
+        raise NotImplementedError(f"Not implemented for time object {type(left)=!r}")
+
 
 def to_seconds(dt) -> float | np.ndarray:
     """utils/time.py:197-214 (timedelta_to_float)."""

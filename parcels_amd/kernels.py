@@ -20,6 +20,9 @@ __all__ = [
     "DeleteOutOfBounds",
     "DeleteParticle",
     "DiffusionUniformKh",
+    "DoNothing",
+    "MoveEast",
+    "MoveNorth",
     "SampleField",
     "SubmergeParticle",
 ]
@@ -87,6 +90,21 @@ def DeleteOutOfBounds(particles, fieldset):  # tests/test_advection.py:157-161
     _device_only("DeleteOutOfBounds")
 
 
+def DoNothing(particles, fieldset):  # tests/common_kernels.py:8-9
+    """Time passes, nothing moves (the kernel of the reference's loop and output tests)."""
+    _device_only("DoNothing")
+
+
+def MoveEast(particles, fieldset):  # tests/common_kernels.py:16-17
+    """particles.dx += 0.1"""
+    _device_only("MoveEast")
+
+
+def MoveNorth(particles, fieldset):  # tests/common_kernels.py:20-21
+    """particles.dy += 0.1"""
+    _device_only("MoveNorth")
+
+
 def SubmergeParticle(particles, fieldset):  # tests/test_advection.py:163-174
     """ErrorThroughSurface -> resample UV, dz = 0, z = 0, state = Evaluate."""
     _device_only("SubmergeParticle")
@@ -134,4 +152,7 @@ KERNEL_IDS = {
     DeleteParticle: 20,
     DeleteOutOfBounds: 21,
     SubmergeParticle: 22,
+    DoNothing: 23,
+    MoveEast: 24,
+    MoveNorth: 25,
 }

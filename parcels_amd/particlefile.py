@@ -38,7 +38,7 @@ def get_schema(pclass, file_metadata, fset_time_interval):
     for v in _get_vars_to_write(pclass):
         attrs = {str(k): str(val) for k, val in v.attrs.items()}
         if v.name == "t" and fset_time_interval is not None:
-            attrs["units"] = f"seconds since {fset_time_interval.left}"
+            attrs.update(fset_time_interval.get_cf_attrs())  # particlefile.py:38-41
         fields.append(pa.field(v.name, pa.from_numpy_dtype(np.dtype(v.dtype)), metadata=attrs))
     return pa.schema(fields, metadata={str(k): str(v) for k, v in file_metadata.items()})
 

@@ -15,7 +15,7 @@ from .particle import Particle, create_particle_data
 __all__ = ["ParticleSet"]
 
 
-class ParticleSetWarning(RuntimeWarning):
+class ParticleSetWarning(UserWarning):  # _core/warnings.py:14-17
     pass
 
 
@@ -210,49 +210,51 @@ class ParticleSet:
         synced = True
         try:
             with output_file if output_file is not None else nullcontext():  # the Parquet footer is written on error too
-                while sign_dt * (time - end_time) < 0:
-                    if next_output is not None:
-                        next_time = (min if sign_dt > 0 else max)(next_output, end_time)
-                    else:
-                        next_time = end_time
-                    stats = kern.launch(self, next_time, dt, have_guess0=have_guess0)
-                    have_guess0 = 1
-                    synced = False
-                    self._t_live = next_time if not np.isnan(next_time) else None
-                    if kern.only_deletions(stats) and self.device_compaction:
-                        # Kernel.remove_deleted on the device: the columns do not leave HBM (pk_particles_compact)
-                        self._data = engine.compact_deleted(self._data)
-                        synced = False
-                        if len(self) == 0:
-                            synced = True
-                            break
-                    elif kern.needs_host_pass(stats):
-                        engine.d2h()
-                        synced = True
-                        kern.finish_on_host(self)  # compacts / raises
-                        if len(self) == 0:
-                            break
-                        engine.bind_particles(self._data)
-                        engine.h2d()
-                    if next_output is not None and np.abs(next_time - next_output) < 0.001:
-                        if writer is not None and not synced:
-                            # snapshot on the device, D2H on the copy stream, filter + Parquet encode on the writer thread --
-                            # all of it overlaps the next interval's launch (particlefile.py:142-180 off the critical path)
-                            writer.submit(self._data, next_output)
+                try:
+                    while sign_dt * (time - end_time) < 0:
+                        if next_output is not None:
+                            next_time = (min if sign_dt > 0 else max)(next_output, end_time)
                         else:
-                            if writer is not None:
-                                writer.drain()  # keep the tables in time order
-                            if not synced:
-                                engine.d2h(out_cols)
-                            output_file.write(self, next_output)
-                        if np.isfinite(outputdt):
-                            next_output += outputdt * sign_dt
-                    time = next_time
-                if writer is not None:
-                    writer.drain()
+                            next_time = end_time
+                        stats = kern.launch(self, next_time, dt, have_guess0=have_guess0)
+                        have_guess0 = 1
+                        synced = False
+                        self._t_live = next_time if not np.isnan(next_time) else None
+                        if kern.only_deletions(stats) and self.device_compaction:
+                            # Kernel.remove_deleted on the device: the columns do not leave HBM (pk_particles_compact)
+                            self._data = engine.compact_deleted(self._data)
+                            synced = False
+                            if len(self) == 0:
+                                synced = True
+                                break
+                        elif kern.needs_host_pass(stats):
+                            engine.d2h()
+                            synced = True
+                            kern.finish_on_host(self)  # compacts / raises
+                            if len(self) == 0:
+                                break
+                            engine.bind_particles(self._data)
+                            engine.h2d()
+                        if next_output is not None and np.abs(next_time - next_output) < 0.001:
+                            if writer is not None and not synced:
+                                # snapshot on the device, D2H on the copy stream, filter + Parquet encode on the writer thread --
+                                # all of it overlaps the next interval's launch (particlefile.py:142-180 off the critical path)
+                                writer.submit(self._data, next_output)
+                            else:
+                                if writer is not None:
+                                    writer.drain()  # keep the tables in time order
+                                if not synced:
+                                    engine.d2h(out_cols)
+                                output_file.write(self, next_output)
+                            if np.isfinite(outputdt):
+                                next_output += outputdt * sign_dt
+                        time = next_time
+                finally:
+                    # pending tables are encoded BEFORE the file is closed (also when a kernel raised: the footer then covers
+                    # every table submitted so far)
+                    if writer is not None:
+                        writer.close()
         finally:
-            if writer is not None:
-                writer.close()
             if not synced and len(self) > 0:
                 engine.d2h()
             self._t_live = None
