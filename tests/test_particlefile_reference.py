@@ -15,7 +15,7 @@ import parcels_amd as pa
 from parcels_amd.particlefile import get_schema
 
 
-def make_fieldset(time="datetime", nt=3, mesh="flat"):
+def make_fieldset(time="datetime", nt=3, mesh="flat", uniform=None):
     """A small A-grid fieldset like the reference's `fieldset` fixture (tests/conftest.py: ds_2d_left, a datetime time axis)."""
     nx, ny = 12, 10
     md = pa.SGrid2DMetadata(node_dimensions=("XG", "YG"), node_coordinates=("lon", "lat"),
@@ -32,6 +32,8 @@ def make_fieldset(time="datetime", nt=3, mesh="flat"):
         else:
             coords["time"] = (("time",), np.arange(nt) * 2 * 86400.0)
     data = {"U": (dims, 1e-5 * rng.standard_normal(shape)), "V": (dims, 1e-5 * rng.standard_normal(shape))}
+    if uniform is not None:
+        data = {"U": (dims, np.full(shape, uniform[0])), "V": (dims, np.full(shape, uniform[1]))}
     return pa.FieldSet.from_sgrid_conventions(pa.Dataset(data, coords, sgrid=md), mesh=mesh)
 
 
@@ -297,9 +299,7 @@ def test_particlefile_init_existing_path_modes(gpu, fieldset, tmp_parquet):  # t
 def test_particlefile_readable_after_kernel_error(gpu, fieldset, tmp_parquet, async_output):  # test_particlefile.py:512-526 (GH-2713)
     """The reference's ErrorKernel sets StatusCode.Error; here the error is the one the hot path raises itself: a particle advected
     out of the domain.  The file must hold a footer and every table written before the error."""
-    fs = make_fieldset()
-    for f in (fs.U, fs.V):
-        f.data[...] = 1.0  # 1 degree/s eastwards on a flat mesh: out of the 6-degree domain within a few steps
+    fs = make_fieldset(uniform=(1.0, 0.0))  # 1 degree/s eastwards on a flat mesh: out of the 6-degree domain within a few steps
     pset = pa.ParticleSet(fs, x=np.zeros(4), y=np.zeros(4))
     pset.async_output = async_output
     ofile = pa.ParticleFile(tmp_parquet, outputdt=np.timedelta64(1, "s"))
