@@ -92,6 +92,13 @@ const char* pk_last_error(const pk_ctx* ctx); /* ctx may be NULL: error of the l
  * Environment variables PK_NO_FAST, PK_NO_SPECIAL, PK_NO_CELL_CACHE, PK_NO_HASH_DIR, PK_SORT_HORIZONTAL give the initial values. */
 int32_t pk_set_option(pk_ctx* ctx, const char* name, int32_t value);
 
+/* Host-side accounting of the level stream (pk_field_upload_level / _group_level with async=1), cumulative since pk_init:
+ * out4[0] seconds the host threads spent filling pinned staging chunks (memcpy / {U,V,W} interleave), out4[1] seconds blocked on
+ * the DMA that still read the chunk about to be refilled (= the PCIe link was the limit), out4[2] bytes handed to the DMA engine,
+ * out4[3] the number of staging threads.  The reference's counterpart is the time WindowedArray spends materialising levels
+ * (src/parcels/_core/_windowed_array.py:56-97); it keeps no such counter. */
+int32_t pk_upload_stats(pk_ctx* ctx, double* out4);
+
 typedef struct pk_device_info {
     char name[128];
     char arch[64];

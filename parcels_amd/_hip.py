@@ -202,6 +202,7 @@ ABI_SYMBOLS = [
     "pk_search",
     "pk_measure_copy_bandwidth",
     "pk_set_option",
+    "pk_upload_stats",
 ]
 
 _lib = None
@@ -259,6 +260,7 @@ def load():
     lib.pk_search.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pk_measure_copy_bandwidth.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_double)]
     lib.pk_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
+    lib.pk_upload_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     if lib.pk_abi_version() != PK_ABI_VERSION:
         raise HipLibraryError(f"ABI version mismatch: library {lib.pk_abi_version()}, binding {PK_ABI_VERSION}")
     _lib = lib
@@ -299,6 +301,12 @@ class Context:
     def set_option(self, name: str, value: int):
         """Tuning / A-B switches (include/parcels_hip.h: pk_set_option), e.g. set_option("fast_path", 0)."""
         self.check(self.lib.pk_set_option(self.handle, name.encode(), int(value)), f"pk_set_option({name})")
+
+    def upload_stats(self) -> dict:
+        """Host-side accounting of the level stream since pk_init (include/parcels_hip.h: pk_upload_stats)."""
+        out = (C.c_double * 4)()
+        self.check(self.lib.pk_upload_stats(self.handle, out), "pk_upload_stats")
+        return {"stage_fill_s": out[0], "stage_wait_s": out[1], "stage_bytes": out[2], "stage_threads": int(out[3])}
 
     def copy_bandwidth(self, nbytes: int = 1 << 30, iters: int = 10) -> float:
         g = C.c_double()

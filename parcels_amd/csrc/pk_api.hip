@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -17,6 +18,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "pk_hashbuild.h"
+#include "pk_host_stage.h"
 #include "pk_kernels.h"
 
 using namespace pk;
@@ -44,6 +46,8 @@ struct HostField {
     std::vector<int32_t> slot_level;    // committed (usable) level per ring slot, -1 = empty
     std::vector<int32_t> slot_pending;  // level being copied into the slot (async upload), -1 = none
 };
+
+constexpr int PK_STAGE_BUFFERS = 3;  // pinned staging chunks of the level stream (see stage_acquire)
 
 struct pk_ctx {
     int device = 0;
@@ -73,10 +77,11 @@ struct pk_ctx {
     DCounters* d_counters = nullptr;
     unsigned long long* d_summary = nullptr;  // PK_NUM_STATE_CODES counts + 2 ordered-double slots
     // pinned staging ring for async level uploads
-    void* stage[2] = {nullptr, nullptr};
-    size_t stage_bytes[2] = {0, 0};
-    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    void* stage[PK_STAGE_BUFFERS] = {};
+    size_t stage_bytes[PK_STAGE_BUFFERS] = {};
+    hipEvent_t stage_ev[PK_STAGE_BUFFERS] = {};
     int stage_next = 0;
+    double stage_fill_s = 0, stage_wait_s = 0, stage_bytes_total = 0;  // pk_upload_stats
     hipDeviceProp_t prop;
     // an advection launch in flight (pk_execute_begin .. pk_execute_end)
     bool in_flight = false;
@@ -320,75 +325,33 @@ __global__ void __launch_bounds__(256) copy_kernel(const float4* __restrict__ sr
 
 }  // namespace pk
 
-// pageable -> pinned staging copy of one field level, split over host threads (a single core moves ~10 GB/s, which would
-// otherwise bound the slab stream well below the PCIe rate).  PK_COPY_THREADS overrides the thread count.
+// pageable -> pinned staging: a ring of PK_STAGE_BUFFERS fixed-size pinned chunks (allocated once; pinning a whole 4 GB level costs
+// ~1 s).  The host fills chunk k+1 (pk_host_stage.cpp: persistent thread pool, AVX2 interleave, non-temporal stores) while chunk k
+// is on the wire; a third chunk keeps the DMA queue from draining while the fill of the next one is being handed to the pool.
 constexpr size_t PK_STAGE_CHUNK_BYTES = (size_t)256 << 20;
-static unsigned copy_threads() {
-    static const unsigned n = [] {
-        if (const char* e = getenv("PK_COPY_THREADS")) return (unsigned)std::max(1, atoi(e));
-        const unsigned hw = std::thread::hardware_concurrency();
-        return std::max(8u, std::min(32u, hw / 4));
-    }();
-    return n;
-}
-static void parallel_memcpy(void* dst, const void* src, size_t bytes) {
-    const size_t min_chunk = 4u << 20;
-    unsigned nthr = (unsigned)std::min<size_t>(copy_threads(), std::max<size_t>(1, bytes / min_chunk));
-    if (nthr <= 1) {
-        memcpy(dst, src, bytes);
-        return;
-    }
-    std::vector<std::thread> pool;
-    const size_t chunk = ((bytes / nthr) + 4095) & ~(size_t)4095;
-    for (unsigned k = 0; k < nthr; k++) {
-        const size_t off = (size_t)k * chunk;
-        if (off >= bytes) break;
-        const size_t len = std::min(chunk, bytes - off);
-        pool.emplace_back([=]() { memcpy((char*)dst + off, (const char*)src + off, len); });
-    }
-    for (auto& t : pool) t.join();
-}
-
-// the same staging step for a packed group: elements [0, n) of `ncomp` separate host arrays -> one array of structs
-// {c0, c1, ...} in the pinned chunk, so that the DMA lands the level in its final layout (no device-side repack)
-template <class T>
-static void interleave_range(T* dst, const T* const* src, int ncomp, size_t lo, size_t hi) {
-    // non-temporal stores: the pinned chunk is written once and read by the DMA engine, never by this core -- no read-for-
-    // ownership of the destination lines, a third less memory traffic for the fill that has to keep up with the PCIe link
-    if (ncomp == 3) {
-        const T *a = src[0], *b = src[1], *c = src[2];
-        for (size_t i = lo; i < hi; i++) {
-            __builtin_nontemporal_store(a[i], &dst[3 * i]);
-            __builtin_nontemporal_store(b[i], &dst[3 * i + 1]);
-            __builtin_nontemporal_store(c[i], &dst[3 * i + 2]);
-        }
-    } else if (ncomp == 2) {
-        const T *a = src[0], *b = src[1];
-        for (size_t i = lo; i < hi; i++) {
-            __builtin_nontemporal_store(a[i], &dst[2 * i]);
-            __builtin_nontemporal_store(b[i], &dst[2 * i + 1]);
-        }
+using pkhost::parallel_interleave;
+using pkhost::parallel_memcpy;
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// the next staging chunk, free of its previous DMA (blocks on that DMA's event; the wait is accounted in stage_wait_s)
+static int32_t stage_acquire(pk_ctx* ctx, int* out) {
+    const int k = ctx->stage_next;
+    ctx->stage_next = (k + 1) % PK_STAGE_BUFFERS;
+    if (!ctx->stage[k]) {
+        PK_HIP(ctx, hipHostMalloc(&ctx->stage[k], PK_STAGE_CHUNK_BYTES, hipHostMallocDefault));
+        ctx->stage_bytes[k] = PK_STAGE_CHUNK_BYTES;
     } else {
-        for (size_t i = lo; i < hi; i++)
-            for (int k = 0; k < ncomp; k++) dst[(size_t)ncomp * i + k] = src[k][i];
+        const double t0 = now_s();
+        PK_HIP(ctx, hipEventSynchronize(ctx->stage_ev[k]));
+        ctx->stage_wait_s += now_s() - t0;
     }
+    *out = k;
+    return 0;
 }
-template <class T>
-static void parallel_interleave(T* dst, const T* const* src, int ncomp, size_t n) {
-    const size_t min_chunk = (size_t)1 << 18;
-    const unsigned nthr = (unsigned)std::min<size_t>(copy_threads(), std::max<size_t>(1, n / min_chunk));
-    if (nthr <= 1) {
-        interleave_range(dst, src, ncomp, 0, n);
-        return;
-    }
-    std::vector<std::thread> pool;
-    const size_t per = (n + nthr - 1) / nthr;
-    for (unsigned k = 0; k < nthr; k++) {
-        const size_t lo = (size_t)k * per, hi = std::min(n, lo + per);
-        if (lo >= hi) break;
-        pool.emplace_back([=]() { interleave_range(dst, src, ncomp, lo, hi); });
-    }
-    for (auto& t : pool) t.join();
+static int32_t stage_submit(pk_ctx* ctx, int k, void* dst, size_t bytes) {
+    PK_HIP(ctx, hipMemcpyAsync(dst, ctx->stage[k], bytes, hipMemcpyHostToDevice, ctx->copy));
+    PK_HIP(ctx, hipEventRecord(ctx->stage_ev[k], ctx->copy));
+    ctx->stage_bytes_total += (double)bytes;
+    return 0;
 }
 
 template <class T>
@@ -439,8 +402,7 @@ int32_t pk_init(int32_t device, pk_ctx** out) {
     PK_HIP(ctx, hipEventCreate(&ctx->ev0));
     PK_HIP(ctx, hipEventCreate(&ctx->ev1));
     PK_HIP(ctx, hipEventCreate(&ctx->ev2));
-    PK_HIP(ctx, hipEventCreateWithFlags(&ctx->stage_ev[0], hipEventDisableTiming));
-    PK_HIP(ctx, hipEventCreateWithFlags(&ctx->stage_ev[1], hipEventDisableTiming));
+    for (int k = 0; k < PK_STAGE_BUFFERS; k++) PK_HIP(ctx, hipEventCreateWithFlags(&ctx->stage_ev[k], hipEventDisableTiming));
     PK_HIP(ctx, hipMalloc((void**)&ctx->d_counters, sizeof(DCounters)));
     PK_HIP(ctx, hipMalloc((void**)&ctx->d_summary, sizeof(unsigned long long) * (PK_NUM_STATE_CODES + 2)));
     PK_HIP(ctx, hipHostMalloc((void**)&ctx->h_counters, sizeof(DCounters), hipHostMallocDefault));
@@ -457,6 +419,15 @@ int32_t pk_set_option(pk_ctx* ctx, const char* name, int32_t value) {
     else if (n == "hash_directory") ctx->no_hash_dir = !value;
     else if (n == "sort_horizontal") ctx->sort_horizontal_major = value;
     else return ctx->fail("pk_set_option: unknown option '" + n + "'");
+    return 0;
+}
+
+int32_t pk_upload_stats(pk_ctx* ctx, double* out4) {
+    if (!ctx || !out4) return -2;
+    out4[0] = ctx->stage_fill_s;       // host threads filling pinned chunks
+    out4[1] = ctx->stage_wait_s;       // blocked on the DMA that still reads the chunk to be refilled
+    out4[2] = ctx->stage_bytes_total;  // bytes handed to the DMA engine through the staging ring
+    out4[3] = (double)pkhost::copy_threads();
     return 0;
 }
 
@@ -519,7 +490,7 @@ int32_t pk_destroy(pk_ctx* ctx) {
     if (ctx->d_summary) (void)hipFree(ctx->d_summary);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->h_summary) (void)hipHostFree(ctx->h_summary);
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < PK_STAGE_BUFFERS; k++) {
         if (ctx->stage[k]) (void)hipHostFree(ctx->stage[k]);
         if (ctx->stage_ev[k]) (void)hipEventDestroy(ctx->stage_ev[k]);
     }
@@ -708,8 +679,8 @@ int32_t pk_field_create(pk_ctx* ctx, const pk_field_desc* desc, int32_t* field_i
         PK_HIP(ctx, hipMemset(f.dev_data, 0, f.level_bytes * nslots * ncomp));  // never expose NaN garbage (weight-0 reads)
     }
     if (nslots < desc->nt) {
-        // a streamed field: pin the two staging chunks now (pinning 512 MiB costs ~0.15 s -- at creation, not inside the first run)
-        for (int k = 0; k < 2; k++)
+        // a streamed field: pin the staging chunks now (pinning 768 MiB costs ~0.2 s -- at creation, not inside the first run)
+        for (int k = 0; k < PK_STAGE_BUFFERS; k++)
             if (!ctx->stage[k]) {
                 PK_HIP(ctx, hipHostMalloc(&ctx->stage[k], PK_STAGE_CHUNK_BYTES, hipHostMallocDefault));
                 ctx->stage_bytes[k] = PK_STAGE_CHUNK_BYTES;
@@ -778,22 +749,16 @@ int32_t pk_field_upload_level(pk_ctx* ctx, int32_t field_id, int32_t level, cons
         if (int32_t rc = interleave()) return rc;
         PK_HIP(ctx, hipStreamSynchronize(ctx->copy));
     } else {
-        // pageable NumPy memory cannot be DMA'd asynchronously: bounce it through a ring of two fixed-size pinned chunks
-        // (allocated once; pinning a whole 4 GB level costs ~1 s) -- the host fills chunk k+1 while chunk k is on the wire
+        // pageable NumPy memory cannot be DMA'd asynchronously: bounce it through the ring of pinned chunks
         const size_t chunk = PK_STAGE_CHUNK_BYTES;
         for (size_t off = 0; off < f.level_bytes; off += chunk) {
             const size_t len = std::min(chunk, f.level_bytes - off);
-            const int k = ctx->stage_next;
-            ctx->stage_next ^= 1;
-            if (!ctx->stage[k]) {
-                PK_HIP(ctx, hipHostMalloc(&ctx->stage[k], chunk, hipHostMallocDefault));
-                ctx->stage_bytes[k] = chunk;
-            } else {
-                PK_HIP(ctx, hipEventSynchronize(ctx->stage_ev[k]));  // previous DMA out of this buffer finished
-            }
+            int k;
+            if (int32_t rc = stage_acquire(ctx, &k)) return rc;
+            const double t0 = now_s();
             parallel_memcpy(ctx->stage[k], (const char*)host_data + off, len);
-            PK_HIP(ctx, hipMemcpyAsync(h2d_dst + off, ctx->stage[k], len, hipMemcpyHostToDevice, ctx->copy));
-            PK_HIP(ctx, hipEventRecord(ctx->stage_ev[k], ctx->copy));
+            ctx->stage_fill_s += now_s() - t0;
+            if (int32_t rc = stage_submit(ctx, k, h2d_dst + off, len)) return rc;
         }
         if (int32_t rc = interleave()) return rc;
     }
@@ -828,14 +793,9 @@ int32_t pk_field_upload_group_level(pk_ctx* ctx, int32_t leader_id, int32_t leve
     const size_t chunk_elems = PK_STAGE_CHUNK_BYTES / (esz * ncomp);
     for (size_t off = 0; off < level_elems; off += chunk_elems) {
         const size_t len = std::min(chunk_elems, level_elems - off);
-        const int k = ctx->stage_next;
-        ctx->stage_next ^= 1;
-        if (!ctx->stage[k]) {
-            PK_HIP(ctx, hipHostMalloc(&ctx->stage[k], PK_STAGE_CHUNK_BYTES, hipHostMallocDefault));
-            ctx->stage_bytes[k] = PK_STAGE_CHUNK_BYTES;
-        } else {
-            PK_HIP(ctx, hipEventSynchronize(ctx->stage_ev[k]));  // previous DMA out of this buffer finished
-        }
+        int k;
+        if (int32_t rc = stage_acquire(ctx, &k)) return rc;
+        const double t0 = now_s();
         if (esz == 8) {
             const double* src[8];
             for (int c = 0; c < ncomp; c++) src[c] = (const double*)host_data[c] + off;
@@ -845,8 +805,8 @@ int32_t pk_field_upload_group_level(pk_ctx* ctx, int32_t leader_id, int32_t leve
             for (int c = 0; c < ncomp; c++) src[c] = (const float*)host_data[c] + off;
             parallel_interleave((float*)ctx->stage[k], src, ncomp, len);
         }
-        PK_HIP(ctx, hipMemcpyAsync(dst + off * esz * ncomp, ctx->stage[k], len * esz * ncomp, hipMemcpyHostToDevice, ctx->copy));
-        PK_HIP(ctx, hipEventRecord(ctx->stage_ev[k], ctx->copy));
+        ctx->stage_fill_s += now_s() - t0;
+        if (int32_t rc = stage_submit(ctx, k, dst + off * esz * ncomp, len * esz * ncomp)) return rc;
     }
     if (!async) PK_HIP(ctx, hipStreamSynchronize(ctx->copy));
     for (size_t f = 0; f < ctx->fields.size(); f++) {  // the leader and its followers change slot state together

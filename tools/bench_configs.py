@@ -281,6 +281,7 @@ def run_config(config="c3", scale=1.0, particles=1e7, steps=24, nt=4, nslots=3, 
             "particle_steps_per_s_wall_incl_h2d_d2h": st["steps"] / wall, "wall_s": wall,
             "remaining_particles": len(pset), "state_counts": st["state_counts"],
             "stream_host_s": {k: st.get(k) for k in ("commit_s", "prefetch_s", "wait_s")},
+            "upload_stats": fs._engine.ctx.upload_stats() if getattr(fs, "_engine", None) is not None else None,
             "dataset_generation_s": gen_s, "hash_build": hash, "host_hash_build_s": hash_s, "device_create_s": upload_s,
         }
         if check:
