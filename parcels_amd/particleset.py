@@ -24,7 +24,7 @@ def _convert_dt_to_float(dt):  # particleset.py:488-505
         dt = to_seconds(dt)
     dt = float(dt)
     if not np.isfinite(dt) or dt == 0:
-        raise ValueError(f"dt must be a non-zero finite number of seconds. Got {dt!r}")
+        raise ValueError(f"dt must be a non-zero datetime.timedelta or np.timedelta64 object, got {dt=!r}")
     return dt, (1 if dt > 0 else -1)
 
 
@@ -262,22 +262,25 @@ class ParticleSet:
     def _start_and_end_times(self, runtime, endtime, sign_dt):  # particleset.py:523-585
         ti = self.fieldset.time_interval
         if runtime is not None and endtime is not None:
-            raise ValueError(f"runtime and endtime are mutually exclusive. Got {runtime=!r}, {endtime=!r}")
+            raise ValueError(f"runtime and endtime are mutually exclusive - provide one or the other. Got {runtime=!r}, {endtime=!r}")
         if runtime is None and ti is None:
             raise ValueError("The runtime must be provided when the time_interval is not defined for a fieldset.")
         if runtime is None and endtime is None:
             raise ValueError("Either runtime or endtime must be provided.")
         rel = self._data["t"]
         first = rel.min() if sign_dt == 1 else rel.max()  # NaN-propagating like the reference: one unset release time => fieldset start
-        if endtime is not None:
-            if isinstance(endtime, np.datetime64) and ti is not None:
-                if not (ti.left <= endtime <= ti.right):
-                    raise ValueError(f"end time {endtime!r} is not in fieldset time interval {ti!r}")
-                endtime = to_seconds(endtime - ti.left)
-            elif isinstance(endtime, (np.timedelta64, datetime.timedelta)):
-                endtime = to_seconds(endtime)
-            else:
-                endtime = float(endtime)
+        if ti is not None and endtime is not None:
+            if type(endtime) != type(ti.left):  # noqa: E721
+                raise ValueError(f"The endtime must be of the same type as the fieldset.time_interval start time. Got {endtime=!r} with time_interval={ti!r}")
+            if endtime not in ti:
+                raise ValueError(
+                    f"Calculated/provided end time of {endtime!r} is not in fieldset time interval {ti!r}. Either reduce your runtime, modify your "
+                    "provided endtime, or change your release timing."
+                    "Important info:\n"
+                    f"    First particle release: {first!r}\n"
+                    f"    runtime: {runtime!r}\n"
+                    f"    (calculated) endtime: {endtime!r}")
+            endtime = to_seconds(endtime - ti.left)
         if sign_dt == 1:
             fieldset_start = 0.0
         else:

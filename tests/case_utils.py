@@ -156,6 +156,12 @@ class OutputRecorder:
         return False
 
 
+def endtime_of(seconds):
+    """Seconds since the start of a float-second time axis as the `endtime` ParticleSet.execute accepts: the type of
+    fieldset.time_interval.left (particleset.py:553-557), the way oracle/ref_shim.py hands it to the reference."""
+    return np.timedelta64(int(round(float(seconds) * 1e9)), "ns")
+
+
 def run_hip(case, endtime=None, nslots=None, async_output=None, **pset_kw):
     """Run a case through parcels_amd (HIP). Returns (soa dict, error name or None, stats).  nslots: stream the field levels
     through a ring of that many slots (None: the engine decides, i.e. resident for test-sized fields)."""
@@ -171,9 +177,9 @@ def run_hip(case, endtime=None, nslots=None, async_output=None, **pset_kw):
     kernels = [pa.SampleField(samples[k][0], into=samples[k][1]) if k in samples else getattr(pa.kernels, k) for k in case["kernels"]]
     kw = {}
     if endtime is not None:
-        kw["endtime"] = float(endtime)
+        kw["endtime"] = endtime_of(endtime)
     elif case.get("endtime") is not None:
-        kw["endtime"] = float(case["endtime"])
+        kw["endtime"] = endtime_of(case["endtime"])
     else:
         kw["runtime"] = float(case["runtime"])
     run_hip.last_recorder = None
@@ -199,7 +205,7 @@ def run_oracle(case, endtime=None, nthreads=1):
 
     c = dict(case)
     if endtime is not None:
-        c["endtime"] = float(endtime)
+        c["endtime"] = float(endtime_of(endtime) / np.timedelta64(1, "s"))  # what run_hip's execute derives from the same argument
         c["runtime"] = None
     if is_curvilinear(c) and "hash_table" not in c:
         attach_hash_table(c)

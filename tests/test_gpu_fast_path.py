@@ -9,7 +9,7 @@ from __future__ import annotations
 import numpy as np
 import pytest
 
-from case_utils import build_fieldset, build_pset, compare, run_oracle
+from case_utils import build_fieldset, build_pset, compare, endtime_of, run_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -24,7 +24,7 @@ def _run(case, fast, nslots=None, endtime=None):
     fs._engine.ctx.set_option("fast_path", 1 if fast else 0)
     pset = build_pset(case, fs)
     kernels = [getattr(pa.kernels, k) for k in case["kernels"]]
-    kw = {"endtime": float(endtime)} if endtime is not None else {"runtime": float(case["runtime"])}
+    kw = {"endtime": endtime_of(endtime)} if endtime is not None else {"runtime": float(case["runtime"])}
     err = None
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")

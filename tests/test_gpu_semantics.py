@@ -93,7 +93,7 @@ def test_execution_endtime(gpu, starttime, endtime, dt):
     """tests/test_particleset_execute.py:315-326: the last step is shortened to land exactly on endtime."""
     fs = pa.FieldSet.from_sgrid_conventions(simple_uv_dataset(mesh="flat", u=0.0), mesh="flat")
     pset = pa.ParticleSet(fs, x=[0.0], y=[0.0], t=[float(starttime)])
-    pset.execute(pa.AdvectionEE, endtime=float(endtime), dt=float(dt))
+    pset.execute(pa.AdvectionEE, endtime=np.timedelta64(endtime, "s"), dt=float(dt))
     assert pset.t[0] == float(endtime)
     assert pset.state[0] == pa.StatusCode.EndofLoop
 
@@ -102,13 +102,13 @@ def test_dont_run_particles_outside_starttime(gpu):
     """tests/test_particleset_execute.py:329-356: delayed release; a particle released after endtime is untouched."""
     fs = pa.FieldSet.from_sgrid_conventions(simple_uv_dataset(mesh="flat", u=1.0), mesh="flat")
     pset = pa.ParticleSet(fs, x=np.zeros(3), y=np.zeros(3), t=np.array([0.0, 2.0, 10.0]))
-    pset.execute(pa.AdvectionEE, dt=1.0, endtime=8.0)
+    pset.execute(pa.AdvectionEE, dt=1.0, endtime=np.timedelta64(8, "s"))
     np.testing.assert_allclose(pset.x, [8, 6, 0], atol=1e-6)
     assert pset.t[0] == 8.0 and pset.t[1] == 8.0 and pset.t[2] == 10.0
     assert pset.state[2] == pa.StatusCode.Evaluate  # never evaluated (kernel.py:193-197)
     tl = fs.time_interval.time_length_as_flt
     pset = pa.ParticleSet(fs, x=np.zeros(3), y=np.zeros(3), t=tl - np.array([0.0, 2.0, 10.0]))
-    pset.execute(pa.AdvectionEE, dt=-1.0, endtime=tl - 8.0)
+    pset.execute(pa.AdvectionEE, dt=-1.0, endtime=fs.time_interval.right - np.timedelta64(8, "s"))
     np.testing.assert_allclose(pset.x, [-8, -6, 0], atol=1e-6)
     assert pset.t[2] == tl - 10.0
 
@@ -377,8 +377,8 @@ def test_run_rk_to_endtime_forward_and_backward(gpu, kernel, dt_days):
     T = 366 * 86400.0
     pset = pa.ParticleSet(fs, pclass=pclass, x=[0.2], y=[5.0], t=[0.0])
     k = getattr(pa.kernels, kernel)
-    pset.execute(k, endtime=T, dt=np.timedelta64(dt_days, "D"))
+    pset.execute(k, endtime=fs.time_interval.right, dt=np.timedelta64(dt_days, "D"))
     assert pset.t[0] == T
-    pset.execute(k, endtime=0.0, dt=-np.timedelta64(dt_days, "D"))
+    pset.execute(k, endtime=fs.time_interval.left, dt=-np.timedelta64(dt_days, "D"))
     assert pset.t[0] == 0.0
     assert pset.x[0] == np.float32(0.2) and pset.y[0] == np.float32(5.0)
