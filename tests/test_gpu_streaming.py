@@ -6,7 +6,7 @@ from __future__ import annotations
 import numpy as np
 import pytest
 
-from case_utils import build_fieldset, build_pset, compare
+from case_utils import build_fieldset, build_pset, compare, endtime_of
 
 pytestmark = pytest.mark.gpu
 
@@ -34,11 +34,11 @@ def test_one_windowed_fieldset_serves_forward_restart_and_backward_runs(gpu):
         b = build_pset(case, fs)  # second release at t = 0 after the ring moved to the end of the time axis
         b.execute(pa.AdvectionRK4, dt=case["dt"], runtime=2.5 * 86400.0)
         c = build_pset(dict(case, t0=np.full(len(case["x"]), tend)), fs)
-        c.execute(pa.AdvectionRK4, dt=-case["dt"], endtime=tend - 6.2 * 86400.0)
+        c.execute(pa.AdvectionRK4, dt=-case["dt"], endtime=endtime_of(tend - 6.2 * 86400.0))
         # particles far apart in time inside ONE set: early ones finish (deleted by endtime semantics = EndofLoop), late ones start later
         t0 = np.where(np.arange(len(case["x"])) % 2 == 0, 0.0, 6.0 * 86400.0)
         d = build_pset(dict(case, t0=t0), fs)
-        d.execute(pa.AdvectionRK4, dt=case["dt"], endtime=7.8 * 86400.0)
+        d.execute(pa.AdvectionRK4, dt=case["dt"], endtime=endtime_of(7.8 * 86400.0))
         out[tag] = [_soa(p) for p in (a, b, c, d)]
         if tag == "win":
             assert all(p._last_stats["launches"] > 1 for p in (a, c, d)), "the ring was not exercised"
