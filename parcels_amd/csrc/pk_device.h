@@ -715,6 +715,36 @@ PK_DEV bool take_first_eval(PCtx& c, int g) {
     return f;
 }
 
+// what follows the search proper: the ravelled `ei` (xgrid.py:349-356), the hints of the next search on the main grid, and the
+// state update of field.py:307-356
+PK_DEV void grid_search_finish(const DGrid& g, bool hint, bool curv, int32_t* ei, PCtx& c, const GPos& p) {
+    const int64_t rav = ravel_ei(g, p.zi, p.yi, p.xi);
+    *ei = (int32_t)rav;
+    if (hint) {
+        c.hz = p.zi; c.hy = p.yi; c.hx = p.xi;
+        c.hyx_valid = curv && p.zi >= 0 && p.yi >= 0 && p.xi >= 0 && rav == (int64_t)*ei;
+    }
+    int s = c.state;
+    if (p.xi == -1 && s < PK_ERROROUTOFBOUNDS) s = PK_ERROROUTOFBOUNDS;
+    if (p.xi == GRID_SEARCH_ERROR && s < PK_ERRORGRIDSEARCHING) s = PK_ERRORGRIDSEARCHING;
+    if (p.yi == -1 && s < PK_ERROROUTOFBOUNDS) s = PK_ERROROUTOFBOUNDS;
+    if (p.yi == GRID_SEARCH_ERROR && s < PK_ERRORGRIDSEARCHING) s = PK_ERRORGRIDSEARCHING;
+    if (p.zi == RIGHT_OUT_OF_BOUNDS && s < PK_ERROROUTOFBOUNDS) s = PK_ERROROUTOFBOUNDS;
+    if (p.zi == LEFT_OUT_OF_BOUNDS && s < PK_ERRORTHROUGHSURFACE) s = PK_ERRORTHROUGHSURFACE;
+    c.state = s;
+}
+
+// The grid position the velocity sample of a kernel found, kept for the scalar samples the same kernel takes at the SAME point of
+// the SAME grid (AdvectionDiffusionM1 / EM read Kh_zonal and Kh_meridional at the particle position after UV,
+// _advectiondiffusion.py:44-62).  The reference searches again, starting from the cell the previous sample left in `ei`; a search
+// that starts in the cell containing the point returns that cell and the same (xsi, eta) (index_search.py:269-285), so re-using the
+// result IS the reference's result -- except for the float32 (xsi, eta) of an unguessed first evaluation (GPos::w32), which a second,
+// guessed search would replace by float64 values: those are never re-used.
+struct SearchMemo {
+    GPos p;
+    int grid;  // -1: nothing to re-use
+};
+
 // XGrid.search (xgrid.py:316-356) + ei write + state update (field.py:307-356)
 // KIND: 0 rectilinear, 1 curvilinear, -1 decide at run time (scalar fields on secondary grids)
 // TYPED: some grid of the fieldset stores a coordinate as float32, so NumPy's float32 arithmetic on coordinate / barycentric
@@ -750,20 +780,7 @@ PK_DEV void grid_search(const DGrid& g, const Coords* mc, double z, double y, do
         if (g.has_x) search_1d(lon, g.nx, mc ? mc->x0 : g.lon[0], mc ? mc->x1 : g.lon[g.nx - 1], x, xf32, pos_f32, hint ? c.hx : 0, p.xi, p.xsi);
         else { p.xi = 0; p.xsi = 0.0; }
     }
-    const int64_t rav = ravel_ei(g, p.zi, p.yi, p.xi);
-    *ei = (int32_t)rav;
-    if (hint) {
-        c.hz = p.zi; c.hy = p.yi; c.hx = p.xi;
-        c.hyx_valid = curv && p.zi >= 0 && p.yi >= 0 && p.xi >= 0 && rav == (int64_t)*ei;
-    }
-    int s = c.state;
-    if (p.xi == -1 && s < PK_ERROROUTOFBOUNDS) s = PK_ERROROUTOFBOUNDS;
-    if (p.xi == GRID_SEARCH_ERROR && s < PK_ERRORGRIDSEARCHING) s = PK_ERRORGRIDSEARCHING;
-    if (p.yi == -1 && s < PK_ERROROUTOFBOUNDS) s = PK_ERROROUTOFBOUNDS;
-    if (p.yi == GRID_SEARCH_ERROR && s < PK_ERRORGRIDSEARCHING) s = PK_ERRORGRIDSEARCHING;
-    if (p.zi == RIGHT_OUT_OF_BOUNDS && s < PK_ERROROUTOFBOUNDS) s = PK_ERROROUTOFBOUNDS;
-    if (p.zi == LEFT_OUT_OF_BOUNDS && s < PK_ERRORTHROUGHSURFACE) s = PK_ERRORTHROUGHSURFACE;
-    c.state = s;
+    grid_search_finish(g, hint, curv, ei, c, p);
 }
 
 // _search_time_index (index_search.py:65-91). false => OutsideTimeInterval
@@ -1373,7 +1390,7 @@ PK_DEV double finish_value(PCtx& c, const GPos& p, double v) { return finish_val
 // straight from float32 particle storage (NumPy then evaluates cos(lat) in float32).
 template <class FT, int KIND, int INTERP, bool TYPED>
 PK_DEV void eval_uvw(const KArgs& a, const Coords& mc, PCtx& c, bool want_w, double t, double z, double y,
-                     double x, bool pos_f32, double& u, double& v, double& w) {
+                     double x, bool pos_f32, double& u, double& v, double& w, SearchMemo* memo = nullptr) {
     const DField& U = a.fields[a.prm.fU];
     const DField& V = a.fields[a.prm.fV];
     const DGrid& g = a.grids[U.grid];
@@ -1389,6 +1406,10 @@ PK_DEV void eval_uvw(const KArgs& a, const Coords& mc, PCtx& c, bool want_w, dou
     int32_t ei = ei_get(c, U.grid);
     grid_search<KIND, TYPED>(g, &mc, z, y, x, pos_f32, &ei, c, use_guess, p);
     ei_set(c, U.grid, ei);
+    if (memo) {
+        memo->p = p;
+        memo->grid = p.w32 ? -1 : U.grid;
+    }
     const int flags = oob_flags(p);
     const bool oob = flags & 1;
     double uu = 0, vv = 0, ww = 0;
@@ -1428,7 +1449,7 @@ PK_DEV void eval_uvw(const KArgs& a, const Coords& mc, PCtx& c, bool want_w, dou
 // Field.eval for a scalar field (field.py:145-195): XLinear or XConstantField
 template <class FT, bool TYPED>
 PK_DEV double eval_scalar(const KArgs& a, const Coords& mc, PCtx& c, int fidx, double t, double z, double y,
-                          double x, bool pos_f32) {
+                          double x, bool pos_f32, const SearchMemo* memo = nullptr) {
     const DField& f = a.fields[fidx];
     const DGrid& g = a.grids[f.grid];
     const bool on_main = (f.grid == a.main_grid);
@@ -1440,7 +1461,16 @@ PK_DEV double eval_scalar(const KArgs& a, const Coords& mc, PCtx& c, int fidx, d
     }
     const bool use_guess = take_first_eval(c, f.grid) ? (a.prm.have_guess0 != 0) : true;
     int32_t ei = ei_get(c, f.grid);
-    grid_search<-1, TYPED>(g, on_main ? &mc : nullptr, z, y, x, pos_f32, &ei, c, use_guess, p);
+    if (memo && memo->grid == f.grid) {  // (t, z, y, x) is the point of the kernel's velocity sample: see SearchMemo
+        const int ti = p.ti;
+        const double tau = p.tau;
+        p = memo->p;
+        p.ti = ti;
+        p.tau = tau;
+        grid_search_finish(g, on_main, g.kind == 1, &ei, c, p);
+    } else {
+        grid_search<-1, TYPED>(g, on_main ? &mc : nullptr, z, y, x, pos_f32, &ei, c, use_guess, p);
+    }
     ei_set(c, f.grid, ei);
     double v = 0.0;
     if (!(p.xi < 0 || p.yi < 0 || p.zi < 0)) {

@@ -42,7 +42,8 @@ enum { RQ_UV = 0, RQ_UVW = 1, RQ_SCALAR = 2 };
 struct Request {
     int kind, fidx;
     double t, z, y, x;
-    bool f32;  // sample point comes straight from float32 particle storage
+    bool f32;    // sample point comes straight from float32 particle storage
+    bool reuse;  // scalar sample at the point of this kernel's velocity sample: the grid position may be re-used (SearchMemo)
 };
 
 // kernel-local registers (all indices are compile-time constants -> scalar-replaced into VGPRs)
@@ -83,6 +84,7 @@ PK_DEV bool prepare(const KArgs& a, int kid, int stage, int kslot, PCtx& c, PSta
     rq.kind = RQ_UV;
     rq.fidx = 0;
     rq.f32 = false;
+    rq.reuse = false;
     rq.t = p.t; rq.z = p.z; rq.y = p.y; rq.x = p.x;
     switch (kid) {
         case PK_KERNEL_ADVECTION_RK4:
@@ -195,10 +197,10 @@ PK_DEV bool prepare(const KArgs& a, int kid, int stage, int kslot, PCtx& c, PSta
                 case 0: rq.kind = RQ_SCALAR; rq.fidx = prm.fKh_zonal; rq.x = padd(pf, p.x, dres); return false;
                 case 1: rq.kind = RQ_SCALAR; rq.fidx = prm.fKh_zonal; rq.x = psub(pf, p.x, dres); return false;
                 case 2: rq.kind = RQ_UV; return false;
-                case 3: rq.kind = RQ_SCALAR; rq.fidx = prm.fKh_zonal; return false;
+                case 3: rq.kind = RQ_SCALAR; rq.fidx = prm.fKh_zonal; rq.reuse = true; return false;
                 case 4: rq.kind = RQ_SCALAR; rq.fidx = prm.fKh_meridional; rq.y = padd(pf, p.y, dres); return false;
                 case 5: rq.kind = RQ_SCALAR; rq.fidx = prm.fKh_meridional; rq.y = psub(pf, p.y, dres); return false;
-                case 6: rq.kind = RQ_SCALAR; rq.fidx = prm.fKh_meridional; return false;
+                case 6: rq.kind = RQ_SCALAR; rq.fidx = prm.fKh_meridional; rq.reuse = true; return false;
                 default: break;
             }
             const DGrid& gz = a.grids[a.fields[prm.fKh_zonal].grid];
@@ -472,13 +474,19 @@ __global__ void __launch_bounds__(wg_size(KIND, LDS), (KIND == 1 || INTERP != 0)
                         KLocal L;
                         L.u1f = L.v1f = false;
                         Request rq;
+                        // the kernels that sample scalars at the point of their velocity sample: AdvectionDiffusionM1 has its own
+                        // program (KID), AdvectionDiffusionEM runs in the kernel-list interpreter (KID < 0)
+                        constexpr bool MEMO = KID == PK_KERNEL_ADVECTIONDIFFUSION_M1 || KID < 0;
+                        SearchMemo memo;
+                        memo.grid = -1;
                         attempts++;
                         for (int stage = 0; !prepare(a, kid, stage, k, c, p, L, rq); stage++) {
                             double u, v = 0.0, w = 0.0;
                             if (rq.kind == RQ_SCALAR) {
-                                u = eval_scalar<FT, TYPED>(a, mc, c, rq.fidx, rq.t, rq.z, rq.y, rq.x, rq.f32);
+                                u = eval_scalar<FT, TYPED>(a, mc, c, rq.fidx, rq.t, rq.z, rq.y, rq.x, rq.f32, (MEMO && rq.reuse) ? &memo : nullptr);
                             } else {
-                                eval_uvw<FT, KIND, INTERP, TYPED>(a, mc, c, rq.kind == RQ_UVW, rq.t, rq.z, rq.y, rq.x, rq.f32, u, v, w);
+                                const bool keep = MEMO && (kid == PK_KERNEL_ADVECTIONDIFFUSION_M1 || kid == PK_KERNEL_ADVECTIONDIFFUSION_EM);
+                                eval_uvw<FT, KIND, INTERP, TYPED>(a, mc, c, rq.kind == RQ_UVW, rq.t, rq.z, rq.y, rq.x, rq.f32, u, v, w, keep ? &memo : nullptr);
                             }
                             consume(kid, stage, c, L, u, v, w);
                         }
