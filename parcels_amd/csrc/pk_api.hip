@@ -1280,17 +1280,18 @@ static int32_t fill_args(pk_ctx* ctx, const pk_exec_params* prm, KArgs& a, size_
     lds_bytes = (size_t)std::max(a.lds_total, 1) * sizeof(double);
     use_lds = lds_bytes <= 64 * 1024;
     if (!use_lds) lds_bytes = 0;
-    // per-lane cell cache of curvilinear grids (pk_device.h: CellCache): 20 node doubles + 4 key ints per lane, plus the
+    // per-lane cell cache of curvilinear grids (pk_device.h: CellCache): CC_NODE_ROWS doubles + 4 key ints per lane, plus the
     // 12 staggered field values of a C-grid evaluation when they still fit the 64 KiB of a workgroup
     a.lds_cc_nodes = a.lds_cc_keys = a.lds_cc_fvals = -1;
     const bool want_cc = use_lds && mg.d.kind == 1 && !ctx->no_cell_cache && (int64_t)mg.d.ny * mg.d.nx < INT32_MAX;
     if (want_cc) {
-        const size_t node_b = 20 * CC_LANES * sizeof(double), key_b = 4 * CC_LANES * sizeof(int32_t);
+        const size_t node_b = CC_NODE_ROWS * CC_LANES * sizeof(double), key_b = 4 * CC_LANES * sizeof(int32_t);
         const size_t fval_b = 12 * CC_LANES * (size_t)(mf.desc.dtype == PK_F32 ? 4 : 8);
         if (lds_bytes + node_b + key_b <= 64 * 1024) {
             a.lds_cc_nodes = a.lds_total;
-            a.lds_cc_keys = a.lds_cc_nodes + 20 * CC_LANES;
+            a.lds_cc_keys = a.lds_cc_nodes + CC_NODE_ROWS * CC_LANES;
             int32_t end = a.lds_cc_keys + (int32_t)(key_b / sizeof(double));
+            // (A/B on config 3: without the cached field values the RK4_3D launch takes 96.6 ms instead of 66.3 ms)
             if (prm->interp_uv == 1 && (size_t)end * sizeof(double) + fval_b <= 64 * 1024) {
                 a.lds_cc_fvals = end;
                 end += (int32_t)(fval_b / sizeof(double));

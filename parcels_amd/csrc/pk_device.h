@@ -267,9 +267,13 @@ PK_DEV NV nv_sqrt(NV a) { return a.dt == 1 ? NV{(double)sqrtf((float)a.v), 1} : 
 #define PK_WG_CURV 64
 #endif
 constexpr int CC_LANES = PK_WG_CURV;
+constexpr int CC_NODE_ROWS = 22;
 __host__ __device__ constexpr inline int wg_size(int kind, bool lds) { return (kind == 1 && lds) ? PK_WG_CURV : 256; }
 struct CellCache {
-    double* nodes;  // [20][256]: corner c (0 (yi,xi), 1 (yi,xi+1), 2 (yi+1,xi+1), 3 (yi+1,xi)), component m -> (c*5+m)
+    // [CC_NODE_ROWS][CC_LANES]: rows 0..7 {lon, lat} of corner c (0 (yi,xi), 1 (yi,xi+1), 2 (yi+1,xi+1), 3 (yi+1,xi)) at 2c, 2c+1;
+    // spherical meshes: rows 8..10 eu, 11..13 ev (the cell's tangent-plane basis), 14..17 / 18..21 the corners projected on it
+    // (spherical_project_cell: everything of _spherical_project_cell_and_query that does not depend on the query point)
+    double* nodes;
     int* key;       // [4][256]: node cell yi*nx+xi | field cell yi*nx+xi | zi | 4*ti + 2*(W cached) + (level ti+1 cached);  -1 = empty
     void* fvals;    // [12][256] of the field dtype: Ua,Ub,Va,Vb,Wa,Wb at level ti, then at level ti+1 (NULL: not cached)
 };
@@ -456,15 +460,15 @@ PK_DEV QPoint make_qpoint(const DGrid& g, double y, double x) {
 // _spherical_project_cell_and_query (index_search.py:180-239).  cX,cY,cZ: unit-sphere coordinates of the 4 corners
 // (index_search.py:197-198), read from the per-node table that the host computed once with the reference's own
 // expression (cos(lon)cos(lat), sin(lon)cos(lat), sin(lat)) instead of 8 sin/cos pairs per evaluation.
-PK_DEV void spherical_project(const double cX[4], const double cY[4], const double cZ[4], const QPoint& q, double pu[4],
-                              double pv[4], double& xq, double& yq) {
+PK_DEV void spherical_project_cell(const double cX[4], const double cY[4], const double cZ[4], double eu[3], double ev[3], double pu[4],
+                                   double pv[4]) {
     double ux = (cX[1] + cX[2]) - (cX[0] + cX[3]);
     double uy = (cY[1] + cY[2]) - (cY[0] + cY[3]);
     double uz = (cZ[1] + cZ[2]) - (cZ[0] + cZ[3]);
     double un = sqrt(ux * ux + uy * uy + uz * uz);
     if (un == 0.0) un = 1.0;
     const Recip run = make_recip(un);
-    double eux = div_shared(ux, run), euy = div_shared(uy, run), euz = div_shared(uz, run);
+    const double eux = div_shared(ux, run), euy = div_shared(uy, run), euz = div_shared(uz, run);
     double vx = (cX[2] + cX[3]) - (cX[0] + cX[1]);
     double vy = (cY[2] + cY[3]) - (cY[0] + cY[1]);
     double vz = (cZ[2] + cZ[3]) - (cZ[0] + cZ[1]);
@@ -475,14 +479,19 @@ PK_DEV void spherical_project(const double cX[4], const double cY[4], const doub
     double vn = sqrt(vx * vx + vy * vy + vz * vz);
     if (vn == 0.0) vn = 1.0;
     const Recip rvn = make_recip(vn);
-    double evx = div_shared(vx, rvn), evy = div_shared(vy, rvn), evz = div_shared(vz, rvn);
+    const double evx = div_shared(vx, rvn), evy = div_shared(vy, rvn), evz = div_shared(vz, rvn);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         pu[k] = cX[k] * eux + cY[k] * euy + cZ[k] * euz;
         pv[k] = cX[k] * evx + cY[k] * evy + cZ[k] * evz;
     }
-    xq = q.qX * eux + q.qY * euy + q.qZ * euz;
-    yq = q.qX * evx + q.qY * evy + q.qZ * evz;
+    eu[0] = eux; eu[1] = euy; eu[2] = euz;
+    ev[0] = evx; ev[1] = evy; ev[2] = evz;
+}
+// the query point on the cell's tangent plane
+PK_DEV void spherical_project_query(const double eu[3], const double ev[3], const QPoint& q, double& xq, double& yq) {
+    xq = q.qX * eu[0] + q.qY * eu[1] + q.qZ * eu[2];
+    yq = q.qX * ev[0] + q.qY * ev[1] + q.qZ * ev[2];
 }
 
 // ---- Morton spatial hash query (spatialhash.py:389-535, 554-597, 647-765) ------------------------------
@@ -529,20 +538,25 @@ PK_DEV bool point_in_cell(const DGrid& g, const QPoint& q, int yi, int xi, doubl
     const int cell = yi * g.nx + xi;
     const bool hit = use_cc && cc->key[0] == cell;
     double* nd = use_cc ? cc->nodes : nullptr;
-#define PK_ND(c_, m_) nd[((c_) * 5 + (m_)) * CC_LANES]
+#define PK_ND(c_, m_) nd[((c_) * 2 + (m_)) * CC_LANES]
     if (g.spherical) {
-        double cX[4], cY[4], cZ[4], pu[4], pv[4], xq, yq;
+        double eu[3], ev[3], pu[4], pv[4], xq, yq;
         // corner order c0=(yi,xi) c1=(yi,xi+1) c2=(yi+1,xi+1) c3=(yi+1,xi)
-        if (hit) {
+        if (hit && !listed) {  // the cell of the previous evaluation: its basis and projected corners are in the lane's cache
 #pragma unroll
-            for (int k = 0; k < 4; k++) { cX[k] = PK_ND(k, 2); cY[k] = PK_ND(k, 3); cZ[k] = PK_ND(k, 4); }
+            for (int k = 0; k < 3; k++) { eu[k] = nd[(8 + k) * CC_LANES]; ev[k] = nd[(11 + k) * CC_LANES]; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) { pu[k] = nd[(14 + k) * CC_LANES]; pv[k] = nd[(18 + k) * CC_LANES]; }
         } else {
+            double cX[4], cY[4], cZ[4];
             double lon1, lat1, lon2, lat2;
             ldpair(r0 + 2, cX[0], cY[0]); ldpair(r0 + 4, cZ[0], lon1);
             ldpair(r0 + 6, lat1, cX[1]);  ldpair(r0 + 8, cY[1], cZ[1]);
             ldpair(r1 + 2, cX[3], cY[3]); ldpair(r1 + 4, cZ[3], lon2);
             ldpair(r1 + 6, lat2, cX[2]);  ldpair(r1 + 8, cY[2], cZ[2]);
-            if (use_cc) {  // the cached cell (the failed guess) is replaced; the key is set once the point is inside
+            if (listed) *listed = in_quantised_box(g, cX, q.qX, 0) && in_quantised_box(g, cY, q.qY, 2) && in_quantised_box(g, cZ, q.qZ, 4);
+            spherical_project_cell(cX, cY, cZ, eu, ev, pu, pv);
+            if (use_cc && !hit) {  // the cached cell (the failed guess) is replaced; the key is set once the point is inside
                 double lon0, lat0, lon3, lat3;
                 ldpair(r0, lon0, lat0);
                 ldpair(r1, lon3, lat3);
@@ -550,11 +564,12 @@ PK_DEV bool point_in_cell(const DGrid& g, const QPoint& q, int yi, int xi, doubl
                 PK_ND(0, 0) = lon0; PK_ND(0, 1) = lat0; PK_ND(1, 0) = lon1; PK_ND(1, 1) = lat1;
                 PK_ND(2, 0) = lon2; PK_ND(2, 1) = lat2; PK_ND(3, 0) = lon3; PK_ND(3, 1) = lat3;
 #pragma unroll
-                for (int k = 0; k < 4; k++) { PK_ND(k, 2) = cX[k]; PK_ND(k, 3) = cY[k]; PK_ND(k, 4) = cZ[k]; }
+                for (int k = 0; k < 3; k++) { nd[(8 + k) * CC_LANES] = eu[k]; nd[(11 + k) * CC_LANES] = ev[k]; }
+#pragma unroll
+                for (int k = 0; k < 4; k++) { nd[(14 + k) * CC_LANES] = pu[k]; nd[(18 + k) * CC_LANES] = pv[k]; }
             }
         }
-        if (listed) *listed = in_quantised_box(g, cX, q.qX, 0) && in_quantised_box(g, cY, q.qY, 2) && in_quantised_box(g, cZ, q.qZ, 4);
-        spherical_project(cX, cY, cZ, q, pu, pv, xq, yq);
+        spherical_project_query(eu, ev, q, xq, yq);
         bilinear_inverse(pu, pv, xq, yq, xsi, eta);
     } else {
         double clon[4], clat[4];
@@ -1156,7 +1171,7 @@ PK_DEV void cgrid_velocity(const DGrid& g, const Coords* mc, const DField& U, co
     } else if (cc_on && mc->cc.key[0] == cell) {  // the search that found (yi, xi) left its corner nodes in the lane's LDS cache
         const double* nd = mc->cc.nodes;
 #pragma unroll
-        for (int k = 0; k < 4; k++) { px[k] = nd[(k * 5 + 0) * CC_LANES]; py[k] = nd[(k * 5 + 1) * CC_LANES]; }
+        for (int k = 0; k < 4; k++) { px[k] = nd[(k * 2 + 0) * CC_LANES]; py[k] = nd[(k * 2 + 1) * CC_LANES]; }
     } else {
         const double* r0 = g.node_tab + ((int64_t)yi * g.nx + xi) * 5;  // same lines the point-in-cell test just read
         const double* r1 = r0 + (int64_t)g.nx * 5;

@@ -697,9 +697,21 @@ void launch_fast(int field_f32, int particles_f32, const KArgs& a, dim3 grid, si
         }                                                                                                               \
     }
 
+// PK_PRINT_OCCUPANCY=1: what the runtime will co-schedule of the chosen instantiation (workgroups per CU at this LDS size)
+inline bool print_occupancy() {
+    static const bool v = getenv("PK_PRINT_OCCUPANCY") != nullptr;
+    return v;
+}
 #define PK_LAUNCH_CASE(FT, KD, IN, LD)                                                                                          \
-    hipLaunchKernelGGL((advect_kernel<FT, KD, IN, KIDV, LD, TYPEDV>), dim3((unsigned)((a.p.n + wg_size(KD, LD) - 1) / wg_size(KD, LD))), \
-                       dim3(wg_size(KD, LD)), lds_bytes, stream, a)
+    do {                                                                                                                        \
+        if (print_occupancy()) {                                                                                                \
+            int nb = 0;                                                                                                         \
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, advect_kernel<FT, KD, IN, KIDV, LD, TYPEDV>, wg_size(KD, LD), lds_bytes); \
+            fprintf(stderr, "[pk] advect_kernel<%s,kind %d,interp %d,kid %d> wg %d lds %zu B: %d workgroups / CU\n", sizeof(FT) == 4 ? "f32" : "f64", KD, IN, KIDV, wg_size(KD, LD), (size_t)lds_bytes, nb); \
+        }                                                                                                                       \
+        hipLaunchKernelGGL((advect_kernel<FT, KD, IN, KIDV, LD, TYPEDV>), dim3((unsigned)((a.p.n + wg_size(KD, LD) - 1) / wg_size(KD, LD))), \
+                           dim3(wg_size(KD, LD)), lds_bytes, stream, a);                                                        \
+    } while (0)
 
 // single-kernel programs require LDS staging (the host falls back to the generic program otherwise)
 // interp: 0 XLinear_Velocity, 1 CGrid_Velocity, 2 slip (XFreeslip / XPartialslip, told apart by prm.interp_uv)
