@@ -80,7 +80,19 @@ def create_particle_data(*, pclass: ParticleClass, nparticles: int, ngrids: int,
             raise ValueError(f"Initial value for {name} must have shape ({nparticles},). Got {values.shape=}")
         initial[name] = np.ascontiguousarray(values.astype(variables[name].dtype))
     data = {"ei": np.zeros((nparticles, ngrids), dtype=np.int32), **initial}
+    import operator
+
     for v in variables.values():
         if v.name not in data:
-            data[v.name] = np.full((nparticles,), v.initial, dtype=v.dtype)
+            if isinstance(v.initial, operator.attrgetter):  # particle.py:213-216: Variable("x0", initial=attrgetter("x"))
+                data[v.name] = data[v.initial(_AttrName())].copy().astype(v.dtype)
+            else:
+                data[v.name] = np.full((nparticles,), v.initial, dtype=v.dtype)
     return data
+
+
+class _AttrName:
+    """attrgetter("x")(_AttrName()) == "x" (the reference's _compat._attrgetter_helper)."""
+
+    def __getattr__(self, name):
+        return name

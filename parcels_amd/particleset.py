@@ -48,6 +48,25 @@ def _warn_particle_times_outside_fieldset_time_bounds(release_times, time_interv
         warnings.warn("Some particles are set to be released outside the FieldSet's executable time domain.", ParticleSetWarning, stacklevel=3)
 
 
+class ParticleSetView:
+    """Attribute access to one row (or an index selection) of the SoA columns."""
+
+    def __init__(self, data, index):
+        object.__setattr__(self, "_data", data)
+        object.__setattr__(self, "_index", index)
+
+    def __getattr__(self, name):
+        try:
+            return self._data[name][self._index]
+        except KeyError as e:
+            raise AttributeError(name) from e
+
+    def __setattr__(self, name, value):
+        if name not in self._data:
+            raise AttributeError(f"particles have no Variable {name!r}")
+        self._data[name][self._index] = value
+
+
 class ParticleSet:
     """Collection of particles stored as a dict of NumPy columns (particle.py:182-222).
 
@@ -141,6 +160,41 @@ class ParticleSet:
 
     def __len__(self):
         return len(self._data["particle_id"])
+
+    def __iter__(self):  # particleset.py:143-153
+        self._index = 0
+        return self
+
+    def __next__(self):
+        if self._index < len(self):
+            p = self[self._index]
+            self._index += 1
+            return p
+        raise StopIteration
+
+    def __getitem__(self, index):
+        """One particle (or a sub-selection) by index: attribute reads and writes go to the set's columns (the part of the
+        reference's ParticleSetView, particlesetview.py:17-96, that user code outside kernels relies on)."""
+        return ParticleSetView(self._data, index)
+
+    def add(self, particles):  # particleset.py:186-225
+        """Append the particles of another ParticleSet; their ids continue after the largest id of this set."""
+        assert particles is not None, f"Trying to add another {type(self)} to this one, but the other one is None - invalid operation."
+        assert type(particles) is type(self)
+        if len(particles) == 0:
+            return
+        if len(self) == 0:
+            self._data = particles._data
+            return
+        offset = self._data["particle_id"].max() + 1
+        particles._data["particle_id"] = particles._data["particle_id"] + offset
+        for d in self._data:
+            self._data[d] = np.concatenate((self._data[d], particles._data[d]))
+        return self
+
+    def __iadd__(self, particles):
+        self.add(particles)
+        return self
 
     @property
     def size(self):
