@@ -84,10 +84,12 @@ def main():
     ap.add_argument("--particles", type=float, default=1e7)
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--evals-per-step", type=int, default=4)
+    ap.add_argument("--no-latest", action="store_true", help="do not rewrite profiles/pmc_latest.json (passes of tools/gpu_profile_cfg.sh: C3 / C5, not the bench workload)")
+    ap.add_argument("--psteps", type=float, default=0, help="particle-steps of the profiled launch when it is not particles x steps (deleted particles)")
     a = ap.parse_args()
     g = os.path.join(ROOT, "gpurun_out", a.tag + "_")
     npart, K = int(a.particles), a.steps
-    psteps = npart * K
+    psteps = int(a.psteps) if a.psteps else npart * K
     wave_evals = psteps * a.evals_per_step / 64
     c = {}
     meta = {}
@@ -123,7 +125,8 @@ def main():
     }
     if fetch_b is not None and write_b is not None:
         out["traffic_bytes_per_launch"] = fetch_b + write_b
-    json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1)
+    if not a.no_latest:
+        json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1)
     L = [f"# PMC counters of the timed advection launch ({a.tag}): {npart} particles x {K} steps", "",
          f"kernel `{meta.get('kernel', '?')[:120]}`: arch VGPR {meta.get('vgpr')} (+{meta.get('accum_vgpr')} acc), SGPR {meta.get('sgpr')}, LDS {meta.get('lds')} B, scratch {meta.get('scratch')} B/lane", "",
          "| counter | value | per wave-evaluation |", "|---|---|---|"]
@@ -135,13 +138,15 @@ def main():
           f"* wave-cycle split: waiting on memory / LDS (SQ_WAIT_ANY) {c.get('SQ_WAIT_ANY', 0) / max(c.get('SQ_WAVE_CYCLES', 1), 1):.2f}, issue stall (SQ_WAIT_INST_ANY) "
           f"{c.get('SQ_WAIT_INST_ANY', 0) / max(c.get('SQ_WAVE_CYCLES', 1), 1):.2f}, issuing (SQ_ACTIVE_INST_ANY) {c.get('SQ_ACTIVE_INST_ANY', 0) / max(c.get('SQ_WAVE_CYCLES', 1), 1):.2f}"]
     if fetch_b is not None and write_b is not None:
-        L += [f"* copy_kernel calibration (1 GiB in + 1 GiB out per dispatch): FETCH_SIZE {copy.get('FETCH_SIZE')} KiB -> x{f_cal:.4f}, WRITE_SIZE {copy.get('WRITE_SIZE')} KiB -> x{w_cal:.4f}",
+        cal = (f"copy_kernel calibration (1 GiB in + 1 GiB out per dispatch): FETCH_SIZE {copy.get('FETCH_SIZE')} KiB -> x{f_cal:.4f}, WRITE_SIZE {copy.get('WRITE_SIZE')} KiB -> x{w_cal:.4f}"
+               if f_cal and w_cal else "no copy kernel in this run: FETCH_SIZE x2, WRITE_SIZE x1 as calibrated on the bench passes of the same binary (r02_g_c2_pmc.md)")
+        L += [f"* {cal}",
               f"* HBM traffic of the launch: fetch {fetch_b / 1e9:.3f} GB + write {write_b / 1e9:.3f} GB = {(fetch_b + write_b) / 1e9:.3f} GB = "
-              f"**{(fetch_b + write_b) / psteps:.1f} B per particle-step** (algorithmic model of SURVEY 8d: 1112 B, served by L2 / Infinity Cache)"]
+              f"**{(fetch_b + write_b) / psteps:.1f} B per particle-step** (algorithmic model of SURVEY 8d for C2: 1112 B, served by L2 / Infinity Cache)"]
     open(os.path.join(ROOT, "profiles", a.name + "_pmc.md"), "w").write("\n".join(L) + "\n")
-    bj = g + "bench.json"
-    if os.path.exists(bj):
-        open(os.path.join(ROOT, "profiles", a.name + "_bench.json"), "w").write(open(bj).read())
+    for suffix in ("bench.json", "run.json"):
+        if os.path.exists(g + suffix):
+            open(os.path.join(ROOT, "profiles", a.name + "_" + suffix), "w").write(open(g + suffix).read())
     print("\n".join(L))
 
 
