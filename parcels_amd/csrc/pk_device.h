@@ -169,6 +169,8 @@ struct GPos {
                // Python scalars alone in float32 (1 - xsi, (1 - xsi) * (1 - eta), ...) before it meets float64 data
     bool x32, e32, z32;  // the bcoord ARRAY of that axis is float32 in the reference: w32, or a float32 coordinate searched with
                          // float32 particle positions (index_search.py:51: f32 - f32 stays f32)
+    double xsi_raw, eta_raw;  // curvilinear: the float64 (xsi, eta) of the point in cell (yi, xi) BEFORE a hash hit is rounded to float32
+                              // (spatialhash.py:505), i.e. what a search started in that cell returns (index_search.py:269-285)
 };
 
 // ---- exact divisions that cost less than v_div_scale / v_rcp / v_div_fmas / v_div_fixup per quotient ----------------------
@@ -599,7 +601,7 @@ PK_DEV bool point_in_cell(const DGrid& g, const QPoint& q, int yi, int xi, doubl
 // order; the first candidate whose cell contains the point wins.  Hash hits return (xsi, eta) rounded to float32 like the
 // reference's float32 coords_best buffer (spatialhash.py:505).  ONE point-in-cell call site serves both paths.
 PK_DEV void curvilinear_search(const DGrid& g, double y, double x, bool use_guess, int gy, int gx, int& yi, int& xi, double& xsi,
-                               double& eta, const CellCache* cc = nullptr) {
+                               double& eta, const CellCache* cc = nullptr, double* xsi_raw = nullptr, double* eta_raw = nullptr) {
     yi = GRID_SEARCH_ERROR;
     xi = GRID_SEARCH_ERROR;
     xsi = -1.0;
@@ -643,6 +645,7 @@ PK_DEV void curvilinear_search(const DGrid& g, double y, double x, bool use_gues
             xi = i;
             xsi = k < 0 ? xs : (double)(float)xs;
             eta = k < 0 ? et : (double)(float)et;
+            if (xsi_raw) { *xsi_raw = xs; *eta_raw = et; }
             return;
         }
         if (k < 0 && g.walk_ok) {
@@ -665,6 +668,7 @@ PK_DEV void curvilinear_search(const DGrid& g, double y, double x, bool use_gues
                         xi = ni;
                         xsi = (double)(float)xs2;
                         eta = (double)(float)et2;
+                        if (xsi_raw) { *xsi_raw = xs2; *eta_raw = et2; }
                         return;
                     }
                 }
@@ -751,10 +755,14 @@ PK_DEV void grid_search_finish(const DGrid& g, bool hint, bool curv, int32_t* ei
 
 // The grid position the velocity sample of a kernel found, kept for the scalar samples the same kernel takes at the SAME point of
 // the SAME grid (AdvectionDiffusionM1 / EM read Kh_zonal and Kh_meridional at the particle position after UV,
-// _advectiondiffusion.py:44-62).  The reference searches again, starting from the cell the previous sample left in `ei`; a search
-// that starts in the cell containing the point returns that cell and the same (xsi, eta) (index_search.py:269-285), so re-using the
-// result IS the reference's result -- except for the float32 (xsi, eta) of an unguessed first evaluation (GPos::w32), which a second,
-// guessed search would replace by float64 values: those are never re-used.
+// _advectiondiffusion.py:44-62).  The reference searches again, starting from the cell the previous sample left in `ei`.  On a
+// rectilinear grid the result is a pure function of the point.  On a curvilinear grid a search that STARTS in the cell containing
+// the point returns that cell with the float64 (xsi, eta) of the point-in-cell test (index_search.py:269-285) -- GPos::xsi_raw /
+// eta_raw, whichever way the memo's own search found the cell -- while one that starts elsewhere goes through the spatial hash
+// (float32-rounded coordinates, and only faces the table lists).  So the memo is re-used exactly when the sample before this one left
+// the particle's `ei` in the memo's cell, which eval_scalar reads off the search hints: always for the Kh sample that directly follows
+// UV, for the one after Kh(y - dres) only if that point lies in the same cell (a 2500-seed fuzz run pins this; a memo re-used
+// regardless differs from the reference in the float32 rounding of (xsi, eta)).  Other lanes search again.
 struct SearchMemo {
     GPos p;
     int grid;  // -1: nothing to re-use
@@ -788,7 +796,7 @@ PK_DEV void grid_search(const DGrid& g, const Coords* mc, double z, double y, do
             if (hint && c.hyx_valid) { gy = c.hy; gx = c.hx; }
             else unravel_yx(g, (int64_t)*ei, gy, gx);
         }
-        curvilinear_search(g, y, x, use_guess, gy, gx, p.yi, p.xi, p.xsi, p.eta, mc ? &mc->cc : nullptr);
+        curvilinear_search(g, y, x, use_guess, gy, gx, p.yi, p.xi, p.xsi, p.eta, mc ? &mc->cc : nullptr, &p.xsi_raw, &p.eta_raw);
     } else {
         if (g.has_y) search_1d(lat, g.ny, mc ? mc->y0 : g.lat[0], mc ? mc->y1 : g.lat[g.ny - 1], y, yf32, pos_f32, hint ? c.hy : 0, p.yi, p.eta);
         else { p.yi = 0; p.eta = 0.0; }
@@ -1423,7 +1431,7 @@ PK_DEV void eval_uvw(const KArgs& a, const Coords& mc, PCtx& c, bool want_w, dou
     ei_set(c, U.grid, ei);
     if (memo) {
         memo->p = p;
-        memo->grid = p.w32 ? -1 : U.grid;
+        memo->grid = (p.xi < 0 || p.yi < 0 || p.zi < 0) ? -1 : U.grid;
     }
     const int flags = oob_flags(p);
     const bool oob = flags & 1;
@@ -1476,13 +1484,20 @@ PK_DEV double eval_scalar(const KArgs& a, const Coords& mc, PCtx& c, int fidx, d
     }
     const bool use_guess = take_first_eval(c, f.grid) ? (a.prm.have_guess0 != 0) : true;
     int32_t ei = ei_get(c, f.grid);
-    if (memo && memo->grid == f.grid) {  // (t, z, y, x) is the point of the kernel's velocity sample: see SearchMemo
+    // (t, z, y, x) is the point of the kernel's velocity sample: see SearchMemo for the two conditions
+    const bool curv = g.kind == 1;
+    if (memo && memo->grid == f.grid && (!curv || (on_main && c.hyx_valid && c.hy == memo->p.yi && c.hx == memo->p.xi))) {
         const int ti = p.ti;
         const double tau = p.tau;
         p = memo->p;
         p.ti = ti;
         p.tau = tau;
-        grid_search_finish(g, on_main, g.kind == 1, &ei, c, p);
+        if (curv) {  // a guessed search that hits: float64 coordinates, no float32 arrays
+            p.xsi = p.xsi_raw;
+            p.eta = p.eta_raw;
+            p.w32 = p.x32 = p.e32 = false;
+        }
+        grid_search_finish(g, on_main, curv, &ei, c, p);
     } else {
         grid_search<-1, TYPED>(g, on_main ? &mc : nullptr, z, y, x, pos_f32, &ei, c, use_guess, p);
     }

@@ -111,7 +111,7 @@ def draw_engine_options(seed, case):
     return dict(nslots=nslots)
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("PARCELS_FUZZ_SEEDS", "128"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PARCELS_FUZZ_SEEDS", "256"))))
 def test_random_configuration_matches_oracle(gpu, seed):
     case, sort_by_cell = draw_case(seed)
     opts = draw_engine_options(seed, case)
