@@ -68,7 +68,13 @@ typedef struct pk_ctx pk_ctx;
 #define PK_KERNEL_DIFFUSION_UNIFORM_KH 9
 #define PK_KERNEL_SAMPLE_FIELD 10 /* `particles.<var> = fieldset.<F>[particles]`: the user kernel every tutorial writes (kernel.py:206-216 runs
                                    it as Python; tests/test_particleset_execute.py:182-205 SampleU / SampleUV).  Field and target
-                                   column per kernel-list slot: pk_exec_params.sample_field / sample_var */
+                                   column per kernel-list slot: pk_exec_params.sample_field / sample_var.  Vector form
+                                   `particles.<a>, particles.<b>[, particles.<c>] = fieldset.UV[W][particles]` (VectorField.__getitem__,
+                                   field.py:250-304: the converted velocity components): sample_field = PK_SAMPLE_UV / PK_SAMPLE_UVW,
+                                   sample_var = a | b << 8 | c << 16 with PK_SAMPLE_DISCARD for a component assigned to `_` */
+#define PK_SAMPLE_UV (-2)
+#define PK_SAMPLE_UVW (-3)
+#define PK_SAMPLE_DISCARD 0xFF
 #define PK_KERNEL_DELETE_ON_ERROR 20
 #define PK_KERNEL_DELETE_OUT_OF_BOUNDS 21
 #define PK_KERNEL_SUBMERGE_THROUGH_SURFACE 22

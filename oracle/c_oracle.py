@@ -340,11 +340,17 @@ class MarshalledCase:
             p.sample_field[i] = p.sample_var[i] = -1
             if k in samples:  # the user kernel `particles.<var> = fieldset.<F>[particles]`
                 fname, vname, _ = samples[k]
-                if vname not in self.sample_vars:
-                    self.sample_vars.append(vname)
+                cols = []
+                for vn in sample_names(vname):
+                    if vn is None:
+                        cols.append(0xFF)
+                        continue
+                    if vn not in self.sample_vars:
+                        self.sample_vars.append(vn)
+                    cols.append(self.sample_vars.index(vn))
                 p.kernels[i] = KERNEL_IDS["SampleField"]
-                p.sample_field[i] = self.field_index[fname]
-                p.sample_var[i] = self.sample_vars.index(vname)
+                p.sample_field[i] = {"UV": -2, "UVW": -3}[fname] if fname in ("UV", "UVW") else self.field_index[fname]
+                p.sample_var[i] = sum(c << (8 * j) for j, c in enumerate(cols)) if fname in ("UV", "UVW") else cols[0]
             else:
                 p.kernels[i] = KERNEL_IDS[k]
         p.cgrid = {"free": 2, "partial": 3}.get(case.get("slip"), int(bool(case.get("cgrid"))))
@@ -411,8 +417,15 @@ def initial_particles(case: dict, ngrids: int) -> dict:
     if "AdvectionRK45" in case["kernels"]:
         d["next_dt"] = np.full(n, float(case.get("next_dt0", case["dt"])), np.dtype(case.get("next_dt_dtype", "float64")))
     for fname, vname, vdt in (case.get("sample_into") or {}).values():
-        d[vname] = np.zeros(n, np.dtype(vdt))
+        for vn in sample_names(vname):
+            if vn is not None:
+                d[vn] = np.zeros(n, np.dtype(vdt))
     return d
+
+
+def sample_names(vname):
+    """Variable names of a `sample_into` entry: one name (scalar field) or a list with None for discarded vector components."""
+    return list(vname) if isinstance(vname, (list, tuple)) else [vname]
 
 
 def execute(mc: MarshalledCase, data: dict, *, kernels, endtime, dt0, context=None, seed=0, have_guess0=0, nthreads=1):

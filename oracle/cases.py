@@ -637,6 +637,15 @@ def all_cases() -> dict:
         cs["sample_into"] = {"SampleP": ["P", "p", pd]}
         add(cs)
 
+    # --- its vector form: particles.u, particles.v = fieldset.UV[particles] (tests/test_particleset_execute.py:195-243): default float32
+    #     particles + Variables on a spherical A-grid; (u, _, w) = fieldset.UVW[particles] in float64 on the curvilinear C-grid, escapes
+    cs = rect_agrid_case("agrid_sph_rk4_sample_uv_f32", mesh="spherical", kernels=["AdvectionRK4", "SampleUV"], seed=35, spatial_dtype="float32")
+    cs["sample_into"] = {"SampleUV": ["UV", ["u", "v"], "float32"]}
+    add(cs)
+    cs = curv_cgrid_case("cgrid_curv_sph_rk4_3d_sample_uvw", mesh="spherical", kernels=["AdvectionRK4_3D", "SampleUVW", "DeleteParticle"], seed=36, vel=1.0)
+    cs["sample_into"] = {"SampleUVW": ["UVW", ["u", None, "w"], "float64"]}
+    add(cs)
+
     # --- scalar interpolators sampled through Field.eval ------------------------------------------------------------
     add(sample_case("sample_xlinear", interp="XLinear", seed=61))
     add(sample_case("sample_xnearest", interp="XNearest", seed=62))

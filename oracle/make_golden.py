@@ -167,7 +167,12 @@ def ref_run_case(case):
 
             def make_sample(fname=fname, vname=vname, name=name):
                 def sample(particles, fieldset):
-                    setattr(particles, vname, getattr(fieldset, fname)[particles])
+                    if isinstance(vname, (list, tuple)):  # particles.u, particles.v[, particles.w] = fieldset.UV[W][particles]
+                        for vn, val in zip(vname, getattr(fieldset, fname)[particles]):
+                            if vn is not None:
+                                setattr(particles, vn, val)
+                    else:
+                        setattr(particles, vname, getattr(fieldset, fname)[particles])
                 sample.__name__ = name
                 return sample
             klist.append(make_sample())
@@ -188,7 +193,9 @@ def ref_run_case(case):
     if "AdvectionRK45" in case["kernels"]:
         extra_vars = [("next_dt", np.dtype(case.get("next_dt_dtype", "float64")).type, float(case.get("next_dt0", case["dt"])))]
     for fname, vname, vdt in samples.values():
-        extra_vars = (extra_vars or []) + [(vname, np.dtype(vdt).type, 0)]
+        for vn in (vname if isinstance(vname, (list, tuple)) else [vname]):
+            if vn is not None:
+                extra_vars = (extra_vars or []) + [(vn, np.dtype(vdt).type, 0)]
     n = len(np.atleast_1d(case["x"]))
     z = case.get("z")
     if z is not None and np.ndim(z) == 0:

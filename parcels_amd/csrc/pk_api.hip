@@ -1437,8 +1437,19 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
         if ((id == PK_KERNEL_ADVECTION_RK4_3D || id == PK_KERNEL_ADVECTION_RK2_3D) && prm->fW < 0)
             return ctx->fail("3-D advection needs the W field");
         if (id == PK_KERNEL_SAMPLE_FIELD) {
-            if (prm->sample_field[k] < 0 || prm->sample_field[k] >= (int)ctx->fields.size()) return ctx->fail("PK_KERNEL_SAMPLE_FIELD: params.sample_field names no field");
-            if (prm->sample_var[k] < 0 || prm->sample_var[k] >= ctx->host.n_extra) return ctx->fail("PK_KERNEL_SAMPLE_FIELD: params.sample_var names no extra particle column");
+            const int sf = prm->sample_field[k];
+            const bool vec = sf == PK_SAMPLE_UV || sf == PK_SAMPLE_UVW;
+            if (!vec && (sf < 0 || sf >= (int)ctx->fields.size())) return ctx->fail("PK_KERNEL_SAMPLE_FIELD: params.sample_field names no field");
+            if (sf == PK_SAMPLE_UVW && prm->fW < 0) return ctx->fail("PK_KERNEL_SAMPLE_FIELD: sampling UVW needs the W field");
+            const int nv = vec ? (sf == PK_SAMPLE_UVW ? 3 : 2) : 1;
+            int stored = 0;
+            for (int j = 0; j < nv; j++) {
+                const int v = vec ? ((prm->sample_var[k] >> (8 * j)) & 0xFF) : prm->sample_var[k];
+                if (vec && v == PK_SAMPLE_DISCARD) continue;
+                if (v < 0 || v >= ctx->host.n_extra) return ctx->fail("PK_KERNEL_SAMPLE_FIELD: params.sample_var names no extra particle column");
+                stored++;
+            }
+            if (!stored) return ctx->fail("PK_KERNEL_SAMPLE_FIELD: every component is discarded");
         }
     }
     if (need_kh && (prm->fKh_zonal < 0 || prm->fKh_meridional < 0)) return ctx->fail("diffusion kernels need Kh_zonal/Kh_meridional");

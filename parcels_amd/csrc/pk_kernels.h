@@ -252,15 +252,22 @@ PK_DEV bool prepare(const KArgs& a, int kid, int stage, int kslot, PCtx& c, PSta
             return true;
         }
         case PK_KERNEL_SAMPLE_FIELD: {  // particles.<var> = fieldset.<F>[particles] (field.py:187-195: eval at the particle's t, z, y, x)
+            const int sf = prm.sample_field[kslot];
             if (stage == 0) {
-                rq.kind = RQ_SCALAR;
-                rq.fidx = prm.sample_field[kslot];
+                rq.kind = sf >= 0 ? RQ_SCALAR : (sf == PK_SAMPLE_UVW ? RQ_UVW : RQ_UV);
+                rq.fidx = sf >= 0 ? sf : 0;
                 rq.f32 = pf;
                 return false;
             }
-            const int v = prm.sample_var[kslot];  // assignment into the Variable's dtype (particlesetview.py:202-205)
-            if (a.p.extra_f32[v]) ((float*)a.p.extra[v])[c.row] = (float)L.r[0];
-            else ((double*)a.p.extra[v])[c.row] = L.r[0];
+            // assignment into the Variable's dtype (particlesetview.py:202-205); a vector sample fills up to three Variables
+            const int nv = sf >= 0 ? 1 : (sf == PK_SAMPLE_UVW ? 3 : 2);
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const int v = (prm.sample_var[kslot] >> (8 * j)) & 0xFF;
+                if (j >= nv || v == PK_SAMPLE_DISCARD) continue;
+                if (a.p.extra_f32[v]) ((float*)a.p.extra[v])[c.row] = (float)L.r[j];
+                else ((double*)a.p.extra[v])[c.row] = L.r[j];
+            }
             return true;
         }
         case PK_KERNEL_DO_NOTHING:  // tests/common_kernels.py:8-9
@@ -340,7 +347,7 @@ PK_DEV void consume(int kid, int stage, const PCtx& c, KLocal& L, double u, doub
             if (stage == 0) L.r[0] = u; else L.r[1] = u;
             break;
         case PK_KERNEL_SAMPLE_FIELD:
-            L.r[0] = u;
+            L.r[0] = u; L.r[1] = v; L.r[2] = w;
             break;
         default:  // RK2, RK2_3D, EE, Submerge: only the latest sample matters
             L.r[3] = u; L.r[4] = v; L.r[5] = w;

@@ -499,7 +499,7 @@ class DeviceEngine:
         for slot in range(_hip.PK_MAX_KERNELS):
             p.sample_field[slot] = p.sample_var[slot] = -1
         for slot, (fname, var) in (samples or {}).items():
-            p.sample_field[slot] = self.field_ids[fname]
+            p.sample_field[slot] = {"UV": -2, "UVW": -3}[fname] if fname in ("UV", "UVW") else self.field_ids[fname]  # PK_SAMPLE_UV / _UVW
             p.sample_var[slot] = int(var)
         return p
 

@@ -66,18 +66,30 @@ class Kernel:
                 continue
             fname, vname = spec
             fld = self._fieldset.fields.get(fname)
-            if fld is None or hasattr(fld, "U"):
+            vector = isinstance(vname, tuple)
+            if vector:  # particles.a, particles.b[, particles.c] = fieldset.UV[W][particles]
+                if fname not in ("UV", "UVW") or fld is None or not hasattr(fld, "U"):
+                    raise ValueError(f"SampleField: a tuple of Variables samples the vector field 'UV' or 'UVW', got '{fname}'")
+                if len(vname) != len(fname):
+                    raise ValueError(f"SampleField: fieldset.{fname}[particles] returns {len(fname)} components, `into` names {len(vname)}")
+            elif fld is None or hasattr(fld, "U"):
                 raise ValueError(f"SampleField: '{fname}' is not a scalar field of the fieldset")
-            if vname not in names or vname in _RESERVED_COLUMNS:
-                raise ValueError(f"SampleField: the ParticleClass has no user Variable '{vname}' (Particle.add_variable)")
-            if np.dtype(names[vname].dtype) not in (np.dtype(np.float32), np.dtype(np.float64)):
-                raise TypeError(f"SampleField: Variable '{vname}' must be float32 or float64")
+            cols = []
+            for vn in (vname if vector else (vname,)):
+                if vn is None:
+                    cols.append(0xFF)  # PK_SAMPLE_DISCARD
+                    continue
+                if vn not in names or vn in _RESERVED_COLUMNS:
+                    raise ValueError(f"SampleField: the ParticleClass has no user Variable '{vn}' (Particle.add_variable)")
+                if np.dtype(names[vn].dtype) not in (np.dtype(np.float32), np.dtype(np.float64)):
+                    raise TypeError(f"SampleField: Variable '{vn}' must be float32 or float64")
+                if vn not in self.device_variables:
+                    self.device_variables.append(vn)
+                cols.append(self.device_variables.index(vn))
             if fname in ("U", "V", "W"):  # field.py:187-190
                 warnings.warn("Sampling of velocities should normally be done using fieldset.UV or fieldset.UVW object; tread carefully",
                               RuntimeWarning, stacklevel=3)
-            if vname not in self.device_variables:
-                self.device_variables.append(vname)
-            self.samples[slot] = (fname, self.device_variables.index(vname))
+            self.samples[slot] = (fname, sum(c << (8 * j) for j, c in enumerate(cols)) if vector else cols[0])
         if len(self.device_variables) > 4:
             raise ValueError("at most 4 particle Variables can be written by device kernels")
 

@@ -110,7 +110,7 @@ def SubmergeParticle(particles, fieldset):  # tests/test_advection.py:163-174
     _device_only("SubmergeParticle")
 
 
-def SampleField(field: str, into: str):
+def SampleField(field: str, into):
     """The user kernel every Parcels tutorial writes,
 
         def SampleP(particles, fieldset):
@@ -119,8 +119,15 @@ def SampleField(field: str, into: str):
     as a device kernel: ``pset.execute([AdvectionRK4, SampleField("P", into="p")], ...)`` samples scalar field ``field`` at every
     particle's (t, z, y, x) in each step of the kernel loop (kernel.py:206-216) and stores it in the particle Variable ``into``
     (float32 or float64, added with ``Particle.add_variable``), with the reference's status-code side effects of a failed
-    sample (field.py:307-378).  Returns a kernel token named ``Sample<field>``."""
-    if not (isinstance(field, str) and isinstance(into, str)):
+    sample (field.py:307-378).  The vector form ``SampleField("UV", into=("u", "v"))`` / ``SampleField("UVW", into=("u", "v", "w"))``
+    is ``particles.u, particles.v = fieldset.UV[particles]`` (tests/test_particleset_execute.py:195-243: the converted velocity
+    components of VectorField.__getitem__, field.py:250-304); ``None`` in the tuple discards a component like ``_`` does.
+    Returns a kernel token named ``Sample<field>``."""
+    if isinstance(into, (tuple, list)):
+        into = tuple(into)
+        if not all(v is None or isinstance(v, str) for v in into) or all(v is None for v in into):
+            raise TypeError("SampleField(vector_field_name, into=(variable_name | None, ...))")
+    if not (isinstance(field, str) and isinstance(into, (str, tuple))):
         raise TypeError("SampleField(field_name, into=variable_name)")
 
     def token(particles, fieldset):

@@ -125,7 +125,9 @@ def build_pset(case, fs, **kw):
         pclass = pclass.add_variable(pa.Variable("next_dt", dtype=np.dtype(case.get("next_dt_dtype", "float64")).type,
                                                  initial=float(case.get("next_dt0", case["dt"]))))
     for fname, vname, vdt in (case.get("sample_into") or {}).values():
-        pclass = pclass.add_variable(pa.Variable(vname, dtype=np.dtype(vdt).type, initial=0))
+        for vn in (vname if isinstance(vname, (list, tuple)) else [vname]):
+            if vn is not None:
+                pclass = pclass.add_variable(pa.Variable(vn, dtype=np.dtype(vdt).type, initial=0))
     n = len(np.atleast_1d(case["x"]))
     t0 = case.get("t0")
     t = np.zeros(n) if t0 is None else np.broadcast_to(np.asarray(t0, dtype=np.float64), (n,)).copy()
@@ -174,7 +176,8 @@ def run_hip(case, endtime=None, nslots=None, async_output=None, **pset_kw):
     if async_output is not None:
         pset.async_output = bool(async_output)
     samples = case.get("sample_into") or {}
-    kernels = [pa.SampleField(samples[k][0], into=samples[k][1]) if k in samples else getattr(pa.kernels, k) for k in case["kernels"]]
+    kernels = [pa.SampleField(samples[k][0], into=tuple(samples[k][1]) if isinstance(samples[k][1], (list, tuple)) else samples[k][1])
+               if k in samples else getattr(pa.kernels, k) for k in case["kernels"]]
     kw = {}
     if endtime is not None:
         kw["endtime"] = endtime_of(endtime)

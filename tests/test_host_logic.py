@@ -304,3 +304,16 @@ def test_sample_field_token_validation():
         Kernel([pa.SampleField("P", into="p")], ip)
     with pytest.raises(RuntimeError):
         pa.SampleField("P", into="p")(None, None)  # device kernels cannot run on the host
+    # vector form: particles.u, particles.v = fieldset.UV[particles] (tests/test_particleset_execute.py:195-243)
+    case, _, _ = load_golden("cgrid_curv_sph_rk4_3d_sample_uvw")
+    fs = build_fieldset(case)
+    pset = build_pset(case, fs)
+    k = Kernel([pa.AdvectionRK4_3D, pa.SampleField("UVW", into=("u", None, "w"))], pset)
+    assert k.samples == {1: ("UVW", 0 | 0xFF << 8 | 1 << 16)} and k.device_variables == ["u", "w"] and k.funcname == "AdvectionRK4_3DSampleUVW"
+    assert Kernel([pa.SampleField("UV", into=("w", "u"))], pset).samples == {0: ("UV", 0 | 1 << 8)}
+    with pytest.raises(ValueError):
+        Kernel([pa.SampleField("UV", into=("u", None, "w"))], pset)  # UV has two components
+    with pytest.raises(ValueError):
+        Kernel([pa.SampleField("W", into=("u", "w"))], pset)  # a tuple needs a vector field
+    with pytest.raises(TypeError):
+        pa.SampleField("UV", into=(None, None))
