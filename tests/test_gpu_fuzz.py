@@ -111,9 +111,30 @@ def draw_engine_options(seed, case):
     return dict(nslots=nslots)
 
 
+def decorate_case(seed, case):
+    """User-kernel tokens on top of the drawn configuration (a third independent stream): with probability 0.3 a vector sample
+    `particles.u, particles.v[, particles.w] = fieldset.UV[W][particles]` (float32 or float64 Variables, sometimes a discarded
+    component) is inserted before or after the advection kernel; now and then MoveEast / DoNothing join the list."""
+    rng = np.random.default_rng(99000 + seed)
+    if rng.random() < 0.3 and "AdvectionRK45" not in case["kernels"]:
+        three_d = "W" in case["fields"] and rng.random() < 0.5
+        names = ["u", "v", "w"][: 3 if three_d else 2]
+        if rng.random() < 0.3:
+            names[int(rng.integers(0, len(names)))] = None
+        if all(n is None for n in names):
+            names[0] = "u"
+        token = "SampleUVW" if three_d else "SampleUV"
+        case["kernels"].insert(int(rng.integers(0, 2)), token)
+        case["sample_into"] = {token: ["UVW" if three_d else "UV", names, str(rng.choice(["float32", "float64"]))]}
+    if rng.random() < 0.15:
+        case["kernels"].insert(0, str(rng.choice(["MoveEast", "DoNothing", "MoveNorth"])))
+    return case
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("PARCELS_FUZZ_SEEDS", "256"))))
 def test_random_configuration_matches_oracle(gpu, seed):
     case, sort_by_cell = draw_case(seed)
+    case = decorate_case(seed, case)
     opts = draw_engine_options(seed, case)
     ref, oerr, ostats = run_oracle(case)
     got, gerr, stats = run_hip(case, sort_by_cell=sort_by_cell, **opts)
