@@ -185,6 +185,54 @@ def test_statistics_of_uniform_diffusion(gpu):
 
 
 @pytest.mark.parametrize("mesh", ["spherical", "flat"])
+def test_fieldKh_Brownian(gpu, mesh):
+    """tests/test_diffusion.py:19-46 as it stands: 100 particles, constant Kh fields, 2 h in 1 h steps; std and mean within 500 m."""
+    kh_zonal, kh_meridional = 100, 50
+    conv = 1 / 1852.0 / 60 if mesh == "spherical" else 1
+    ds = simple_uv_dataset(dims=(2, 1, 2, 2), mesh=mesh)
+    ds["lon"] = (("XG",), np.array([-1e6, 1e6]))
+    ds["lat"] = (("YG",), np.array([-1e6, 1e6]))
+    fs = pa.FieldSet.from_sgrid_conventions(ds, mesh=mesh)
+    fs.add_constant_field("Kh_zonal", kh_zonal, mesh=mesh)
+    fs.add_constant_field("Kh_meridional", kh_meridional, mesh=mesh)
+    npart, runtime = 100, 7200.0
+    pset = pa.ParticleSet(fs, x=np.zeros(npart), y=np.zeros(npart), seed=1234)
+    pset.execute(pa.DiffusionUniformKh, runtime=np.timedelta64(2, "h"), dt=np.timedelta64(1, "h"))
+    tol = 500 * conv
+    np.testing.assert_allclose(np.std(pset.y), np.sqrt(2 * kh_meridional * conv**2 * runtime), atol=tol)
+    np.testing.assert_allclose(np.std(pset.x), np.sqrt(2 * kh_zonal * conv**2 * runtime), atol=tol)
+    np.testing.assert_allclose(np.mean(pset.x), 0, atol=tol)
+    np.testing.assert_allclose(np.mean(pset.y), 0, atol=tol)
+
+
+@pytest.mark.parametrize("mesh", ["spherical", "flat"])
+@pytest.mark.parametrize("kernel", ["AdvectionDiffusionM1", "AdvectionDiffusionEM"])
+def test_fieldKh_SpatiallyVaryingDiffusion(gpu, mesh, kernel):
+    """tests/test_diffusion.py:49-78: a tanh gradient of Kh along x skews the zonal displacements, not the meridional ones."""
+    from scipy import stats
+
+    ydim, xdim = 100, 200
+    conv = 1 / 1852.0 / 60 if mesh == "spherical" else 1
+    ds = simple_uv_dataset(dims=(2, 1, ydim, xdim), mesh=mesh)
+    lon, lat = np.linspace(-1e6, 1e6, xdim), np.linspace(-1e6, 1e6, ydim)
+    ds["lon"] = (("XG",), lon)
+    ds["lat"] = (("YG",), lat)
+    Kh = np.zeros((ydim, xdim), dtype=np.float32)
+    Kh[:, :] = np.tanh(lon / lon[-1] * 10.0) * xdim / 2.0 + xdim / 2.0 + 100.0
+    ds["Kh_zonal"] = (("time", "depth", "YG", "XG"), np.full((2, 1, ydim, xdim), Kh))
+    ds["Kh_meridional"] = (("time", "depth", "YG", "XG"), np.full((2, 1, ydim, xdim), Kh))
+    fs = pa.FieldSet.from_sgrid_conventions(ds, mesh=mesh)
+    fs.add_context("dres", float(lon[1] - lon[0]))
+    npart = 10000
+    pset = pa.ParticleSet(fs, x=np.zeros(npart), y=np.zeros(npart), seed=1636)
+    pset.execute(getattr(pa.kernels, kernel), runtime=np.timedelta64(3, "h"), dt=np.timedelta64(1, "h"))
+    tol = 2000 * conv  # effectively 2000 m errors (because of low numbers of particles)
+    assert np.allclose(np.mean(pset.x), 0, atol=tol)
+    assert np.allclose(np.mean(pset.y), 0, atol=tol)
+    assert abs(stats.skew(pset.x)) > abs(stats.skew(pset.y))
+
+
+@pytest.mark.parametrize("mesh", ["spherical", "flat"])
 def test_advection_meridional(gpu, mesh, npart=10):
     """tests/test_advection.py:110-128: uniform V moves every particle the same dlat, whatever its latitude."""
     fs = pa.FieldSet.from_sgrid_conventions(simple_uv_dataset(mesh=mesh, v=1.0), mesh=mesh)

@@ -1,6 +1,6 @@
 """Offline sweep (build container only): the reference under oracle/ref_shim.py vs the C oracle on configurations of the GPU fuzz
 generator (tests/test_gpu_fuzz.py), one subprocess per seed with a timeout (the reference can hang, DESIGN.md deviation 5).
-Usage: python tools/fuzz_oracle_vs_reference.py LO HI"""
+Usage: python tools/fuzz_oracle_vs_reference.py LO HI [decorate]   (decorate: with the user-kernel tokens of test_gpu_fuzz.decorate_case)"""
 import sys, time, multiprocessing as mp, traceback
 sys.path.insert(0,'/root/repo/tests'); sys.path.insert(0,'/root/repo')
 sys.dont_write_bytecode=True
@@ -12,6 +12,11 @@ def run(seed, q):
         from oracle import make_golden as mg
         from case_utils import run_oracle, compare, stop_time_of_reference, is_curvilinear
         case,sort=f.draw_case(seed)
+        if len(sys.argv) > 3 and sys.argv[3] == "decorate":
+            before = list(case["kernels"])
+            case = f.decorate_case(seed, case)
+            if case["kernels"] == before:
+                q.put((seed,"ok","undecorated",None)); return
         out, err, extras = mg.ref_run_case(case)
         tstop = stop_time_of_reference(case, out, err)
         got, gerr, _ = run_oracle(case, endtime=tstop)
