@@ -88,6 +88,31 @@ def test_peninsula_streamfunction_conserved(gpu, grid_type, mesh):
     assert np.all(np.abs(pset.x - np.asarray(case["x"])) > 0)
 
 
+@pytest.mark.parametrize("kernel", ["AdvectionRK2", "AdvectionRK4", "AdvectionRK45"])
+@pytest.mark.parametrize("grid_type", ["A", "C"])
+def test_stommelgyre_fieldset(gpu, kernel, grid_type):
+    """tests/test_advection.py:354-387: along a Stommel-gyre trajectory the sampled streamfunction stays at its start value (rtol 0.1).
+    The reference's UpdateP kernel is the SampleField token here; p_start is the same sample taken before the run."""
+    from case_utils import build_fieldset
+    from oracle import cases
+
+    rtol = 0.1
+    case = cases.stommel_case("stom", grid_type=grid_type, xdim=200, ydim=200)
+    fs = build_fieldset(case)
+    pclass = pa.Particle.add_variable(pa.Variable("p", initial=0.0, dtype=np.float32))
+    if kernel == "AdvectionRK45":
+        pclass = pclass.add_variable(pa.Variable("next_dt", dtype=np.float32, initial=1800.0))
+        fs.add_context("RK45_tol", rtol)
+        fs.add_context("RK45_min_dt", 1)
+        fs.add_context("RK45_max_dt", 24 * 60 * 60)
+    start_lon = np.linspace(10e3, 100e3, 2)
+    pset = pa.ParticleSet(fs, pclass=pclass, x=start_lon, y=np.ones_like(start_lon) * 5000e3, t=np.timedelta64(0, "s"))
+    p_start = fs.P.eval(pset.t, pset.z, pset.y, pset.x)
+    pset.execute([getattr(pa.kernels, kernel), pa.SampleField("P", into="p")], dt=np.timedelta64(30, "m"), runtime=np.timedelta64(1, "D"))
+    assert np.all(pset.x != start_lon.astype(np.float32))
+    np.testing.assert_allclose(pset.p, p_start, rtol=rtol)
+
+
 @pytest.mark.parametrize("starttime,endtime,dt", [(0, 10, 1), (0, 10, 3), (2, 16, 3), (20, 10, -1), (20, 0, -2), (5, 15, 1)])
 def test_execution_endtime(gpu, starttime, endtime, dt):
     """tests/test_particleset_execute.py:315-326: the last step is shortened to land exactly on endtime."""
