@@ -93,9 +93,11 @@ const char* pk_last_error(const pk_ctx* ctx); /* ctx may be NULL: error of the l
  *                      coordinates run the dedicated kernels of csrc/pk_fast_agrid.h; 0 = the general program
  *   "special_programs" 1 (default) single-kernel programs for AdvectionRK45 / AdvectionDiffusionM1; 0 = kernel-list interpreter
  *   "cell_cache"       1 (default) per-lane LDS cache of the curvilinear cell;  "hash_directory" 1 (default) key directory;
- *                      both take effect for grids created / launches made afterwards
+ *                      "cell_table" 1 (default) per-cell table of the query-independent part of the point-in-cell test (192 B per
+ *                      cell of a curvilinear grid); they take effect for grids created / launches made afterwards
  *   "sort_horizontal"  -1 (default) automatic, 0 depth-major, 1 horizontal-major cell sort of curvilinear grids
- * Environment variables PK_NO_FAST, PK_NO_SPECIAL, PK_NO_CELL_CACHE, PK_NO_HASH_DIR, PK_SORT_HORIZONTAL give the initial values. */
+ * Environment variables PK_NO_FAST, PK_NO_SPECIAL, PK_NO_CELL_CACHE, PK_NO_HASH_DIR, PK_NO_CELL_TABLE, PK_SORT_HORIZONTAL give the initial
+ * values. */
 int32_t pk_set_option(pk_ctx* ctx, const char* name, int32_t value);
 
 /* Host-side accounting of the level stream (pk_field_upload_level / _group_level with async=1), cumulative since pk_init:

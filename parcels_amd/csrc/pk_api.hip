@@ -94,6 +94,7 @@ struct pk_ctx {
     int no_special = 0;
     int no_cell_cache = 0;
     int no_hash_dir = 0;
+    int no_cell_table = 0;
     int no_fast = 0;
     // asynchronous write-out snapshots (pk_particles_snapshot_begin / _wait): two sets of device staging columns (host row order)
     // + pinned host columns, so that the D2H and the encode of interval k overlap the launch of interval k+1
@@ -354,6 +355,39 @@ static int32_t stage_submit(pk_ctx* ctx, int k, void* dst, size_t bytes) {
     return 0;
 }
 
+// DGrid::cell_tab: one record per cell, written by the device functions the search would otherwise run on every cache miss
+// (identical instruction sequences, so the values are the ones the per-miss computation produces)
+__global__ void cell_table_kernel(const pk::DGrid g, double* tab) {
+    using namespace pk;
+    const int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= (int64_t)(g.ny - 1) * g.nx) return;
+    const int xi = (int)(cell % g.nx);
+    double* out = tab + cell * CT_STRIDE;
+    if (xi >= g.nx - 1) {  // not a cell (last node of a row): never read
+        for (int k = 0; k < CT_STRIDE; k++) out[k] = 0.0;
+        return;
+    }
+    const double* r0 = g.node_tab + cell * 5;
+    const double* r1 = r0 + (int64_t)g.nx * 5;
+    // corner order c0=(yi,xi) c1=(yi,xi+1) c2=(yi+1,xi+1) c3=(yi+1,xi)
+    const double* nodes[4] = {r0, r0 + 5, r1 + 5, r1};
+    double lon[4], lat[4], cX[4], cY[4], cZ[4];
+    for (int k = 0; k < 4; k++) { lon[k] = nodes[k][0]; lat[k] = nodes[k][1]; cX[k] = nodes[k][2]; cY[k] = nodes[k][3]; cZ[k] = nodes[k][4]; }
+    double eu[3] = {0, 0, 0}, ev[3] = {0, 0, 0}, pu[4] = {0, 0, 0, 0}, pv[4] = {0, 0, 0, 0};
+    unsigned long long box;
+    if (g.spherical) {
+        spherical_project_cell(cX, cY, cZ, eu, ev, pu, pv);
+        box = pack_quantised_box(g, cX, cY, cZ, true);
+    } else {
+        box = pack_quantised_box(g, lon, lat, lat, false);
+    }
+    for (int k = 0; k < 4; k++) { out[2 * k] = lon[k]; out[2 * k + 1] = lat[k]; }
+    for (int k = 0; k < 3; k++) { out[8 + k] = eu[k]; out[11 + k] = ev[k]; }
+    for (int k = 0; k < 4; k++) { out[14 + k] = pu[k]; out[18 + k] = pv[k]; }
+    out[22] = __longlong_as_double((long long)box);
+    out[23] = 0.0;
+}
+
 template <class T>
 static int32_t upload(pk_ctx* ctx, HostGrid& g, const T* host, size_t n, const T** dev) {
     *dev = nullptr;
@@ -393,6 +427,7 @@ int32_t pk_init(int32_t device, pk_ctx** out) {
     if (const char* e = getenv("PK_NO_SPECIAL")) ctx->no_special = atoi(e);
     if (const char* e = getenv("PK_NO_CELL_CACHE")) ctx->no_cell_cache = atoi(e);
     if (const char* e = getenv("PK_NO_HASH_DIR")) ctx->no_hash_dir = atoi(e);
+    if (const char* e = getenv("PK_NO_CELL_TABLE")) ctx->no_cell_table = atoi(e);
     if (const char* e = getenv("PK_NO_FAST")) ctx->no_fast = atoi(e);
     *out = ctx;
     PK_HIP(ctx, hipSetDevice(device));
@@ -417,6 +452,7 @@ int32_t pk_set_option(pk_ctx* ctx, const char* name, int32_t value) {
     else if (n == "special_programs") ctx->no_special = !value;
     else if (n == "cell_cache") ctx->no_cell_cache = !value;
     else if (n == "hash_directory") ctx->no_hash_dir = !value;
+    else if (n == "cell_table") ctx->no_cell_table = !value;
     else if (n == "sort_horizontal") ctx->sort_horizontal_major = value;
     else return ctx->fail("pk_set_option: unknown option '" + n + "'");
     return 0;
@@ -600,6 +636,25 @@ int32_t pk_grid_create(pk_ctx* ctx, const pk_grid_desc* desc, int32_t* grid_id) 
             d.walk_ok = coincident ? 0 : 1;
         } else {
             d.walk_ok = probe > 0 ? 1 : 0;
+        }
+        if (!ctx->no_cell_table && (int64_t)desc->ny * desc->nx < INT32_MAX) {
+            // optional: a grid that does not get its table (allocation failure on a crowded device) searches from node_tab
+            const int64_t ncell = (int64_t)(desc->ny - 1) * desc->nx;
+            double* ct = nullptr;
+            const double t0 = now_s();
+            if (ncell > 0 && hipMalloc((void**)&ct, (size_t)ncell * CT_STRIDE * sizeof(double)) == hipSuccess) {
+                g.allocs.push_back(ct);
+                const double t1 = now_s();
+                hipLaunchKernelGGL(cell_table_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, ctx->compute, d, ct);
+                PK_HIP(ctx, hipGetLastError());
+                PK_HIP(ctx, hipStreamSynchronize(ctx->compute));
+                d.cell_tab = ct;
+                if (pk::print_occupancy())
+                    fprintf(stderr, "[pk] cell table: %lld cells, %.2f GB, hipMalloc %.3f s, build %.3f s\n", (long long)ncell,
+                            (double)ncell * CT_STRIDE * 8 / 1e9, t1 - t0, now_s() - t1);
+            } else {
+                (void)hipGetLastError();
+            }
         }
         if (!ctx->no_hash_dir) {
             int32_t* dir = nullptr;

@@ -30,6 +30,11 @@ struct DGrid {
     const double* depth;
     const double* node_tab;  // curvilinear: array-of-structs {lon, lat, X, Y, Z} per node (X,Y,Z unit sphere; 0 on a flat mesh):
                              // the 2 nodes of a cell row are 80 contiguous bytes -> 2 rows = 2-4 cache lines instead of 10
+    // curvilinear, optional (NULL = compute from node_tab): per cell (yi * nx + xi) CT_STRIDE doubles -- {lon, lat} of the four corners,
+    // the tangent-plane basis and projected corners of _spherical_project_cell_and_query (everything that does not depend on the query
+    // point), and the cell's quantised hash box.  Built once per grid by the same device functions the search would run per miss:
+    // 2.5 GB for a 4322 x 3059 mesh, a trade the 288 GB of HBM make cheap.
+    const double* cell_tab;
     const uint32_t* h_keys;
     const int64_t* h_starts;
     const int64_t* h_counts;
@@ -270,6 +275,7 @@ PK_DEV NV nv_sqrt(NV a) { return a.dt == 1 ? NV{(double)sqrtf((float)a.v), 1} : 
 #endif
 constexpr int CC_LANES = PK_WG_CURV;
 constexpr int CC_NODE_ROWS = 22;
+constexpr int CT_STRIDE = 24;  // DGrid::cell_tab record: rows 0..21 as in CellCache::nodes, 22 = the packed quantised box, 23 unused
 __host__ __device__ constexpr inline int wg_size(int kind, bool lds) { return (kind == 1 && lds) ? PK_WG_CURV : 256; }
 struct CellCache {
     // [CC_NODE_ROWS][CC_LANES]: rows 0..7 {lon, lat} of corner c (0 (yi,xi), 1 (yi,xi+1), 2 (yi+1,xi+1), 3 (yi+1,xi)) at 2c, 2c+1;
@@ -521,6 +527,35 @@ PK_DEV bool in_quantised_box(const DGrid& g, const double c[4], double v, int ax
     const uint32_t qv = quantize(v, g.h_bbox[axis2], g.h_bbox[axis2 + 1], g.h_bitwidth, ri);
     return quantize(lo, g.h_bbox[axis2], g.h_bbox[axis2 + 1], g.h_bitwidth, ri) <= qv && qv <= quantize(hi, g.h_bbox[axis2], g.h_bbox[axis2 + 1], g.h_bitwidth, ri);
 }
+// the quantised [min, max] of a face's corners along the three hash axes, 10 bits each (what in_quantised_box compares against)
+PK_DEV unsigned long long pack_quantised_box(const DGrid& g, const double c0[4], const double c1[4], const double c2[4], bool three_axes) {
+    unsigned long long b = 0;
+    const double* cs[3] = {c0, c1, c2};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        unsigned lo = 0, hi = 1023;
+        if (a < 2 || three_axes) {
+            const double* c = cs[a];
+            const double vlo = fmin(fmin(c[0], c[1]), fmin(c[2], c[3])), vhi = fmax(fmax(c[0], c[1]), fmax(c[2], c[3]));
+            lo = quantize(vlo, g.h_bbox[2 * a], g.h_bbox[2 * a + 1], g.h_bitwidth, g.h_rinv[a]);
+            hi = quantize(vhi, g.h_bbox[2 * a], g.h_bbox[2 * a + 1], g.h_bitwidth, g.h_rinv[a]);
+        }
+        b |= ((unsigned long long)(lo & 1023u) | ((unsigned long long)(hi & 1023u) << 10)) << (20 * a);
+    }
+    return b;
+}
+PK_DEV bool box_lists(const DGrid& g, unsigned long long b, double v0, double v1, double v2, bool three_axes) {
+    const double v[3] = {v0, v1, v2};
+    bool ok = true;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        if (a == 2 && !three_axes) break;
+        const unsigned qv = quantize(v[a], g.h_bbox[2 * a], g.h_bbox[2 * a + 1], g.h_bitwidth, g.h_rinv[a]);
+        const unsigned lo = (unsigned)(b >> (20 * a)) & 1023u, hi = (unsigned)(b >> (20 * a + 10)) & 1023u;
+        ok = ok && lo <= qv && qv <= hi;
+    }
+    return ok;
+}
 PK_DEV uint32_t morton_code(const DGrid& g, const QPoint& q) {
     return (dilate_bits(quantize(q.qZ, g.h_bbox[4], g.h_bbox[5], g.h_bitwidth, g.h_rinv[2])) << 2) |
            (dilate_bits(quantize(q.qY, g.h_bbox[2], g.h_bbox[3], g.h_bitwidth, g.h_rinv[1])) << 1) |
@@ -549,6 +584,27 @@ PK_DEV bool point_in_cell(const DGrid& g, const QPoint& q, int yi, int xi, doubl
             for (int k = 0; k < 3; k++) { eu[k] = nd[(8 + k) * CC_LANES]; ev[k] = nd[(11 + k) * CC_LANES]; }
 #pragma unroll
             for (int k = 0; k < 4; k++) { pu[k] = nd[(14 + k) * CC_LANES]; pv[k] = nd[(18 + k) * CC_LANES]; }
+        } else if (g.cell_tab) {  // one contiguous record instead of two node rows + the two normalisations
+            const double* ct = g.cell_tab + (int64_t)cell * CT_STRIDE;
+            double boxd, unused;
+            ldpair(ct + 8, eu[0], eu[1]); ldpair(ct + 10, eu[2], ev[0]); ldpair(ct + 12, ev[1], ev[2]);
+            ldpair(ct + 14, pu[0], pu[1]); ldpair(ct + 16, pu[2], pu[3]); ldpair(ct + 18, pv[0], pv[1]); ldpair(ct + 20, pv[2], pv[3]);
+            if (listed) {
+                ldpair(ct + 22, boxd, unused);
+                *listed = box_lists(g, (unsigned long long)__double_as_longlong(boxd), q.qX, q.qY, q.qZ, true);
+            }
+            if (use_cc && !hit) {
+                double ll[8];
+#pragma unroll
+                for (int k = 0; k < 4; k++) ldpair(ct + 2 * k, ll[2 * k], ll[2 * k + 1]);
+                cc->key[0] = -1;
+#pragma unroll
+                for (int k = 0; k < 8; k++) nd[k * CC_LANES] = ll[k];
+#pragma unroll
+                for (int k = 0; k < 3; k++) { nd[(8 + k) * CC_LANES] = eu[k]; nd[(11 + k) * CC_LANES] = ev[k]; }
+#pragma unroll
+                for (int k = 0; k < 4; k++) { nd[(14 + k) * CC_LANES] = pu[k]; nd[(18 + k) * CC_LANES] = pv[k]; }
+            }
         } else {
             double cX[4], cY[4], cZ[4];
             double lon1, lat1, lon2, lat2;
@@ -579,8 +635,14 @@ PK_DEV bool point_in_cell(const DGrid& g, const QPoint& q, int yi, int xi, doubl
 #pragma unroll
             for (int k = 0; k < 4; k++) { clon[k] = PK_ND(k, 0); clat[k] = PK_ND(k, 1); }
         } else {
-            ldpair(r0, clon[0], clat[0]); ldpair(r0 + 5, clon[1], clat[1]);
-            ldpair(r1, clon[3], clat[3]); ldpair(r1 + 5, clon[2], clat[2]);
+            if (g.cell_tab) {
+                const double* ct = g.cell_tab + (int64_t)cell * CT_STRIDE;
+#pragma unroll
+                for (int k = 0; k < 4; k++) ldpair(ct + 2 * k, clon[k], clat[k]);
+            } else {
+                ldpair(r0, clon[0], clat[0]); ldpair(r0 + 5, clon[1], clat[1]);
+                ldpair(r1, clon[3], clat[3]); ldpair(r1 + 5, clon[2], clat[2]);
+            }
             if (use_cc) {
                 cc->key[0] = -1;
 #pragma unroll
