@@ -151,7 +151,10 @@ typedef struct pk_grid_desc {
                                 a mesh WITHOUT coincident nodes (no cyclic halo / fold rows, so cells cannot overlap) the
                                 neighbour cell the barycentric coordinates point at is tested before the hash-cell faces
                                 -- same answer as the reference's table-order walk (spatialhash.py:389-535), found in one
-                                probe instead of ~10; on a mesh WITH coincident nodes the table order is kept.
+                                probe instead of ~10; on a mesh WITH coincident nodes the table order is kept, and so it is on
+                                a mesh with a cell whose point-in-cell test is numerically unreliable (a parallelogram to
+                                rounding that still takes the quadratic branch of index_search.py:122-177 -- flat meshes in
+                                metres), because such a cell "contains" points of its neighbours.
                                 1 = always probe the neighbour first, -1 = never.                                        */
     double h_bbox[6]; /* xmin,xmax,ymin,ymax,zmin,zmax of the hash grid                             */
 } pk_grid_desc;

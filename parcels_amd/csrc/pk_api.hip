@@ -388,6 +388,34 @@ __global__ void cell_table_kernel(const pk::DGrid g, double* tab) {
     out[23] = 0.0;
 }
 
+// Cells on which the reference's bilinear inverse (index_search.py:122-177, restated in bilinear_inverse) is numerically unreliable:
+// the quadratic branch is taken (|aa| >= 1e-12) although the cell is a parallelogram to rounding, so (-bb + sqrt(bb^2 - 4 aa cc)) /
+// (2 aa) cancels completely and the point-in-cell test of such a cell accepts points that lie elsewhere.  (A flat mesh in metres has
+// aa ~ 1e-9 of pure rounding noise on an exact parallelogram; in degrees or on the unit sphere the same noise is below the 1e-12
+// switch to the linear branch.)  The reference then returns whichever listed face comes first in table order; neighbour-first
+// probing assumes at most one face contains the point, so it must be off on such a mesh.  Found by seed 2985 of the fuzz generator.
+__global__ void illconditioned_cell_kernel(const pk::DGrid g, int* flag) {
+    using namespace pk;
+    const int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= (int64_t)(g.ny - 1) * g.nx || (int)(cell % g.nx) >= g.nx - 1) return;
+    const double* r0 = g.node_tab + cell * 5;
+    const double* r1 = r0 + (int64_t)g.nx * 5;
+    const double* nodes[4] = {r0, r0 + 5, r1 + 5, r1};
+    double px[4], py[4];
+    if (g.spherical) {
+        double cX[4], cY[4], cZ[4], eu[3], ev[3];
+        for (int k = 0; k < 4; k++) { cX[k] = nodes[k][2]; cY[k] = nodes[k][3]; cZ[k] = nodes[k][4]; }
+        spherical_project_cell(cX, cY, cZ, eu, ev, px, py);
+    } else {
+        for (int k = 0; k < 4; k++) { px[k] = nodes[k][0]; py[k] = nodes[k][1]; }
+    }
+    const double a1 = -px[0] + px[1], a2 = -px[0] + px[3], a3 = ((px[0] + -px[1]) + px[2]) + -px[3];
+    const double b1 = -py[0] + py[1], b2 = -py[0] + py[3], b3 = ((py[0] + -py[1]) + py[2]) + -py[3];
+    const double aa = a3 * b2 - a2 * b3;
+    const double scale = fmax(fmax(fabs(a1 * b2), fabs(a2 * b1)), fmax(fabs(a3 * b2), fabs(a2 * b3)));
+    if (fabs(aa) >= 1e-12 && fabs(aa) < 1e-9 * scale) atomicOr(flag, 1);
+}
+
 template <class T>
 static int32_t upload(pk_ctx* ctx, HostGrid& g, const T* host, size_t n, const T** dev) {
     *dev = nullptr;
@@ -634,6 +662,18 @@ int32_t pk_grid_create(pk_ctx* ctx, const pk_grid_desc* desc, int32_t* grid_id) 
             if (mesh_has_coincident_nodes(ctx->compute, d.node_tab, desc->ny, desc->nx, desc->spherical, d.h_bbox, &coincident, &msg) != hipSuccess)
                 return ctx->fail("coincident-node scan: " + msg);
             d.walk_ok = coincident ? 0 : 1;
+            if (d.walk_ok) {  // ... and only where the point-in-cell test itself is reliable on every cell
+                int* d_flag = nullptr;
+                int h_flag = 0;
+                PK_HIP(ctx, hipMalloc((void**)&d_flag, sizeof(int)));
+                PK_HIP(ctx, hipMemsetAsync(d_flag, 0, sizeof(int), ctx->compute));
+                const int64_t ncell = (int64_t)(desc->ny - 1) * desc->nx;
+                if (ncell > 0) hipLaunchKernelGGL(illconditioned_cell_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, ctx->compute, d, d_flag);
+                PK_HIP(ctx, hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->compute));
+                PK_HIP(ctx, hipStreamSynchronize(ctx->compute));
+                (void)hipFree(d_flag);
+                if (h_flag) d.walk_ok = 0;
+            }
         } else {
             d.walk_ok = probe > 0 ? 1 : 0;
         }
