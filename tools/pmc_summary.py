@@ -139,7 +139,7 @@ def main():
           f"{c.get('SQ_WAIT_INST_ANY', 0) / max(c.get('SQ_WAVE_CYCLES', 1), 1):.2f}, issuing (SQ_ACTIVE_INST_ANY) {c.get('SQ_ACTIVE_INST_ANY', 0) / max(c.get('SQ_WAVE_CYCLES', 1), 1):.2f}"]
     if fetch_b is not None and write_b is not None:
         cal = (f"copy_kernel calibration (1 GiB in + 1 GiB out per dispatch): FETCH_SIZE {copy.get('FETCH_SIZE')} KiB -> x{f_cal:.4f}, WRITE_SIZE {copy.get('WRITE_SIZE')} KiB -> x{w_cal:.4f}"
-               if f_cal and w_cal else "no copy kernel in this run: FETCH_SIZE x2, WRITE_SIZE x1 as calibrated on the bench passes of the same binary (r02_g_c2_pmc.md)")
+               if f_cal and w_cal else "no copy kernel in this run: FETCH_SIZE x2, WRITE_SIZE x1 as calibrated on the bench passes of the same binary (the *_c2_pmc.md of the same round letter)")
         L += [f"* {cal}",
               f"* HBM traffic of the launch: fetch {fetch_b / 1e9:.3f} GB + write {write_b / 1e9:.3f} GB = {(fetch_b + write_b) / 1e9:.3f} GB = "
               f"**{(fetch_b + write_b) / psteps:.1f} B per particle-step** (algorithmic model of SURVEY 8d for C2: 1112 B, served by L2 / Infinity Cache)"]
