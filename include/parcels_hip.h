@@ -107,6 +107,10 @@ int32_t pk_set_option(pk_ctx* ctx, const char* name, int32_t value);
  * (src/parcels/_core/_windowed_array.py:56-97); it keeps no such counter. */
 int32_t pk_upload_stats(pk_ctx* ctx, double* out4);
 
+/* Host-only self-test of the staging fills behind pk_field_upload_group_level (float / double, 2 / 3 planes, AVX2 body and scalar
+ * tail, one thread and the pool) against the plain loop: 0 = all equal.  Needs no device. */
+int32_t pk_host_stage_selftest(void);
+
 typedef struct pk_device_info {
     char name[128];
     char arch[64];

@@ -203,6 +203,7 @@ ABI_SYMBOLS = [
     "pk_measure_copy_bandwidth",
     "pk_set_option",
     "pk_upload_stats",
+    "pk_host_stage_selftest",
 ]
 
 _lib = None

@@ -17,6 +17,8 @@
 #include <thread>
 #include <vector>
 
+#include <unistd.h>
+
 namespace pkhost {
 
 unsigned copy_threads() {
@@ -37,6 +39,7 @@ class Pool {
     unsigned njob = 0, pending = 0;
     unsigned long generation = 0;
     bool stop = false;
+    pid_t owner = getpid();
 
     void worker(unsigned index) {
         unsigned long seen = 0;
@@ -64,6 +67,13 @@ class Pool {
         std::lock_guard<std::mutex> serial(run_m);  // one job at a time (two contexts may stream from two Python threads)
         {
             std::lock_guard<std::mutex> lk(m);
+            if (owner != getpid()) {
+                // a fork()ed child (multiprocessing) inherits the bookkeeping but none of the threads: start over.  The thread
+                // objects of the parent's workers cannot be destroyed here (joinable), so they are parked for the process lifetime.
+                if (!workers.empty()) new std::vector<std::thread>(std::move(workers));
+                workers.clear();
+                owner = getpid();
+            }
             while (workers.size() + 1 < n) {
                 const unsigned index = (unsigned)workers.size() + 1;
                 workers.emplace_back([this, index] { worker(index); });
@@ -80,6 +90,10 @@ class Pool {
         job = nullptr;
     }
     ~Pool() {
+        if (owner != getpid()) {  // forked child that never streamed: nothing of ours to join
+            if (!workers.empty()) new std::vector<std::thread>(std::move(workers));
+            return;
+        }
         {
             std::lock_guard<std::mutex> lk(m);
             stop = true;
@@ -211,5 +225,36 @@ void parallel_interleave(T* dst, const T* const* src, int ncomp, size_t n) {
 }
 template void parallel_interleave<float>(float*, const float* const*, int, size_t);
 template void parallel_interleave<double>(double*, const double* const*, int, size_t);
+
+// every interleave variant (float / double, 2 / 3 planes, vector body + scalar tail, one thread / the pool) against the plain loop
+template <class T>
+static int selftest_type() {
+    int bad = 0;
+    for (size_t n : {(size_t)1, (size_t)7, (size_t)8, (size_t)9, (size_t)1000, (size_t)300007, ((size_t)1 << 20) + 13}) {
+        for (int ncomp = 2; ncomp <= 3; ncomp++) {
+            std::vector<T> planes[3];
+            const T* src[3];
+            for (int k = 0; k < 3; k++) {
+                planes[k].resize(n + 1);
+                for (size_t i = 0; i <= n; i++) planes[k][i] = (T)((double)(i * 3 + (size_t)k) * 0.37 - 11.0);
+                src[k] = planes[k].data() + 1;  // deliberately not 32-byte aligned
+            }
+            void* p = nullptr;
+            if (posix_memalign(&p, 4096, n * (size_t)ncomp * sizeof(T) + 64)) return 1000;
+            T* dst = (T*)p;
+            parallel_interleave(dst, src, ncomp, n);
+            for (size_t i = 0; i < n && !bad; i++)
+                for (int k = 0; k < ncomp; k++)
+                    if (dst[(size_t)ncomp * i + k] != src[k][i]) { bad++; break; }
+            free(p);
+        }
+    }
+    return bad;
+}
+}  // namespace pkhost
+
+extern "C" int32_t pk_host_stage_selftest(void) { return pkhost::selftest_type<float>() + pkhost::selftest_type<double>(); }
+
+namespace pkhost {
 
 }  // namespace pkhost

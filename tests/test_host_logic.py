@@ -317,3 +317,12 @@ def test_sample_field_token_validation():
         Kernel([pa.SampleField("W", into=("u", "w"))], pset)  # a tuple needs a vector field
     with pytest.raises(TypeError):
         pa.SampleField("UV", into=(None, None))
+
+
+def test_host_staging_fills_match_the_plain_loop():
+    """pk_host_stage.cpp: the AVX2 / pooled {U,V[,W]} interleave of the level stream equals the scalar loop for every variant
+    (runs on the host: no device needed)."""
+    from parcels_amd import _hip
+
+    lib = _hip.load()
+    assert lib.pk_host_stage_selftest() == 0
