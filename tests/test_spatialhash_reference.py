@@ -1,0 +1,184 @@
+"""The reference's tests/test_spatialhash.py restated: its `2d_left_rotated` mesh (30 x 60 nodes, rotated by -pi/24) and the numbers its
+own test pins (`SpatialHash.describe`: 1,711 faces, bitwidth 1023, 796,054 occupied hash cells, 1,080,194 entries, 1 / 1.36 / 4
+faces per cell).  Checked on the NumPy host build (parcels_amd.spatialhash), on the CPU oracle's query (po_hash_query) and -- `-m gpu`
+-- on the device build (pk_hashbuild.hip) and the device search (pk_search)."""
+
+import numpy as np
+import pytest
+
+from parcels_amd import spatialhash as sh
+
+X, Y = 30, 60  # _datasets/structured/__init__.py
+
+
+def rotated_mesh():
+    """_datasets/structured/generic.py:13-22"""
+    LON, LAT = np.meshgrid(np.arange(X), np.arange(Y))
+    angle = -np.pi / 24
+    rotation = np.array([[np.cos(angle), -np.sin(angle)], [np.sin(angle), np.cos(angle)]])
+    LON, LAT = np.einsum("ji, mni -> jmn", rotation, np.dstack([LON, LAT]))
+    return np.ascontiguousarray(LON), np.ascontiguousarray(LAT)
+
+
+def cell_centers(lon, lat):
+    clon = 0.25 * (lon[:-1, :-1] + lon[:-1, 1:] + lon[1:, :-1] + lon[1:, 1:])
+    clat = 0.25 * (lat[:-1, :-1] + lat[:-1, 1:] + lat[1:, :-1] + lat[1:, 1:])
+    jj, ii = np.meshgrid(np.arange(clat.shape[0]), np.arange(clat.shape[1]), indexing="ij")
+    return clat, clon, jj, ii
+
+
+def mesh_case(mesh, lon=None, lat=None):
+    if lon is None:
+        lon, lat = rotated_mesh()
+    z = np.zeros((1, 1) + lon.shape)
+    dims = ("mockT", "mockZ", "YG", "XG")
+    return dict(name="rot", mesh=mesh, lon=lon, lat=lat, depth=None, x_pad="high", y_pad="high", z_pad="both", time_s=None,
+                fields={"U": z, "V": z.copy()}, field_dims={"U": dims, "V": dims}, cgrid=False, kernels=["AdvectionRK4"],
+                spatial_dtype="float64", x=np.zeros(1), y=np.zeros(1), z=None, t0=None, dt=1.0, runtime=1.0, seed=0)
+
+
+def oracle_query(case, y, x):
+    """SpatialHash.query through the CPU oracle (hash_query of oracle/parcels_oracle.c on the host-built table)."""
+    import ctypes as C
+
+    from case_utils import attach_hash_table
+    from oracle import c_oracle as co
+
+    attach_hash_table(case)
+    mc = co.MarshalledCase(case)
+    y, x = np.ascontiguousarray(y, dtype=np.float64), np.ascontiguousarray(x, dtype=np.float64)
+    m = len(x)
+    yi, xi = np.zeros(m, np.int32), np.zeros(m, np.int32)
+    xsi, eta = np.zeros(m), np.zeros(m)
+    rc = co.lib().po_hash_query(mc.grids, C.c_int64(m), co._ptr(y), co._ptr(x), co._ptr(yi), co._ptr(xi), co._ptr(xsi), co._ptr(eta))
+    assert rc == 0
+    return yi, xi
+
+
+def test_spatialhash_describe():  # test_spatialhash.py:25-47 (the statistics its describe() prints)
+    lon, lat = rotated_mesh()
+    h = sh.SpatialHash(lon, lat, spherical=False)
+    assert h.xlow.size == 1711 and int(h.valid.sum()) == 1711
+    assert h.bitwidth == 1023
+    assert len(h.keys) == 796_054
+    assert h.faces.size == 1_080_194
+    assert f"{h.faces.size / len(h.keys):.2f}" == "1.36" and f"{h.faces.size / 1711:.2f}" == "631.32"
+    assert (int(h.counts.min()), f"{h.counts.mean():.2f}", int(h.counts.max())) == (1, "1.36", 4)
+
+
+def test_invalid_and_mixed_positions():  # test_spatialhash.py:50-56, 111-122
+    lon, lat = rotated_mesh()
+    j, i = oracle_query(mesh_case("flat"), [np.nan, np.inf], [np.nan, np.inf])
+    assert np.all(j == -3) and np.all(i == -3)
+    j, i = oracle_query(mesh_case("flat"), [lat.mean(), np.nan], [lon.mean(), np.nan])
+    assert (j[0], i[0]) == (29, 14)  # "Actual value for 2d_left_rotated center"
+    assert (j[1], i[1]) == (-3, -3)
+
+
+def test_spherical_regional_bounds():  # test_spatialhash.py:59-87
+    lon, lat = rotated_mesh()
+    h = sh.SpatialHash(lon, lat, spherical=True)
+    extents = np.array([h.bbox[1] - h.bbox[0], h.bbox[3] - h.bbox[2], h.bbox[5] - h.bbox[4]])
+    assert np.all(extents > 0.0) and np.all(extents < 2.0)
+    clat, clon, jj, ii = cell_centers(lon, lat)
+    j, i = oracle_query(mesh_case("spherical"), clat.ravel(), clon.ravel())
+    assert np.array_equal(j, jj.ravel()) and np.array_equal(i, ii.ravel())
+    j, i = oracle_query(mesh_case("spherical"), [-60.0, 80.0], [120.0, -150.0])
+    assert np.all(j == -3) and np.all(i == -3)
+
+
+def test_hash_entry_budget():  # test_spatialhash.py:90-108
+    lon, lat = rotated_mesh()
+    h = sh.SpatialHash(lon, lat, spherical=True)
+    budget = max(sh.HASH_ENTRIES_PER_FACE * h.xlow.size, sh.HASH_ENTRY_BUDGET_MIN)
+    assert h._total_entries(1023) > budget  # this grid requires the cap
+    assert h.bitwidth < 1023
+    assert h._total_entries(h.bitwidth) <= budget
+    assert h.faces.size <= budget
+
+
+def nan_node_mesh():
+    lon, lat = rotated_mesh()
+    lon[10, 10] = np.nan
+    lat[10, 10] = np.nan
+    return lon, lat, [(9, 9), (9, 10), (10, 9), (10, 10)]
+
+
+def test_nan_node_invalidates_touching_faces():  # test_spatialhash.py:125-185
+    lon0, lat0 = rotated_mesh()
+    clat, clon, jj, ii = cell_centers(lon0, lat0)
+    lon, lat, touching = nan_node_mesh()
+    h = sh.SpatialHash(lon, lat, spherical=False)
+    invalid_ids = {j * clon.shape[1] + i for j, i in touching}
+    faces_in_table = set(np.unique(h.faces).tolist())
+    assert invalid_ids.isdisjoint(faces_in_table)
+    assert jj.size > len(faces_in_table)
+    case = mesh_case("flat", lon, lat)
+    j, i = oracle_query(case, [clat[a, b] for a, b in touching], [clon[a, b] for a, b in touching])
+    assert np.all(j == -3) and np.all(i == -3)
+    mask = np.ones(clat.shape, dtype=bool)
+    for a, b in touching:
+        mask[a, b] = False
+    j, i = oracle_query(mesh_case("flat", lon, lat), clat[mask], clon[mask])
+    assert np.array_equal(j, jj[mask]) and np.array_equal(i, ii[mask])
+
+
+# ---- the device build and the device search -------------------------------------------------------------------------------------
+def device_engine(case):
+    from case_utils import build_fieldset
+    from parcels_amd.engine import DeviceEngine
+
+    return DeviceEngine(build_fieldset(case))
+
+
+def unravel(ei, xdim):
+    """(j, i) of a ravelled 2-D `ei`; a failed search ravels (-3, -3)"""
+    ei = np.asarray(ei, dtype=np.int64)
+    bad = ei == -3 * xdim - 3
+    j, i = np.where(bad, -3, ei // xdim), np.where(bad, -3, ei % xdim)
+    return j, i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mesh", ["flat", "spherical"])
+def test_device_build_equals_the_host_build(gpu, mesh):
+    lon, lat = rotated_mesh()
+    host = sh.SpatialHash(lon, lat, spherical=(mesh == "spherical"))
+    dev = device_engine(mesh_case(mesh)).hash_table(0)
+    assert sh.table_checksum(dev) == host.checksum()
+    if mesh == "flat":
+        assert len(dev["keys"]) == 796_054 and dev["faces"].size == 1_080_194 and dev["bitwidth"] == 1023
+    else:
+        assert dev["bitwidth"] < 1023
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mesh", ["flat", "spherical"])
+def test_device_search_resolves_cell_centers_and_rejects_invalid_positions(gpu, mesh):
+    lon, lat = rotated_mesh()
+    clat, clon, jj, ii = cell_centers(lon, lat)
+    eng = device_engine(mesh_case(mesh))
+    xdim = lon.shape[1] - 1
+    n = clat.size
+    j, i = unravel(eng.search(0, np.zeros(n), clat.ravel(), clon.ravel()), xdim)
+    assert np.array_equal(j, jj.ravel()) and np.array_equal(i, ii.ravel())
+    far = ([np.nan, np.inf], [np.nan, np.inf]) if mesh == "flat" else ([-60.0, 80.0], [120.0, -150.0])
+    j, i = unravel(eng.search(0, np.zeros(2), np.array(far[0]), np.array(far[1])), xdim)
+    assert np.all(j == -3) and np.all(i == -3)
+
+
+@pytest.mark.gpu
+def test_device_nan_node_invalidates_touching_faces(gpu):
+    lon0, lat0 = rotated_mesh()
+    clat, clon, jj, ii = cell_centers(lon0, lat0)
+    lon, lat, touching = nan_node_mesh()
+    eng = device_engine(mesh_case("flat", lon, lat))
+    assert sh.table_checksum(eng.hash_table(0)) == sh.SpatialHash(lon, lat, spherical=False).checksum()
+    xdim = lon.shape[1] - 1
+    j, i = unravel(eng.search(0, np.zeros(4), np.array([clat[a, b] for a, b in touching]), np.array([clon[a, b] for a, b in touching])), xdim)
+    assert np.all(j == -3) and np.all(i == -3)
+    mask = np.ones(clat.shape, dtype=bool)
+    for a, b in touching:
+        mask[a, b] = False
+    j, i = unravel(eng.search(0, np.zeros(int(mask.sum())), clat[mask], clon[mask]), xdim)
+    assert np.array_equal(j, jj[mask]) and np.array_equal(i, ii[mask])
