@@ -182,3 +182,75 @@ def test_device_nan_node_invalidates_touching_faces(gpu):
         mask[a, b] = False
     j, i = unravel(eng.search(0, np.zeros(int(mask.sum())), clat[mask], clon[mask]), xdim)
     assert np.array_equal(j, jj[mask]) and np.array_equal(i, ii[mask])
+
+
+# ---- tests/test_index_search.py and the _search_1d_array vectors of tests/test_xgrid.py ------------------------------------------
+def unrolled_cone_mesh():
+    """_datasets/structured/generic.py:76-101 (`2d_left_unrolled_cone`)"""
+    XG, YG = np.arange(X), np.arange(Y) * 0.25
+    pivot = -10, 0
+    LON, LAT = np.meshgrid(XG, YG)
+    min_lon = np.min(XG)
+    r = np.sqrt((LON - pivot[0]) ** 2 + (LAT - pivot[1]) ** 2) * 1.2
+    theta = np.arctan2(LAT - pivot[1], min_lon - pivot[0]) * 1.2
+    return np.ascontiguousarray(r * np.cos(theta) + pivot[0]), np.ascontiguousarray(r * np.sin(theta) + pivot[1])
+
+
+def check_fpoints(lon, lat, yi, xi, x, y):
+    """test_index_search.py:16-47: a point just off node (j, i) is found in cell (j, i) (or its lower neighbour) and lies in that
+    cell's bounding box"""
+    ny, nx = lon.shape
+    k = 0
+    for j in range(ny - 2):
+        for i in range(nx - 2):
+            assert yi[k] in (j, j - 1) and xi[k] in (i, i - 1), (j, i, yi[k], xi[k])
+            cj, ci = yi[k], xi[k]
+            clon = [lon[cj, ci], lon[cj, ci + 1], lon[cj + 1, ci + 1], lon[cj + 1, ci]]
+            clat = [lat[cj, ci], lat[cj, ci + 1], lat[cj + 1, ci + 1], lat[cj + 1, ci]]
+            assert min(clon) < x[k] < max(clon) and min(clat) < y[k] < max(clat)
+            k += 1
+
+
+def fpoints(lon, lat):
+    ny, nx = lon.shape
+    x = np.array([lon[j, i] + 0.00001 for j in range(ny - 2) for i in range(nx - 2)])
+    y = np.array([lat[j, i] + 0.00001 for j in range(ny - 2) for i in range(nx - 2)])
+    return x, y
+
+
+def test_grid_indexing_fpoints_oracle():
+    lon, lat = unrolled_cone_mesh()
+    x, y = fpoints(lon, lat)
+    yi, xi = oracle_query(mesh_case("flat", lon, lat), y, x)
+    check_fpoints(lon, lat, yi, xi, x, y)
+
+
+@pytest.mark.gpu
+def test_grid_indexing_fpoints(gpu):
+    lon, lat = unrolled_cone_mesh()
+    x, y = fpoints(lon, lat)
+    eng = device_engine(mesh_case("flat", lon, lat))
+    yi, xi = unravel(eng.search(0, np.zeros(len(x)), y, x), lon.shape[1] - 1)
+    check_fpoints(lon, lat, yi, xi, x, y)
+
+
+@pytest.mark.gpu
+def test_search_1d_array_known_answers(gpu):
+    """tests/test_xgrid.py:242-278 on the device: indices of _search_1d_array for in-range points (0-based cell, a point on node
+    k >= 1 belongs to cell k - 1) and the out-of-bounds codes, read off the ravelled `ei` of a grid with one horizontal axis pair."""
+    import parcels_amd as pa
+    from parcels_amd.engine import DeviceEngine
+
+    md = pa.SGrid2DMetadata(node_dimensions=("XG", "YG"), node_coordinates=("lon", "lat"),
+                            face_dimensions=(pa.FaceNodePadding("XC", "XG", pa.Padding.LOW), pa.FaceNodePadding("YC", "YG", pa.Padding.LOW)),
+                            vertical_dimensions=None)
+    arr = np.array([1.0, 2.0, 3.0, 4.0, 5.0])
+    z = np.zeros((5, 5))
+    ds = pa.Dataset({"U": (("YG", "XG"), z), "V": (("YG", "XG"), z.copy())}, {"lon": (("XG",), arr), "lat": (("YG",), arr)}, sgrid=md)
+    eng = DeviceEngine(pa.FieldSet.from_sgrid_conventions(ds, mesh="flat"))
+    xs = np.array([1.1, 2.1, 3.1, 4.5])
+    ei = eng.search(0, np.zeros(4), np.full(4, 1.5), xs)  # y in cell 0: ei = xi
+    assert ei.tolist() == [0, 1, 2, 3]
+    xdim = 4
+    ei = np.asarray(eng.search(0, np.zeros(2), np.full(2, 1.5), np.array([-0.1, 6.5])), dtype=np.int64)
+    assert (ei % xdim - xdim).tolist() == [-2, -1]  # LEFT_OUT_OF_BOUNDS = -2, RIGHT_OUT_OF_BOUNDS = -1 (basegrid.py) in the x digit of ei
