@@ -131,7 +131,10 @@ def decorate_case(seed, case):
     return case
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("PARCELS_FUZZ_SEEDS", "256"))))
+_SEED0 = int(os.environ.get("PARCELS_FUZZ_SEED0", "0"))  # sweeps beyond the default range: PARCELS_FUZZ_SEED0=12000 PARCELS_FUZZ_SEEDS=20000
+
+
+@pytest.mark.parametrize("seed", range(_SEED0, _SEED0 + int(os.environ.get("PARCELS_FUZZ_SEEDS", "256"))))
 def test_random_configuration_matches_oracle(gpu, seed):
     case, sort_by_cell = draw_case(seed)
     case = decorate_case(seed, case)
