@@ -50,3 +50,33 @@ def test_c4_two_ranks_write_the_single_process_file(gpu, tmp_path):
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["particles_total"] == 80000 and out["byte_identical_to_single_process_file"] is True
     assert out["parquet_rows"] >= 4 * out["remaining_particles"]
+
+
+@pytest.mark.gpu
+def test_bench_py_runs_under_torchrun_with_two_ranks(gpu):
+    """The driver's multi-GPU entry point, `python -m torch.distributed.run ... bench.py --gpus N`, rehearsed with two ranks sharing
+    this box's one GPU over gloo (PARCELS_AMD_BENCH_REHEARSAL=1; RCCL refuses two ranks on one device): one JSON line from rank 0,
+    whole-job value over one id space sharded by id, the write-out all-gather of the device columns timed."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    from case_utils import ROOT_DIR
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PARCELS_AMD_BENCH_REHEARSAL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(port), os.path.join(ROOT_DIR, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--particles", "200000", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT_DIR, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line"
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["value"] > 0 and out["config"]["all_states_endofloop"] is True and out["config"]["rehearsal_shared_gpu_gloo"] is True
+    assert out["writeout_allgather_ms"] is not None and out["writeout_allgather_ms"] > 0
+    assert abs(out["value"] * out["ms_per_step"] * 1e-3 * out["steps"] - 2 * 200000 * 4) < 1e-6 * 2 * 200000 * 4  # value x time = all ranks' steps
