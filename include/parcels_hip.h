@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PK_ABI_VERSION 3
+#define PK_ABI_VERSION 4 /* 4: pk_upload_stats, pk_host_stage_selftest, PK_KERNEL_DO_NOTHING / _MOVE_EAST / _MOVE_NORTH, vector PK_KERNEL_SAMPLE_FIELD, "cell_table" option */
 #define PK_MAX_GRIDS 4
 #define PK_MAX_FIELDS 16
 #define PK_MAX_KERNELS 8
