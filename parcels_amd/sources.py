@@ -16,9 +16,9 @@ A level source is anything with
 ``StructuredModelData`` does for in-memory arrays (model.py:135-143).
 
 * ``NpyLevels``  -- a directory / list of ``.npy`` files, one per time level (memory-mapped).
-* ``ZarrLevels`` -- one array of a zarr v2 store on a local filesystem, chunked with ONE time level per chunk along the first axis
-  (chunks may split z / y / x), compressor null, zstd, lz4, or blosc (lz4 / zstd / zlib inner codec, byte shuffle) --
-  the formats pyarrow's codecs can decode; no zarr / numcodecs installation is needed.
+* ``ZarrLevels`` -- one array of a zarr v2 or v3 directory store on a local filesystem, chunked with ONE time level per chunk along
+  the first axis (chunks may split z / y / x), compressor null, zstd, lz4, gzip or blosc (lz4 / zstd / zlib inner codec, byte
+  shuffle) -- the formats pyarrow's codecs can decode; no zarr / numcodecs installation is needed.
 """
 
 from __future__ import annotations
@@ -138,27 +138,56 @@ def _blosc_decode(buf: bytes) -> bytes:
 
 
 class ZarrLevels(LevelSource):
-    """``ZarrLevels("/data/model.zarr", "uo")``: the array ``uo`` of a zarr v2 directory store whose first axis is time with
-    chunk length 1.  ``shape_tzyx`` inserts size-1 axes when the array has fewer than four (e.g. a (time, y, x) surface field:
-    ``shape_tzyx=("t", None, "y", "x")`` is implied for 3-D arrays)."""
+    """``ZarrLevels("/data/model.zarr", "uo")``: the array ``uo`` of a zarr directory store whose first axis is time with chunk
+    length 1 (a (time, y, x) surface field gets a depth axis of size 1).
+
+    * zarr **v2** (``.zarray``): C order, no filters; compressor null, zstd, lz4, zlib / gzip or blosc.
+    * zarr **v3** (``zarr.json``): regular chunk grid, ``default`` ("c/0/1/2") or ``v2`` chunk keys, codec chain ``bytes`` (little
+      endian) optionally followed by ONE of ``zstd``, ``gzip``, ``blosc``; no sharding, no transpose."""
 
     def __init__(self, store, array, fill_nan=True):
         self.root = os.path.join(str(store), array)
-        meta_path = os.path.join(self.root, ".zarray")
-        if not os.path.exists(meta_path):
-            raise FileNotFoundError(f"{meta_path}: not a zarr v2 array (zarr v3 stores are not read)")
-        meta = json.load(open(meta_path))
-        if meta.get("zarr_format") != 2 or meta.get("order", "C") != "C" or meta.get("filters"):
-            raise ValueError("ZarrLevels reads zarr v2 arrays in C order without filters")
-        self.zshape = tuple(meta["shape"])
-        self.chunks = tuple(meta["chunks"])
+        v2, v3 = os.path.join(self.root, ".zarray"), os.path.join(self.root, "zarr.json")
+        if os.path.exists(v2):
+            meta = json.load(open(v2))
+            if meta.get("zarr_format") != 2 or meta.get("order", "C") != "C" or meta.get("filters"):
+                raise ValueError("ZarrLevels reads zarr v2 arrays in C order without filters")
+            self.zshape = tuple(meta["shape"])
+            self.chunks = tuple(meta["chunks"])
+            self.zdtype = np.dtype(meta["dtype"])
+            self.compressor = meta.get("compressor")
+            self.fill_value = meta.get("fill_value")
+            sep = meta.get("dimension_separator", ".")
+            self._key = lambda idx: sep.join(str(v) for v in idx)
+        elif os.path.exists(v3):
+            meta = json.load(open(v3))
+            if meta.get("zarr_format") != 3 or meta.get("node_type") != "array":
+                raise ValueError(f"{v3}: not a zarr v3 array")
+            grid = meta.get("chunk_grid", {})
+            if grid.get("name") != "regular":
+                raise ValueError("ZarrLevels reads zarr v3 arrays with a regular chunk grid")
+            self.zshape = tuple(meta["shape"])
+            self.chunks = tuple(grid["configuration"]["chunk_shape"])
+            self.zdtype = np.dtype({"float32": "<f4", "float64": "<f8", "int16": "<i2", "int32": "<i4", "int64": "<i8"}[meta["data_type"]])
+            self.fill_value = meta.get("fill_value")
+            cke = meta.get("chunk_key_encoding", {"name": "default"})
+            sep = (cke.get("configuration") or {}).get("separator", "/" if cke.get("name", "default") == "default" else ".")
+            self._key = (lambda idx: "c" + sep + sep.join(str(v) for v in idx)) if cke.get("name", "default") == "default" else (lambda idx: sep.join(str(v) for v in idx))
+            self.compressor = None
+            for c in meta.get("codecs", []):
+                name, conf = c.get("name"), c.get("configuration") or {}
+                if name == "bytes":
+                    if conf.get("endian", "little") != "little":
+                        raise ValueError("ZarrLevels reads little-endian zarr v3 arrays")
+                elif name in ("zstd", "gzip", "blosc") and self.compressor is None:
+                    self.compressor = {"id": name}
+                else:
+                    raise ValueError(f"unsupported zarr v3 codec chain (codec {name!r}): bytes [+ zstd | gzip | blosc] is read")
+        else:
+            raise FileNotFoundError(f"{self.root}: neither .zarray (zarr v2) nor zarr.json (zarr v3)")
         if self.chunks[0] != 1:
             raise ValueError(f"the time axis must be chunked one level per chunk, got chunks={self.chunks}")
-        self.zdtype = np.dtype(meta["dtype"])
         self.dtype = np.dtype(np.float64 if self.zdtype.itemsize == 8 else np.float32) if self.zdtype.kind == "f" else np.dtype(np.float64)
-        self.compressor = meta.get("compressor")
-        self.fill_value = meta.get("fill_value")
-        self.sep = meta.get("dimension_separator", ".")
         rest = self.zshape[1:]
         if not (1 <= len(rest) <= 3):
             raise ValueError(f"expected a (time, [z,] [y,] x) array, got shape {self.zshape}")
@@ -191,11 +220,10 @@ class ZarrLevels(LevelSource):
         out = np.empty(rest_shape, dtype=self.zdtype)
         grid = [range((s + c - 1) // c) for s, c in zip(rest_shape, rest_chunks)]
         for idx in np.ndindex(*[len(g) for g in grid]):
-            key = self.sep.join(str(v) for v in (k,) + tuple(idx))
-            path = os.path.join(self.root, key)
+            path = os.path.join(self.root, self._key((k,) + tuple(idx)))
             sl = tuple(slice(i * c, min((i + 1) * c, s)) for i, c, s in zip(idx, rest_chunks, rest_shape))
             if not os.path.exists(path):  # an unwritten chunk holds the fill value
-                out[sl] = np.nan if self.fill_value in (None, "NaN") else self.fill_value
+                out[sl] = np.nan if self.fill_value in (None, "NaN") else self.fill_value  # "NaN": the JSON spelling of both formats
                 continue
             buf = self._decode(open(path, "rb").read())
             chunk = np.frombuffer(buf, dtype=self.zdtype, count=int(np.prod(rest_chunks))).reshape(rest_chunks)

@@ -57,6 +57,64 @@ def test_zarr_levels_reads_what_was_written(tmp_path, compressor):
         pa.ZarrLevels(str(tmp_path), "bad")
 
 
+def _write_zarr_v3(root, name, arr, chunks, codec, key_encoding="default"):
+    """A zarr v3 directory array written by hand: zarr.json, "c/<i>/<j>/..." (or v2-style "i.j.k") chunk keys, codecs bytes [+ zstd | gzip]."""
+    import zlib
+
+    import pyarrow as pyarrow
+
+    d = os.path.join(root, name)
+    os.makedirs(d, exist_ok=True)
+    codecs = [{"name": "bytes", "configuration": {"endian": "little"}}]
+    if codec:
+        codecs.append({"name": codec, "configuration": {"level": 1}})
+    meta = {"zarr_format": 3, "node_type": "array", "shape": list(arr.shape), "data_type": {"<f4": "float32", "<f8": "float64"}[arr.dtype.str],
+            "chunk_grid": {"name": "regular", "configuration": {"chunk_shape": list(chunks)}},
+            "chunk_key_encoding": {"name": key_encoding, "configuration": {"separator": "/" if key_encoding == "default" else "."}},
+            "fill_value": "NaN", "codecs": codecs, "attributes": {}}
+    json.dump(meta, open(os.path.join(d, "zarr.json"), "w"))
+    grid = [range((s + c - 1) // c) for s, c in zip(arr.shape, chunks)]
+    for idx in np.ndindex(*[len(g) for g in grid]):
+        chunk = np.full(chunks, np.nan, arr.dtype)
+        sl = tuple(slice(i * c, min((i + 1) * c, s)) for i, c, s in zip(idx, chunks, arr.shape))
+        part = arr[sl]
+        chunk[tuple(slice(0, n) for n in part.shape)] = part
+        raw = chunk.tobytes()
+        if codec == "zstd":
+            raw = pyarrow.Codec("zstd").compress(raw).to_pybytes()
+        elif codec == "gzip":
+            co = zlib.compressobj(1, zlib.DEFLATED, 31)
+            raw = co.compress(raw) + co.flush()
+        key = os.path.join("c", *[str(i) for i in idx]) if key_encoding == "default" else ".".join(str(i) for i in idx)
+        path = os.path.join(d, key)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        open(path, "wb").write(raw)
+
+
+@pytest.mark.parametrize("codec, key_encoding", [(None, "default"), ("zstd", "default"), ("gzip", "default"), ("zstd", "v2")])
+def test_zarr_v3_levels_read_what_was_written(tmp_path, codec, key_encoding):
+    rng = np.random.default_rng(2)
+    a = rng.standard_normal((4, 3, 10, 21)).astype(np.float32)
+    a[1, 2, 3, 4] = np.nan
+    _write_zarr_v3(str(tmp_path), "V", a, (1, 2, 6, 21), codec, key_encoding)
+    src = pa.ZarrLevels(str(tmp_path), "V")
+    assert src.shape == a.shape and src.dtype == np.float32
+    for k in range(4):
+        assert np.array_equal(src.read_level(k), a[k], equal_nan=True)
+    assert src.level(1)[2, 3, 4] == 0.0
+    os.remove(os.path.join(str(tmp_path), "V", "c", "3", "1", "1", "0") if key_encoding == "default" else os.path.join(str(tmp_path), "V", "3.1.1.0"))
+    missing = src.read_level(3)  # an unwritten chunk holds the fill value
+    assert np.isnan(missing[2:3, 6:10]).all() and np.array_equal(missing[:2], a[3, :2])
+    b = rng.standard_normal((3, 7, 9))
+    _write_zarr_v3(str(tmp_path), "S", b, (1, 7, 9), codec, key_encoding)
+    assert pa.ZarrLevels(str(tmp_path), "S").shape == (3, 1, 7, 9)
+    meta = json.load(open(os.path.join(str(tmp_path), "V", "zarr.json")))
+    meta["codecs"].insert(0, {"name": "transpose", "configuration": {"order": [0, 1, 3, 2]}})
+    json.dump(meta, open(os.path.join(str(tmp_path), "V", "zarr.json"), "w"))
+    with pytest.raises(ValueError, match="codec chain"):
+        pa.ZarrLevels(str(tmp_path), "V")
+
+
 def test_zarr_levels_decodes_the_reference_s_blosc_stores():
     """The zarr stores the reference ships (tests/test_data/*.zarr, numcodecs Blosc lz4 + byte shuffle) through the product's own
     frame decoder, against oracle/mini_zarr.py (build container only)."""
