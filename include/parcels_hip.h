@@ -322,7 +322,10 @@ int32_t pk_execute_end(pk_ctx* ctx, pk_exec_stats* stats);
 
 /* ---- sampling: Field.eval / VectorField.eval at explicit points (field.py:145-195, 250-304) ------ */
 /* what = field id, or -1 for UV, -2 for UVW (fields taken from params).  All pointers are host
- * arrays of length m; out_v/out_w/out_state may be NULL. */
+ * arrays of length m; out_v/out_w/out_state may be NULL.  out_state[i] = the StatusCode the sample leaves (PK_EVALUATE = none),
+ * with PK_EVAL_MASKED or'ed in where the value was set to 0 because an index was out of bounds (_mask_outofbounds_values,
+ * field.py:359-370 -- also for the left / bottom exits in X / Y that set no error code, field.py:327-356). */
+#define PK_EVAL_MASKED 0x10000
 int32_t pk_eval(pk_ctx* ctx, const pk_exec_params* params, int32_t what, int64_t m, const double* t, const double* z,
                 const double* y, const double* x, double* out_u, double* out_v, double* out_w, int32_t* out_state);
 

@@ -7,7 +7,7 @@ include/parcels_hip.h.  There is no NumPy/CPU execution path.
 
 from . import convert, kernels
 from .dataset import DataArray, Dataset
-from .field import Field, TimeInterval, VectorField
+from .field import Field, FieldEvalWarning, TimeInterval, VectorField
 from .fieldset import FieldSet
 from .interpolators import (
     CGrid_Tracer,

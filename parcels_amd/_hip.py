@@ -18,6 +18,7 @@ PK_F32, PK_F64 = 0, 1
 PK_MAX_GRIDS, PK_MAX_FIELDS, PK_MAX_KERNELS, PK_NUM_STATE_CODES = 4, 16, 8, 80
 PK_MAX_EXTRA = 4
 PK_KERNEL_SAMPLE_FIELD = 10
+PK_EVAL_MASKED = 0x10000  # pk_eval: or'ed into out_state where the value was zeroed for an out-of-bounds index
 PK_COL_EXTRA0 = 0x1000
 COLUMN_BITS = {n: 1 << i for i, n in enumerate(
     ["t", "z", "y", "x", "dz", "dy", "dx", "dt", "next_dt", "state", "ei", "particle_id"])}

@@ -184,6 +184,7 @@ __global__ void __launch_bounds__(256) eval_kernel(const KArgs a, int what, int6
     c.hyx_valid = false;
     c.first_eval = 0xFu;
     c.u32 = c.v32 = false;
+    c.oob = false;
     c.ei0 = c.ei1 = c.ei2 = c.ei3 = 0;
     if (what < 0) {
         double u, v, w;
@@ -194,7 +195,7 @@ __global__ void __launch_bounds__(256) eval_kernel(const KArgs a, int what, int6
     } else {
         ou[i] = eval_scalar<FT, TYPED>(a, mc, c, what, t[i], z[i], y[i], x[i], false);
     }
-    if (ost) ost[i] = c.state;
+    if (ost) ost[i] = c.state | (c.oob ? PK_EVAL_MASKED : 0);
 }
 
 // One pk_eval call is one batch of the reference: lenT = 2 if np.any(tau > 0) else 1, lenZ likewise over the WHOLE batch

@@ -780,6 +780,7 @@ struct PCtx {
     unsigned first_eval;  // bit g: no evaluation on grid g yet in this execute() call
     int32_t ei0, ei1, ei2, ei3;  // the particle's `ei` row, one register per grid (no dynamic indexing -> no scratch)
     bool u32, v32;  // the u / v ARRAYS of the last eval_uvw are float32 in the reference (AdvectionRK45's stage-1 products)
+    bool oob;       // some sample of this context was masked to 0 by _mask_outofbounds_values (field.py:359-370); read by pk_eval only
     int64_t row;    // device row of the particle (kernels that write user Variables)
 };
 
@@ -1466,7 +1467,10 @@ PK_DEV int oob_flags(const GPos& p) {
 PK_DEV double finish_value(PCtx& c, int flags, double v) {
     if (flags & 2) v = NAN;
     if (v != v && c.state < PK_ERRORINTERPOLATION) c.state = PK_ERRORINTERPOLATION;
-    if (flags & 1) v = 0.0;
+    if (flags & 1) {
+        v = 0.0;
+        c.oob = true;
+    }
     return v;
 }
 PK_DEV double finish_value(PCtx& c, const GPos& p, double v) { return finish_value(c, oob_flags(p), v); }

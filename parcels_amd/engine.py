@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import warnings
 
 import numpy as np
 
@@ -584,8 +585,19 @@ class DeviceEngine:
             self.lib.pk_eval(self.ctx.handle, C.byref(prm), what, m, _ptr(t), _ptr(z), _ptr(y), _ptr(x), _ptr(u), _ptr(v), _ptr(w), _ptr(st)),
             "pk_eval",
         )
-        self.last_sample_state = st
+        self.last_sample_state = self._finish_sample_state(st)
         return u, v, w
+
+    @staticmethod
+    def _finish_sample_state(st):
+        """Strip PK_EVAL_MASKED from the state codes of pk_eval and give the reference's warning for masked values (field.py:359-370)."""
+        masked = (st & _hip.PK_EVAL_MASKED) != 0
+        if masked.any():
+            from .field import FieldEvalWarning
+
+            warnings.warn("Some interpolated values are out-of-bounds. These values are set to 0. Treat carefully.", FieldEvalWarning, stacklevel=4)
+            st = st & ~np.int32(_hip.PK_EVAL_MASKED)
+        return st
 
 
 def _sample_streamed(self, name, t, z, y, x):

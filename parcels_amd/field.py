@@ -26,6 +26,10 @@ from .xgrid import XGrid
 _FIELD_DATA_ORDERING = ("T", "Z", "Y", "X")
 
 
+class FieldEvalWarning(UserWarning):  # _core/warnings.py:31-38
+    """Issues during the evaluation of a Field (out-of-bounds indices during interpolation)."""
+
+
 class TimeInterval:
     """Closed interval [left, right] (utils/time.py:17-91)."""
 

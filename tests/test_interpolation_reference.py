@@ -138,3 +138,29 @@ def test_interpolation_mesh_type(gpu, mesh):  # test_interpolation.py:189-205
     u, v = fs.UV.eval(0.0, 0, lat, 0)
     assert np.isclose(u, u_expected, atol=1e-7)
     assert v == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("field_name, location, expected", [  # tests/test_field.py:187-214
+    ("U", (0.0, 0.0, 0.0, 5e6), 0.0),
+    ("UV", (0.0, 0.0, 0.0, 5e6), [[0.0], [0.0]]),
+    ("U", (0.0, 0.0, 5e6, 0.0), 0.0),
+    ("UV", (0.0, 0.0, 5e6, 0.0), [[0.0], [0.0]]),
+    ("U", (0.0, 5e6, 0.0, 0.0), 0.0),
+    ("UV", (0.0, 5e6, 0.0, 0.0), [[0.0], [0.0]]),
+])
+def test_field_eval_out_of_bounds_structured(gpu, field_name, location, expected):
+    """Field.eval outside the grid returns 0 with the reference's FieldEvalWarning."""
+    import parcels_amd as pa
+    from test_gpu_semantics import simple_uv_dataset
+
+    fs = pa.FieldSet.from_sgrid_conventions(simple_uv_dataset(mesh="flat", u=1.0, v=2.0), mesh="flat")
+    field = getattr(fs, field_name)
+    with pytest.warns(pa.FieldEvalWarning, match="Some interpolated values are out-of-bounds. These values are set to 0. Treat carefully."):
+        np.testing.assert_allclose(field.eval(*location), expected)
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", pa.FieldEvalWarning)
+        inside = field.eval(0.0, 0.0, 0.0, 0.0)  # no warning inside the grid
+    np.testing.assert_allclose(inside, 1.0 if field_name == "U" else [[1.0], [2.0]])
