@@ -63,7 +63,7 @@ def trace_summary(tag, out_md):
              "| kernel | calls | total_us | avg_us | % |", "|---|---|---|---|---|"]
     for name, calls, total, avg, pct in cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
         short = name if len(name) < 110 else name[:70] + " ... " + name[-30:]
-        lines.append(f"| `{short}` | {calls} | {total / 1e3:.1f} | {avg / 1e3:.1f} | {pct:.2f} |")
+        lines.append(f"| `{short}` | {calls} | {total:.1f} | {avg:.1f} | {pct:.2f} |")  # the stats view is in microseconds already
     lines += ["", "## dispatches of the advection / sort kernels (the LAST advect dispatch is the timed launch)", "",
               "| kernel | duration_us | grid | wg | lds | scratch | vgpr | agpr | sgpr |", "|---|---|---|---|---|---|---|---|---|"]
     q = ("select name,duration,grid_x,workgroup_x,lds_size,scratch_size,vgpr_count,accum_vgpr_count,sgpr_count from kernels "
