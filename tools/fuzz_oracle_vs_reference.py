@@ -21,11 +21,16 @@ def run(seed, q):
         tstop = stop_time_of_reference(case, out, err)
         got, gerr, _ = run_oracle(case, endtime=tstop)
         tol=f.tolerance(case)
-        exact = tol==1e-10
+        # the classes of tests/test_oracle_golden.py::test_oracle_matches_reference_on_random_configurations: bit-identical for fp64
+        # rectilinear cases, 1e-13 where NumPy's SIMD sin / cos and libm may differ by an ulp (curvilinear meshes, sampled velocities),
+        # 1e-11 for the stochastic kernels (libm vs NumPy log / sin / cos), the float32 class as drawn
+        stochastic = any(k.startswith("AdvectionDiffusion") or k == "DiffusionUniformKh" for k in case["kernels"])
+        if tol in (1e-10, 1e-11):
+            tol = 1e-11 if stochastic else (1e-13 if (is_curvilinear(case) or case.get("sample_into")) else 0.0)
         scale=float(max(np.nanmax(np.abs(case["lon"])), np.nanmax(np.abs(case["lat"]))))
         try:
             assert gerr==err, f"error {gerr} vs {err}"
-            compare(got, out, rtol=0.0 if exact else tol, atol_pos=0.0 if exact else tol*scale, check_state="errors" if tstop is not None else "all", label=f"seed {seed}")
+            compare(got, out, rtol=tol, atol_pos=tol*scale, check_state="errors" if tstop is not None else "all", label=f"seed {seed}")
             q.put((seed,"ok",str(err),case['kernels']))
         except AssertionError as e:
             q.put((seed,"MISMATCH",str(e)[:300],case['kernels']))
