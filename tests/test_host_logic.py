@@ -326,3 +326,32 @@ def test_host_staging_fills_match_the_plain_loop():
 
     lib = _hip.load()
     assert lib.pk_host_stage_selftest() == 0
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under parcels_amd/ or include/ may import, link or name it (a comment in pk_device.h says
+    exactly that), bench.py only in its cpu_baseline leg, __graft_entry__ only to build it and in smoke()."""
+    import ast
+
+    prod = os.path.join(ROOT, "parcels_amd")
+    for dirpath, _, files in os.walk(prod):
+        for f in files:
+            path = os.path.join(dirpath, f)
+            if f.endswith(".py"):
+                tree = ast.parse(open(path).read())
+                for node in ast.walk(tree):
+                    if isinstance(node, ast.Import):
+                        assert not any(a.name.split(".")[0] == "oracle" for a in node.names), path
+                    if isinstance(node, ast.ImportFrom):
+                        assert (node.module or "").split(".")[0] != "oracle", path
+            elif f.endswith((".h", ".hip", ".cpp")) or f == "Makefile":
+                for ln in open(path, errors="ignore"):
+                    if "oracle" in ln:
+                        assert "shares no code with oracle/" in ln, (path, ln)
+    for ln in open(os.path.join(ROOT, "include", "parcels_hip.h")):
+        assert "oracle" not in ln
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
+        imports = [n for n in ast.walk(fn) if isinstance(n, ast.ImportFrom) and (n.module or "").split(".")[0] == "oracle"]
+        if imports:
+            assert fn.name == "cpu_baseline", fn.name
