@@ -199,3 +199,53 @@ def test_advection_from_level_sources_equals_in_memory_fields(gpu, tmp_path, kin
         if ns is not None:
             assert pset._last_stats["launches"] > 1
         compare({k: np.array(v) for k, v in pset._data.items()}, want, rtol=0.0, check_state="all", label=f"{kind} nslots={ns}", skip=())
+
+
+class _CountingLevels(pa.LevelSource):
+    """A level source that counts how often each level is read (the `loads` counter of the reference's WindowedArray)."""
+
+    def __init__(self, inner):
+        self.inner, self.shape, self.dtype = inner, inner.shape, inner.dtype
+        self.reads = {}
+
+    def read_level(self, k):
+        self.reads[k] = self.reads.get(k, 0) + 1
+        return self.inner.read_level(k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("direction", [1, -1])
+def test_streamed_levels_are_read_once_and_at_most_three_are_resident(gpu, tmp_path, direction):
+    """tests/test_windowed_array.py:15-80 of the reference (each time level read exactly once, forward and backward, only the
+    bracketing levels resident), for the device ring: every level the run touches is read from its source exactly once, levels the
+    run never reaches are never read, and the ring never holds more than its three slots."""
+    case, lazy = _case_on_disk(tmp_path, "npy")
+    for name in list(lazy["fields"]):
+        lazy["fields"][name] = _CountingLevels(lazy["fields"][name])
+    fs = build_fieldset(lazy)
+    fs.to_device(nslots=3)
+    pset = build_pset(lazy, fs)
+    dt = case["dt"] * direction
+    if direction < 0:
+        pset._data["t"][:] = float(case["time_s"][-1])
+    resident_max = 0
+    eng = fs._engine_or_create()
+    upload = eng._upload
+
+    def counting_upload(*a, **k):
+        nonlocal resident_max
+        r = upload(*a, **k)
+        resident_max = max(resident_max, max(len([l for l in eng._slots(n) if l >= 0]) for n in ("U", "V", "W")))
+        return r
+
+    eng._upload = counting_upload
+    pset.execute([pa.AdvectionRK4_3D, pa.DeleteParticle], dt=dt, runtime=case["runtime"])
+    nt = len(case["time_s"])
+    span = case["runtime"] / (case["time_s"][1] - case["time_s"][0])  # levels the clock crosses
+    for name, src in lazy["fields"].items():
+        assert all(v == 1 for v in src.reads.values()), (name, src.reads)  # never twice
+        touched = sorted(src.reads)
+        assert len(touched) >= int(span) + 1 and len(touched) <= int(span) + 3, (name, touched)
+        assert (touched[0] == 0) if direction > 0 else (touched[-1] == nt - 1)
+        assert touched == list(range(touched[0], touched[-1] + 1))  # contiguous: nothing skipped, nothing beyond the run read
+    assert 2 <= resident_max <= 3
