@@ -105,6 +105,97 @@ def cpu_baseline(case, steps: int, sample: int):
             "sample": f"{sample} particles x {steps} RK4 steps of the same FieldSet, oracle/parcels_oracle.c with OpenMP ({el:.1f} s)"}
 
 
+def self_launch(n: int, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks under torch.distributed.run (one process per GPU, rendezvous
+    on 127.0.0.1 at a free port) and pass their output through -- rank 0 prints the one JSON line.  On a box with fewer than N
+    GPUs the ranks share cuda:0 and talk over gloo (rehearsal; the line is marked `rehearsal_shared_gpu_gloo` and is no measurement)."""
+    import socket
+    import subprocess
+
+    import torch
+
+    env = dict(os.environ)
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        env["PARCELS_AMD_BENCH_REHEARSAL"] = "1"
+        print(f"[bench] {have} GPU(s) visible, {n} ranks requested: rehearsal on cuda:0 over gloo", file=sys.stderr)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    return subprocess.call(cmd, env=env)
+
+
+def launch_command_world(argv_gpus: int, environ) -> tuple[int, bool]:
+    """(world size the process will run with, must it launch the ranks itself) -- the rule main() applies, for the CPU test."""
+    if argv_gpus > 1 and "WORLD_SIZE" not in environ:
+        return argv_gpus, True
+    return int(environ.get("WORLD_SIZE", "1")), False
+
+
+ALGO_BYTES_PER_STEP_C3_RK4_3D = 4 * (12 * 4 + 8 * 8) + 88  # SURVEY.md section 8(d): 12 staggered f32 values + 8 corner coordinates per evaluation
+ALGO_BYTES_PER_STEP_C5_RK45 = 6 * (8 * 4 + 8 * 8) + 96      # per attempt: 6 evaluations of U, V at two levels + the corner coordinates
+ALGO_BYTES_PER_STEP_C5_M1 = 568                              # DESIGN.md section 4
+
+
+def secondary_runs(args):
+    """BASELINE configs 3 and 5 at full size on this GPU (tools/bench_configs.py builds them), outside the timed region of the
+    headline: per run the particle-steps/s of the fused launch (HIP events on the compute stream), the algorithmic-byte roofline
+    fraction, the HBM counters of the last committed rocprofv3 PMC pass of that program, and the verdict of re-running the first
+    `--secondary-check` particle ids through the CPU oracle on the same arrays (the oracle is the checker here, never the thing
+    measured: tools/bench_configs.py::check_against_oracle)."""
+    from tools import bench_configs as bc
+
+    out = []
+    algo = {"AdvectionRK4_3D": ALGO_BYTES_PER_STEP_C3_RK4_3D, "AdvectionRK45": ALGO_BYTES_PER_STEP_C5_RK45, "AdvectionDiffusionM1": ALGO_BYTES_PER_STEP_C5_M1}
+    pmc = {}
+    pj_path = os.path.join(ROOT, "profiles", "pmc_secondary_latest.json")
+    if os.path.exists(pj_path):
+        try:
+            pmc = json.load(open(pj_path))
+        except Exception:
+            pmc = {}
+    for config in ("c3", "c5"):
+        t0 = time.perf_counter()
+        try:
+            res = bc.run_config(config, scale=args.secondary_scale, particles=args.secondary_particles, steps=24, nt=4, nslots=3, nz=75,
+                                check=int(args.secondary_check), emit=lambda o: None)
+        except AssertionError as e:  # the subset check failed: report it, do not hide it
+            out.append({"config": config, "check": {"passed": False, "error": str(e)[:2000]}})
+            continue
+        for r in res:
+            ks = r["kernel_ms"] * 1e-3
+            units = r["attempts"] if r["kernels"] == "AdvectionRK45" else r["particle_steps"]  # RK45: bytes move per attempt
+            if r["kernels"] == "AdvectionRK45":
+                units = units / 2  # `attempts` counts the DeleteParticle slot of every attempt too
+            ab = algo[r["kernels"]]
+            e = {"config": config, "workload": f"{config.upper()}: curvilinear C-grid {r['grid'][0]}x{r['grid'][1]}x{r['grid'][2]} f32 U,V,W, "
+                                               f"{r['nslots']}-slot ring, {r['particles']} fp64 particles, {r['kernels']} + DeleteParticle, 24 steps of 3600 s",
+                 "kernels": r["kernels"], "particle_steps": r["particle_steps"], "attempts": r["attempts"], "kernel_ms": r["kernel_ms"],
+                 "value": r["particle_steps_per_s_kernel"], "unit": "particle-steps/s (kernel time, levels resident)",
+                 "cell_sort_ms": r["sort_ms"], "wall_s_incl_h2d_d2h": r["wall_s"],
+                 "roofline": {"bound": "hbm", "algorithmic_bytes_per_unit": ab, "units": units,
+                              "achieved": ab * units / ks / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ab * units / ks / 1e9 / HBM_PEAK_GBPS,
+                              "traffic": None},
+                 "check": None, "setup_s": {"dataset": r["dataset_generation_s"], "device_create": r["device_create_s"]}}
+            pp = pmc.get(r["kernels"])
+            if pp and pp.get("hbm_bytes_per_particle_step") is not None:  # counters of the committed PMC pass, scaled to this launch
+                tr = pp["hbm_bytes_per_particle_step"] * r["particle_steps"]
+                e["roofline"]["traffic"] = tr
+                e["roofline"]["hbm_counter_frac"] = tr / ks / 1e9 / HBM_PEAK_GBPS
+                e["roofline"]["counters_source"] = pp.get("source")
+                e["roofline"]["valu_insts_per_wave_evaluation"] = pp.get("valu_insts_per_wave_eval")
+                e["roofline"]["scratch_bytes_per_lane"] = pp.get("scratch")
+            if r.get("check"):
+                c = r["check"]
+                e["check"] = {"passed": True, "n_check": c["n_check"], "deleted": c["deleted"], "exact": c["exact"],
+                              "max_abs_diff": c["max_abs_diff"], "tolerance": c["tolerance"], "oracle_s": c["oracle_s"]}
+            out.append(e)
+        out[-1]["total_s"] = time.perf_counter() - t0
+    return out
+
+
 def kernel_source_hash():
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "parcels_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "parcels_amd", "csrc", "*.hip"))):
@@ -121,13 +212,25 @@ def main():
     ap.add_argument("--sort", type=int, default=1, help="cell-sort the device copy of the particles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="particles of the CPU-baseline sample (~10-20 s on the host cores)")
+    ap.add_argument("--secondary", type=int, default=1,
+                    help="N = 1 only: also run BASELINE configs 3 and 5 (C3 RK4_3D, C5 RK45 + M1) at full size, each with a subset "
+                         "re-run through the CPU oracle, and attach them as `secondary` (0 = off)")
+    ap.add_argument("--secondary-check", type=float, default=1e5, help="particle ids of every secondary run re-run through the oracle")
+    ap.add_argument("--secondary-scale", type=float, default=1.0, help="shrinks nx, ny of the secondary grid (1.0 = BASELINE size)")
+    ap.add_argument("--secondary-particles", type=float, default=1e7)
     args = ap.parse_args()
+
+    if launch_command_world(args.gpus, os.environ)[1]:  # --gpus N without a launcher: start the N ranks here
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
 
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python bench.py --gpus N starts them itself)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     # rehearsal knob for a 1-GPU box: all ranks share cuda:0 and talk over gloo (RCCL refuses two ranks on one device); the
@@ -288,6 +391,16 @@ def main():
                 pass
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(case, steps=K, sample=min(args.cpu_sample, npart))
+        if args.secondary and world == 1:
+            # release the headline's device and host memory first: C3 needs 36 GB of HBM and 48 GB of host arrays
+            del pset, kern, eng, fs, case
+            import gc
+
+            gc.collect()
+            try:
+                out["secondary"] = secondary_runs(args)
+            except Exception as e:  # the headline line must survive a failing secondary leg
+                out["secondary"] = [{"error": repr(e)[:2000]}]
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

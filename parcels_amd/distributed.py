@@ -50,6 +50,19 @@ def dist_rank_world(group=None) -> tuple[int, int]:
     return dist.get_rank(group), dist.get_world_size(group)
 
 
+def allreduce_scalars(values, op: str, group=None, device=None) -> list:
+    """All-reduce a few float64 scalars ("min" / "max" / "sum") over the group: the host-side agreement a collective write-out
+    needs (first release time, "is every shard empty").  Device tensors under RCCL, host tensors under gloo."""
+    import torch
+    import torch.distributed as dist
+
+    on_gpu = dist.get_backend(group) == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device() if device is None else int(device)) if on_gpu else torch.device("cpu")
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op={"min": dist.ReduceOp.MIN, "max": dist.ReduceOp.MAX, "sum": dist.ReduceOp.SUM}[op], group=group)
+    return t.cpu().tolist()
+
+
 def gather_write_columns(columns: dict, group=None, device=None) -> dict | None:
     """The write-out exchange of ParticleFile.write (particlefile.py:142-180) across ranks: every rank passes the NumPy columns of
     ITS particles that pass the write filter; rank 0 receives the concatenation in rank order (= id order for contiguous

@@ -215,7 +215,10 @@ class ParticleSet:
 
     # -- the outer time loop (particleset.py:355-470) ------------------------------------------------------------
     def execute(self, kernels, dt, endtime=None, runtime=None, output_file=None, verbose_progress=False):
-        if len(self) == 0:
+        # A multi-rank ParticleFile makes write() a collective: every rank must then make the SAME sequence of write() calls at the
+        # SAME output times, whatever its own shard looks like (empty from the start, emptied by deletions, later releases).
+        collective = output_file is not None and getattr(output_file, "_world", 1) > 1
+        if len(self) == 0 and not collective:
             return
         if isinstance(kernels, types.FunctionType):
             kernels = [kernels]
@@ -229,7 +232,18 @@ class ParticleSet:
                 raise ValueError(f"The runtime must be a datetime.timedelta, np.timedelta64 or float object. Got {type(runtime)}") from e
             if runtime < 0:
                 raise ValueError(f"The runtime must be a non-negative timedelta or float. Got {runtime=!r}")
-        start_time, end_time = self._start_and_end_times(runtime, endtime, sign_dt)
+        first = None
+        if collective:
+            # the first release over ALL shards (NaN-propagating like rel.min(): one unset release time anywhere => fieldset start)
+            from .distributed import allreduce_scalars
+
+            rel = self._data["t"]
+            mine = (rel.min() if sign_dt == 1 else rel.max()) if len(rel) else np.nan
+            unset = bool(len(rel)) and bool(np.isnan(mine))
+            lo_hi = allreduce_scalars([sign_dt * mine if np.isfinite(mine) else np.inf, -1.0 if unset else -0.0], "min", output_file._group,
+                                      device=getattr(getattr(self.fieldset, "_engine", None), "device", None))
+            first = np.nan if (lo_hi[1] < 0 or not np.isfinite(lo_hi[0])) else sign_dt * lo_hi[0]
+        start_time, end_time = self._start_and_end_times(runtime, endtime, sign_dt, first=first)
         if np.isnan(self._data["t"]).any():
             self._data["t"][:] = start_time
         outputdt = output_file.outputdt if output_file else None
@@ -250,9 +264,10 @@ class ParticleSet:
         kern = self._kernel
         self._t_live = None
         engine.device_variables = list(kern.device_variables)  # user Variables that device kernels write live on the device
-        engine.bind_particles(self._data)
-        engine.h2d()
-        have_guess0 = kern._have_guess0(self._data)
+        if len(self) > 0:
+            engine.bind_particles(self._data)
+            engine.h2d()
+        have_guess0 = kern._have_guess0(self._data) if len(self) > 0 else 1
         out_cols = None
         writer = None
         if output_file is not None:
@@ -270,25 +285,29 @@ class ParticleSet:
                             next_time = (min if sign_dt > 0 else max)(next_output, end_time)
                         else:
                             next_time = end_time
-                        stats = kern.launch(self, next_time, dt, have_guess0=have_guess0)
-                        have_guess0 = 1
-                        synced = False
-                        self._t_live = next_time if not np.isnan(next_time) else None
-                        if kern.only_deletions(stats) and self.device_compaction:
-                            # Kernel.remove_deleted on the device: the columns do not leave HBM (pk_particles_compact)
-                            self._data = engine.compact_deleted(self._data)
+                        if len(self) > 0:  # (an empty shard of a collective run only keeps the write() schedule)
+                            stats = kern.launch(self, next_time, dt, have_guess0=have_guess0)
+                            have_guess0 = 1
                             synced = False
-                            if len(self) == 0:
+                            self._t_live = next_time if not np.isnan(next_time) else None
+                            if kern.only_deletions(stats) and self.device_compaction:
+                                # Kernel.remove_deleted on the device: the columns do not leave HBM (pk_particles_compact)
+                                self._data = engine.compact_deleted(self._data)
+                                synced = len(self) == 0
+                            elif kern.needs_host_pass(stats):
+                                engine.d2h()
                                 synced = True
+                                kern.finish_on_host(self)  # compacts / raises
+                                if len(self) > 0:
+                                    engine.bind_particles(self._data)
+                                    engine.h2d()
+                        if collective:  # the reference's `if len(pset) == 0: break`, decided over all shards
+                            from .distributed import allreduce_scalars
+
+                            if allreduce_scalars([float(len(self))], "sum", output_file._group, device=engine.device)[0] == 0:
                                 break
-                        elif kern.needs_host_pass(stats):
-                            engine.d2h()
-                            synced = True
-                            kern.finish_on_host(self)  # compacts / raises
-                            if len(self) == 0:
-                                break
-                            engine.bind_particles(self._data)
-                            engine.h2d()
+                        elif len(self) == 0:
+                            break
                         if next_output is not None and np.abs(next_time - next_output) < 0.001:
                             if writer is not None and not synced:
                                 # snapshot on the device, D2H on the copy stream, filter + Parquet encode on the writer thread --
@@ -313,7 +332,7 @@ class ParticleSet:
                 engine.d2h()
             self._t_live = None
 
-    def _start_and_end_times(self, runtime, endtime, sign_dt):  # particleset.py:523-585
+    def _start_and_end_times(self, runtime, endtime, sign_dt, first=None):  # particleset.py:523-585
         ti = self.fieldset.time_interval
         if runtime is not None and endtime is not None:
             raise ValueError(f"runtime and endtime are mutually exclusive - provide one or the other. Got {runtime=!r}, {endtime=!r}")
@@ -322,7 +341,8 @@ class ParticleSet:
         if runtime is None and endtime is None:
             raise ValueError("Either runtime or endtime must be provided.")
         rel = self._data["t"]
-        first = rel.min() if sign_dt == 1 else rel.max()  # NaN-propagating like the reference: one unset release time => fieldset start
+        if first is None:  # (given: the first release over all shards of a collective run)
+            first = rel.min() if sign_dt == 1 else rel.max()  # NaN-propagating like the reference: one unset release time => fieldset start
         if ti is not None and endtime is not None:
             if type(endtime) != type(ti.left):  # noqa: E721
                 raise ValueError(f"The endtime must be of the same type as the fieldset.time_interval start time. Got {endtime=!r} with time_interval={ti!r}")

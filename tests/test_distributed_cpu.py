@@ -153,3 +153,113 @@ def test_two_ranks_write_the_single_process_file_byte_for_byte(tmp_path):
     assert one.read_bytes() == two.read_bytes()
     df = pa.read_particlefile(two)
     assert len(df) > n_total and df["particle_id"].max() == n_total - 1
+
+
+# ---- ParticleSet.execute with a collective ParticleFile: every rank keeps the same write() schedule ------------------------------
+class _HostEngine:
+    """Stand-in for parcels_amd.engine.Engine in the CPU suite (the product has no CPU path; this fakes only the calls
+    ParticleSet.execute makes around a launch, so that its multi-rank output schedule can run under gloo without a GPU)."""
+
+    device = None
+
+    def __init__(self):
+        self.device_variables = []
+        self.data = None
+
+    def bind_particles(self, data):
+        self.data = data
+
+    def h2d(self):
+        pass
+
+    def d2h(self, cols=None):
+        pass
+
+    def compact_deleted(self, data):
+        from parcels_amd import StatusCode
+
+        keep = data["state"] != StatusCode.Delete
+        self.data = {k: v[keep] for k, v in data.items()}
+        return self.data
+
+
+def _host_launch(self, pset, endtime, dt, have_guess0=0):
+    """Kernel.launch on the host columns: released particles move to `endtime`; particle ids divisible by 3 are deleted once they
+    have reached t = 1800 (that empties the whole second shard of the test below)."""
+    from parcels_amd import StatusCode
+
+    d = pset._engine().data
+    live = d["t"] <= endtime
+    d["x"][live] += (endtime - d["t"][live]) * 1e-4
+    d["t"][live] = endtime
+    d["state"][:] = StatusCode.Evaluate
+    gone = live & (endtime >= 1800.0) & ((d["particle_id"] % 3 == 0) | (d["particle_id"] >= 50))
+    d["state"][gone] = StatusCode.Delete
+    sc = {int(StatusCode.Evaluate): int((~gone).sum())}
+    if gone.any():
+        sc[int(StatusCode.Delete)] = int(gone.sum())
+    return {"state_counts": sc, "steps": int(live.sum()), "kernel_ms": 0.0, "sort_ms": 0.0, "launches": 1, "attempts": 0}
+
+
+def _execute_run(path, shard, n_total=100):
+    import parcels_amd as pa
+    from parcels_amd.kernel import Kernel
+
+    fs = _make_fieldset()
+    ids = np.arange(n_total)
+    # unequal release times: the first shard starts at t = 0, the second one (ids >= 50) at t = 1200 -- and loses every particle at
+    # t = 1800 (ids >= 50 and the multiples of 3 are deleted); with world size 3 the last shard would start empty as well
+    t = np.where(ids < 50, 0.0, 1200.0)
+    pset = pa.ParticleSet(fs, x=ids * 0.1, y=ids * 0.0, z=ids * 0.0, t=t, shard=shard)
+    eng = _HostEngine()
+    pset._engine = lambda: eng
+    pset.async_output = False  # (the snapshot writer needs the real engine)
+    old = Kernel.launch
+    Kernel.launch = _host_launch
+    try:
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            pset.execute([pa.AdvectionRK4], dt=600.0, runtime=3600.0, output_file=pa.ParticleFile(path, outputdt=600.0))
+    finally:
+        Kernel.launch = old
+    return len(pset)
+
+
+def _exec_worker(rank, world, port, path, q):
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        q.put((rank, _execute_run(path, "auto")))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_execute_keeps_the_collective_write_schedule_on_every_rank(tmp_path, world):
+    """ParticleSet.execute with a multi-rank ParticleFile: shards with different release times, a shard that empties halfway and
+    (world 3 of 100 ids released late) ranks whose particles do not exist yet all make the same write() calls -- no hang, and the
+    file is the single-process file byte for byte (the start time, the output times and the stop come from ALL shards)."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    one = tmp_path / "one.parquet"
+    left = _execute_run(str(one), None)
+    many = tmp_path / "many.parquet"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exec_worker, args=(r, world, port, str(many), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0, "a rank hung or failed"
+    counts = dict(q.get(timeout=10) for _ in range(world))
+    assert sum(counts.values()) == left and counts[world - 1] == 0  # the last shard lost every particle
+    assert one.read_bytes() == many.read_bytes()

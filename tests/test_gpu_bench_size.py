@@ -80,3 +80,50 @@ def test_bench_py_runs_under_torchrun_with_two_ranks(gpu):
     assert out["value"] > 0 and out["config"]["all_states_endofloop"] is True and out["config"]["rehearsal_shared_gpu_gloo"] is True
     assert out["writeout_allgather_ms"] is not None and out["writeout_allgather_ms"] > 0
     assert abs(out["value"] * out["ms_per_step"] * 1e-3 * out["steps"] - 2 * 200000 * 4) < 1e-6 * 2 * 200000 * 4  # value x time = all ranks' steps
+
+
+@pytest.mark.gpu
+def test_bench_py_starts_its_own_ranks(gpu):
+    """`python bench.py --gpus 2` WITHOUT a launcher: bench.py re-executes itself under torch.distributed.run (one rank per GPU; on
+    this 1-GPU box the ranks share cuda:0 over gloo and the line says so) and still prints exactly one JSON line with n_gpus = 2."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from case_utils import ROOT_DIR
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PARCELS_AMD_BENCH_REHEARSAL")}
+    cmd = [sys.executable, os.path.join(ROOT_DIR, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--particles", "200000", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT_DIR, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["all_states_endofloop"] is True
+    import torch
+
+    assert out["config"].get("rehearsal_shared_gpu_gloo", False) == (torch.cuda.device_count() < 2)
+
+
+@pytest.mark.gpu
+def test_bench_py_secondary_configs_carry_the_oracle_check(gpu):
+    """The bench line's `secondary` array (BASELINE configs 3 and 5 next to the C2 headline), here on a shrunken grid: one entry per
+    kernel list with steps/s, the algorithmic-byte roofline fraction and the verdict of the oracle re-run of a subset."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from case_utils import ROOT_DIR
+
+    cmd = [sys.executable, os.path.join(ROOT_DIR, "bench.py"), "--steps", "4", "--warmup", "1", "--particles", "200000", "--no-cpu-baseline",
+           "--secondary-scale", "0.1", "--secondary-particles", "100000", "--secondary-check", "5000"]
+    r = subprocess.run(cmd, cwd=ROOT_DIR, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    sec = out["secondary"]
+    assert [e["kernels"] for e in sec] == ["AdvectionRK4_3D", "AdvectionRK45", "AdvectionDiffusionM1"], sec
+    for e in sec:
+        assert e["check"]["passed"] is True and e["check"]["n_check"] == 5000 and e["value"] > 0
+        assert e["roofline"]["bound"] == "hbm" and 0 < e["roofline"]["frac"] < 1

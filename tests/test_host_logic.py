@@ -355,3 +355,19 @@ def test_product_never_touches_the_oracle():
         imports = [n for n in ast.walk(fn) if isinstance(n, ast.ImportFrom) and (n.module or "").split(".")[0] == "oracle"]
         if imports:
             assert fn.name == "cpu_baseline", fn.name
+
+
+def test_bench_gpus_flag_decides_the_world_size():
+    """`python bench.py --gpus N` must run N ranks: it launches them itself when no launcher set WORLD_SIZE, and refuses a mismatch."""
+    import subprocess
+    import sys
+
+    import bench
+
+    assert bench.launch_command_world(8, {}) == (8, True)
+    assert bench.launch_command_world(8, {"WORLD_SIZE": "8"}) == (8, False)
+    assert bench.launch_command_world(1, {}) == (1, False)
+    # a launcher that started fewer ranks than --gpus asks for is an error, not a silent n_gpus = 1 line
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
