@@ -91,12 +91,15 @@ const char* pk_last_error(const pk_ctx* ctx); /* ctx may be NULL: error of the l
 /* Tuning / A-B switches of the library (the reference has no counterpart; its behaviour is the same for every setting):
  *   "fast_path"        1 (default) AdvectionRK4 / AdvectionRK4_3D with XLinear_Velocity on a rectilinear grid with float64
  *                      coordinates run the dedicated kernels of csrc/pk_fast_agrid.h; 0 = the general program
+ *   "fast_cgrid"       1 (default) AdvectionRK4 / AdvectionRK4_3D with CGrid_Velocity on a spherical curvilinear grid with float64
+ *                      node coordinates run the dedicated kernels of csrc/pk_fast_cgrid.h (needs "cell_table"; 256 B more per
+ *                      cell); 0 = the general program
  *   "special_programs" 1 (default) single-kernel programs for AdvectionRK45 / AdvectionDiffusionM1; 0 = kernel-list interpreter
  *   "cell_cache"       1 (default) per-lane LDS cache of the curvilinear cell;  "hash_directory" 1 (default) key directory;
  *                      "cell_table" 1 (default) per-cell table of the query-independent part of the point-in-cell test (192 B per
  *                      cell of a curvilinear grid); they take effect for grids created / launches made afterwards
  *   "sort_horizontal"  -1 (default) automatic, 0 depth-major, 1 horizontal-major cell sort of curvilinear grids
- * Environment variables PK_NO_FAST, PK_NO_SPECIAL, PK_NO_CELL_CACHE, PK_NO_HASH_DIR, PK_NO_CELL_TABLE, PK_SORT_HORIZONTAL give the initial
+ * Environment variables PK_NO_FAST, PK_NO_FAST_CGRID, PK_NO_SPECIAL, PK_NO_CELL_CACHE, PK_NO_HASH_DIR, PK_NO_CELL_TABLE, PK_SORT_HORIZONTAL give the initial
  * values. */
 int32_t pk_set_option(pk_ctx* ctx, const char* name, int32_t value);
 
@@ -311,7 +314,9 @@ typedef struct pk_exec_stats {
     double kernel_ms; /* HIP-event time of the advection kernel(s) on the compute stream            */
     double sort_ms;   /* HIP-event time of the cell sort (0 when not sorting)                        */
     int32_t launches;
-    int32_t reserved0;
+    int32_t program; /* which device program ran (diagnostic; same results whichever): 0-5 the general programs RK4, RK4_3D, kernel-list
+                        interpreter, RK45, M1, dtype-emulating interpreter; 100 the dedicated A-grid kernels (csrc/pk_fast_agrid.h), 101 the
+                        dedicated curvilinear C-grid kernels (csrc/pk_fast_cgrid.h)                                     */
 } pk_exec_stats;
 int32_t pk_execute(pk_ctx* ctx, const pk_exec_params* params, pk_exec_stats* stats);
 /* The same in two halves: _begin enqueues the sort + advection kernel + statistics on the compute stream and returns;

@@ -164,7 +164,7 @@ class ExecStats(C.Structure):
         ("kernel_ms", C.c_double),
         ("sort_ms", C.c_double),
         ("launches", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("program", C.c_int32),
     ]
 
 

@@ -86,6 +86,7 @@ struct pk_ctx {
     // an advection launch in flight (pk_execute_begin .. pk_execute_end)
     bool in_flight = false;
     int fl_launches = 0;
+    int fl_program = 0;
     bool fl_sorted = false;
     int64_t fl_n = 0;
     DCounters* h_counters = nullptr;          // pinned: the async D2H of the counters must not block the host
@@ -96,6 +97,7 @@ struct pk_ctx {
     int no_hash_dir = 0;
     int no_cell_table = 0;
     int no_fast = 0;
+    int no_fast_cgrid = 0;
     // asynchronous write-out snapshots (pk_particles_snapshot_begin / _wait): two sets of device staging columns (host row order)
     // + pinned host columns, so that the D2H and the encode of interval k overlap the launch of interval k+1
     struct Snapshot {
@@ -116,6 +118,14 @@ struct pk_ctx {
     int fast_tab_grid = -1, fast_tab_field = -1;
     bool fast_tab_ok = false;
     int32_t fast_tab_off[5] = {0, 0, 0, 0, 0};
+    // fast C-grid path (pk_fast_cgrid.h): per-cell records of one grid + {a, 1/width} tables of time | depth, cached per (grid, field)
+    double* d_ct2 = nullptr;
+    int ct2_grid = -1;
+    double* d_cg_tab = nullptr;
+    size_t cg_tab_cap = 0;
+    int cg_tab_grid = -1, cg_tab_field = -1;
+    bool cg_tab_ok = false;
+    int32_t cg_tab_off[3] = {0, 0, 0};
 
     int32_t fail(const char* where, hipError_t e) {
         err = std::string(where) + ": " + hipGetErrorString(e);
@@ -389,6 +399,46 @@ __global__ void cell_table_kernel(const pk::DGrid g, double* tab) {
     out[23] = 0.0;
 }
 
+// FastC::ct2 (pk_fast_cgrid.h): per cell, the record of cell_table_kernel re-expressed for the dedicated C-grid kernels -- the
+// query-independent sub-expressions of bilinear_inverse in ITS evaluation order (so that finishing them with the query point gives
+// the bits bilinear_inverse gives) and the corner longitudes after CGrid_Velocity's antimeridian unwrapping (cgrid_velocity).
+__global__ void cell_table2_kernel(const pk::DGrid g, double* tab) {
+    using namespace pk;
+    const int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= (int64_t)(g.ny - 1) * g.nx) return;
+    const int xi = (int)(cell % g.nx);
+    double* out = tab + cell * CT2_STRIDE;
+    for (int k = 0; k < CT2_STRIDE; k++) out[k] = 0.0;
+    if (xi >= g.nx - 1) return;  // not a cell (last node of a row): never read
+    const double* ct = g.cell_tab + cell * CT_STRIDE;
+    double px[4], py[4];
+    for (int k = 0; k < 4; k++) { px[k] = ct[14 + k]; py[k] = ct[18 + k]; }
+    const double a0 = px[0];
+    const double a1 = -px[0] + px[1];
+    const double a2 = -px[0] + px[3];
+    const double a3 = ((px[0] + -px[1]) + px[2]) + -px[3];
+    const double b0 = py[0];
+    const double b1 = -py[0] + py[1];
+    const double b2 = -py[0] + py[3];
+    const double b3 = ((py[0] + -py[1]) + py[2]) + -py[3];
+    const double aa = a3 * b2 - a2 * b3;
+    const double bb0 = a3 * b0 - a0 * b3 + a1 * b2 - a2 * b1;  // bb = bb0 + xq * b3 - yq * a3
+    const double cc0 = a1 * b0 - a0 * b1;                      // cc = cc0 + xq * b1 - yq * a1
+    for (int k = 0; k < 6; k++) out[k] = ct[8 + k];  // eu, ev
+    out[6] = a0; out[7] = a1; out[8] = a2; out[9] = a3; out[10] = b1; out[11] = b3;
+    out[12] = 4 * aa;
+    out[13] = bb0;
+    out[14] = cc0;
+    out[15] = ct[22];  // quantised hash box
+    double lon[4];
+    for (int k = 0; k < 4; k++) lon[k] = pymod360(ct[2 * k] + 180.0) - 180.0;  // _xinterpolators.py:230-233
+    for (int k = 1; k < 4; k++)
+        if (lon[k] - lon[0] > 180) lon[k] = lon[k] - 360;
+    for (int k = 1; k < 4; k++)
+        if (-lon[k] + lon[0] > 180) lon[k] = lon[k] + 360;
+    for (int k = 0; k < 4; k++) { out[16 + k] = lon[k]; out[20 + k] = ct[2 * k + 1]; out[24 + k] = py[k]; }
+}
+
 // Cells on which the reference's bilinear inverse (index_search.py:122-177, restated in bilinear_inverse) is numerically unreliable:
 // the quadratic branch is taken (|aa| >= 1e-12) although the cell is a parallelogram to rounding, so (-bb + sqrt(bb^2 - 4 aa cc)) /
 // (2 aa) cancels completely and the point-in-cell test of such a cell accepts points that lie elsewhere.  (A flat mesh in metres has
@@ -458,6 +508,7 @@ int32_t pk_init(int32_t device, pk_ctx** out) {
     if (const char* e = getenv("PK_NO_HASH_DIR")) ctx->no_hash_dir = atoi(e);
     if (const char* e = getenv("PK_NO_CELL_TABLE")) ctx->no_cell_table = atoi(e);
     if (const char* e = getenv("PK_NO_FAST")) ctx->no_fast = atoi(e);
+    if (const char* e = getenv("PK_NO_FAST_CGRID")) ctx->no_fast_cgrid = atoi(e);
     *out = ctx;
     PK_HIP(ctx, hipSetDevice(device));
     PK_HIP(ctx, hipGetDeviceProperties(&ctx->prop, device));
@@ -478,6 +529,7 @@ int32_t pk_set_option(pk_ctx* ctx, const char* name, int32_t value) {
     if (!ctx || !name) return -2;
     const std::string n(name);
     if (n == "fast_path") ctx->no_fast = !value;
+    else if (n == "fast_cgrid") ctx->no_fast_cgrid = !value;
     else if (n == "special_programs") ctx->no_special = !value;
     else if (n == "cell_cache") ctx->no_cell_cache = !value;
     else if (n == "hash_directory") ctx->no_hash_dir = !value;
@@ -551,6 +603,8 @@ int32_t pk_destroy(pk_ctx* ctx) {
     }
     if (ctx->d_pack_tmp) (void)hipFree(ctx->d_pack_tmp);
     if (ctx->d_fast_tab) (void)hipFree(ctx->d_fast_tab);
+    if (ctx->d_cg_tab) (void)hipFree(ctx->d_cg_tab);
+    if (ctx->d_ct2) (void)hipFree(ctx->d_ct2);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_summary) (void)hipFree(ctx->d_summary);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
@@ -1513,6 +1567,144 @@ static int32_t fill_fast(pk_ctx* ctx, const pk_exec_params* prm, KArgs& a, bool 
     return 0;
 }
 
+// Fold the descriptors of a C-grid velocity and its spherical curvilinear grid into the wave-uniform constants of the fast C-grid
+// path (pk_device.h: FastC, pk_fast_cgrid.h).  a.fastc.ok == 0 when a precondition fails (the general program runs): float64 node
+// coordinates, spherical mesh, per-cell table present, U / V (/ W) of one shape on the grid's own node counts with staggering offsets
+// in {0, 1} (then no staggered index needs clipping), a level below 2^31 elements, every search of the launch guessed.
+static int32_t fill_fastc(pk_ctx* ctx, const pk_exec_params* prm, KArgs& a, bool want_w, size_t& lds_bytes) {
+    FastC& F = a.fastc;
+    memset(&F, 0, sizeof(F));
+    if (ctx->no_fast_cgrid || prm->interp_uv != 1 || prm->rk45_mode) return 0;
+    if (prm->reset_state && !prm->have_guess0) return 0;  // an unguessed first search returns float32 (xsi, eta) ARRAYS (GPos::w32)
+    const HostField& U = ctx->fields[prm->fU];
+    const HostField& V = ctx->fields[prm->fV];
+    const HostField* W = (want_w && prm->fW >= 0) ? &ctx->fields[prm->fW] : nullptr;
+    if (want_w && !W) return 0;
+    const int gid = U.d.grid;
+    const HostGrid& g = ctx->grids[gid];
+    if (g.d.kind != 1 || !g.d.spherical || g.d.lon_f32 || g.d.lat_f32 || g.d.depth_f32 || !g.d.cell_tab) return 0;
+    if (V.d.grid != gid || (W && W->d.grid != gid)) return 0;
+    auto same = [](const DField& x, const DField& y) {
+        return x.ncomp == y.ncomp && x.dtype == y.dtype && x.st_t == y.st_t && x.st_z == y.st_z && x.st_y == y.st_y && x.st_x == y.st_x &&
+               x.nt == y.nt && x.nz == y.nz && x.ny == y.ny && x.nx == y.nx && x.nslots == y.nslots && x.has_time_interval == y.has_time_interval;
+    };
+    if (!same(U.d, V.d) || (W && !same(U.d, W->d))) return 0;
+    if (V.time != U.time || (W && W->time != U.time)) return 0;
+    const DField& f = U.d;
+    const int64_t esz = f.dtype == PK_F64 ? 8 : 4;
+    if (!g.d.has_x || !g.d.has_y || f.st_x != 1 || f.nx != g.d.nx || f.ny != g.d.ny || g.d.nx < 2 || g.d.ny < 2) return 0;
+    for (int o : {g.d.off_x, g.d.off_y, g.d.off_z})
+        if (o != 0 && o != 1) return 0;
+    if (g.d.has_z) {
+        if (g.d.nz < 2 || f.nz < g.d.nz + (W ? g.d.off_z : 0) || g.d.nz >= 4096) return 0;
+    } else if (W) {
+        return 0;
+    }
+    if (f.has_time_interval && (f.nt < 2 || U.time.front() != 0.0)) return 0;
+    if (f.nt >= (1 << 18)) return 0;
+    if ((int64_t)f.st_t >= (1ll << 31)) return 0;
+    // `ei` must not wrap (the guess of the next search is the cell itself)
+    if ((int64_t)std::max(g.d.xdim, 1) * std::max(g.d.ydim, 1) * std::max(g.d.zdim, 1) >= (1ll << 31)) return 0;
+    if (!(g.d.deg2m > 1e-100 && g.d.deg2m < 1e100)) return 0;
+    // coordinate tables of time | depth, built once per (grid, field)
+    if (ctx->cg_tab_grid != gid || ctx->cg_tab_field != prm->fU) {
+        ctx->cg_tab_grid = gid;
+        ctx->cg_tab_field = prm->fU;
+        ctx->cg_tab_ok = false;
+        std::vector<double> tab;
+        bool ok = true;
+        auto push = [&](const double* arr, int n) {
+            for (int i = 0; i < n; i++) {
+                double r = 0.0;
+                if (i + 1 < n) {
+                    const double d = arr[i + 1] - arr[i];
+                    r = 1.0 / d;
+                    if (!(d > 1e-100 && d < 1e100) || !std::isfinite(r)) ok = false;
+                }
+                tab.push_back(arr[i]);
+                tab.push_back(r);
+            }
+        };
+        const int nt = f.has_time_interval ? f.nt : 0;
+        const int nz = g.d.has_z ? g.d.nz : 0;
+        ctx->cg_tab_off[0] = 0;
+        push(U.time.data(), nt);
+        ctx->cg_tab_off[1] = (int32_t)(tab.size() / 2);
+        std::vector<double> tmp((size_t)std::max(nz, 0), 0.0);
+        if (nz > 0) PK_HIP(ctx, hipMemcpy(tmp.data(), g.d.depth, sizeof(double) * nz, hipMemcpyDeviceToHost));
+        push(tmp.data(), nz);
+        ctx->cg_tab_off[2] = (int32_t)(tab.size() / 2);
+        if (tab.size() * sizeof(double) > 24 * 1024) ok = false;  // next to the per-lane slots in the LDS of a one-wavefront workgroup
+        if (tab.empty()) tab.assign(2, 0.0);
+        if (ok) {
+            PK_HIP(ctx, hipStreamSynchronize(ctx->compute));
+            if (tab.size() > ctx->cg_tab_cap) {
+                if (ctx->d_cg_tab) PK_HIP(ctx, hipFree(ctx->d_cg_tab));
+                PK_HIP(ctx, hipMalloc((void**)&ctx->d_cg_tab, tab.size() * sizeof(double)));
+                ctx->cg_tab_cap = tab.size();
+            }
+            PK_HIP(ctx, hipMemcpy(ctx->d_cg_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+        ctx->cg_tab_ok = ok;
+    }
+    if (!ctx->cg_tab_ok) return 0;
+    // per-cell records, built once per grid (optional: without the memory for them the general program runs)
+    if (ctx->ct2_grid != gid) {
+        if (ctx->d_ct2) {
+            PK_HIP(ctx, hipStreamSynchronize(ctx->compute));
+            (void)hipFree(ctx->d_ct2);
+            ctx->d_ct2 = nullptr;
+        }
+        ctx->ct2_grid = gid;
+        const int64_t ncell = (int64_t)(g.d.ny - 1) * g.d.nx;
+        if (hipMalloc((void**)&ctx->d_ct2, (size_t)ncell * CT2_STRIDE * sizeof(double)) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->d_ct2 = nullptr;
+        } else {
+            hipLaunchKernelGGL(cell_table2_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, ctx->compute, g.d, ctx->d_ct2);
+            PK_HIP(ctx, hipGetLastError());
+        }
+    }
+    if (!ctx->d_ct2) return 0;
+    F.grid = gid;
+    F.has_ti = f.has_time_interval;
+    F.has_z = g.d.has_z;
+    F.walk_ok = g.d.walk_ok;
+    F.nt = f.nt;
+    F.nslots = f.nslots;
+    F.gnz = g.d.nz; F.gny = g.d.ny; F.gnx = g.d.nx;
+    uint32_t stride = 1;
+    if (g.d.has_x) { F.ex = stride; stride *= (uint32_t)g.d.xdim; }
+    if (g.d.has_y) { F.ey = stride; stride *= (uint32_t)g.d.ydim; }
+    if (g.d.has_z) { F.ez = stride; }
+    F.st_z = (int32_t)f.st_z;
+    F.st_y = (int32_t)f.st_y;
+    const int64_t cb = (int64_t)f.ncomp * esz;
+    F.cb = (int32_t)cb;
+    F.lvl_b = (int64_t)f.st_t * cb;
+    const int64_t oz = g.d.has_z ? g.d.off_z : 0;
+    F.dU0 = (int64_t)g.d.off_y * f.st_y * cb + (int64_t)U.d.comp * esz;
+    F.dU1 = F.dU0 + cb;
+    F.dV0 = (int64_t)g.d.off_x * cb + (int64_t)V.d.comp * esz;
+    F.dV1 = F.dV0 + (int64_t)f.st_y * cb;
+    if (W) {
+        F.dW0 = (oz * f.st_z + (int64_t)g.d.off_y * f.st_y + g.d.off_x) * cb + (int64_t)W->d.comp * esz;
+        F.dW1 = F.dW0 + (int64_t)f.st_z * cb;
+    }
+    F.U = (const char*)U.d.data; F.V = (const char*)V.d.data; F.W = W ? (const char*)W->d.data : nullptr;
+    F.ct2 = ctx->d_ct2;
+    F.tab = ctx->d_cg_tab;
+    F.lds_time = ctx->cg_tab_off[0]; F.lds_depth = ctx->cg_tab_off[1]; F.lds_n = ctx->cg_tab_off[2];
+    F.lds_rec = 2 * F.lds_n;
+    F.lds_fv = F.lds_rec + FC_REC_ROWS * FC_LANES;
+    lds_bytes = (size_t)F.lds_fv * sizeof(double) + (size_t)12 * FC_LANES * (size_t)esz;
+    F.tlen = f.tlen; F.t0 = f.tfirst; F.t1 = f.tlast;
+    F.z0 = g.d.zfirst; F.z1 = g.d.zlast;
+    F.deg2m = g.d.deg2m;
+    F.ok = 1;
+    return 0;
+}
+
 int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
     if (!ctx || !prm) return -2;
     if (!ctx->bound) return ctx->fail("no particles bound");
@@ -1574,9 +1766,16 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
             if (prm->kernels[0] == PK_KERNEL_ADVECTIONDIFFUSION_M1 && !ctx->no_special) prog = PROG_M1;
         }
         if (ctx_is_typed(ctx)) prog = PROG_TYPED;
+        bool fast_a = false, fast_c = false;  // a.fast / a.fastc share storage: at most one is filled
+        size_t cgrid_lds = 0;
         if ((prog == PROG_RK4 || prog == PROG_RK4_3D) && !curv) {
             rc = fill_fast(ctx, prm, a, prog == PROG_RK4_3D);
             if (rc) return rc;
+            fast_a = a.fast.ok != 0;
+        } else if ((prog == PROG_RK4 || prog == PROG_RK4_3D) && curv) {
+            rc = fill_fastc(ctx, prm, a, prog == PROG_RK4_3D, cgrid_lds);
+            if (rc) return rc;
+            fast_c = a.fastc.ok != 0;
         }
         if (prm->sort_by_cell) {
             PK_HIP(ctx, hipEventRecord(ctx->ev2, ctx->compute));
@@ -1592,10 +1791,11 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
             sorted = true;
         }
         PK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->compute));
-        const size_t fast_lds = (size_t)a.fast.lds_n * 2 * sizeof(double);
+        const size_t fast_lds = fast_a ? (size_t)a.fast.lds_n * 2 * sizeof(double) : 0;
         const int pf32 = ctx->dev.spatial_f32;
-        if (a.fast.ok && prog == PROG_RK4) launch_fast<PROG_RK4>(field_f32, pf32, a, grid, fast_lds, ctx->compute);
-        else if (a.fast.ok && prog == PROG_RK4_3D) launch_fast<PROG_RK4_3D>(field_f32, pf32, a, grid, fast_lds, ctx->compute);
+        if (fast_a && prog == PROG_RK4) launch_fast<PROG_RK4>(field_f32, pf32, a, grid, fast_lds, ctx->compute);
+        else if (fast_a && prog == PROG_RK4_3D) launch_fast<PROG_RK4_3D>(field_f32, pf32, a, grid, fast_lds, ctx->compute);
+        else if (fast_c) launch_cgrid(field_f32, pf32, prog == PROG_RK4_3D, a, n, cgrid_lds, ctx->compute);
         else switch (prog) {
             case PROG_RK4: launch_program<PROG_RK4>(field_f32, curv, prm->interp_uv, use_lds, a, grid, lds_bytes, ctx->compute); break;
             case PROG_RK4_3D: launch_program<PROG_RK4_3D>(field_f32, curv, prm->interp_uv, use_lds, a, grid, lds_bytes, ctx->compute); break;
@@ -1607,6 +1807,7 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
         PK_HIP(ctx, hipGetLastError());
         PK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->compute));
         launches = 1;
+        ctx->fl_program = fast_a ? 100 : (fast_c ? 101 : prog);
         const unsigned sgrid = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
         hipLaunchKernelGGL(summarize_kernel, dim3(sgrid), dim3(256), 0, ctx->compute, ctx->dev.state, ctx->dev.t, n, ctx->d_summary);
         PK_HIP(ctx, hipGetLastError());
@@ -1650,6 +1851,7 @@ int32_t pk_execute_end(pk_ctx* ctx, pk_exec_stats* stats) {
         if (ctx->fl_sorted) PK_HIP(ctx, hipEventElapsedTime(&sms, ctx->ev2, ctx->ev0));
         stats->sort_ms = sms;
         stats->launches = ctx->fl_launches;
+        stats->program = ctx->fl_launches ? ctx->fl_program : 0;
     }
     return 0;
 }

@@ -98,6 +98,26 @@ struct FastA {
     double deg2m, inv_deg2m;
 };
 
+// Wave-uniform constants of the fast path for CGrid_Velocity on a spherical curvilinear C-grid with float64 node coordinates
+// (pk_fast_cgrid.h), folded from the grid / field descriptors by the host (pk_api.hip: fill_fastc).
+struct FastC {
+    int32_t ok, grid;                    // preconditions hold; grid id (column of `ei`)
+    int32_t has_ti, has_z, walk_ok, pad0;
+    int32_t nt, nslots;                  // time levels of U / V / W and their ring
+    int32_t gnz, gny, gnx;               // node counts of the grid axes
+    uint32_t ex, ey, ez;                 // ravel strides of `ei` (basegrid.py:83-152)
+    int32_t lds_time, lds_depth, lds_n;  // offsets (in pairs) of the {a, 1/width} tables of time | depth inside `tab`
+    int32_t lds_rec, lds_fv;             // offsets (in doubles) of the per-lane cell slots inside the dynamic LDS
+    int32_t st_z, st_y;                  // element strides of the fields inside a level (cells)
+    int32_t cb;                          // bytes per cell struct of the (possibly packed) field buffers
+    int64_t lvl_b;                       // bytes per time-level slot
+    int64_t dU0, dU1, dV0, dV1, dW0, dW1;  // byte offsets of the six staggered values relative to the struct of cell (zi, yi, xi)
+    const char *U, *V, *W;               // level rings (component offset folded into dU0.. for packed groups; W may be NULL)
+    const double* ct2;                   // per-cell records (pk_fast_cgrid.h: CT2_STRIDE doubles each)
+    const double* tab;                   // global copy of the interleaved coordinate tables: time | depth
+    double tlen, t0, t1, z0, z1, deg2m;
+};
+
 struct KArgs {
     DGrid grids[PK_MAX_GRIDS];
     DField fields[PK_MAX_FIELDS];
@@ -109,7 +129,10 @@ struct KArgs {
     int32_t lds_time, lds_depth, lds_lat, lds_lon, lds_total;
     int32_t lds_cc_nodes, lds_cc_keys, lds_cc_fvals;  // cell cache (CellCache) offsets in doubles from the LDS base, -1 = off
     int32_t main_grid, main_field;
-    FastA fast;
+    union {  // at most one of the dedicated kernels runs per launch
+        FastA fast;
+        FastC fastc;
+    };
 };
 
 // ---- small helpers ------------------------------------------------------------------------------------

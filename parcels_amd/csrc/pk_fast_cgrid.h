@@ -1,0 +1,366 @@
+// pk_fast_cgrid.h -- VectorField.eval for BASELINE configurations 3 / 4: CGrid_Velocity on a spherical curvilinear C-grid with
+// float64 node coordinates (field.py:250-304, index_search.py:94-295, spatialhash.py:389-535, _xinterpolators.py:193-332).
+//
+// Same arithmetic, expression by expression, as the general eval_uvw<FT, 1, 1, false> of pk_device.h (the parity tests run both
+// against the same fixtures, and against each other at rtol 0), laid out for what bounds that program on MI355X -- instruction
+// issue and memory latency, not bandwidth:
+//   * everything the general path re-derives per evaluation from the grid / field descriptors is folded into one compact
+//     wave-uniform `FastC` block by the host (pk_api.hip: fill_fastc): element strides in bytes, the six staggered offsets of a
+//     cell, ravel strides;
+//   * a second per-cell table (`ct2`, 256 B per cell = two cache lines) holds, besides the tangent-plane basis, the
+//     query-independent part of the bilinear inverse (index_search.py:122-177: the coefficients a0..a3, b1, b3, the products
+//     4*aa, and the prefixes of bb and cc that do not contain the query point -- formed in the reference's evaluation order, so the
+//     remaining operations give the same bits) and the antimeridian-unwrapped corner longitudes of CGrid_Velocity
+//     (_xinterpolators.py:230-233);
+//   * the per-lane LDS slot caches that record (23 doubles) and the 12 raw staggered field values; the tags of the slot live in
+//     registers, a miss fetches record AND field values of the new cell in ONE memory round trip (the general path needs two
+//     dependent ones: the record, then -- after the point-in-cell test -- the values);
+//   * phi2D_lin rows with a literal 0 / 1 argument are written with their exact zero products removed, the cosine of the
+//     particle latitude is shared between the unit-sphere query point and the metres -> degrees conversion, the ring slot
+//     of a time level (`level % nslots`) is computed on the scalar unit once per distinct level of a wavefront.
+// The rare branches (no valid guess, neighbour probe rejected, degenerate bilinear inverse) call the general device functions.
+#pragma once
+#include "pk_device.h"
+#include "pk_fast_agrid.h"
+
+namespace pk {
+
+// ct2 record (doubles): 0..2 eu, 3..5 ev, 6 a0, 7 a1, 8 a2, 9 a3, 10 b1, 11 b3, 12 4*aa, 13 bb0, 14 cc0, 15 quantised box,
+// 16..19 unwrapped corner longitudes, 20..23 corner latitudes, 24..27 pv (projected corners, second coordinate: only the degenerate
+// branch of the bilinear inverse reads them), 28..31 unused
+constexpr int CT2_STRIDE = 32;
+constexpr int FC_REC_ROWS = 23;  // LDS rows of a lane's slot: record rows 0..14, then 16..23
+constexpr int FC_LANES = 64;     // one-wavefront workgroups (see CC_LANES)
+
+struct CgLds {
+    const pk_tab2* time;   // {a, 1/width} tables
+    const pk_tab2* depth;
+    double* rec;           // [FC_REC_ROWS][64] + lane
+    void* fv;              // [12][64] of the field dtype + lane
+};
+
+// per-particle evaluation context of the fast C-grid kernels
+struct CCtx {
+    int state;
+    int32_t ei;
+    int ht, hz;          // cells of the previous time / depth search (valid cell indices: hints)
+    int zi;              // memo: index or out-of-bounds code of the last depth searched
+    int gy, gx;          // the guess of the next horizontal search: the cell the previous one found (index_search.py:269-274)
+    int rc_cell;         // cell whose record sits in the lane's LDS slot, -1 = none
+    int fv_cell, fv_zt;  // tags of the cached field values: cell, (ti << 13) | (zi << 1) | (level ti+1 cached)
+    double mt, mtau, mz, mzeta;
+};
+PK_DEV void cctx_init(CCtx& c, int state, int32_t ei, int gy, int gx) {
+    c.state = state;
+    c.ei = ei;
+    c.ht = c.hz = 0;
+    c.zi = 0;
+    c.gy = gy;
+    c.gx = gx;
+    c.rc_cell = -1;
+    c.fv_cell = -1;
+    c.fv_zt = 0;
+    c.mt = c.mz = __builtin_nan("");
+    c.mtau = c.mzeta = 0.0;
+}
+
+// Fetch the ct2 record of `cell` into the lane's LDS slot -- and, WITH_F, the staggered field values of (zi, yi, xi) at level ti
+// (and ti+1 if lenT) in the same memory round trip.  Returns the packed quantised box of the cell (row 15).
+template <class FT, bool D3>
+PK_DEV void cg_issue_fields(const FastC& F, int zi, int yi, int xi, int ti, bool lenT, FT raw[12]) {
+    const uint32_t e = (uint32_t)zi * (uint32_t)F.st_z + (uint32_t)yi * (uint32_t)F.st_y + (uint32_t)xi;  // < 2^31 elements per level (host check)
+    const int64_t vb = (int64_t)((uint64_t)e * (uint64_t)(uint32_t)F.cb);
+    // byte offsets of the slots of levels ti and ti+1 (slot_off of pk_device.h).  A ring needs `level % nslots`: the level is
+    // wave-uniform unless particles of one wavefront sit on different levels, so the modulo runs on the scalar unit, once per
+    // distinct level of the wavefront (readfirstlane waterfall); every lane keeps the offsets of ITS level.
+    int64_t o0 = 0, o1 = 0;
+    for (bool done = false; !done;) {
+        const int uti = uniform_i32(ti);
+        int s0 = uti, s1 = mini(uti + 1, F.nt - 1);
+        if (F.nslots < F.nt) {  // level L lives in slot L % nslots
+            s0 = (int)((uint32_t)s0 % (uint32_t)F.nslots);
+            s1 = (int)((uint32_t)s1 % (uint32_t)F.nslots);
+        }
+        const int64_t u0 = (int64_t)s0 * F.lvl_b, u1 = (int64_t)s1 * F.lvl_b;  // derived from the uniform level BEFORE the lane test
+        if (ti == uti) {
+            o0 = u0;
+            o1 = u1;
+            done = true;
+        }
+    }
+    const int64_t b0 = vb + o0;
+    raw[0] = *reinterpret_cast<const FT*>(F.U + F.dU0 + b0);
+    raw[1] = *reinterpret_cast<const FT*>(F.U + F.dU1 + b0);
+    raw[2] = *reinterpret_cast<const FT*>(F.V + F.dV0 + b0);
+    raw[3] = *reinterpret_cast<const FT*>(F.V + F.dV1 + b0);
+    raw[4] = D3 ? *reinterpret_cast<const FT*>(F.W + F.dW0 + b0) : (FT)0;
+    raw[5] = D3 ? *reinterpret_cast<const FT*>(F.W + F.dW1 + b0) : (FT)0;
+#pragma unroll
+    for (int k = 6; k < 12; k++) raw[k] = (FT)0;
+    if (lenT) {  // per lane: a particle exactly on a time level reads that level only
+        const int64_t b1 = vb + o1;
+        raw[6] = *reinterpret_cast<const FT*>(F.U + F.dU0 + b1);
+        raw[7] = *reinterpret_cast<const FT*>(F.U + F.dU1 + b1);
+        raw[8] = *reinterpret_cast<const FT*>(F.V + F.dV0 + b1);
+        raw[9] = *reinterpret_cast<const FT*>(F.V + F.dV1 + b1);
+        if (D3) {
+            raw[10] = *reinterpret_cast<const FT*>(F.W + F.dW0 + b1);
+            raw[11] = *reinterpret_cast<const FT*>(F.W + F.dW1 + b1);
+        }
+    }
+}
+template <class FT>
+PK_DEV void cg_store_fields(CCtx& c, const CgLds& L, int cell, int zi, int ti, bool lenT, const FT raw[12]) {
+    FT* fv = (FT*)L.fv;
+#pragma unroll
+    for (int k = 0; k < 12; k++) fv[k * FC_LANES] = raw[k];
+    c.fv_cell = cell;
+    c.fv_zt = (ti << 13) | (zi << 1) | (lenT ? 1 : 0);
+}
+PK_DEV bool cg_fields_cached(const CCtx& c, int cell, int zi, int ti, bool lenT) {
+    return c.fv_cell == cell && (c.fv_zt >> 1) == ((ti << 12) | zi) && (!lenT || (c.fv_zt & 1));
+}
+
+template <class FT, bool D3, bool WITH_F>
+PK_DEV double cg_fetch_cell(const FastC& F, const CgLds& L, CCtx& c, int cell, int yi, int xi, int zi, int ti, bool lenT) {
+    const double* g = F.ct2 + (int64_t)cell * CT2_STRIDE;
+    double r[24];
+#pragma unroll
+    for (int k = 0; k < 12; k++) ldpair(g + 2 * k, r[2 * k], r[2 * k + 1]);
+    FT raw[12];
+    const bool wantf = WITH_F && zi >= 0 && !cg_fields_cached(c, cell, zi, ti, lenT);
+    if (WITH_F) {
+        if (wantf) cg_issue_fields<FT, D3>(F, zi, yi, xi, ti, lenT, raw);
+    }
+    double* rec = L.rec;
+#pragma unroll
+    for (int k = 0; k < 15; k++) rec[k * FC_LANES] = r[k];
+#pragma unroll
+    for (int k = 0; k < 8; k++) rec[(15 + k) * FC_LANES] = r[16 + k];
+    c.rc_cell = cell;
+    if (WITH_F) {
+        if (wantf) cg_store_fields<FT>(c, L, cell, zi, ti, lenT, raw);
+    }
+    return r[15];
+}
+
+// curvilinear_point_in_cell (index_search.py:94-177) on the record in the lane's LDS slot.  Bit for bit what point_in_cell ->
+// spherical_project_query -> bilinear_inverse of pk_device.h compute: the cell-only sub-expressions were formed by the table build
+// in the same order.  `cell`: for the degenerate branch (reads pv from the global record).
+PK_DEV bool cg_point_in_cell(const FastC& F, const double* rec, int cell, double qX, double qY, double qZ, double& xsi, double& eta) {
+    const double eu0 = rec[0 * FC_LANES], eu1 = rec[1 * FC_LANES], eu2 = rec[2 * FC_LANES];
+    const double ev0 = rec[3 * FC_LANES], ev1 = rec[4 * FC_LANES], ev2 = rec[5 * FC_LANES];
+    const double a0 = rec[6 * FC_LANES], a1 = rec[7 * FC_LANES], a2 = rec[8 * FC_LANES], a3 = rec[9 * FC_LANES];
+    const double b1 = rec[10 * FC_LANES], b3 = rec[11 * FC_LANES];
+    const double aa4 = rec[12 * FC_LANES], bb0 = rec[13 * FC_LANES], cc0 = rec[14 * FC_LANES];
+    const double xq = qX * eu0 + qY * eu1 + qZ * eu2;  // spherical_project_query
+    const double yq = qX * ev0 + qY * ev1 + qZ * ev2;
+    const double bb = bb0 + xq * b3 - yq * a3;
+    const double cc = cc0 + xq * b1 - yq * a1;
+    const double det2 = bb * bb - aa4 * cc;  // 4 * aa * cc with 4 * aa from the table (exact scaling)
+    const double det = det2 > 0 ? sqrt(det2) : -1.0;
+    double e;
+    if (__builtin_expect(fabs(aa4) < 4 * 1e-12, 0)) {  // |aa| < 1e-12
+        double cn = cc;
+        asm volatile("" : "+v"(cn));  // keep the rare branch a branch (see div_by_recip)
+        e = -cn / bb;
+    } else {
+        e = det2 > 0 ? (-bb + det) / (aa4 * 0.5) : -1.0;  // 2 * aa
+    }
+    const double den = a1 + a3 * e;
+    double x;
+    if (__builtin_expect(fabs(den) < 1e-12, 0)) {
+        const double* g = F.ct2 + (int64_t)cell * CT2_STRIDE;
+        double py0, py1, py2, py3;
+        ldpair(g + 24, py0, py1);
+        ldpair(g + 26, py2, py3);
+        x = ((yq - py0) / (py1 - py0) + (yq - py3) / (py2 - py3)) * 0.5;
+    } else {
+        x = (xq - a0 - a2 * e) / den;
+    }
+    xsi = x;
+    eta = e;
+    return (x >= 0) && (x <= 1) && (e >= 0) && (e <= 1);
+}
+
+// VectorField.eval (field.py:250-304) + XGrid.search (xgrid.py:316-356) + CGrid_Velocity.interp (_xinterpolators.py:193-332).
+// PF: the sample point may come straight from float32 particle storage (pos_f32); D3: sample W as well.
+template <class FT, bool PF, bool D3>
+PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtx& c, double t, double z, double y, double x, bool pos_f32, double& u,
+                           double& v, double& w) {
+    const FastC& F = a.fastc;
+    u = v = w = 0.0;
+    int ti = 0;
+    double tau = 0.0;
+    if (F.has_ti) {  // _search_time_index (index_search.py:65-91)
+        if (!(0 <= t) || !(t <= F.tlen)) {
+            c.state = PK_ERROROUTSIDETIMEINTERVAL;
+            return;
+        }
+        if (t != c.mt) {
+            int idx;
+            fast_search(L.time, F.nt, F.t0, F.t1, t, c.ht, idx, c.mtau);  // level times start at 0 (host check): idx == c.ht
+            c.mt = t;
+        }
+        ti = c.ht;
+        tau = c.mtau;
+    }
+    int zi = 0;
+    double zeta = 0.0;
+    if (F.has_z) {
+        if (!(z == c.mz)) {
+            fast_search(L.depth, F.gnz, F.z0, F.z1, z, c.hz, c.zi, c.mzeta);
+            c.mz = z;
+        }
+        zi = c.zi;
+        zeta = c.mzeta;
+    }
+    const bool lenT = tau > 0;
+    // the query point on the unit sphere (make_qpoint / latlon_rad_to_xyz)
+    double sl, cl, so, co;
+    sincos_geo(y * DEG2RAD, sl, cl);
+    sincos_geo(x * DEG2RAD, so, co);
+    const double qX = co * cl, qY = so * cl, qZ = sl;
+    // _search_indices_curvilinear_2d with a guess (index_search.py:242-295); see curvilinear_search for the probing order
+    int yi = GRID_SEARCH_ERROR, xi = GRID_SEARCH_ERROR;
+    double xsi = -1.0, eta = -1.0;
+    bool found = false;
+    const bool guess_ok = c.gy >= 0 && c.gy < F.gny - 1 && c.gx >= 0 && c.gx < F.gnx - 1;
+    if (__builtin_expect(guess_ok, 1)) {
+        const int cell = c.gy * F.gnx + c.gx;
+        if (c.rc_cell != cell) cg_fetch_cell<FT, D3, true>(F, L, c, cell, c.gy, c.gx, zi, ti, lenT);
+        double xs, et;
+        if (cg_point_in_cell(F, L.rec, cell, qX, qY, qZ, xs, et)) {
+            found = true;
+            yi = c.gy;
+            xi = c.gx;
+            xsi = xs;
+            eta = et;
+        } else if (F.walk_ok) {
+            // the particle left the guessed cell: the neighbour its barycentric coordinates point at (curvilinear_search)
+            const int dj = et < 0 ? -1 : (et > 1 ? 1 : 0), di = xs < 0 ? -1 : (xs > 1 ? 1 : 0);
+            const int nj = c.gy + dj, ni = c.gx + di;
+            if ((dj | di) != 0 && nj >= 0 && nj < F.gny - 1 && ni >= 0 && ni < F.gnx - 1) {
+                const int ncell = nj * F.gnx + ni;
+                const double boxd = cg_fetch_cell<FT, D3, true>(F, L, c, ncell, nj, ni, zi, ti, lenT);
+                double xs2, et2;
+                const double m = 1e-9;
+                if (cg_point_in_cell(F, L.rec, ncell, qX, qY, qZ, xs2, et2) && xs2 > m && xs2 < 1 - m && et2 > m && et2 < 1 - m) {
+                    if (box_lists(a.grids[F.grid], (unsigned long long)__double_as_longlong(boxd), qX, qY, qZ, true)) {
+                        found = true;
+                        yi = nj;
+                        xi = ni;
+                        xsi = (double)(float)xs2;  // rounded like a hash hit (spatialhash.py:505)
+                        eta = (double)(float)et2;
+                    }
+                }
+            }
+        }
+    }
+    if (__builtin_expect(!found, 0)) {
+        // the faces of the query's hash cell in table order (SpatialHash.query, spatialhash.py:389-535): the general routine
+        int wy, wx;
+        double wxs, wet;
+        curvilinear_search(a.grids[F.grid], y, x, false, 0, 0, wy, wx, wxs, wet);
+        yi = wy;
+        xi = wx;
+        xsi = wxs;
+        eta = wet;
+    }
+    // ravel_index (basegrid.py:83-152): the low 32 bits of the int64 sum are the wrapped 32-bit sum
+    c.ei = (int32_t)((uint32_t)xi * F.ex + (uint32_t)yi * F.ey + (uint32_t)zi * F.ez);
+    if (__builtin_expect((xi | yi | zi) < 0, 0)) {
+        int s = c.state;  // field.py:307-356
+        if (xi == GRID_SEARCH_ERROR && s < PK_ERRORGRIDSEARCHING) s = PK_ERRORGRIDSEARCHING;
+        if (zi == RIGHT_OUT_OF_BOUNDS && s < PK_ERROROUTOFBOUNDS) s = PK_ERROROUTOFBOUNDS;
+        if (zi == LEFT_OUT_OF_BOUNDS && s < PK_ERRORTHROUGHSURFACE) s = PK_ERRORTHROUGHSURFACE;
+        // field.py:359-378: a non-finite barycentric coordinate makes the (wrapped-around) gather NaN, then everything is zeroed
+        const bool bad = !(isfinite(xsi) && isfinite(eta) && isfinite(zeta) && isfinite(tau));
+        if (bad && s < PK_ERRORINTERPOLATION) s = PK_ERRORINTERPOLATION;
+        c.state = s;
+        // the next guess is what unravelling this `ei` gives (index_search.py:269-274)
+        if (xi >= 0) { c.gy = yi; c.gx = xi; }
+        else unravel_yx(a.grids[F.grid], (int64_t)c.ei, c.gy, c.gx);
+        return;
+    }
+    c.gy = yi;
+    c.gx = xi;
+    const int cell = yi * F.gnx + xi;
+    const bool need_rec = c.rc_cell != cell, need_f = !cg_fields_cached(c, cell, zi, ti, lenT);
+    if (__builtin_expect(need_rec, 0)) {  // found by the table walk
+        cg_fetch_cell<FT, D3, true>(F, L, c, cell, yi, xi, zi, ti, lenT);
+    } else if (need_f) {  // same cell, another depth or time level
+        FT raw[12];
+        cg_issue_fields<FT, D3>(F, zi, yi, xi, ti, lenT, raw);
+        cg_store_fields<FT>(c, L, cell, zi, ti, lenT, raw);
+    }
+    // ---- CGrid_Velocity.interp (_xinterpolators.py:193-332), float64 coordinates and barycentric arrays ----
+    const double* rec = L.rec;
+    double px[4], py[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { px[k] = rec[(15 + k) * FC_LANES]; py[k] = rec[(19 + k) * FC_LANES]; }
+    const FT* fv = (const FT*)L.fv;
+    FT rawf[12];
+#pragma unroll
+    for (int k = 0; k < 6; k++) rawf[k] = fv[k * FC_LANES];
+    if (lenT) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) rawf[6 + k] = fv[(6 + k) * FC_LANES];
+    }
+    const double omx = 1 - xsi, ome = 1 - eta;
+    // einsum("ij,ji->i", phi2D_lin(eta, xsi), py) at (0, xsi), (eta, 1), (1, xsi), (eta, 0): the products with an exact zero weight
+    // add +-0 to a finite sum and are left out; 1 * w is w
+    const double lat1 = omx * py[0] + xsi * py[1];
+    const double lat2 = ome * py[1] + eta * py[2];
+    const double lat3 = xsi * py[2] + omx * py[3];
+    const double lat4 = ome * py[0] + eta * py[3];
+    auto geod = [&](double la1, double la2, double lo1, double lo2, double lat) {  // _geodetic_distance (utils/interpolation.py:178-185)
+        const double dl = (lo2 - lo1) * F.deg2m, dla = (la2 - la1) * F.deg2m;
+        const double aa_ = dl * cos_lat(DEG2RAD * lat);
+        return sqrt(aa_ * aa_ + dla * dla);
+    };
+    const double c1 = geod(py[0], py[1], px[0], px[1], lat1);
+    const double c2 = geod(py[1], py[2], px[1], px[2], lat2);
+    const double c3 = geod(py[2], py[3], px[2], px[3], lat3);
+    const double c4 = geod(py[3], py[0], px[3], px[0], lat4);
+    double raw[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) raw[k] = lenT ? (double)rawf[k] * (1 - tau) + (double)rawf[6 + k] * tau : (double)rawf[k];
+    const double ua = raw[0], ub = raw[1], va = raw[2], vb = raw[3];
+    const double U0 = ua * c4, U1 = ub * c2;
+    const double Uvel = omx * U0 + xsi * U1;
+    const double V0 = va * c1, V1 = vb * c3;
+    const double Vvel = ome * V0 + eta * V1;
+    // _compute_jacobian_determinant (utils/interpolation.py:188-198)
+    const double dxs0 = eta - 1, dxs1 = ome, dxs2 = eta, dxs3 = -eta;
+    const double det0 = xsi - 1, det1 = -xsi, det2 = xsi, det3 = omx;
+    const double dxdxsi = ((dxs0 * px[0] + dxs1 * px[1]) + dxs2 * px[2]) + dxs3 * px[3];
+    const double dxdeta = ((det0 * px[0] + det1 * px[1]) + det2 * px[2]) + det3 * px[3];
+    const double dydxsi = ((dxs0 * py[0] + dxs1 * py[1]) + dxs2 * py[2]) + dxs3 * py[3];
+    const double dydeta = ((det0 * py[0] + det1 * py[1]) + det2 * py[2]) + det3 * py[3];
+    double jac = dxdxsi * dydeta - dxdeta * dydxsi;
+    jac = jac * F.deg2m;  // spherical mesh
+    const double A = -ome * Uvel - omx * Vvel;
+    const double B = ome * Uvel - xsi * Vvel;
+    const double C = eta * Uvel + xsi * Vvel;
+    const double D = -eta * Uvel + omx * Vvel;
+    const Recip rjac = make_recip(jac);
+    double uu = div_shared(A * px[0] + B * px[1] + C * px[2] + D * px[3], rjac);
+    double vv = div_shared(A * py[0] + B * py[1] + C * py[2] + D * py[3], rjac);
+    double conv;  // :311-314 (both components divided by deg2m * cos(lat))
+    if (PF && pos_f32) conv = (double)((float)F.deg2m * cosf((float)y * DEG2RADF));
+    else conv = F.deg2m * cl;  // cl == cos_lat(y * DEG2RAD): same reduction, same kernels (pk_device.h)
+    const Recip rconv = make_recip(conv);
+    uu = div_shared(uu, rconv);
+    vv = div_shared(vv, rconv);
+    double ww = 0.0;
+    if (D3) ww = raw[4] * (1 - zeta) + raw[5] * zeta;  // :316-328
+    if (__builtin_expect(uu != uu || vv != vv || ww != ww, 0)) {  // field.py:373-378
+        if (c.state < PK_ERRORINTERPOLATION) c.state = PK_ERRORINTERPOLATION;
+    }
+    u = uu;
+    v = vv;
+    w = ww;
+}
+
+}  // namespace pk

@@ -14,6 +14,7 @@
 #pragma once
 #include "pk_device.h"
 #include "pk_fast_agrid.h"
+#include "pk_fast_cgrid.h"
 
 namespace pk {
 
@@ -680,6 +681,137 @@ __global__ void __launch_bounds__(256, PK_MIN_WAVES_FAST) advect_fast_kernel(con
         if (wpaused) atomicAdd(&a.counters->paused, wpaused);
     }
 }
+
+
+// ---- AdvectionRK4 / AdvectionRK4_3D with CGrid_Velocity on a spherical curvilinear C-grid (BASELINE configs 3 / 4) -------------
+// The step loop of advect_fast_kernel around the evaluation site of pk_fast_cgrid.h; one-wavefront workgroups, because the
+// per-lane LDS slot (record of the particle's cell + its 12 staggered field values, ~15 KB per wavefront) is what bounds residency.
+#ifndef PK_MIN_WAVES_CGRID
+#define PK_MIN_WAVES_CGRID 2
+#endif
+template <class FT, int PFM, bool D3>
+__global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID) advect_cgrid_kernel(const KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const FastC& F = a.fastc;
+    CgLds L;
+    {
+        pk_tab2* s_tab = reinterpret_cast<pk_tab2*>(smem);
+        const pk_tab2* g_tab = reinterpret_cast<const pk_tab2*>(F.tab);
+        for (int k = threadIdx.x; k < F.lds_n; k += FC_LANES) s_tab[k] = g_tab[k];
+        __syncthreads();
+        L.time = s_tab + F.lds_time;
+        L.depth = s_tab + F.lds_depth;
+        L.rec = smem + F.lds_rec + threadIdx.x;  // lane-private slots: no barrier needed
+        L.fv = (void*)((FT*)(smem + F.lds_fv) + threadIdx.x);
+    }
+    auto row = [&]() { return (int64_t)xcd_swizzle(blockIdx.x, gridDim.x) * FC_LANES + threadIdx.x; };
+    unsigned steps = 0, attempts = 0, paused = 0;
+    if (row() < a.p.n) {
+        int64_t i = row();
+        const DParticles& P = a.p;
+        const pk_exec_params& prm = a.prm;
+        constexpr bool pf = PFM == 1;
+        CCtx c;
+        c.state = prm.reset_state ? PK_EVALUATE : P.state[i];  // kernel.py:188
+        if (c.state == PK_EVALUATE) {
+            {
+                const int32_t ei0 = P.ei[i * P.ngrids + F.grid];
+                int gy, gx;
+                unravel_yx(a.grids[F.grid], (int64_t)ei0, gy, gx);  // the guess of the first search (index_search.py:269-274)
+                cctx_init(c, PK_EVALUATE, ei0, gy, gx);
+            }
+            double pt = P.t[i];
+            double pz = ldp(P.z, i, pf), py = ldp(P.y, i, pf), px = ldp(P.x, i, pf);
+            double pdz = ldp(P.dz, i, pf), pdy = ldp(P.dy, i, pf), pdx = ldp(P.dx, i, pf);
+            double pdt = P.dt[i];
+            const double endtime = prm.endtime;
+            const int sign = prm.dt0 > 0 ? 1 : -1;  // kernel.py:186
+            const bool windowed = a.win_lo > -INFINITY || a.win_hi < INFINITY;
+            while (c.state == PK_EVALUATE) {  // :190
+                const double tte = sign * (endtime - pt);
+                if (!(tte >= 0)) break;  // :193-197
+                double dtc;
+                if (sign == 1) dtc = fmax(fmin(pdt, tte), 0.0);  // :200-203
+                else dtc = fmin(fmax(pdt, -tte), 0.0);
+                if (windowed) {  // field-slab streaming: step only inside the resident time window (advect_kernel)
+                    const double t1 = pt + dtc;
+                    const double lo = fmin(pt, t1), hi = fmax(pt, t1);
+                    if (lo < a.win_lo || hi > a.win_hi) { paused = 1; break; }
+                }
+                pdt = dtc;
+                attempts++;
+                // AdvectionRK4(_3D), _advection.py:42-75: (u1 + 2*u2 + 2*u3 + u4) summed left to right
+                double su = 0.0, sv = 0.0, sw = 0.0, lu = 0.0, lv = 0.0, lw = 0.0;
+#pragma unroll 1
+                for (int stage = 0; stage < 4; stage++) {
+                    double st = pt, sz = pz, sy = py, sx = px;
+                    if (stage > 0) {
+                        const double cdt = stage == 3 ? 1.0 : 0.5;  // u*1.0 == u and 1.0*dt == dt exactly
+                        sx = px + lu * cdt * pdt;
+                        sy = py + lv * cdt * pdt;
+                        if (D3) sz = pz + lw * cdt * pdt;
+                        st = pt + cdt * pdt;
+                    }
+                    double u, v, w;
+                    eval_uvw_cgrid<FT, pf, D3>(a, L, c, st, sz, sy, sx, pf && stage == 0, u, v, w);
+                    if (stage == 0) { su = u; sv = v; sw = w; }
+                    else if (stage == 3) { su = su + u; sv = sv + v; sw = sw + w; }
+                    else { su = su + 2 * u; sv = sv + 2 * v; sw = sw + 2 * w; }
+                    lu = u; lv = v; lw = w;
+                }
+                constexpr double sixth = 1.0 / 6.0;  // RN(1/6): su / 6.0 exactly (div_by_recip)
+                pdx = pstore(pf, pdx + div_by_recip(su, 6.0, sixth) * pdt);
+                pdy = pstore(pf, pdy + div_by_recip(sv, 6.0, sixth) * pdt);
+                if (D3) pdz = pstore(pf, pdz + div_by_recip(sw, 6.0, sixth) * pdt);
+                for (int k = 1; k < prm.nk; k++) {  // the sampling-free recovery kernels that may follow (Delete*)
+                    const int kid = prm.kernels[k];
+                    attempts++;
+                    if (kid == PK_KERNEL_DELETE_ON_ERROR) {
+                        if (c.state >= PK_ERROR) c.state = PK_DELETE;
+                    } else if (c.state == PK_ERROROUTOFBOUNDS || c.state == PK_ERRORTHROUGHSURFACE) {
+                        c.state = PK_DELETE;  // PK_KERNEL_DELETE_OUT_OF_BOUNDS
+                    }
+                }
+                if (c.state == PK_EVALUATE || c.state == PK_SUCCESS) {  // :219-222 -> _position_update :108-120
+                    if (tte > 0 && pt + pdt == pt) {  // dt == 0 before endtime: see advect_kernel
+                        c.state = PK_ERROR;
+                        break;
+                    }
+                    px = padd(pf, px, pdx);
+                    py = padd(pf, py, pdy);
+                    pz = padd(pf, pz, pdz);
+                    pt += pdt;
+                    pdx = pdy = pdz = 0.0;
+                    steps++;
+                }
+                pdt = prm.dt0;                                                        // :225-226 (not RK45 mode)
+                if (c.state == PK_EVALUATE && pt == endtime) c.state = PK_ENDOFLOOP;  // :229-230
+            }
+            i = row();
+            asm volatile("" : "+v"(i));
+            P.t[i] = pt;
+            stp(P.z, i, pz, pf);
+            stp(P.y, i, py, pf);
+            stp(P.x, i, px, pf);
+            stp(P.dz, i, pdz, pf);
+            stp(P.dy, i, pdy, pf);
+            stp(P.dx, i, pdx, pf);
+            P.dt[i] = pdt;
+            P.state[i] = c.state;
+            P.ei[i * P.ngrids + F.grid] = c.ei;
+        }
+    }
+    const unsigned long long wsteps = wave_sum((unsigned long long)steps), wattempts = wave_sum((unsigned long long)attempts),
+                             wpaused = wave_sum((unsigned long long)paused);
+    if ((threadIdx.x & 63) == 0) {
+        if (wsteps) atomicAdd(&a.counters->steps, wsteps);
+        if (wattempts) atomicAdd(&a.counters->attempts, wattempts);
+        if (wpaused) atomicAdd(&a.counters->paused, wpaused);
+    }
+}
+
+// fast C-grid programs: one TU defines launch_cgrid (field dtype x particle dtype x 2-D / 3-D)
+void launch_cgrid(int field_f32, int particles_f32, int d3, const KArgs& a, int64_t n, size_t lds_bytes, hipStream_t stream);
 
 // One translation unit per program (compiled in parallel) defines launch_program<PROG>.
 // key bits: field f32 | curvilinear | C-grid ; lds: coordinate vectors staged in LDS

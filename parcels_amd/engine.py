@@ -542,6 +542,7 @@ class DeviceEngine:
             total["kernel_ms"] += st.kernel_ms
             total["sort_ms"] += st.sort_ms
             total["launches"] += st.launches
+            total["program"] = int(st.program)  # which device program the (last) launch ran: include/parcels_hip.h, pk_exec_stats
             counts = {code: int(st.state_counts[code]) for code in range(_hip.PK_NUM_STATE_CODES) if st.state_counts[code]}
             if st.paused == 0:
                 break

@@ -1,0 +1,148 @@
+"""The dedicated RK4 kernels of csrc/pk_fast_cgrid.h (CGrid_Velocity on a spherical curvilinear C-grid, BASELINE configs 3 / 4)
+against the general program of the same library -- bit for bit (rtol 0: positions, t, state, ei, counters) -- and against the CPU
+oracle, on the inputs where the two code paths differ most: cell crossings in every stage (neighbour probe + record / field fetch),
+particles leaving the mesh (table walk, GridSearchingError, DeleteParticle), meshes where neighbour probing is off, level rings
+with several launches, particles of one wavefront on different time levels, backward time, float32 particles and float64 fields."""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from case_utils import build_fieldset, build_pset, compare, endtime_of, run_oracle
+
+pytestmark = pytest.mark.gpu
+
+PROGRAM_FAST_CGRID = 101
+
+
+def _run(case, fast, nslots=None, endtime=None, probe=None, sort=False):
+    import warnings
+
+    import parcels_amd as pa
+
+    from parcels_amd.engine import DeviceEngine
+
+    fs = build_fieldset(case)
+    fs.__dict__["_engine"] = DeviceEngine(fs, nslots=nslots, neighbour_probe=probe or 0)  # what FieldSet.to_device does, plus the probe switch
+    fs._engine.ctx.set_option("fast_cgrid", 1 if fast else 0)
+    pset = build_pset(case, fs, sort_by_cell=sort)
+    if case.get("populate", True):
+        pset.populate_indices()
+    kernels = [getattr(pa.kernels, k) for k in case["kernels"]]
+    kw = {"endtime": endtime_of(endtime)} if endtime is not None else {"runtime": float(case["runtime"])}
+    err = None
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        try:
+            pset.execute(kernels, dt=float(case["dt"]), **kw)
+        except (pa.FieldOutOfBoundError, pa.FieldOutOfBoundSurfaceError, pa.FieldInterpolationError, pa.GridSearchingError,
+                pa.OutsideTimeInterval, pa.GeneralError) as e:
+            err = type(e).__name__
+    return {k: np.array(v) for k, v in pset._data.items()}, err, pset._last_stats
+
+
+def _check(case, *, nslots=None, oracle=True, rtol=1e-12, endtime=None, probe=None, sort=False, expect_fast=True):
+    fast, ferr, fstats = _run(case, True, nslots, endtime, probe, sort)
+    gen, gerr, gstats = _run(case, False, nslots, endtime, probe, sort)
+    assert ferr == gerr
+    assert gstats["program"] != PROGRAM_FAST_CGRID
+    assert (fstats["program"] == PROGRAM_FAST_CGRID) == expect_fast, fstats["program"]
+    assert fstats["steps"] == gstats["steps"] and fstats["attempts"] == gstats["attempts"]
+    compare(fast, gen, rtol=0.0, check_state="all", label=case["name"] + ": fast vs general", skip=())
+    if oracle:
+        c = dict(case, populate=case.get("populate", True))
+        ref, oerr, _ = run_oracle(c, endtime=endtime)
+        assert ferr == oerr
+        if ferr is None:
+            compare(fast, ref, rtol=rtol, check_state="all", label=case["name"] + ": fast vs oracle", skip=())
+    return fast, fstats
+
+
+@pytest.mark.parametrize("kernel", ["AdvectionRK4", "AdvectionRK4_3D"])
+@pytest.mark.parametrize("fdt,sdt", [(np.float32, "float64"), (np.float64, "float64"), (np.float32, "float32"), (np.float64, "float32")])
+def test_fast_equals_general_and_oracle(gpu, kernel, fdt, sdt):
+    from oracle import cases
+
+    case = cases.curv_cgrid_case("fastc_" + kernel, mesh="spherical", kernels=[kernel, "DeleteParticle"], seed=5, npart=3000, field_dtype=fdt,
+                                 spatial_dtype=sdt, with_w=True, dt=3600.0, runtime=30 * 3600.0, vel=0.8)
+    _check(case, rtol=5e-7 if sdt == "float32" else 1e-12)
+
+
+def test_cells_are_crossed_and_particles_leave_the_mesh(gpu):
+    """Fast flow on a small mesh: most stages cross a cell edge (neighbour probe), many particles leave the mesh (the table walk
+    finds nothing: GridSearchingError -> DeleteParticle) or the depth range."""
+    from oracle import cases
+
+    case = cases.curv_cgrid_case("fastc_fast_flow", mesh="spherical", kernels=["AdvectionRK4_3D", "DeleteParticle"], seed=9, nx=48, ny=36, nz=6, nt=4,
+                                 npart=6000, dt=3600.0, runtime=60 * 3600.0, vel=6.0)
+    fast, st = _check(case)
+    assert len(fast["x"]) < 6000, "nothing left the mesh: the test does not test"
+
+
+def test_errors_raise_the_same(gpu):
+    from oracle import cases
+
+    case = cases.curv_cgrid_case("fastc_raise", mesh="spherical", kernels=["AdvectionRK4_3D"], seed=10, nx=30, ny=24, nz=5, nt=3, npart=800, dt=3600.0,
+                                 runtime=48 * 3600.0, vel=8.0)
+    fast, ferr, fst = _run(case, True)
+    gen, gerr, gst = _run(case, False)
+    assert ferr == gerr and ferr is not None
+    assert fst["program"] == PROGRAM_FAST_CGRID
+    compare(fast, gen, rtol=0.0, check_state="all", label="raise", skip=())
+
+
+@pytest.mark.parametrize("probe", [-1, 1])
+def test_table_order_search_when_neighbour_probing_is_off(gpu, probe):
+    """neighbour_probe = -1 (what a mesh with coincident nodes gets): every cell change goes through the hash-table walk."""
+    from oracle import cases
+
+    case = cases.curv_cgrid_case("fastc_walk", mesh="spherical", kernels=["AdvectionRK4_3D", "DeleteParticle"], seed=12, npart=2000, dt=3600.0,
+                                 runtime=36 * 3600.0, vel=3.0)
+    _check(case, probe=probe)
+
+
+def test_level_ring_and_staggered_release_times(gpu):
+    """Release times spread over the time levels (lanes of one wavefront on different levels: the waterfall of the field fetch
+    iterates) through a ring of 3 levels (pause / resume, several launches), cell-sorted."""
+    from oracle import cases
+
+    case = cases.curv_cgrid_case("fastc_ring", mesh="spherical", kernels=["AdvectionRK4_3D", "DeleteParticle"], seed=13, nt=6, npart=4000, dt=3600.0,
+                                 runtime=None, vel=1.5)
+    n = len(case["x"])
+    case["t0"] = np.random.default_rng(2).uniform(0, 3 * 86400.0, n)
+    case["t0"][::5] = 86400.0 * (np.arange(len(case["t0"][::5])) % 3)  # some exactly on a level
+    case["endtime"] = 4.5 * 86400.0
+    case["runtime"] = None
+    fast, fst = _check(case, endtime=case["endtime"])
+    ring, rerr, rstats = _run(case, True, nslots=3, endtime=case["endtime"], sort=True)
+    assert rerr is None and rstats["launches"] > 1 and rstats["program"] == PROGRAM_FAST_CGRID
+    compare(ring, fast, rtol=0.0, check_state="all", label="ring", skip=())
+
+
+def test_backward_in_time(gpu):
+    from oracle import cases
+
+    case = cases.curv_cgrid_case("fastc_back", mesh="spherical", kernels=["AdvectionRK4", "DeleteParticle"], seed=14, npart=2000, dt=-3600.0,
+                                 runtime=40 * 3600.0, vel=2.0)
+    case["t0"] = np.full(len(case["x"]), float(case["time_s"][-1]))
+    _check(case)
+
+
+def test_unguessed_first_launch_runs_the_general_program(gpu):
+    """Without populate_indices() the first search of the reference has no guess and returns float32 (xsi, eta) arrays
+    (spatialhash.py:505): that launch belongs to the general program; results equal with the option on or off."""
+    from oracle import cases
+
+    case = cases.curv_cgrid_case("fastc_unpop", mesh="spherical", kernels=["AdvectionRK4_3D", "DeleteParticle"], seed=15, npart=1500, dt=3600.0,
+                                 runtime=12 * 3600.0, vel=1.0)
+    case["populate"] = False
+    _check(case, expect_fast=False, oracle=False)
+
+
+def test_flat_mesh_is_not_eligible(gpu):
+    from oracle import cases
+
+    case = cases.curv_cgrid_case("fastc_flat", mesh="flat", kernels=["AdvectionRK4_3D", "DeleteParticle"], seed=16, npart=500, dt=3600.0,
+                                 runtime=6 * 3600.0, vel=1.0)
+    _check(case, expect_fast=False, oracle=False)

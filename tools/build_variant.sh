@@ -11,7 +11,7 @@ for tu in ${PK_VARIANT_TUS:-pk_prog_rk4_fast pk_prog_rk4_3d_fast}; do
 done
 wait
 OBJS=""
-for o in pk_api pk_host_stage pk_hashbuild pk_prog_rk4 pk_prog_rk4_3d pk_prog_rk45 pk_prog_m1 pk_prog_generic pk_prog_typed pk_prog_rk4_fast pk_prog_rk4_3d_fast; do
+for o in pk_api pk_host_stage pk_hashbuild pk_prog_rk4 pk_prog_rk4_3d pk_prog_rk45 pk_prog_m1 pk_prog_generic pk_prog_typed pk_prog_rk4_fast pk_prog_rk4_3d_fast pk_prog_cgrid_fast; do
   if [ -f /tmp/pkv_$NAME/$o.o ]; then OBJS="$OBJS /tmp/pkv_$NAME/$o.o"; else OBJS="$OBJS $o.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o ../libparcels_hip_$NAME.so $OBJS
