@@ -351,6 +351,22 @@ def main():
                                    "frac": traffic / kernel_s / 1e9 / HBM_PEAK_GBPS, "bytes_per_particle_step": pp["fetch_bytes"] + pp["write_bytes"]}
                 roof["counters_source"] = pj.get("source")
                 roof["counters_stale"] = pj.get("source_hash") != kernel_source_hash()  # kernels changed since the PMC passes
+                isa = os.path.join(ROOT, "profiles", "isa_latest.json")
+                if os.path.exists(isa):
+                    # what the VALU-busy fraction above is made of (tools/isa_histogram.py: instruction classes of the kernel's inner loops
+                    # from hipcc -S): only the fp64 add / mul / fma / division / sqrt instructions are arithmetic the algorithm asks for
+                    ij = json.load(open(isa))
+                    evals_s = per_gpu_steps * 4 / kernel_s  # RK4: 4 evaluations per particle-step; per lane
+                    ops = pp["valu_insts_per_wave_eval"] * ij["fp64_arith_fraction_of_valu"]
+                    flops = pp["valu_insts_per_wave_eval"] * ij["fp64_flops_per_valu_instruction_per_lane"]
+                    roof["fp64_ops_per_evaluation"] = ops  # fp64 arithmetic wave-instructions per evaluation
+                    roof["fp64_flops_per_evaluation"] = flops  # per lane, an FMA counts 2
+                    roof["frac_fp64_peak"] = flops * evals_s / 78.6e12  # of the 78.6 TFLOP/s fp64 FMA peak
+                    roof["frac_fp64_peak_no_fma"] = ops * evals_s / 39.3e12  # one operation per lane and issue slot (-ffp-contract=off: NumPy never fuses)
+                    roof["valu_class_fractions"] = ij["valu_class_fractions"]
+                    roof["valu_cycles_per_instruction_model"] = ij["valu_cycles_per_instruction"]  # fp64 / conversions 4 cycles, everything else 2
+                    roof["frac_issue_model"] = pp["valu_insts_per_wave_eval"] * ij["valu_cycles_per_instruction"] * (evals_s / 64) / (peak_cycles * 1e9)
+                    roof["isa_source"] = "profiles/isa_latest.json (tools/isa_histogram.py, static mix of the inner loops x the PMC instruction count)"
             except Exception as e:  # a malformed summary must not kill the bench line
                 roof["counters_error"] = repr(e)
         t_all = el + t_h2d + t_d2h + sort_ms * 1e-3

@@ -250,6 +250,16 @@ def compare(got, ref, *, rtol, atol_pos=0.0, check_state="all", err_mask=None, s
 
 
 # tolerance class of every golden case (see DESIGN.md "Parity"); the north star's bar is 1e-6 relative
+# Fourth tolerance class, for runs whose FIRST curvilinear search has no guess (no populate_indices()): the reference then takes
+# (xsi, eta) from the float32 buffer of the hash query (spatialhash.py:505).  The device's sin / cos of the query point differ from
+# the oracle's libm by <= 1 ulp of float64 (both are <= 1 ulp routines; neither is the reference's NumPy SIMD loop either), and where
+# that ulp straddles a float32 rounding boundary of xsi or eta the rounded value moves by one float32 ulp (6e-8): a handful of
+# particles out of 50 000 start 6e-8 of a cell width (~1e-9 of the coordinate) apart and keep that offset.  It is a discontinuity of
+# the reference itself (float32 rounding of a float64 intermediate), not an accumulation: it cannot be removed without bit-identical
+# transcendentals, so it is bounded and named here.  Populated runs (every search guessed) are in the 1e-12 class.
+UNGUESSED_CURVILINEAR_RTOL = 1e-7
+
+
 def tolerance_for(name, case):
     if case.get("spatial_dtype", "float64") == "float32":
         # one float32 ulp of the stored position: the float32 cos() of the first stage (device cosf vs NumPy's) may differ by an
