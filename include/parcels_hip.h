@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PK_ABI_VERSION 4 /* 4: pk_upload_stats, pk_host_stage_selftest, PK_KERNEL_DO_NOTHING / _MOVE_EAST / _MOVE_NORTH, vector PK_KERNEL_SAMPLE_FIELD, "cell_table" option */
+#define PK_ABI_VERSION 5 /* 5: pk_exec_params.horizon_lo / horizon_hi / max_iters, pk_exec_stats.first_error_iter / program, pk_execute_rerun, "fast_cgrid" option; 4: pk_upload_stats, pk_host_stage_selftest, PK_KERNEL_DO_NOTHING / _MOVE_EAST / _MOVE_NORTH, vector PK_KERNEL_SAMPLE_FIELD, "cell_table" option */
 #define PK_MAX_GRIDS 4
 #define PK_MAX_FIELDS 16
 #define PK_MAX_KERNELS 8
@@ -303,6 +303,13 @@ typedef struct pk_exec_params {
     double rk45_tol, rk45_min_dt, rk45_max_dt; /* fieldset.context (kernel.py:134-159)              */
     double dres;    /* fieldset.dres (_advectiondiffusion.py:40-58)                                 */
     uint64_t seed;  /* counter-based RNG seed of the stochastic kernels                             */
+    double horizon_lo, horizon_hi; /* soft time horizon (seconds; used when lo < hi, so a zeroed struct means none): a particle whose next step [t, t+dt] would leave it
+                            pauses untouched (state Evaluate, counted in pk_exec_stats.paused) exactly like at the edge of a level
+                            ring -- the host re-sorts by cell and relaunches with reset_state = 0.  No step is clipped or altered.  */
+    int32_t max_iters; /* 0 = no limit; otherwise a particle makes at most this many iterations of the loop of kernel.py:190 counted
+                            from the start of the Kernel.execute call (reset_state = 1 zeroes the per-particle count) and then stays
+                            in Evaluate: how pk_execute_rerun reproduces the reference's stop after the first erroring iteration     */
+    int32_t reserved1;
 } pk_exec_params;
 
 typedef struct pk_exec_stats {
@@ -317,8 +324,16 @@ typedef struct pk_exec_stats {
     int32_t program; /* which device program ran (diagnostic; same results whichever): 0-5 the general programs RK4, RK4_3D, kernel-list
                         interpreter, RK45, M1, dtype-emulating interpreter; 100 the dedicated A-grid kernels (csrc/pk_fast_agrid.h), 101 the
                         dedicated curvilinear C-grid kernels (csrc/pk_fast_cgrid.h)                                     */
+    int64_t first_error_iter; /* 0 = no particle entered an error state (or StopAllExecution); else the smallest 1-based index of the
+                        iteration of the loop of kernel.py:190 in which one did (kernel.py:236-245 raises after THAT iteration)          */
 } pk_exec_stats;
 int32_t pk_execute(pk_ctx* ctx, const pk_exec_params* params, pk_exec_stats* stats);
+/* kernel.py:236-245: the reference checks the error codes after every iteration of its batch loop, so when it raises, EVERY particle
+ * has made exactly as many iterations as the first erroring one.  A fused launch runs every particle to `endtime`; when its
+ * pk_exec_stats.first_error_iter is non-zero, this call restores the particle columns to their state before that launch (the launch
+ * wrote into the second column set: nothing was copied) and runs it again with max_iters = that index.  Must directly follow the
+ * pk_execute / pk_execute_end of the launch (before any pk_particles_* call); stats replace those of the launch. */
+int32_t pk_execute_rerun(pk_ctx* ctx, int32_t max_iters, pk_exec_stats* stats);
 /* The same in two halves: _begin enqueues the sort + advection kernel + statistics on the compute stream and returns;
  * the host can then stage and enqueue the NEXT field level (pk_field_upload_level async) while the RK sub-steps run;
  * _end waits and fills the statistics.  pk_execute == begin + end. */

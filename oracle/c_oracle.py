@@ -134,7 +134,7 @@ class PoParams(C.Structure):
         ("next_dt_f32", C.c_int32),
         ("force_lent", C.c_int32),
         ("force_lenz", C.c_int32),
-        ("pad2", C.c_int32),
+        ("max_iters", C.c_int32),
         ("sample_field", C.c_int32 * 8),
         ("sample_var", C.c_int32 * 8),
         ("endtime", C.c_double),
@@ -148,7 +148,7 @@ class PoParams(C.Structure):
 
 
 class PoStats(C.Structure):
-    _fields_ = [("steps", C.c_int64), ("attempts", C.c_int64)]
+    _fields_ = [("steps", C.c_int64), ("attempts", C.c_int64), ("first_error_iter", C.c_int64)]
 
 
 def build(force: bool = False) -> str:
@@ -428,11 +428,25 @@ def sample_names(vname):
     return list(vname) if isinstance(vname, (list, tuple)) else [vname]
 
 
-def execute(mc: MarshalledCase, data: dict, *, kernels, endtime, dt0, context=None, seed=0, have_guess0=0, nthreads=1):
+def execute(mc: MarshalledCase, data: dict, *, kernels, endtime, dt0, context=None, seed=0, have_guess0=0, nthreads=1, batch_stop=True,
+            _max_iters=0):
     """One Kernel.execute(pset, endtime, dt) call on the SoA dict ``data`` (updated in place).
 
-    Deleted particles are compacted afterwards like ``Kernel.remove_deleted`` (kernel.py:98-106).
+    Deleted particles are compacted afterwards like ``Kernel.remove_deleted`` (kernel.py:98-106).  ``batch_stop``: the reference
+    checks the error codes after every iteration of its batch loop (kernel.py:236-245), so when some particle errs in its k-th
+    iteration, every particle has made at most k iterations when the exception is raised: the per-particle C loop reports that k
+    and the call is run again from the same inputs with ``max_iters = k`` (False: every other particle runs on to ``endtime``).
     """
+    if batch_stop:
+        saved = {k: np.array(v, copy=True) for k, v in data.items()}
+        st = execute(mc, data, kernels=kernels, endtime=endtime, dt0=dt0, context=context, seed=seed, have_guess0=have_guess0,
+                     nthreads=nthreads, batch_stop=False)
+        if not st["first_error_iter"]:
+            return st
+        for k in list(data):
+            data[k] = saved[k]
+        return execute(mc, data, kernels=kernels, endtime=endtime, dt0=dt0, context=context, seed=seed, have_guess0=have_guess0,
+                       nthreads=nthreads, batch_stop=False, _max_iters=st["first_error_iter"])
     n = data["x"].shape[0]
     sdt = data["x"].dtype
     w = {k: np.ascontiguousarray(data[k], dtype=np.float64) for k in ("t", "z", "y", "x", "dz", "dy", "dx", "dt")}
@@ -449,6 +463,7 @@ def execute(mc: MarshalledCase, data: dict, *, kernels, endtime, dt0, context=No
     P.next_dt = _ptr(nd)
     P.state, P.ei, P.particle_id = _ptr(state), _ptr(ei), _ptr(pid)
     prm = mc.params(kernels=kernels, endtime=endtime, dt0=dt0, context=context, seed=seed, have_guess0=have_guess0)
+    prm.max_iters = int(_max_iters)
     xw = {}
     for k, vname in enumerate(getattr(mc, "sample_vars", [])):
         xw[vname] = np.ascontiguousarray(data[vname], dtype=np.float64)
@@ -470,7 +485,7 @@ def execute(mc: MarshalledCase, data: dict, *, kernels, endtime, dt0, context=No
     if not keep.all():
         for k in list(data):
             data[k] = data[k][keep]
-    return {"steps": st.steps, "attempts": st.attempts}
+    return {"steps": st.steps, "attempts": st.attempts, "first_error_iter": int(st.first_error_iter)}
 
 
 def populate_indices(mc: MarshalledCase, data: dict):

@@ -797,4 +797,19 @@ def all_cases() -> dict:
                 lc["fields"] = {k: np.ascontiguousarray(np.take(v, [0], axis=axis)) for k, v in lc["fields"].items()}
         add(lc)
 
+    # --- errors WITHOUT a recovery kernel: the reference raises after the iteration of its batch loop in which the first particle
+    #     errs (kernel.py:236-245), every other particle stopped there too.  Staggered release times (iteration k is every particle's
+    #     own k-th step, not a common time), output intervals (the iteration count restarts with every Kernel.execute), the
+    #     populated curvilinear C-grid (dedicated kernels) -------------------------------------------------------------------------
+    add(rect_agrid_case("agrid_flat_rk4_escape_stagger", mesh="flat", kernels=["AdvectionRK4"], seed=71, vel=5.0, margin=0.01, dt=1800.0,
+                        runtime=30 * 1800.0, stagger=True))
+    oc = rect_agrid_case("agrid_flat_rk4_3d_escape_outputdt", mesh="flat", kernels=["AdvectionRK4_3D"], seed=72, vel=2.5, margin=0.06, with_w=True,
+                         wscale=0.002, dt=1800.0, runtime=40 * 1800.0, npart=200)
+    oc["outputdt"] = 3.5 * 1800.0
+    add(oc)
+    pc = dict(curv_cgrid_case("cgrid_curv_sph_rk4_3d_err_populated_stagger", mesh="spherical", kernels=["AdvectionRK4_3D"], seed=73, vel=1.2))
+    pc["populate"] = True
+    pc["t0"] = np.round(_rng(74).uniform(0, 6, len(pc["x"]))) * 1800.0
+    add(pc)
+
     return c

@@ -13,7 +13,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PARCELS_HIP_LIB", os.path.join(_HERE, "libparcels_hip.so"))  # override: A/B builds
 
-PK_ABI_VERSION = 4
+PK_ABI_VERSION = 5
 PK_F32, PK_F64 = 0, 1
 PK_MAX_GRIDS, PK_MAX_FIELDS, PK_MAX_KERNELS, PK_NUM_STATE_CODES = 4, 16, 8, 80
 PK_MAX_EXTRA = 4
@@ -150,6 +150,10 @@ class ExecParams(C.Structure):
         ("rk45_max_dt", C.c_double),
         ("dres", C.c_double),
         ("seed", C.c_uint64),
+        ("horizon_lo", C.c_double),
+        ("horizon_hi", C.c_double),
+        ("max_iters", C.c_int32),
+        ("reserved1", C.c_int32),
     ]
 
 
@@ -165,6 +169,7 @@ class ExecStats(C.Structure):
         ("sort_ms", C.c_double),
         ("launches", C.c_int32),
         ("program", C.c_int32),
+        ("first_error_iter", C.c_int64),
     ]
 
 
@@ -199,6 +204,7 @@ ABI_SYMBOLS = [
     "pk_execute",
     "pk_execute_begin",
     "pk_execute_end",
+    "pk_execute_rerun",
     "pk_eval",
     "pk_search",
     "pk_measure_copy_bandwidth",
@@ -258,6 +264,7 @@ def load():
     lib.pk_execute.argtypes = [C.c_void_p, C.POINTER(ExecParams), C.POINTER(ExecStats)]
     lib.pk_execute_begin.argtypes = [C.c_void_p, C.POINTER(ExecParams)]
     lib.pk_execute_end.argtypes = [C.c_void_p, C.POINTER(ExecStats)]
+    lib.pk_execute_rerun.argtypes = [C.c_void_p, C.c_int32, C.POINTER(ExecStats)]
     lib.pk_eval.argtypes = [C.c_void_p, C.POINTER(ExecParams), C.c_int32, C.c_int64] + [C.c_void_p] * 8
     lib.pk_search.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pk_measure_copy_bandwidth.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_double)]

@@ -87,6 +87,9 @@ struct pk_ctx {
     bool in_flight = false;
     int fl_launches = 0;
     int fl_program = 0;
+    // the last advection launch wrote into the second column set, which now is `dev`; `alt` still holds what it read
+    bool rerun_valid = false;
+    pk_exec_params rerun_prm{};
     bool fl_sorted = false;
     int64_t fl_n = 0;
     DCounters* h_counters = nullptr;          // pinned: the async D2H of the counters must not block the host
@@ -563,7 +566,8 @@ static void free_snapshots(pk_ctx* ctx) {
 
 static void free_particles(pk_ctx* ctx) {
     void* cols[] = {ctx->dev.t,  ctx->dev.z,  ctx->dev.y,       ctx->dev.x,     ctx->dev.dz, ctx->dev.dy,
-                    ctx->dev.dx, ctx->dev.dt, ctx->dev.next_dt, ctx->dev.state, ctx->dev.ei, ctx->dev.particle_id};
+                    ctx->dev.dx, ctx->dev.dt, ctx->dev.next_dt, ctx->dev.state, ctx->dev.ei, ctx->dev.particle_id, ctx->dev.iter, ctx->alt.iter};
+    ctx->rerun_valid = false;
     for (void* p : cols)
         if (p) (void)hipFree(p);
     void* alts[] = {ctx->alt.t,  ctx->alt.z,  ctx->alt.y,       ctx->alt.x,     ctx->alt.dz, ctx->alt.dy,
@@ -1040,11 +1044,13 @@ int32_t pk_particles_bind(pk_ctx* ctx, const pk_particles_desc* host) {
         PK_HIP(ctx, hipMalloc((void**)&ctx->dev.state, cap * 4));
         PK_HIP(ctx, hipMalloc((void**)&ctx->dev.ei, cap * 4 * host->ngrids));
         PK_HIP(ctx, hipMalloc((void**)&ctx->dev.particle_id, cap * 8));
+        PK_HIP(ctx, hipMalloc((void**)&ctx->dev.iter, cap * 4));
         for (int k = 0; k < host->n_extra; k++) PK_HIP(ctx, hipMalloc(&ctx->dev.extra[k], cap * (host->extra_dtype[k] == PK_F32 ? 4 : 8)));
         ctx->capacity = cap;
     }
     for (int k = 0; k < PK_MAX_EXTRA; k++) ctx->dev.extra_f32[k] = ctx->alt.extra_f32[k] = (k < host->n_extra && host->extra_dtype[k] == PK_F32);
     ctx->has_perm = false;
+    ctx->rerun_valid = false;
     ctx->dev.n = host->n;
     ctx->dev.ngrids = host->ngrids;
     ctx->dev.spatial_f32 = host->spatial_dtype == PK_F32;
@@ -1078,6 +1084,7 @@ static std::vector<ColRef> particle_columns(pk_ctx* ctx) {
         {ctx->host.extra[1], ctx->dev.extra[1], ctx->alt.extra[1], (size_t)(ctx->dev.extra_f32[1] ? 4 : 8), 1},
         {ctx->host.extra[2], ctx->dev.extra[2], ctx->alt.extra[2], (size_t)(ctx->dev.extra_f32[2] ? 4 : 8), 1},
         {ctx->host.extra[3], ctx->dev.extra[3], ctx->alt.extra[3], (size_t)(ctx->dev.extra_f32[3] ? 4 : 8), 1},
+        {nullptr, ctx->dev.iter, ctx->alt.iter, 4, 1},  // device only (index PK_NCOLS: beyond the column masks of the ABI)
     };
 }
 constexpr int PK_NCOLS = 12 + PK_MAX_EXTRA;
@@ -1090,6 +1097,15 @@ static void swap_column_sets(pk_ctx* ctx) {
     std::swap(d.dz, a.dz); std::swap(d.dy, a.dy); std::swap(d.dx, a.dx); std::swap(d.dt, a.dt);
     std::swap(d.next_dt, a.next_dt); std::swap(d.state, a.state); std::swap(d.ei, a.ei); std::swap(d.particle_id, a.particle_id);
     for (int k = 0; k < PK_MAX_EXTRA; k++) std::swap(d.extra[k], a.extra[k]);
+    std::swap(d.iter, a.iter);
+    ctx->rerun_valid = false;  // the second set no longer holds the state before the last launch
+}
+// exchange the columns an advection launch writes (pk_device.h: DPOut): the launch read `dev` and wrote `alt`
+static void swap_launch_outputs(pk_ctx* ctx) {
+    DParticles &d = ctx->dev, &a = ctx->alt;
+    std::swap(d.t, a.t); std::swap(d.z, a.z); std::swap(d.y, a.y); std::swap(d.x, a.x);
+    std::swap(d.dz, a.dz); std::swap(d.dy, a.dy); std::swap(d.dx, a.dx); std::swap(d.dt, a.dt);
+    std::swap(d.next_dt, a.next_dt); std::swap(d.state, a.state); std::swap(d.ei, a.ei); std::swap(d.iter, a.iter);
 }
 
 // second column set + permutation buffers, allocated on first use (only when cell sorting is requested)
@@ -1109,6 +1125,7 @@ static int32_t ensure_alt(pk_ctx* ctx) {
     PK_HIP(ctx, hipMalloc((void**)&ctx->alt.state, cap * 4));
     PK_HIP(ctx, hipMalloc((void**)&ctx->alt.ei, cap * 4 * ctx->host.ngrids));
     PK_HIP(ctx, hipMalloc((void**)&ctx->alt.particle_id, cap * 8));
+    PK_HIP(ctx, hipMalloc((void**)&ctx->alt.iter, cap * 4));
     for (int k = 0; k < PK_MAX_EXTRA; k++)
         if (ctx->dev.extra[k]) PK_HIP(ctx, hipMalloc(&ctx->alt.extra[k], cap * (ctx->dev.extra_f32[k] ? 4 : 8)));
     PK_HIP(ctx, hipMalloc((void**)&ctx->d_perm, cap * 8));
@@ -1177,6 +1194,7 @@ static int32_t copy_particles(pk_ctx* ctx, bool to_device, uint32_t mask = 0xFFF
     if (!ctx->bound) return ctx->fail("no particles bound");
     PK_HIP(ctx, hipSetDevice(ctx->device));
     const int64_t n = ctx->host.n;
+    ctx->rerun_valid = false;  // d2h stages through the second column set, h2d replaces the state
     if (n == 0) return 0;
     if (to_device) ctx->has_perm = false;  // host order
     int bit = 0;
@@ -1416,6 +1434,11 @@ static int32_t fill_args(pk_ctx* ctx, const pk_exec_params* prm, KArgs& a, size_
         // nothing earlier / later exists at the ends of the axis: let the kernels raise code 70 there
         if (lo > 0) a.win_lo = std::max(a.win_lo, f.time[lo]);
         if (hi < f.desc.nt - 1) a.win_hi = std::min(a.win_hi, f.time[hi]);
+    }
+    // soft horizon of the launch (re-sort cadence of a long fused run): same pause as at the edge of a level ring
+    if (prm->horizon_lo < prm->horizon_hi) {  // (lo >= hi, e.g. a zeroed struct: no horizon)
+        if (prm->horizon_lo > a.win_lo) a.win_lo = prm->horizon_lo;
+        if (prm->horizon_hi < a.win_hi) a.win_hi = prm->horizon_hi;
     }
     // LDS staging of the main grid's 1-D vectors
     const int nt = mf.d.has_time_interval ? mf.d.nt : 0;
@@ -1747,7 +1770,8 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
         if (f >= 0 && ctx->fields[f].d.dtype != U.d.dtype) return ctx->fail("U, V, W must share one dtype");
     const int curv = ctx->grids[a.main_grid].d.kind == 1;
     const int64_t n = ctx->dev.n;
-    PK_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(DCounters), ctx->compute));
+    static const DCounters counters0 = {0ull, 0ull, 0ull, 0xFFFFFFFFu, 0u};
+    PK_HIP(ctx, hipMemcpyAsync(ctx->d_counters, &counters0, sizeof(DCounters), hipMemcpyHostToDevice, ctx->compute));
     PK_HIP(ctx, hipMemsetAsync(ctx->d_summary, 0, sizeof(unsigned long long) * PK_NUM_STATE_CODES, ctx->compute));
     const unsigned long long init_mm[2] = {~0ull, 0ull};
     PK_HIP(ctx, hipMemcpyAsync(ctx->d_summary + PK_NUM_STATE_CODES, init_mm, sizeof(init_mm), hipMemcpyHostToDevice, ctx->compute));
@@ -1790,6 +1814,13 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
             a.p = ctx->dev;  // the column pointers were swapped
             sorted = true;
         }
+        // the launch reads `dev` and writes the second column set (pk_device.h: DPOut), which then becomes `dev`: the state before
+        // the launch survives in `alt` at no cost, for pk_execute_rerun
+        rc = ensure_alt(ctx);
+        if (rc) return rc;
+        a.p = ctx->dev;
+        a.po = DPOut{ctx->alt.t, ctx->alt.z, ctx->alt.y, ctx->alt.x, ctx->alt.dz, ctx->alt.dy, ctx->alt.dx, ctx->alt.dt, ctx->alt.next_dt,
+                     ctx->alt.state, ctx->alt.ei, ctx->alt.iter};
         PK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->compute));
         const size_t fast_lds = fast_a ? (size_t)a.fast.lds_n * 2 * sizeof(double) : 0;
         const int pf32 = ctx->dev.spatial_f32;
@@ -1808,6 +1839,9 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
         PK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->compute));
         launches = 1;
         ctx->fl_program = fast_a ? 100 : (fast_c ? 101 : prog);
+        swap_launch_outputs(ctx);
+        ctx->rerun_valid = true;
+        ctx->rerun_prm = *prm;
         const unsigned sgrid = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
         hipLaunchKernelGGL(summarize_kernel, dim3(sgrid), dim3(256), 0, ctx->compute, ctx->dev.state, ctx->dev.t, n, ctx->d_summary);
         PK_HIP(ctx, hipGetLastError());
@@ -1852,8 +1886,23 @@ int32_t pk_execute_end(pk_ctx* ctx, pk_exec_stats* stats) {
         stats->sort_ms = sms;
         stats->launches = ctx->fl_launches;
         stats->program = ctx->fl_launches ? ctx->fl_program : 0;
+        stats->first_error_iter = (ctx->fl_launches && hc.err_iter != 0xFFFFFFFFu) ? (int64_t)hc.err_iter : 0;
     }
     return 0;
+}
+
+int32_t pk_execute_rerun(pk_ctx* ctx, int32_t max_iters, pk_exec_stats* stats) {
+    if (!ctx) return -2;
+    if (ctx->in_flight) return ctx->fail("pk_execute_rerun: a launch is in flight (call pk_execute_end)");
+    if (!ctx->rerun_valid) return ctx->fail("pk_execute_rerun: the state before the last launch is gone (it must directly follow pk_execute / pk_execute_end)");
+    if (max_iters < 1) return ctx->fail("pk_execute_rerun: max_iters must be >= 1");
+    swap_launch_outputs(ctx);  // `dev` is the state the launch read again (cell-sorted if it sorted: the permutation is unchanged)
+    pk_exec_params prm = ctx->rerun_prm;
+    prm.sort_by_cell = 0;
+    prm.max_iters = max_iters;
+    int32_t rc = pk_execute_begin(ctx, &prm);
+    if (rc) return rc;
+    return pk_execute_end(ctx, stats);
 }
 
 int32_t pk_execute(pk_ctx* ctx, const pk_exec_params* prm, pk_exec_stats* stats) {

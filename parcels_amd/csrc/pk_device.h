@@ -73,10 +73,27 @@ struct DParticles {
     int64_t* particle_id;
     void* extra[PK_MAX_EXTRA];        // user Variables written by device kernels (PK_KERNEL_SAMPLE_FIELD)
     int32_t extra_f32[PK_MAX_EXTRA];  // 1: float32 column, 0: float64
+    int32_t* iter;                    // device only: loop iterations (kernel.py:190) the particle has made since this Kernel.execute call began
+};
+
+// Where a launch WRITES the particle state.  The advection kernels read a particle from DParticles (KArgs::p) and write it here:
+// the host points this at the second column set, so the set a launch read stays intact -- the state before the launch, for free --
+// and the launch can be repeated with an iteration limit when some particle raised an error (pk_execute_rerun, kernel.py:236-245:
+// the reference stops every particle after the iteration in which the first one erred).  particle_id and the user Variables are
+// not part of it (never written / rewritten by every iteration).
+struct DPOut {
+    double* t;
+    void *z, *y, *x, *dz, *dy, *dx;
+    double* dt;
+    double* next_dt;
+    int32_t* state;
+    int32_t* ei;
+    int32_t* iter;
 };
 
 struct DCounters {
     unsigned long long steps, attempts, paused;
+    unsigned int err_iter, pad;  // smallest iteration index (1-based) in which a particle entered an error state; 0xFFFFFFFF = none
 };
 
 // Wave-uniform constants of the fast path for XLinear_Velocity on a rectilinear A-grid with float64 coordinates
@@ -129,6 +146,7 @@ struct KArgs {
     int32_t lds_time, lds_depth, lds_lat, lds_lon, lds_total;
     int32_t lds_cc_nodes, lds_cc_keys, lds_cc_fvals;  // cell cache (CellCache) offsets in doubles from the LDS base, -1 = off
     int32_t main_grid, main_field;
+    DPOut po;  // output columns of the launch (== the columns of `p` for an in-place launch)
     union {  // at most one of the dedicated kernels runs per launch
         FastA fast;
         FastC fastc;

@@ -356,6 +356,29 @@ PK_DEV void consume(int kid, int stage, const PCtx& c, KLocal& L, double u, doub
     }
 }
 
+// A lane that does not step in this launch (its state was not Evaluate when a paused call is continued) hands its row from the
+// columns the launch reads to the columns it writes (no-op for an in-place launch).
+PK_DEV void copy_row_through(const DParticles& P, const DPOut& O, int64_t i, bool pf) {
+    if (O.t == P.t) return;
+    O.t[i] = P.t[i];
+    stp(O.z, i, ldp(P.z, i, pf), pf);
+    stp(O.y, i, ldp(P.y, i, pf), pf);
+    stp(O.x, i, ldp(P.x, i, pf), pf);
+    stp(O.dz, i, ldp(P.dz, i, pf), pf);
+    stp(O.dy, i, ldp(P.dy, i, pf), pf);
+    stp(O.dx, i, ldp(P.dx, i, pf), pf);
+    O.dt[i] = P.dt[i];
+    if (P.next_dt) O.next_dt[i] = P.next_dt[i];
+    O.state[i] = P.state[i];
+    for (int g = 0; g < P.ngrids; g++) O.ei[i * P.ngrids + g] = P.ei[i * P.ngrids + g];
+    O.iter[i] = P.iter[i];
+}
+// kernel.py:236-245: the first iteration (1-based, counted per particle since the Kernel.execute call began) that left a particle in
+// an error state or StopAllExecution -- the reference raises / returns after THAT iteration of its batch loop
+PK_DEV void note_error_iteration(const KArgs& a, int state, unsigned it) {
+    if (state >= PK_ERROR || state == PK_STOPALLEXECUTION) atomicMin(&a.counters->err_iter, it);
+}
+
 PK_DEV unsigned long long wave_sum(unsigned long long v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -431,13 +454,17 @@ __global__ void __launch_bounds__(wg_size(KIND, LDS), (KIND == 1 || INTERP != 0)
     unsigned long long steps = 0, attempts = 0, paused = 0;
     if (i < a.p.n) {
         const DParticles& P = a.p;
+        const DPOut& O = a.po;
         const pk_exec_params& prm = a.prm;
         PCtx c;
         const bool pf = PFM < 0 ? (P.spatial_f32 != 0) : (PFM == 1);
         c.pf = pf;
         c.row = i;
         c.state = prm.reset_state ? PK_EVALUATE : P.state[i];  // kernel.py:188
-        if (c.state == PK_EVALUATE) {
+        if (c.state != PK_EVALUATE) {
+            copy_row_through(P, O, i, pf);
+        } else {
+            unsigned it = prm.reset_state ? 0u : (unsigned)P.iter[i];
             c.hz = c.hy = c.hx = c.ht = 0;
             c.hyx_valid = false;
             c.first_eval = prm.reset_state ? 0xFu : 0u;
@@ -465,6 +492,7 @@ __global__ void __launch_bounds__(wg_size(KIND, LDS), (KIND == 1 || INTERP != 0)
             while (c.state == PK_EVALUATE || c.state == PK_REPEAT) {  // :190
                 const double tte = sign * (endtime - p.t);
                 if (!(tte >= 0)) break;  // :193-197 (state is Evaluate here)
+                if (prm.max_iters > 0 && it >= (unsigned)prm.max_iters) break;  // pk_execute_rerun: stop where the reference raised
                 double dtc;
                 if (sign == 1) dtc = fmax(fmin(p.dt, tte), 0.0);  // :200-203
                 else dtc = fmin(fmax(p.dt, -tte), 0.0);
@@ -475,6 +503,7 @@ __global__ void __launch_bounds__(wg_size(KIND, LDS), (KIND == 1 || INTERP != 0)
                     const double lo = fmin(p.t, t1), hi = fmax(p.t, t1);
                     if (lo < a.win_lo || hi > a.win_hi) { paused = 1; break; }
                 }
+                it++;
                 p.dt = dtc;
                 for (int k = 0; k < nk; k++) {  // :206-216
                     const int kid = KID >= 0 ? KID : prm.kernels[k];
@@ -532,20 +561,22 @@ __global__ void __launch_bounds__(wg_size(KIND, LDS), (KIND == 1 || INTERP != 0)
                 if (!prm.rk45_mode) p.dt = prm.dt0;                                 // :225-226
                 if (c.state == PK_EVALUATE && p.t == endtime) c.state = PK_ENDOFLOOP;  // :229-230
             }
-            P.t[i] = p.t;
-            stp(P.z, i, p.z, pf);
-            stp(P.y, i, p.y, pf);
-            stp(P.x, i, p.x, pf);
-            stp(P.dz, i, p.dz, pf);
-            stp(P.dy, i, p.dy, pf);
-            stp(P.dx, i, p.dx, pf);
-            P.dt[i] = p.dt;
-            if (P.next_dt) P.next_dt[i] = p.next_dt;
-            P.state[i] = c.state;
-            P.ei[i * ng] = c.ei0;
-            if (ng > 1) P.ei[i * ng + 1] = c.ei1;
-            if (ng > 2) P.ei[i * ng + 2] = c.ei2;
-            if (ng > 3) P.ei[i * ng + 3] = c.ei3;
+            O.t[i] = p.t;
+            stp(O.z, i, p.z, pf);
+            stp(O.y, i, p.y, pf);
+            stp(O.x, i, p.x, pf);
+            stp(O.dz, i, p.dz, pf);
+            stp(O.dy, i, p.dy, pf);
+            stp(O.dx, i, p.dx, pf);
+            O.dt[i] = p.dt;
+            if (P.next_dt) O.next_dt[i] = p.next_dt;
+            O.state[i] = c.state;
+            O.ei[i * ng] = c.ei0;
+            if (ng > 1) O.ei[i * ng + 1] = c.ei1;
+            if (ng > 2) O.ei[i * ng + 2] = c.ei2;
+            if (ng > 3) O.ei[i * ng + 3] = c.ei3;
+            O.iter[i] = (int32_t)it;
+            note_error_iteration(a, c.state, it);
         }
     }
     steps = wave_sum(steps);
@@ -586,11 +617,15 @@ __global__ void __launch_bounds__(256, PK_MIN_WAVES_FAST) advect_fast_kernel(con
     if (row() < a.p.n) {
         int64_t i = row();
         const DParticles& P = a.p;
+        const DPOut& O = a.po;
         const pk_exec_params& prm = a.prm;
         constexpr bool pf = PFM == 1;
         FCtx c;
         c.state = prm.reset_state ? PK_EVALUATE : P.state[i];  // kernel.py:188
-        if (c.state == PK_EVALUATE) {
+        if (c.state != PK_EVALUATE) {
+            copy_row_through(P, O, i, pf);
+        } else {
+            unsigned it = prm.reset_state ? 0u : (unsigned)P.iter[i];
             fctx_init(c, PK_EVALUATE, P.ei[i * P.ngrids + a.fast.grid]);  // only the velocity grid's `ei` is touched
             double pt = P.t[i];
             double pz = ldp(P.z, i, pf), py = ldp(P.y, i, pf), px = ldp(P.x, i, pf);
@@ -602,6 +637,7 @@ __global__ void __launch_bounds__(256, PK_MIN_WAVES_FAST) advect_fast_kernel(con
             while (c.state == PK_EVALUATE) {  // :190 (no kernel of these programs sets Repeat)
                 const double tte = sign * (endtime - pt);
                 if (!(tte >= 0)) break;  // :193-197
+                if (prm.max_iters > 0 && it >= (unsigned)prm.max_iters) break;  // pk_execute_rerun: stop where the reference raised
                 double dtc;
                 if (sign == 1) dtc = fmax(fmin(pdt, tte), 0.0);  // :200-203
                 else dtc = fmin(fmax(pdt, -tte), 0.0);
@@ -610,6 +646,7 @@ __global__ void __launch_bounds__(256, PK_MIN_WAVES_FAST) advect_fast_kernel(con
                     const double lo = fmin(pt, t1), hi = fmax(pt, t1);
                     if (lo < a.win_lo || hi > a.win_hi) { paused = 1; break; }
                 }
+                it++;
                 pdt = dtc;
                 attempts++;
                 // AdvectionRK4(_3D), _advection.py:42-75: (u1 + 2*u2 + 2*u3 + u4) summed left to right
@@ -661,16 +698,19 @@ __global__ void __launch_bounds__(256, PK_MIN_WAVES_FAST) advect_fast_kernel(con
             }
             i = row();
             asm volatile("" : "+v"(i));  // keep it re-derived: not hoisted above the loop
-            P.t[i] = pt;
-            stp(P.z, i, pz, pf);
-            stp(P.y, i, py, pf);
-            stp(P.x, i, px, pf);
-            stp(P.dz, i, pdz, pf);
-            stp(P.dy, i, pdy, pf);
-            stp(P.dx, i, pdx, pf);
-            P.dt[i] = pdt;
-            P.state[i] = c.state;
-            P.ei[i * P.ngrids + a.fast.grid] = c.ei;
+            O.t[i] = pt;
+            stp(O.z, i, pz, pf);
+            stp(O.y, i, py, pf);
+            stp(O.x, i, px, pf);
+            stp(O.dz, i, pdz, pf);
+            stp(O.dy, i, pdy, pf);
+            stp(O.dx, i, pdx, pf);
+            O.dt[i] = pdt;
+            if (P.next_dt && O.next_dt != P.next_dt) O.next_dt[i] = P.next_dt[i];
+            O.state[i] = c.state;
+            for (int g = 0; g < P.ngrids; g++) O.ei[i * P.ngrids + g] = g == a.fast.grid ? c.ei : P.ei[i * P.ngrids + g];
+            O.iter[i] = (int32_t)it;
+            note_error_iteration(a, c.state, it);
         }
     }
     const unsigned long long wsteps = wave_sum((unsigned long long)steps), wattempts = wave_sum((unsigned long long)attempts),
@@ -709,11 +749,15 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID) advect_cgrid_ker
     if (row() < a.p.n) {
         int64_t i = row();
         const DParticles& P = a.p;
+        const DPOut& O = a.po;
         const pk_exec_params& prm = a.prm;
         constexpr bool pf = PFM == 1;
         CCtx c;
         c.state = prm.reset_state ? PK_EVALUATE : P.state[i];  // kernel.py:188
-        if (c.state == PK_EVALUATE) {
+        if (c.state != PK_EVALUATE) {
+            copy_row_through(P, O, i, pf);
+        } else {
+            unsigned it = prm.reset_state ? 0u : (unsigned)P.iter[i];
             {
                 const int32_t ei0 = P.ei[i * P.ngrids + F.grid];
                 int gy, gx;
@@ -730,6 +774,7 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID) advect_cgrid_ker
             while (c.state == PK_EVALUATE) {  // :190
                 const double tte = sign * (endtime - pt);
                 if (!(tte >= 0)) break;  // :193-197
+                if (prm.max_iters > 0 && it >= (unsigned)prm.max_iters) break;  // pk_execute_rerun: stop where the reference raised
                 double dtc;
                 if (sign == 1) dtc = fmax(fmin(pdt, tte), 0.0);  // :200-203
                 else dtc = fmin(fmax(pdt, -tte), 0.0);
@@ -738,6 +783,7 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID) advect_cgrid_ker
                     const double lo = fmin(pt, t1), hi = fmax(pt, t1);
                     if (lo < a.win_lo || hi > a.win_hi) { paused = 1; break; }
                 }
+                it++;
                 pdt = dtc;
                 attempts++;
                 // AdvectionRK4(_3D), _advection.py:42-75: (u1 + 2*u2 + 2*u3 + u4) summed left to right
@@ -789,16 +835,19 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID) advect_cgrid_ker
             }
             i = row();
             asm volatile("" : "+v"(i));
-            P.t[i] = pt;
-            stp(P.z, i, pz, pf);
-            stp(P.y, i, py, pf);
-            stp(P.x, i, px, pf);
-            stp(P.dz, i, pdz, pf);
-            stp(P.dy, i, pdy, pf);
-            stp(P.dx, i, pdx, pf);
-            P.dt[i] = pdt;
-            P.state[i] = c.state;
-            P.ei[i * P.ngrids + F.grid] = c.ei;
+            O.t[i] = pt;
+            stp(O.z, i, pz, pf);
+            stp(O.y, i, py, pf);
+            stp(O.x, i, px, pf);
+            stp(O.dz, i, pdz, pf);
+            stp(O.dy, i, pdy, pf);
+            stp(O.dx, i, pdx, pf);
+            O.dt[i] = pdt;
+            if (P.next_dt && O.next_dt != P.next_dt) O.next_dt[i] = P.next_dt[i];
+            O.state[i] = c.state;
+            for (int g = 0; g < P.ngrids; g++) O.ei[i * P.ngrids + g] = g == F.grid ? c.ei : P.ei[i * P.ngrids + g];
+            O.iter[i] = (int32_t)it;
+            note_error_iteration(a, c.state, it);
         }
     }
     const unsigned long long wsteps = wave_sum((unsigned long long)steps), wattempts = wave_sum((unsigned long long)attempts),

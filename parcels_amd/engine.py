@@ -243,6 +243,7 @@ class DeviceEngine:
                 for lv in range(self.field_host[f.name].shape[0]):
                     self._upload(f.name, lv, asynchronous=False)
         self.windowed = any(self.field_nslots[f.name] < self.field_host[f.name].shape[0] for f in self.scalar_fields)
+        self.exact_error_stop = True  # kernel.py:236-245: after an error every particle stops where the reference's batch loop did
 
     def _upload(self, name, level, asynchronous):
         leader = self.pack_leader_of.get(name)
@@ -466,7 +467,8 @@ class DeviceEngine:
         return out
 
     # ---- execution -------------------------------------------------------------------------------------------
-    def make_params(self, kernel_ids, *, endtime, dt0, context=None, seed=0, reset_state=1, have_guess0=0, sort_by_cell=0, samples=None):
+    def make_params(self, kernel_ids, *, endtime, dt0, context=None, seed=0, reset_state=1, have_guess0=0, sort_by_cell=0, samples=None,
+                    horizon=None, max_iters=0):
         fs = self.fieldset
         context = context or {}
         p = _hip.ExecParams()
@@ -497,6 +499,8 @@ class DeviceEngine:
         p.rk45_max_dt = float(context.get("RK45_max_dt", 0.0))
         p.dres = float(context.get("dres", 0.0))
         p.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        p.horizon_lo, p.horizon_hi = (-np.inf, np.inf) if horizon is None else (float(horizon[0]), float(horizon[1]))
+        p.max_iters = int(max_iters)
         for slot in range(_hip.PK_MAX_KERNELS):
             p.sample_field[slot] = p.sample_var[slot] = -1
         for slot, (fname, var) in (samples or {}).items():
@@ -504,17 +508,31 @@ class DeviceEngine:
             p.sample_var[slot] = int(var)
         return p
 
-    def execute(self, kernel_ids, *, endtime, dt0, context=None, seed=0, have_guess0=0, sort_by_cell=0, t_start=None, samples=None) -> dict:
-        """One Kernel.execute(pset, endtime, dt) on the bound (device-resident) particle columns."""
+    def execute(self, kernel_ids, *, endtime, dt0, context=None, seed=0, have_guess0=0, sort_by_cell=0, t_start=None, samples=None,
+                resort_every=None) -> dict:
+        """One Kernel.execute(pset, endtime, dt) on the bound (device-resident) particle columns.
+
+        ``resort_every`` (seconds of model time, with ``sort_by_cell``): the fused launch is cut at a soft horizon every that many
+        seconds -- particles pause untouched before a step that would cross it -- and the device rows are re-sorted by cell before the
+        next piece, so that the gather locality of a long run does not decay.  Trajectories do not depend on it.
+
+        When a particle enters an error state the reference raises after THAT iteration of its batch loop (kernel.py:236-245), with
+        every other particle stopped there too: the launch is repeated from the state before it with that iteration limit
+        (``pk_execute_rerun``; ``self.exact_error_stop = False`` skips this and leaves the other particles at ``endtime``)."""
         sign = 1 if dt0 > 0 else -1
         import time as _time
 
         # host-side split of a streamed run: commit = synchronous level uploads before a launch, prefetch = staging + enqueueing
         # the next level while the kernel runs, wait = pk_execute_end after the prefetch was enqueued
-        total = {"steps": 0, "attempts": 0, "kernel_ms": 0.0, "sort_ms": 0.0, "launches": 0, "commit_s": 0.0, "prefetch_s": 0.0, "wait_s": 0.0}
+        total = {"steps": 0, "attempts": 0, "kernel_ms": 0.0, "sort_ms": 0.0, "launches": 0, "commit_s": 0.0, "prefetch_s": 0.0, "wait_s": 0.0,
+                 "first_error_iter": 0, "reran": 0}
         reset = 1
         t_live = t_start
         last_live = None
+        span = None
+        if resort_every and sort_by_cell:
+            ctx_ = context or {}
+            span = max(float(resort_every), abs(float(dt0)), abs(float(ctx_.get("RK45_max_dt", 0.0))))
         while True:
             nxt = None
             if self.windowed:
@@ -523,8 +541,11 @@ class DeviceEngine:
                 _t = _time.perf_counter()
                 nxt = self._commit_window(float(t_live), sign)
                 total["commit_s"] += _time.perf_counter() - _t
+            horizon = None
+            if span is not None and t_live is not None and np.isfinite(t_live):
+                horizon = (-np.inf, float(t_live) + span) if sign > 0 else (float(t_live) - span, np.inf)
             prm = self.make_params(kernel_ids, endtime=endtime, dt0=dt0, context=context, seed=seed, reset_state=reset,
-                                   have_guess0=(have_guess0 if reset else 1), sort_by_cell=sort_by_cell, samples=samples)
+                                   have_guess0=(have_guess0 if reset else 1), sort_by_cell=sort_by_cell, samples=samples, horizon=horizon)
             st = _hip.ExecStats()
             self.ctx.check(self.lib.pk_execute_begin(self.ctx.handle, C.byref(prm)), "pk_execute_begin")
             prefetched = False
@@ -537,6 +558,14 @@ class DeviceEngine:
                 self.ctx.check(self.lib.pk_execute_end(self.ctx.handle, C.byref(st)), "pk_execute_end")
                 total["wait_s"] += _time.perf_counter() - _t
             reset = 0
+            if st.first_error_iter > 0 and self.exact_error_stop:
+                # kernel.py:236-245: stop every particle after the iteration in which the first one erred
+                total["first_error_iter"] = int(st.first_error_iter)
+                total["reran"] += 1
+                ms = st.kernel_ms
+                st = _hip.ExecStats()
+                self.ctx.check(self.lib.pk_execute_rerun(self.ctx.handle, int(total["first_error_iter"]), C.byref(st)), "pk_execute_rerun")
+                st.kernel_ms += ms
             total["steps"] += st.steps
             total["attempts"] += st.attempts
             total["kernel_ms"] += st.kernel_ms
@@ -544,18 +573,21 @@ class DeviceEngine:
             total["launches"] += st.launches
             total["program"] = int(st.program)  # which device program the (last) launch ran: include/parcels_hip.h, pk_exec_stats
             counts = {code: int(st.state_counts[code]) for code in range(_hip.PK_NUM_STATE_CODES) if st.state_counts[code]}
-            if st.paused == 0:
+            if st.paused == 0 or total["reran"]:
                 break
-            if not self.windowed:
+            if not self.windowed and span is None:
                 raise _hip.HipLibraryError("particles paused although all time levels are resident (internal error)")
             t_live = st.t_min_live if sign > 0 else st.t_max_live
             # no particle moved AND no new level is on its way (a small ring needs one launch per cycle just to bring in the
             # level behind the window; the next commit makes it resident): the step itself does not fit
             if last_live is not None and t_live == last_live and not prefetched:
-                raise RuntimeError(
-                    "field window too small: a single step does not fit into the resident time levels; "
-                    "increase nslots (FieldSet.to_device(nslots=...))"
-                )
+                if span is not None:
+                    span *= 2.0  # the soft horizon, not the ring, stopped every particle: widen it
+                else:
+                    raise RuntimeError(
+                        "field window too small: a single step does not fit into the resident time levels; "
+                        "increase nslots (FieldSet.to_device(nslots=...))"
+                    )
             last_live = t_live
         total["state_counts"] = counts
         self.last_stats = total

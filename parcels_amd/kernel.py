@@ -152,8 +152,12 @@ class Kernel:
             raise KeyError("next_dt: fieldset.context has RK45_tol (RK45 mode) but the ParticleClass has no next_dt Variable")
         sign = 1 if dt > 0 else -1
         t_start = pset._t_live if getattr(pset, "_t_live", None) is not None else float(np.nanmin(data["t"]) if sign > 0 else np.nanmax(data["t"]))
+        every = getattr(pset, "resort_every", None)
+        if every is None:
+            every = getattr(type(pset), "RESORT_EVERY_DEFAULT", None)
         stats = engine.execute(self.kernel_ids, endtime=endtime, dt0=dt, context=self.fieldset.context, seed=pset.seed,
-                               have_guess0=have_guess0, sort_by_cell=int(pset.sort_by_cell), t_start=t_start, samples=self.samples)
+                               have_guess0=have_guess0, sort_by_cell=int(pset.sort_by_cell), t_start=t_start, samples=self.samples,
+                               resort_every=every or None)
         pset._last_stats = stats
         return stats
 

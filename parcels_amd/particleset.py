@@ -71,11 +71,16 @@ class ParticleSet:
     """Collection of particles stored as a dict of NumPy columns (particle.py:182-222).
 
     ``seed`` keys the counter-based RNG of the stochastic kernels; ``sort_by_cell`` lets the engine reorder the
-    device copy by grid cell for gather locality (host row order is never affected)."""
+    device copy by grid cell for gather locality (host row order is never affected): "auto" (default) sorts sets of at least
+    ``SORT_AUTO_MIN`` particles; ``resort_every`` (seconds of model time, None = ``RESORT_EVERY_DEFAULT``, 0 = never) is the cadence at
+    which a long fused launch is cut and re-sorted (measured on BASELINE config 2)."""
+
+    SORT_AUTO_MIN = 100_000
+    RESORT_EVERY_DEFAULT = 30 * 86400.0  # profiles/r03_c2_long_run.json: over 23 days of C2 the locality of ONE sort does not decay (re-sorting only costs)
 
 
     def __init__(self, fieldset, pclass=Particle, *, t=None, z=None, y=None, x=None, particle_ids=None, seed=0,
-                 sort_by_cell=False, shard=None, **kwargs):
+                 sort_by_cell="auto", resort_every=None, shard=None, **kwargs):
         """``shard``: None = all particles live here; ``(rank, world)`` or ``"auto"`` (rank / world size of the initialised
         torch.distributed group) = every process is given the SAME arrays and keeps its contiguous block of the id space
         (parcels_amd.distributed.shard_slice) -- fields are replicated, particles never migrate, and a ParticleFile gathers
@@ -85,7 +90,10 @@ class ParticleSet:
         self.fieldset = fieldset
         self._kernel = None
         self.seed = int(seed)
-        self.sort_by_cell = bool(sort_by_cell)
+        self._sort_by_cell = sort_by_cell if isinstance(sort_by_cell, str) else bool(sort_by_cell)
+        if isinstance(sort_by_cell, str) and sort_by_cell != "auto":
+            raise ValueError(f"sort_by_cell must be True, False or 'auto'. Got {sort_by_cell!r}")
+        self.resort_every = resort_every
         self.device_compaction = True  # deleted particles are removed on the device (False: through NumPy on the host)
         self.async_output = True  # ParticleFile tables are encoded on a writer thread behind the next interval (False: inline)
         self._last_stats = None
@@ -143,6 +151,17 @@ class ParticleSet:
             if kwvar not in names:
                 raise RuntimeError(f"Particle class does not have Variable {kwvar}")
             self._data[kwvar][:] = kwval
+
+    @property
+    def sort_by_cell(self) -> bool:
+        """Whether launches cell-sort the device copy ("auto": from SORT_AUTO_MIN particles on)."""
+        if isinstance(self._sort_by_cell, str):
+            return len(self) >= self.SORT_AUTO_MIN
+        return self._sort_by_cell
+
+    @sort_by_cell.setter
+    def sort_by_cell(self, value):
+        self._sort_by_cell = value if isinstance(value, str) else bool(value)
 
     # -- container protocol (particleset.py:140-190) ---------------------------------------------------------------
     def __getattr__(self, name):

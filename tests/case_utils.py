@@ -164,12 +164,12 @@ def endtime_of(seconds):
     return np.timedelta64(int(round(float(seconds) * 1e9)), "ns")
 
 
-def run_hip(case, endtime=None, nslots=None, async_output=None, **pset_kw):
+def run_hip(case, endtime=None, nslots=None, async_output=None, fieldset=None, **pset_kw):
     """Run a case through parcels_amd (HIP). Returns (soa dict, error name or None, stats).  nslots: stream the field levels
     through a ring of that many slots (None: the engine decides, i.e. resident for test-sized fields)."""
     import parcels_amd as pa
 
-    fs = build_fieldset(case)
+    fs = fieldset if fieldset is not None else build_fieldset(case)
     if nslots is not None:
         fs.to_device(nslots=nslots)
     pset = build_pset(case, fs, **pset_kw)
