@@ -43,7 +43,7 @@ from .particle import Particle, ParticleClass, Variable, get_default_particle
 from .particlefile import ParticleFile, read_particlefile
 from .particleset import ParticleSet, ParticleSetWarning
 from .sgrid import FaceNodePadding, Padding, SGrid2DMetadata
-from .sources import LevelSource, NpyLevels, ZarrLevels
+from .sources import LevelSource, NetCDFLevels, NpyLevels, ZarrLevels, read_netcdf_variable
 from .statuscodes import (
     AllParcelsErrorCodes,
     FieldInterpolationError,

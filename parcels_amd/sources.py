@@ -16,6 +16,9 @@ A level source is anything with
 ``StructuredModelData`` does for in-memory arrays (model.py:135-143).
 
 * ``NpyLevels``  -- a directory / list of ``.npy`` files, one per time level (memory-mapped).
+* ``NetCDFLevels`` -- one variable of a NetCDF-4 (HDF5: contiguous or chunked, deflate / shuffle / fletcher32) or classic NetCDF-3
+  file, or of a list of such files that continue each other in time (one file per day / month, as models write them); CF packing
+  (scale_factor, add_offset, _FillValue, missing_value) is undone.  The reader is parcels_amd/hdf5.py: no netCDF4 / h5py needed.
 * ``ZarrLevels`` -- one array of a zarr v2 or v3 directory store on a local filesystem, chunked with ONE time level per chunk along
   the first axis (chunks may split z / y / x), compressor null, zstd, lz4, gzip or blosc (lz4 / zstd / zlib inner codec, byte
   shuffle) -- the formats pyarrow's codecs can decode; no zarr / numcodecs installation is needed.
@@ -30,7 +33,7 @@ import struct
 
 import numpy as np
 
-__all__ = ["LevelSource", "NpyLevels", "ZarrLevels", "is_level_source"]
+__all__ = ["LevelSource", "NetCDFLevels", "NpyLevels", "ZarrLevels", "is_level_source", "read_netcdf_variable"]
 
 
 class LevelSource:
@@ -91,6 +94,123 @@ class NpyLevels(LevelSource):
 
     def read_level(self, k):
         return np.load(self.paths[k], mmap_mode="r").reshape(self.shape[1:])
+
+
+def cf_unpack(a: np.ndarray, attrs: dict, fill_dtype=None) -> np.ndarray:
+    """CF conventions: _FillValue / missing_value -> NaN, then packed * scale_factor + add_offset in the dtype of those attributes
+    (what xarray's decode_cf does for the reference, convert.py:308-408 via xr.open_dataset).  Integer data without packing
+    attributes becomes float64."""
+    sf, ao = attrs.get("scale_factor"), attrs.get("add_offset")
+    fv = [np.asarray(attrs[k]).ravel() for k in ("_FillValue", "missing_value") if k in attrs]
+    if a.dtype.kind == "f" and sf is None and ao is None and not fv:
+        return a
+    out_dt = np.result_type(*[np.asarray(v).dtype for v in (sf, ao) if v is not None], np.float32) if (sf is not None or ao is not None) else (
+        a.dtype if a.dtype.kind == "f" else np.dtype(np.float64))
+    if a.dtype.kind == "f" and a.dtype.itemsize > np.dtype(out_dt).itemsize:
+        out_dt = a.dtype
+    mask = None
+    for v in fv:
+        for x in v:
+            m = np.isnan(a) if (isinstance(x, (float, np.floating)) and np.isnan(x)) else (a == x)
+            mask = m if mask is None else (mask | m)
+    out = a.astype(out_dt)
+    if sf is not None:
+        out *= np.asarray(sf, dtype=out_dt).ravel()[0]
+    if ao is not None:
+        out += np.asarray(ao, dtype=out_dt).ravel()[0]
+    if mask is not None and mask.any():
+        out[mask] = np.nan
+    return out
+
+
+def _open_netcdf(path):
+    """HDF5File (NetCDF-4) or NetCDF3File (classic) by the magic number."""
+    from . import hdf5
+
+    with open(path, "rb") as fh:
+        magic = fh.read(4)
+    return hdf5.NetCDF3File(path) if magic[:3] == b"CDF" else hdf5.HDF5File(path)
+
+
+def read_netcdf_variable(path, name, decode=True) -> np.ndarray:
+    """A whole (small) variable -- coordinates, time axes, masks -- of a NetCDF-4 or classic NetCDF file as a NumPy array."""
+    f = _open_netcdf(path)
+    try:
+        if hasattr(f, "vars"):
+            a, attrs = f.read(name), f.vars[name]["attrs"]
+        else:
+            d = f.dataset(name)
+            a, attrs = d.read(), d.attrs
+        return cf_unpack(a, attrs) if decode else a
+    finally:
+        f.close()
+
+
+class NetCDFLevels(LevelSource):
+    """``NetCDFLevels("U_y2000.nc", "vozocrtx")`` or ``NetCDFLevels(["U_m01.nc", "U_m02.nc", ...], "vozocrtx")``: a (time, [z,] y, x)
+    variable read one time level per request (for a chunked variable: only the chunks of that level are read and inflated).
+    ``dims``: which of "tzyx" the variable's axes are when it has fewer than four (default "tyx" for 3-D, "yx" for 2-D)."""
+
+    def __init__(self, paths, variable, dims=None, fill_nan=True):
+        if isinstance(paths, (str, os.PathLike)):
+            p = str(paths)
+            paths = sorted(glob.glob(p)) if any(ch in p for ch in "*?[") else [p]
+        self.paths = [str(p) for p in paths]
+        if not self.paths:
+            raise ValueError("NetCDFLevels: no file found")
+        self.variable = variable
+        self._files = [None] * len(self.paths)
+        self._nt = []
+        vshape = None
+        for k in range(len(self.paths)):
+            shp, dt, attrs = self._meta(k)
+            if vshape is None:
+                vshape, self._vdtype, self.attrs = shp, dt, attrs
+            elif shp[1:] != vshape[1:] or dt != self._vdtype:
+                raise ValueError(f"{self.paths[k]}: variable {variable!r} has shape {shp} / dtype {dt}, the first file {vshape} / {self._vdtype}")
+            self._nt.append(shp[0] if self._has_t(shp, dims) else 1)
+        nd = len(vshape)
+        dims = dims or {4: "tzyx", 3: "tyx", 2: "yx", 1: "x"}.get(nd)
+        if dims is None or len(dims) != nd or any(c not in "tzyx" for c in dims) or list(dims) != sorted(dims, key="tzyx".index):
+            raise ValueError(f"NetCDFLevels: variable {variable!r} has {nd} axes; dims={dims!r} must name them in t, z, y, x order")
+        self._dims = dims
+        self._offsets = np.concatenate([[0], np.cumsum(self._nt)])
+        level = tuple(vshape[dims.index(c)] if c in dims else 1 for c in "zyx")
+        self.shape = (int(self._offsets[-1]),) + level
+        probe = cf_unpack(np.zeros(1, self._vdtype), self.attrs)
+        self.dtype = np.dtype(np.float32 if probe.dtype == np.float32 else np.float64)
+        self.fill_nan = fill_nan
+
+    @staticmethod
+    def _has_t(shp, dims):
+        return (dims or {4: "tzyx", 3: "tyx"}.get(len(shp), "")).startswith("t")
+
+    def _file(self, k):
+        if self._files[k] is None:
+            self._files[k] = _open_netcdf(self.paths[k])
+        return self._files[k]
+
+    def _meta(self, k):
+        f = self._file(k)
+        if hasattr(f, "vars"):
+            v = f.vars[self.variable]
+            return tuple(f.shape(self.variable)), v["dtype"].newbyteorder("="), v["attrs"]
+        d = f.dataset(self.variable)
+        return tuple(d.shape), np.dtype(d.dtype).newbyteorder("="), d.attrs
+
+    def read_level(self, k):
+        fi = int(np.searchsorted(self._offsets, k, side="right") - 1)
+        local = int(k - self._offsets[fi])
+        f = self._file(fi)
+        first = local if self._dims.startswith("t") else None
+        a = f.read(self.variable, first) if hasattr(f, "vars") else f.dataset(self.variable).read(first)
+        return cf_unpack(a, self.attrs).reshape(self.shape[1:])
+
+    def close(self):
+        for k, f in enumerate(self._files):
+            if f is not None:
+                f.close()
+                self._files[k] = None
 
 
 # ---- zarr v2 ----------------------------------------------------------------------------------------------------------------
@@ -187,7 +307,17 @@ class ZarrLevels(LevelSource):
             raise FileNotFoundError(f"{self.root}: neither .zarray (zarr v2) nor zarr.json (zarr v3)")
         if self.chunks[0] != 1:
             raise ValueError(f"the time axis must be chunked one level per chunk, got chunks={self.chunks}")
-        self.dtype = np.dtype(np.float64 if self.zdtype.itemsize == 8 else np.float32) if self.zdtype.kind == "f" else np.dtype(np.float64)
+        # CF packing attributes (.zattrs of zarr v2, "attributes" of zarr.json): packed integers are unpacked level by level
+        self.attrs = {}
+        za = os.path.join(self.root, ".zattrs")
+        raw_attrs = json.load(open(za)) if os.path.exists(za) else (meta.get("attributes") or {})
+        for key in ("scale_factor", "add_offset", "_FillValue", "missing_value"):
+            if isinstance(raw_attrs.get(key), (int, float)):
+                self.attrs[key] = np.float32(raw_attrs[key]) if (key in ("scale_factor", "add_offset") and self.zdtype.itemsize <= 2) else (
+                    np.float64(raw_attrs[key]) if key in ("scale_factor", "add_offset") else np.asarray(raw_attrs[key]).astype(self.zdtype if self.zdtype.kind != "f" else np.float64))
+        self.dtype = np.dtype(cf_unpack(np.zeros(1, self.zdtype), self.attrs).dtype)
+        if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+            self.dtype = np.dtype(np.float64)
         rest = self.zshape[1:]
         if not (1 <= len(rest) <= 3):
             raise ValueError(f"expected a (time, [z,] [y,] x) array, got shape {self.zshape}")
@@ -218,14 +348,26 @@ class ZarrLevels(LevelSource):
     def read_level(self, k):
         rest_shape, rest_chunks = self.zshape[1:], self.chunks[1:]
         out = np.empty(rest_shape, dtype=self.zdtype)
+        missing = None  # cells of unwritten chunks of an INTEGER array whose fill value is null / "NaN": NaN after unpacking
         grid = [range((s + c - 1) // c) for s, c in zip(rest_shape, rest_chunks)]
         for idx in np.ndindex(*[len(g) for g in grid]):
             path = os.path.join(self.root, self._key((k,) + tuple(idx)))
             sl = tuple(slice(i * c, min((i + 1) * c, s)) for i, c, s in zip(idx, rest_chunks, rest_shape))
             if not os.path.exists(path):  # an unwritten chunk holds the fill value
-                out[sl] = np.nan if self.fill_value in (None, "NaN") else self.fill_value  # "NaN": the JSON spelling of both formats
+                nanfill = self.fill_value in (None, "NaN")  # "NaN": the JSON spelling of both formats
+                if nanfill and self.zdtype.kind != "f":
+                    out[sl] = 0
+                    if missing is None:
+                        missing = np.zeros(rest_shape, dtype=bool)
+                    missing[sl] = True
+                else:
+                    out[sl] = np.nan if nanfill else self.fill_value
                 continue
             buf = self._decode(open(path, "rb").read())
             chunk = np.frombuffer(buf, dtype=self.zdtype, count=int(np.prod(rest_chunks))).reshape(rest_chunks)
             out[sl] = chunk[tuple(slice(0, s.stop - s.start) for s in sl)]
+        out = cf_unpack(out, self.attrs)
+        if missing is not None:
+            out = out.astype(self.dtype, copy=False)
+            out[missing] = np.nan
         return out.reshape(self.shape[1:])

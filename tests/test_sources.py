@@ -168,6 +168,21 @@ def _case_on_disk(tmp_path, kind):
             for k in range(arr.shape[0]):
                 np.save(d / f"{k:04d}.npy", arr[k])
             lazy["fields"][name] = pa.NpyLevels(str(d))
+        elif kind == "netcdf3":  # classic NetCDF, two files that continue each other in time (what scipy can write without libhdf5)
+            from scipy.io import netcdf_file
+
+            paths = []
+            for part, sl in enumerate((slice(0, 3), slice(3, None))):
+                p = str(tmp_path / f"{name}_{part}.nc")
+                with netcdf_file(p, "w", version=2) as nc:
+                    nc.createDimension("time_counter", None)
+                    for dn, n in zip(("z", "y", "x"), arr.shape[1:]):
+                        nc.createDimension(dn, n)
+                    v = nc.createVariable(name, "f4", ("time_counter", "z", "y", "x"))
+                    for k, lvl in enumerate(arr[sl]):
+                        v[k] = lvl
+                paths.append(p)
+            lazy["fields"][name] = pa.NetCDFLevels(paths, name)
         else:
             _write_zarr_v2(str(tmp_path / "store.zarr"), name, arr, (1, 3, 20, 16), "zstd")
             lazy["fields"][name] = pa.ZarrLevels(str(tmp_path / "store.zarr"), name)
@@ -182,7 +197,7 @@ def test_fieldset_accepts_level_sources(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["npy", "zarr"])
+@pytest.mark.parametrize("kind", ["npy", "zarr", "netcdf3"])
 def test_advection_from_level_sources_equals_in_memory_fields(gpu, tmp_path, kind):
     """Levels read from disk on demand into a ring of 3 (and all at once into a resident device copy) give the trajectories of the
     in-memory NumPy fields, bit for bit."""
@@ -249,3 +264,58 @@ def test_streamed_levels_are_read_once_and_at_most_three_are_resident(gpu, tmp_p
         assert (touched[0] == 0) if direction > 0 else (touched[-1] == nt - 1)
         assert touched == list(range(touched[0], touched[-1] + 1))  # contiguous: nothing skipped, nothing beyond the run read
     assert 2 <= resident_max <= 3
+
+
+@pytest.mark.gpu
+def test_advection_from_a_netcdf4_file_equals_in_memory_fields(gpu):
+    """The reference's own NetCDF-4 input (tests/test_data/test_interpolation_data_random_linear.nc, re-packed by h5repack to one
+    deflated chunk per time level: tests/golden/hdf5/) as U, V, W of a FieldSet: read one level per request into a ring of 3 device
+    slots -- every level read exactly once -- and all at once; the trajectories equal those of the in-memory arrays, bit for bit."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hdf5", "reference_linear_chunked_gzip.nc")
+    rd = lambda n: pa.read_netcdf_variable(path, n)
+    lon, lat, depth, time_s = rd("lon"), rd("lat"), rd("depth"), rd("time")
+    rng = np.random.default_rng(3)
+    n = 2000
+    case = dict(name="nc4", mesh="flat", lon=lon, lat=lat, depth=depth, x_pad="low", y_pad="low", z_pad="both", time_s=time_s - time_s[0],
+                fields={k: rd(k) for k in "UVW"}, field_dims={k: ("time", "depth", "YG", "XG") for k in "UVW"}, cgrid=False,
+                kernels=["AdvectionRK4_3D", "DeleteParticle"], spatial_dtype="float64",
+                x=rng.uniform(lon[2], lon[-3], n), y=rng.uniform(lat[2], lat[-3], n), z=rng.uniform(depth[1], depth[-2], n), t0=None,
+                dt=float(time_s[1] - time_s[0]) / 4, runtime=float(time_s[-1] - time_s[0]) * 0.8, seed=0)
+    ref = build_pset(case, build_fieldset(case))
+    ref.execute([pa.AdvectionRK4_3D, pa.DeleteParticle], dt=case["dt"], runtime=case["runtime"])
+    want = {k: np.array(v) for k, v in ref._data.items()}
+    assert len(want["x"]) > 0 and ref._last_stats["steps"] > 10 * len(want["x"])
+    for ns in (3, None):
+        lazy = dict(case)
+        lazy["fields"] = {k: _CountingLevels(pa.NetCDFLevels(path, k)) for k in "UVW"}
+        fs = build_fieldset(lazy)
+        fs.to_device(nslots=ns)
+        pset = build_pset(lazy, fs)
+        pset.execute([pa.AdvectionRK4_3D, pa.DeleteParticle], dt=case["dt"], runtime=case["runtime"])
+        compare({k: np.array(v) for k, v in pset._data.items()}, want, rtol=0.0, check_state="all", label=f"netcdf4 nslots={ns}", skip=())
+        for src in lazy["fields"].values():
+            assert all(v == 1 for v in src.reads.values()), src.reads
+            if ns is not None:
+                assert pset._last_stats["launches"] > 1 and len(src.reads) < len(time_s)  # levels beyond the run are never read
+
+
+def test_zarr_levels_unpack_cf_packed_integers(tmp_path):
+    """An int16 zarr array with scale_factor / add_offset in .zattrs and an unwritten chunk (fill_value null): values are unpacked
+    per level, the missing chunk reads as NaN (then 0), nothing raises (`cannot convert float NaN to integer`)."""
+    rng = np.random.default_rng(5)
+    raw = rng.integers(-3000, 3000, (3, 2, 8, 10)).astype(np.int16)
+    _write_zarr_v2(str(tmp_path), "P", raw.astype(np.float32), (1, 2, 4, 10), None)  # writes float chunks: rewrite them as int16 below
+    d = os.path.join(str(tmp_path), "P")
+    meta = json.load(open(os.path.join(d, ".zarray")))
+    meta["dtype"], meta["fill_value"] = "<i2", None
+    json.dump(meta, open(os.path.join(d, ".zarray"), "w"))
+    for k in range(3):
+        for j in range(2):
+            open(os.path.join(d, f"{k}.0.{j}.0"), "wb").write(np.ascontiguousarray(raw[k, :, 4 * j:4 * j + 4, :]).tobytes())
+    os.remove(os.path.join(d, "1.0.1.0"))
+    json.dump({"scale_factor": 0.001, "add_offset": 2.0}, open(os.path.join(d, ".zattrs"), "w"))
+    src = pa.ZarrLevels(str(tmp_path), "P")
+    assert src.dtype == np.float32
+    lv = src.read_level(1)
+    assert np.isnan(lv[:, 4:, :]).all() and np.allclose(lv[:, :4, :], raw[1, :, :4, :].astype(np.float32) * np.float32(0.001) + np.float32(2.0), rtol=1e-6)
+    assert np.all(src.level(1)[:, 4:, :] == 0.0)
