@@ -78,6 +78,12 @@ def nemo_to_sgrid(*, fields: dict, coords) -> Dataset:
             dims = ["y_center" if d == "y" else d for d in dims]
         elif new_name == "V":
             dims = ["x_center" if d == "x" else d for d in dims]
+        from .sources import is_level_source
+
+        if is_level_source(da.data):
+            raise TypeError(f"nemo_to_sgrid needs the values of field {name!r} in memory (it drops singleton dimensions and negates W): pass "
+                            "np.asarray / np.memmap here, or build the Dataset with the level source directly (dims time, depth, y, x and "
+                            "W already negated: parcels_amd.Dataset, DESIGN.md section 8)")
         a = np.asarray(da.data)
         keep = [i for i, d in enumerate(dims) if d in _NEMO_KEEP_DIMS]  # convert.py:175-186: unknown dimensions are dropped
         if len(keep) != len(dims):

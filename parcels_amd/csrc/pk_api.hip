@@ -79,6 +79,7 @@ struct pk_ctx {
     // pinned staging ring for async level uploads
     void* stage[PK_STAGE_BUFFERS] = {};
     size_t stage_bytes[PK_STAGE_BUFFERS] = {};
+    size_t stage_chunk = 0;  // bytes per staging chunk: the largest streamed level (x its packed components), at most PK_STAGE_CHUNK_BYTES
     hipEvent_t stage_ev[PK_STAGE_BUFFERS] = {};
     int stage_next = 0;
     double stage_fill_s = 0, stage_wait_s = 0, stage_bytes_total = 0;  // pk_upload_stats
@@ -352,8 +353,9 @@ static int32_t stage_acquire(pk_ctx* ctx, int* out) {
     const int k = ctx->stage_next;
     ctx->stage_next = (k + 1) % PK_STAGE_BUFFERS;
     if (!ctx->stage[k]) {
-        PK_HIP(ctx, hipHostMalloc(&ctx->stage[k], PK_STAGE_CHUNK_BYTES, hipHostMallocDefault));
-        ctx->stage_bytes[k] = PK_STAGE_CHUNK_BYTES;
+        if (!ctx->stage_chunk) ctx->stage_chunk = PK_STAGE_CHUNK_BYTES;
+        PK_HIP(ctx, hipHostMalloc(&ctx->stage[k], ctx->stage_chunk, hipHostMallocDefault));
+        ctx->stage_bytes[k] = ctx->stage_chunk;
     } else {
         const double t0 = now_s();
         PK_HIP(ctx, hipEventSynchronize(ctx->stage_ev[k]));
@@ -833,11 +835,27 @@ int32_t pk_field_create(pk_ctx* ctx, const pk_field_desc* desc, int32_t* field_i
         PK_HIP(ctx, hipMemset(f.dev_data, 0, f.level_bytes * nslots * ncomp));  // never expose NaN garbage (weight-0 reads)
     }
     if (nslots < desc->nt) {
-        // a streamed field: pin the staging chunks now (pinning 768 MiB costs ~0.2 s -- at creation, not inside the first run)
+        // a streamed field: pin the staging chunks now (at creation, not inside the first run), sized for the largest streamed level --
+        // at most 3 x 256 MiB (pinning that costs ~0.2 s), a few MB for a small field: locked memory is scarce on shared nodes
+        const size_t mib = (size_t)1 << 20;
+        const size_t want_raw = f.level_bytes * (size_t)(desc->pack_count > 1 ? desc->pack_count : 1);
+        size_t want = std::min(PK_STAGE_CHUNK_BYTES, (want_raw + mib - 1) / mib * mib);
+        if (want > ctx->stage_chunk) {
+            PK_HIP(ctx, hipStreamSynchronize(ctx->copy));
+            for (int k = 0; k < PK_STAGE_BUFFERS; k++)
+                if (ctx->stage[k]) { (void)hipHostFree(ctx->stage[k]); ctx->stage[k] = nullptr; }
+            ctx->stage_chunk = want;
+        }
         for (int k = 0; k < PK_STAGE_BUFFERS; k++)
             if (!ctx->stage[k]) {
-                PK_HIP(ctx, hipHostMalloc(&ctx->stage[k], PK_STAGE_CHUNK_BYTES, hipHostMallocDefault));
-                ctx->stage_bytes[k] = PK_STAGE_CHUNK_BYTES;
+                hipError_t e = hipHostMalloc(&ctx->stage[k], ctx->stage_chunk, hipHostMallocDefault);
+                while (e != hipSuccess && k == 0 && ctx->stage_chunk > 16 * mib) {  // pinning failed: smaller chunks (more DMA calls, same result)
+                    (void)hipGetLastError();
+                    ctx->stage_chunk /= 2;
+                    e = hipHostMalloc(&ctx->stage[k], ctx->stage_chunk, hipHostMallocDefault);
+                }
+                if (e != hipSuccess) return ctx->fail("hipHostMalloc of a staging chunk", e);
+                ctx->stage_bytes[k] = ctx->stage_chunk;
                 PK_HIP(ctx, hipEventRecord(ctx->stage_ev[k], ctx->copy));
             }
     }
@@ -904,7 +922,7 @@ int32_t pk_field_upload_level(pk_ctx* ctx, int32_t field_id, int32_t level, cons
         PK_HIP(ctx, hipStreamSynchronize(ctx->copy));
     } else {
         // pageable NumPy memory cannot be DMA'd asynchronously: bounce it through the ring of pinned chunks
-        const size_t chunk = PK_STAGE_CHUNK_BYTES;
+        const size_t chunk = ctx->stage_chunk ? ctx->stage_chunk : PK_STAGE_CHUNK_BYTES;
         for (size_t off = 0; off < f.level_bytes; off += chunk) {
             const size_t len = std::min(chunk, f.level_bytes - off);
             int k;
@@ -944,7 +962,7 @@ int32_t pk_field_upload_group_level(pk_ctx* ctx, int32_t leader_id, int32_t leve
     const size_t esz = L.desc.dtype == PK_F64 ? 8 : 4;
     const size_t level_elems = L.level_bytes / esz;
     char* dst = (char*)L.dev_data + (size_t)slot * L.level_bytes * ncomp;
-    const size_t chunk_elems = PK_STAGE_CHUNK_BYTES / (esz * ncomp);
+    const size_t chunk_elems = (ctx->stage_chunk ? ctx->stage_chunk : PK_STAGE_CHUNK_BYTES) / (esz * ncomp);
     for (size_t off = 0; off < level_elems; off += chunk_elems) {
         const size_t len = std::min(chunk_elems, level_elems - off);
         int k;

@@ -33,14 +33,21 @@ def _ptr(a):
 class _LazyLevels:
     """A level source (parcels_amd.sources) behind the `host[level]` indexing the engine uses for NumPy arrays."""
 
-    def __init__(self, src, dtype):
+    def __init__(self, src, dtype, fill_nan=True):
         self.src, self.dtype = src, np.dtype(dtype)
         self.shape = tuple(src.shape)
         self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self.fill_nan = bool(fill_nan)
 
     def __getitem__(self, level):
-        lvl = self.src.level(int(level), self.dtype) if hasattr(self.src, "level") else np.ascontiguousarray(self.src.read_level(int(level)), dtype=self.dtype)
-        return lvl
+        """One level ready for the upload, whatever the source (a LevelSource or any object with read_level / shape / dtype): shape
+        checked, NaN -> 0 per the model's setting (model.py:135-143), C-contiguous, target dtype."""
+        a = np.asarray(self.src.read_level(int(level)))
+        if tuple(a.shape) != self.shape[1:]:
+            raise ValueError(f"level {level} of {type(self.src).__name__} has shape {a.shape}, expected {self.shape[1:]}")
+        if self.fill_nan and np.issubdtype(a.dtype, np.floating) and np.isnan(a).any():
+            a = np.nan_to_num(a, nan=0.0)
+        return np.ascontiguousarray(a, dtype=self.dtype)
 
 
 class DeviceEngine:
@@ -159,7 +166,8 @@ class DeviceEngine:
             a = f.data.data
             tgt = share.get(f.name, np.float32 if np.dtype(a.dtype) == np.float32 else np.float64)
             if is_level_source(a):
-                hosts[f.name] = _LazyLevels(a, tgt)  # levels are read (and converted) when `_upload` asks for them
+                fill = getattr(f.model, "level_fill_nan", {}).get(f.name, getattr(a, "fill_nan", True))
+                hosts[f.name] = _LazyLevels(a, tgt, fill_nan=fill)  # levels are read (and converted) when `_upload` asks for them
             else:  # no copy for a C-contiguous array / np.memmap of the target dtype
                 hosts[f.name] = np.ascontiguousarray(np.asarray(a), dtype=tgt)
         # residency plan: keep all levels if they fit the budget, else a ring

@@ -130,7 +130,10 @@ class StructuredModelData:
                 for want, got, d in zip("ZYX", axes, da.dims[1:]):
                     if got not in (want, None) or (got is None and not str(d).startswith("mock")):
                         raise ValueError(f"level source '{name}': dimension '{d}' is not the {want} axis of the grid (use 'mock{want}' for an absent axis)")
-                da.data.fill_nan = bool(getattr(da.data, "fill_nan", True)) and not skip_field_data_validation
+                # NaN -> 0 at read time unless validation is skipped: kept HERE (the engine asks for it), the caller's source object is
+                # shared by every FieldSet built from it and is left alone
+                self.level_fill_nan = getattr(self, "level_fill_nan", {})
+                self.level_fill_nan[name] = bool(getattr(da.data, "fill_nan", True)) and not skip_field_data_validation
                 continue
             da = transpose_to_tzyx(ds.data_vars[name], md)
             if not skip_field_data_validation and np.issubdtype(da.data.dtype, np.floating):
