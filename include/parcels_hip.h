@@ -258,6 +258,8 @@ int32_t pk_particles_d2h(pk_ctx* ctx);
 #define PK_COL_PARTICLE_ID 0x800u
 #define PK_COL_EXTRA0 0x1000u /* extra column k: PK_COL_EXTRA0 << k */
 int32_t pk_particles_d2h_columns(pk_ctx* ctx, uint32_t column_mask);
+/* Selection of a pk_exec_params.body_only launch: mask[i] != 0 <=> host row i takes part (n int32 values in host row order). */
+int32_t pk_particles_set_mask(pk_ctx* ctx, const int32_t* mask);
 /* Asynchronous write-out (ParticleSet.execute's output step, particleset.py:452-459, overlapped with the next interval):
  * _begin snapshots the selected columns -- un-sorted into host row order -- into one of two device staging sets on the compute
  * stream and enqueues their copy into pinned host columns on the copy stream; it returns at once and the next pk_execute may
@@ -309,7 +311,11 @@ typedef struct pk_exec_params {
     int32_t max_iters; /* 0 = no limit; otherwise a particle makes at most this many iterations of the loop of kernel.py:190 counted
                             from the start of the Kernel.execute call (reset_state = 1 zeroes the per-particle count) and then stays
                             in Evaluate: how pk_execute_rerun reproduces the reference's stop after the first erroring iteration     */
-    int32_t reserved1;
+    int32_t body_only; /* 1: run the kernel list ONCE on every particle selected by pk_particles_set_mask (the `evaluate_particles` of
+                            kernel.py:193-195, fixed for one iteration whatever a kernel does to the states) and return: no dt clipping,
+                            no position update, no EndofLoop, states neither reset nor interpreted -- the caller owns the loop of
+                            kernel.py:190-245.  This is how arbitrary Python kernels run next to device
+                            kernels (parcels_amd/hostkernels.py: the loop on the host columns, the built-in kernels' bodies here).   */
 } pk_exec_params;
 
 typedef struct pk_exec_stats {

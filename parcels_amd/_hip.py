@@ -153,7 +153,7 @@ class ExecParams(C.Structure):
         ("horizon_lo", C.c_double),
         ("horizon_hi", C.c_double),
         ("max_iters", C.c_int32),
-        ("reserved1", C.c_int32),
+        ("body_only", C.c_int32),
     ]
 
 
@@ -197,6 +197,7 @@ ABI_SYMBOLS = [
     "pk_particles_h2d",
     "pk_particles_d2h",
     "pk_particles_d2h_columns",
+    "pk_particles_set_mask",
     "pk_particles_snapshot_begin",
     "pk_particles_snapshot_wait",
     "pk_particles_device",
@@ -257,6 +258,7 @@ def load():
     lib.pk_particles_h2d.argtypes = [C.c_void_p]
     lib.pk_particles_d2h.argtypes = [C.c_void_p]
     lib.pk_particles_d2h_columns.argtypes = [C.c_void_p, C.c_uint32]
+    lib.pk_particles_set_mask.argtypes = [C.c_void_p, C.c_void_p]
     lib.pk_particles_snapshot_begin.argtypes = [C.c_void_p, C.c_uint32, C.c_int32]
     lib.pk_particles_snapshot_wait.argtypes = [C.c_void_p, C.c_int32, C.POINTER(ParticlesDesc)]
     lib.pk_particles_device.argtypes = [C.c_void_p, C.POINTER(ParticlesDesc), C.POINTER(C.c_void_p)]

@@ -1244,6 +1244,16 @@ int32_t pk_particles_d2h(pk_ctx* ctx) {
     if (!ctx) return -2;
     return copy_particles(ctx, false);
 }
+int32_t pk_particles_set_mask(pk_ctx* ctx, const int32_t* mask) {
+    if (!ctx || !mask) return -2;
+    if (!ctx->bound) return ctx->fail("no particles bound");
+    if (ctx->has_perm) return ctx->fail("pk_particles_set_mask: the device rows are cell-sorted (body_only launches run on host-ordered rows: pk_particles_h2d first)");
+    PK_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->dev.n > 0) PK_HIP(ctx, hipMemcpyAsync(ctx->dev.iter, mask, (size_t)ctx->dev.n * 4, hipMemcpyHostToDevice, ctx->compute));
+    PK_HIP(ctx, hipStreamSynchronize(ctx->compute));
+    return 0;
+}
+
 int32_t pk_particles_d2h_columns(pk_ctx* ctx, uint32_t mask) {
     if (!ctx) return -2;
     return copy_particles(ctx, false, mask);
@@ -1807,6 +1817,7 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
             if (prm->kernels[0] == PK_KERNEL_ADVECTION_RK45 && !ctx->no_special) prog = PROG_RK45;
             if (prm->kernels[0] == PK_KERNEL_ADVECTIONDIFFUSION_M1 && !ctx->no_special) prog = PROG_M1;
         }
+        if (prm->body_only) prog = PROG_GENERIC;  // only the kernel-list interpreter knows the mode
         if (ctx_is_typed(ctx)) prog = PROG_TYPED;
         bool fast_a = false, fast_c = false;  // a.fast / a.fastc share storage: at most one is filled
         size_t cgrid_lds = 0;
@@ -1819,7 +1830,7 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
             if (rc) return rc;
             fast_c = a.fastc.ok != 0;
         }
-        if (prm->sort_by_cell) {
+        if (prm->sort_by_cell && !prm->body_only) {
             PK_HIP(ctx, hipEventRecord(ctx->ev2, ctx->compute));
             // curvilinear sort order (measured on the NEMO-size grid): depth-major for 3-D advection (+4 %), horizontal-major
             // (water columns share node-table lines) for 2-D kernels (RK45 +18 %, M1 +28 %); PK_SORT_HORIZONTAL overrides

@@ -460,11 +460,17 @@ __global__ void __launch_bounds__(wg_size(KIND, LDS), (KIND == 1 || INTERP != 0)
         const bool pf = PFM < 0 ? (P.spatial_f32 != 0) : (PFM == 1);
         c.pf = pf;
         c.row = i;
-        c.state = prm.reset_state ? PK_EVALUATE : P.state[i];  // kernel.py:188
-        if (c.state != PK_EVALUATE) {
+        // body_only: the caller runs the loop of kernel.py:190-245 itself (Python kernels between device kernels) and asks for ONE pass of
+        // the kernel list over the particles the reference would evaluate now (kernel.py:193-195); states are the caller's
+        const bool body = prm.body_only != 0;
+        c.state = (prm.reset_state && !body) ? PK_EVALUATE : P.state[i];  // kernel.py:188
+        const bool run = body ? P.iter[i] != 0  // the caller's `evaluate_particles` mask of this iteration (pk_particles_set_mask): every kernel
+                                                 // of one iteration sees the same particles, whatever an earlier kernel did to their state
+                              : c.state == PK_EVALUATE;
+        if (!run) {
             copy_row_through(P, O, i, pf);
         } else {
-            unsigned it = prm.reset_state ? 0u : (unsigned)P.iter[i];
+            unsigned it = (prm.reset_state || body) ? 0u : (unsigned)P.iter[i];
             c.hz = c.hy = c.hx = c.ht = 0;
             c.hyx_valid = false;
             c.first_eval = prm.reset_state ? 0xFu : 0u;
@@ -489,14 +495,17 @@ __global__ void __launch_bounds__(wg_size(KIND, LDS), (KIND == 1 || INTERP != 0)
             const int sign = prm.dt0 > 0 ? 1 : -1;  // kernel.py:186
             const bool windowed = a.win_lo > -INFINITY || a.win_hi < INFINITY;  // some field streams through a ring of levels
             const int nk = KID >= 0 ? 1 : prm.nk;
-            while (c.state == PK_EVALUATE || c.state == PK_REPEAT) {  // :190
+            bool once = body;
+            while (once || (!body && (c.state == PK_EVALUATE || c.state == PK_REPEAT))) {  // :190
+                once = false;
                 const double tte = sign * (endtime - p.t);
-                if (!(tte >= 0)) break;  // :193-197 (state is Evaluate here)
+                if (!body && !(tte >= 0)) break;  // :193-197 (state is Evaluate here)
                 if (prm.max_iters > 0 && it >= (unsigned)prm.max_iters) break;  // pk_execute_rerun: stop where the reference raised
                 double dtc;
                 if (sign == 1) dtc = fmax(fmin(p.dt, tte), 0.0);  // :200-203
                 else dtc = fmin(fmax(p.dt, -tte), 0.0);
-                if (windowed) {
+                if (body) dtc = p.dt;  // the caller clipped dt (for ALL particles, like :199-203)
+                if (windowed && !body) {
                     // field-slab streaming: only step while [t, t+dt] lies inside the resident time window;
                     // otherwise leave the particle untouched (state Evaluate) for the next launch
                     const double t1 = p.t + dtc;
@@ -529,6 +538,7 @@ __global__ void __launch_bounds__(wg_size(KIND, LDS), (KIND == 1 || INTERP != 0)
                         }
                     } while (c.state == PK_REPEAT);
                 }
+                if (body) break;  // position update, dt reset and EndofLoop belong to the caller's loop
                 if (KID >= 0) {
                     // single-kernel programs may be followed by the sampling-free recovery kernels (Delete*)
                     for (int k = 1; k < prm.nk; k++) {
@@ -575,8 +585,8 @@ __global__ void __launch_bounds__(wg_size(KIND, LDS), (KIND == 1 || INTERP != 0)
             if (ng > 1) O.ei[i * ng + 1] = c.ei1;
             if (ng > 2) O.ei[i * ng + 2] = c.ei2;
             if (ng > 3) O.ei[i * ng + 3] = c.ei3;
-            O.iter[i] = (int32_t)it;
-            note_error_iteration(a, c.state, it);
+            O.iter[i] = body ? P.iter[i] : (int32_t)it;
+            if (!body) note_error_iteration(a, c.state, it);
         }
     }
     steps = wave_sum(steps);

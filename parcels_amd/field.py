@@ -7,6 +7,8 @@ Sampling -- ``fieldset.UV[t, z, y, x]`` / ``field.eval(...)`` -- runs on the GPU
 
 from __future__ import annotations
 
+import warnings
+
 import numpy as np
 
 from .dataset import DataArray, Dataset
@@ -227,16 +229,45 @@ class Field:
             self._fieldset._engine = None
 
     def eval(self, t, z, y, x, particles=None):
-        """Interpolate in space and time on the GPU (field.py:145-185). Returns the values as float64."""
+        """Interpolate in space and time on the GPU (field.py:145-185). Returns the values as float64.  ``particles`` (the view a
+        Python kernel received): the particles the sampling fails on get the reference's error codes (field.py:307-378)."""
         if self._fieldset is None:
             raise RuntimeError("Field is not attached to a FieldSet")
-        return self._fieldset._engine_or_create().sample(self.name, t, z, y, x)[0]
+        eng = self._fieldset._engine_or_create()
+        val = eng.sample(self.name, *_sample_points(t, z, y, x))[0]
+        _mark_particles(particles, eng)
+        return val
 
     def __getitem__(self, key):
-        if hasattr(key, "_data"):
-            d = key._data
-            return self.eval(d["t"], d["z"], d["y"], d["x"])
-        return self.eval(*key[:4])
+        if self.name in ("U", "V", "W"):  # field.py:134-143
+            warnings.warn("Sampling of velocities should normally be done using fieldset.UV or fieldset.UVW object; tread carefully",
+                          RuntimeWarning, stacklevel=2)
+        return self.eval(*_unpack_key(key))
+
+
+def _sample_points(t, z, y, x):
+    """Sample coordinates as float64 arrays (the columns of a kernel's `particles` arrive as write-through proxies)."""
+    return tuple(np.asarray(v, dtype=np.float64) if not np.isscalar(v) else v for v in (t, z, y, x))
+
+
+def _unpack_key(key):
+    """`field[particles]` / `field[pset]` / `field[t, z, y, x]` / `field[t, z, y, x, particles]` (field.py:187-195, 297-304)."""
+    from .hostkernels import HostParticles
+
+    if isinstance(key, HostParticles):
+        return key.t, key.z, key.y, key.x, key
+    if hasattr(key, "_data"):  # a ParticleSet (or the single-row view pset[i]): every row it holds
+        d = key._data
+        idx = getattr(key, "_index", slice(None))
+        return d["t"][idx], d["z"][idx], d["y"][idx], d["x"][idx], None
+    key = tuple(key)
+    return key[0], key[1], key[2], key[3], (key[4] if len(key) > 4 else None)
+
+
+def _mark_particles(particles, eng):
+    from .hostkernels import _apply_sample_states
+
+    _apply_sample_states(particles, getattr(eng, "last_sample_state", None))
 
 
 class VectorField:
@@ -276,11 +307,10 @@ class VectorField:
     def eval(self, t, z, y, x, particles=None):
         if self._fieldset is None:
             raise RuntimeError("VectorField is not attached to a FieldSet")
-        u, v, w = self._fieldset._engine_or_create().sample(self.name, t, z, y, x)
+        eng = self._fieldset._engine_or_create()
+        u, v, w = eng.sample(self.name, *_sample_points(t, z, y, x))
+        _mark_particles(particles, eng)
         return (u, v, w) if self.vector_type == "3D" else (u, v)
 
     def __getitem__(self, key):
-        if hasattr(key, "_data"):
-            d = key._data
-            return self.eval(d["t"], d["z"], d["y"], d["x"])
-        return self.eval(*key[:4])
+        return self.eval(*_unpack_key(key))

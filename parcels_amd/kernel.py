@@ -43,12 +43,9 @@ class Kernel:
                 raise ValueError(f"Kernel function {f.__name__} must have the signature (particles, fieldset)")
         if len(kernels) == 0:
             raise ValueError("List of `kernels` should have at least one function.")
-        unknown = [f.__name__ for f in kernels if _k.kernel_id(f) is None]
-        if unknown:
-            raise NotImplementedError(
-                f"{unknown} are not built-in device kernels. parcels_amd executes kernels inside a HIP kernel and has "
-                f"no host (NumPy) path; supported: {sorted(f.__name__ for f in _k.KERNEL_IDS)} and parcels_amd.SampleField(field, into=variable)"
-            )
+        # Python functions that are not built-in device kernels: the loop of Kernel.execute then runs on the host columns and only
+        # the built-in kernels' bodies on the GPU (parcels_amd/hostkernels.py) -- correct, and slow by construction
+        self.host_functions = [f.__name__ for f in kernels if _k.kernel_id(f) is None]
         self._fieldset = pset.fieldset
         self._pclass = pset._pclass
         for f in kernels:
@@ -145,6 +142,8 @@ class Kernel:
     def launch(self, pset, endtime, dt, have_guess0=0):
         """Device part of Kernel.execute: advance the BOUND, device-resident particle columns to ``endtime``.
         No host<->device copies; returns the engine statistics (steps, state histogram, kernel time)."""
+        if self.host_functions:
+            return self._launch_hosted(pset, endtime, dt)
         engine = pset._engine()
         data = pset._data
         if "RK45_tol" in self.fieldset.context and "next_dt" not in data:
@@ -158,6 +157,24 @@ class Kernel:
         stats = engine.execute(self.kernel_ids, endtime=endtime, dt0=dt, context=self.fieldset.context, seed=pset.seed,
                                have_guess0=have_guess0, sort_by_cell=int(pset.sort_by_cell), t_start=t_start, samples=self.samples,
                                resort_every=every or None)
+        pset._last_stats = stats
+        return stats
+
+    def _launch_hosted(self, pset, endtime, dt):
+        """A kernel list with Python functions: columns to the host, the reference's loop there (hostkernels.execute_hosted: deletes
+        and raises like kernel.py:233-245), columns back to the device for whatever follows (output snapshots, the next interval)."""
+        from .hostkernels import execute_hosted
+
+        engine = pset._engine()
+        if getattr(engine, "_bound", None) is pset._data and len(pset) > 0:  # device-resident columns of the running execute()
+            engine.d2h()
+        try:
+            stats = execute_hosted(self, pset, endtime, dt)
+        finally:
+            if len(pset) > 0:
+                engine.device_variables = list(self.device_variables)
+                engine.bind_particles(pset._data)
+                engine.h2d()
         pset._last_stats = stats
         return stats
 

@@ -59,7 +59,9 @@ def test_no_gpu_fails_loudly():
         pset.execute(pa.AdvectionRK4, dt=3600.0, runtime=3600.0)
 
 
-def test_python_kernels_are_rejected():
+def test_python_kernels_are_accepted_but_still_need_the_device():
+    """A Python kernel puts the loop of Kernel.execute on the host (parcels_amd/hostkernels.py); the built-in kernels of the list and
+    all field sampling stay on the GPU, so without a device the run fails as loudly as any other."""
     case, _, _ = load_golden("agrid_flat_rk4_f64")
     fs = build_fieldset(case)
     pset = build_pset(case, fs)
@@ -67,7 +69,9 @@ def test_python_kernels_are_rejected():
     def MyKernel(particles, fieldset):
         particles.dx += 1
 
-    with pytest.raises(NotImplementedError):
+    k = pa.Kernel([pa.AdvectionRK4, MyKernel], pset)
+    assert k.host_functions == ["MyKernel"] and k.kernel_ids[0] is not None and k.kernel_ids[1] is None
+    with pytest.raises(pa._hip.HipLibraryError):
         pset.execute([pa.AdvectionRK4, MyKernel], dt=3600.0, runtime=3600.0)
 
     def BadSignature(p):
