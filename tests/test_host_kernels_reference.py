@@ -22,7 +22,7 @@ def test_sampling_in_a_python_kernel(gpu, fieldset):  # :182-205, :230-243
     def SampleU(particles, fieldset):
         _ = fieldset.U[particles]
 
-    pset = pa.ParticleSet(fieldset, x=[0.2], y=[5.0])
+    pset = pa.ParticleSet(fieldset, x=[0.2], y=[1.0])
     with pytest.warns(RuntimeWarning, match="Sampling of velocities should normally be done using fieldset.UV or fieldset.UVW object; tread carefully"):
         pset.execute(SampleU, runtime=np.timedelta64(1, "D"), dt=np.timedelta64(1, "D"))
 
@@ -143,7 +143,7 @@ def test_execution_check_stopallexecution(gpu, fieldset):  # :413-421
     np.testing.assert_allclose(pset.t, 9)
 
 
-def test_execution_recover_out_of_bounds(gpu, fieldset):  # :424-444
+def test_execution_recover_out_of_bounds(gpu, fieldset):  # :424-444 (the domain of THIS fieldset is lon -2..4: expected values by the same rule)
     npart = 2
 
     def MoveRight(particles, fieldset):
@@ -155,12 +155,16 @@ def test_execution_recover_out_of_bounds(gpu, fieldset):  # :424-444
         particles[inds].dx -= 1.0
         particles[inds].state = StatusCode.Success
 
-    lon = np.linspace(0.05, 6.95, npart)
+    lon = np.array([-1.93, 3.93])
     lat = np.linspace(1, 0, npart)
     pset = pa.ParticleSet(fieldset, x=lon, y=lat)
     pset.execute([MoveRight, MoveLeft], runtime=np.timedelta64(60, "s"), dt=np.timedelta64(1, "s"))
     assert len(pset) == npart
-    np.testing.assert_allclose(pset.x, [6.05, 5.95], rtol=1e-5)
+    expect = lon.copy()
+    for _ in range(60):  # a step of +0.1, or of 0.1 - 1.0 when the sample point x + 0.1 lies beyond the last node (4.0)
+        expect += np.where(expect + 0.1 > 4.0, 0.1 - 1.0, 0.1)
+    assert np.allclose(expect, [3.07, 3.93])  # the first particle bounced once, the second six times
+    np.testing.assert_allclose(pset.x, expect, rtol=1e-5)
     np.testing.assert_allclose(pset.y, lat, rtol=1e-5)
 
 
