@@ -5,10 +5,10 @@ tests/test_particleset_execute.py:67-95), so it shards with NO data-path collect
 
 * particles are partitioned by ``particle_id`` into contiguous blocks, one shard per rank (``shard_slice``);
 * grids and fields are replicated on every GPU (each rank uploads its own copy);
-* the only exchange is the periodic trajectory write-out (``ParticleFile.write``, particlefile.py:142-221):
-  ``gather_output_columns`` all-gathers the to-write columns (t, z, y, x, particle_id, ...) so that rank 0 can
-  append one table per output time.  Ranks may hold different particle counts (deletions): counts are
-  all-gathered first and the columns are padded to the maximum, i.e. an all-gather-v built from two all-gathers.
+* the only exchange is the periodic trajectory write-out (``ParticleFile.write``, particlefile.py:142-221): the rows that pass the
+  write filter -- selected ON THE DEVICE from the device-resident columns (``device_write_rows``) -- are gathered to rank 0
+  (``gather_rows_to_root``: the row counts are all-gathered, then one padded gather per column), which appends one table per
+  output time.  ``gather_output_columns`` is the all-gather form of the same exchange (what bench.py times).
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): an 8-rank all-gather of N bytes per rank moves N bytes per
 link concurrently, ~2 ms for the 280 MB of 1e7 default-schema particles -- negligible next to the integration.
@@ -64,10 +64,11 @@ def allreduce_scalars(values, op: str, group=None, device=None) -> list:
 
 
 def gather_write_columns(columns: dict, group=None, device=None) -> dict | None:
-    """The write-out exchange of ParticleFile.write (particlefile.py:142-180) across ranks: every rank passes the NumPy columns of
-    ITS particles that pass the write filter; rank 0 receives the concatenation in rank order (= id order for contiguous
-    shards), the others None.  Over RCCL (backend "nccl") the columns travel as device tensors on ``device``; over gloo as
-    host tensors.  Ranks may contribute different, also zero, row counts."""
+    """The write-out exchange of ParticleFile.write (particlefile.py:142-180) across ranks: every rank passes the columns of ITS
+    particles that pass the write filter -- NumPy arrays, or torch tensors that already live on the device (gather_device_rows) --
+    and rank 0 receives the concatenation in rank order (= id order for contiguous shards), the others None.  The rows go to rank 0
+    ONLY (one gather per column; a rank other than 0 sends its rows and copies nothing back); over RCCL (backend "nccl") they travel
+    as device tensors over xGMI, over gloo as host tensors.  Ranks may contribute different, also zero, row counts."""
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -76,18 +77,42 @@ def gather_write_columns(columns: dict, group=None, device=None) -> dict | None:
     dev = torch.device("cuda", torch.cuda.current_device() if device is None else int(device)) if on_gpu else torch.device("cpu")
     tens = {}
     for name, col in columns.items():
-        tens[name] = torch.from_numpy(np.ascontiguousarray(col)).to(dev)
-    out = gather_output_columns(tens, group)
-    if dist.get_rank(group) != 0:
+        tens[name] = col.to(dev) if isinstance(col, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(col)).to(dev)
+    out = gather_rows_to_root(tens, group)
+    if out is None:
         return None
     return {k: v.cpu().numpy() for k, v in out.items()}
 
 
-def gather_output_columns(columns: dict, group=None) -> dict:
-    """All-gather a dict of equally long 1-D torch tensors (one row per local particle) over the process group.
+def gather_rows_to_root(columns: dict, group=None) -> dict | None:
+    """Gather a dict of equally long 1-D torch tensors to rank 0 (all-gather of the row counts, then ONE padded gather per column);
+    returns the concatenation over ranks in rank order on rank 0, None elsewhere."""
+    import torch
+    import torch.distributed as dist
 
-    Returns the concatenation over ranks in rank order.  Works for any backend (RCCL on GPUs, gloo in the CPU tests).
-    """
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    names = list(columns)
+    n_local = int(columns[names[0]].shape[0]) if names else 0
+    dev = columns[names[0]].device if names else torch.device("cpu")
+    counts = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, torch.tensor([n_local], dtype=torch.int64, device=dev), group=group)
+    counts = counts.tolist()  # world x 8 bytes: the only thing every rank reads back
+    nmax = max(counts) if counts else 0
+    out = {}
+    for name in names:
+        col = columns[name].contiguous()
+        if col.shape[0] < nmax:
+            col = torch.cat([col, torch.zeros(nmax - col.shape[0], dtype=col.dtype, device=col.device)])
+        bufs = [torch.empty(nmax, dtype=col.dtype, device=col.device) for _ in range(world)] if rank == 0 else None
+        dist.gather(col, bufs, dst=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        if rank == 0:
+            out[name] = torch.cat([bufs[r][: counts[r]] for r in range(world)]) if world > 1 else bufs[0][: counts[0]]
+    return out if rank == 0 else None
+
+
+def gather_output_columns(columns: dict, group=None) -> dict:
+    """ALL-gather a dict of equally long 1-D torch tensors (one row per local particle) over the process group: every rank receives
+    the concatenation in rank order (the exchange the north star names; ParticleFile itself gathers to rank 0 only)."""
     import torch
     import torch.distributed as dist
 
@@ -97,20 +122,41 @@ def gather_output_columns(columns: dict, group=None) -> dict:
     dev = columns[names[0]].device if names else torch.device("cpu")
     counts = torch.zeros(world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(counts, torch.tensor([n_local], dtype=torch.int64, device=dev), group=group)
-    counts = counts.cpu().tolist()
+    counts = counts.tolist()
     nmax = max(counts) if counts else 0
     ragged = any(c != nmax for c in counts)
     out = {}
     for name in names:
         col = columns[name]
         if col.shape[0] < nmax:
-            pad = torch.zeros(nmax - col.shape[0], dtype=col.dtype, device=col.device)
-            col = torch.cat([col, pad])
+            col = torch.cat([col, torch.zeros(nmax - col.shape[0], dtype=col.dtype, device=col.device)])
         buf = torch.empty(world * nmax, dtype=col.dtype, device=col.device)
         dist.all_gather_into_tensor(buf, col.contiguous(), group=group)
         # equal shards (the common case): the gathered buffer IS the result, no second pass over the data
         out[name] = torch.cat([buf[r * nmax : r * nmax + counts[r]] for r in range(world)]) if ragged else buf
     return out
+
+
+def device_write_rows(engine, names, t) -> dict:
+    """The reference's write filter `|t_p - t| <= |dt|/2` (particlefile.py:198-221) applied ON THE DEVICE to the device-resident
+    columns, in host row order: torch tensors of the to-write columns `names` of the particles that pass it.  Nothing crosses PCIe."""
+    import torch
+
+    cols, perm = device_columns(engine, sorted(set(names) | {"t", "dt", "particle_id"}))
+    n = cols["t"].shape[0]
+    if perm is not None and n:  # undo the cell sort: host row perm[i] <- device row i
+        ordered = {}
+        for k, v in cols.items():
+            o = torch.empty_like(v)
+            o[perm] = v
+            ordered[k] = o
+        cols = ordered
+    tp, dt = cols["t"], cols["dt"]
+    half = torch.abs(dt / 2)
+    sel = ((t - half <= tp) & (t + half >= tp)) | (torch.isnan(dt) & (tp == t))
+    sel &= torch.isfinite(tp)
+    idx = torch.nonzero(sel, as_tuple=True)[0]
+    return {k: cols[k][idx] for k in names}
 
 
 class _DeviceColumn:
@@ -120,8 +166,12 @@ class _DeviceColumn:
         self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
-def device_output_columns(engine) -> dict:
-    """torch views (no copy) of the device-resident output columns of the bound particles, in device row order."""
+_DEVICE_COLUMN_TYPES = {"t": "<f8", "dt": "<f8", "next_dt": "<f8", "state": "<i4", "particle_id": "<i8"}
+
+
+def device_columns(engine, names):
+    """(torch views of the named device-resident particle columns in device row order -- no copy --, the device-row -> host-row
+    permutation as an int64 tensor or None when the rows are in host order)."""
     import torch
 
     from . import _hip
@@ -131,14 +181,25 @@ def device_output_columns(engine) -> dict:
     engine.ctx.check(engine.lib.pk_particles_device(engine.ctx.handle, C.byref(d), C.byref(perm)), "pk_particles_device")
     n = d.n
     sp = "<f4" if d.spatial_dtype == _hip.PK_F32 else "<f8"
-    cols = {}
     dev = f"cuda:{engine.device}"
-    for name, ptr, ts in (("t", d.t, "<f8"), ("z", d.z, sp), ("y", d.y, sp), ("x", d.x, sp), ("particle_id", d.particle_id, "<i8")):
-        if n == 0:  # an empty shard still takes part in the all-gather
-            cols[name] = torch.empty(0, dtype={"<f8": torch.float64, "<f4": torch.float32, "<i8": torch.int64}[ts], device=dev)
+    tt = {"<f8": torch.float64, "<f4": torch.float32, "<i8": torch.int64, "<i4": torch.int32}
+    cols = {}
+    for name in names:
+        ts = _DEVICE_COLUMN_TYPES.get(name, sp if name in ("z", "y", "x", "dz", "dy", "dx") else None)
+        if ts is None:
+            raise KeyError(f"'{name}' is not a device-resident particle column")
+        ptr = getattr(d, name)
+        if n == 0 or not ptr:  # an empty shard still takes part in the exchange
+            cols[name] = torch.empty(0, dtype=tt[ts], device=dev)
         else:
             cols[name] = torch.as_tensor(_DeviceColumn(ptr, n, ts), device=dev)
-    return cols
+    p = torch.as_tensor(_DeviceColumn(perm.value, n, "<i8"), device=dev) if (perm.value and n) else None
+    return cols, p
+
+
+def device_output_columns(engine) -> dict:
+    """torch views (no copy) of the device-resident output columns of the bound particles, in device row order."""
+    return device_columns(engine, ("t", "z", "y", "x", "particle_id"))[0]
 
 
 def allgather_output(engine, world: int, group=None) -> dict:

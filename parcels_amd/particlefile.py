@@ -119,20 +119,40 @@ class ParticleFile:
         data = pset._data
         if isinstance(t, (np.timedelta64, np.datetime64)):
             t = to_seconds(t - fieldset.time_interval.left)
-        idx = _to_write_particles(data, t) if indices is None else indices  # the reference's filter, applied BEFORE the exchange
-        cols = {v.name: data[v.name][idx] for v in _get_vars_to_write(pset._pclass)}
+        names = [v.name for v in _get_vars_to_write(pset._pclass)]
         if self._world > 1:
             import time as _time
 
-            from .distributed import gather_write_columns
+            from .distributed import device_write_rows, gather_write_columns
 
             t0 = _time.perf_counter()
             eng = getattr(fieldset, "_engine", None)
+            cols = None
+            if indices is None and getattr(pset, "_device_rows_current", False) and eng is not None and self._device_gather_ok(eng, names):
+                # the columns are device-resident (ParticleSet.execute): filter there, send the device rows -- no D2H / H2D round trip
+                cols = device_write_rows(eng, names, float(t))
+            if cols is None:
+                idx = _to_write_particles(data, t) if indices is None else indices  # the reference's filter, applied BEFORE the exchange
+                cols = {n: data[n][idx] for n in names}
             cols = gather_write_columns(cols, self._group, device=getattr(eng, "device", None))
             self.gather_seconds += _time.perf_counter() - t0
             if cols is None:
                 return
+        else:
+            idx = _to_write_particles(data, t) if indices is None else indices
+            cols = {n: data[n][idx] for n in names}
         self.write_columns(pset._pclass, cols, fieldset.time_interval)
+
+    def _device_gather_ok(self, eng, names) -> bool:
+        """Every to-write Variable lives in a device column and the exchange runs over RCCL (device tensors)."""
+        try:
+            import torch.distributed as dist
+
+            from .distributed import _DEVICE_COLUMN_TYPES
+        except Exception:
+            return False
+        spatial = ("z", "y", "x", "dz", "dy", "dx")
+        return dist.get_backend(self._group) == "nccl" and all(n in _DEVICE_COLUMN_TYPES or n in spatial for n in names)
 
     def async_writer(self, pset, engine, out_cols):
         """Writer that takes the output step off the critical path of ParticleSet.execute (None for a collective multi-rank file:

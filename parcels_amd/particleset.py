@@ -335,9 +335,16 @@ class ParticleSet:
                             else:
                                 if writer is not None:
                                     writer.drain()  # keep the tables in time order
-                                if not synced:
+                                names = [v.name for v in self._pclass.variables if v.to_write is not False]
+                                probe = getattr(output_file, "_device_gather_ok", None)
+                                on_device = bool(collective and not synced and len(self) > 0 and probe is not None and probe(engine, names))
+                                if not synced and not on_device:
                                     engine.d2h(out_cols)
-                                output_file.write(self, next_output)
+                                self._device_rows_current = on_device  # a collective file filters and gathers the DEVICE rows
+                                try:
+                                    output_file.write(self, next_output)
+                                finally:
+                                    self._device_rows_current = False
                             if np.isfinite(outputdt):
                                 next_output += outputdt * sign_dt
                         time = next_time
