@@ -50,13 +50,20 @@ class ParticleFile:
     appends the one table; the file is byte-identical to the one a single process writes for the whole id space.
     ``distributed=False`` keeps a ParticleFile rank-local."""
 
-    def __init__(self, path, outputdt, compression="zstd", mode=None, distributed=None, group=None, use_dictionary=False):
+    def __init__(self, path, outputdt, compression="zstd", mode=None, distributed=None, group=None, use_dictionary=False, writer="auto",
+                 encode_threads=None):
         if not isinstance(outputdt, (np.timedelta64, timedelta, float)):
             raise ValueError(f"Expected outputdt to be a np.timedelta64, datetime.timedelta or float (in seconds), got {type(outputdt)}")
         self._compression = compression
         # dictionary pages are useless for coordinates, times and unique ids and double the encode time (measured: 1.5 s vs 0.7 s
         # per table of 1e7 rows with zstd); the reference leaves pyarrow's default (on) -- same values, same schema either way
         self._use_dictionary = use_dictionary
+        # "auto": the multi-threaded writer of parcels_amd/parquet_writer.py for the flat numeric tables a ParticleSet produces (pyarrow
+        # encodes a table on one thread: 0.5 s per 1e7 particles), pyarrow's own writer for anything else; "pyarrow" / "fast" force one
+        if writer not in ("auto", "pyarrow", "fast"):
+            raise ValueError(f"writer must be 'auto', 'pyarrow' or 'fast'. Got {writer!r}")
+        self._writer_kind = writer
+        self._encode_threads = encode_threads
         outputdt = to_seconds(outputdt)
         path = Path(path)
         if path.suffix != ".parquet":
@@ -108,11 +115,22 @@ class ParticleFile:
         import pyarrow as pa
         import pyarrow.parquet as pq
 
+        names = [v.name for v in _get_vars_to_write(pclass)]
         if self._writer is None:
-            self._writer = pq.ParquetWriter(self.path, get_schema(pclass, self.metadata, time_interval), compression=self._compression,
-                                            use_dictionary=self._use_dictionary)
-        self._writer.write_table(pa.table({v.name: pa.array(np.asarray(columns[v.name])) for v in _get_vars_to_write(pclass)},
-                                          schema=self._writer.schema))
+            schema = get_schema(pclass, self.metadata, time_interval)
+            from .parquet_writer import _CODEC, FastParquetWriter, supports_schema
+
+            fast_ok = supports_schema(schema) and self._compression in _CODEC and not self._use_dictionary
+            if self._writer_kind == "fast" and not fast_ok:
+                raise ValueError("writer='fast' needs flat bool / int / float Variables, no dictionary pages and compression zstd / lz4 / snappy / gzip / None")
+            if fast_ok and self._writer_kind in ("auto", "fast"):
+                self._writer = FastParquetWriter(self.path, schema, compression=self._compression, threads=self._encode_threads)
+            else:
+                self._writer = pq.ParquetWriter(self.path, schema, compression=self._compression, use_dictionary=self._use_dictionary)
+        if hasattr(self._writer, "write_columns"):
+            self._writer.write_columns({n: np.asarray(columns[n]) for n in names})
+        else:
+            self._writer.write_table(pa.table({n: pa.array(np.asarray(columns[n])) for n in names}, schema=self._writer.schema))
 
     def write(self, pset, t, fieldset=None, indices=None):
         fieldset = fieldset or pset.fieldset

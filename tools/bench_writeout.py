@@ -53,6 +53,32 @@ def main():
         pset.execute(pa.AdvectionRK4, dt=case["dt"], runtime=a.steps * case["dt"])
         torch.cuda.synchronize()
         out["no_output"] = {"wall_s": time.perf_counter() - t0}
+        # the Parquet encode of ONE table of n rows (the default Variables: particle_id, t, z, y, x), multi-threaded writer vs pyarrow's
+        import pyarrow as pyarrow
+        import pyarrow.parquet as pq
+
+        from parcels_amd.parquet_writer import FastParquetWriter
+
+        cols = {k: np.ascontiguousarray(pset._data[k]) for k in ("particle_id", "t", "z", "y", "x")}
+        schema = pyarrow.schema([pyarrow.field(k, pyarrow.from_numpy_dtype(v.dtype)) for k, v in cols.items()])
+        enc = {}
+        for label, threads in (("fast_writer_1_thread", 1), ("fast_writer_8_threads", 8), ("fast_writer_32_threads", 32)):
+            best = 1e9
+            for _ in range(3):
+                t0 = time.perf_counter()
+                with FastParquetWriter(os.path.join(tmp, "enc.parquet"), schema, compression="zstd", threads=threads) as w:
+                    w.write_columns(cols)
+                best = min(best, time.perf_counter() - t0)
+            enc[label] = best
+        best = 1e9
+        for _ in range(2):
+            t0 = time.perf_counter()
+            with pq.ParquetWriter(os.path.join(tmp, "enc_pa.parquet"), schema, compression="zstd", use_dictionary=False) as w:
+                w.write_table(pyarrow.table(cols, schema=schema))
+            best = min(best, time.perf_counter() - t0)
+        enc["pyarrow_writer"] = best
+        enc["same_table"] = bool(pq.read_table(os.path.join(tmp, "enc.parquet")).equals(pq.read_table(os.path.join(tmp, "enc_pa.parquet"))))
+        out["encode_seconds_per_table_of_n_rows"] = enc
     out["byte_identical"] = files["inline"] == files["async"]
     out["write_out_cost_inline_s"] = out["inline"]["wall_s"] - out["no_output"]["wall_s"]
     out["write_out_cost_async_s"] = out["async"]["wall_s"] - out["no_output"]["wall_s"]
