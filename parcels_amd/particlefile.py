@@ -31,6 +31,15 @@ def _to_write_particles(particle_data, t):
     return np.where(sel & fin & np.isfinite(particle_data["particle_id"]))[0]
 
 
+def _take_rows(data, names, idx):
+    """The to-write columns of the selected rows; when EVERY row is selected (the usual output step of a run whose particles move in
+    lock-step) the columns themselves, not 1e7-row copies of them."""
+    n = len(data[names[0]]) if names else 0
+    if isinstance(idx, np.ndarray) and idx.dtype != bool and len(idx) == n and (n == 0 or (idx[0] == 0 and idx[-1] == n - 1)):
+        return {k: data[k] for k in names}
+    return {k: data[k][idx] for k in names}
+
+
 def get_schema(pclass, file_metadata, fset_time_interval):
     import pyarrow as pa
 
@@ -151,14 +160,14 @@ class ParticleFile:
                 cols = device_write_rows(eng, names, float(t))
             if cols is None:
                 idx = _to_write_particles(data, t) if indices is None else indices  # the reference's filter, applied BEFORE the exchange
-                cols = {n: data[n][idx] for n in names}
+                cols = _take_rows(data, names, idx)
             cols = gather_write_columns(cols, self._group, device=getattr(eng, "device", None))
             self.gather_seconds += _time.perf_counter() - t0
             if cols is None:
                 return
         else:
             idx = _to_write_particles(data, t) if indices is None else indices
-            cols = {n: data[n][idx] for n in names}
+            cols = _take_rows(data, names, idx)
         self.write_columns(pset._pclass, cols, fieldset.time_interval)
 
     def _device_gather_ok(self, eng, names) -> bool:
