@@ -154,8 +154,8 @@ class PoStats(C.Structure):
 def build(force: bool = False) -> str:
     """Compile oracle/liboracle.so with gcc (building the checker is not using it)."""
     so = os.path.join(_HERE, "liboracle.so")
-    src = os.path.join(_HERE, "parcels_oracle.c")
-    if force or not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+    srcs = [os.path.join(_HERE, f) for f in ("parcels_oracle.c", "fast_agrid_cpu.c")]
+    if force or not os.path.exists(so) or any(os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so) for src in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle.so"])
     return so
 
@@ -175,6 +175,44 @@ def lib():
 
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def fast_rk4_agrid(case: dict, endtime: float, nthreads: int = 1, sort_by_cell: bool = True):
+    """AdvectionRK4 of `case` (rectilinear A-grid, float64 everything, particles released at t = 0) to `endtime` through
+    oracle/fast_agrid_cpu.c, the CPU-idiomatic restatement of the headline workload (hinted searches, no dtype emulation, OpenMP).
+    Returns ({"t", "y", "x", "state"} in the caller's particle order, steps, seconds of the timed call).  sort_by_cell: the particles
+    are handed over ordered by cell (what the GPU path does on the device, outside ITS timed region too)."""
+    import time as _time
+
+    lon, lat, depth = (np.ascontiguousarray(case[k], dtype=np.float64) for k in ("lon", "lat", "depth"))
+    tm = np.ascontiguousarray(case["time_s"], dtype=np.float64)
+    U = np.ascontiguousarray(case["fields"]["U"], dtype=np.float64)
+    V = np.ascontiguousarray(case["fields"]["V"], dtype=np.float64)
+    assert U.shape == (len(tm), len(depth), len(lat), len(lon)) == V.shape
+    x, y, z = (np.array(case[k], dtype=np.float64) for k in ("x", "y", "z"))
+    n = len(x)
+    order = np.arange(n)
+    if sort_by_cell:
+        zi = np.clip(np.searchsorted(depth, z) - 1, 0, max(len(depth) - 2, 0))
+        yi = np.clip(np.searchsorted(lat, y) - 1, 0, max(len(lat) - 2, 0))
+        xi = np.clip(np.searchsorted(lon, x) - 1, 0, max(len(lon) - 2, 0))
+        order = np.argsort((zi * len(lat) + yi) * len(lon) + xi, kind="stable")
+        x, y, z = x[order], y[order], z[order]
+    t = np.zeros(n)
+    state = np.zeros(n, np.int32)
+    steps = C.c_int64(0)
+    fn = lib().pf_rk4_agrid
+    fn.restype = C.c_int64
+    t0 = _time.perf_counter()
+    bad = fn(_ptr(lon), C.c_int(len(lon)), _ptr(lat), C.c_int(len(lat)), _ptr(depth), C.c_int(len(depth)), _ptr(tm), C.c_int(len(tm)), _ptr(U), _ptr(V),
+             C.c_int(int(case["mesh"] == "spherical")), C.c_double(EARTH_RADIUS * np.pi / 180.0), C.c_int64(n), _ptr(t), _ptr(z), _ptr(y), _ptr(x), _ptr(state),
+             C.c_double(float(case["dt"])), C.c_double(float(endtime)), C.c_int(int(nthreads)), C.byref(steps))
+    el = _time.perf_counter() - t0
+    if bad:
+        raise ValueError(f"{bad} particles leave the domain / time interval: fast_agrid_cpu.c covers the in-bounds workload only")
+    inv = np.empty(n, np.int64)
+    inv[order] = np.arange(n)
+    return {"t": t[inv], "y": y[inv], "x": x[inv], "state": state[inv]}, int(steps.value), el
 
 
 _PAD_N_FACES = {"low": 0, "high": 0, "none": -1, "both": +1}  # _sgrid/core.py:41-49 (n_faces - n_nodes)
