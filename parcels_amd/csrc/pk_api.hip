@@ -1850,6 +1850,19 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
         a.p = ctx->dev;
         a.po = DPOut{ctx->alt.t, ctx->alt.z, ctx->alt.y, ctx->alt.x, ctx->alt.dz, ctx->alt.dy, ctx->alt.dx, ctx->alt.dt, ctx->alt.next_dt,
                      ctx->alt.state, ctx->alt.ei, ctx->alt.iter};
+        if (!prm->reset_state || prm->body_only) {
+            // a continued (paused) call or a masked body launch: some rows are not stepped -- they keep their values by this
+            // device-to-device copy of the columns a launch writes (the kernels themselves carry no copy code: pk_kernels.h)
+            const size_t ss = spatial_size(ctx);
+            const size_t nn = (size_t)n;
+            const struct { void* dst; const void* src; size_t bytes; } cp[] = {
+                {ctx->alt.t, ctx->dev.t, nn * 8}, {ctx->alt.z, ctx->dev.z, nn * ss}, {ctx->alt.y, ctx->dev.y, nn * ss}, {ctx->alt.x, ctx->dev.x, nn * ss},
+                {ctx->alt.dz, ctx->dev.dz, nn * ss}, {ctx->alt.dy, ctx->dev.dy, nn * ss}, {ctx->alt.dx, ctx->dev.dx, nn * ss}, {ctx->alt.dt, ctx->dev.dt, nn * 8},
+                {ctx->alt.next_dt, ctx->dev.next_dt, nn * 8}, {ctx->alt.state, ctx->dev.state, nn * 4},
+                {ctx->alt.ei, ctx->dev.ei, nn * 4 * (size_t)ctx->host.ngrids}, {ctx->alt.iter, ctx->dev.iter, nn * 4}};
+            for (const auto& c : cp)
+                if (c.dst && c.src) PK_HIP(ctx, hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyDeviceToDevice, ctx->compute));
+        }
         PK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->compute));
         const size_t fast_lds = fast_a ? (size_t)a.fast.lds_n * 2 * sizeof(double) : 0;
         const int pf32 = ctx->dev.spatial_f32;

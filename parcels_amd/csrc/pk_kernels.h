@@ -356,23 +356,10 @@ PK_DEV void consume(int kid, int stage, const PCtx& c, KLocal& L, double u, doub
     }
 }
 
-// A lane that does not step in this launch (its state was not Evaluate when a paused call is continued) hands its row from the
-// columns the launch reads to the columns it writes (no-op for an in-place launch).
-PK_DEV void copy_row_through(const DParticles& P, const DPOut& O, int64_t i, bool pf) {
-    if (O.t == P.t) return;
-    O.t[i] = P.t[i];
-    stp(O.z, i, ldp(P.z, i, pf), pf);
-    stp(O.y, i, ldp(P.y, i, pf), pf);
-    stp(O.x, i, ldp(P.x, i, pf), pf);
-    stp(O.dz, i, ldp(P.dz, i, pf), pf);
-    stp(O.dy, i, ldp(P.dy, i, pf), pf);
-    stp(O.dx, i, ldp(P.dx, i, pf), pf);
-    O.dt[i] = P.dt[i];
-    if (P.next_dt) O.next_dt[i] = P.next_dt[i];
-    O.state[i] = P.state[i];
-    for (int g = 0; g < P.ngrids; g++) O.ei[i * P.ngrids + g] = P.ei[i * P.ngrids + g];
-    O.iter[i] = P.iter[i];
-}
+// Lanes that do not step in a launch (their state was not Evaluate when a paused call is continued; not selected by the mask of a
+// body_only launch) keep their row: the host copies the input columns to the output columns before such a launch (pk_api.hip:
+// pk_execute_begin, device-to-device), so the kernels never branch into copy code -- a copy block in the entry branch of advect_kernel
+// made the compiler keep a private copy of the 3.9 KB kernel-argument struct (4 KB of scratch per lane, M1 82 -> 203 ms).
 // kernel.py:236-245: the first iteration (1-based, counted per particle since the Kernel.execute call began) that left a particle in
 // an error state or StopAllExecution -- the reference raises / returns after THAT iteration of its batch loop
 PK_DEV void note_error_iteration(const KArgs& a, int state, unsigned it) {
@@ -467,9 +454,7 @@ __global__ void __launch_bounds__(wg_size(KIND, LDS), (KIND == 1 || INTERP != 0)
         const bool run = body ? P.iter[i] != 0  // the caller's `evaluate_particles` mask of this iteration (pk_particles_set_mask): every kernel
                                                  // of one iteration sees the same particles, whatever an earlier kernel did to their state
                               : c.state == PK_EVALUATE;
-        if (!run) {
-            copy_row_through(P, O, i, pf);
-        } else {
+        if (run) {
             unsigned it = (prm.reset_state || body) ? 0u : (unsigned)P.iter[i];
             c.hz = c.hy = c.hx = c.ht = 0;
             c.hyx_valid = false;
@@ -632,9 +617,7 @@ __global__ void __launch_bounds__(256, PK_MIN_WAVES_FAST) advect_fast_kernel(con
         constexpr bool pf = PFM == 1;
         FCtx c;
         c.state = prm.reset_state ? PK_EVALUATE : P.state[i];  // kernel.py:188
-        if (c.state != PK_EVALUATE) {
-            copy_row_through(P, O, i, pf);
-        } else {
+        if (c.state == PK_EVALUATE) {
             unsigned it = prm.reset_state ? 0u : (unsigned)P.iter[i];
             fctx_init(c, PK_EVALUATE, P.ei[i * P.ngrids + a.fast.grid]);  // only the velocity grid's `ei` is touched
             double pt = P.t[i];
@@ -764,9 +747,7 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID) advect_cgrid_ker
         constexpr bool pf = PFM == 1;
         CCtx c;
         c.state = prm.reset_state ? PK_EVALUATE : P.state[i];  // kernel.py:188
-        if (c.state != PK_EVALUATE) {
-            copy_row_through(P, O, i, pf);
-        } else {
+        if (c.state == PK_EVALUATE) {
             unsigned it = prm.reset_state ? 0u : (unsigned)P.iter[i];
             {
                 const int32_t ei0 = P.ei[i * P.ngrids + F.grid];
