@@ -1622,10 +1622,13 @@ static int32_t fill_fast(pk_ctx* ctx, const pk_exec_params* prm, KArgs& a, bool 
 // path (pk_device.h: FastC, pk_fast_cgrid.h).  a.fastc.ok == 0 when a precondition fails (the general program runs): float64 node
 // coordinates, spherical mesh, per-cell table present, U / V (/ W) of one shape on the grid's own node counts with staggering offsets
 // in {0, 1} (then no staggered index needs clipping), a level below 2^31 elements, every search of the launch guessed.
-static int32_t fill_fastc(pk_ctx* ctx, const pk_exec_params* prm, KArgs& a, bool want_w, size_t& lds_bytes) {
+static int32_t fill_fastc(pk_ctx* ctx, const pk_exec_params* prm, KArgs& a, bool want_w, size_t& lds_bytes, bool rk45 = false) {
     FastC& F = a.fastc;
     memset(&F, 0, sizeof(F));
-    if (ctx->no_fast_cgrid || prm->interp_uv != 1 || prm->rk45_mode) return 0;
+    // the RK4 kernels reset dt every iteration (kernel.py:225-226); in RK45 mode (fieldset.RK45_tol present) dt follows next_dt, which
+    // only the RK45 kernel implements -- and AdvectionRK45 itself always runs in that mode (Kernel.check_fieldsets_in_kernels)
+    if (ctx->no_fast_cgrid || prm->interp_uv != 1 || (prm->rk45_mode != 0) != rk45) return 0;
+    if (rk45 && !ctx->dev.next_dt) return 0;
     if (prm->reset_state && !prm->have_guess0) return 0;  // an unguessed first search returns float32 (xsi, eta) ARRAYS (GPos::w32)
     const HostField& U = ctx->fields[prm->fU];
     const HostField& V = ctx->fields[prm->fV];
@@ -1825,8 +1828,8 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
             rc = fill_fast(ctx, prm, a, prog == PROG_RK4_3D);
             if (rc) return rc;
             fast_a = a.fast.ok != 0;
-        } else if ((prog == PROG_RK4 || prog == PROG_RK4_3D) && curv) {
-            rc = fill_fastc(ctx, prm, a, prog == PROG_RK4_3D, cgrid_lds);
+        } else if ((prog == PROG_RK4 || prog == PROG_RK4_3D || prog == PROG_RK45) && curv) {
+            rc = fill_fastc(ctx, prm, a, prog == PROG_RK4_3D, cgrid_lds, prog == PROG_RK45);
             if (rc) return rc;
             fast_c = a.fastc.ok != 0;
         }
@@ -1868,6 +1871,7 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
         const int pf32 = ctx->dev.spatial_f32;
         if (fast_a && prog == PROG_RK4) launch_fast<PROG_RK4>(field_f32, pf32, a, grid, fast_lds, ctx->compute);
         else if (fast_a && prog == PROG_RK4_3D) launch_fast<PROG_RK4_3D>(field_f32, pf32, a, grid, fast_lds, ctx->compute);
+        else if (fast_c && prog == PROG_RK45) launch_cgrid_rk45(field_f32, pf32, a, n, cgrid_lds, ctx->compute);
         else if (fast_c) launch_cgrid(field_f32, pf32, prog == PROG_RK4_3D, a, n, cgrid_lds, ctx->compute);
         else switch (prog) {
             case PROG_RK4: launch_program<PROG_RK4>(field_f32, curv, prm->interp_uv, use_lds, a, grid, lds_bytes, ctx->compute); break;

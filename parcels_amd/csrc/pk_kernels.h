@@ -850,8 +850,177 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID) advect_cgrid_ker
     }
 }
 
+// AdvectionRK45 (_advection.py:85-155) on the same evaluation site: the step loop of advect_kernel for the single-kernel RK45 program
+// (Repeat loop, next_dt column, `dt = next_dt` of kernel.py:118-120), the Fehlberg stages written out like `prepare` does.  Every sample
+// of these programs is guessed and float64 (the host checks it), so the float32-array products of the general program never arise.
+template <class FT, int PFM>
+__global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID) advect_cgrid_rk45_kernel(const KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const FastC& F = a.fastc;
+    CgLds L;
+    {
+        pk_tab2* s_tab = reinterpret_cast<pk_tab2*>(smem);
+        const pk_tab2* g_tab = reinterpret_cast<const pk_tab2*>(F.tab);
+        for (int k = threadIdx.x; k < F.lds_n; k += FC_LANES) s_tab[k] = g_tab[k];
+        __syncthreads();
+        L.time = s_tab + F.lds_time;
+        L.depth = s_tab + F.lds_depth;
+        L.rec = smem + F.lds_rec + threadIdx.x;
+        L.fv = (void*)((FT*)(smem + F.lds_fv) + threadIdx.x);
+    }
+    auto row = [&]() { return (int64_t)xcd_swizzle(blockIdx.x, gridDim.x) * FC_LANES + threadIdx.x; };
+    unsigned steps = 0, attempts = 0, paused = 0;
+    if (row() < a.p.n) {
+        int64_t i = row();
+        const DParticles& P = a.p;
+        const DPOut& O = a.po;
+        const pk_exec_params& prm = a.prm;
+        constexpr bool pf = PFM == 1;
+        CCtx c;
+        c.state = prm.reset_state ? PK_EVALUATE : P.state[i];  // kernel.py:188
+        if (c.state == PK_EVALUATE) {
+            unsigned it = prm.reset_state ? 0u : (unsigned)P.iter[i];
+            {
+                const int32_t ei0 = P.ei[i * P.ngrids + F.grid];
+                int gy, gx;
+                unravel_yx(a.grids[F.grid], (int64_t)ei0, gy, gx);
+                cctx_init(c, PK_EVALUATE, ei0, gy, gx);
+            }
+            double pt = P.t[i];
+            const double pz = ldp(P.z, i, pf);
+            double py = ldp(P.y, i, pf), px = ldp(P.x, i, pf);
+            double pdz = ldp(P.dz, i, pf), pdy = ldp(P.dy, i, pf), pdx = ldp(P.dx, i, pf);
+            double pdt = P.dt[i], pnd = P.next_dt[i];
+            double pzz = pz;
+            const double endtime = prm.endtime;
+            const int sign = prm.dt0 > 0 ? 1 : -1;
+            const bool windowed = a.win_lo > -INFINITY || a.win_hi < INFINITY;
+            while (c.state == PK_EVALUATE || c.state == PK_REPEAT) {  // :190
+                const double tte = sign * (endtime - pt);
+                if (!(tte >= 0)) break;  // :193-197
+                if (prm.max_iters > 0 && it >= (unsigned)prm.max_iters) break;
+                double dtc;
+                if (sign == 1) dtc = fmax(fmin(pdt, tte), 0.0);  // :200-203
+                else dtc = fmin(fmax(pdt, -tte), 0.0);
+                if (windowed) {
+                    const double t1 = pt + dtc;
+                    const double lo = fmin(pt, t1), hi = fmax(pt, t1);
+                    if (lo < a.win_lo || hi > a.win_hi) { paused = 1; break; }
+                }
+                it++;
+                pdt = dtc;
+                do {  // the Repeat loop of kernel.py:211-216
+                    using namespace rk45c;
+                    attempts++;
+                    const double dt = pdt;
+                    double u1 = 0, u2 = 0, u3 = 0, u4 = 0, u5 = 0, u6 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0, v6 = 0;
+#pragma unroll 1
+                    for (int stage = 0; stage < 6; stage++) {
+                        double sx = px, sy = py, st = pt;
+                        switch (stage) {
+                            case 1: sx = px + u1 * A00 * dt; sy = py + v1 * A00 * dt; st = pt + c0 * dt; break;
+                            case 2: sx = px + (u1 * A10 + u2 * A11) * dt; sy = py + (v1 * A10 + v2 * A11) * dt; st = pt + c1 * dt; break;
+                            case 3:
+                                sx = px + (u1 * A20 + u2 * A21 + u3 * A22) * dt;
+                                sy = py + (v1 * A20 + v2 * A21 + v3 * A22) * dt;
+                                st = pt + c2 * dt;
+                                break;
+                            case 4:
+                                sx = px + (u1 * A30 + u2 * A31 + u3 * A32 + u4 * A33) * dt;
+                                sy = py + (v1 * A30 + v2 * A31 + v3 * A32 + v4 * A33) * dt;
+                                st = pt + c3 * dt;
+                                break;
+                            case 5:
+                                sx = px + (u1 * A40 + u2 * A41 + u3 * A42 + u4 * A43 + u5 * A44) * dt;
+                                sy = py + (v1 * A40 + v2 * A41 + v3 * A42 + v4 * A43 + v5 * A44) * dt;
+                                st = pt + c4 * dt;
+                                break;
+                            default: break;
+                        }
+                        double u, v, w;
+                        eval_uvw_cgrid<FT, pf, false>(a, L, c, st, pzz, sy, sx, pf && stage == 0, u, v, w);
+                        switch (stage) {
+                            case 0: u1 = u; v1 = v; break;
+                            case 1: u2 = u; v2 = v; break;
+                            case 2: u3 = u; v3 = v; break;
+                            case 3: u4 = u; v4 = v; break;
+                            case 4: u5 = u; v5 = v; break;
+                            default: u6 = u; v6 = v; break;
+                        }
+                    }
+                    const double sign_dt = (dt > 0) ? 1.0 : ((dt < 0) ? -1.0 : dt);  // np.sign
+                    const double x_4th = (u1 * b40 + u2 * b41 + u3 * b42 + u4 * b43 + u5 * b44) * dt;
+                    const double y_4th = (v1 * b40 + v2 * b41 + v3 * b42 + v4 * b43 + v5 * b44) * dt;
+                    const double x_5th = (u1 * b50 + u2 * b51 + u3 * b52 + u4 * b53 + u5 * b54 + u6 * b55) * dt;
+                    const double y_5th = (v1 * b50 + v2 * b51 + v3 * b52 + v4 * b53 + v5 * b54 + v6 * b55) * dt;
+                    const double ex = x_5th - x_4th, ey = y_5th - y_4th;
+                    const double kappa = sqrt(ex * ex + ey * ey);
+                    const bool good = (kappa <= prm.rk45_tol) || (fabs(dt) <= fabs(prm.rk45_min_dt));
+                    pdx = pstore(pf, pdx + (good ? x_5th : 0.0));
+                    pdy = pstore(pf, pdy + (good ? y_5th : 0.0));
+                    const bool increase = good && (kappa <= prm.rk45_tol / 10) && (fabs(dt * 2) <= fabs(prm.rk45_max_dt));
+                    double next_dt = increase ? dt * 2 : dt;
+                    if (fabs(next_dt) > fabs(prm.rk45_max_dt)) next_dt = prm.rk45_max_dt * sign_dt;
+                    pnd = prm.next_dt_f32 ? (double)(float)next_dt : next_dt;
+                    if (good) c.state = PK_EVALUATE;  // :146 overwrites any sampling error code
+                    double ndt = good ? dt : dt / 2;
+                    if (fabs(ndt) < fabs(prm.rk45_min_dt)) ndt = prm.rk45_min_dt * sign_dt;
+                    pdt = ndt;
+                    if (!good) c.state = PK_REPEAT;
+                } while (c.state == PK_REPEAT);
+                for (int k = 1; k < prm.nk; k++) {  // the sampling-free recovery kernels that may follow (Delete*)
+                    const int kid = prm.kernels[k];
+                    attempts++;
+                    if (kid == PK_KERNEL_DELETE_ON_ERROR) {
+                        if (c.state >= PK_ERROR) c.state = PK_DELETE;
+                    } else if (c.state == PK_ERROROUTOFBOUNDS || c.state == PK_ERRORTHROUGHSURFACE) {
+                        c.state = PK_DELETE;
+                    }
+                }
+                if (c.state == PK_EVALUATE || c.state == PK_SUCCESS) {  // :219-222 -> _position_update :108-120
+                    if (tte > 0 && pt + pdt == pt) {
+                        c.state = PK_ERROR;
+                        break;
+                    }
+                    px = padd(pf, px, pdx);
+                    py = padd(pf, py, pdy);
+                    pzz = padd(pf, pzz, pdz);
+                    pt += pdt;
+                    pdx = pdy = pdz = 0.0;
+                    pdt = pnd;  // kernel.py:118-120 (RK45 mode)
+                    steps++;
+                }
+                if (c.state == PK_EVALUATE && pt == endtime) c.state = PK_ENDOFLOOP;  // :229-230
+            }
+            i = row();
+            asm volatile("" : "+v"(i));
+            O.t[i] = pt;
+            stp(O.z, i, pzz, pf);
+            stp(O.y, i, py, pf);
+            stp(O.x, i, px, pf);
+            stp(O.dz, i, pdz, pf);
+            stp(O.dy, i, pdy, pf);
+            stp(O.dx, i, pdx, pf);
+            O.dt[i] = pdt;
+            O.next_dt[i] = pnd;
+            O.state[i] = c.state;
+            for (int g = 0; g < P.ngrids; g++) O.ei[i * P.ngrids + g] = g == F.grid ? c.ei : P.ei[i * P.ngrids + g];
+            O.iter[i] = (int32_t)it;
+            note_error_iteration(a, c.state, it);
+        }
+    }
+    const unsigned long long wsteps = wave_sum((unsigned long long)steps), wattempts = wave_sum((unsigned long long)attempts),
+                             wpaused = wave_sum((unsigned long long)paused);
+    if ((threadIdx.x & 63) == 0) {
+        if (wsteps) atomicAdd(&a.counters->steps, wsteps);
+        if (wattempts) atomicAdd(&a.counters->attempts, wattempts);
+        if (wpaused) atomicAdd(&a.counters->paused, wpaused);
+    }
+}
+
 // fast C-grid programs: one TU defines launch_cgrid (field dtype x particle dtype x 2-D / 3-D)
 void launch_cgrid(int field_f32, int particles_f32, int d3, const KArgs& a, int64_t n, size_t lds_bytes, hipStream_t stream);
+void launch_cgrid_rk45(int field_f32, int particles_f32, const KArgs& a, int64_t n, size_t lds_bytes, hipStream_t stream);
 
 // One translation unit per program (compiled in parallel) defines launch_program<PROG>.
 // key bits: field f32 | curvilinear | C-grid ; lds: coordinate vectors staged in LDS

@@ -26,4 +26,14 @@ void launch_cgrid(int field_f32, int particles_f32, int d3, const KArgs& a, int6
         default: PK_CG_CASE(float, 1, true); break;
     }
 }
+void launch_cgrid_rk45(int field_f32, int particles_f32, const KArgs& a, int64_t n, size_t lds_bytes, hipStream_t stream) {
+    const dim3 grid((unsigned)((n + FC_LANES - 1) / FC_LANES));
+    if (field_f32) {
+        if (particles_f32) hipLaunchKernelGGL((advect_cgrid_rk45_kernel<float, 1>), grid, dim3(FC_LANES), lds_bytes, stream, a);
+        else hipLaunchKernelGGL((advect_cgrid_rk45_kernel<float, 0>), grid, dim3(FC_LANES), lds_bytes, stream, a);
+    } else {
+        if (particles_f32) hipLaunchKernelGGL((advect_cgrid_rk45_kernel<double, 1>), grid, dim3(FC_LANES), lds_bytes, stream, a);
+        else hipLaunchKernelGGL((advect_cgrid_rk45_kernel<double, 0>), grid, dim3(FC_LANES), lds_bytes, stream, a);
+    }
+}
 }  // namespace pk

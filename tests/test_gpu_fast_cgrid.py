@@ -69,6 +69,22 @@ def test_fast_equals_general_and_oracle(gpu, kernel, fdt, sdt):
     _check(case, rtol=5e-7 if sdt == "float32" else 1e-12)
 
 
+@pytest.mark.parametrize("sdt", ["float64", "float32"])
+@pytest.mark.parametrize("delete", [True, False])
+def test_rk45_on_the_fast_evaluation_equals_the_general_program(gpu, sdt, delete):
+    """AdvectionRK45 (adaptive dt, Repeat loop, next_dt column) through advect_cgrid_rk45_kernel: accepted and rejected attempts, dt
+    halved and doubled between min_dt and max_dt, particles that leave the mesh with and without the recovery kernel (without it the
+    launch is repeated with the iteration limit of the first error) -- bit for bit the general program, and the oracle to 1e-12."""
+    from oracle import cases
+
+    kernels = ["AdvectionRK45"] + (["DeleteParticle"] if delete else [])
+    case = cases.curv_cgrid_case("fastc_rk45", mesh="spherical", kernels=kernels, seed=21, npart=2500, spatial_dtype=sdt, with_w=False, dt=1800.0,
+                                 runtime=20 * 3600.0, vel=2.5 if delete else 0.4)
+    case["context"] = {"RK45_tol": 30.0, "RK45_min_dt": 60.0, "RK45_max_dt": 4 * 3600.0}
+    fast, st = _check(case, rtol=5e-7 if sdt == "float32" else 1e-12)
+    assert st["attempts"] > st["steps"], "no attempt was rejected: the test does not test the Repeat loop"
+
+
 def test_cells_are_crossed_and_particles_leave_the_mesh(gpu):
     """Fast flow on a small mesh: most stages cross a cell edge (neighbour probe), many particles leave the mesh (the table walk
     finds nothing: GridSearchingError -> DeleteParticle) or the depth range."""
