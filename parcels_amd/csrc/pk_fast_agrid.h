@@ -101,9 +101,25 @@ PK_DEV void fast_search(const pk_tab2* tab, int n, double first, double last, do
 }
 
 // The two x-corners of one (level, z, y) row at byte offset `off` from a wave-uniform base: one wide load in saddr form.
+// PK_ABLATE_FIELDS (measurement builds only, results are wrong on purpose; tools/build_variant.sh): what an ideal LDS field tile
+//  could buy at most.  1 = every lane reads the SAME global address (the 16 loads become one cache line per wavefront: no L2
+// / Infinity-Cache latency spread, no TA divergence); 2 = the corner values come out of LDS (ds_read_b128 from the staged coordinate
+// tables: a tile that costs nothing to maintain).
+#ifndef PK_ABLATE_FIELDS
+#define PK_ABLATE_FIELDS 0
+#endif
 template <class FT>
 PK_DEV void ldrow(const char* base, uint32_t off, double& a, double& b) {
+#if PK_ABLATE_FIELDS == 1
+    ldpair(reinterpret_cast<const FT*>(base + (off & 8u)), a, b);
+#elif PK_ABLATE_FIELDS == 2
+    extern __shared__ __attribute__((aligned(16))) double pk_ablate_smem[];
+    const pk_tab2 v = reinterpret_cast<const pk_tab2*>(pk_ablate_smem)[(off >> 4) & 63u];
+    a = v.x * 1e-9 + (double)((uintptr_t)base & 1);
+    b = v.y * 1e-9;
+#else
     ldpair(reinterpret_cast<const FT*>(base + off), a, b);
+#endif
 }
 
 // XLinear.interp (_xinterpolators.py:112-153) for one field; LT / LZ: the second time / depth level takes part (wave-uniform,
