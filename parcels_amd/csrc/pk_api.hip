@@ -1622,7 +1622,7 @@ static int32_t fill_fast(pk_ctx* ctx, const pk_exec_params* prm, KArgs& a, bool 
 // path (pk_device.h: FastC, pk_fast_cgrid.h).  a.fastc.ok == 0 when a precondition fails (the general program runs): float64 node
 // coordinates, spherical mesh, per-cell table present, U / V (/ W) of one shape on the grid's own node counts with staggering offsets
 // in {0, 1} (then no staggered index needs clipping), a level below 2^31 elements, every search of the launch guessed.
-static int32_t fill_fastc(pk_ctx* ctx, const pk_exec_params* prm, KArgs& a, bool want_w, size_t& lds_bytes, bool rk45 = false) {
+static int32_t fill_fastc(pk_ctx* ctx, const pk_exec_params* prm, KArgs& a, bool want_w, size_t& lds_bytes, bool rk45 = false, bool m1 = false) {
     FastC& F = a.fastc;
     memset(&F, 0, sizeof(F));
     // the RK4 kernels reset dt every iteration (kernel.py:225-226); in RK45 mode (fieldset.RK45_tol present) dt follows next_dt, which
@@ -1748,6 +1748,26 @@ static int32_t fill_fastc(pk_ctx* ctx, const pk_exec_params* prm, KArgs& a, bool
     F.U = (const char*)U.d.data; F.V = (const char*)V.d.data; F.W = W ? (const char*)W->d.data : nullptr;
     F.ct2 = ctx->d_ct2;
     F.tab = ctx->d_cg_tab;
+    if (m1) {  // AdvectionDiffusionM1: Kh_zonal / Kh_meridional as XLinear fields on the nodes of the same grid
+        const int ids[2] = {prm->fKh_zonal, prm->fKh_meridional};
+        for (int k = 0; k < 2; k++) {
+            if (ids[k] < 0 || ids[k] >= (int)ctx->fields.size()) return 0;
+            const HostField& K = ctx->fields[ids[k]];
+            const DField& kd = K.d;
+            if (kd.grid != gid || kd.dtype != f.dtype || kd.ncomp != 1 || kd.is_const != 0 || kd.st_x != 1 || kd.nx != g.d.nx || kd.ny != g.d.ny) return 0;
+            if (!(kd.nz == 1 || kd.nz == g.d.nz)) return 0;
+            if (kd.has_time_interval && (K.time != U.time || kd.nt != f.nt)) return 0;
+            if (!kd.has_time_interval && kd.nt != 1) return 0;
+            if ((int64_t)kd.st_t * esz >= (1ll << 31)) return 0;
+            F.kh[k] = (const char*)kd.data;
+            F.kh_st[k] = (int32_t)(kd.st_t * esz);
+            F.kh_sz[k] = (int32_t)(kd.st_z * esz);
+            F.kh_sy[k] = (int32_t)(kd.st_y * esz);
+            F.kh_nt[k] = kd.nt; F.kh_nz[k] = kd.nz; F.kh_ny[k] = kd.ny; F.kh_nx[k] = kd.nx;
+            F.kh_has_ti[k] = kd.has_time_interval;
+            F.kh_nslots[k] = kd.nslots;
+        }
+    }
     F.lds_time = ctx->cg_tab_off[0]; F.lds_depth = ctx->cg_tab_off[1]; F.lds_n = ctx->cg_tab_off[2];
     F.lds_rec = 2 * F.lds_n;
     F.lds_fv = F.lds_rec + FC_REC_ROWS * FC_LANES;
@@ -1828,8 +1848,8 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
             rc = fill_fast(ctx, prm, a, prog == PROG_RK4_3D);
             if (rc) return rc;
             fast_a = a.fast.ok != 0;
-        } else if ((prog == PROG_RK4 || prog == PROG_RK4_3D || prog == PROG_RK45) && curv) {
-            rc = fill_fastc(ctx, prm, a, prog == PROG_RK4_3D, cgrid_lds, prog == PROG_RK45);
+        } else if ((prog == PROG_RK4 || prog == PROG_RK4_3D || prog == PROG_RK45 || prog == PROG_M1) && curv) {
+            rc = fill_fastc(ctx, prm, a, prog == PROG_RK4_3D, cgrid_lds, prog == PROG_RK45, prog == PROG_M1);
             if (rc) return rc;
             fast_c = a.fastc.ok != 0;
         }
@@ -1872,6 +1892,7 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
         if (fast_a && prog == PROG_RK4) launch_fast<PROG_RK4>(field_f32, pf32, a, grid, fast_lds, ctx->compute);
         else if (fast_a && prog == PROG_RK4_3D) launch_fast<PROG_RK4_3D>(field_f32, pf32, a, grid, fast_lds, ctx->compute);
         else if (fast_c && prog == PROG_RK45) launch_cgrid_rk45(field_f32, pf32, a, n, cgrid_lds, ctx->compute);
+        else if (fast_c && prog == PROG_M1) launch_cgrid_m1(field_f32, pf32, a, n, cgrid_lds, ctx->compute);
         else if (fast_c) launch_cgrid(field_f32, pf32, prog == PROG_RK4_3D, a, n, cgrid_lds, ctx->compute);
         else switch (prog) {
             case PROG_RK4: launch_program<PROG_RK4>(field_f32, curv, prm->interp_uv, use_lds, a, grid, lds_bytes, ctx->compute); break;

@@ -130,6 +130,11 @@ struct FastC {
     int64_t lvl_b;                       // bytes per time-level slot
     int64_t dU0, dU1, dV0, dV1, dW0, dW1;  // byte offsets of the six staggered values relative to the struct of cell (zi, yi, xi)
     const char *U, *V, *W;               // level rings (component offset folded into dU0.. for packed groups; W may be NULL)
+    // AdvectionDiffusionM1: the two scalar fields Kh_zonal / Kh_meridional on the nodes of the SAME grid (XLinear): base, byte strides of
+    // their axes (0 for an axis the field does not have), extents, and whether they share the velocity's time axis (else: no time axis)
+    const char* kh[2];
+    int32_t kh_st[2], kh_sz[2], kh_sy[2];   // bytes per time level / depth level / row
+    int32_t kh_nt[2], kh_nz[2], kh_ny[2], kh_nx[2], kh_has_ti[2], kh_nslots[2];
     const double* ct2;                   // per-cell records (pk_fast_cgrid.h: CT2_STRIDE doubles each)
     const double* tab;                   // global copy of the interleaved coordinate tables: time | depth
     double tlen, t0, t1, z0, z1, deg2m;

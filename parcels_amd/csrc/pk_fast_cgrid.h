@@ -49,6 +49,9 @@ struct CCtx {
     int rc_cell;         // cell whose record sits in the lane's LDS slot, -1 = none
     int fv_cell, fv_zt;  // tags of the cached field values: cell, (ti << 13) | (zi << 1) | (level ti+1 cached)
     double mt, mtau, mz, mzeta;
+    // AdvectionDiffusionM1's program: its seven samples per step share latitudes (x +- dres, x) and longitudes (y +- dres, y) -- the
+    // sines / cosines of the query point are memoised on the bits of the coordinate (unused, and optimised away, elsewhere)
+    double qy, qx, q_sl, q_cl, q_so, q_co;
 };
 PK_DEV void cctx_init(CCtx& c, int state, int32_t ei, int gy, int gx) {
     c.state = state;
@@ -62,6 +65,8 @@ PK_DEV void cctx_init(CCtx& c, int state, int32_t ei, int gy, int gx) {
     c.fv_zt = 0;
     c.mt = c.mz = __builtin_nan("");
     c.mtau = c.mzeta = 0.0;
+    c.qy = c.qx = __builtin_nan("");
+    c.q_sl = c.q_cl = c.q_so = c.q_co = 0.0;
 }
 
 // Fetch the ct2 record of `cell` into the lane's LDS slot -- and, WITH_F, the staggered field values of (zi, yi, xi) at level ti
@@ -183,16 +188,63 @@ PK_DEV bool cg_point_in_cell(const FastC& F, const double* rec, int cell, double
     return (x >= 0) && (x <= 1) && (e >= 0) && (e <= 1);
 }
 
+// XLinear.interp (_xinterpolators.py:112-153) of scalar field `k` (FastC::kh) at a grid position: xlinear<FT> of pk_device.h for a
+// float64-coordinate grid, with the field's own strides (an axis the field lacks has stride 0: the two "levels" are then the same
+// values, and c * (1 - zeta) + c * zeta is still formed, like the reference does)
+template <class FT>
+PK_DEV double cg_scalar_xlinear(const FastC& F, int k, int ti, double tau, int zi, double zeta, int yi, int xi, double xsi, double eta) {
+    const bool lenT = tau > 0, lenZ = !(zeta <= 0);
+    const int nt = F.kh_nt[k], ns = F.kh_nslots[k];
+    int s0 = ti, s1 = mini(ti + 1, nt - 1);
+    if (ns < nt) { s0 = (int)((uint32_t)s0 % (uint32_t)ns); s1 = (int)((uint32_t)s1 % (uint32_t)ns); }
+    const char* d0 = F.kh[k] + (int64_t)s0 * F.kh_st[k];
+    const char* d1 = F.kh[k] + (int64_t)s1 * F.kh_st[k];
+    const int64_t oz0 = (int64_t)zi * F.kh_sz[k], oz1 = (int64_t)mini(zi + 1, F.kh_nz[k] - 1) * F.kh_sz[k];
+    const int64_t oy0 = (int64_t)yi * F.kh_sy[k], oy1 = (int64_t)mini(yi + 1, F.kh_ny[k] - 1) * F.kh_sy[k];
+    const int64_t ox = (int64_t)xi * (int64_t)sizeof(FT);  // xi + 1 <= nx - 1 for a cell of the grid the field lives on
+    double c[2][2];
+#pragma unroll
+    for (int iz = 0; iz < 2; iz++) {
+        if (iz == 1 && !lenZ) break;
+        const int64_t oz = iz ? oz1 : oz0;
+        double lv[2][2];
+#pragma unroll
+        for (int iy = 0; iy < 2; iy++) {
+            const int64_t o = oz + (iy ? oy1 : oy0) + ox;
+            double a0, a1;
+            ldpair(reinterpret_cast<const FT*>(d0 + o), a0, a1);
+            if (lenT) {
+                double b0, b1;
+                ldpair(reinterpret_cast<const FT*>(d1 + o), b0, b1);
+                a0 = a0 * (1 - tau) + b0 * tau;
+                a1 = a1 * (1 - tau) + b1 * tau;
+            }
+            lv[iy][0] = a0;
+            lv[iy][1] = a1;
+        }
+#pragma unroll
+        for (int iy = 0; iy < 2; iy++)
+#pragma unroll
+            for (int ix = 0; ix < 2; ix++) c[iy][ix] = iz ? c[iy][ix] * (1 - zeta) + lv[iy][ix] * zeta : lv[iy][ix];
+    }
+    return (1 - xsi) * (1 - eta) * c[0][0] + xsi * (1 - eta) * c[0][1] + (1 - xsi) * eta * c[1][0] + xsi * eta * c[1][1];
+}
+
 // VectorField.eval (field.py:250-304) + XGrid.search (xgrid.py:316-356) + CGrid_Velocity.interp (_xinterpolators.py:193-332).
 // PF: the sample point may come straight from float32 particle storage (pos_f32); D3: sample W as well.
-template <class FT, bool PF, bool D3>
+// WITH_SCALAR (AdvectionDiffusionM1's program): `sk` >= 0 asks for Field.eval (field.py:145-195) of scalar field FastC::kh[sk] instead --
+// same search on the same grid (the `ei` guess chain of the particle runs through velocity and scalar samples alike), XLinear on the
+// field's nodes; the value is returned in u.  One call site serves all seven samples of a step (sk is a run-time value there).
+template <class FT, bool PF, bool D3, bool WITH_SCALAR = false>
 PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtx& c, double t, double z, double y, double x, bool pos_f32, double& u,
-                           double& v, double& w) {
+                           double& v, double& w, int sk = -1) {
     const FastC& F = a.fastc;
+    const bool scalar = WITH_SCALAR && sk >= 0;
+    const int ks = scalar ? (sk & 1) : 0;
     u = v = w = 0.0;
     int ti = 0;
     double tau = 0.0;
-    if (F.has_ti) {  // _search_time_index (index_search.py:65-91)
+    if (scalar ? F.kh_has_ti[ks] != 0 : F.has_ti != 0) {  // _search_time_index (index_search.py:65-91)
         if (!(0 <= t) || !(t <= F.tlen)) {
             c.state = PK_ERROROUTSIDETIMEINTERVAL;
             return;
@@ -218,8 +270,14 @@ PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtx& c, double t, do
     const bool lenT = tau > 0;
     // the query point on the unit sphere (make_qpoint / latlon_rad_to_xyz)
     double sl, cl, so, co;
-    sincos_geo(y * DEG2RAD, sl, cl);
-    sincos_geo(x * DEG2RAD, so, co);
+    if (WITH_SCALAR) {
+        if (!(y == c.qy)) { sincos_geo(y * DEG2RAD, c.q_sl, c.q_cl); c.qy = y; }
+        if (!(x == c.qx)) { sincos_geo(x * DEG2RAD, c.q_so, c.q_co); c.qx = x; }
+        sl = c.q_sl; cl = c.q_cl; so = c.q_so; co = c.q_co;
+    } else {
+        sincos_geo(y * DEG2RAD, sl, cl);
+        sincos_geo(x * DEG2RAD, so, co);
+    }
     const double qX = co * cl, qY = so * cl, qZ = sl;
     // _search_indices_curvilinear_2d with a guess (index_search.py:242-295); see curvilinear_search for the probing order
     int yi = GRID_SEARCH_ERROR, xi = GRID_SEARCH_ERROR;
@@ -228,7 +286,10 @@ PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtx& c, double t, do
     const bool guess_ok = c.gy >= 0 && c.gy < F.gny - 1 && c.gx >= 0 && c.gx < F.gnx - 1;
     if (__builtin_expect(guess_ok, 1)) {
         const int cell = c.gy * F.gnx + c.gx;
-        if (c.rc_cell != cell) cg_fetch_cell<FT, D3, true>(F, L, c, cell, c.gy, c.gx, zi, ti, lenT);
+        if (c.rc_cell != cell) {  // (a scalar sample fetches the record only)
+            if (scalar) cg_fetch_cell<FT, D3, false>(F, L, c, cell, c.gy, c.gx, zi, ti, lenT);
+            else cg_fetch_cell<FT, D3, true>(F, L, c, cell, c.gy, c.gx, zi, ti, lenT);
+        }
         double xs, et;
         if (cg_point_in_cell(F, L.rec, cell, qX, qY, qZ, xs, et)) {
             found = true;
@@ -242,7 +303,7 @@ PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtx& c, double t, do
             const int nj = c.gy + dj, ni = c.gx + di;
             if ((dj | di) != 0 && nj >= 0 && nj < F.gny - 1 && ni >= 0 && ni < F.gnx - 1) {
                 const int ncell = nj * F.gnx + ni;
-                const double boxd = cg_fetch_cell<FT, D3, true>(F, L, c, ncell, nj, ni, zi, ti, lenT);
+                const double boxd = scalar ? cg_fetch_cell<FT, D3, false>(F, L, c, ncell, nj, ni, zi, ti, lenT) : cg_fetch_cell<FT, D3, true>(F, L, c, ncell, nj, ni, zi, ti, lenT);
                 double xs2, et2;
                 const double m = 1e-9;
                 if (cg_point_in_cell(F, L.rec, ncell, qX, qY, qZ, xs2, et2) && xs2 > m && xs2 < 1 - m && et2 > m && et2 < 1 - m) {
@@ -285,6 +346,14 @@ PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtx& c, double t, do
     }
     c.gy = yi;
     c.gx = xi;
+    if (scalar) {  // Field.eval: XLinear on the nodes of the cell, NaN -> ErrorInterpolation (field.py:373-378)
+        const double val = cg_scalar_xlinear<FT>(F, ks, ti, tau, zi, zeta, yi, xi, xsi, eta);
+        if (__builtin_expect(val != val, 0)) {
+            if (c.state < PK_ERRORINTERPOLATION) c.state = PK_ERRORINTERPOLATION;
+        }
+        u = val;
+        return;
+    }
     const int cell = yi * F.gnx + xi;
     const bool need_rec = c.rc_cell != cell, need_f = !cg_fields_cached(c, cell, zi, ti, lenT);
     if (__builtin_expect(need_rec, 0)) {  // found by the table walk

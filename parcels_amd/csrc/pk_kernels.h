@@ -1018,9 +1018,162 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID) advect_cgrid_rk4
     }
 }
 
+// AdvectionDiffusionM1 (_advectiondiffusion.py:21-67) on the same evaluation site: Kh_zonal at x +- dres, UV, Kh_zonal at x, Kh_meridional
+// at y +- dres and at y -- seven samples whose `ei` guesses chain through one another exactly like in the general program (a sample that
+// starts in the cell of the point returns float64 (xsi, eta), one that has to move returns the float32-rounded ones of a hash hit:
+// SearchMemo of pk_device.h is that same rule, spelled as a re-use).
+template <class FT, int PFM>
+__global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID) advect_cgrid_m1_kernel(const KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const FastC& F = a.fastc;
+    CgLds L;
+    {
+        pk_tab2* s_tab = reinterpret_cast<pk_tab2*>(smem);
+        const pk_tab2* g_tab = reinterpret_cast<const pk_tab2*>(F.tab);
+        for (int k = threadIdx.x; k < F.lds_n; k += FC_LANES) s_tab[k] = g_tab[k];
+        __syncthreads();
+        L.time = s_tab + F.lds_time;
+        L.depth = s_tab + F.lds_depth;
+        L.rec = smem + F.lds_rec + threadIdx.x;
+        L.fv = (void*)((FT*)(smem + F.lds_fv) + threadIdx.x);
+    }
+    auto row = [&]() { return (int64_t)xcd_swizzle(blockIdx.x, gridDim.x) * FC_LANES + threadIdx.x; };
+    unsigned steps = 0, attempts = 0, paused = 0;
+    if (row() < a.p.n) {
+        int64_t i = row();
+        const DParticles& P = a.p;
+        const DPOut& O = a.po;
+        const pk_exec_params& prm = a.prm;
+        constexpr bool pf = PFM == 1;
+        CCtx c;
+        c.state = prm.reset_state ? PK_EVALUATE : P.state[i];  // kernel.py:188
+        if (c.state == PK_EVALUATE) {
+            unsigned it = prm.reset_state ? 0u : (unsigned)P.iter[i];
+            {
+                const int32_t ei0 = P.ei[i * P.ngrids + F.grid];
+                int gy, gx;
+                unravel_yx(a.grids[F.grid], (int64_t)ei0, gy, gx);
+                cctx_init(c, PK_EVALUATE, ei0, gy, gx);
+            }
+            double pt = P.t[i];
+            double pz = ldp(P.z, i, pf), py = ldp(P.y, i, pf), px = ldp(P.x, i, pf);
+            double pdz = ldp(P.dz, i, pf), pdy = ldp(P.dy, i, pf), pdx = ldp(P.dx, i, pf);
+            double pdt = P.dt[i];
+            const int64_t pid = P.particle_id[i];
+            const double endtime = prm.endtime;
+            const int sign = prm.dt0 > 0 ? 1 : -1;
+            const bool windowed = a.win_lo > -INFINITY || a.win_hi < INFINITY;
+            const double dres = prm.dres;
+            while (c.state == PK_EVALUATE) {  // :190
+                const double tte = sign * (endtime - pt);
+                if (!(tte >= 0)) break;  // :193-197
+                if (prm.max_iters > 0 && it >= (unsigned)prm.max_iters) break;
+                double dtc;
+                if (sign == 1) dtc = fmax(fmin(pdt, tte), 0.0);  // :200-203
+                else dtc = fmin(fmax(pdt, -tte), 0.0);
+                if (windowed) {
+                    const double t1 = pt + dtc;
+                    const double lo = fmin(pt, t1), hi = fmax(pt, t1);
+                    if (lo < a.win_lo || hi > a.win_hi) { paused = 1; break; }
+                }
+                it++;
+                pdt = dtc;
+                attempts++;
+                // seven samples at one call site (_advectiondiffusion.py:44-57): Kxp1, Kxm1, UV, khz, Kyp1, Kym1, khm
+                double Kxp1 = 0, Kxm1 = 0, khz = 0, Kyp1 = 0, Kym1 = 0, khm = 0, u = 0, v = 0;
+#pragma unroll 1
+                for (int stage = 0; stage < 7; stage++) {
+                    double sx = px, sy = py;
+                    int sk = stage < 4 ? 0 : 1;
+                    switch (stage) {
+                        case 0: sx = padd(pf, px, dres); break;
+                        case 1: sx = psub(pf, px, dres); break;
+                        case 2: sk = -1; break;
+                        case 4: sy = padd(pf, py, dres); break;
+                        case 5: sy = psub(pf, py, dres); break;
+                        default: break;
+                    }
+                    double r0, r1, r2;
+                    eval_uvw_cgrid<FT, pf, false, true>(a, L, c, pt, pz, sy, sx, pf, r0, r1, r2, sk);
+                    switch (stage) {
+                        case 0: Kxp1 = r0; break;
+                        case 1: Kxm1 = r0; break;
+                        case 2: u = r0; v = r1; break;
+                        case 3: khz = r0; break;
+                        case 4: Kyp1 = r0; break;
+                        case 5: Kym1 = r0; break;
+                        default: khm = r0; break;
+                    }
+                }
+                // prepare(PK_KERNEL_ADVECTIONDIFFUSION_M1) of the general program, spherical mesh
+                Kxp1 = m2_to_deg2_zonal(pf, Kxp1, py, F.deg2m);
+                Kxm1 = m2_to_deg2_zonal(pf, Kxm1, py, F.deg2m);
+                khz = m2_to_deg2_zonal(pf, khz, py, F.deg2m);
+                Kyp1 = m2_to_deg2_merid(Kyp1, F.deg2m);
+                Kym1 = m2_to_deg2_merid(Kym1, F.deg2m);
+                khm = m2_to_deg2_merid(khm, F.deg2m);
+                const double dKdx = (Kxp1 - Kxm1) / (2 * dres), dKdy = (Kyp1 - Kym1) / (2 * dres);
+                const double bx = sqrt(2 * khz), by = sqrt(2 * khm);
+                double z0, z1;
+                normal_pair(prm.seed, 0, pid, pt, z0, z1);
+                const double sq = sqrt(fabs(pdt));
+                const double dWx = sq * z0, dWy = sq * z1;
+                pdx = pstore(pf, pdx + (u * pdt + 0.5 * dKdx * (dWx * dWx + pdt) + bx * dWx));  // :66-67
+                pdy = pstore(pf, pdy + (v * pdt + 0.5 * dKdy * (dWy * dWy + pdt) + by * dWy));
+                for (int k = 1; k < prm.nk; k++) {  // the sampling-free recovery kernels that may follow (Delete*)
+                    const int kid = prm.kernels[k];
+                    attempts++;
+                    if (kid == PK_KERNEL_DELETE_ON_ERROR) {
+                        if (c.state >= PK_ERROR) c.state = PK_DELETE;
+                    } else if (c.state == PK_ERROROUTOFBOUNDS || c.state == PK_ERRORTHROUGHSURFACE) {
+                        c.state = PK_DELETE;
+                    }
+                }
+                if (c.state == PK_EVALUATE || c.state == PK_SUCCESS) {  // :219-222 -> _position_update :108-120
+                    if (tte > 0 && pt + pdt == pt) {
+                        c.state = PK_ERROR;
+                        break;
+                    }
+                    px = padd(pf, px, pdx);
+                    py = padd(pf, py, pdy);
+                    pz = padd(pf, pz, pdz);
+                    pt += pdt;
+                    pdx = pdy = pdz = 0.0;
+                    steps++;
+                }
+                pdt = prm.dt0;                                                        // :225-226 (not RK45 mode)
+                if (c.state == PK_EVALUATE && pt == endtime) c.state = PK_ENDOFLOOP;  // :229-230
+            }
+            i = row();
+            asm volatile("" : "+v"(i));
+            O.t[i] = pt;
+            stp(O.z, i, pz, pf);
+            stp(O.y, i, py, pf);
+            stp(O.x, i, px, pf);
+            stp(O.dz, i, pdz, pf);
+            stp(O.dy, i, pdy, pf);
+            stp(O.dx, i, pdx, pf);
+            O.dt[i] = pdt;
+            if (P.next_dt && O.next_dt != P.next_dt) O.next_dt[i] = P.next_dt[i];
+            O.state[i] = c.state;
+            for (int g = 0; g < P.ngrids; g++) O.ei[i * P.ngrids + g] = g == F.grid ? c.ei : P.ei[i * P.ngrids + g];
+            O.iter[i] = (int32_t)it;
+            note_error_iteration(a, c.state, it);
+        }
+    }
+    const unsigned long long wsteps = wave_sum((unsigned long long)steps), wattempts = wave_sum((unsigned long long)attempts),
+                             wpaused = wave_sum((unsigned long long)paused);
+    if ((threadIdx.x & 63) == 0) {
+        if (wsteps) atomicAdd(&a.counters->steps, wsteps);
+        if (wattempts) atomicAdd(&a.counters->attempts, wattempts);
+        if (wpaused) atomicAdd(&a.counters->paused, wpaused);
+    }
+}
+
 // fast C-grid programs: one TU defines launch_cgrid (field dtype x particle dtype x 2-D / 3-D)
 void launch_cgrid(int field_f32, int particles_f32, int d3, const KArgs& a, int64_t n, size_t lds_bytes, hipStream_t stream);
 void launch_cgrid_rk45(int field_f32, int particles_f32, const KArgs& a, int64_t n, size_t lds_bytes, hipStream_t stream);
+void launch_cgrid_m1(int field_f32, int particles_f32, const KArgs& a, int64_t n, size_t lds_bytes, hipStream_t stream);
 
 // One translation unit per program (compiled in parallel) defines launch_program<PROG>.
 // key bits: field f32 | curvilinear | C-grid ; lds: coordinate vectors staged in LDS

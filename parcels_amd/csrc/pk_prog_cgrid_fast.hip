@@ -36,4 +36,14 @@ void launch_cgrid_rk45(int field_f32, int particles_f32, const KArgs& a, int64_t
         else hipLaunchKernelGGL((advect_cgrid_rk45_kernel<double, 0>), grid, dim3(FC_LANES), lds_bytes, stream, a);
     }
 }
+void launch_cgrid_m1(int field_f32, int particles_f32, const KArgs& a, int64_t n, size_t lds_bytes, hipStream_t stream) {
+    const dim3 grid((unsigned)((n + FC_LANES - 1) / FC_LANES));
+    if (field_f32) {
+        if (particles_f32) hipLaunchKernelGGL((advect_cgrid_m1_kernel<float, 1>), grid, dim3(FC_LANES), lds_bytes, stream, a);
+        else hipLaunchKernelGGL((advect_cgrid_m1_kernel<float, 0>), grid, dim3(FC_LANES), lds_bytes, stream, a);
+    } else {
+        if (particles_f32) hipLaunchKernelGGL((advect_cgrid_m1_kernel<double, 1>), grid, dim3(FC_LANES), lds_bytes, stream, a);
+        else hipLaunchKernelGGL((advect_cgrid_m1_kernel<double, 0>), grid, dim3(FC_LANES), lds_bytes, stream, a);
+    }
+}
 }  // namespace pk

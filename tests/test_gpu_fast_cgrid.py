@@ -85,6 +85,21 @@ def test_rk45_on_the_fast_evaluation_equals_the_general_program(gpu, sdt, delete
     assert st["attempts"] > st["steps"], "no attempt was rejected: the test does not test the Repeat loop"
 
 
+@pytest.mark.parametrize("kh", ["node4d", "node2d"])
+@pytest.mark.parametrize("sdt", ["float64", "float32"])
+def test_m1_on_the_fast_evaluation_equals_the_general_program(gpu, kh, sdt):
+    """AdvectionDiffusionM1 through advect_cgrid_m1_kernel: six scalar samples (Kh_zonal / Kh_meridional on the grid's nodes, 4-D with
+    their own time / depth interpolation or 2-D) + one velocity sample per step, the `ei` guesses chained through all seven -- bit for
+    bit the general program (which re-uses the velocity sample's grid position where the reference's renewed search would return it),
+    the oracle to 1e-11 (Box-Muller's log / sin / cos)."""
+    from oracle import cases
+
+    case = cases.curv_cgrid_diffusion_case("fastc_m1", mesh="spherical", kernels=["AdvectionDiffusionM1", "DeleteParticle"], seed=31, npart=2500,
+                                           spatial_dtype=sdt, kh=kh, dt=1800.0)
+    fast, st = _check(case, rtol=5e-7 if sdt == "float32" else 1e-11)
+    assert st["steps"] > 10 * len(fast["x"])
+
+
 def test_cells_are_crossed_and_particles_leave_the_mesh(gpu):
     """Fast flow on a small mesh: most stages cross a cell edge (neighbour probe), many particles leave the mesh (the table walk
     finds nothing: GridSearchingError -> DeleteParticle) or the depth range."""

@@ -33,6 +33,9 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+MATCH = "advect"  # --match: substring that selects the advection kernel of interest (a run of config c5 launches two programs)
+
+
 def read_pass(d):
     """-> {kernel class: [ {counter: value, ...} per dispatch ]} for the advection and the copy kernel"""
     out = {"advect": {}, "copy": {}}
@@ -42,7 +45,7 @@ def read_pass(d):
         return out, meta
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        cls = "advect" if "advect" in k else ("copy" if "copy_kernel" in k else None)
+        cls = "advect" if ("advect" in k and MATCH in k) else ("copy" if "copy_kernel" in k else None)
         if cls is None:
             continue
         disp = int(r["Dispatch_Id"])
@@ -86,7 +89,11 @@ def main():
     ap.add_argument("--evals-per-step", type=int, default=4)
     ap.add_argument("--no-latest", action="store_true", help="do not rewrite profiles/pmc_latest.json (passes of tools/gpu_profile_cfg.sh: C3 / C5, not the bench workload)")
     ap.add_argument("--psteps", type=float, default=0, help="particle-steps of the profiled launch when it is not particles x steps (deleted particles)")
+    ap.add_argument("--match", default="advect", help="substring of the kernel name to summarise (e.g. rk45_kernel, m1_kernel)")
+    ap.add_argument("--secondary", default=None, help="also record this kernel under that key in profiles/pmc_secondary_latest.json (bench.py's `secondary` reads it)")
     a = ap.parse_args()
+    global MATCH
+    MATCH = a.match
     g = os.path.join(ROOT, "gpurun_out", a.tag + "_")
     npart, K = int(a.particles), a.steps
     psteps = int(a.psteps) if a.psteps else npart * K
@@ -127,6 +134,15 @@ def main():
         out["traffic_bytes_per_launch"] = fetch_b + write_b
     if not a.no_latest:
         json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1)
+    if a.secondary:
+        sp = os.path.join(ROOT, "profiles", "pmc_secondary_latest.json")
+        sec = json.load(open(sp)) if os.path.exists(sp) else {}
+        pps = out["per_particle_step"]
+        sec[a.secondary] = {"source": out["source"], "source_hash": out["source_hash"], "kernel": meta.get("kernel"), "scratch": meta.get("scratch"),
+                            "hbm_bytes_per_particle_step": (pps["fetch_bytes"] + pps["write_bytes"]) if pps["fetch_bytes"] is not None and pps["write_bytes"] is not None else None,
+                            "valu_insts_per_wave_eval": pps["valu_insts_per_wave_eval"], "salu_insts_per_wave_eval": pps["salu_insts_per_wave_eval"],
+                            "valu_utilisation_at_measured_clock": out["profiled_launch"]["valu_utilisation_at_measured_clock"]}
+        json.dump(sec, open(sp, "w"), indent=1)
     L = [f"# PMC counters of the timed advection launch ({a.tag}): {npart} particles x {K} steps", "",
          f"kernel `{meta.get('kernel', '?')[:120]}`: arch VGPR {meta.get('vgpr')} (+{meta.get('accum_vgpr')} acc), SGPR {meta.get('sgpr')}, LDS {meta.get('lds')} B, scratch {meta.get('scratch')} B/lane", "",
          "| counter | value | per wave-evaluation |", "|---|---|---|"]
