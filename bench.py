@@ -192,6 +192,7 @@ def secondary_runs(args):
                 e["roofline"]["counters_source"] = pp.get("source")
                 e["roofline"]["valu_insts_per_wave_evaluation"] = pp.get("valu_insts_per_wave_eval")
                 e["roofline"]["scratch_bytes_per_lane"] = pp.get("scratch")
+                e["roofline"]["counters_stale"] = pp.get("source_hash") != kernel_source_hash()  # kernels changed since the PMC passes
             if r.get("check"):
                 c = r["check"]
                 e["check"] = {"passed": True, "n_check": c["n_check"], "deleted": c["deleted"], "exact": c["exact"],
