@@ -260,6 +260,13 @@ int32_t pk_particles_d2h(pk_ctx* ctx);
 int32_t pk_particles_d2h_columns(pk_ctx* ctx, uint32_t column_mask);
 /* Selection of a pk_exec_params.body_only launch: mask[i] != 0 <=> host row i takes part (n int32 values in host row order). */
 int32_t pk_particles_set_mask(pk_ctx* ctx, const int32_t* mask);
+/* Device-side checkpoint of every particle column (and of the row order of the cell sort): _checkpoint keeps a copy, _restore puts
+ * it back.  For a Kernel.execute that spans several launches (streamed time levels, re-sort horizons): when a particle errs in a later
+ * launch the reference has stopped EVERY particle after that iteration of its batch loop (kernel.py:236-245), which only a run from
+ * the state before the first launch with pk_exec_params.max_iters can reproduce (single launches: pk_execute_rerun).  Binding other
+ * particles discards the checkpoint; ~88 B of HBM per particle. */
+int32_t pk_particles_checkpoint(pk_ctx* ctx);
+int32_t pk_particles_restore(pk_ctx* ctx);
 /* Asynchronous write-out (ParticleSet.execute's output step, particleset.py:452-459, overlapped with the next interval):
  * _begin snapshots the selected columns -- un-sorted into host row order -- into one of two device staging sets on the compute
  * stream and enqueues their copy into pinned host columns on the copy stream; it returns at once and the next pk_execute may

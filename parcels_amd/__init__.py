@@ -41,6 +41,7 @@ from .kernels import (
 )
 from .particle import Particle, ParticleClass, Variable, get_default_particle
 from .particlefile import ParticleFile, read_particlefile
+from .compat_v3 import particlefile_to_v3_zarr
 from .particleset import ParticleSet, ParticleSetWarning
 from .sgrid import FaceNodePadding, Padding, SGrid2DMetadata
 from .sources import LevelSource, NetCDFLevels, NpyLevels, ZarrLevels, read_netcdf_variable

@@ -91,6 +91,11 @@ struct pk_ctx {
     // the last advection launch wrote into the second column set, which now is `dev`; `alt` still holds what it read
     bool rerun_valid = false;
     pk_exec_params rerun_prm{};
+    // pk_particles_checkpoint: one packed device copy of every column (+ the row permutation of the cell sort)
+    char* d_chk = nullptr;
+    size_t chk_bytes = 0;
+    bool chk_valid = false, chk_has_perm = false;
+    int64_t chk_n = 0;
     bool fl_sorted = false;
     int64_t fl_n = 0;
     DCounters* h_counters = nullptr;          // pinned: the async D2H of the counters must not block the host
@@ -567,6 +572,10 @@ static void free_snapshots(pk_ctx* ctx) {
 }
 
 static void free_particles(pk_ctx* ctx) {
+    if (ctx->d_chk) (void)hipFree(ctx->d_chk);
+    ctx->d_chk = nullptr;
+    ctx->chk_bytes = 0;
+    ctx->chk_valid = false;
     void* cols[] = {ctx->dev.t,  ctx->dev.z,  ctx->dev.y,       ctx->dev.x,     ctx->dev.dz, ctx->dev.dy,
                     ctx->dev.dx, ctx->dev.dt, ctx->dev.next_dt, ctx->dev.state, ctx->dev.ei, ctx->dev.particle_id, ctx->dev.iter, ctx->alt.iter};
     ctx->rerun_valid = false;
@@ -1069,6 +1078,7 @@ int32_t pk_particles_bind(pk_ctx* ctx, const pk_particles_desc* host) {
     for (int k = 0; k < PK_MAX_EXTRA; k++) ctx->dev.extra_f32[k] = ctx->alt.extra_f32[k] = (k < host->n_extra && host->extra_dtype[k] == PK_F32);
     ctx->has_perm = false;
     ctx->rerun_valid = false;
+    ctx->chk_valid = false;
     ctx->dev.n = host->n;
     ctx->dev.ngrids = host->ngrids;
     ctx->dev.spatial_f32 = host->spatial_dtype == PK_F32;
@@ -1251,6 +1261,69 @@ int32_t pk_particles_set_mask(pk_ctx* ctx, const int32_t* mask) {
     PK_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->dev.n > 0) PK_HIP(ctx, hipMemcpyAsync(ctx->dev.iter, mask, (size_t)ctx->dev.n * 4, hipMemcpyHostToDevice, ctx->compute));
     PK_HIP(ctx, hipStreamSynchronize(ctx->compute));
+    return 0;
+}
+
+// The state of every device column (and the row order of the cell sort) as of now, kept on the device: what a Kernel.execute that
+// spans several launches (streamed levels, re-sort horizons) goes back to when a particle errs in a later launch and the whole
+// batch has to stop at that iteration (kernel.py:236-245).  One packed buffer of ~88 B per particle, allocated on first use.
+static int32_t checkpoint_copy(pk_ctx* ctx, bool save) {
+    const int64_t n = save ? ctx->dev.n : ctx->chk_n;
+    size_t off = 0;
+    for (const ColRef& c : particle_columns(ctx)) {
+        if (!c.d) continue;
+        const size_t bytes = (size_t)n * c.elem * c.width;
+        if (bytes) {
+            if (save) PK_HIP(ctx, hipMemcpyAsync(ctx->d_chk + off, c.d, bytes, hipMemcpyDeviceToDevice, ctx->compute));
+            else PK_HIP(ctx, hipMemcpyAsync(c.d, ctx->d_chk + off, bytes, hipMemcpyDeviceToDevice, ctx->compute));
+        }
+        off += (bytes + 255) & ~(size_t)255;
+    }
+    if (save ? ctx->has_perm : ctx->chk_has_perm) {
+        const size_t bytes = (size_t)n * 8;
+        if (save) PK_HIP(ctx, hipMemcpyAsync(ctx->d_chk + off, ctx->d_perm, bytes, hipMemcpyDeviceToDevice, ctx->compute));
+        else PK_HIP(ctx, hipMemcpyAsync(ctx->d_perm, ctx->d_chk + off, bytes, hipMemcpyDeviceToDevice, ctx->compute));
+    }
+    PK_HIP(ctx, hipStreamSynchronize(ctx->compute));
+    return 0;
+}
+int32_t pk_particles_checkpoint(pk_ctx* ctx) {
+    if (!ctx) return -2;
+    if (!ctx->bound) return ctx->fail("no particles bound");
+    if (ctx->in_flight) return ctx->fail("pk_particles_checkpoint: a launch is in flight (call pk_execute_end)");
+    PK_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t n = ctx->dev.n;
+    size_t need = 0;
+    for (const ColRef& c : particle_columns(ctx))
+        if (c.d) need += ((size_t)n * c.elem * c.width + 255) & ~(size_t)255;
+    need += (size_t)n * 8 + 256;  // the permutation
+    if (need > ctx->chk_bytes) {
+        if (ctx->d_chk) (void)hipFree(ctx->d_chk);
+        ctx->d_chk = nullptr;
+        ctx->chk_bytes = 0;
+        PK_HIP(ctx, hipMalloc((void**)&ctx->d_chk, need));
+        ctx->chk_bytes = need;
+    }
+    ctx->chk_valid = false;
+    const int32_t rc = checkpoint_copy(ctx, true);
+    if (rc) return rc;
+    ctx->chk_n = n;
+    ctx->chk_has_perm = ctx->has_perm;
+    ctx->chk_valid = true;
+    return 0;
+}
+int32_t pk_particles_restore(pk_ctx* ctx) {
+    if (!ctx) return -2;
+    if (!ctx->bound) return ctx->fail("no particles bound");
+    if (ctx->in_flight) return ctx->fail("pk_particles_restore: a launch is in flight (call pk_execute_end)");
+    if (!ctx->chk_valid) return ctx->fail("pk_particles_restore: no checkpoint (pk_particles_checkpoint; binding new particles discards it)");
+    if (ctx->chk_n != ctx->dev.n) return ctx->fail("pk_particles_restore: the particle count changed since the checkpoint");
+    PK_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->chk_has_perm && !ctx->d_perm) return ctx->fail("pk_particles_restore: permutation buffer missing (internal error)");
+    const int32_t rc = checkpoint_copy(ctx, false);
+    if (rc) return rc;
+    ctx->has_perm = ctx->chk_has_perm;
+    ctx->rerun_valid = false;
     return 0;
 }
 

@@ -534,69 +534,94 @@ class DeviceEngine:
         # the next level while the kernel runs, wait = pk_execute_end after the prefetch was enqueued
         total = {"steps": 0, "attempts": 0, "kernel_ms": 0.0, "sort_ms": 0.0, "launches": 0, "commit_s": 0.0, "prefetch_s": 0.0, "wait_s": 0.0,
                  "first_error_iter": 0, "reran": 0}
-        reset = 1
-        t_live = t_start
-        last_live = None
-        span = None
+        span0 = None
         if resort_every and sort_by_cell:
             ctx_ = context or {}
-            span = max(float(resort_every), abs(float(dt0)), abs(float(ctx_.get("RK45_max_dt", 0.0))))
-        while True:
-            nxt = None
-            if self.windowed:
-                if t_live is None or not np.isfinite(t_live):
-                    t_live = 0.0 if sign > 0 else max(float(f.model.time_flt[-1]) for f in self._windowed_fields())
-                _t = _time.perf_counter()
-                nxt = self._commit_window(float(t_live), sign)
-                total["commit_s"] += _time.perf_counter() - _t
-            horizon = None
-            if span is not None and t_live is not None and np.isfinite(t_live):
-                horizon = (-np.inf, float(t_live) + span) if sign > 0 else (float(t_live) - span, np.inf)
-            prm = self.make_params(kernel_ids, endtime=endtime, dt0=dt0, context=context, seed=seed, reset_state=reset,
-                                   have_guess0=(have_guess0 if reset else 1), sort_by_cell=sort_by_cell, samples=samples, horizon=horizon)
-            st = _hip.ExecStats()
-            self.ctx.check(self.lib.pk_execute_begin(self.ctx.handle, C.byref(prm)), "pk_execute_begin")
-            prefetched = False
-            try:
-                _t = _time.perf_counter()
-                prefetched = self._prefetch(nxt)  # overlaps the kernel that was just launched
-                total["prefetch_s"] += _time.perf_counter() - _t
-            finally:
-                _t = _time.perf_counter()
-                self.ctx.check(self.lib.pk_execute_end(self.ctx.handle, C.byref(st)), "pk_execute_end")
-                total["wait_s"] += _time.perf_counter() - _t
-            reset = 0
-            if st.first_error_iter > 0 and self.exact_error_stop:
-                # kernel.py:236-245: stop every particle after the iteration in which the first one erred
-                total["first_error_iter"] = int(st.first_error_iter)
-                total["reran"] += 1
-                ms = st.kernel_ms
+            span0 = max(float(resort_every), abs(float(dt0)), abs(float(ctx_.get("RK45_max_dt", 0.0))))
+        # A run that may take several launches keeps the state before the first one on the device: an error in a LATER launch stops the
+        # whole batch at an iteration some particles passed launches ago (kernel.py:236-245), so the run starts over with that limit.
+        checkpointed = False
+        if (self.windowed or span0 is not None) and self.exact_error_stop:
+            self.ctx.check(self.lib.pk_particles_checkpoint(self.ctx.handle), "pk_particles_checkpoint")
+            checkpointed = True
+        cap = 0  # iteration limit of the batch loop (0: none)
+        restart = True
+        while restart:
+            restart = False
+            reset = 1
+            t_live = t_start
+            last_live = None
+            span = span0
+            first_launch = True
+            while True:
+                nxt = None
+                if self.windowed:
+                    if t_live is None or not np.isfinite(t_live):
+                        t_live = 0.0 if sign > 0 else max(float(f.model.time_flt[-1]) for f in self._windowed_fields())
+                    _t = _time.perf_counter()
+                    nxt = self._commit_window(float(t_live), sign)
+                    total["commit_s"] += _time.perf_counter() - _t
+                horizon = None
+                if span is not None and t_live is not None and np.isfinite(t_live):
+                    horizon = (-np.inf, float(t_live) + span) if sign > 0 else (float(t_live) - span, np.inf)
+                prm = self.make_params(kernel_ids, endtime=endtime, dt0=dt0, context=context, seed=seed, reset_state=reset,
+                                       have_guess0=(have_guess0 if reset else 1), sort_by_cell=sort_by_cell, samples=samples, horizon=horizon,
+                                       max_iters=cap)
                 st = _hip.ExecStats()
-                self.ctx.check(self.lib.pk_execute_rerun(self.ctx.handle, int(total["first_error_iter"]), C.byref(st)), "pk_execute_rerun")
-                st.kernel_ms += ms
-            total["steps"] += st.steps
-            total["attempts"] += st.attempts
-            total["kernel_ms"] += st.kernel_ms
-            total["sort_ms"] += st.sort_ms
-            total["launches"] += st.launches
-            total["program"] = int(st.program)  # which device program the (last) launch ran: include/parcels_hip.h, pk_exec_stats
-            counts = {code: int(st.state_counts[code]) for code in range(_hip.PK_NUM_STATE_CODES) if st.state_counts[code]}
-            if st.paused == 0 or total["reran"]:
-                break
-            if not self.windowed and span is None:
-                raise _hip.HipLibraryError("particles paused although all time levels are resident (internal error)")
-            t_live = st.t_min_live if sign > 0 else st.t_max_live
-            # no particle moved AND no new level is on its way (a small ring needs one launch per cycle just to bring in the
-            # level behind the window; the next commit makes it resident): the step itself does not fit
-            if last_live is not None and t_live == last_live and not prefetched:
-                if span is not None:
-                    span *= 2.0  # the soft horizon, not the ring, stopped every particle: widen it
-                else:
-                    raise RuntimeError(
-                        "field window too small: a single step does not fit into the resident time levels; "
-                        "increase nslots (FieldSet.to_device(nslots=...))"
-                    )
-            last_live = t_live
+                self.ctx.check(self.lib.pk_execute_begin(self.ctx.handle, C.byref(prm)), "pk_execute_begin")
+                prefetched = False
+                try:
+                    _t = _time.perf_counter()
+                    prefetched = self._prefetch(nxt)  # overlaps the kernel that was just launched
+                    total["prefetch_s"] += _time.perf_counter() - _t
+                finally:
+                    _t = _time.perf_counter()
+                    self.ctx.check(self.lib.pk_execute_end(self.ctx.handle, C.byref(st)), "pk_execute_end")
+                    total["wait_s"] += _time.perf_counter() - _t
+                reset = 0
+                err_at = int(st.first_error_iter)
+                if err_at > 0 and self.exact_error_stop and (cap == 0 or err_at < cap):
+                    # kernel.py:236-245: stop every particle after the iteration in which the first one erred
+                    cap = err_at
+                    total["first_error_iter"] = cap
+                    total["reran"] += 1
+                    total["kernel_ms"] += st.kernel_ms
+                    total["sort_ms"] += st.sort_ms
+                    total["launches"] += st.launches
+                    if first_launch:  # the state before this launch still sits in the second column set
+                        st = _hip.ExecStats()
+                        self.ctx.check(self.lib.pk_execute_rerun(self.ctx.handle, cap, C.byref(st)), "pk_execute_rerun")
+                    else:
+                        if not checkpointed:
+                            raise _hip.HipLibraryError("error in a later launch of a run without a checkpoint (internal error)")
+                        self.ctx.check(self.lib.pk_particles_restore(self.ctx.handle), "pk_particles_restore")
+                        total["steps"] = total["attempts"] = 0
+                        restart = True
+                        break
+                first_launch = False
+                total["steps"] += st.steps
+                total["attempts"] += st.attempts
+                total["kernel_ms"] += st.kernel_ms
+                total["sort_ms"] += st.sort_ms
+                total["launches"] += st.launches
+                total["program"] = int(st.program)  # which device program the (last) launch ran: include/parcels_hip.h, pk_exec_stats
+                counts = {code: int(st.state_counts[code]) for code in range(_hip.PK_NUM_STATE_CODES) if st.state_counts[code]}
+                if st.paused == 0:
+                    break
+                if not self.windowed and span is None:
+                    raise _hip.HipLibraryError("particles paused although all time levels are resident (internal error)")
+                t_live = st.t_min_live if sign > 0 else st.t_max_live
+                # no particle moved AND no new level is on its way (a small ring needs one launch per cycle just to bring in the
+                # level behind the window; the next commit makes it resident): the step itself does not fit
+                if last_live is not None and t_live == last_live and not prefetched:
+                    if span is not None:
+                        span *= 2.0  # the soft horizon, not the ring, stopped every particle: widen it
+                    else:
+                        raise RuntimeError(
+                            "field window too small: a single step does not fit into the resident time levels; "
+                            "increase nslots (FieldSet.to_device(nslots=...))"
+                        )
+                last_live = t_live
         total["state_counts"] = counts
         self.last_stats = total
         return total
