@@ -29,18 +29,26 @@ namespace pk {
 // 16..19 unwrapped corner longitudes, 20..23 corner latitudes, 24..27 pv (projected corners, second coordinate: only the degenerate
 // branch of the bilinear inverse reads them), 28..31 unused
 constexpr int CT2_STRIDE = 32;
-constexpr int FC_REC_ROWS = 23;  // LDS rows of a lane's slot: record rows 0..14, then 16..23
+// What a lane caches of its cell, and where (`CM`, a template parameter of everything below; one value per kernel, pk_kernels.h).
+// The LDS slot and the register count together bound the occupancy of these one-wavefront workgroups: 23 record rows + 12 field values
+// in LDS are 232 B per lane = 10 workgroups per CU (160 KB), and ~170 VGPRs are 2 waves per SIMD.  Bit 0 (CG_FV_REGS): the 12 staggered
+// field values live in registers; bit 1 (CG_PXY_REGS): the 8 corner coordinates CGrid_Velocity reads (rows 16..23 of the record) do.
+// Both are read with compile-time indices only.  The 15 rows of the point-in-cell test always stay in LDS.
+constexpr int CG_FV_REGS = 1, CG_PXY_REGS = 2;
+constexpr int fc_rec_rows(int cm) { return (cm & CG_PXY_REGS) ? 15 : 23; }  // LDS rows of a lane's slot: record rows 0..14 (then 16..23)
+constexpr int fc_fv_lds(int cm) { return (cm & CG_FV_REGS) ? 0 : 12; }       // field values of a lane kept in LDS
 constexpr int FC_LANES = 64;     // one-wavefront workgroups (see CC_LANES)
 
 struct CgLds {
     const pk_tab2* time;   // {a, 1/width} tables
     const pk_tab2* depth;
-    double* rec;           // [FC_REC_ROWS][64] + lane
-    void* fv;              // [12][64] of the field dtype + lane
+    double* rec;           // [fc_rec_rows(CM)][64] + lane
+    void* fv;              // [fc_fv_lds(CM)][64] of the field dtype + lane
 };
 
-// per-particle evaluation context of the fast C-grid kernels
-struct CCtx {
+// per-particle evaluation context of the fast C-grid kernels (FT: dtype of the velocity fields)
+template <class FT, int CM>
+struct CCtxT {
     int state;
     int32_t ei;
     int ht, hz;          // cells of the previous time / depth search (valid cell indices: hints)
@@ -52,8 +60,11 @@ struct CCtx {
     // AdvectionDiffusionM1's program: its seven samples per step share latitudes (x +- dres, x) and longitudes (y +- dres, y) -- the
     // sines / cosines of the query point are memoised on the bits of the coordinate (unused, and optimised away, elsewhere)
     double qy, qx, q_sl, q_cl, q_so, q_co;
+    FT fvr[(CM & CG_FV_REGS) ? 12 : 1];      // the cached field values (CG_FV_REGS)
+    double pxy[(CM & CG_PXY_REGS) ? 8 : 1];  // unwrapped corner longitudes, corner latitudes of rc_cell (CG_PXY_REGS)
 };
-PK_DEV void cctx_init(CCtx& c, int state, int32_t ei, int gy, int gx) {
+template <class FT, int CM>
+PK_DEV void cctx_init(CCtxT<FT, CM>& c, int state, int32_t ei, int gy, int gx) {
     c.state = state;
     c.ei = ei;
     c.ht = c.hz = 0;
@@ -67,6 +78,10 @@ PK_DEV void cctx_init(CCtx& c, int state, int32_t ei, int gy, int gx) {
     c.mtau = c.mzeta = 0.0;
     c.qy = c.qx = __builtin_nan("");
     c.q_sl = c.q_cl = c.q_so = c.q_co = 0.0;
+#pragma unroll
+    for (int k = 0; k < ((CM & CG_FV_REGS) ? 12 : 1); k++) c.fvr[k] = (FT)0;
+#pragma unroll
+    for (int k = 0; k < ((CM & CG_PXY_REGS) ? 8 : 1); k++) c.pxy[k] = 0.0;
 }
 
 // Fetch the ct2 record of `cell` into the lane's LDS slot -- and, WITH_F, the staggered field values of (zi, yi, xi) at level ti
@@ -114,20 +129,26 @@ PK_DEV void cg_issue_fields(const FastC& F, int zi, int yi, int xi, int ti, bool
         }
     }
 }
-template <class FT>
-PK_DEV void cg_store_fields(CCtx& c, const CgLds& L, int cell, int zi, int ti, bool lenT, const FT raw[12]) {
-    FT* fv = (FT*)L.fv;
+template <class FT, int CM>
+PK_DEV void cg_store_fields(CCtxT<FT, CM>& c, const CgLds& L, int cell, int zi, int ti, bool lenT, const FT raw[12]) {
+    if constexpr ((CM & CG_FV_REGS) != 0) {
 #pragma unroll
-    for (int k = 0; k < 12; k++) fv[k * FC_LANES] = raw[k];
+        for (int k = 0; k < 12; k++) c.fvr[k] = raw[k];
+    } else {
+        FT* fv = (FT*)L.fv;
+#pragma unroll
+        for (int k = 0; k < 12; k++) fv[k * FC_LANES] = raw[k];
+    }
     c.fv_cell = cell;
     c.fv_zt = (ti << 13) | (zi << 1) | (lenT ? 1 : 0);
 }
-PK_DEV bool cg_fields_cached(const CCtx& c, int cell, int zi, int ti, bool lenT) {
+template <class FT, int CM>
+PK_DEV bool cg_fields_cached(const CCtxT<FT, CM>& c, int cell, int zi, int ti, bool lenT) {
     return c.fv_cell == cell && (c.fv_zt >> 1) == ((ti << 12) | zi) && (!lenT || (c.fv_zt & 1));
 }
 
-template <class FT, bool D3, bool WITH_F>
-PK_DEV double cg_fetch_cell(const FastC& F, const CgLds& L, CCtx& c, int cell, int yi, int xi, int zi, int ti, bool lenT) {
+template <class FT, bool D3, bool WITH_F, int CM>
+PK_DEV double cg_fetch_cell(const FastC& F, const CgLds& L, CCtxT<FT, CM>& c, int cell, int yi, int xi, int zi, int ti, bool lenT) {
     const double* g = F.ct2 + (int64_t)cell * CT2_STRIDE;
     double r[24];
 #pragma unroll
@@ -140,11 +161,16 @@ PK_DEV double cg_fetch_cell(const FastC& F, const CgLds& L, CCtx& c, int cell, i
     double* rec = L.rec;
 #pragma unroll
     for (int k = 0; k < 15; k++) rec[k * FC_LANES] = r[k];
+    if constexpr ((CM & CG_PXY_REGS) != 0) {
 #pragma unroll
-    for (int k = 0; k < 8; k++) rec[(15 + k) * FC_LANES] = r[16 + k];
+        for (int k = 0; k < 8; k++) c.pxy[k] = r[16 + k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) rec[(15 + k) * FC_LANES] = r[16 + k];
+    }
     c.rc_cell = cell;
     if (WITH_F) {
-        if (wantf) cg_store_fields<FT>(c, L, cell, zi, ti, lenT, raw);
+        if (wantf) cg_store_fields<FT, CM>(c, L, cell, zi, ti, lenT, raw);
     }
     return r[15];
 }
@@ -235,8 +261,8 @@ PK_DEV double cg_scalar_xlinear(const FastC& F, int k, int ti, double tau, int z
 // WITH_SCALAR (AdvectionDiffusionM1's program): `sk` >= 0 asks for Field.eval (field.py:145-195) of scalar field FastC::kh[sk] instead --
 // same search on the same grid (the `ei` guess chain of the particle runs through velocity and scalar samples alike), XLinear on the
 // field's nodes; the value is returned in u.  One call site serves all seven samples of a step (sk is a run-time value there).
-template <class FT, bool PF, bool D3, bool WITH_SCALAR = false>
-PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtx& c, double t, double z, double y, double x, bool pos_f32, double& u,
+template <class FT, bool PF, bool D3, bool WITH_SCALAR = false, int CM = 0>
+PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtxT<FT, CM>& c, double t, double z, double y, double x, bool pos_f32, double& u,
                            double& v, double& w, int sk = -1) {
     const FastC& F = a.fastc;
     const bool scalar = WITH_SCALAR && sk >= 0;
@@ -287,8 +313,8 @@ PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtx& c, double t, do
     if (__builtin_expect(guess_ok, 1)) {
         const int cell = c.gy * F.gnx + c.gx;
         if (c.rc_cell != cell) {  // (a scalar sample fetches the record only)
-            if (scalar) cg_fetch_cell<FT, D3, false>(F, L, c, cell, c.gy, c.gx, zi, ti, lenT);
-            else cg_fetch_cell<FT, D3, true>(F, L, c, cell, c.gy, c.gx, zi, ti, lenT);
+            if (scalar) cg_fetch_cell<FT, D3, false, CM>(F, L, c, cell, c.gy, c.gx, zi, ti, lenT);
+            else cg_fetch_cell<FT, D3, true, CM>(F, L, c, cell, c.gy, c.gx, zi, ti, lenT);
         }
         double xs, et;
         if (cg_point_in_cell(F, L.rec, cell, qX, qY, qZ, xs, et)) {
@@ -303,7 +329,7 @@ PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtx& c, double t, do
             const int nj = c.gy + dj, ni = c.gx + di;
             if ((dj | di) != 0 && nj >= 0 && nj < F.gny - 1 && ni >= 0 && ni < F.gnx - 1) {
                 const int ncell = nj * F.gnx + ni;
-                const double boxd = scalar ? cg_fetch_cell<FT, D3, false>(F, L, c, ncell, nj, ni, zi, ti, lenT) : cg_fetch_cell<FT, D3, true>(F, L, c, ncell, nj, ni, zi, ti, lenT);
+                const double boxd = scalar ? cg_fetch_cell<FT, D3, false, CM>(F, L, c, ncell, nj, ni, zi, ti, lenT) : cg_fetch_cell<FT, D3, true, CM>(F, L, c, ncell, nj, ni, zi, ti, lenT);
                 double xs2, et2;
                 const double m = 1e-9;
                 if (cg_point_in_cell(F, L.rec, ncell, qX, qY, qZ, xs2, et2) && xs2 > m && xs2 < 1 - m && et2 > m && et2 < 1 - m) {
@@ -357,24 +383,34 @@ PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtx& c, double t, do
     const int cell = yi * F.gnx + xi;
     const bool need_rec = c.rc_cell != cell, need_f = !cg_fields_cached(c, cell, zi, ti, lenT);
     if (__builtin_expect(need_rec, 0)) {  // found by the table walk
-        cg_fetch_cell<FT, D3, true>(F, L, c, cell, yi, xi, zi, ti, lenT);
+        cg_fetch_cell<FT, D3, true, CM>(F, L, c, cell, yi, xi, zi, ti, lenT);
     } else if (need_f) {  // same cell, another depth or time level
         FT raw[12];
         cg_issue_fields<FT, D3>(F, zi, yi, xi, ti, lenT, raw);
-        cg_store_fields<FT>(c, L, cell, zi, ti, lenT, raw);
+        cg_store_fields<FT, CM>(c, L, cell, zi, ti, lenT, raw);
     }
     // ---- CGrid_Velocity.interp (_xinterpolators.py:193-332), float64 coordinates and barycentric arrays ----
-    const double* rec = L.rec;
     double px[4], py[4];
+    if constexpr ((CM & CG_PXY_REGS) != 0) {
 #pragma unroll
-    for (int k = 0; k < 4; k++) { px[k] = rec[(15 + k) * FC_LANES]; py[k] = rec[(19 + k) * FC_LANES]; }
-    const FT* fv = (const FT*)L.fv;
+        for (int k = 0; k < 4; k++) { px[k] = c.pxy[k]; py[k] = c.pxy[4 + k]; }
+    } else {
+        const double* rec = L.rec;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { px[k] = rec[(15 + k) * FC_LANES]; py[k] = rec[(19 + k) * FC_LANES]; }
+    }
     FT rawf[12];
+    if constexpr ((CM & CG_FV_REGS) != 0) {
 #pragma unroll
-    for (int k = 0; k < 6; k++) rawf[k] = fv[k * FC_LANES];
-    if (lenT) {
+        for (int k = 0; k < 12; k++) rawf[k] = c.fvr[k];
+    } else {
+        const FT* fv = (const FT*)L.fv;
 #pragma unroll
-        for (int k = 0; k < 6; k++) rawf[6 + k] = fv[(6 + k) * FC_LANES];
+        for (int k = 0; k < 6; k++) rawf[k] = fv[k * FC_LANES];
+        if (lenT) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) rawf[6 + k] = fv[(6 + k) * FC_LANES];
+        }
     }
     const double omx = 1 - xsi, ome = 1 - eta;
     // einsum("ij,ji->i", phi2D_lin(eta, xsi), py) at (0, xsi), (eta, 1), (1, xsi), (eta, 0): the products with an exact zero weight

@@ -719,9 +719,27 @@ __global__ void __launch_bounds__(256, PK_MIN_WAVES_FAST) advect_fast_kernel(con
 // ---- AdvectionRK4 / AdvectionRK4_3D with CGrid_Velocity on a spherical curvilinear C-grid (BASELINE configs 3 / 4) -------------
 // The step loop of advect_fast_kernel around the evaluation site of pk_fast_cgrid.h; one-wavefront workgroups, because the
 // per-lane LDS slot (record of the particle's cell + its 12 staggered field values, ~15 KB per wavefront) is what bounds residency.
+// Occupancy target and cell-cache placement (pk_fast_cgrid.h: CG_FV_REGS | CG_PXY_REGS) of the three kernels, chosen by measurement on
+// config 3 / 5 (tools/ab_cgrid_occupancy.sh, profiles/r03_r_cgrid_occupancy.txt); overridable for A/B builds.
 #ifndef PK_MIN_WAVES_CGRID
-#define PK_MIN_WAVES_CGRID 2
+#define PK_MIN_WAVES_CGRID 3
 #endif
+#ifndef PK_MIN_WAVES_CGRID_RK45
+#define PK_MIN_WAVES_CGRID_RK45 3
+#endif
+#ifndef PK_MIN_WAVES_CGRID_M1
+#define PK_MIN_WAVES_CGRID_M1 3
+#endif
+#ifndef PK_CG_CACHE
+#define PK_CG_CACHE 2
+#endif
+#ifndef PK_CG_CACHE_RK45
+#define PK_CG_CACHE_RK45 2
+#endif
+#ifndef PK_CG_CACHE_M1
+#define PK_CG_CACHE_M1 2
+#endif
+constexpr int CG_CACHE_RK4 = PK_CG_CACHE, CG_CACHE_RK45 = PK_CG_CACHE_RK45, CG_CACHE_M1 = PK_CG_CACHE_M1;
 template <class FT, int PFM, bool D3>
 __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID) advect_cgrid_kernel(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -745,7 +763,7 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID) advect_cgrid_ker
         const DPOut& O = a.po;
         const pk_exec_params& prm = a.prm;
         constexpr bool pf = PFM == 1;
-        CCtx c;
+        CCtxT<FT, CG_CACHE_RK4> c;
         c.state = prm.reset_state ? PK_EVALUATE : P.state[i];  // kernel.py:188
         if (c.state == PK_EVALUATE) {
             unsigned it = prm.reset_state ? 0u : (unsigned)P.iter[i];
@@ -790,7 +808,7 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID) advect_cgrid_ker
                         st = pt + cdt * pdt;
                     }
                     double u, v, w;
-                    eval_uvw_cgrid<FT, pf, D3>(a, L, c, st, sz, sy, sx, pf && stage == 0, u, v, w);
+                    eval_uvw_cgrid<FT, pf, D3, false, CG_CACHE_RK4>(a, L, c, st, sz, sy, sx, pf && stage == 0, u, v, w);
                     if (stage == 0) { su = u; sv = v; sw = w; }
                     else if (stage == 3) { su = su + u; sv = sv + v; sw = sw + w; }
                     else { su = su + 2 * u; sv = sv + 2 * v; sw = sw + 2 * w; }
@@ -854,7 +872,7 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID) advect_cgrid_ker
 // (Repeat loop, next_dt column, `dt = next_dt` of kernel.py:118-120), the Fehlberg stages written out like `prepare` does.  Every sample
 // of these programs is guessed and float64 (the host checks it), so the float32-array products of the general program never arise.
 template <class FT, int PFM>
-__global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID) advect_cgrid_rk45_kernel(const KArgs a) {
+__global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID_RK45) advect_cgrid_rk45_kernel(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const FastC& F = a.fastc;
     CgLds L;
@@ -876,7 +894,7 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID) advect_cgrid_rk4
         const DPOut& O = a.po;
         const pk_exec_params& prm = a.prm;
         constexpr bool pf = PFM == 1;
-        CCtx c;
+        CCtxT<FT, CG_CACHE_RK45> c;
         c.state = prm.reset_state ? PK_EVALUATE : P.state[i];  // kernel.py:188
         if (c.state == PK_EVALUATE) {
             unsigned it = prm.reset_state ? 0u : (unsigned)P.iter[i];
@@ -938,7 +956,7 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID) advect_cgrid_rk4
                             default: break;
                         }
                         double u, v, w;
-                        eval_uvw_cgrid<FT, pf, false>(a, L, c, st, pzz, sy, sx, pf && stage == 0, u, v, w);
+                        eval_uvw_cgrid<FT, pf, false, false, CG_CACHE_RK45>(a, L, c, st, pzz, sy, sx, pf && stage == 0, u, v, w);
                         switch (stage) {
                             case 0: u1 = u; v1 = v; break;
                             case 1: u2 = u; v2 = v; break;
@@ -1023,7 +1041,7 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID) advect_cgrid_rk4
 // starts in the cell of the point returns float64 (xsi, eta), one that has to move returns the float32-rounded ones of a hash hit:
 // SearchMemo of pk_device.h is that same rule, spelled as a re-use).
 template <class FT, int PFM>
-__global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID) advect_cgrid_m1_kernel(const KArgs a) {
+__global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID_M1) advect_cgrid_m1_kernel(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const FastC& F = a.fastc;
     CgLds L;
@@ -1045,7 +1063,7 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID) advect_cgrid_m1_
         const DPOut& O = a.po;
         const pk_exec_params& prm = a.prm;
         constexpr bool pf = PFM == 1;
-        CCtx c;
+        CCtxT<FT, CG_CACHE_M1> c;
         c.state = prm.reset_state ? PK_EVALUATE : P.state[i];  // kernel.py:188
         if (c.state == PK_EVALUATE) {
             unsigned it = prm.reset_state ? 0u : (unsigned)P.iter[i];
@@ -1094,7 +1112,7 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID) advect_cgrid_m1_
                         default: break;
                     }
                     double r0, r1, r2;
-                    eval_uvw_cgrid<FT, pf, false, true>(a, L, c, pt, pz, sy, sx, pf, r0, r1, r2, sk);
+                    eval_uvw_cgrid<FT, pf, false, true, CG_CACHE_M1>(a, L, c, pt, pz, sy, sx, pf, r0, r1, r2, sk);
                     switch (stage) {
                         case 0: Kxp1 = r0; break;
                         case 1: Kxm1 = r0; break;
