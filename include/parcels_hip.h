@@ -27,7 +27,7 @@ extern "C" {
 
 #define PK_ABI_VERSION 5 /* 5: pk_exec_params.horizon_lo / horizon_hi / max_iters, pk_exec_stats.first_error_iter / program, pk_execute_rerun, "fast_cgrid" option; 4: pk_upload_stats, pk_host_stage_selftest, PK_KERNEL_DO_NOTHING / _MOVE_EAST / _MOVE_NORTH, vector PK_KERNEL_SAMPLE_FIELD, "cell_table" option */
 #define PK_MAX_GRIDS 4
-#define PK_MAX_FIELDS 16
+#define PK_MAX_FIELDS 64
 #define PK_MAX_KERNELS 8
 #define PK_MAX_EXTRA 4 /* user Variables that device kernels write (PK_KERNEL_SAMPLE_FIELD) */
 #define PK_NUM_STATE_CODES 80

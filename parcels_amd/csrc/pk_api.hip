@@ -75,6 +75,9 @@ struct pk_ctx {
     size_t pack_tmp_bytes = 0;
     // scratch
     DCounters* d_counters = nullptr;
+    // device copy of the grid / field descriptors the kernels read through KArgs::grids / fields (pk_device.h), and its pinned source
+    char *d_desc = nullptr, *h_desc = nullptr;
+    size_t desc_bytes = 0;
     unsigned long long* d_summary = nullptr;  // PK_NUM_STATE_CODES counts + 2 ordered-double slots
     // pinned staging ring for async level uploads
     void* stage[PK_STAGE_BUFFERS] = {};
@@ -193,8 +196,8 @@ __global__ void __launch_bounds__(256) eval_kernel(const KArgs a, int what, int6
                                                    int32_t* ost) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= m) return;
-    const DField& mf = a.fields[a.main_field];
-    const DGrid& mg = a.grids[a.main_grid];
+    const DField& mf = kfield(a, a.main_field);
+    const DGrid& mg = kgrid(a, a.main_grid);
     Coords mc{CellCache{nullptr, nullptr, nullptr}, mf.time, mg.depth, mg.lat, mg.lon, mf.tfirst, mf.tlast, mg.zfirst, mg.zlast, mg.yfirst, mg.ylast, mg.xfirst, mg.xlast};
     PCtx c;
     c.state = PK_EVALUATE;
@@ -621,6 +624,8 @@ int32_t pk_destroy(pk_ctx* ctx) {
     if (ctx->d_cg_tab) (void)hipFree(ctx->d_cg_tab);
     if (ctx->d_ct2) (void)hipFree(ctx->d_ct2);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    if (ctx->d_desc) (void)hipFree(ctx->d_desc);
+    if (ctx->h_desc) (void)hipHostFree(ctx->h_desc);
     if (ctx->d_summary) (void)hipFree(ctx->d_summary);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->h_summary) (void)hipHostFree(ctx->h_summary);
@@ -1508,8 +1513,37 @@ static bool ctx_is_typed(const pk_ctx* ctx) {
 
 static int32_t fill_args(pk_ctx* ctx, const pk_exec_params* prm, KArgs& a, size_t& lds_bytes, int& use_lds) {
     memset(&a, 0, sizeof(a));
-    for (size_t g = 0; g < ctx->grids.size(); g++) a.grids[g] = ctx->grids[g].d;
-    for (size_t f = 0; f < ctx->fields.size(); f++) a.fields[f] = ctx->fields[f].d;
+    {
+        // descriptor tables: [grids][fields] in one device buffer, refreshed on the compute stream when anything changed since the last
+        // launch (ring slots move with every streamed level).  In stream order, so a kernel still running keeps reading the old values.
+        const size_t gb = ctx->grids.size() * sizeof(DGrid), fb = ctx->fields.size() * sizeof(DField);
+        const size_t need = gb + fb;
+        if (need > ctx->desc_bytes) {
+            const size_t cap = (size_t)PK_MAX_GRIDS * sizeof(DGrid) + (size_t)PK_MAX_FIELDS * sizeof(DField);
+            if (ctx->d_desc) (void)hipFree(ctx->d_desc);
+            if (ctx->h_desc) (void)hipHostFree(ctx->h_desc);
+            ctx->d_desc = ctx->h_desc = nullptr;
+            ctx->desc_bytes = 0;
+            PK_HIP(ctx, hipMalloc((void**)&ctx->d_desc, cap));
+            PK_HIP(ctx, hipHostMalloc((void**)&ctx->h_desc, 2 * cap, hipHostMallocDefault));  // staged copy + what the device holds
+            memset(ctx->h_desc, 0xFF, 2 * cap);
+            ctx->desc_bytes = cap;
+        }
+        char* stage = ctx->h_desc;                    // what this launch needs
+        char* mirror = ctx->h_desc + ctx->desc_bytes;  // what was uploaded last
+        std::vector<char> cur(need);
+        for (size_t g = 0; g < ctx->grids.size(); g++) memcpy(cur.data() + g * sizeof(DGrid), &ctx->grids[g].d, sizeof(DGrid));
+        for (size_t f = 0; f < ctx->fields.size(); f++) memcpy(cur.data() + gb + f * sizeof(DField), &ctx->fields[f].d, sizeof(DField));
+        if (need && memcmp(cur.data(), mirror, need) != 0) {
+            // the previous upload from `stage` completed long ago unless a launch is still queued behind it: wait for the stream then
+            PK_HIP(ctx, hipStreamSynchronize(ctx->compute));
+            memcpy(stage, cur.data(), need);
+            PK_HIP(ctx, hipMemcpyAsync(ctx->d_desc, stage, need, hipMemcpyHostToDevice, ctx->compute));
+            memcpy(mirror, cur.data(), need);
+        }
+        a.grids = (const PK_CONST_AS DGrid*)ctx->d_desc;
+        a.fields = (const PK_CONST_AS DField*)(ctx->d_desc + gb);
+    }
     a.p = ctx->dev;
     a.prm = *prm;
     a.counters = ctx->d_counters;

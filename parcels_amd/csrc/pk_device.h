@@ -140,9 +140,14 @@ struct FastC {
     double tlen, t0, t1, z0, z1, deg2m;
 };
 
+// The grid / field descriptors of a context live in ONE device buffer (uploaded before a launch when they changed), not in the kernel
+// arguments: the kernarg segment is 4 KiB, and 4 grids + 16 fields used 3 KiB of it -- one more descriptor member and the design had to
+// change (and any code shape that made the compiler take the address of the by-value argument cost a 4 KiB private copy per lane).
+// The pointers are in the CONSTANT address space: uniform loads through them are scalar loads, hoistable like kernarg loads.
+#define PK_CONST_AS __attribute__((address_space(4)))
 struct KArgs {
-    DGrid grids[PK_MAX_GRIDS];
-    DField fields[PK_MAX_FIELDS];
+    const PK_CONST_AS DGrid* grids;    // [number of grids of the context]   (kgrid / kfield below)
+    const PK_CONST_AS DField* fields;  // [number of fields of the context]
     DParticles p;
     pk_exec_params prm;
     double win_lo, win_hi;  // resident time window of the time-varying fields (seconds)
@@ -160,6 +165,9 @@ struct KArgs {
 
 // ---- small helpers ------------------------------------------------------------------------------------
 #define PK_DEV __device__ __forceinline__
+// descriptor g / f of the launch (the cast to the generic address space is undone by address-space inference once inlined)
+PK_DEV const DGrid& kgrid(const KArgs& a, int g) { return *(const DGrid*)(a.grids + g); }
+PK_DEV const DField& kfield(const KArgs& a, int f) { return *(const DField*)(a.fields + f); }
 // Scheduling fence between the gathers of two fields: without it the compiler hoists all 16 (32, 48) corner loads of
 // U, V (and W) above the first interpolation, which costs ~64 VGPRs per field and caps occupancy at 2 waves/SIMD.
 #ifndef PK_FIELD_FENCE
@@ -1526,9 +1534,9 @@ PK_DEV double finish_value(PCtx& c, const GPos& p, double v) { return finish_val
 template <class FT, int KIND, int INTERP, bool TYPED>
 PK_DEV void eval_uvw(const KArgs& a, const Coords& mc, PCtx& c, bool want_w, double t, double z, double y,
                      double x, bool pos_f32, double& u, double& v, double& w, SearchMemo* memo = nullptr) {
-    const DField& U = a.fields[a.prm.fU];
-    const DField& V = a.fields[a.prm.fV];
-    const DGrid& g = a.grids[U.grid];
+    const DField& U = kfield(a, a.prm.fU);
+    const DField& V = kfield(a, a.prm.fV);
+    const DGrid& g = kgrid(a, U.grid);
     GPos p;
     u = v = w = 0.0;
     c.u32 = c.v32 = false;
@@ -1549,7 +1557,7 @@ PK_DEV void eval_uvw(const KArgs& a, const Coords& mc, PCtx& c, bool want_w, dou
     const bool oob = flags & 1;
     double uu = 0, vv = 0, ww = 0;
     if (!oob) {
-        const DField* W = (want_w && a.prm.fW >= 0) ? &a.fields[a.prm.fW] : nullptr;
+        const DField* W = (want_w && a.prm.fW >= 0) ? &kfield(a, a.prm.fW) : nullptr;
         if (INTERP == 1) {
             cgrid_velocity<FT, KIND, TYPED>(g, &mc, U, V, W, p, y, pos_f32, uu, vv, ww, c.u32, c.v32);
         } else if (INTERP == 2) {  // XFreeslip (interp_uv == 2) / XPartialslip (3)
@@ -1585,11 +1593,11 @@ PK_DEV void eval_uvw(const KArgs& a, const Coords& mc, PCtx& c, bool want_w, dou
 template <class FT, bool TYPED>
 PK_DEV double eval_scalar(const KArgs& a, const Coords& mc, PCtx& c, int fidx, double t, double z, double y,
                           double x, bool pos_f32, const SearchMemo* memo = nullptr) {
-    const DField& f = a.fields[fidx];
-    const DGrid& g = a.grids[f.grid];
+    const DField& f = kfield(a, fidx);
+    const DGrid& g = kgrid(a, f.grid);
     const bool on_main = (f.grid == a.main_grid);
     GPos p;
-    const double* time = (on_main && f.time == a.fields[a.main_field].time) ? mc.time : f.time;
+    const double* time = (on_main && f.time == kfield(a, a.main_field).time) ? mc.time : f.time;
     if (!time_search(f, time, t, on_main ? c.ht : 0, p)) {
         c.state = PK_ERROROUTSIDETIMEINTERVAL;
         return 0.0;

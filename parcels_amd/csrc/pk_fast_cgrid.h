@@ -333,7 +333,7 @@ PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtxT<FT, CM>& c, dou
                 double xs2, et2;
                 const double m = 1e-9;
                 if (cg_point_in_cell(F, L.rec, ncell, qX, qY, qZ, xs2, et2) && xs2 > m && xs2 < 1 - m && et2 > m && et2 < 1 - m) {
-                    if (box_lists(a.grids[F.grid], (unsigned long long)__double_as_longlong(boxd), qX, qY, qZ, true)) {
+                    if (box_lists(kgrid(a, F.grid), (unsigned long long)__double_as_longlong(boxd), qX, qY, qZ, true)) {
                         found = true;
                         yi = nj;
                         xi = ni;
@@ -348,7 +348,7 @@ PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtxT<FT, CM>& c, dou
         // the faces of the query's hash cell in table order (SpatialHash.query, spatialhash.py:389-535): the general routine
         int wy, wx;
         double wxs, wet;
-        curvilinear_search(a.grids[F.grid], y, x, false, 0, 0, wy, wx, wxs, wet);
+        curvilinear_search(kgrid(a, F.grid), y, x, false, 0, 0, wy, wx, wxs, wet);
         yi = wy;
         xi = wx;
         xsi = wxs;
@@ -367,7 +367,7 @@ PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtxT<FT, CM>& c, dou
         c.state = s;
         // the next guess is what unravelling this `ei` gives (index_search.py:269-274)
         if (xi >= 0) { c.gy = yi; c.gx = xi; }
-        else unravel_yx(a.grids[F.grid], (int64_t)c.ei, c.gy, c.gx);
+        else unravel_yx(kgrid(a, F.grid), (int64_t)c.ei, c.gy, c.gx);
         return;
     }
     c.gy = yi;

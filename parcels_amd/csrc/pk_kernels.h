@@ -204,8 +204,8 @@ PK_DEV bool prepare(const KArgs& a, int kid, int stage, int kslot, PCtx& c, PSta
                 case 6: rq.kind = RQ_SCALAR; rq.fidx = prm.fKh_meridional; rq.reuse = true; return false;
                 default: break;
             }
-            const DGrid& gz = a.grids[a.fields[prm.fKh_zonal].grid];
-            const DGrid& gm = a.grids[a.fields[prm.fKh_meridional].grid];
+            const DGrid& gz = kgrid(a, kfield(a, prm.fKh_zonal).grid);
+            const DGrid& gm = kgrid(a, kfield(a, prm.fKh_meridional).grid);
             double Kxp1 = L.r[0], Kxm1 = L.r[1], khz = L.r[4], Kyp1 = L.r[5], Kym1 = L.r[6], khm = L.r[7];
             const double u = L.r[2], v = L.r[3];
             if (gz.spherical) {
@@ -238,8 +238,8 @@ PK_DEV bool prepare(const KArgs& a, int kid, int stage, int kslot, PCtx& c, PSta
             rq.f32 = pf;
             if (stage == 0) { rq.kind = RQ_SCALAR; rq.fidx = prm.fKh_zonal; return false; }
             if (stage == 1) { rq.kind = RQ_SCALAR; rq.fidx = prm.fKh_meridional; return false; }
-            const DGrid& gz = a.grids[a.fields[prm.fKh_zonal].grid];
-            const DGrid& gm = a.grids[a.fields[prm.fKh_meridional].grid];
+            const DGrid& gz = kgrid(a, kfield(a, prm.fKh_zonal).grid);
+            const DGrid& gm = kgrid(a, kfield(a, prm.fKh_meridional).grid);
             double khz = L.r[0], khm = L.r[1];
             if (gz.spherical) {
                 khz = m2_to_deg2_zonal(pf, khz, p.y, gz.deg2m);
@@ -393,8 +393,8 @@ template <class FT, int KIND, int INTERP, int KID, bool LDS, bool TYPED, int PFM
 __global__ void __launch_bounds__(wg_size(KIND, LDS), (KIND == 1 || INTERP != 0) ? PK_MIN_WAVES_HEAVY : PK_MIN_WAVES) advect_kernel(const KArgs a) {
     constexpr int WG = wg_size(KIND, LDS);
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const DField& mf = a.fields[a.main_field];
-    const DGrid& mg = a.grids[a.main_grid];
+    const DField& mf = kfield(a, a.main_field);
+    const DGrid& mg = kgrid(a, a.main_grid);
     Coords mc;
     if (LDS) {
         // stage the 1-D coordinate vectors of the main grid once per workgroup (coalesced), search them from LDS
@@ -770,7 +770,7 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID) advect_cgrid_ker
             {
                 const int32_t ei0 = P.ei[i * P.ngrids + F.grid];
                 int gy, gx;
-                unravel_yx(a.grids[F.grid], (int64_t)ei0, gy, gx);  // the guess of the first search (index_search.py:269-274)
+                unravel_yx(kgrid(a, F.grid), (int64_t)ei0, gy, gx);  // the guess of the first search (index_search.py:269-274)
                 cctx_init(c, PK_EVALUATE, ei0, gy, gx);
             }
             double pt = P.t[i];
@@ -901,7 +901,7 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID_RK45) advect_cgri
             {
                 const int32_t ei0 = P.ei[i * P.ngrids + F.grid];
                 int gy, gx;
-                unravel_yx(a.grids[F.grid], (int64_t)ei0, gy, gx);
+                unravel_yx(kgrid(a, F.grid), (int64_t)ei0, gy, gx);
                 cctx_init(c, PK_EVALUATE, ei0, gy, gx);
             }
             double pt = P.t[i];
@@ -1070,7 +1070,7 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID_M1) advect_cgrid_
             {
                 const int32_t ei0 = P.ei[i * P.ngrids + F.grid];
                 int gy, gx;
-                unravel_yx(a.grids[F.grid], (int64_t)ei0, gy, gx);
+                unravel_yx(kgrid(a, F.grid), (int64_t)ei0, gy, gx);
                 cctx_init(c, PK_EVALUATE, ei0, gy, gx);
             }
             double pt = P.t[i];
