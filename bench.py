@@ -7,6 +7,7 @@ of every particle (4 velocity evaluations each: time search, 3 x 1-D cell search
 interpolation).  Fields and particles are resident in HBM when the timed region starts.
 
     python bench.py --gpus 1 --steps 24 --warmup 2
+    python bench.py --gpus N ...          (without a launcher: starts its own N ranks under torch.distributed.run, 127.0.0.1 rendezvous)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Multi-GPU (weak scaling, 1e7 particles per GPU): ONE id space of N x 1e7 particles, generated in shard-independent blocks and
@@ -26,6 +27,10 @@ Prints ONE JSON line (rank 0).  What the objects mean:
             particle-step to this run;  `hbm` = that traffic over the kernel time against the 8 TB/s peak
   algorithmic  SURVEY.md 8(d)'s byte model (1112 B per particle-step = 4 stages x 2 fields x 16 corners x 8 B + 88 B state) over
             the kernel time.  It exceeds the HBM peak because those bytes come out of cache: it is NOT an HBM fraction.
+`secondary` (N = 1 only; `--secondary 0` switches it off) -- BASELINE configs 3 and 5 at FULL size next to the headline: C3 AdvectionRK4_3D,
+  C5 AdvectionRK45 and AdvectionDiffusionM1 on the 4322 x 3059 x 75 curvilinear C-grid with 1e7 particles, each with kernel ms, value,
+  a `roofline` by SURVEY 8(d)'s algorithmic bytes (536 / 672 / 568 B per unit; these working sets ARE beyond the caches) plus the counter
+  traffic of profiles/pmc_secondary_latest.json, and `check`: 1e5 particle ids re-run through the CPU oracle on the same arrays.
 `cpu_baseline` -- oracle/fast_agrid_cpu.c (kind "port"): the headline workload restated the way one writes it for a CPU, bit-identical
   to the checker oracle, OpenMP on this box's host cores, bounded sample.
 `cpu_baseline_reference` -- the reference itself (Parcels under oracle/ref_shim.py).  It is Python and /root/reference does not exist

@@ -455,3 +455,42 @@ def test_run_rk_to_endtime_forward_and_backward(gpu, kernel, dt_days):
     pset.execute(k, endtime=fs.time_interval.left, dt=-np.timedelta64(dt_days, "D"))
     assert pset.t[0] == 0.0
     assert pset.x[0] == np.float32(0.2) and pset.y[0] == np.float32(5.0)
+
+
+@pytest.mark.gpu
+def test_more_fields_than_the_old_descriptor_cap(gpu):
+    """The grid / field descriptors live in a device buffer, not in the 4 KiB of kernel arguments (round 3): a FieldSet may hold up to
+    PK_MAX_FIELDS = 64 fields (16 until then).  40 scalar fields next to U and V: every one samples its own values, the velocity
+    fields advect as if they were alone."""
+    import parcels_amd as pa
+    from parcels_amd import _hip
+    from case_utils import build_fieldset, run_hip
+    from oracle import cases
+
+    assert _hip.PK_MAX_FIELDS == 64
+    case = dict(cases.rect_agrid_case("many_fields", mesh="spherical", kernels=["AdvectionRK4"], seed=9, npart=200, runtime=6 * 3600.0))
+    alone, err0, _ = run_hip(case)
+    shp = np.asarray(case["fields"]["U"]).shape
+    case["fields"] = dict(case["fields"])
+    case["field_dims"] = dict(case["field_dims"])
+    for k in range(40):
+        case["fields"][f"T{k}"] = np.full(shp, float(k + 1)) + np.asarray(case["fields"]["U"]) * 0.0
+        case["field_dims"][f"T{k}"] = case["field_dims"]["U"]
+    fs = build_fieldset(case)
+    assert len([f for f in fs.fields.values() if isinstance(f, pa.Field)]) == 42
+    got, err, st = run_hip(case, fieldset=fs)
+    assert err == err0
+    for k in ("x", "y", "z", "t", "state", "ei"):
+        assert np.array_equal(got[k], alone[k]), k
+    t = np.zeros(5)
+    z, y, x = np.full(5, 10.0), np.linspace(-30, 30, 5), np.linspace(20, 200, 5)
+    for k in (0, 17, 39):
+        assert np.array_equal(fs.fields[f"T{k}"].eval(t, z, y, x), np.full(5, float(k + 1)))
+    with pytest.raises(ValueError, match="at most 64 fields"):
+        big = dict(case)
+        big["fields"] = dict(case["fields"])
+        big["field_dims"] = dict(case["field_dims"])
+        for k in range(40, 70):
+            big["fields"][f"T{k}"] = case["fields"]["T0"]
+            big["field_dims"][f"T{k}"] = case["field_dims"]["U"]
+        build_fieldset(big).to_device()
