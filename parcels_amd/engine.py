@@ -541,7 +541,9 @@ class DeviceEngine:
         # A run that may take several launches keeps the state before the first one on the device: an error in a LATER launch stops the
         # whole batch at an iteration some particles passed launches ago (kernel.py:236-245), so the run starts over with that limit.
         checkpointed = False
-        if (self.windowed or span0 is not None) and self.exact_error_stop:
+        # (a re-sort horizon only cuts runs longer than itself: the usual output interval is one launch and needs no checkpoint)
+        several = self.windowed or (span0 is not None and not (t_start is not None and np.isfinite(t_start) and abs(float(endtime) - float(t_start)) <= span0))
+        if several and self.exact_error_stop:
             self.ctx.check(self.lib.pk_particles_checkpoint(self.ctx.handle), "pk_particles_checkpoint")
             checkpointed = True
         cap = 0  # iteration limit of the batch loop (0: none)

@@ -494,3 +494,52 @@ def test_more_fields_than_the_old_descriptor_cap(gpu):
             big["fields"][f"T{k}"] = case["fields"]["T0"]
             big["field_dims"][f"T{k}"] = case["field_dims"]["U"]
         build_fieldset(big).to_device()
+
+
+@pytest.mark.gpu
+def test_advection_zonal_with_particlefile(gpu, tmp_path):
+    """tests/test_advection.py:64-81: flat mesh, uniform U, a ParticleFile every 30 min of a 2 h run: the last table holds the final x."""
+    npart = 10
+    fs = pa.FieldSet.from_sgrid_conventions(simple_uv_dataset(mesh="flat", u=1.0), mesh="flat")
+    pset = pa.ParticleSet(fs, x=np.zeros(npart) + 20.0, y=np.linspace(0, 80, npart))
+    path = tmp_path / "zonal.parquet"
+    pfile = pa.ParticleFile(path, outputdt=np.timedelta64(30, "m"))
+    pset.execute(pa.AdvectionRK4, runtime=np.timedelta64(2, "h"), dt=np.timedelta64(15, "m"), output_file=pfile)
+    pfile.close()
+    assert (np.diff(pset.x) < 1.0e-4).all()
+    df = pa.read_particlefile(path)
+    final_time = df["t"].max()
+    assert final_time == 7200.0 and sorted(df["t"].unique()) == [0.0, 1800.0, 3600.0, 5400.0, 7200.0]
+    np.testing.assert_allclose(df[df["t"] == final_time]["x"].values, pset.x, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_advection_zonal_periodic(gpu):
+    """tests/test_advection.py:84-107: a 2 x 2 cell domain with a halo column, AdvectionEE followed by a user-written periodic boundary
+    kernel (a Python function: runs on the host between the device kernels of every iteration) -- after 40 s at 0.1 m/s every particle
+    has travelled 4 m and sits where it started."""
+    md = pa.SGrid2DMetadata(
+        node_dimensions=("XG", "YG"), node_coordinates=("lon", "lat"),
+        face_dimensions=(pa.FaceNodePadding("XC", "XG", pa.Padding.LOW), pa.FaceNodePadding("YC", "YG", pa.Padding.LOW)),
+        vertical_dimensions=(pa.FaceNodePadding("ZC", "depth", pa.Padding.BOTH),),
+    )
+    dims = (2, 2, 2, 3)  # the reference concatenates the first XG column behind the last one: lon = [0, 2, 3]
+    ds = pa.Dataset(
+        {"U": (("time", "depth", "YG", "XG"), np.full(dims, 0.1)), "V": (("time", "depth", "YG", "XG"), np.zeros(dims))},
+        {"time": (("time",), np.array([0.0, 366 * 86400.0])), "depth": (("depth",), np.array([0.0, 1.0])),
+         "lat": (("YG",), np.array([0.0, 2.0])), "lon": (("XG",), np.array([0.0, 2.0, 3.0]))},
+        sgrid=md,
+    )
+    fs = pa.FieldSet.from_sgrid_conventions(ds, mesh="flat")
+
+    def periodicBC(particles, fieldset):
+        particles.total_dlon += particles.dx
+        particles.x = np.fmod(particles.x, 2)
+
+    PeriodicParticle = pa.Particle.add_variable(pa.Variable("total_dlon", initial=0))
+    startlon = np.array([0.5, 0.4])
+    pset = pa.ParticleSet(fs, pclass=PeriodicParticle, x=startlon, y=[0.5, 0.5])
+    pset.execute([pa.AdvectionEE, periodicBC], runtime=np.timedelta64(40, "s"), dt=np.timedelta64(1, "s"))
+    np.testing.assert_allclose(pset.total_dlon, 4.0, atol=1e-5)
+    np.testing.assert_allclose(pset.x, startlon, atol=1e-5)
+    np.testing.assert_allclose(pset.y, 0.5, atol=1e-5)

@@ -243,3 +243,37 @@ def test_python_kernel_between_device_kernels_equals_the_fused_run(gpu):
         assert np.array_equal(hosted._data[k], fused._data[k]), k
     assert np.all(hosted.age == case["runtime"])
     assert hosted._last_stats["hosted"] and hosted._last_stats["launches"] == 2 * 12
+
+
+# ---- tests/test_diffusion.py:81-126 of the reference: user-written kernels that draw random numbers -------------------------------
+@pytest.mark.parametrize("lambd", [1, 5])
+def test_randomexponential(gpu, fieldset, lambd):
+    npart = 1000
+    fieldset.add_context("lambd", lambd)
+    np.random.seed(1234)
+    pset = pa.ParticleSet(fieldset=fieldset, x=np.zeros(npart), y=np.zeros(npart), z=np.zeros(npart))
+
+    def vertical_randomexponential(particles, fieldset):
+        particles.z = np.random.exponential(scale=1 / fieldset.lambd, size=len(particles))
+
+    pset.execute(vertical_randomexponential, runtime=np.timedelta64(1, "s"), dt=np.timedelta64(1, "s"))
+    assert np.allclose(np.mean(pset.z), 1.0 / fieldset.lambd, rtol=0.1)
+
+
+@pytest.mark.parametrize("mu", [0.8 * np.pi, np.pi])
+@pytest.mark.parametrize("kappa", [2, 4])
+def test_randomvonmises(gpu, fieldset, mu, kappa):
+    import random
+
+    npart = 10000
+    fieldset.add_context("mu", mu)
+    fieldset.add_context("kappa", kappa)
+    random.seed(1234)
+    AngleParticle = pa.Particle.add_variable(pa.Variable("angle"))
+    pset = pa.ParticleSet(fieldset=fieldset, pclass=AngleParticle, x=np.zeros(npart), y=np.zeros(npart), z=np.zeros(npart))
+
+    def vonmises(particles, fieldset):
+        particles.angle = np.array([random.vonmisesvariate(fieldset.mu, fieldset.kappa) for _ in range(len(particles))])
+
+    pset.execute(vonmises, runtime=np.timedelta64(1, "s"), dt=np.timedelta64(1, "s"))
+    assert np.allclose(np.mean(pset.angle), mu, atol=0.1)
