@@ -81,6 +81,11 @@ typedef struct pk_ctx pk_ctx;
 #define PK_KERNEL_DO_NOTHING 23 /* tests/common_kernels.py:8-9: the kernel of the reference's loop / output tests (time passes, nothing moves) */
 #define PK_KERNEL_MOVE_EAST 24  /* tests/common_kernels.py:16-17: particles.dx += 0.1 */
 #define PK_KERNEL_MOVE_NORTH 25 /* tests/common_kernels.py:20-21: particles.dy += 0.1 */
+/* 40 .. 47: user-written kernels (the reference's plug-in point #1, `def kernel(particles, fieldset)`, kernel.py:67-70) compiled at run
+ * time into the kernel-list interpreter: parcels_amd/jit.py translates the Python function into a stage of the fused step loop, builds
+ * a module for the program variant pk_generic_variant names and registers its launcher with pk_set_user_program. */
+#define PK_KERNEL_USER0 40
+#define PK_MAX_USER_KERNELS 8
 
 /* ---- context ------------------------------------------------------------------------------------ */
 int32_t pk_abi_version(void);
@@ -99,6 +104,9 @@ const char* pk_last_error(const pk_ctx* ctx); /* ctx may be NULL: error of the l
  *                      "cell_table" 1 (default) per-cell table of the query-independent part of the point-in-cell test (192 B per
  *                      cell of a curvilinear grid); they take effect for grids created / launches made afterwards
  *   "sort_horizontal"  -1 (default) automatic, 0 depth-major, 1 horizontal-major cell sort of curvilinear grids
+ *   "eval_points_f32"  0 (default); 1 = the y / x / z handed to pk_eval are float32 particle columns widened to double: the reference then
+ *                      forms np.cos(np.deg2rad(y)) -- and, with float32 coordinate arrays, the barycentric coordinates -- in float32
+ *                      (what a fused launch does for the default float32 Particle); set around the pk_eval calls it applies to
  * Environment variables PK_NO_FAST, PK_NO_FAST_CGRID, PK_NO_SPECIAL, PK_NO_CELL_CACHE, PK_NO_HASH_DIR, PK_NO_CELL_TABLE, PK_SORT_HORIZONTAL give the initial
  * values. */
 int32_t pk_set_option(pk_ctx* ctx, const char* name, int32_t value);
@@ -346,6 +354,13 @@ int32_t pk_execute(pk_ctx* ctx, const pk_exec_params* params, pk_exec_stats* sta
  * pk_exec_stats.first_error_iter is non-zero, this call restores the particle columns to their state before that launch (the launch
  * wrote into the second column set: nothing was copied) and runs it again with max_iters = that index.  Must directly follow the
  * pk_execute / pk_execute_end of the launch (before any pk_particles_* call); stats replace those of the launch. */
+/* User kernels (PK_KERNEL_USER0 ..).  pk_generic_variant: which instantiation of the kernel-list interpreter a launch with `prm` would run
+ * on this context -- key = (float32 fields ? 6 : 0) + (curvilinear main grid ? 3 : 0) + min(interp_uv, 2), lds = the 1-D coordinate vectors
+ * are staged in LDS, typed = NumPy float32 dtype propagation (float32 coordinate arrays).  pk_set_user_program: the launcher of a module
+ * built for exactly that variant -- void launcher(const void* kargs, int32_t key, int32_t lds, uint64_t lds_bytes, void* hip_stream),
+ * returning nothing; it must refuse (abort) any other key.  NULL unregisters.  A kernel list with a user id and no launcher fails. */
+int32_t pk_generic_variant(pk_ctx* ctx, const pk_exec_params* prm, int32_t* key, int32_t* lds, int32_t* typed);
+int32_t pk_set_user_program(pk_ctx* ctx, void* launcher);
 int32_t pk_execute_rerun(pk_ctx* ctx, int32_t max_iters, pk_exec_stats* stats);
 /* The same in two halves: _begin enqueues the sort + advection kernel + statistics on the compute stream and returns;
  * the host can then stage and enqueue the NEXT field level (pk_field_upload_level async) while the RK sub-steps run;

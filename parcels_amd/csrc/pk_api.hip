@@ -94,6 +94,8 @@ struct pk_ctx {
     // the last advection launch wrote into the second column set, which now is `dev`; `alt` still holds what it read
     bool rerun_valid = false;
     pk_exec_params rerun_prm{};
+    // launcher of the run-time compiled kernel-list interpreter that carries the user kernels (pk_set_user_program)
+    void (*user_launch)(const void*, int32_t, int32_t, uint64_t, void*) = nullptr;
     // pk_particles_checkpoint: one packed device copy of every column (+ the row permutation of the cell sort)
     char* d_chk = nullptr;
     size_t chk_bytes = 0;
@@ -105,6 +107,7 @@ struct pk_ctx {
     unsigned long long* h_summary = nullptr;  // pinned
     int sort_horizontal_major = -1;  // tuning knobs (environment: PK_SORT_HORIZONTAL = 0/1 forces, PK_NO_SPECIAL, PK_NO_CELL_CACHE)
     int no_special = 0;
+    bool eval_points_f32 = false;  // pk_eval: the sample points are float32 particle columns (np.cos(np.deg2rad(y)) is then a float32 cosine)
     int no_cell_cache = 0;
     int no_hash_dir = 0;
     int no_cell_table = 0;
@@ -208,14 +211,15 @@ __global__ void __launch_bounds__(256) eval_kernel(const KArgs a, int what, int6
     c.u32 = c.v32 = false;
     c.oob = false;
     c.ei0 = c.ei1 = c.ei2 = c.ei3 = 0;
+    const bool pos_f32 = a.prm.reset_state != 0;  // (pk_eval's own use of the field: option "eval_points_f32")
     if (what < 0) {
         double u, v, w;
-        eval_uvw<FT, -1, INTERP, TYPED>(a, mc, c, what == -2, t[i], z[i], y[i], x[i], false, u, v, w);
+        eval_uvw<FT, -1, INTERP, TYPED>(a, mc, c, what == -2, t[i], z[i], y[i], x[i], pos_f32, u, v, w);
         ou[i] = u;
         if (ov) ov[i] = v;
         if (ow) ow[i] = w;
     } else {
-        ou[i] = eval_scalar<FT, TYPED>(a, mc, c, what, t[i], z[i], y[i], x[i], false);
+        ou[i] = eval_scalar<FT, TYPED>(a, mc, c, what, t[i], z[i], y[i], x[i], pos_f32);
     }
     if (ost) ost[i] = c.state | (c.oob ? PK_EVAL_MASKED : 0);
 }
@@ -548,6 +552,7 @@ int32_t pk_set_option(pk_ctx* ctx, const char* name, int32_t value) {
     else if (n == "hash_directory") ctx->no_hash_dir = !value;
     else if (n == "cell_table") ctx->no_cell_table = !value;
     else if (n == "sort_horizontal") ctx->sort_horizontal_major = value;
+    else if (n == "eval_points_f32") ctx->eval_points_f32 = value != 0;
     else return ctx->fail("pk_set_option: unknown option '" + n + "'");
     return 0;
 }
@@ -1898,12 +1903,17 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
     int use_lds = 0;
     int32_t rc = fill_args(ctx, prm, a, lds_bytes, use_lds);
     if (rc) return rc;
-    bool need_kh = false;
+    bool need_kh = false, has_user = false;
     for (int k = 0; k < prm->nk; k++) {
         const int id = prm->kernels[k];
         if (id == PK_KERNEL_ADVECTIONDIFFUSION_M1 || id == PK_KERNEL_ADVECTIONDIFFUSION_EM || id == PK_KERNEL_DIFFUSION_UNIFORM_KH)
             need_kh = true;
         if (id == PK_KERNEL_ADVECTION_RK45 && !ctx->dev.next_dt) return ctx->fail("AdvectionRK45 needs the next_dt column");
+        if (id >= PK_KERNEL_USER0 && id < PK_KERNEL_USER0 + PK_MAX_USER_KERNELS) {
+            has_user = true;
+            if (!ctx->user_launch) return ctx->fail("a user kernel id without a registered program (pk_set_user_program)");
+            if (prm->body_only) return ctx->fail("user kernels do not run in body_only launches");
+        }
         if ((id == PK_KERNEL_ADVECTION_RK4_3D || id == PK_KERNEL_ADVECTION_RK2_3D) && prm->fW < 0)
             return ctx->fail("3-D advection needs the W field");
         if (id == PK_KERNEL_SAMPLE_FIELD) {
@@ -1950,6 +1960,7 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
         }
         if (prm->body_only) prog = PROG_GENERIC;  // only the kernel-list interpreter knows the mode
         if (ctx_is_typed(ctx)) prog = PROG_TYPED;
+        if (has_user && prog != PROG_GENERIC) return ctx->fail("user kernels run in the plain kernel-list interpreter only (float32 coordinate arrays are not supported)");
         bool fast_a = false, fast_c = false;  // a.fast / a.fastc share storage: at most one is filled
         size_t cgrid_lds = 0;
         if ((prog == PROG_RK4 || prog == PROG_RK4_3D) && !curv) {
@@ -2008,7 +2019,14 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
             case PROG_RK45: launch_program<PROG_RK45>(field_f32, curv, prm->interp_uv, use_lds, a, grid, lds_bytes, ctx->compute); break;
             case PROG_M1: launch_program<PROG_M1>(field_f32, curv, prm->interp_uv, use_lds, a, grid, lds_bytes, ctx->compute); break;
             case PROG_TYPED: launch_program<PROG_TYPED>(field_f32, curv, prm->interp_uv, use_lds, a, grid, lds_bytes, ctx->compute); break;
-            default: launch_program<PROG_GENERIC>(field_f32, curv, prm->interp_uv, use_lds, a, grid, lds_bytes, ctx->compute); break;
+            default:
+                if (has_user) {
+                    const int ik = prm->interp_uv >= 2 ? 2 : prm->interp_uv;
+                    ctx->user_launch(&a, (field_f32 ? 6 : 0) + (curv ? 3 : 0) + ik, use_lds, (uint64_t)lds_bytes, (void*)ctx->compute);
+                } else {
+                    launch_program<PROG_GENERIC>(field_f32, curv, prm->interp_uv, use_lds, a, grid, lds_bytes, ctx->compute);
+                }
+                break;
         }
         PK_HIP(ctx, hipGetLastError());
         PK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->compute));
@@ -2066,6 +2084,26 @@ int32_t pk_execute_end(pk_ctx* ctx, pk_exec_stats* stats) {
     return 0;
 }
 
+int32_t pk_generic_variant(pk_ctx* ctx, const pk_exec_params* prm, int32_t* key, int32_t* lds, int32_t* typed) {
+    if (!ctx || !prm || !key || !lds || !typed) return -2;
+    KArgs a;
+    size_t lds_bytes = 0;
+    int use_lds = 0;
+    const int32_t rc = fill_args(ctx, prm, a, lds_bytes, use_lds);
+    if (rc) return rc;
+    const int ik = prm->interp_uv >= 2 ? 2 : prm->interp_uv;
+    *key = (ctx->fields[prm->fU].d.dtype == PK_F32 ? 6 : 0) + (ctx->grids[a.main_grid].d.kind == 1 ? 3 : 0) + ik;
+    *lds = use_lds;
+    *typed = ctx_is_typed(ctx) ? 1 : 0;
+    return 0;
+}
+int32_t pk_set_user_program(pk_ctx* ctx, void* launcher) {
+    if (!ctx) return -2;
+    if (ctx->in_flight) return ctx->fail("pk_set_user_program: a launch is in flight (call pk_execute_end)");
+    ctx->user_launch = (void (*)(const void*, int32_t, int32_t, uint64_t, void*))launcher;
+    return 0;
+}
+
 int32_t pk_execute_rerun(pk_ctx* ctx, int32_t max_iters, pk_exec_stats* stats) {
     if (!ctx) return -2;
     if (ctx->in_flight) return ctx->fail("pk_execute_rerun: a launch is in flight (call pk_execute_end)");
@@ -2093,6 +2131,7 @@ int32_t pk_eval(pk_ctx* ctx, const pk_exec_params* prm, int32_t what, int64_t m,
     PK_HIP(ctx, hipSetDevice(ctx->device));
     if (m <= 0) return 0;
     pk_exec_params p2 = *prm;
+    p2.reset_state = ctx->eval_points_f32 ? 1 : 0;  // read by eval_kernel as "sample points are float32 columns"
     if (what >= 0) {  // scalar sampling: the main grid is the sampled field's grid
         if (what >= (int)ctx->fields.size()) return ctx->fail("unknown field id");
         if (p2.fU < 0) { p2.fU = what; p2.fV = what; }

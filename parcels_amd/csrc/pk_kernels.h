@@ -51,6 +51,9 @@ struct Request {
 struct KLocal {
     double r[14];
     bool u1f, v1f;  // AdvectionRK45: u1 / v1 are float32 ARRAYS in the reference (PCtx::u32 / v32 of the stage-0 sample)
+#ifdef PK_USER_KERNELS
+    PkUserLocals ul;  // locals of the user kernel being run (generated struct, parcels_amd/jit.py)
+#endif
 };
 
 // meters_to_degrees_zonal / _meridional (_advectiondiffusion.py:11-18); `particles.y * np.pi / 180` is float32
@@ -78,6 +81,12 @@ constexpr double b50 = 16.0 / 135.0, b51 = 0.0, b52 = 6656.0 / 12825.0, b53 = 28
                  b55 = 2.0 / 55.0;
 }  // namespace rk45c
 
+#ifdef PK_USER_KERNELS
+// User-written kernels translated from Python (parcels_amd/jit.py), defined by the generated translation unit after this header: stage 0
+// runs the statements up to the first field sample (and names it in rq), stage k those after the k-th sample (its values are in
+// L.r[3..5], where consume() leaves the latest sample), the last stage returns true.
+PK_DEV bool user_prepare(const KArgs& a, int uk, int stage, int kslot, PCtx& c, PState& p, KLocal& L, Request& rq);
+#endif
 // prepare(): returns true when the kernel is finished (after writing its result into p / c), otherwise fills rq.
 PK_DEV bool prepare(const KArgs& a, int kid, int stage, int kslot, PCtx& c, PState& p, KLocal& L, Request& rq) {
     const pk_exec_params& prm = a.prm;
@@ -297,7 +306,12 @@ PK_DEV bool prepare(const KArgs& a, int kid, int stage, int kslot, PCtx& c, PSta
             p.z = 0.0;
             c.state = PK_EVALUATE;
             return true;
-        default: c.state = PK_ERROR; return true;
+        default:
+#ifdef PK_USER_KERNELS
+            if (kid >= PK_KERNEL_USER0 && kid < PK_KERNEL_USER0 + PK_MAX_USER_KERNELS) return user_prepare(a, kid - PK_KERNEL_USER0, stage, kslot, c, p, L, rq);
+#endif
+            c.state = PK_ERROR;
+            return true;
     }
 }
 

@@ -516,8 +516,16 @@ class DeviceEngine:
             p.sample_var[slot] = int(var)
         return p
 
+    def set_user_program(self, program):
+        """Register (or, with None, unregister) the run-time compiled module that carries a kernel list's user kernels (jit.py)."""
+        cur = getattr(self, "_user_program", None)
+        if program is cur:
+            return
+        self.ctx.check(self.lib.pk_set_user_program(self.ctx.handle, C.c_void_p(program.launcher() if program is not None else None)), "pk_set_user_program")
+        self._user_program = program
+
     def execute(self, kernel_ids, *, endtime, dt0, context=None, seed=0, have_guess0=0, sort_by_cell=0, t_start=None, samples=None,
-                resort_every=None) -> dict:
+                resort_every=None, in_place_variables=False) -> dict:
         """One Kernel.execute(pset, endtime, dt) on the bound (device-resident) particle columns.
 
         ``resort_every`` (seconds of model time, with ``sort_by_cell``): the fused launch is cut at a soft horizon every that many
@@ -543,6 +551,9 @@ class DeviceEngine:
         checkpointed = False
         # (a re-sort horizon only cuts runs longer than itself: the usual output interval is one launch and needs no checkpoint)
         several = self.windowed or (span0 is not None and not (t_start is not None and np.isfinite(t_start) and abs(float(endtime) - float(t_start)) <= span0))
+        # user kernels update their Variables in place (they are not part of the column set a launch writes): repeating a launch from the
+        # columns it read would apply them twice, so an error stop of such a list always restarts from the checkpoint
+        several = several or in_place_variables
         if several and self.exact_error_stop:
             self.ctx.check(self.lib.pk_particles_checkpoint(self.ctx.handle), "pk_particles_checkpoint")
             checkpointed = True
@@ -590,7 +601,7 @@ class DeviceEngine:
                     total["kernel_ms"] += st.kernel_ms
                     total["sort_ms"] += st.sort_ms
                     total["launches"] += st.launches
-                    if first_launch:  # the state before this launch still sits in the second column set
+                    if first_launch and not in_place_variables:  # the state before this launch still sits in the second column set
                         st = _hip.ExecStats()
                         self.ctx.check(self.lib.pk_execute_rerun(self.ctx.handle, cap, C.byref(st)), "pk_execute_rerun")
                     else:

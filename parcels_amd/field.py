@@ -234,8 +234,9 @@ class Field:
         if self._fieldset is None:
             raise RuntimeError("Field is not attached to a FieldSet")
         eng = self._fieldset._engine_or_create()
-        val = eng.sample(self.name, *_sample_points(t, z, y, x))[0]
-        _mark_particles(particles, eng)
+        with _points_dtype(eng, y):
+            val = eng.sample(self.name, *_sample_points(t, z, y, x))[0]
+        _mark_particles(particles, eng, self, z, y, x)
         return val
 
     def __getitem__(self, key):
@@ -248,6 +249,23 @@ class Field:
 def _sample_points(t, z, y, x):
     """Sample coordinates as float64 arrays (the columns of a kernel's `particles` arrive as write-through proxies)."""
     return tuple(np.asarray(v, dtype=np.float64) if not np.isscalar(v) else v for v in (t, z, y, x))
+
+
+class _points_dtype:
+    """Tell the library when the sample points are float32 columns (the default Particle): `np.cos(np.deg2rad(y))` of the velocity
+    conversion is then a float32 cosine in the reference (_xinterpolators.py:183-187), as it is inside a fused launch."""
+
+    def __init__(self, eng, y):
+        self.eng = eng
+        self.f32 = getattr(y, "dtype", None) == np.float32
+
+    def __enter__(self):
+        if self.f32:
+            self.eng.ctx.check(self.eng.lib.pk_set_option(self.eng.ctx.handle, b"eval_points_f32", 1), "pk_set_option")
+
+    def __exit__(self, *a):
+        if self.f32:
+            self.eng.ctx.check(self.eng.lib.pk_set_option(self.eng.ctx.handle, b"eval_points_f32", 0), "pk_set_option")
 
 
 def _unpack_key(key):
@@ -264,9 +282,17 @@ def _unpack_key(key):
     return key[0], key[1], key[2], key[3], (key[4] if len(key) > 4 else None)
 
 
-def _mark_particles(particles, eng):
-    from .hostkernels import _apply_sample_states
+def _mark_particles(particles, eng, field=None, z=None, y=None, x=None):
+    """What sampling does to the particles a kernel passed along (field.py:394-405): their `ei` on the field's grid becomes the cell of
+    the sample point (_update_particles_ei, :307-317), the points it fails on get the error codes (:327-378)."""
+    from .hostkernels import HostParticles, _apply_sample_states
 
+    if field is not None and isinstance(particles, HostParticles) and len(particles) > 0:
+        igrid = eng.grids.index(field.grid)
+        _, zz, yy, xx = _sample_points(0.0, z, y, x)
+        n = len(particles)
+        zz, yy, xx = (np.broadcast_to(np.asarray(v, dtype=np.float64), (n,)) for v in (zz, yy, xx))
+        particles._data["ei"][particles._rows, igrid] = eng.search(igrid, zz, yy, xx)
     _apply_sample_states(particles, getattr(eng, "last_sample_state", None))
 
 
@@ -308,8 +334,9 @@ class VectorField:
         if self._fieldset is None:
             raise RuntimeError("VectorField is not attached to a FieldSet")
         eng = self._fieldset._engine_or_create()
-        u, v, w = eng.sample(self.name, *_sample_points(t, z, y, x))
-        _mark_particles(particles, eng)
+        with _points_dtype(eng, y):
+            u, v, w = eng.sample(self.name, *_sample_points(t, z, y, x))
+        _mark_particles(particles, eng, self.U, z, y, x)
         return (u, v, w) if self.vector_type == "3D" else (u, v)
 
     def __getitem__(self, key):

@@ -1,0 +1,656 @@
+"""User-written kernels on the device (the reference's plug-in point #1: ``def kernel(particles, fieldset)``, kernel.py:67-70, run by
+the loop of kernel.py:206-216).
+
+A Python function cannot run inside a HIP kernel, but the kernels users write for Parcels are almost always a handful of ELEMENTWISE
+statements over particle Variables -- ``particles.age += particles.dt``, ``particles.state = np.where(..., StatusCode.Delete, ...)``,
+``particles[particles.state >= 50].state = StatusCode.Delete``, ``particles.temp = fieldset.T[particles]``.  For that class this
+module translates the function's AST into one more kernel of the fused step loop (a stage machine like the built-in ones: the
+statements up to a field sample, the sample, the statements after it), compiles the kernel-list interpreter with it for the one program
+variant the FieldSet needs (``hipcc``, ~5 s, cached on disk by content hash) and registers the module with the library
+(``pk_set_user_program``); the kernel list then runs as ONE launch, built-in and user kernels alike, the particle columns never leave
+the GPU.  Anything outside the class (``NotTranslatable``: control flow, reductions, ``len(particles)``, random numbers, transcendental
+functions, integer Variables, more than PK_MAX_EXTRA touched Variables, ...) keeps running through ``hostkernels.py`` -- the
+reference's loop on the host columns.
+
+NumPy's semantics are reproduced statically, per expression: every sub-expression carries its NumPy dtype (NEP 50: Python scalars
+are weak), an operation is computed in ``np.result_type`` of its operands (``float32 + float32`` is a float add, ``int32 + float32``
+a float64 add), ``/`` of integers is a float64 division, an in-place operator computes in the promoted dtype and casts back to the
+column's, an assignment casts like ``ndarray.__setitem__``.  tests/test_gpu_jit_kernels.py compares every supported construct with the
+host path (which IS NumPy) bit for bit.
+"""
+
+from __future__ import annotations
+
+import ast
+import ctypes as C
+import hashlib
+import inspect
+import os
+import subprocess
+import textwrap
+
+import numpy as np
+
+from . import _hip
+from .statuscodes import StatusCode
+
+__all__ = ["NotTranslatable", "translate", "UserProgram", "jit_enabled"]
+
+PK_KERNEL_USER0, PK_MAX_USER_KERNELS = 40, 8
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+_INCLUDE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+
+
+class NotTranslatable(Exception):
+    """The function is outside the elementwise class: it runs on the host path instead."""
+
+
+def jit_enabled() -> bool:
+    return os.environ.get("PARCELS_AMD_JIT", "1") not in ("0", "false", "no")
+
+
+_CT = {"b": "bool", "i32": "int32_t", "i64": "int64_t", "f32": "float", "f64": "double"}
+_NP = {"b": np.bool_, "i32": np.int32, "i64": np.int64, "f32": np.float32, "f64": np.float64}
+_WEAK = ("wb", "wi", "wf")
+
+
+def _ty_of_dtype(dt) -> str:
+    dt = np.dtype(dt)
+    for k, v in _NP.items():
+        if dt == np.dtype(v):
+            return k
+    raise NotTranslatable(f"dtype {dt} has no device form")
+
+
+class _V:
+    """A typed elementwise expression: C++ code, NumPy dtype tag (or weak Python scalar tag), constant value, array-ness."""
+
+    __slots__ = ("code", "ty", "const", "array")
+
+    def __init__(self, code, ty, const=None, array=False):
+        self.code, self.ty, self.const, self.array = code, ty, const, array
+
+
+def _lit(v, ty) -> str:
+    if ty in ("b", "wb"):
+        return "true" if v else "false"
+    if ty in ("i32", "i64", "wi"):
+        return f"{int(v)}LL" if ty != "i32" else f"{int(v)}"
+    v = float(v)
+    if v != v:
+        return "__builtin_nan(\"\")"
+    if v in (float("inf"), float("-inf")):
+        return ("-" if v < 0 else "") + "__builtin_inf()"
+    s = repr(v)
+    if "e" not in s and "." not in s and "n" not in s:
+        s += ".0"
+    return f"({s})"
+
+
+def _const(v) -> _V:
+    if isinstance(v, (bool, np.bool_)):
+        return _V(_lit(v, "wb"), "wb" if isinstance(v, bool) else "b", bool(v))
+    if isinstance(v, np.generic):
+        ty = _ty_of_dtype(v.dtype)
+        return _V(f"(({_CT[ty]}){_lit(v.item(), 'wf' if ty[0] == 'f' else 'wi')})", ty, v.item())
+    if isinstance(v, int):  # IntEnum (StatusCode) included
+        return _V(_lit(int(v), "wi"), "wi", int(v))
+    if isinstance(v, float):
+        return _V(_lit(v, "wf"), "wf", float(v))
+    raise NotTranslatable(f"constant of type {type(v).__name__}")
+
+
+def _np_arg(v: _V):
+    if v.ty == "wb":
+        return True
+    if v.ty == "wi":
+        return int(v.const) if v.const is not None and abs(int(v.const)) < 2**31 else 1
+    if v.ty == "wf":
+        return 1.5
+    return np.dtype(_NP[v.ty])
+
+
+def _promote(a: _V, b: _V) -> str:
+    if a.ty in _WEAK and b.ty in _WEAK:
+        return "wf" if "wf" in (a.ty, b.ty) else ("wi" if "wi" in (a.ty, b.ty) else "wb")
+    return _ty_of_dtype(np.result_type(_np_arg(a), _np_arg(b)))
+
+
+def _cast(v: _V, ty: str) -> str:
+    if ty in _WEAK:
+        return v.code
+    if v.ty == ty:
+        return v.code
+    return f"(({_CT[ty]})({v.code}))"
+
+
+def _strong(ty: str) -> str:
+    """The dtype a weak Python scalar takes when it becomes an array element by itself."""
+    return {"wb": "b", "wi": "i64", "wf": "f64"}.get(ty, ty)
+
+
+_SPATIAL = ("x", "y", "z", "dx", "dy", "dz")
+
+
+class _Translator(ast.NodeVisitor):
+    def __init__(self, func, pclass, fieldset, var_slot, field_ids, next_dt_f32=False, slot_prefix=""):
+        self.func, self.fieldset, self.field_ids = func, fieldset, field_ids
+        self.slot_prefix = slot_prefix
+        self.var_slot = var_slot  # user Variable name -> (extra column index, dtype tag)
+        self.vars = {v.name: np.dtype(v.dtype) for v in pclass.variables}
+        self.spatial = _ty_of_dtype(self.vars["x"])
+        self.next_dt_f32 = next_dt_f32
+        src = textwrap.dedent(inspect.getsource(func))
+        tree = ast.parse(src)
+        fdef = tree.body[0]
+        if not isinstance(fdef, ast.FunctionDef) or len(fdef.args.args) != 2 or fdef.args.vararg or fdef.args.kwarg or fdef.decorator_list:
+            raise NotTranslatable("not a plain `def kernel(particles, fieldset)`")
+        self.pname, self.fname = fdef.args.args[0].arg, fdef.args.args[1].arg
+        self.fdef = fdef
+        self.env = dict(func.__globals__)
+        if func.__closure__:
+            for name, cell in zip(func.__code__.co_freevars, func.__closure__):
+                try:
+                    self.env[name] = cell.cell_contents
+                except ValueError:
+                    pass
+        self.locals: dict[str, _V] = {}
+        self.decl: list[str] = []  # members of PkUserLocals
+        self.stages: list[list[str]] = [[]]
+        self.touched: set[str] = set()
+        self.nslot = 0
+
+    # ---- helpers -------------------------------------------------------------------------------------------------------------
+    def emit(self, line):
+        self.stages[-1].append(line)
+
+    def new_slot(self, ty, prefix="l") -> str:
+        name = f"{self.slot_prefix}{prefix}{self.nslot}"
+        self.nslot += 1
+        self.decl.append(f"{_CT[ty]} {name};")
+        return f"L.ul.{name}"
+
+    def var_type(self, name) -> str:
+        if name in _SPATIAL:
+            return self.spatial
+        if name in ("t", "dt"):
+            return "f64"
+        if name == "next_dt":
+            if self.next_dt_f32 or np.dtype(self.vars.get("next_dt", np.float64)) != np.float64:
+                raise NotTranslatable("a float32 next_dt Variable")
+            return "f64"
+        if name == "state":
+            return "i32"
+        if name == "particle_id":
+            return "i64"
+        if name in self.var_slot:
+            return self.var_slot[name][1]
+        raise NotTranslatable(f"particle Variable '{name}' has no device column")
+
+    def load_var(self, name) -> _V:
+        if name not in self.vars:
+            raise NotTranslatable(f"particles have no Variable '{name}'")
+        ty = self.var_type(name)
+        self.touched.add(name)
+        if name in _SPATIAL or name in ("t", "dt", "next_dt"):
+            code = f"p.{name}" if ty == "f64" else f"((float)p.{name})"
+        elif name == "state":
+            code = "((int32_t)c.state)"
+        elif name == "particle_id":
+            code = "((int64_t)p.id)"
+        else:
+            code = f"(({_CT[ty]}*)a.p.extra[{self.var_slot[name][0]}])[c.row]"
+        return _V(code, ty, array=True)
+
+    def store_var(self, name, value: _V, mask: _V | None = None):
+        if name not in self.vars:
+            raise NotTranslatable(f"particles have no Variable '{name}'")
+        if name in ("particle_id", "ei"):
+            raise NotTranslatable(f"assignment to particles.{name}")
+        ty = self.var_type(name)
+        self.touched.add(name)
+        val = _cast(value, ty)
+        if name in _SPATIAL or name in ("t", "dt", "next_dt"):
+            stmt = f"p.{name} = (double)({val});"
+        elif name == "state":
+            stmt = f"c.state = (int)({val});"
+        else:
+            stmt = f"(({_CT[ty]}*)a.p.extra[{self.var_slot[name][0]}])[c.row] = {val};"
+        self.emit(f"if ({mask.code}) {{ {stmt} }}" if mask is not None else stmt)
+
+    def try_const(self, node):
+        """Evaluate a sub-tree that involves neither the particles nor a field nor a local: module constants, np.pi, StatusCode.X,
+        fieldset.<context constant>."""
+        for n in ast.walk(node):
+            if isinstance(n, ast.Name) and (n.id == self.pname or n.id in self.locals):
+                return None
+            if isinstance(n, (ast.Call, ast.Subscript, ast.Lambda, ast.ListComp, ast.GeneratorExp)):
+                return None
+        env = dict(self.env)
+
+        class _Ctx:
+            pass
+
+        ctx = _Ctx()
+        for k, v in dict(self.fieldset.context).items():
+            setattr(ctx, k, v)
+        env[self.fname] = ctx
+        try:
+            val = eval(compile(ast.Expression(body=node), "<kernel>", "eval"), env)  # noqa: S307 -- the user's own kernel source
+        except Exception:
+            return None
+        if isinstance(val, (bool, int, float, np.generic)):
+            return _const(val)
+        return None
+
+    # ---- expressions ---------------------------------------------------------------------------------------------------------
+    def expr(self, node) -> _V:
+        c = self.try_const(node)
+        if c is not None:
+            return c
+        m = getattr(self, "e_" + type(node).__name__, None)
+        if m is None:
+            raise NotTranslatable(f"expression {type(node).__name__}")
+        return m(node)
+
+    def e_Constant(self, node):
+        return _const(node.value)
+
+    def e_Name(self, node):
+        if node.id in self.locals:
+            return self.locals[node.id]
+        raise NotTranslatable(f"name '{node.id}'")
+
+    def e_Attribute(self, node):
+        if isinstance(node.value, ast.Name) and node.value.id == self.pname:
+            return self.load_var(node.attr)
+        raise NotTranslatable(f"attribute .{node.attr}")
+
+    def is_sample(self, node):
+        return (isinstance(node, ast.Subscript) and isinstance(node.value, ast.Attribute) and isinstance(node.value.value, ast.Name)
+                and node.value.value.id == self.fname and isinstance(node.slice, ast.Name) and node.slice.id == self.pname)
+
+    def sample(self, node):
+        """`fieldset.F[particles]` -> a stage boundary; returns the tuple of sampled components (float64 arrays)."""
+        name = node.value.attr
+        fld = self.fieldset.fields.get(name)
+        if fld is None:
+            raise NotTranslatable(f"fieldset has no field '{name}'")
+        vector = hasattr(fld, "U")
+        if vector:
+            if name not in ("UV", "UVW"):
+                raise NotTranslatable(f"vector field '{name}'")
+            if fld is not self.fieldset.fields.get(name):
+                raise NotTranslatable("vector field alias")
+            kind, n, fid = ("RQ_UVW", 3, 0) if name == "UVW" else ("RQ_UV", 2, 0)
+        else:
+            if name in ("U", "V", "W"):
+                raise NotTranslatable("sampling a velocity component by itself (the reference warns: host path)")
+            kind, n, fid = "RQ_SCALAR", 1, self.field_ids[name]
+        self.emit(f"rq.kind = {kind}; rq.fidx = {fid}; rq.f32 = c.pf; rq.t = p.t; rq.z = p.z; rq.y = p.y; rq.x = p.x; return false;")
+        self.stages.append([])
+        out = []
+        for j in range(n):
+            slot = self.new_slot("f64", "s")
+            self.emit(f"{slot} = L.r[{3 + j}];")
+            out.append(_V(slot, "f64", array=True))
+        return out if vector else out[0]
+
+    def e_Subscript(self, node):
+        if self.is_sample(node):
+            r = self.sample(node)
+            if isinstance(r, list):
+                raise NotTranslatable("a vector sample must be unpacked: u, v = fieldset.UV[particles]")
+            return r
+        raise NotTranslatable("subscript in an expression")
+
+    def e_UnaryOp(self, node):
+        v = self.expr(node.operand)
+        if isinstance(node.op, ast.USub):
+            if v.ty in ("b", "wb"):
+                raise NotTranslatable("negating a boolean")
+            return _V(f"(-({v.code}))", v.ty, array=v.array)
+        if isinstance(node.op, ast.UAdd):
+            return v
+        if isinstance(node.op, ast.Invert) and v.ty in ("b", "wb"):
+            return _V(f"(!({v.code}))", "b", array=v.array)
+        raise NotTranslatable(f"unary {type(node.op).__name__}")
+
+    def e_BinOp(self, node):
+        op = node.op
+        if isinstance(op, ast.Pow):
+            e = self.try_const(node.right)
+            if e is None or e.const != 2 or e.ty not in ("wi", "wf"):
+                raise NotTranslatable("** with an exponent other than the literal 2")
+            v = self.expr(node.left)
+            if v.ty in ("b", "wb"):
+                raise NotTranslatable("boolean ** 2")
+            ty = _strong(v.ty) if (e.ty == "wi" or _strong(v.ty)[0] == "f") else "f64"  # ndarray.__pow__(2) is np.square: the array's dtype
+            tmp = self.new_slot(ty)
+            self.emit(f"{tmp} = {_cast(v, ty)};")
+            return _V(f"({tmp} * {tmp})", ty, array=v.array)
+        a, b = self.expr(node.left), self.expr(node.right)
+        arr = a.array or b.array
+        if isinstance(op, (ast.BitAnd, ast.BitOr, ast.BitXor)):
+            if a.ty not in ("b", "wb") or b.ty not in ("b", "wb"):
+                raise NotTranslatable("bitwise operator on non-boolean operands")
+            sym = {"BitAnd": "&&", "BitOr": "||", "BitXor": "!="}[type(op).__name__]
+            return _V(f"(({a.code}) {sym} ({b.code}))", "b", array=arr)
+        ty = _promote(a, b)
+        if ty in ("b", "wb"):
+            raise NotTranslatable("arithmetic on booleans")
+        if isinstance(op, (ast.Add, ast.Sub, ast.Mult)):
+            sym = {"Add": "+", "Sub": "-", "Mult": "*"}[type(op).__name__]
+            return _V(f"({_cast(a, ty)} {sym} {_cast(b, ty)})", ty, array=arr)
+        if isinstance(op, ast.Div):  # np.true_divide: integers divide as float64
+            if ty in ("i32", "i64"):
+                ty = "f64"
+            elif ty == "wi":
+                ty = "wf"
+            ca, cb = (_cast(a, ty), _cast(b, ty)) if ty not in _WEAK else (f"((double)({a.code}))", f"((double)({b.code}))")
+            return _V(f"({ca} / {cb})", ty, array=arr)
+        if isinstance(op, ast.Mod):  # np.remainder on floats: fmod, then the sign of the divisor (npy_divmod)
+            if ty not in ("f32", "f64"):
+                raise NotTranslatable("% on integers")
+            fm = "fmodf" if ty == "f32" else "fmod"
+            ta, tb, tm = self.new_slot(ty), self.new_slot(ty), self.new_slot(ty)
+            self.emit(f"{ta} = {_cast(a, ty)}; {tb} = {_cast(b, ty)}; {tm} = {fm}({ta}, {tb});")
+            self.emit(f"if ({tb} != 0) {{ if ({tm} != 0) {{ if (({tb} < 0) != ({tm} < 0)) {tm} += {tb}; }} else {{ {tm} = __builtin_copysign{'f' if ty == 'f32' else ''}(({_CT[ty]})0, {tb}); }} }}")
+            return _V(tm, ty, array=arr)
+        raise NotTranslatable(f"operator {type(op).__name__}")
+
+    def e_Compare(self, node):
+        if len(node.ops) != 1:
+            raise NotTranslatable("chained comparison")
+        a, b = self.expr(node.left), self.expr(node.comparators[0])
+        sym = {"Lt": "<", "LtE": "<=", "Gt": ">", "GtE": ">=", "Eq": "==", "NotEq": "!="}.get(type(node.ops[0]).__name__)
+        if sym is None:
+            raise NotTranslatable(f"comparison {type(node.ops[0]).__name__}")
+        ty = _promote(a, b)
+        ct = _strong(ty)
+        return _V(f"({_cast(a, ct)} {sym} {_cast(b, ct)})", "b", array=a.array or b.array)
+
+    def np_func(self, node):
+        f = node.func
+        if isinstance(f, ast.Attribute) and isinstance(f.value, ast.Name) and self.env.get(f.value.id) is np:
+            return f.attr
+        if isinstance(f, ast.Name) and f.id == "abs" and "abs" not in self.env:
+            return "abs"
+        return None
+
+    def e_Call(self, node):
+        name = self.np_func(node)
+        if name is None or node.keywords:
+            raise NotTranslatable("call of something other than a supported numpy function")
+        args = [self.expr(a) for a in node.args]
+        arr = any(a.array for a in args)
+        if name == "where" and len(args) == 3:
+            c, a, b = args
+            ty = _strong(_promote(a, b))
+            cond = c.code if c.ty in ("b", "wb") else f"(({c.code}) != 0)"
+            return _V(f"(({cond}) ? {_cast(a, ty)} : {_cast(b, ty)})", ty, array=arr)
+        if name in ("abs", "absolute", "fabs") and len(args) == 1:
+            v = args[0]
+            ty = _strong(v.ty)
+            if ty == "b":
+                raise NotTranslatable("abs of a boolean")
+            if ty[0] == "f":
+                return _V(f"{'fabsf' if ty == 'f32' else 'fabs'}({_cast(v, ty)})", ty, array=arr)
+            t = self.new_slot(ty)
+            self.emit(f"{t} = {_cast(v, ty)};")
+            return _V(f"({t} < 0 ? -{t} : {t})", ty, array=arr)
+        if name in ("sqrt", "floor", "ceil", "trunc") and len(args) == 1:
+            v = args[0]
+            ty = _strong(v.ty)
+            if ty[0] != "f":
+                ty = "f64"
+            return _V(f"{name}{'f' if ty == 'f32' else ''}({_cast(v, ty)})", ty, array=arr)
+        if name == "fmod" and len(args) == 2:
+            ty = _strong(_promote(*args))
+            if ty[0] != "f":
+                raise NotTranslatable("np.fmod on integers")
+            return _V(f"{'fmodf' if ty == 'f32' else 'fmod'}({_cast(args[0], ty)}, {_cast(args[1], ty)})", ty, array=arr)
+        if name in ("minimum", "maximum") and len(args) == 2:  # NaN-propagating, like the ufuncs
+            ty = _strong(_promote(*args))
+            if ty == "b":
+                raise NotTranslatable(f"np.{name} on booleans")
+            ta, tb = self.new_slot(ty), self.new_slot(ty)
+            self.emit(f"{ta} = {_cast(args[0], ty)}; {tb} = {_cast(args[1], ty)};")
+            cmp_ = "<=" if name == "minimum" else ">="
+            nan = f" || {ta} != {ta}" if ty[0] == "f" else ""
+            return _V(f"(({ta} {cmp_} {tb}{nan}) ? {ta} : {tb})", ty, array=arr)
+        if name in ("isnan", "isfinite") and len(args) == 1:
+            v = args[0]
+            ty = _strong(v.ty)
+            if ty[0] != "f":
+                return _V("false" if name == "isnan" else "true", "b", array=arr)
+            t = self.new_slot(ty)
+            self.emit(f"{t} = {_cast(v, ty)};")
+            return _V(f"({t} != {t})" if name == "isnan" else f"(({t} - {t}) == 0)", "b", array=arr)
+        if name in ("float32", "float64", "int32", "int64") and len(args) == 1:
+            ty = {"float32": "f32", "float64": "f64", "int32": "i32", "int64": "i64"}[name]
+            return _V(f"(({_CT[ty]})({args[0].code}))", ty, array=arr)
+        raise NotTranslatable(f"np.{name}")
+
+    # ---- statements ----------------------------------------------------------------------------------------------------------
+    def target(self, node):
+        """-> ('local', name) | ('var', name, mask or None) | ('skip',)"""
+        if isinstance(node, ast.Name):
+            if node.id in (self.pname, self.fname):
+                raise NotTranslatable("rebinding a kernel argument")
+            return ("local", node.id)
+        if isinstance(node, ast.Attribute):
+            base = node.value
+            if isinstance(base, ast.Name) and base.id == self.pname:
+                return ("var", node.attr, None)
+            if isinstance(base, ast.Subscript) and isinstance(base.value, ast.Name) and base.value.id == self.pname:  # particles[mask].v
+                return ("var", node.attr, self.mask(base.slice))
+        if isinstance(node, ast.Subscript) and isinstance(node.value, ast.Attribute) and isinstance(node.value.value, ast.Name) \
+                and node.value.value.id == self.pname:  # particles.v[mask]
+            return ("var", node.value.attr, self.mask(node.slice))
+        raise NotTranslatable("assignment target")
+
+    def mask(self, node) -> _V:
+        m = self.expr(node)
+        if m.ty not in ("b", "wb") or not m.array:
+            raise NotTranslatable("a selection that is not a boolean mask over the particles")
+        t = self.new_slot("b")
+        self.emit(f"{t} = {m.code};")
+        return _V(t, "b", array=True)
+
+    def assign(self, tgt, value: _V):
+        if tgt[0] == "local":
+            ty = _strong(value.ty)
+            if value.array:
+                slot = self.new_slot(ty)
+                self.emit(f"{slot} = {_cast(value, ty)};")
+                self.locals[tgt[1]] = _V(slot, ty, array=True)
+            else:
+                self.locals[tgt[1]] = value  # a scalar stays a (weak) scalar
+        else:
+            _, name, mask = tgt
+            if mask is not None and value.array:
+                raise NotTranslatable("masked assignment of an array (NumPy would need matching shapes)")
+            self.store_var(name, value, mask)
+
+    def run(self):
+        body = self.fdef.body
+        for i, st in enumerate(body):
+            if isinstance(st, ast.Expr) and isinstance(st.value, ast.Constant) and isinstance(st.value.value, str):
+                continue
+            if isinstance(st, ast.Pass):
+                continue
+            if isinstance(st, ast.Assign):
+                if len(st.targets) != 1:
+                    raise NotTranslatable("chained assignment")
+                t = st.targets[0]
+                if isinstance(t, ast.Tuple):
+                    if not self.is_sample(st.value):
+                        raise NotTranslatable("tuple assignment of something other than a vector sample")
+                    comps = self.sample(st.value)
+                    if not isinstance(comps, list) or len(comps) != len(t.elts):
+                        raise NotTranslatable("vector sample unpacked into the wrong number of names")
+                    for el, comp in zip(t.elts, comps):
+                        if isinstance(el, ast.Name) and el.id == "_":
+                            continue
+                        self.assign(self.target(el), comp)
+                else:
+                    tgt = self.target(t)  # (the mask, if any, is evaluated first: it cannot depend on the value)
+                    self.assign(tgt, self.expr(st.value))
+                continue
+            if isinstance(st, ast.AugAssign):
+                tgt = self.target(st.target)
+                if tgt[0] != "var":
+                    raise NotTranslatable("in-place operator on a local (it may alias a particle column)")
+                _, name, mask = tgt
+                cur = self.load_var(name)
+                val = self.expr(st.value)
+                if mask is not None and val.array:
+                    raise NotTranslatable("masked in-place operator with an array operand")
+                if not isinstance(st.op, (ast.Add, ast.Sub, ast.Mult, ast.Div)):
+                    raise NotTranslatable(f"in-place {type(st.op).__name__}")
+                ty = _promote(cur, val)
+                if isinstance(st.op, ast.Div) and ty in ("i32", "i64"):
+                    ty = "f64"
+                # ufunc(..., out=column): the result must cast back with 'same_kind'
+                if not np.can_cast(np.dtype(_NP[_strong(ty)]), np.dtype(_NP[cur.ty]), "same_kind"):
+                    raise NotTranslatable(f"in-place operator: {_strong(ty)} does not cast back to {cur.ty} (NumPy raises)")
+                sym = {"Add": "+", "Sub": "-", "Mult": "*", "Div": "/"}[type(st.op).__name__]
+                ct = _strong(ty)
+                self.store_var(name, _V(f"({_cast(cur, ct)} {sym} {_cast(val, ct)})", ct, array=True), mask)
+                continue
+            if isinstance(st, ast.Return) and st.value is None and i == len(body) - 1:
+                continue
+            raise NotTranslatable(f"statement {type(st).__name__}")
+        self.emit("return true;")
+
+
+class UserKernelSource:
+    def __init__(self, name, decl, stages, touched):
+        self.name, self.decl, self.stages, self.touched = name, decl, stages, touched
+
+    def case_body(self) -> str:
+        out = ["switch (stage) {"]
+        for k, lines in enumerate(self.stages):
+            out.append(f"    case {k}: {{")
+            out += ["        " + ln for ln in lines]
+            out.append("    }")
+        out.append("    default: return true;")
+        out.append("}")
+        return "\n".join(out)
+
+
+def translate(func, pclass, fieldset, var_slot, field_ids, next_dt_f32=False, slot_prefix="") -> UserKernelSource:
+    """Python kernel -> stage-machine source.  var_slot: {user Variable name: (extra column index, dtype tag 'f32' | 'f64')}."""
+    try:
+        tr = _Translator(func, pclass, fieldset, var_slot, field_ids, next_dt_f32, slot_prefix)
+    except (OSError, TypeError, SyntaxError, IndentationError) as e:
+        raise NotTranslatable(f"source of {getattr(func, '__name__', func)!r} is not available: {e}") from None
+    tr.run()
+    return UserKernelSource(func.__name__, tr.decl, tr.stages, tr.touched)
+
+
+def candidate_variables(func, pclass):
+    """User Variables a kernel mentions (``particles.<name>`` with <name> a non-core Variable): what must be bound as device columns."""
+    try:
+        tree = ast.parse(textwrap.dedent(inspect.getsource(func)))
+    except (OSError, TypeError, SyntaxError, IndentationError):
+        return []
+    core = set(_SPATIAL) | {"t", "dt", "next_dt", "state", "particle_id", "ei"}
+    names = [v.name for v in pclass.variables]
+    out = []
+    for n in ast.walk(tree):
+        if isinstance(n, ast.Attribute) and n.attr in names and n.attr not in core and n.attr not in out:
+            out.append(n.attr)
+    return out
+
+
+_TEMPLATE = """// generated by parcels_amd/jit.py -- user kernels: {names}
+#define PK_USER_KERNELS 1
+#ifndef PK_MIN_WAVES
+#define PK_MIN_WAVES 2
+#endif
+#include <stdint.h>
+namespace pk {{
+struct PkUserLocals {{
+{decl}
+}};
+}}
+#include "pk_kernels.h"
+namespace pk {{
+PK_DEV bool user_prepare(const KArgs& a, int uk, int stage, int kslot, PCtx& c, PState& p, KLocal& L, Request& rq) {{
+    switch (uk) {{
+{cases}
+        default: c.state = PK_ERROR; return true;
+    }}
+}}
+}}  // namespace pk
+extern "C" void pk_user_launch(const void* kargs, int32_t key, int32_t lds, uint64_t lds_bytes, void* stream) {{
+    using namespace pk;
+    const KArgs& a = *(const KArgs*)kargs;
+    if (key != {key} || lds != {lds}) {{
+        fprintf(stderr, "parcels_amd user program built for variant (%d, %d), launched as (%d, %d)\\n", {key}, {lds}, key, lds);
+        abort();
+    }}
+    constexpr int WG = wg_size({kind}, {ldsb});
+    hipLaunchKernelGGL((advect_kernel<{ft}, {kind}, {interp}, -1, {ldsb}, false>), dim3((unsigned)((a.p.n + WG - 1) / WG)), dim3(WG), (size_t)lds_bytes,
+                       (hipStream_t)stream, a);
+}}
+"""
+
+
+def _csrc_hash() -> str:
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(_CSRC)):
+        if f.endswith((".h", ".hip")) and f not in ("pk_api.hip",):
+            h.update(open(os.path.join(_CSRC, f), "rb").read())
+    h.update(open(os.path.join(_INCLUDE, "parcels_hip.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cache_dir() -> str:
+    d = os.environ.get("PARCELS_AMD_JIT_CACHE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "_jit_cache")
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+class UserProgram:
+    """One compiled module: the kernel-list interpreter of ONE variant with up to PK_MAX_USER_KERNELS user kernels in it."""
+
+    def __init__(self, sources: list[UserKernelSource], key: int, lds: int):
+        if not (1 <= len(sources) <= PK_MAX_USER_KERNELS):
+            raise NotTranslatable(f"1 .. {PK_MAX_USER_KERNELS} user kernels per kernel list")
+        decl = "\n".join("    " + d for s in sources for d in s.decl) or "    char unused;"
+        # the locals of different kernels never live at the same time, but they are few: one struct, distinct names
+        cases = "\n".join(f"        case {k}: {{\n" + textwrap.indent(s.case_body(), "            ") + "\n        }" for k, s in enumerate(sources))
+        ft = "float" if key >= 6 else "double"
+        kind, interp = (key % 6) // 3, key % 3
+        self.source = _TEMPLATE.format(names=", ".join(s.name for s in sources), decl=decl, cases=cases, key=key, lds=lds, ft=ft, kind=kind,
+                                       interp=interp, ldsb="true" if lds else "false")
+        self.digest = hashlib.sha256((self.source + _csrc_hash()).encode()).hexdigest()[:20]
+        self.path = os.path.join(cache_dir(), f"user_{self.digest}.so")
+        self._lib = None
+
+    def build(self):
+        if os.path.exists(self.path):
+            return self.path
+        src = self.path[:-3] + ".hip"
+        with open(src, "w") as f:
+            f.write(self.source)
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unused-function",
+               f"-I{_CSRC}", f"-I{_INCLUDE}", src, "-o", self.path + ".tmp"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on the generated user-kernel module {src}:\n{r.stderr[-4000:]}")
+        os.replace(self.path + ".tmp", self.path)
+        return self.path
+
+    def launcher(self) -> int:
+        """Address of pk_user_launch (loads the module; its code object registers with the HIP runtime of this process)."""
+        if self._lib is None:
+            self._lib = C.CDLL(self.build())
+        return C.cast(self._lib.pk_user_launch, C.c_void_p).value
+
+
+_ = (StatusCode, _hip)  # (re-exported names user kernels commonly reference; keeps linters quiet)

@@ -3,8 +3,9 @@
 
 The reference runs every kernel function on a NumPy view of the particle set, one dt at a time
 (kernel.py:188-245).  Here the kernel list is translated to PK_KERNEL_* ids and ONE ``pk_execute`` call advances all
-particles to ``endtime`` on the GPU.  Only the built-in kernels of ``parcels_amd.kernels`` are accepted: a Python
-function cannot run inside a HIP kernel and this package deliberately has no host execution path.
+particles to ``endtime`` on the GPU.  User-written Python kernels join that launch when they are elementwise (parcels_amd/jit.py
+translates and compiles them into the kernel-list interpreter); any other Python function makes the loop run on the host columns
+(parcels_amd/hostkernels.py) with the built-in kernels' bodies still on the GPU.
 """
 
 from __future__ import annotations
@@ -46,6 +47,9 @@ class Kernel:
         # Python functions that are not built-in device kernels: the loop of Kernel.execute then runs on the host columns and only
         # the built-in kernels' bodies on the GPU (parcels_amd/hostkernels.py) -- correct, and slow by construction
         self.host_functions = [f.__name__ for f in kernels if _k.kernel_id(f) is None]
+        self.user_program = None   # parcels_amd.jit.UserProgram once the Python functions of the list were compiled for the device
+        self.jit_report = None     # why they were not (the host path runs them then)
+        self._jit_tried = False
         self._fieldset = pset.fieldset
         self._pclass = pset._pclass
         for f in kernels:
@@ -139,12 +143,65 @@ class Kernel:
             return int(np.any(np.mod(data["ei"][:, 0].astype(np.int64), xdim) != 0))
         return 0
 
+    def _try_jit(self, pset):
+        """Compile the Python functions of the list into the device program (parcels_amd/jit.py).  On success the list is a pure
+        device list: user ids PK_KERNEL_USER0 + j, the Variables the functions touch bound as device columns."""
+        from . import _hip, jit
+        import ctypes as C
+
+        self._jit_tried = True
+        if not jit.jit_enabled():
+            self.jit_report = "PARCELS_AMD_JIT=0"
+            return
+        try:
+            engine = pset._engine()
+            funcs = [f for f in self._kernels if _k.kernel_id(f) is None]
+            if len(funcs) > jit.PK_MAX_USER_KERNELS:
+                raise jit.NotTranslatable(f"more than {jit.PK_MAX_USER_KERNELS} Python kernels in one list")
+            names = {v.name: v for v in self._pclass.variables}
+            dev_vars = list(self.device_variables)
+            for f in funcs:
+                for vn in jit.candidate_variables(f, self._pclass):
+                    if np.dtype(names[vn].dtype) not in (np.dtype(np.float32), np.dtype(np.float64)):
+                        raise jit.NotTranslatable(f"Variable '{vn}' is {np.dtype(names[vn].dtype)}: device columns are float32 / float64")
+                    if vn not in dev_vars:
+                        dev_vars.append(vn)
+            if len(dev_vars) > 4:
+                raise jit.NotTranslatable("more than 4 user Variables touched by device kernels (PK_MAX_EXTRA)")
+            var_slot = {vn: (k, "f32" if np.dtype(names[vn].dtype) == np.float32 else "f64") for k, vn in enumerate(dev_vars)}
+            next_dt_f32 = "next_dt" in names and np.dtype(names["next_dt"].dtype) != np.float64
+            sources, ids, j = [], [], 0
+            for f in self._kernels:
+                kid = _k.kernel_id(f)
+                if kid is None:
+                    sources.append(jit.translate(f, self._pclass, self._fieldset, var_slot, engine.field_ids, next_dt_f32, slot_prefix=f"k{j}_"))
+                    kid = jit.PK_KERNEL_USER0 + j
+                    j += 1
+                ids.append(kid)
+            prm = engine.make_params([i if i < jit.PK_KERNEL_USER0 else 23 for i in ids], endtime=0.0, dt0=1.0, context=self._fieldset.context,
+                                     samples=self.samples)  # (variant of the program: the kernel ids do not matter, DoNothing stands in)
+            key, lds, typed = C.c_int32(), C.c_int32(), C.c_int32()
+            engine.ctx.check(engine.lib.pk_generic_variant(engine.ctx.handle, C.byref(prm), C.byref(key), C.byref(lds), C.byref(typed)), "pk_generic_variant")
+            if typed.value:
+                raise jit.NotTranslatable("float32 coordinate arrays (NumPy dtype propagation of the typed program)")
+            prog = jit.UserProgram(sources, key.value, lds.value)
+            prog.launcher()  # builds (or finds in the cache) and loads the module
+        except jit.NotTranslatable as e:
+            self.jit_report = str(e)
+            return
+        self.user_program = prog
+        self.kernel_ids = ids
+        self.device_variables = dev_vars
+        self.host_functions = []
+        self.jit_report = f"compiled {[s.name for s in sources]} into {prog.path}"
+
     def launch(self, pset, endtime, dt, have_guess0=0):
         """Device part of Kernel.execute: advance the BOUND, device-resident particle columns to ``endtime``.
         No host<->device copies; returns the engine statistics (steps, state histogram, kernel time)."""
         if self.host_functions:
             return self._launch_hosted(pset, endtime, dt)
         engine = pset._engine()
+        engine.set_user_program(self.user_program)
         data = pset._data
         if "RK45_tol" in self.fieldset.context and "next_dt" not in data:
             # kernel.py:118-120: `particles.dt = particles.next_dt` runs whenever the fieldset has RK45_tol
@@ -156,7 +213,7 @@ class Kernel:
             every = getattr(type(pset), "RESORT_EVERY_DEFAULT", None)
         stats = engine.execute(self.kernel_ids, endtime=endtime, dt0=dt, context=self.fieldset.context, seed=pset.seed,
                                have_guess0=have_guess0, sort_by_cell=int(pset.sort_by_cell), t_start=t_start, samples=self.samples,
-                               resort_every=every or None)
+                               resort_every=every or None, in_place_variables=self.user_program is not None)
         pset._last_stats = stats
         return stats
 
@@ -204,6 +261,8 @@ class Kernel:
             return StatusCode.Success
         engine = pset._engine()
         pset._t_live = None
+        if self.host_functions and not self._jit_tried:
+            self._try_jit(pset)
         engine.device_variables = list(self.device_variables)
         engine.bind_particles(pset._data)
         engine.h2d()

@@ -282,6 +282,8 @@ class ParticleSet:
         engine = self._engine()
         kern = self._kernel
         self._t_live = None
+        if kern.host_functions and not kern._jit_tried:
+            kern._try_jit(self)  # elementwise Python kernels are compiled into the device program here (parcels_amd/jit.py)
         engine.device_variables = list(kern.device_variables)  # user Variables that device kernels write live on the device
         if len(self) > 0:
             engine.bind_particles(self._data)

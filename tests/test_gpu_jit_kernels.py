@@ -1,0 +1,235 @@
+"""GPU: user-written Python kernels compiled into the fused step loop (parcels_amd/jit.py) against the host path
+(parcels_amd/hostkernels.py: the reference's loop of kernel.py:190-245 on the host columns, i.e. NumPy itself).  Every supported
+construct -- in-place operators across dtypes, np.where, masked assignment, comparisons and boolean algebra, %, fmod, minimum / maximum,
+scalar and vector field samples, changes of dt and of the state -- gives the same columns bit for bit either way, the compiled list is ONE
+launch of the kernel-list interpreter, and whatever the translator does not take (control flow, random numbers, integer Variables ...)
+still runs, on the host path."""
+import os
+
+import numpy as np
+import pytest
+
+import parcels_amd as pa
+from parcels_amd import StatusCode
+
+pytestmark = pytest.mark.gpu
+
+
+def _fieldset(mesh="flat", seed=4):
+    """U, V and a scalar T on a small rectilinear A-grid with three time levels (smooth random data)."""
+    nx, ny, nt = 24, 18, 3
+    md = pa.SGrid2DMetadata(node_dimensions=("XG", "YG"), node_coordinates=("lon", "lat"),
+                            face_dimensions=(pa.FaceNodePadding("XC", "XG", pa.Padding.LOW), pa.FaceNodePadding("YC", "YG", pa.Padding.LOW)),
+                            vertical_dimensions=None)
+    if mesh == "flat":
+        lon, lat, vel = np.linspace(0.0, 4.0e4, nx), np.linspace(0.0, 3.0e4, ny), 0.1
+    else:
+        lon, lat, vel = np.linspace(-20.0, 20.0, nx), np.linspace(-15.0, 15.0, ny), 1.5
+    coords = {"lon": (("XG",), lon), "lat": (("YG",), lat), "time": (("time",), np.arange(nt) * 43200.0)}
+    rng = np.random.default_rng(seed)
+    yy, xx = np.meshgrid(np.linspace(0, 1, ny), np.linspace(0, 1, nx), indexing="ij")
+
+    def smooth(scale):
+        a = sum(rng.normal() * np.sin(2 * np.pi * (kx * xx + ky * yy) + rng.uniform(0, 6)) for kx in (1, 2) for ky in (1, 2))
+        return np.stack([scale * a * (1 + 0.1 * k) for k in range(nt)])
+
+    dims = ("time", "YG", "XG")
+    data = {"U": (dims, smooth(vel)), "V": (dims, smooth(vel)), "T": (dims, 10.0 + smooth(3.0)), "S": (dims, smooth(1.0).astype(np.float32))}
+    return pa.FieldSet.from_sgrid_conventions(pa.Dataset(data, coords, sgrid=md), mesh=mesh)
+
+
+def _pclass(spatial=np.float32):
+    P = pa.get_default_particle(spatial)
+    return P.add_variable([pa.Variable("age", dtype=np.float32, initial=0), pa.Variable("acc", dtype=np.float64, initial=0),
+                           pa.Variable("temp", dtype=np.float32, initial=0), pa.Variable("speed", dtype=np.float64, initial=0)])
+
+
+def _run(kernels, *, jit, mesh="flat", spatial=np.float32, n=300, runtime=12 * 600.0, dt=600.0, context=None, margin=0.15, expect_error=None,
+         output=None, seed=1):
+    old = os.environ.get("PARCELS_AMD_JIT")
+    os.environ["PARCELS_AMD_JIT"] = "1" if jit else "0"
+    try:
+        fs = _fieldset(mesh)
+        for k, v in (context or {}).items():
+            fs.add_context(k, v)
+        rng = np.random.default_rng(seed)
+        lon, lat = np.asarray(fs.U.grid.lon), np.asarray(fs.U.grid.lat)
+        x = lon[0] + (margin + (1 - 2 * margin) * rng.uniform(size=n)) * (lon[-1] - lon[0])
+        y = lat[0] + (margin + (1 - 2 * margin) * rng.uniform(size=n)) * (lat[-1] - lat[0])
+        pset = pa.ParticleSet(fs, pclass=_pclass(spatial), x=x, y=y, t=np.where(np.arange(n) % 4 == 0, 600.0, 0.0))
+        err = None
+        kw = {"output_file": output} if output is not None else {}
+        try:
+            pset.execute(kernels, runtime=runtime, dt=dt, **kw)
+        except (pa.FieldOutOfBoundError, pa.FieldOutOfBoundSurfaceError) as e:
+            err = type(e).__name__
+        assert err == expect_error, err
+        return pset, {k: np.array(v) for k, v in pset._data.items()}
+    finally:
+        if old is None:
+            os.environ.pop("PARCELS_AMD_JIT", None)
+        else:
+            os.environ["PARCELS_AMD_JIT"] = old
+
+
+def _both(kernels, **kw):
+    """Run the list compiled and on the host path; return the compiled run after asserting both agree bit for bit."""
+    pj, dj = _run(kernels, jit=True, **kw)
+    ph, dh = _run(kernels, jit=False, **kw)
+    assert pj._kernel.user_program is not None and not pj._kernel.host_functions, pj._kernel.jit_report
+    assert pj._last_stats["launches"] >= 1 and not pj._last_stats.get("hosted"), pj._last_stats
+    assert ph._kernel.user_program is None and (ph._last_stats is None or ph._last_stats.get("hosted")), ph._kernel.jit_report  # (None: it raised)
+    assert set(dj) == set(dh)
+    for k in dj:
+        assert dj[k].dtype == dh[k].dtype and np.array_equal(dj[k], dh[k], equal_nan=True), (k, np.flatnonzero(dj[k] != dh[k])[:5], dj[k][:4], dh[k][:4])
+    return pj, dj
+
+
+# ---- the kernels (module level: the translator reads their source) ----------------------------------------------------------------
+def Age(particles, fieldset):
+    particles.age += particles.dt  # float32 += float64: computed in float64, stored as float32
+
+
+def DeleteOld(particles, fieldset):
+    particles.state = np.where(particles.age > fieldset.max_age, StatusCode.Delete, particles.state)
+
+
+def DeleteErrorParticle(particles, fieldset):
+    any_error = particles.state >= 50
+    particles[any_error].state = StatusCode.Delete
+
+
+def PeriodicBC(particles, fieldset):
+    particles.acc += particles.dx
+    particles.x = np.fmod(particles.x, fieldset.width)
+
+
+def SampleT(particles, fieldset):
+    particles.temp = fieldset.T[particles]
+
+
+def SampleExpr(particles, fieldset):
+    t = fieldset.T[particles]
+    s = fieldset.S[particles]
+    particles.acc = t * 2 + s / 3 - particles.age
+    particles.temp += s
+
+
+def SampleSpeed(particles, fieldset):
+    u, v = fieldset.UV[particles]
+    particles.speed = np.sqrt(u**2 + v**2)
+    _, particles.acc = fieldset.UV[particles]
+
+
+def Algebra(particles, fieldset):
+    m = (particles.x > fieldset.x0) & ~(particles.y < fieldset.y0) | (particles.age == 0)
+    particles.acc = np.where(m, particles.acc + 1, particles.acc - 0.25)
+    particles.temp = np.minimum(np.maximum(particles.temp + particles.dx * 1000, -5), 7.5) + np.abs(particles.dy) % 0.3
+    particles.age = np.floor(particles.age / 7) * 7 + 1
+    particles.speed = particles.state / 3 + particles.particle_id * 2
+
+
+def ChangeDt(particles, fieldset):
+    particles.dt = np.where(particles.t >= 3000.0, 300.0, particles.dt)
+    particles.dx[particles.age > 2000] = 0
+
+
+def Kick(particles, fieldset):
+    particles.dx += 0.1
+    particles.dy -= fieldset.kick
+
+
+def NotElementwise(particles, fieldset):
+    if len(particles) > 0:  # control flow + a reduction: the host path
+        particles.acc += len(particles)
+
+
+@pytest.mark.parametrize("spatial", [np.float32, np.float64])
+def test_age_and_delete(gpu, spatial):
+    p, d = _both([pa.AdvectionRK4, Age, DeleteOld], spatial=spatial, context={"max_age": 4000.0})
+    assert 0 < len(p) < 300 or np.all(d["age"] <= 4000.0)  # particles older than max_age were deleted on the way
+    assert p._last_stats["program"] == 2  # ONE kernel-list interpreter launch (include/parcels_hip.h: pk_exec_stats.program)
+
+
+@pytest.mark.parametrize("mesh", ["flat", "spherical"])
+def test_recovery_kernel_written_by_the_user(gpu, mesh):
+    """tutorials: particles that leave the domain are deleted by a user kernel behind the advection kernel."""
+    p, d = _both([pa.AdvectionRK4, DeleteErrorParticle], mesh=mesh, margin=0.01, runtime=40 * 600.0, n=400)
+    assert len(p) < 400  # some did leave
+
+
+def test_periodic_boundary_and_accumulator(gpu):
+    _both([pa.AdvectionEE, PeriodicBC], context={"width": 3.0e4}, spatial=np.float32)
+    _both([pa.AdvectionEE, PeriodicBC], context={"width": 3.0e4}, spatial=np.float64)
+
+
+def test_scalar_and_vector_samples(gpu):
+    _both([pa.AdvectionRK4, SampleT])
+    _both([Age, SampleExpr, pa.AdvectionRK4], spatial=np.float64)
+    _both([SampleSpeed, pa.AdvectionRK2], mesh="spherical")
+
+
+def test_sampling_outside_the_domain_marks_the_particle(gpu):
+    """field.py:307-356: a sample outside the domain sets the error state like a built-in kernel's would; the user's recovery kernel
+    behind it deletes the particle."""
+    p, d = _both([pa.AdvectionRK4, SampleT, DeleteErrorParticle], margin=0.01, runtime=40 * 600.0, n=400)
+    assert len(p) < 400
+
+
+def test_boolean_algebra_and_numpy_functions(gpu):
+    ctx = {"x0": 1.5e4, "y0": 1.0e4}
+    _both([pa.AdvectionRK4, Age, Algebra], context=ctx)
+    _both([pa.AdvectionRK4, Age, Algebra], context=ctx, spatial=np.float64)
+
+
+def test_kernels_that_change_dt_and_displacements(gpu):
+    _both([pa.AdvectionRK4, Age, ChangeDt])
+    _both([Kick, pa.AdvectionEE], context={"kick": 0.05})
+    _both([Kick, pa.AdvectionEE], context={"kick": np.float32(0.05)}, spatial=np.float64)
+
+
+def test_error_stop_with_an_accumulating_user_kernel(gpu):
+    """Without a recovery kernel the run raises after the iteration of the first escape (kernel.py:236-245); the accumulated age of every
+    particle is that of the iterations it made -- the compiled list restarts from the device checkpoint rather than repeating the launch
+    on top of Variables it already updated in place."""
+    p, d = _both([pa.AdvectionRK4, Age], margin=0.01, runtime=40 * 600.0, n=400, expect_error="FieldOutOfBoundError")
+    assert p._last_stats["reran"] >= 1 and np.all(d["age"] <= d["t"].max() + 1)
+
+
+def test_what_is_not_elementwise_runs_on_the_host(gpu):
+    p, d = _run([pa.AdvectionRK4, NotElementwise], jit=True)
+    assert p._kernel.user_program is None and "If" in p._kernel.jit_report and p._last_stats.get("hosted")
+    assert np.all(d["acc"] > 0)
+
+    def Closure(particles, fieldset):  # defined inside a function, with a free variable: still translatable
+        particles.acc += scale * particles.dt
+
+    scale = 0.5
+    p, d = _both([Closure, pa.AdvectionEE])
+    assert np.allclose(d["acc"][d["t"] == d["t"].max()].max(), 0.5 * 12 * 600.0)
+
+    P = pa.Particle.add_variable(pa.Variable("count", dtype=np.int32, initial=0))
+
+    def CountSteps(particles, fieldset):
+        particles.count += 1
+
+    fs = _fieldset()
+    pset = pa.ParticleSet(fs, pclass=P, x=[2.0e4], y=[1.5e4])
+    pset.execute([pa.AdvectionRK4, CountSteps], runtime=3000.0, dt=600.0)
+    assert pset._kernel.user_program is None and "int32" in pset._kernel.jit_report and pset.count[0] == 5
+
+
+def test_compiled_list_with_output_file(gpu, tmp_path):
+    """The Variables a compiled kernel writes are device columns: the ParticleFile gets their values at every output time."""
+    outs = []
+    for jit in (True, False):
+        path = tmp_path / f"out_{int(jit)}.parquet"
+        pf = pa.ParticleFile(path, outputdt=1800.0)
+        p, d = _run([pa.AdvectionRK4, Age, SampleT], jit=jit, output=pf, n=50)
+        pf.close()
+        outs.append(pa.read_particlefile(path).sort_values(["t", "particle_id"]).reset_index(drop=True))
+    a, b = outs
+    assert list(a.columns) == list(b.columns) and len(a) == len(b) and {"age", "temp"} <= set(a.columns)
+    for c in a.columns:
+        assert np.array_equal(a[c].values, b[c].values), c
+    assert a["age"].max() > 0
