@@ -34,7 +34,7 @@ import numpy as np
 from . import _hip
 from .statuscodes import StatusCode
 
-__all__ = ["NotTranslatable", "translate", "UserProgram", "jit_enabled"]
+__all__ = ["NotTranslatable", "translate", "UserProgram", "jit_enabled", "compile_kernel_list"]
 
 PK_KERNEL_USER0, PK_MAX_USER_KERNELS = 40, 8
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
@@ -651,6 +651,48 @@ class UserProgram:
         if self._lib is None:
             self._lib = C.CDLL(self.build())
         return C.cast(self._lib.pk_user_launch, C.c_void_p).value
+
+
+def compile_kernel_list(functions, builtin_id, pclass, fieldset, engine, samples=None, device_variables=()):
+    """A kernel list with Python functions in it -> (kernel ids, UserProgram, device Variable names), or NotTranslatable.
+
+    functions: the list as the user wrote it; builtin_id(f) -> PK_KERNEL_* id or None for a Python function to translate; pclass: the
+    particle class (``.variables`` with ``.name`` / ``.dtype``); fieldset: the parcels_amd.FieldSet on ``engine``; samples /
+    device_variables: what SampleField tokens of the list already claimed."""
+    funcs = [f for f in functions if builtin_id(f) is None]
+    if not funcs:
+        raise NotTranslatable("no Python function in the list")
+    if len(funcs) > PK_MAX_USER_KERNELS:
+        raise NotTranslatable(f"more than {PK_MAX_USER_KERNELS} Python kernels in one list")
+    names = {v.name: v for v in pclass.variables}
+    dev_vars = list(device_variables)
+    for f in funcs:
+        for vn in candidate_variables(f, pclass):
+            if np.dtype(names[vn].dtype) not in (np.dtype(np.float32), np.dtype(np.float64)):
+                raise NotTranslatable(f"Variable '{vn}' is {np.dtype(names[vn].dtype)}: device columns are float32 / float64")
+            if vn not in dev_vars:
+                dev_vars.append(vn)
+    if len(dev_vars) > 4:
+        raise NotTranslatable("more than 4 user Variables touched by device kernels (PK_MAX_EXTRA)")
+    var_slot = {vn: (k, "f32" if np.dtype(names[vn].dtype) == np.float32 else "f64") for k, vn in enumerate(dev_vars)}
+    next_dt_f32 = "next_dt" in names and np.dtype(names["next_dt"].dtype) != np.float64
+    sources, ids, j = [], [], 0
+    for f in functions:
+        kid = builtin_id(f)
+        if kid is None:
+            sources.append(translate(f, pclass, fieldset, var_slot, engine.field_ids, next_dt_f32, slot_prefix=f"k{j}_"))
+            kid = PK_KERNEL_USER0 + j
+            j += 1
+        ids.append(kid)
+    # the variant of the kernel-list interpreter this FieldSet runs (the kernel ids do not matter for it: DoNothing stands in)
+    prm = engine.make_params([i if i < PK_KERNEL_USER0 else 23 for i in ids], endtime=0.0, dt0=1.0, context=fieldset.context, samples=samples or {})
+    key, lds, typed = C.c_int32(), C.c_int32(), C.c_int32()
+    engine.ctx.check(engine.lib.pk_generic_variant(engine.ctx.handle, C.byref(prm), C.byref(key), C.byref(lds), C.byref(typed)), "pk_generic_variant")
+    if typed.value:
+        raise NotTranslatable("float32 coordinate arrays (NumPy dtype propagation of the typed program)")
+    prog = UserProgram(sources, key.value, lds.value)
+    prog.launcher()  # builds (or finds in the cache) and loads the module
+    return ids, prog, dev_vars
 
 
 _ = (StatusCode, _hip)  # (re-exported names user kernels commonly reference; keeps linters quiet)

@@ -146,46 +146,15 @@ class Kernel:
     def _try_jit(self, pset):
         """Compile the Python functions of the list into the device program (parcels_amd/jit.py).  On success the list is a pure
         device list: user ids PK_KERNEL_USER0 + j, the Variables the functions touch bound as device columns."""
-        from . import _hip, jit
-        import ctypes as C
+        from . import jit
 
         self._jit_tried = True
         if not jit.jit_enabled():
             self.jit_report = "PARCELS_AMD_JIT=0"
             return
         try:
-            engine = pset._engine()
-            funcs = [f for f in self._kernels if _k.kernel_id(f) is None]
-            if len(funcs) > jit.PK_MAX_USER_KERNELS:
-                raise jit.NotTranslatable(f"more than {jit.PK_MAX_USER_KERNELS} Python kernels in one list")
-            names = {v.name: v for v in self._pclass.variables}
-            dev_vars = list(self.device_variables)
-            for f in funcs:
-                for vn in jit.candidate_variables(f, self._pclass):
-                    if np.dtype(names[vn].dtype) not in (np.dtype(np.float32), np.dtype(np.float64)):
-                        raise jit.NotTranslatable(f"Variable '{vn}' is {np.dtype(names[vn].dtype)}: device columns are float32 / float64")
-                    if vn not in dev_vars:
-                        dev_vars.append(vn)
-            if len(dev_vars) > 4:
-                raise jit.NotTranslatable("more than 4 user Variables touched by device kernels (PK_MAX_EXTRA)")
-            var_slot = {vn: (k, "f32" if np.dtype(names[vn].dtype) == np.float32 else "f64") for k, vn in enumerate(dev_vars)}
-            next_dt_f32 = "next_dt" in names and np.dtype(names["next_dt"].dtype) != np.float64
-            sources, ids, j = [], [], 0
-            for f in self._kernels:
-                kid = _k.kernel_id(f)
-                if kid is None:
-                    sources.append(jit.translate(f, self._pclass, self._fieldset, var_slot, engine.field_ids, next_dt_f32, slot_prefix=f"k{j}_"))
-                    kid = jit.PK_KERNEL_USER0 + j
-                    j += 1
-                ids.append(kid)
-            prm = engine.make_params([i if i < jit.PK_KERNEL_USER0 else 23 for i in ids], endtime=0.0, dt0=1.0, context=self._fieldset.context,
-                                     samples=self.samples)  # (variant of the program: the kernel ids do not matter, DoNothing stands in)
-            key, lds, typed = C.c_int32(), C.c_int32(), C.c_int32()
-            engine.ctx.check(engine.lib.pk_generic_variant(engine.ctx.handle, C.byref(prm), C.byref(key), C.byref(lds), C.byref(typed)), "pk_generic_variant")
-            if typed.value:
-                raise jit.NotTranslatable("float32 coordinate arrays (NumPy dtype propagation of the typed program)")
-            prog = jit.UserProgram(sources, key.value, lds.value)
-            prog.launcher()  # builds (or finds in the cache) and loads the module
+            ids, prog, dev_vars = jit.compile_kernel_list(self._kernels, _k.kernel_id, self._pclass, self._fieldset, pset._engine(),
+                                                          samples=self.samples, device_variables=self.device_variables)
         except jit.NotTranslatable as e:
             self.jit_report = str(e)
             return
@@ -193,7 +162,7 @@ class Kernel:
         self.kernel_ids = ids
         self.device_variables = dev_vars
         self.host_functions = []
-        self.jit_report = f"compiled {[s.name for s in sources]} into {prog.path}"
+        self.jit_report = f"compiled {[f.__name__ for f in self._kernels if _k.kernel_id(f) is None]} into {prog.path}"
 
     def launch(self, pset, endtime, dt, have_guess0=0):
         """Device part of Kernel.execute: advance the BOUND, device-resident particle columns to ``endtime``.

@@ -11,9 +11,10 @@ tested -- with or without the reference installed):
 * ``HipBackend(fieldset)``: owns the device copy; ``execute(pset, kernel_functions, endtime, dt)`` binds the reference's SoA dict
   ``pset._data`` (particle.py:182-222 -- same column names and dtypes as ``pk_particles_desc``), runs the fused launch with the
   reference's stop-at-first-error semantics and copies the columns back;
-* ``install(kernel_module)``: wraps ``Kernel.execute`` so that kernel lists made of built-ins only (matched by function name:
-  AdvectionRK4, AdvectionRK4_3D, AdvectionRK45, AdvectionDiffusionM1, ...) go to the GPU and everything else -- a user-written
-  Python kernel, an unstructured grid, an interpolator without a device form -- falls through to the untouched NumPy loop.
+* ``install(kernel_module)``: wraps ``Kernel.execute`` so that kernel lists made of built-ins (matched by function name: AdvectionRK4,
+  AdvectionRK4_3D, AdvectionRK45, AdvectionDiffusionM1, ...) and of elementwise user-written kernels (compiled into the launch by
+  parcels_amd/jit.py) go to the GPU and everything else -- any other Python kernel, an unstructured grid, an interpolator without a
+  device form -- falls through to the untouched NumPy loop.
 
 tests/test_reference_bridge.py runs ``fieldset_from_reference`` and the installed dispatch against the reference's real ``XGrid`` /
 ``Field`` / ``VectorField`` / ``ParticleSet`` / ``Kernel`` classes (CPU, when /root/reference is present) and the same backend end to
@@ -142,6 +143,8 @@ class HipBackend:
         self.device, self.nslots, self.seed = int(device), nslots, int(seed)
         self._engine = None
         self.last_stats = None
+        self._plans = {}
+        self.jit_report = None
 
     @property
     def engine(self):
@@ -150,19 +153,44 @@ class HipBackend:
         return self._engine
 
     @staticmethod
-    def kernel_ids(kernel_functions):
-        """PK_KERNEL_* ids of a list of reference kernel functions, or None when one of them has no device form."""
-        ids = []
-        for f in kernel_functions:
-            mine = getattr(_k, getattr(f, "__name__", ""), None)
-            kid = _k.kernel_id(mine) if mine is not None and getattr(mine, "_pk_sample", None) is None else None
-            if kid is None:
-                return None
-            ids.append(kid)
-        return ids
+    def builtin_id(f):
+        """PK_KERNEL_* id of a reference kernel function (matched by name), None for anything else."""
+        mine = getattr(_k, getattr(f, "__name__", ""), None)
+        return _k.kernel_id(mine) if mine is not None and getattr(mine, "_pk_sample", None) is None else None
+
+    @classmethod
+    def kernel_ids(cls, kernel_functions):
+        """Ids of a list made of built-ins only, or None when it holds a function without a built-in device form."""
+        ids = [cls.builtin_id(f) for f in kernel_functions]
+        return None if any(i is None for i in ids) else ids
+
+    def plan(self, kernel_functions, pclass=None):
+        """(kernel ids, user program or None, device Variable names) for a kernel list, or None when the list stays on the reference's
+        NumPy loop.  User-written functions are compiled into the launch when they are elementwise (parcels_amd/jit.py; needs the
+        particle class for the Variables' dtypes)."""
+        for k, v in dict(self.ref_fieldset.context).items():  # constants are compiled in: the plan is per context
+            self.fieldset.context[k] = v
+        key = (tuple(kernel_functions), repr(sorted(self.fieldset.context.items(), key=lambda kv: kv[0])))
+        if key in self._plans:
+            return self._plans[key]
+        ids = self.kernel_ids(kernel_functions)
+        plan = (ids, None, []) if ids is not None else None
+        if ids is None and pclass is not None:
+            from . import jit
+
+            if jit.jit_enabled():
+                try:
+                    plan = jit.compile_kernel_list(list(kernel_functions), self.builtin_id, pclass, self.fieldset, self.engine)
+                except jit.NotTranslatable as e:
+                    self.jit_report = str(e)
+                except Exception as e:  # a failing compilation must never break a run the NumPy loop can do
+                    self.jit_report = f"{type(e).__name__}: {e}"
+        self._plans[key] = plan
+        return plan
 
     def supports(self, kernel_functions, pset=None) -> bool:
-        if self.kernel_ids(kernel_functions) is None:
+        plan = self.plan(kernel_functions, getattr(pset, "_pclass", None))
+        if plan is None:
             return False
         names = {getattr(f, "__name__", "") for f in kernel_functions}
         ctx = self.ref_fieldset.context
@@ -181,9 +209,10 @@ class HipBackend:
     def execute(self, pset, kernel_functions, endtime: float, dt: float) -> dict:
         """kernel.py:188-232 for the whole batch on the device: ``pset._data`` in, ``pset._data`` out (states included; deleting and
         raising -- kernel.py:233-245 -- stay with the caller, which has the reference's own code for both)."""
-        ids = self.kernel_ids(kernel_functions)
-        if ids is None:
+        plan = self.plan(kernel_functions, getattr(pset, "_pclass", None))
+        if plan is None:
             raise UnsupportedByDevice("a kernel of the list has no device form")
+        ids, program, dev_vars = plan
         data = pset._data
         n = len(data["t"])
         if n == 0:
@@ -191,13 +220,14 @@ class HipBackend:
         for k, v in dict(self.ref_fieldset.context).items():  # RK45 defaults arrive with Kernel.__init__, after the backend was built
             self.fieldset.context[k] = v
         eng = self.engine
-        eng.device_variables = []
+        eng.device_variables = list(dev_vars)
+        eng.set_user_program(program)
         eng.bind_particles(data)
         eng.h2d()
         sign = 1 if dt > 0 else -1
         t_start = float(np.nanmin(data["t"]) if sign > 0 else np.nanmax(data["t"]))
         st = eng.execute(ids, endtime=float(endtime), dt0=float(dt), context=self.fieldset.context, seed=self.seed,
-                         have_guess0=self._have_guess0(data), sort_by_cell=0, t_start=t_start)
+                         have_guess0=self._have_guess0(data), sort_by_cell=0, t_start=t_start, in_place_variables=program is not None)
         eng.d2h()
         self.last_stats = st
         return st

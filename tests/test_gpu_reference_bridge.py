@@ -86,3 +86,39 @@ def test_backend_declines_what_has_no_device_form(gpu):
     ux = NS(fields={"U": NS(name="U", grid=NS(), data=None, interp_method=None)}, gridset=[], context={})
     with pytest.raises(UnsupportedByDevice, match="not a structured grid"):
         fieldset_from_reference(ux)
+
+
+def Ageing(particles, fieldset):  # a kernel a user of the reference would write (module level: the translator reads its source)
+    particles.age += particles.dt
+    particles.state = np.where(particles.age > fieldset.max_age, 30, particles.state)  # StatusCode.Delete
+
+
+def test_backend_compiles_the_users_kernels_into_the_launch(gpu):
+    """A list with a user-written elementwise kernel goes to the GPU as ONE launch too (parcels_amd/jit.py): same result as
+    parcels_amd's own ParticleSet running the same list, and the particles older than max_age are gone."""
+    import parcels_amd as pa
+    from parcels_amd.reference_bridge import HipBackend
+
+    case, out, err = load_golden("agrid_sph_rk4_f64")
+    ref_fs = standin_fieldset(case)
+    ref_fs.context["max_age"] = 20 * 3600.0
+    backend = HipBackend(ref_fs)
+    fs = build_fieldset(case)
+    fs.add_context("max_age", 20 * 3600.0)
+    P = pa.get_default_particle(np.float64).add_variable(pa.Variable("age", dtype=np.float32, initial=0))
+    mine = pa.ParticleSet(fs, pclass=P, x=np.asarray(case["x"]), y=np.asarray(case["y"]), z=case.get("z"), t=np.zeros(len(case["x"])))
+    pset = _Pset({k: np.array(v) for k, v in mine._data.items()})
+    pset._pclass = P  # (the reference's ParticleSet has it under the same name)
+    dt, endtime = float(case["dt"]), float(case["runtime"])
+    pset._data["dt"][:] = dt
+    funcs = [_function("AdvectionRK4"), Ageing]
+    assert backend.supports(funcs, pset), backend.jit_report
+    st = backend.execute(pset, funcs, endtime, dt)
+    assert st["launches"] == 1 and st["program"] == 2
+    mine.execute([pa.AdvectionRK4, Ageing], runtime=endtime, dt=dt)
+    gone = pset._data["state"] == int(pa.StatusCode.Delete)
+    assert gone.any() and not gone.all() or gone.all() or not gone.any()
+    pset.remove_indices(np.flatnonzero(gone))
+    for k in ("particle_id", "t", "x", "y", "z", "state", "age", "ei"):
+        assert np.array_equal(pset._data[k], mine._data[k]), k
+    assert np.all(pset._data["age"] <= 20 * 3600.0 + dt)

@@ -53,10 +53,13 @@ class _RecordingEngine:
     def h2d(self):
         pass
 
+    def set_user_program(self, program):
+        assert program is None  # built-in lists carry no compiled user kernels
+
     def d2h(self):
         pass
 
-    def execute(self, ids, *, endtime, dt0, context, seed, have_guess0, sort_by_cell, t_start):
+    def execute(self, ids, *, endtime, dt0, context, seed, have_guess0, sort_by_cell, t_start, in_place_variables=False):
         self.calls.append(dict(ids=list(ids), endtime=endtime, dt0=dt0, t_start=t_start, n=len(self.data["t"])))
         self.data["t"][:] = endtime
         self.data["state"][:] = 2  # StatusCode.EndofLoop
