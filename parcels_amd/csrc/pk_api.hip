@@ -95,7 +95,8 @@ struct pk_ctx {
     bool rerun_valid = false;
     pk_exec_params rerun_prm{};
     // launcher of the run-time compiled kernel-list interpreter that carries the user kernels (pk_set_user_program)
-    void (*user_launch)(const void*, int32_t, int32_t, uint64_t, void*) = nullptr;
+    void (*user_launch)(const void*, int32_t, int32_t, int32_t, uint64_t, void*) = nullptr;
+    int32_t user_flags = 0;
     // pk_particles_checkpoint: one packed device copy of every column (+ the row permutation of the cell sort)
     char* d_chk = nullptr;
     size_t chk_bytes = 0;
@@ -1892,6 +1893,24 @@ static int32_t fill_fastc(pk_ctx* ctx, const pk_exec_params* prm, KArgs& a, bool
     return 0;
 }
 
+// A kernel list WITH user kernels may still run in the dedicated A-grid kernel (the module carries an instantiation with the user kernels
+// as side kernels, pk_kernels.h: side_kernel): exactly one AdvectionRK4 / AdvectionRK4_3D anywhere in the list, everything else a
+// sampling-free recovery kernel or a user kernel, and a module whose user kernels sample no field.  -1: no; 0 / 1: yes, 2-D / 3-D.
+static int user_fast_shape(const pk_exec_params* prm, int32_t user_flags) {
+    if (!(user_flags & PK_USER_NOSAMPLE) || prm->body_only) return -1;
+    int nadv = 0, d3 = 0;
+    for (int k = 0; k < prm->nk; k++) {
+        const int id = prm->kernels[k];
+        if (id == PK_KERNEL_ADVECTION_RK4 || id == PK_KERNEL_ADVECTION_RK4_3D) {
+            nadv++;
+            d3 = id == PK_KERNEL_ADVECTION_RK4_3D;
+        } else if (!(id == PK_KERNEL_DELETE_ON_ERROR || id == PK_KERNEL_DELETE_OUT_OF_BOUNDS || (id >= PK_KERNEL_USER0 && id < PK_KERNEL_USER0 + PK_MAX_USER_KERNELS))) {
+            return -1;
+        }
+    }
+    return nadv == 1 ? d3 : -1;
+}
+
 int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
     if (!ctx || !prm) return -2;
     if (!ctx->bound) return ctx->fail("no particles bound");
@@ -1963,7 +1982,13 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
         if (has_user && prog != PROG_GENERIC) return ctx->fail("user kernels run in the plain kernel-list interpreter only (float32 coordinate arrays are not supported)");
         bool fast_a = false, fast_c = false;  // a.fast / a.fastc share storage: at most one is filled
         size_t cgrid_lds = 0;
-        if ((prog == PROG_RK4 || prog == PROG_RK4_3D) && !curv) {
+        const int ufast = (has_user && use_lds && !curv) ? user_fast_shape(prm, ctx->user_flags) : -1;
+        if (ufast >= 0) {
+            rc = fill_fast(ctx, prm, a, ufast == 1);
+            if (rc) return rc;
+            fast_a = a.fast.ok != 0;
+            if (fast_a) prog = ufast ? PROG_RK4_3D : PROG_RK4;
+        } else if ((prog == PROG_RK4 || prog == PROG_RK4_3D) && !curv) {
             rc = fill_fast(ctx, prm, a, prog == PROG_RK4_3D);
             if (rc) return rc;
             fast_a = a.fast.ok != 0;
@@ -2008,7 +2033,8 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
         PK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->compute));
         const size_t fast_lds = fast_a ? (size_t)a.fast.lds_n * 2 * sizeof(double) : 0;
         const int pf32 = ctx->dev.spatial_f32;
-        if (fast_a && prog == PROG_RK4) launch_fast<PROG_RK4>(field_f32, pf32, a, grid, fast_lds, ctx->compute);
+        if (has_user && fast_a) ctx->user_launch(&a, prog == PROG_RK4_3D ? 2 : 1, field_f32 * 2 + pf32, 1, (uint64_t)fast_lds, (void*)ctx->compute);
+        else if (fast_a && prog == PROG_RK4) launch_fast<PROG_RK4>(field_f32, pf32, a, grid, fast_lds, ctx->compute);
         else if (fast_a && prog == PROG_RK4_3D) launch_fast<PROG_RK4_3D>(field_f32, pf32, a, grid, fast_lds, ctx->compute);
         else if (fast_c && prog == PROG_RK45) launch_cgrid_rk45(field_f32, pf32, a, n, cgrid_lds, ctx->compute);
         else if (fast_c && prog == PROG_M1) launch_cgrid_m1(field_f32, pf32, a, n, cgrid_lds, ctx->compute);
@@ -2022,7 +2048,7 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
             default:
                 if (has_user) {
                     const int ik = prm->interp_uv >= 2 ? 2 : prm->interp_uv;
-                    ctx->user_launch(&a, (field_f32 ? 6 : 0) + (curv ? 3 : 0) + ik, use_lds, (uint64_t)lds_bytes, (void*)ctx->compute);
+                    ctx->user_launch(&a, 0, (field_f32 ? 6 : 0) + (curv ? 3 : 0) + ik, use_lds, (uint64_t)lds_bytes, (void*)ctx->compute);
                 } else {
                     launch_program<PROG_GENERIC>(field_f32, curv, prm->interp_uv, use_lds, a, grid, lds_bytes, ctx->compute);
                 }
@@ -2084,8 +2110,8 @@ int32_t pk_execute_end(pk_ctx* ctx, pk_exec_stats* stats) {
     return 0;
 }
 
-int32_t pk_generic_variant(pk_ctx* ctx, const pk_exec_params* prm, int32_t* key, int32_t* lds, int32_t* typed) {
-    if (!ctx || !prm || !key || !lds || !typed) return -2;
+int32_t pk_generic_variant(pk_ctx* ctx, const pk_exec_params* prm, int32_t* key, int32_t* lds, int32_t* typed, int32_t* fast) {
+    if (!ctx || !prm || !key || !lds || !typed || !fast) return -2;
     KArgs a;
     size_t lds_bytes = 0;
     int use_lds = 0;
@@ -2095,12 +2121,20 @@ int32_t pk_generic_variant(pk_ctx* ctx, const pk_exec_params* prm, int32_t* key,
     *key = (ctx->fields[prm->fU].d.dtype == PK_F32 ? 6 : 0) + (ctx->grids[a.main_grid].d.kind == 1 ? 3 : 0) + ik;
     *lds = use_lds;
     *typed = ctx_is_typed(ctx) ? 1 : 0;
+    *fast = 0;
+    const int ufast = (use_lds && !*typed && ctx->grids[a.main_grid].d.kind != 1) ? user_fast_shape(prm, PK_USER_NOSAMPLE) : -1;
+    if (ufast >= 0) {
+        const int32_t rc2 = fill_fast(ctx, prm, a, ufast == 1);
+        if (rc2) return rc2;
+        if (a.fast.ok) *fast = 1 + ufast;
+    }
     return 0;
 }
-int32_t pk_set_user_program(pk_ctx* ctx, void* launcher) {
+int32_t pk_set_user_program(pk_ctx* ctx, void* launcher, int32_t flags) {
     if (!ctx) return -2;
     if (ctx->in_flight) return ctx->fail("pk_set_user_program: a launch is in flight (call pk_execute_end)");
-    ctx->user_launch = (void (*)(const void*, int32_t, int32_t, uint64_t, void*))launcher;
+    ctx->user_launch = (void (*)(const void*, int32_t, int32_t, int32_t, uint64_t, void*))launcher;
+    ctx->user_flags = launcher ? flags : 0;
     return 0;
 }
 

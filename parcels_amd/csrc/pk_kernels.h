@@ -598,6 +598,41 @@ __global__ void __launch_bounds__(wg_size(KIND, LDS), (KIND == 1 || INTERP != 0)
     }
 }
 
+#ifdef PK_USER_KERNELS
+// A kernel of the list that rides along in a DEDICATED kernel (pk_fast_agrid.h / pk_fast_cgrid.h): a sampling-free recovery kernel or a
+// user kernel that samples no field (the host checks: pk_set_user_program flag PK_USER_NOSAMPLE), so its stage machine ends in stage 0.
+PK_DEV void side_kernel(const KArgs& a, int kid, int kslot, int& state, bool pf, int64_t row, double& t, double& z, double& y, double& x,
+                        double& dz, double& dy, double& dx, double& dt) {
+    if (kid == PK_KERNEL_DELETE_ON_ERROR) {
+        if (state >= PK_ERROR) state = PK_DELETE;
+        return;
+    }
+    if (kid == PK_KERNEL_DELETE_OUT_OF_BOUNDS) {
+        if (state == PK_ERROROUTOFBOUNDS || state == PK_ERRORTHROUGHSURFACE) state = PK_DELETE;
+        return;
+    }
+    PState p;
+    p.t = t; p.z = z; p.y = y; p.x = x; p.dz = dz; p.dy = dy; p.dx = dx; p.dt = dt;
+    p.next_dt = 0.0;  // (kernels that touch next_dt do not ride here)
+    p.id = a.p.particle_id[row];
+    PCtx c;
+    c.state = state;
+    c.pf = pf;
+    c.row = row;
+    c.hz = c.hy = c.hx = c.ht = 0;
+    c.hyx_valid = false;
+    c.first_eval = 0u;
+    c.u32 = c.v32 = c.oob = false;
+    c.ei0 = c.ei1 = c.ei2 = c.ei3 = 0;
+    KLocal L;
+    Request rq;
+    (void)user_prepare(a, kid - PK_KERNEL_USER0, 0, kslot, c, p, L, rq);
+    t = p.t; z = p.z; y = p.y; x = p.x; dz = p.dz; dy = p.dy; dx = p.dx; dt = p.dt;
+    state = c.state;
+}
+PK_DEV bool is_rk4_id(int kid) { return kid == PK_KERNEL_ADVECTION_RK4 || kid == PK_KERNEL_ADVECTION_RK4_3D; }
+#endif
+
 // ---- the headline kernel: AdvectionRK4 / AdvectionRK4_3D on a rectilinear A-grid with float64 coordinates -----------------
 // Same step loop as advect_kernel (Kernel.execute, kernel.py:174-247) with the Runge-Kutta stages of _advection.py:42-75 written
 // out around ONE evaluation site (pk_fast_agrid.h) instead of the prepare / consume stage machine: fewer loop-carried values,
@@ -656,6 +691,16 @@ __global__ void __launch_bounds__(256, PK_MIN_WAVES_FAST) advect_fast_kernel(con
                 it++;
                 pdt = dtc;
                 attempts++;
+#ifdef PK_USER_KERNELS
+                // a list with user kernels: [kernels before the advection kernel ..., AdvectionRK4(_3D), kernels after it ...]
+                int adv = 0;
+                for (; adv < prm.nk && !is_rk4_id(prm.kernels[adv]); adv++) {
+                    attempts++;
+                    side_kernel(a, prm.kernels[adv], adv, c.state, pf, row(), pt, pz, py, px, pdz, pdy, pdx, pdt);
+                }
+#else
+                constexpr int adv = 0;
+#endif
                 // AdvectionRK4(_3D), _advection.py:42-75: (u1 + 2*u2 + 2*u3 + u4) summed left to right
                 double su = 0.0, sv = 0.0, sw = 0.0, lu = 0.0, lv = 0.0, lw = 0.0;
 #pragma unroll 1
@@ -679,9 +724,15 @@ __global__ void __launch_bounds__(256, PK_MIN_WAVES_FAST) advect_fast_kernel(con
                 pdx = pstore(pf, pdx + div_by_recip(su, 6.0, sixth) * pdt);
                 pdy = pstore(pf, pdy + div_by_recip(sv, 6.0, sixth) * pdt);
                 if (D3) pdz = pstore(pf, pdz + div_by_recip(sw, 6.0, sixth) * pdt);
-                for (int k = 1; k < prm.nk; k++) {  // the sampling-free recovery kernels that may follow (Delete*)
+                for (int k = adv + 1; k < prm.nk; k++) {  // the sampling-free recovery kernels that may follow (Delete*)
                     const int kid = prm.kernels[k];
                     attempts++;
+#ifdef PK_USER_KERNELS
+                    if (kid >= PK_KERNEL_USER0) {
+                        side_kernel(a, kid, k, c.state, pf, row(), pt, pz, py, px, pdz, pdy, pdx, pdt);
+                        continue;
+                    }
+#endif
                     if (kid == PK_KERNEL_DELETE_ON_ERROR) {
                         if (c.state >= PK_ERROR) c.state = PK_DELETE;
                     } else if (c.state == PK_ERROROUTOFBOUNDS || c.state == PK_ERRORTHROUGHSURFACE) {

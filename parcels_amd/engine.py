@@ -374,9 +374,11 @@ class DeviceEngine:
             a = data[name]
             if not a.flags["C_CONTIGUOUS"]:
                 a = data[name] = np.ascontiguousarray(a)
-            if a.dtype not in (np.float32, np.float64) or a.shape != (n,):
-                raise TypeError(f"device Variable '{name}' must be a float32 / float64 column of length n")
-            d.extra_dtype[k] = _hip.PK_F32 if a.dtype == np.float32 else _hip.PK_F64
+            if a.dtype not in (np.float32, np.float64, np.int32, np.int64) or a.shape != (n,):
+                raise TypeError(f"device Variable '{name}' must be a float32 / float64 / int32 / int64 column of length n")
+            # the library moves these columns as opaque 4- or 8-byte elements (only PK_KERNEL_SAMPLE_FIELD interprets its targets, and
+            # Kernel restricts those to float Variables): integer Variables of compiled user kernels travel under the float code of their size
+            d.extra_dtype[k] = _hip.PK_F32 if a.dtype.itemsize == 4 else _hip.PK_F64
             d.extra[k] = a.ctypes.data
         return d
 
@@ -438,7 +440,7 @@ class DeviceEngine:
             mask |= self._column_bit(name)
         self._snap_extra = list(self.device_variables)
         self.ctx.check(self.lib.pk_particles_snapshot_begin(self.ctx.handle, mask, int(slot)), "pk_particles_snapshot_begin")
-        self._snap_dtypes = {k: self._bound[k].dtype for k in self._bound if k in _hip.COLUMN_BITS}
+        self._snap_dtypes = {k: self._bound[k].dtype for k in self._bound if k in _hip.COLUMN_BITS or k in self.device_variables}
 
     def snapshot_wait(self, slot: int) -> dict:
         """Block until snapshot ``slot`` has landed; NumPy views of its pinned columns (valid until the slot is reused).  Callable
@@ -471,6 +473,9 @@ class DeviceEngine:
             if not ptr:
                 continue
             dt = np.dtype(np.float32 if d.extra_dtype[k] == _hip.PK_F32 else np.float64)
+            want = self._snap_dtypes.get(name)
+            if want is not None and want.itemsize == dt.itemsize:
+                dt = want  # (an integer Variable: same bytes)
             out[name] = np.frombuffer((C.c_char * (n * dt.itemsize)).from_address(ptr), dtype=dt, count=n)
         return out
 
@@ -521,7 +526,8 @@ class DeviceEngine:
         cur = getattr(self, "_user_program", None)
         if program is cur:
             return
-        self.ctx.check(self.lib.pk_set_user_program(self.ctx.handle, C.c_void_p(program.launcher() if program is not None else None)), "pk_set_user_program")
+        self.ctx.check(self.lib.pk_set_user_program(self.ctx.handle, C.c_void_p(program.launcher() if program is not None else None),
+                                                    int(program.flags) if program is not None else 0), "pk_set_user_program")
         self._user_program = program
 
     def execute(self, kernel_ids, *, endtime, dt0, context=None, seed=0, have_guess0=0, sort_by_cell=0, t_start=None, samples=None,

@@ -9,7 +9,7 @@ statements up to a field sample, the sample, the statements after it), compiles 
 variant the FieldSet needs (``hipcc``, ~5 s, cached on disk by content hash) and registers the module with the library
 (``pk_set_user_program``); the kernel list then runs as ONE launch, built-in and user kernels alike, the particle columns never leave
 the GPU.  Anything outside the class (``NotTranslatable``: control flow, reductions, ``len(particles)``, random numbers, transcendental
-functions, integer Variables, more than PK_MAX_EXTRA touched Variables, ...) keeps running through ``hostkernels.py`` -- the
+functions, more than PK_MAX_EXTRA touched Variables, ...) keeps running through ``hostkernels.py`` -- the
 reference's loop on the host columns.
 
 NumPy's semantics are reproduced statically, per expression: every sub-expression carries its NumPy dtype (NEP 50: Python scalars
@@ -419,6 +419,16 @@ class _Translator(ast.NodeVisitor):
             cmp_ = "<=" if name == "minimum" else ">="
             nan = f" || {ta} != {ta}" if ty[0] == "f" else ""
             return _V(f"(({ta} {cmp_} {tb}{nan}) ? {ta} : {tb})", ty, array=arr)
+        if name == "clip" and len(args) == 3:  # np.clip(a, lo, hi) == np.minimum(np.maximum(a, lo), hi) (the ufunc's definition)
+            inner = ast.Call(func=ast.Attribute(value=node.func.value, attr="maximum", ctx=ast.Load()), args=[node.args[0], node.args[1]], keywords=[])
+            outer = ast.Call(func=ast.Attribute(value=node.func.value, attr="minimum", ctx=ast.Load()), args=[inner, node.args[2]], keywords=[])
+            return self.e_Call(outer)
+        if name in ("logical_and", "logical_or") and len(args) == 2:
+            ca, cb = (a.code if a.ty in ("b", "wb") else f"(({a.code}) != 0)" for a in args)
+            return _V(f"(({ca}) {'&&' if name == 'logical_and' else '||'} ({cb}))", "b", array=arr)
+        if name == "logical_not" and len(args) == 1:
+            a = args[0]
+            return _V(f"(!({a.code if a.ty in ('b', 'wb') else f'(({a.code}) != 0)'}))", "b", array=arr)
         if name in ("isnan", "isfinite") and len(args) == 1:
             v = args[0]
             ty = _strong(v.ty)
@@ -585,9 +595,14 @@ PK_DEV bool user_prepare(const KArgs& a, int uk, int stage, int kslot, PCtx& c, 
     }}
 }}
 }}  // namespace pk
-extern "C" void pk_user_launch(const void* kargs, int32_t key, int32_t lds, uint64_t lds_bytes, void* stream) {{
+extern "C" void pk_user_launch(const void* kargs, int32_t prog, int32_t key, int32_t lds, uint64_t lds_bytes, void* stream) {{
     using namespace pk;
     const KArgs& a = *(const KArgs*)kargs;
+    if (prog != 0) {{  // the dedicated A-grid kernel with the user kernels riding along (pk_kernels.h: side_kernel)
+{fast_launch}
+        fprintf(stderr, "parcels_amd user program: no dedicated kernel (%d, %d) in this module\\n", prog, key);
+        abort();
+    }}
     if (key != {key} || lds != {lds}) {{
         fprintf(stderr, "parcels_amd user program built for variant (%d, %d), launched as (%d, %d)\\n", {key}, {lds}, key, lds);
         abort();
@@ -617,7 +632,9 @@ def cache_dir() -> str:
 class UserProgram:
     """One compiled module: the kernel-list interpreter of ONE variant with up to PK_MAX_USER_KERNELS user kernels in it."""
 
-    def __init__(self, sources: list[UserKernelSource], key: int, lds: int):
+    def __init__(self, sources: list[UserKernelSource], key: int, lds: int, fast: int = 0, particles_f32: bool = False):
+        """key / lds: the interpreter variant (pk_generic_variant); fast: 1 / 2 = also carry the dedicated A-grid kernel (2-D / 3-D) with
+        the user kernels riding along -- only for modules whose kernels sample no field and leave next_dt alone."""
         if not (1 <= len(sources) <= PK_MAX_USER_KERNELS):
             raise NotTranslatable(f"1 .. {PK_MAX_USER_KERNELS} user kernels per kernel list")
         decl = "\n".join("    " + d for s in sources for d in s.decl) or "    char unused;"
@@ -625,8 +642,17 @@ class UserProgram:
         cases = "\n".join(f"        case {k}: {{\n" + textwrap.indent(s.case_body(), "            ") + "\n        }" for k, s in enumerate(sources))
         ft = "float" if key >= 6 else "double"
         kind, interp = (key % 6) // 3, key % 3
+        nosample = all(len(s.stages) == 1 and "next_dt" not in s.touched for s in sources)
+        self.flags = 1 if (nosample and fast) else 0  # PK_USER_NOSAMPLE: the library may choose the dedicated kernel
+        fast_launch = ""
+        if self.flags:
+            fkey = (2 if key >= 6 else 0) + (1 if particles_f32 else 0)
+            fast_launch = (f"        if (prog == {int(fast)} && key == {fkey}) {{\n"
+                           f"            hipLaunchKernelGGL((advect_fast_kernel<{ft}, {1 if particles_f32 else 0}, {'true' if fast == 2 else 'false'}>), "
+                           f"dim3((unsigned)((a.p.n + 255) / 256)), dim3(256), (size_t)lds_bytes, (hipStream_t)stream, a);\n"
+                           f"            return;\n        }}")
         self.source = _TEMPLATE.format(names=", ".join(s.name for s in sources), decl=decl, cases=cases, key=key, lds=lds, ft=ft, kind=kind,
-                                       interp=interp, ldsb="true" if lds else "false")
+                                       interp=interp, ldsb="true" if lds else "false", fast_launch=fast_launch)
         self.digest = hashlib.sha256((self.source + _csrc_hash()).encode()).hexdigest()[:20]
         self.path = os.path.join(cache_dir(), f"user_{self.digest}.so")
         self._lib = None
@@ -668,13 +694,13 @@ def compile_kernel_list(functions, builtin_id, pclass, fieldset, engine, samples
     dev_vars = list(device_variables)
     for f in funcs:
         for vn in candidate_variables(f, pclass):
-            if np.dtype(names[vn].dtype) not in (np.dtype(np.float32), np.dtype(np.float64)):
-                raise NotTranslatable(f"Variable '{vn}' is {np.dtype(names[vn].dtype)}: device columns are float32 / float64")
+            if np.dtype(names[vn].dtype) not in (np.dtype(np.float32), np.dtype(np.float64), np.dtype(np.int32), np.dtype(np.int64)):
+                raise NotTranslatable(f"Variable '{vn}' is {np.dtype(names[vn].dtype)}: device columns are float32 / float64 / int32 / int64")
             if vn not in dev_vars:
                 dev_vars.append(vn)
     if len(dev_vars) > 4:
         raise NotTranslatable("more than 4 user Variables touched by device kernels (PK_MAX_EXTRA)")
-    var_slot = {vn: (k, "f32" if np.dtype(names[vn].dtype) == np.float32 else "f64") for k, vn in enumerate(dev_vars)}
+    var_slot = {vn: (k, _ty_of_dtype(names[vn].dtype)) for k, vn in enumerate(dev_vars)}
     next_dt_f32 = "next_dt" in names and np.dtype(names["next_dt"].dtype) != np.float64
     sources, ids, j = [], [], 0
     for f in functions:
@@ -684,13 +710,15 @@ def compile_kernel_list(functions, builtin_id, pclass, fieldset, engine, samples
             kid = PK_KERNEL_USER0 + j
             j += 1
         ids.append(kid)
-    # the variant of the kernel-list interpreter this FieldSet runs (the kernel ids do not matter for it: DoNothing stands in)
-    prm = engine.make_params([i if i < PK_KERNEL_USER0 else 23 for i in ids], endtime=0.0, dt0=1.0, context=fieldset.context, samples=samples or {})
-    key, lds, typed = C.c_int32(), C.c_int32(), C.c_int32()
-    engine.ctx.check(engine.lib.pk_generic_variant(engine.ctx.handle, C.byref(prm), C.byref(key), C.byref(lds), C.byref(typed)), "pk_generic_variant")
+    # which programs this list runs as on this FieldSet: the variant of the kernel-list interpreter, and whether the dedicated A-grid kernel
+    # would take it if the user kernels sample nothing
+    prm = engine.make_params(ids, endtime=0.0, dt0=1.0, context=fieldset.context, samples=samples or {})
+    key, lds, typed, fast = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    engine.ctx.check(engine.lib.pk_generic_variant(engine.ctx.handle, C.byref(prm), C.byref(key), C.byref(lds), C.byref(typed), C.byref(fast)),
+                     "pk_generic_variant")
     if typed.value:
         raise NotTranslatable("float32 coordinate arrays (NumPy dtype propagation of the typed program)")
-    prog = UserProgram(sources, key.value, lds.value)
+    prog = UserProgram(sources, key.value, lds.value, fast=fast.value, particles_f32=np.dtype(names["x"].dtype) == np.float32)
     prog.launcher()  # builds (or finds in the cache) and loads the module
     return ids, prog, dev_vars
 

@@ -41,7 +41,8 @@ def _fieldset(mesh="flat", seed=4):
 def _pclass(spatial=np.float32):
     P = pa.get_default_particle(spatial)
     return P.add_variable([pa.Variable("age", dtype=np.float32, initial=0), pa.Variable("acc", dtype=np.float64, initial=0),
-                           pa.Variable("temp", dtype=np.float32, initial=0), pa.Variable("speed", dtype=np.float64, initial=0)])
+                           pa.Variable("temp", dtype=np.float32, initial=0), pa.Variable("speed", dtype=np.float64, initial=0),
+                           pa.Variable("count", dtype=np.int32, initial=0), pa.Variable("flag", dtype=np.int64, initial=-1)])
 
 
 def _run(kernels, *, jit, mesh="flat", spatial=np.float32, n=300, runtime=12 * 600.0, dt=600.0, context=None, margin=0.15, expect_error=None,
@@ -139,6 +140,14 @@ def Kick(particles, fieldset):
     particles.dy -= fieldset.kick
 
 
+def Counters(particles, fieldset):
+    particles.count += 1                                        # int32 += Python int stays int32
+    moved = np.logical_and(np.abs(particles.dx) > 0, ~np.isnan(particles.dy))
+    particles.flag = np.where(moved, particles.count * 3 - particles.flag, particles.flag)  # int32 * int + int64 -> int64
+    particles.count[particles.age > 3000] = 7.9                 # a float into an integer column truncates
+    particles.acc = particles.count / 2 + np.clip(particles.flag, -2, 5)  # integer / integer is a float64 division
+
+
 def NotElementwise(particles, fieldset):
     if len(particles) > 0:  # control flow + a reduction: the host path
         particles.acc += len(particles)
@@ -148,7 +157,8 @@ def NotElementwise(particles, fieldset):
 def test_age_and_delete(gpu, spatial):
     p, d = _both([pa.AdvectionRK4, Age, DeleteOld], spatial=spatial, context={"max_age": 4000.0})
     assert 0 < len(p) < 300 or np.all(d["age"] <= 4000.0)  # particles older than max_age were deleted on the way
-    assert p._last_stats["program"] == 2  # ONE kernel-list interpreter launch (include/parcels_hip.h: pk_exec_stats.program)
+    # ONE launch -- of the dedicated A-grid kernel (pk_exec_stats.program 100), the two user kernels riding along: they sample no field
+    assert p._last_stats["program"] == 100 and p._kernel.user_program.flags == 1
 
 
 @pytest.mark.parametrize("mesh", ["flat", "spherical"])
@@ -164,7 +174,8 @@ def test_periodic_boundary_and_accumulator(gpu):
 
 
 def test_scalar_and_vector_samples(gpu):
-    _both([pa.AdvectionRK4, SampleT])
+    p, _ = _both([pa.AdvectionRK4, SampleT])
+    assert p._last_stats["program"] == 2 and p._kernel.user_program.flags == 0  # a sampling kernel: the kernel-list interpreter
     _both([Age, SampleExpr, pa.AdvectionRK4], spatial=np.float64)
     _both([SampleSpeed, pa.AdvectionRK2], mesh="spherical")
 
@@ -180,6 +191,12 @@ def test_boolean_algebra_and_numpy_functions(gpu):
     ctx = {"x0": 1.5e4, "y0": 1.0e4}
     _both([pa.AdvectionRK4, Age, Algebra], context=ctx)
     _both([pa.AdvectionRK4, Age, Algebra], context=ctx, spatial=np.float64)
+
+
+def test_integer_variables(gpu):
+    p, d = _both([pa.AdvectionRK4, Age, Counters])
+    assert d["count"].dtype == np.int32 and d["flag"].dtype == np.int64 and set(np.unique(d["count"])) <= set(range(0, 14)) and (d["count"] == 7).any()
+    _both([Counters, pa.AdvectionEE, Age], spatial=np.float64)
 
 
 def test_kernels_that_change_dt_and_displacements(gpu):
@@ -208,7 +225,7 @@ def test_what_is_not_elementwise_runs_on_the_host(gpu):
     p, d = _both([Closure, pa.AdvectionEE])
     assert np.allclose(d["acc"][d["t"] == d["t"].max()].max(), 0.5 * 12 * 600.0)
 
-    P = pa.Particle.add_variable(pa.Variable("count", dtype=np.int32, initial=0))
+    P = pa.Particle.add_variable(pa.Variable("count", dtype=np.int16, initial=0))
 
     def CountSteps(particles, fieldset):
         particles.count += 1
@@ -216,7 +233,7 @@ def test_what_is_not_elementwise_runs_on_the_host(gpu):
     fs = _fieldset()
     pset = pa.ParticleSet(fs, pclass=P, x=[2.0e4], y=[1.5e4])
     pset.execute([pa.AdvectionRK4, CountSteps], runtime=3000.0, dt=600.0)
-    assert pset._kernel.user_program is None and "int32" in pset._kernel.jit_report and pset.count[0] == 5
+    assert pset._kernel.user_program is None and "int16" in pset._kernel.jit_report and pset.count[0] == 5
 
 
 def test_compiled_list_with_output_file(gpu, tmp_path):
