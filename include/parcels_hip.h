@@ -357,13 +357,13 @@ int32_t pk_execute(pk_ctx* ctx, const pk_exec_params* params, pk_exec_stats* sta
 /* User kernels (PK_KERNEL_USER0 ..).  pk_generic_variant: what a launch with `prm` (the real kernel list, user ids included) runs on this
  * context -- key = (float32 fields ? 6 : 0) + (curvilinear main grid ? 3 : 0) + min(interp_uv, 2) and lds (the 1-D coordinate vectors are
  * staged in LDS) name the instantiation of the kernel-list interpreter, typed = NumPy float32 dtype propagation (float32 coordinate
- * arrays: no user kernels), fast = 1 / 2 when the list has the shape [.., AdvectionRK4 / AdvectionRK4_3D, ..] around sampling-free
- * kernels on a FieldSet the dedicated A-grid kernel takes (csrc/pk_fast_agrid.h): a module whose user kernels sample no field
- * (PK_USER_NOSAMPLE) then also carries that kernel with the user kernels riding along.
+ * arrays: no user kernels), fast = 1 / 2 (3 / 4) when the list has the shape [.., AdvectionRK4 / AdvectionRK4_3D, ..] around sampling-free
+ * kernels on a FieldSet the dedicated A-grid (curvilinear C-grid) kernel takes (csrc/pk_fast_agrid.h, pk_fast_cgrid.h): a module whose
+ * user kernels sample no field (PK_USER_NOSAMPLE) then also carries that kernel with the user kernels riding along.
  * pk_set_user_program: the launcher of a module built for exactly that --
  *   void launcher(const void* kargs, int32_t prog, int32_t key, int32_t lds, uint64_t lds_bytes, void* hip_stream)
- * prog 0: the interpreter variant (key, lds); prog 1 / 2: the dedicated A-grid kernel 2-D / 3-D with key = float32 fields * 2 + float32
- * particles; it must refuse (abort) what it was not built for.  NULL unregisters.  A kernel list with a user id and no launcher fails. */
+ * prog 0: the interpreter variant (key, lds); prog 1 / 2 (3 / 4): the dedicated A-grid (C-grid) kernel 2-D / 3-D with key = float32 fields
+ * * 2 + float32 particles; it must refuse (abort) what it was not built for.  NULL unregisters.  A kernel list with a user id and no launcher fails. */
 #define PK_USER_NOSAMPLE 1
 int32_t pk_generic_variant(pk_ctx* ctx, const pk_exec_params* prm, int32_t* key, int32_t* lds, int32_t* typed, int32_t* fast);
 int32_t pk_set_user_program(pk_ctx* ctx, void* launcher, int32_t flags);

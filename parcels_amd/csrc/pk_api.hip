@@ -1982,12 +1982,17 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
         if (has_user && prog != PROG_GENERIC) return ctx->fail("user kernels run in the plain kernel-list interpreter only (float32 coordinate arrays are not supported)");
         bool fast_a = false, fast_c = false;  // a.fast / a.fastc share storage: at most one is filled
         size_t cgrid_lds = 0;
-        const int ufast = (has_user && use_lds && !curv) ? user_fast_shape(prm, ctx->user_flags) : -1;
-        if (ufast >= 0) {
+        const int ufast = (has_user && use_lds) ? user_fast_shape(prm, ctx->user_flags) : -1;
+        if (ufast >= 0 && !curv) {
             rc = fill_fast(ctx, prm, a, ufast == 1);
             if (rc) return rc;
             fast_a = a.fast.ok != 0;
             if (fast_a) prog = ufast ? PROG_RK4_3D : PROG_RK4;
+        } else if (ufast >= 0 && curv) {
+            rc = fill_fastc(ctx, prm, a, ufast == 1, cgrid_lds);
+            if (rc) return rc;
+            fast_c = a.fastc.ok != 0;
+            if (fast_c) prog = ufast ? PROG_RK4_3D : PROG_RK4;
         } else if ((prog == PROG_RK4 || prog == PROG_RK4_3D) && !curv) {
             rc = fill_fast(ctx, prm, a, prog == PROG_RK4_3D);
             if (rc) return rc;
@@ -2034,6 +2039,7 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
         const size_t fast_lds = fast_a ? (size_t)a.fast.lds_n * 2 * sizeof(double) : 0;
         const int pf32 = ctx->dev.spatial_f32;
         if (has_user && fast_a) ctx->user_launch(&a, prog == PROG_RK4_3D ? 2 : 1, field_f32 * 2 + pf32, 1, (uint64_t)fast_lds, (void*)ctx->compute);
+        else if (has_user && fast_c) ctx->user_launch(&a, prog == PROG_RK4_3D ? 4 : 3, field_f32 * 2 + pf32, 1, (uint64_t)cgrid_lds, (void*)ctx->compute);
         else if (fast_a && prog == PROG_RK4) launch_fast<PROG_RK4>(field_f32, pf32, a, grid, fast_lds, ctx->compute);
         else if (fast_a && prog == PROG_RK4_3D) launch_fast<PROG_RK4_3D>(field_f32, pf32, a, grid, fast_lds, ctx->compute);
         else if (fast_c && prog == PROG_RK45) launch_cgrid_rk45(field_f32, pf32, a, n, cgrid_lds, ctx->compute);
@@ -2122,11 +2128,18 @@ int32_t pk_generic_variant(pk_ctx* ctx, const pk_exec_params* prm, int32_t* key,
     *lds = use_lds;
     *typed = ctx_is_typed(ctx) ? 1 : 0;
     *fast = 0;
-    const int ufast = (use_lds && !*typed && ctx->grids[a.main_grid].d.kind != 1) ? user_fast_shape(prm, PK_USER_NOSAMPLE) : -1;
-    if (ufast >= 0) {
+    const int ufast = (use_lds && !*typed) ? user_fast_shape(prm, PK_USER_NOSAMPLE) : -1;
+    if (ufast >= 0 && ctx->grids[a.main_grid].d.kind != 1) {
         const int32_t rc2 = fill_fast(ctx, prm, a, ufast == 1);
         if (rc2) return rc2;
         if (a.fast.ok) *fast = 1 + ufast;
+    } else if (ufast >= 0) {  // the dedicated curvilinear C-grid kernel (a first launch without `ei` guesses still runs the interpreter)
+        pk_exec_params guessed = *prm;
+        guessed.have_guess0 = 1;
+        size_t cl = 0;
+        const int32_t rc2 = fill_fastc(ctx, &guessed, a, ufast == 1, cl);
+        if (rc2) return rc2;
+        if (a.fastc.ok) *fast = 3 + ufast;
     }
     return 0;
 }

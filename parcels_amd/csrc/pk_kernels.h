@@ -860,6 +860,15 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID) advect_cgrid_ker
                 it++;
                 pdt = dtc;
                 attempts++;
+#ifdef PK_USER_KERNELS
+                int adv = 0;  // a list with user kernels: [kernels before the advection kernel ..., AdvectionRK4(_3D), kernels after it ...]
+                for (; adv < prm.nk && !is_rk4_id(prm.kernels[adv]); adv++) {
+                    attempts++;
+                    side_kernel(a, prm.kernels[adv], adv, c.state, pf, row(), pt, pz, py, px, pdz, pdy, pdx, pdt);
+                }
+#else
+                constexpr int adv = 0;
+#endif
                 // AdvectionRK4(_3D), _advection.py:42-75: (u1 + 2*u2 + 2*u3 + u4) summed left to right
                 double su = 0.0, sv = 0.0, sw = 0.0, lu = 0.0, lv = 0.0, lw = 0.0;
 #pragma unroll 1
@@ -883,9 +892,15 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID) advect_cgrid_ker
                 pdx = pstore(pf, pdx + div_by_recip(su, 6.0, sixth) * pdt);
                 pdy = pstore(pf, pdy + div_by_recip(sv, 6.0, sixth) * pdt);
                 if (D3) pdz = pstore(pf, pdz + div_by_recip(sw, 6.0, sixth) * pdt);
-                for (int k = 1; k < prm.nk; k++) {  // the sampling-free recovery kernels that may follow (Delete*)
+                for (int k = adv + 1; k < prm.nk; k++) {  // the sampling-free recovery kernels that may follow (Delete*)
                     const int kid = prm.kernels[k];
                     attempts++;
+#ifdef PK_USER_KERNELS
+                    if (kid >= PK_KERNEL_USER0) {
+                        side_kernel(a, kid, k, c.state, pf, row(), pt, pz, py, px, pdz, pdy, pdx, pdt);
+                        continue;
+                    }
+#endif
                     if (kid == PK_KERNEL_DELETE_ON_ERROR) {
                         if (c.state >= PK_ERROR) c.state = PK_DELETE;
                     } else if (c.state == PK_ERROROUTOFBOUNDS || c.state == PK_ERRORTHROUGHSURFACE) {

@@ -647,10 +647,15 @@ class UserProgram:
         fast_launch = ""
         if self.flags:
             fkey = (2 if key >= 6 else 0) + (1 if particles_f32 else 0)
-            fast_launch = (f"        if (prog == {int(fast)} && key == {fkey}) {{\n"
-                           f"            hipLaunchKernelGGL((advect_fast_kernel<{ft}, {1 if particles_f32 else 0}, {'true' if fast == 2 else 'false'}>), "
-                           f"dim3((unsigned)((a.p.n + 255) / 256)), dim3(256), (size_t)lds_bytes, (hipStream_t)stream, a);\n"
-                           f"            return;\n        }}")
+            d3 = "true" if fast in (2, 4) else "false"
+            pfm = 1 if particles_f32 else 0
+            if fast in (1, 2):
+                launch = (f"hipLaunchKernelGGL((advect_fast_kernel<{ft}, {pfm}, {d3}>), dim3((unsigned)((a.p.n + 255) / 256)), dim3(256), "
+                          f"(size_t)lds_bytes, (hipStream_t)stream, a);")
+            else:
+                launch = (f"hipLaunchKernelGGL((advect_cgrid_kernel<{ft}, {pfm}, {d3}>), dim3((unsigned)((a.p.n + FC_LANES - 1) / FC_LANES)), dim3(FC_LANES), "
+                          f"(size_t)lds_bytes, (hipStream_t)stream, a);")
+            fast_launch = f"        if (prog == {int(fast)} && key == {fkey}) {{\n            {launch}\n            return;\n        }}"
         self.source = _TEMPLATE.format(names=", ".join(s.name for s in sources), decl=decl, cases=cases, key=key, lds=lds, ft=ft, kind=kind,
                                        interp=interp, ldsb="true" if lds else "false", fast_launch=fast_launch)
         self.digest = hashlib.sha256((self.source + _csrc_hash()).encode()).hexdigest()[:20]

@@ -250,3 +250,31 @@ def test_compiled_list_with_output_file(gpu, tmp_path):
     for c in a.columns:
         assert np.array_equal(a[c].values, b[c].values), c
     assert a["age"].max() > 0
+
+
+def test_user_kernels_ride_in_the_dedicated_cgrid_kernel(gpu):
+    """BASELINE config 3's shape (spherical curvilinear C-grid, AdvectionRK4_3D, populated `ei`) with an ageing kernel and the user's own
+    recovery kernel around the advection kernel: the module carries advect_cgrid_kernel with the user kernels riding along
+    (pk_exec_stats.program 101), bit-identical to the host path."""
+    from case_utils import build_fieldset
+    from oracle import cases
+
+    case = cases.curv_cgrid_case("jit_curv", mesh="spherical", kernels=["AdvectionRK4_3D"], seed=5, npart=600, nx=50, ny=40, vel=1.0, runtime=10 * 1800.0)
+    out = []
+    for jit in (True, False):
+        os.environ["PARCELS_AMD_JIT"] = "1" if jit else "0"
+        try:
+            fs = build_fieldset(case)
+            P = pa.get_default_particle(np.float64).add_variable(pa.Variable("age", dtype=np.float32, initial=0))
+            pset = pa.ParticleSet(fs, pclass=P, x=np.asarray(case["x"]), y=np.asarray(case["y"]), z=np.asarray(case["z"]), t=np.zeros(len(case["x"])))
+            pset.populate_indices()
+            pset.execute([Age, pa.AdvectionRK4_3D, DeleteErrorParticle], runtime=float(case["runtime"]), dt=float(case["dt"]))
+            out.append((pset, {k: np.array(v) for k, v in pset._data.items()}))
+        finally:
+            os.environ.pop("PARCELS_AMD_JIT", None)
+    (pj, dj), (ph, dh) = out
+    assert pj._kernel.user_program is not None and pj._kernel.user_program.flags == 1 and pj._last_stats["program"] == 101, pj._last_stats
+    assert ph._kernel.user_program is None
+    for k in dj:
+        assert np.array_equal(dj[k], dh[k], equal_nan=True), k
+    assert dj["age"].max() == 10 * 1800.0
