@@ -13,7 +13,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PARCELS_HIP_LIB", os.path.join(_HERE, "libparcels_hip.so"))  # override: A/B builds
 
-PK_ABI_VERSION = 5
+PK_ABI_VERSION = 6
 PK_F32, PK_F64 = 0, 1
 PK_MAX_GRIDS, PK_MAX_FIELDS, PK_MAX_KERNELS, PK_NUM_STATE_CODES = 4, 64, 8, 80
 PK_MAX_EXTRA = 4

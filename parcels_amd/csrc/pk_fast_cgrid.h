@@ -12,9 +12,10 @@
 //     4*aa, and the prefixes of bb and cc that do not contain the query point -- formed in the reference's evaluation order, so the
 //     remaining operations give the same bits) and the antimeridian-unwrapped corner longitudes of CGrid_Velocity
 //     (_xinterpolators.py:230-233);
-//   * the per-lane LDS slot caches that record (23 doubles) and the 12 raw staggered field values; the tags of the slot live in
-//     registers, a miss fetches record AND field values of the new cell in ONE memory round trip (the general path needs two
-//     dependent ones: the record, then -- after the point-in-cell test -- the values);
+//   * a lane caches that record and the 12 raw staggered field values of its cell: the 15 rows of the point-in-cell test and the field
+//     values in its LDS slot, the 8 corner coordinates and the tags of the slot in registers (CM below: the split that gives 3 waves per
+//     SIMD); a miss fetches record AND field values of the new cell in ONE memory round trip (the general path needs two dependent
+//     ones: the record, then -- after the point-in-cell test -- the values);
 //   * phi2D_lin rows with a literal 0 / 1 argument are written with their exact zero products removed, the cosine of the
 //     particle latitude is shared between the unit-sphere query point and the metres -> degrees conversion, the ring slot
 //     of a time level (`level % nslots`) is computed on the scalar unit once per distinct level of a wavefront.
