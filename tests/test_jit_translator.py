@@ -1,0 +1,282 @@
+"""CPU: the Python -> device-kernel translator of parcels_amd/jit.py, checked WITHOUT a GPU.  The C++ the translator emits for a kernel
+is plain scalar code over `p.*`, `c.state`, the user-Variable columns and its locals, so it also compiles for the host: a 40-line shim
+of the device structs (PState, PCtx, KLocal, Request), g++ -O2 -ffp-contract=off, a loop over the particles that plays the stage machine
+-- a field sample is answered from arrays the test supplies -- and the result is compared BIT FOR BIT with NumPy running the same Python
+function on the same columns through HostParticles (the object a Python kernel receives on the host path).  This pins the translator's
+static NumPy semantics (NEP 50 promotion, in-place casts, true division, truncating stores, %, fmod, minimum / maximum with NaN, masked
+stores ...) in the suite that needs no GPU; tests/test_gpu_jit_kernels.py repeats it end to end on the device."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import parcels_amd as pa
+from parcels_amd import StatusCode, jit
+from parcels_amd.hostkernels import HostParticles
+
+SHIM = r"""
+#include <stdint.h>
+#include <math.h>
+#include <string.h>
+#define PK_DEV static inline
+enum { RQ_UV = 0, RQ_UVW = 1, RQ_SCALAR = 2 };
+enum { PK_ERROR = 50 };
+struct PState { double t, z, y, x, dz, dy, dx, dt, next_dt; int64_t id; };
+struct PCtx { int state; bool pf; int64_t row; };
+struct Request { int kind, fidx; double t, z, y, x; bool f32; };
+struct DParticles { void* extra[4]; };
+struct KArgs { DParticles p; };
+struct PkUserLocals {
+%(decl)s
+};
+struct KLocal { double r[14]; PkUserLocals ul; };
+PK_DEV bool user_prepare(const KArgs& a, int uk, int stage, int kslot, PCtx& c, PState& p, KLocal& L, Request& rq) {
+    switch (uk) {
+        case 0: {
+%(body)s
+        }
+        default: return true;
+    }
+}
+// cols: t z y x dz dy dx dt (double each, spatial ones hold float values when pf), state (int32), id (int64), 4 extra columns;
+// samples[k * 3 * n + j * n + i]: component j of the k-th sample of particle i
+extern "C" void run(int64_t n, int pf, double* t, double* z, double* y, double* x, double* dz, double* dy, double* dx, double* dt,
+                    int32_t* state, int64_t* id, void* e0, void* e1, void* e2, void* e3, const double* samples, int32_t* nsamples) {
+    KArgs a;
+    a.p.extra[0] = e0; a.p.extra[1] = e1; a.p.extra[2] = e2; a.p.extra[3] = e3;
+    for (int64_t i = 0; i < n; i++) {
+        PState p = {t[i], z[i], y[i], x[i], dz[i], dy[i], dx[i], dt[i], 0.0, id[i]};
+        PCtx c = {state[i], pf != 0, i};
+        KLocal L;
+        memset(&L, 0, sizeof(L));
+        Request rq;
+        int k = 0;
+        for (int stage = 0; !user_prepare(a, 0, stage, 0, c, p, L, rq); stage++, k++)
+            for (int j = 0; j < 3; j++) L.r[3 + j] = samples[((int64_t)k * 3 + j) * n + i];
+        *nsamples = k;
+        t[i] = p.t; z[i] = p.z; y[i] = p.y; x[i] = p.x; dz[i] = p.dz; dy[i] = p.dy; dx[i] = p.dx; dt[i] = p.dt; state[i] = c.state;
+    }
+}
+"""
+
+
+class _FakeField:
+    def __init__(self, values):
+        self.values = values  # list of component arrays (1 for a scalar field, 2 / 3 for UV / UVW)
+
+    def __getitem__(self, particles):
+        rows = particles._rows
+        out = tuple(v[rows] for v in self.values)
+        return out[0] if len(out) == 1 else out
+
+
+class _FakeFieldSet:
+    def __init__(self, context, fields):
+        self.context = dict(context)
+        self.fields = fields
+
+    def __getattr__(self, name):
+        d = self.__dict__
+        if name in d.get("fields", {}):
+            return d["fields"][name]
+        if name in d.get("context", {}):
+            return d["context"][name]
+        raise AttributeError(name)
+
+
+def _columns(pclass, n, seed, finite=False):
+    rng = np.random.default_rng(seed)
+    data = {}
+    for v in pclass.variables:
+        dt = np.dtype(v.dtype)
+        if v.name == "ei":
+            data["ei"] = np.zeros((n, 1), np.int32)
+        elif v.name == "state":
+            data["state"] = rng.choice([int(StatusCode.Evaluate), int(StatusCode.Success), 60, 61, 70], size=n).astype(np.int32)
+        elif v.name == "particle_id":
+            data["particle_id"] = np.arange(n, dtype=np.int64) * 7 + 3
+        elif dt.kind == "f":
+            a = rng.normal(scale=3.0, size=n)
+            a[rng.random(n) < 0.05] = 0.0
+            if v.name not in ("t", "dt", "x", "y", "z") and not finite:
+                a[rng.random(n) < 0.03] = np.nan
+            data[v.name] = a.astype(dt)
+        else:
+            data[v.name] = rng.integers(-5, 9, size=n).astype(dt)
+    data["dt"] = np.full(n, 600.0)
+    return data
+
+
+def _run_translated(func, pclass, fieldset, data, var_slot, field_ids, samples, tmp_path):
+    src = jit.translate(func, pclass, fieldset, var_slot, field_ids)
+    body = "\n".join("            " + ln for ln in src.case_body().split("\n"))
+    code = SHIM % {"decl": "\n".join("    " + d for d in src.decl) or "    char unused;", "body": body}
+    cpp = tmp_path / f"{func.__name__}.cpp"
+    so = tmp_path / f"{func.__name__}.so"
+    cpp.write_text(code)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-w", str(cpp), "-o", str(so)], check=True)
+    lib = C.CDLL(str(so))
+    n = len(data["t"])
+    pf = data["x"].dtype == np.float32
+    cols = {k: np.array(data[k], dtype=np.float64) for k in ("t", "z", "y", "x", "dz", "dy", "dx", "dt")}  # (copies: data stays the input)
+    state, pid = data["state"].copy(), data["particle_id"].copy()
+    extras = [None] * 4
+    for name, (slot, _) in var_slot.items():
+        extras[slot] = data[name].copy()
+    sam = np.ascontiguousarray(samples, dtype=np.float64) if samples is not None else np.zeros(3 * n)
+    ns = C.c_int32(0)
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None  # noqa: E731
+    lib.run(C.c_int64(n), C.c_int(int(pf)), *[ptr(cols[k]) for k in ("t", "z", "y", "x", "dz", "dy", "dx", "dt")], ptr(state), ptr(pid),
+            *[ptr(e) for e in extras], ptr(sam), C.byref(ns))
+    out = {k: cols[k].astype(data[k].dtype) for k in cols}
+    out["state"] = state
+    for name, (slot, _) in var_slot.items():
+        out[name] = extras[slot]
+    return out, ns.value, src
+
+
+def _check(func, tmp_path, *, spatial=np.float32, context=None, fields=None, n=400, seed=0, finite=False):
+    P = pa.get_default_particle(spatial).add_variable([
+        pa.Variable("age", dtype=np.float32, initial=0), pa.Variable("acc", dtype=np.float64, initial=0),
+        pa.Variable("count", dtype=np.int32, initial=0), pa.Variable("flag", dtype=np.int64, initial=0)])
+    data = _columns(P, n, seed, finite)
+    var_slot = {"age": (0, "f32"), "acc": (1, "f64"), "count": (2, "i32"), "flag": (3, "i64")}
+    rng = np.random.default_rng(seed + 100)
+    fields = fields or {}
+    fake_fields, field_ids, sample_arrays = {}, {}, []
+    for k, (name, ncomp) in enumerate(fields.items()):
+        comps = [rng.normal(size=n) for _ in range(ncomp)]
+        f = _FakeField(comps)
+        if ncomp > 1:
+            f.U = f.V = None  # what marks a VectorField for the translator
+        fake_fields[name] = f
+        field_ids[name] = k
+    fs = _FakeFieldSet(context or {}, fake_fields)
+    # the order in which the function samples the fields is the order of `fields` (the tests are written that way)
+    sam = np.zeros((max(len(fields), 1), 3, n))
+    for k, name in enumerate(fields):
+        for j, comp in enumerate(fake_fields[name].values):
+            sam[k, j] = comp
+    got, nsamples, src = _run_translated(func, P, fs, data, var_slot, field_ids, sam, tmp_path)
+    assert nsamples == len(fields)
+    ref = {k: v.copy() for k, v in data.items()}
+    with np.errstate(all="ignore"):
+        func(HostParticles(ref, np.arange(n)), fs)
+    for k in got:
+        assert got[k].dtype == ref[k].dtype, k
+        assert np.array_equal(got[k], ref[k], equal_nan=True), (func.__name__, k, np.flatnonzero(~((got[k] == ref[k]) | (np.isnan(got[k].astype(float)) & np.isnan(ref[k].astype(float)))))[:5])
+    return src
+
+
+# ---- kernels --------------------------------------------------------------------------------------------------------------------------
+def InPlace(particles, fieldset):
+    particles.age += particles.dt          # f32 += f64
+    particles.acc -= particles.age         # f64 -= f32
+    particles.age *= 1.5                   # f32 *= Python float
+    particles.acc /= particles.count + 10  # f64 /= int32
+    particles.count += 2
+    particles.flag -= particles.count      # int64 -= int32
+    particles.dx += 0.1
+    particles.dy *= particles.dt / 1200
+
+
+def Promotion(particles, fieldset):
+    a = particles.x + particles.age        # spatial dtype + f32
+    b = particles.count * particles.age    # int32 * f32 -> f64
+    c = particles.count / 4                # true division
+    d = particles.count * 3 + particles.flag
+    particles.acc = a + b - c + d / 2 + particles.x * particles.x
+    particles.age = particles.acc          # f64 into f32
+    particles.count = particles.age * 0.7  # float into int32: truncation (NaN / huge values: undefined, masked out below)
+    particles.flag = np.where(particles.count > 2, particles.flag, 11)
+
+
+def Functions(particles, fieldset):
+    particles.acc = np.fmod(particles.acc, 2.5) + np.abs(particles.age) % 1.25 + (-particles.age) % fieldset.m
+    particles.age = np.minimum(np.maximum(particles.age, -1), particles.acc) + np.sqrt(np.abs(particles.x)) ** 2
+    particles.dz = np.clip(particles.dz, -0.5, fieldset.hi) + np.floor(particles.dy) - np.ceil(particles.dx)
+    particles.count = np.abs(particles.count) - np.where(np.isnan(particles.acc), 1, 0)
+    particles.flag = np.where(np.isfinite(particles.age) & (particles.flag != 3), particles.flag, -particles.flag)
+
+
+def Masks(particles, fieldset):
+    err = particles.state >= 50
+    particles[err].state = StatusCode.Delete
+    m = (particles.x > 0.5) & ~(particles.y < -1) | (particles.count == 0)
+    particles.dx[m] = 0
+    particles[np.logical_and(m, particles.age > 1)].acc = fieldset.k * 2
+    particles.age[particles.flag < 0] += 3
+    particles.state = np.where(np.logical_not(err) & (particles.acc > 4), StatusCode.StopExecution, particles.state)
+    particles.dt = np.where(particles.t >= 1.0, 300.0, particles.dt)
+
+
+def Samples(particles, fieldset):
+    tval = fieldset.T[particles]
+    particles.age = tval * 2 - particles.age
+    u, v = fieldset.UV[particles]
+    particles.acc += np.sqrt(u**2 + v**2)
+    _, particles.dy, w = fieldset.UVW[particles]
+    particles.dz = w + fieldset.T2[particles]
+
+
+@pytest.mark.parametrize("spatial", [np.float32, np.float64])
+def test_in_place_operators(tmp_path, spatial):
+    _check(InPlace, tmp_path, spatial=spatial)
+
+
+@pytest.mark.parametrize("spatial", [np.float32, np.float64])
+def test_promotion_and_casts(tmp_path, spatial):
+    # float -> int32 of NaN / out-of-range values is undefined in C and in NumPy alike: finite columns here
+    _check(Promotion, tmp_path, spatial=spatial, seed=1, finite=True)
+
+
+@pytest.mark.parametrize("spatial", [np.float32, np.float64])
+def test_numpy_functions(tmp_path, spatial):
+    _check(Functions, tmp_path, spatial=spatial, context={"m": 0.75, "hi": np.float32(0.25)}, seed=2)
+
+
+def test_masks_and_states(tmp_path):
+    src = _check(Masks, tmp_path, context={"k": 1.25}, seed=3)
+    assert len(src.stages) == 1 and "state" in src.touched
+
+
+def test_field_samples_are_stage_boundaries(tmp_path):
+    src = _check(Samples, tmp_path, spatial=np.float64, fields={"T": 1, "UV": 2, "UVW": 3, "T2": 1}, seed=4)
+    assert len(src.stages) == 5  # four samples: five stages
+
+
+def test_what_the_translator_refuses():
+    P = pa.get_default_particle(np.float32).add_variable(pa.Variable("age", dtype=np.float32, initial=0))
+    fs = _FakeFieldSet({}, {})
+
+    def k_if(particles, fieldset):
+        if fieldset:
+            particles.age += 1
+
+    def k_reduce(particles, fieldset):
+        particles.age += len(particles)
+
+    def k_random(particles, fieldset):
+        particles.age = np.random.rand(len(particles))
+
+    def k_trig(particles, fieldset):
+        particles.age = np.sin(particles.x)
+
+    def k_intcast(particles, fieldset):
+        particles.state += 0.5  # NumPy raises (same_kind): the host path raises it for the user
+
+    def k_local_inplace(particles, fieldset):
+        a = particles.age
+        a += 1
+
+    def k_unknown(particles, fieldset):
+        particles.nope = 1
+
+    for f, word in ((k_if, "If"), (k_reduce, "call"), (k_random, "call"), (k_trig, "np.sin"), (k_intcast, "does not cast back"),
+                    (k_local_inplace, "in-place operator on a local"), (k_unknown, "no Variable")):
+        with pytest.raises(jit.NotTranslatable, match=word):
+            jit.translate(f, P, fs, {"age": (0, "f32")}, {})
+    assert jit.candidate_variables(k_unknown, P) == [] and jit.candidate_variables(k_trig, P) == ["age"]
