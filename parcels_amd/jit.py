@@ -130,6 +130,10 @@ def _strong(ty: str) -> str:
 
 
 _SPATIAL = ("x", "y", "z", "dx", "dy", "dz")
+# numpy name -> (C function, arity) of the transcendental functions accepted under PARCELS_AMD_JIT_LIBM=1
+_LIBM = {"sin": ("sin", 1), "cos": ("cos", 1), "tan": ("tan", 1), "arcsin": ("asin", 1), "arccos": ("acos", 1), "arctan": ("atan", 1),
+         "arctan2": ("atan2", 2), "exp": ("exp", 1), "log": ("log", 1), "log10": ("log10", 1), "sinh": ("sinh", 1), "cosh": ("cosh", 1),
+         "tanh": ("tanh", 1), "hypot": ("hypot", 2)}
 
 
 class _Translator(ast.NodeVisitor):
@@ -437,6 +441,24 @@ class _Translator(ast.NodeVisitor):
             t = self.new_slot(ty)
             self.emit(f"{t} = {_cast(v, ty)};")
             return _V(f"({t} != {t})" if name == "isnan" else f"(({t} - {t}) == 0)", "b", array=arr)
+        if name in ("deg2rad", "radians", "rad2deg", "degrees") and len(args) == 1:  # x * (pi / 180) in the loop's dtype, like the ufunc
+            v = args[0]
+            ty = _strong(v.ty)
+            if ty[0] != "f":
+                ty = "f64"
+            k = "3.14159265358979323846 / 180.0" if name in ("deg2rad", "radians") else "180.0 / 3.14159265358979323846"
+            kk = f"(({_CT[ty]})({k}))" if ty == "f64" else (f"(3.14159265358979323846f / 180.0f)" if name in ("deg2rad", "radians") else "(180.0f / 3.14159265358979323846f)")
+            return _V(f"({_cast(v, ty)} * {kk})", ty, array=arr)
+        if name in _LIBM and len(args) == _LIBM[name][1]:
+            # transcendental functions are NOT bit-identical between NumPy's loops and the device library (each within ~1 ulp of the
+            # exact value): only on request -- PARCELS_AMD_JIT_LIBM=1 -- otherwise the kernel keeps NumPy's own values on the host path
+            if os.environ.get("PARCELS_AMD_JIT_LIBM", "0") in ("0", "", "false", "no"):
+                raise NotTranslatable(f"np.{name} (set PARCELS_AMD_JIT_LIBM=1 to accept device transcendentals: within ~1 ulp of NumPy's, not bit-identical)")
+            ty = _strong(args[0].ty) if len(args) == 1 else _strong(_promote(*args))
+            if ty[0] != "f":
+                ty = "f64"
+            fn = _LIBM[name][0] + ("f" if ty == "f32" else "")
+            return _V(f"{fn}({', '.join(_cast(a, ty) for a in args)})", ty, array=arr)
         if name in ("float32", "float64", "int32", "int64") and len(args) == 1:
             ty = {"float32": "f32", "float64": "f64", "int32": "i32", "int64": "i64"}[name]
             return _V(f"(({_CT[ty]})({args[0].code}))", ty, array=arr)

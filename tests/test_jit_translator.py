@@ -248,6 +248,45 @@ def test_field_samples_are_stage_boundaries(tmp_path):
     assert len(src.stages) == 5  # four samples: five stages
 
 
+def Trig(particles, fieldset):
+    particles.acc = np.deg2rad(particles.y) * 2 + np.rad2deg(particles.age)
+    particles.age = np.deg2rad(particles.age)
+
+
+def Libm(particles, fieldset):
+    lat = np.deg2rad(particles.y)
+    particles.acc = np.cos(lat) * np.sin(particles.x) + np.exp(-np.abs(particles.age)) + np.arctan2(particles.dy, particles.dx)
+    particles.age = np.cos(particles.age) + np.hypot(particles.age, 2)
+
+
+@pytest.mark.parametrize("spatial", [np.float32, np.float64])
+def test_degrees_and_radians_are_exact(tmp_path, spatial):
+    _check(Trig, tmp_path, spatial=spatial, seed=5)
+
+
+def test_transcendental_functions_only_on_request(tmp_path, monkeypatch):
+    """np.sin & co are within an ulp or so of NumPy's on the device, not bit-identical: the translator takes them only under
+    PARCELS_AMD_JIT_LIBM=1 (here the host's libm stands in for the device's: same order of agreement)."""
+    P = pa.get_default_particle(np.float64).add_variable([pa.Variable("age", dtype=np.float32, initial=0), pa.Variable("acc", dtype=np.float64, initial=0)])
+    fs = _FakeFieldSet({}, {})
+    monkeypatch.delenv("PARCELS_AMD_JIT_LIBM", raising=False)
+    with pytest.raises(jit.NotTranslatable, match="PARCELS_AMD_JIT_LIBM"):
+        jit.translate(Libm, P, fs, {"age": (0, "f32"), "acc": (1, "f64")}, {})
+    monkeypatch.setenv("PARCELS_AMD_JIT_LIBM", "1")
+    n = 300
+    Pfull = pa.get_default_particle(np.float64).add_variable([
+        pa.Variable("age", dtype=np.float32, initial=0), pa.Variable("acc", dtype=np.float64, initial=0),
+        pa.Variable("count", dtype=np.int32, initial=0), pa.Variable("flag", dtype=np.int64, initial=0)])
+    data = _columns(Pfull, n, 6, finite=True)
+    var_slot = {"age": (0, "f32"), "acc": (1, "f64"), "count": (2, "i32"), "flag": (3, "i64")}
+    got, _, _ = _run_translated(Libm, Pfull, fs, data, var_slot, {}, None, tmp_path)
+    ref = {k: v.copy() for k, v in data.items()}
+    Libm(HostParticles(ref, np.arange(n)), fs)
+    # (`np.exp(-np.abs(particles.age))` is a FLOAT32 exponential of the float32 Variable: its ulp is 1.2e-7)
+    np.testing.assert_allclose(got["acc"], ref["acc"], rtol=5e-7, atol=5e-7)
+    np.testing.assert_allclose(got["age"], ref["age"], rtol=5e-7)
+
+
 def test_what_the_translator_refuses():
     P = pa.get_default_particle(np.float32).add_variable(pa.Variable("age", dtype=np.float32, initial=0))
     fs = _FakeFieldSet({}, {})
