@@ -278,3 +278,23 @@ def test_user_kernels_ride_in_the_dedicated_cgrid_kernel(gpu):
     for k in dj:
         assert np.array_equal(dj[k], dh[k], equal_nan=True), k
     assert dj["age"].max() == 10 * 1800.0
+
+
+def CosLat(particles, fieldset):
+    particles.acc = np.cos(np.deg2rad(particles.y)) * np.exp(-particles.age / 5000)
+
+
+def test_transcendental_functions_on_request(gpu, monkeypatch):
+    """np.cos / np.exp in a kernel: by default the kernel keeps NumPy's values (host path); with PARCELS_AMD_JIT_LIBM=1 it is compiled and
+    agrees with them to the ulp of the dtype the function ran in (float32 here for exp: `age` is a float32 Variable)."""
+    monkeypatch.delenv("PARCELS_AMD_JIT_LIBM", raising=False)
+    p0, d0 = _run([pa.AdvectionRK4, Age, CosLat], jit=True, mesh="spherical")
+    assert p0._kernel.user_program is None and "PARCELS_AMD_JIT_LIBM" in p0._kernel.jit_report
+    monkeypatch.setenv("PARCELS_AMD_JIT_LIBM", "1")
+    p1, d1 = _run([pa.AdvectionRK4, Age, CosLat], jit=True, mesh="spherical")
+    assert p1._kernel.user_program is not None
+    for k in d0:
+        if k == "acc":
+            np.testing.assert_allclose(d1[k], d0[k], rtol=5e-7)
+        else:
+            assert np.array_equal(d1[k], d0[k], equal_nan=True), k
