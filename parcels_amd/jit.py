@@ -687,16 +687,20 @@ class UserProgram:
     def build(self):
         if os.path.exists(self.path):
             return self.path
-        src = self.path[:-3] + ".hip"
+        # several ranks of one node compile the same module at the same time: private temporaries, atomic rename
+        tag = f"{os.getpid()}"
+        src = self.path[:-3] + f".{tag}.hip"
+        tmp = self.path + f".{tag}.tmp"
         with open(src, "w") as f:
             f.write(self.source)
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unused-function",
-               f"-I{_CSRC}", f"-I{_INCLUDE}", src, "-o", self.path + ".tmp"]
+               f"-I{_CSRC}", f"-I{_INCLUDE}", src, "-o", tmp]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on the generated user-kernel module {src}:\n{r.stderr[-4000:]}")
-        os.replace(self.path + ".tmp", self.path)
+        os.replace(src, self.path[:-3] + ".hip")  # (kept next to the module: what was compiled)
+        os.replace(tmp, self.path)
         return self.path
 
     def launcher(self) -> int:
