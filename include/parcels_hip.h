@@ -25,11 +25,11 @@
 extern "C" {
 #endif
 
-#define PK_ABI_VERSION 6 /* 6: PK_MAX_FIELDS 64 (descriptors in device memory), pk_particles_checkpoint / _restore, user kernels (PK_KERNEL_USER0 .., pk_generic_variant, pk_set_user_program), "eval_points_f32" option; 5: pk_exec_params.horizon_lo / horizon_hi / max_iters, pk_exec_stats.first_error_iter / program, pk_execute_rerun, "fast_cgrid" option; 4: pk_upload_stats, pk_host_stage_selftest, PK_KERNEL_DO_NOTHING / _MOVE_EAST / _MOVE_NORTH, vector PK_KERNEL_SAMPLE_FIELD, "cell_table" option */
+#define PK_ABI_VERSION 6 /* 6: PK_MAX_FIELDS 64 (descriptors in device memory), PK_MAX_EXTRA 8, pk_particles_checkpoint / _restore, user kernels (PK_KERNEL_USER0 .., pk_generic_variant, pk_set_user_program), "eval_points_f32" option; 5: pk_exec_params.horizon_lo / horizon_hi / max_iters, pk_exec_stats.first_error_iter / program, pk_execute_rerun, "fast_cgrid" option; 4: pk_upload_stats, pk_host_stage_selftest, PK_KERNEL_DO_NOTHING / _MOVE_EAST / _MOVE_NORTH, vector PK_KERNEL_SAMPLE_FIELD, "cell_table" option */
 #define PK_MAX_GRIDS 4
 #define PK_MAX_FIELDS 64
 #define PK_MAX_KERNELS 8
-#define PK_MAX_EXTRA 4 /* user Variables that device kernels write (PK_KERNEL_SAMPLE_FIELD) */
+#define PK_MAX_EXTRA 8 /* user Variables that device kernels write (PK_KERNEL_SAMPLE_FIELD, compiled user kernels) */
 #define PK_NUM_STATE_CODES 80
 
 typedef struct pk_ctx pk_ctx;

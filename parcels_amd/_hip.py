@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("PARCELS_HIP_LIB", os.path.join(_HERE, "libparcels_hip
 PK_ABI_VERSION = 6
 PK_F32, PK_F64 = 0, 1
 PK_MAX_GRIDS, PK_MAX_FIELDS, PK_MAX_KERNELS, PK_NUM_STATE_CODES = 4, 64, 8, 80
-PK_MAX_EXTRA = 4
+PK_MAX_EXTRA = 8
 PK_KERNEL_SAMPLE_FIELD = 10
 PK_EVAL_MASKED = 0x10000  # pk_eval: or'ed into out_state where the value was zeroed for an out-of-bounds index
 PK_COL_EXTRA0 = 0x1000

@@ -1123,11 +1123,15 @@ static std::vector<ColRef> particle_columns(pk_ctx* ctx) {
         {ctx->host.extra[1], ctx->dev.extra[1], ctx->alt.extra[1], (size_t)(ctx->dev.extra_f32[1] ? 4 : 8), 1},
         {ctx->host.extra[2], ctx->dev.extra[2], ctx->alt.extra[2], (size_t)(ctx->dev.extra_f32[2] ? 4 : 8), 1},
         {ctx->host.extra[3], ctx->dev.extra[3], ctx->alt.extra[3], (size_t)(ctx->dev.extra_f32[3] ? 4 : 8), 1},
+        {ctx->host.extra[4], ctx->dev.extra[4], ctx->alt.extra[4], (size_t)(ctx->dev.extra_f32[4] ? 4 : 8), 1},
+        {ctx->host.extra[5], ctx->dev.extra[5], ctx->alt.extra[5], (size_t)(ctx->dev.extra_f32[5] ? 4 : 8), 1},
+        {ctx->host.extra[6], ctx->dev.extra[6], ctx->alt.extra[6], (size_t)(ctx->dev.extra_f32[6] ? 4 : 8), 1},
+        {ctx->host.extra[7], ctx->dev.extra[7], ctx->alt.extra[7], (size_t)(ctx->dev.extra_f32[7] ? 4 : 8), 1},
         {nullptr, ctx->dev.iter, ctx->alt.iter, 4, 1},  // device only (index PK_NCOLS: beyond the column masks of the ABI)
     };
 }
 constexpr int PK_NCOLS = 12 + PK_MAX_EXTRA;
-static_assert(PK_MAX_EXTRA == 4, "particle_columns lists four extra columns");
+static_assert(PK_MAX_EXTRA == 8, "particle_columns lists eight extra columns");
 
 // exchange the two column sets (sizes / flags stay): after the cell sort and the compaction wrote the new order into `alt`
 static void swap_column_sets(pk_ctx* ctx) {

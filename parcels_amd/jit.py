@@ -729,8 +729,8 @@ def compile_kernel_list(functions, builtin_id, pclass, fieldset, engine, samples
                 raise NotTranslatable(f"Variable '{vn}' is {np.dtype(names[vn].dtype)}: device columns are float32 / float64 / int32 / int64")
             if vn not in dev_vars:
                 dev_vars.append(vn)
-    if len(dev_vars) > 4:
-        raise NotTranslatable("more than 4 user Variables touched by device kernels (PK_MAX_EXTRA)")
+    if len(dev_vars) > _hip.PK_MAX_EXTRA:
+        raise NotTranslatable(f"more than {_hip.PK_MAX_EXTRA} user Variables touched by device kernels (PK_MAX_EXTRA)")
     var_slot = {vn: (k, _ty_of_dtype(names[vn].dtype)) for k, vn in enumerate(dev_vars)}
     next_dt_f32 = "next_dt" in names and np.dtype(names["next_dt"].dtype) != np.float64
     sources, ids, j = [], [], 0

@@ -91,8 +91,10 @@ class Kernel:
                 warnings.warn("Sampling of velocities should normally be done using fieldset.UV or fieldset.UVW object; tread carefully",
                               RuntimeWarning, stacklevel=3)
             self.samples[slot] = (fname, sum(c << (8 * j) for j, c in enumerate(cols)) if vector else cols[0])
-        if len(self.device_variables) > 4:
-            raise ValueError("at most 4 particle Variables can be written by device kernels")
+        from . import _hip as _h
+
+        if len(self.device_variables) > _h.PK_MAX_EXTRA:
+            raise ValueError(f"at most {_h.PK_MAX_EXTRA} particle Variables can be written by device kernels")
 
     @property
     def funcname(self):

@@ -298,3 +298,17 @@ def test_transcendental_functions_on_request(gpu, monkeypatch):
             np.testing.assert_allclose(d1[k], d0[k], rtol=5e-7)
         else:
             assert np.array_equal(d1[k], d0[k], equal_nan=True), k
+
+
+def SixVariables(particles, fieldset):
+    particles.age += particles.dt
+    particles.acc += particles.age
+    particles.temp = particles.acc / 1000
+    particles.speed = particles.dx - particles.dy
+    particles.count += 1
+    particles.flag = particles.count * 2 + particles.particle_id
+
+
+def test_up_to_eight_user_variables_are_device_columns(gpu):
+    p, d = _both([SixVariables, pa.AdvectionRK4])
+    assert len(p._kernel.device_variables) == 6 and (d["count"] >= 12).any()

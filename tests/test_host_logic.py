@@ -43,7 +43,7 @@ def test_ctypes_structs_match_header_layout(tmp_path):
     for n, cls in names.items():
         assert C.sizeof(cls) == int(out[n]), n
     # the members the kernels index by constant
-    assert _hip.PK_MAX_EXTRA == 4 and _hip.PK_MAX_KERNELS == 8
+    assert _hip.PK_MAX_EXTRA == 8 and _hip.PK_MAX_KERNELS == 8
 
 
 def test_no_gpu_fails_loudly():
