@@ -162,6 +162,7 @@ class _Translator(ast.NodeVisitor):
         self.decl: list[str] = []  # members of PkUserLocals
         self.stages: list[list[str]] = [[]]
         self.touched: set[str] = set()
+        self.aliases: set[str] = set()  # locals bound to a bare `particles.<var>`: a write-through view on the host, not a temporary
         self.nslot = 0
 
     # ---- helpers -------------------------------------------------------------------------------------------------------------
@@ -490,7 +491,7 @@ class _Translator(ast.NodeVisitor):
         self.emit(f"{t} = {m.code};")
         return _V(t, "b", array=True)
 
-    def assign(self, tgt, value: _V):
+    def assign(self, tgt, value: _V, alias=False):
         if tgt[0] == "local":
             ty = _strong(value.ty)
             if value.array:
@@ -499,6 +500,7 @@ class _Translator(ast.NodeVisitor):
                 self.locals[tgt[1]] = _V(slot, ty, array=True)
             else:
                 self.locals[tgt[1]] = value  # a scalar stays a (weak) scalar
+            (self.aliases.add if alias else self.aliases.discard)(tgt[1])
         else:
             _, name, mask = tgt
             if mask is not None and value.array:
@@ -506,7 +508,10 @@ class _Translator(ast.NodeVisitor):
             self.store_var(name, value, mask)
 
     def run(self):
-        body = self.fdef.body
+        self.run_body(self.fdef.body, top=True)
+        self.emit("return true;")
+
+    def run_body(self, body, top):
         for i, st in enumerate(body):
             if isinstance(st, ast.Expr) and isinstance(st.value, ast.Constant) and isinstance(st.value.value, str):
                 continue
@@ -528,12 +533,36 @@ class _Translator(ast.NodeVisitor):
                         self.assign(self.target(el), comp)
                 else:
                     tgt = self.target(t)  # (the mask, if any, is evaluated first: it cannot depend on the value)
-                    self.assign(tgt, self.expr(st.value))
+                    bare = isinstance(st.value, ast.Attribute) and isinstance(st.value.value, ast.Name) and st.value.value.id == self.pname
+                    self.assign(tgt, self.expr(st.value), alias=bare)
+                continue
+            if isinstance(st, ast.If):  # only a condition that is a constant of the run (fieldset.<context>, module constants): one branch
+                c = self.try_const(st.test)
+                if c is None or c.array:
+                    raise NotTranslatable("`if` on something other than a constant of the run (elementwise code has no control flow)")
+                self.run_body(st.body if c.const else st.orelse, top=False)
                 continue
             if isinstance(st, ast.AugAssign):
                 tgt = self.target(st.target)
-                if tgt[0] != "var":
-                    raise NotTranslatable("in-place operator on a local (it may alias a particle column)")
+                if tgt[0] == "local":
+                    # a local TEMPORARY (ndarray on the host): in-place ufunc, dtype kept, the result must cast back with 'same_kind'
+                    lname = tgt[1]
+                    if lname not in self.locals or lname in self.aliases or not self.locals[lname].array:
+                        raise NotTranslatable("in-place operator on a local that is a particle column's view or a scalar")
+                    if not isinstance(st.op, (ast.Add, ast.Sub, ast.Mult, ast.Div)):
+                        raise NotTranslatable(f"in-place {type(st.op).__name__}")
+                    cur, val = self.locals[lname], self.expr(st.value)
+                    ty = _promote(cur, val)
+                    if isinstance(st.op, ast.Div) and ty in ("i32", "i64"):
+                        ty = "f64"
+                    if not np.can_cast(np.dtype(_NP[_strong(ty)]), np.dtype(_NP[cur.ty]), "same_kind"):
+                        raise NotTranslatable(f"in-place operator: {_strong(ty)} does not cast back to {cur.ty} (NumPy raises)")
+                    sym = {"Add": "+", "Sub": "-", "Mult": "*", "Div": "/"}[type(st.op).__name__]
+                    ct = _strong(ty)
+                    slot = self.new_slot(cur.ty)
+                    self.emit(f"{slot} = {_cast(_V(f'({_cast(cur, ct)} {sym} {_cast(val, ct)})', ct), cur.ty)};")
+                    self.locals[lname] = _V(slot, cur.ty, array=True)
+                    continue
                 _, name, mask = tgt
                 cur = self.load_var(name)
                 val = self.expr(st.value)
@@ -551,10 +580,9 @@ class _Translator(ast.NodeVisitor):
                 ct = _strong(ty)
                 self.store_var(name, _V(f"({_cast(cur, ct)} {sym} {_cast(val, ct)})", ct, array=True), mask)
                 continue
-            if isinstance(st, ast.Return) and st.value is None and i == len(body) - 1:
+            if isinstance(st, ast.Return) and st.value is None and top and i == len(body) - 1:
                 continue
             raise NotTranslatable(f"statement {type(st).__name__}")
-        self.emit("return true;")
 
 
 class UserKernelSource:

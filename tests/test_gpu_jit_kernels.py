@@ -215,7 +215,7 @@ def test_error_stop_with_an_accumulating_user_kernel(gpu):
 
 def test_what_is_not_elementwise_runs_on_the_host(gpu):
     p, d = _run([pa.AdvectionRK4, NotElementwise], jit=True)
-    assert p._kernel.user_program is None and "If" in p._kernel.jit_report and p._last_stats.get("hosted")
+    assert p._kernel.user_program is None and "`if`" in p._kernel.jit_report and p._last_stats.get("hosted")
     assert np.all(d["acc"] > 0)
 
     def Closure(particles, fieldset):  # defined inside a function, with a free variable: still translatable

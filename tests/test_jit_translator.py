@@ -287,12 +287,40 @@ def test_transcendental_functions_only_on_request(tmp_path, monkeypatch):
     np.testing.assert_allclose(got["age"], ref["age"], rtol=5e-7)
 
 
+def Branches(particles, fieldset):
+    if fieldset.mode == 1:
+        particles.acc += 1
+    elif fieldset.mode == 2:
+        particles.acc += 2
+        if STRICT:
+            particles.age = 0
+    else:
+        particles.acc -= 1
+    tmp = particles.x * 2          # a temporary: in-place operators keep its dtype
+    tmp += particles.dt            # spatial dtype += f64 -> cast back
+    tmp /= 3
+    cnt = particles.count + 1
+    cnt *= 2
+    particles.dz = tmp
+    particles.flag = cnt
+
+
+STRICT = True
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("spatial", [np.float32, np.float64])
+def test_constant_branches_and_local_temporaries(tmp_path, mode, spatial):
+    src = _check(Branches, tmp_path, spatial=spatial, context={"mode": mode}, seed=7 + mode)
+    assert ("age" in src.touched) == (mode == 2)
+
+
 def test_what_the_translator_refuses():
     P = pa.get_default_particle(np.float32).add_variable(pa.Variable("age", dtype=np.float32, initial=0))
     fs = _FakeFieldSet({}, {})
 
     def k_if(particles, fieldset):
-        if fieldset:
+        if particles.age.max() > 1:
             particles.age += 1
 
     def k_reduce(particles, fieldset):
@@ -307,15 +335,15 @@ def test_what_the_translator_refuses():
     def k_intcast(particles, fieldset):
         particles.state += 0.5  # NumPy raises (same_kind): the host path raises it for the user
 
-    def k_local_inplace(particles, fieldset):
-        a = particles.age
-        a += 1
-
     def k_unknown(particles, fieldset):
         particles.nope = 1
 
-    for f, word in ((k_if, "If"), (k_reduce, "call"), (k_random, "call"), (k_trig, "np.sin"), (k_intcast, "does not cast back"),
-                    (k_local_inplace, "in-place operator on a local"), (k_unknown, "no Variable")):
+    def k_view_inplace(particles, fieldset):
+        a = particles.age
+        a += 1
+
+    for f, word in ((k_if, "`if` on something other"), (k_view_inplace, "particle column's view"), (k_reduce, "call"), (k_random, "call"), (k_trig, "np.sin"), (k_intcast, "does not cast back"),
+                    (k_unknown, "no Variable")):
         with pytest.raises(jit.NotTranslatable, match=word):
             jit.translate(f, P, fs, {"age": (0, "f32")}, {})
     assert jit.candidate_variables(k_unknown, P) == [] and jit.candidate_variables(k_trig, P) == ["age"]
