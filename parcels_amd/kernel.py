@@ -160,6 +160,11 @@ class Kernel:
         except jit.NotTranslatable as e:
             self.jit_report = str(e)
             return
+        except (OSError, RuntimeError) as e:  # no hipcc on this machine, a failed compilation: the host path still runs the list
+            self.jit_report = f"{type(e).__name__}: {e}"
+            warnings.warn(f"user kernels could not be compiled for the device ({self.jit_report.splitlines()[0]}); running them on the host path",
+                          KernelWarning, stacklevel=3)
+            return
         self.user_program = prog
         self.kernel_ids = ids
         self.device_variables = dev_vars
