@@ -31,6 +31,8 @@ Prints ONE JSON line (rank 0).  What the objects mean:
   C5 AdvectionRK45 and AdvectionDiffusionM1 on the 4322 x 3059 x 75 curvilinear C-grid with 1e7 particles, each with kernel ms, value,
   a `roofline` by SURVEY 8(d)'s algorithmic bytes (536 / 672 / 568 B per unit; these working sets ARE beyond the caches) plus the counter
   traffic of profiles/pmc_secondary_latest.json, and `check`: 1e5 particle ids re-run through the CPU oracle on the same arrays.
+`user_kernels` (N = 1 only; `--user-kernels 0` switches it off) -- AdvectionRK4 + two user-written Python kernels on the headline FieldSet:
+  compiled into the launch (parcels_amd/jit.py) vs the host path, 2e6 particles, 24 steps, wall seconds.
 `cpu_baseline` -- oracle/fast_agrid_cpu.c (kind "port"): the headline workload restated the way one writes it for a CPU, bit-identical
   to the checker oracle, OpenMP on this box's host cores, bounded sample.
 `cpu_baseline_reference` -- the reference itself (Parcels under oracle/ref_shim.py).  It is Python and /root/reference does not exist
@@ -149,6 +151,31 @@ ALGO_BYTES_PER_STEP_C5_RK45 = 6 * (8 * 4 + 8 * 8) + 96      # per attempt: 6 eva
 ALGO_BYTES_PER_STEP_C5_M1 = 568
 
 
+def user_kernel_runs(n):
+    """The reference's plug-in point #1 on the headline FieldSet: AdvectionRK4 followed by two user-written Python kernels (ageing,
+    delete-when-old), (a) translated and compiled into the fused launch (parcels_amd/jit.py), (b) on the host path (the reference's loop on
+    the host columns), next to (c) AdvectionRK4 alone; wall times include the H2D / D2H of the particle columns."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_user_kernels as bu
+    import parcels_amd as pa
+
+    steps = 24
+    old = os.environ.get("PARCELS_AMD_JIT")
+    try:
+        res = {"particles": n, "steps": steps, "kernels": "AdvectionRK4, Age, DeleteOld",
+               "rk4_alone": bu.run([pa.AdvectionRK4], True, n, steps),
+               "compiled": bu.run([pa.AdvectionRK4, bu.Age, bu.DeleteOld], True, n, steps),
+               "host_path": bu.run([pa.AdvectionRK4, bu.Age, bu.DeleteOld], False, n, steps)}
+    finally:
+        if old is None:
+            os.environ.pop("PARCELS_AMD_JIT", None)
+        else:
+            os.environ["PARCELS_AMD_JIT"] = old
+    res["same_survivors"] = res["compiled"]["remaining"] == res["host_path"]["remaining"]
+    res["speedup_wall"] = res["host_path"]["wall_s"] / max(res["compiled"]["wall_s"], 1e-9)
+    return res
+
+
 def secondary_runs(args):
     """BASELINE configs 3 and 5 at full size on this GPU (tools/bench_configs.py builds them), outside the timed region of the
     headline: per run the particle-steps/s of the fused launch (HIP events on the compute stream), the algorithmic-byte roofline
@@ -226,6 +253,9 @@ def main():
     ap.add_argument("--secondary", type=int, default=1,
                     help="N = 1 only: also run BASELINE configs 3 and 5 (C3 RK4_3D, C5 RK45 + M1) at full size, each with a subset "
                          "re-run through the CPU oracle, and attach them as `secondary` (0 = off)")
+    ap.add_argument("--user-kernels", type=float, default=2e6,
+                    help="N = 1 only, with --secondary: particles of the user-kernel leg (C2 FieldSet, AdvectionRK4 + a user-written ageing and a "
+                         "delete-when-old kernel: compiled into the launch by parcels_amd/jit.py vs the host path); 0 = off")
     ap.add_argument("--secondary-check", type=float, default=1e5, help="particle ids of every secondary run re-run through the oracle")
     ap.add_argument("--secondary-scale", type=float, default=1.0, help="shrinks nx, ny of the secondary grid (1.0 = BASELINE size)")
     ap.add_argument("--secondary-particles", type=float, default=1e7)
@@ -429,6 +459,11 @@ def main():
                 out["secondary"] = secondary_runs(args)
             except Exception as e:  # the headline line must survive a failing secondary leg
                 out["secondary"] = [{"error": repr(e)[:2000]}]
+            if args.user_kernels:
+                try:
+                    out["user_kernels"] = user_kernel_runs(int(args.user_kernels))
+                except Exception as e:
+                    out["user_kernels"] = {"error": repr(e)[:2000]}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -27,7 +27,10 @@ def DeleteOld(particles, fieldset):
 
 def run(kernels, jit, n, steps):
     import parcels_amd as pa
-    from bench import c2_case
+    try:
+        from __main__ import c2_case  # (called from bench.py itself)
+    except ImportError:
+        from bench import c2_case
     from case_utils import build_fieldset
 
     os.environ["PARCELS_AMD_JIT"] = "1" if jit else "0"
