@@ -354,19 +354,25 @@ int32_t pk_execute(pk_ctx* ctx, const pk_exec_params* params, pk_exec_stats* sta
  * pk_exec_stats.first_error_iter is non-zero, this call restores the particle columns to their state before that launch (the launch
  * wrote into the second column set: nothing was copied) and runs it again with max_iters = that index.  Must directly follow the
  * pk_execute / pk_execute_end of the launch (before any pk_particles_* call); stats replace those of the launch. */
-/* User kernels (PK_KERNEL_USER0 ..).  pk_generic_variant: what a launch with `prm` (the real kernel list, user ids included) runs on this
- * context -- key = (float32 fields ? 6 : 0) + (curvilinear main grid ? 3 : 0) + min(interp_uv, 2) and lds (the 1-D coordinate vectors are
- * staged in LDS) name the instantiation of the kernel-list interpreter, typed = NumPy float32 dtype propagation (float32 coordinate
- * arrays: no user kernels), fast = 1 / 2 (3 / 4) when the list has the shape [.., AdvectionRK4 / AdvectionRK4_3D, ..] around sampling-free
- * kernels on a FieldSet the dedicated A-grid (curvilinear C-grid) kernel takes (csrc/pk_fast_agrid.h, pk_fast_cgrid.h): a module whose
- * user kernels sample no field (PK_USER_NOSAMPLE) then also carries that kernel with the user kernels riding along.
+/* User kernels (PK_KERNEL_USER0 ..), compiled at run time (parcels_amd/jit.py).
+ * pk_generic_variant: what a launch with `prm` (the real kernel list, user ids included) runs on this context, given what the user kernels
+ * sample (sample_flags: PK_USER_SAMPLES_UV / _UVW; sample_fids: nsample <= 4 scalar field ids) -- key = (float32 fields ? 6 : 0) +
+ * (curvilinear main grid ? 3 : 0) + min(interp_uv, 2) and lds (the 1-D coordinate vectors are staged in LDS) name the instantiation of the
+ * kernel-list interpreter, typed = NumPy float32 dtype propagation (float32 coordinate arrays: no user kernels), fast = which dedicated
+ * kernel would take the list with the user kernels riding along: 1 / 2 the A-grid kernel 2-D / 3-D (csrc/pk_fast_agrid.h: list of the shape
+ * [.., AdvectionRK4 / AdvectionRK4_3D, ..] around sampling-free recovery kernels and user kernels; sampled scalar fields laid out exactly
+ * like U), 3 / 4 the curvilinear C-grid kernel (csrc/pk_fast_cgrid.h: user kernels that sample nothing), 0 none.
  * pk_set_user_program: the launcher of a module built for exactly that --
  *   void launcher(const void* kargs, int32_t prog, int32_t key, int32_t lds, uint64_t lds_bytes, void* hip_stream)
  * prog 0: the interpreter variant (key, lds); prog 1 / 2 (3 / 4): the dedicated A-grid (C-grid) kernel 2-D / 3-D with key = float32 fields
- * * 2 + float32 particles; it must refuse (abort) what it was not built for.  NULL unregisters.  A kernel list with a user id and no launcher fails. */
-#define PK_USER_NOSAMPLE 1
-int32_t pk_generic_variant(pk_ctx* ctx, const pk_exec_params* prm, int32_t* key, int32_t* lds, int32_t* typed, int32_t* fast);
-int32_t pk_set_user_program(pk_ctx* ctx, void* launcher, int32_t flags);
+ * * 2 + float32 particles; it must refuse (abort) what it was not built for.  flags: PK_USER_RIDE = the module carries the dedicated kernel
+ * pk_generic_variant named, PK_USER_SAMPLES_* and sample_fids as above.  NULL unregisters.  A list with a user id and no launcher fails. */
+#define PK_USER_RIDE 1
+#define PK_USER_SAMPLES_UV 2
+#define PK_USER_SAMPLES_UVW 4
+int32_t pk_generic_variant(pk_ctx* ctx, const pk_exec_params* prm, int32_t sample_flags, int32_t nsample, const int32_t* sample_fids, int32_t* key,
+                           int32_t* lds, int32_t* typed, int32_t* fast);
+int32_t pk_set_user_program(pk_ctx* ctx, void* launcher, int32_t flags, int32_t nsample, const int32_t* sample_fids);
 int32_t pk_execute_rerun(pk_ctx* ctx, int32_t max_iters, pk_exec_stats* stats);
 /* The same in two halves: _begin enqueues the sort + advection kernel + statistics on the compute stream and returns;
  * the host can then stage and enqueue the NEXT field level (pk_field_upload_level async) while the RK sub-steps run;

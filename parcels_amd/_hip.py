@@ -264,8 +264,9 @@ def load():
     lib.pk_particles_d2h_columns.argtypes = [C.c_void_p, C.c_uint32]
     lib.pk_particles_set_mask.argtypes = [C.c_void_p, C.c_void_p]
     lib.pk_particles_checkpoint.argtypes = [C.c_void_p]
-    lib.pk_generic_variant.argtypes = [C.c_void_p, C.POINTER(ExecParams), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
-    lib.pk_set_user_program.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    lib.pk_generic_variant.argtypes = [C.c_void_p, C.POINTER(ExecParams), C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.pk_set_user_program.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
     lib.pk_particles_restore.argtypes = [C.c_void_p]
     lib.pk_particles_snapshot_begin.argtypes = [C.c_void_p, C.c_uint32, C.c_int32]
     lib.pk_particles_snapshot_wait.argtypes = [C.c_void_p, C.c_int32, C.POINTER(ParticlesDesc)]

@@ -97,6 +97,8 @@ struct pk_ctx {
     // launcher of the run-time compiled kernel-list interpreter that carries the user kernels (pk_set_user_program)
     void (*user_launch)(const void*, int32_t, int32_t, int32_t, uint64_t, void*) = nullptr;
     int32_t user_flags = 0;
+    int32_t user_nsample = 0;       // scalar fields the module's user kernels sample (PK_USER_RIDE modules)
+    int32_t user_sample_fid[4] = {0, 0, 0, 0};
     // pk_particles_checkpoint: one packed device copy of every column (+ the row permutation of the cell sort)
     char* d_chk = nullptr;
     size_t chk_bytes = 0;
@@ -1901,7 +1903,7 @@ static int32_t fill_fastc(pk_ctx* ctx, const pk_exec_params* prm, KArgs& a, bool
 // as side kernels, pk_kernels.h: side_kernel): exactly one AdvectionRK4 / AdvectionRK4_3D anywhere in the list, everything else a
 // sampling-free recovery kernel or a user kernel, and a module whose user kernels sample no field.  -1: no; 0 / 1: yes, 2-D / 3-D.
 static int user_fast_shape(const pk_exec_params* prm, int32_t user_flags) {
-    if (!(user_flags & PK_USER_NOSAMPLE) || prm->body_only) return -1;
+    if (!(user_flags & PK_USER_RIDE) || prm->body_only) return -1;
     int nadv = 0, d3 = 0;
     for (int k = 0; k < prm->nk; k++) {
         const int id = prm->kernels[k];
@@ -1912,7 +1914,30 @@ static int user_fast_shape(const pk_exec_params* prm, int32_t user_flags) {
             return -1;
         }
     }
-    return nadv == 1 ? d3 : -1;
+    if (nadv != 1) return -1;
+    if ((user_flags & PK_USER_SAMPLES_UVW) && !d3) return -1;  // a 2-D host kernel carries no W
+    return d3;
+}
+// the scalar fields a riding module samples must look exactly like U to the dedicated A-grid kernel: same grid, dtype, layout, time axis,
+// ring, XLinear -- then only the base pointer differs (FastA::S)
+static bool fill_fast_scalars(pk_ctx* ctx, const pk_exec_params* prm, FastA& F, int nsample, const int32_t* fids) {
+    if (nsample < 0 || nsample > 4) return false;
+    const HostField& U = ctx->fields[prm->fU];
+    F.ns = 0;
+    for (int k = 0; k < nsample; k++) {
+        const int fid = fids[k];
+        if (fid < 0 || fid >= (int)ctx->fields.size()) return false;
+        const HostField& S = ctx->fields[fid];
+        const DField &x = S.d, &y = U.d;
+        const bool same = x.grid == y.grid && x.ncomp == 1 && x.dtype == y.dtype && x.st_t == y.st_t && x.st_z == y.st_z && x.st_y == y.st_y &&
+                          x.st_x == y.st_x && x.nt == y.nt && x.nz == y.nz && x.ny == y.ny && x.nx == y.nx && x.nslots == y.nslots &&
+                          x.has_time_interval == y.has_time_interval && x.is_const == 0 && S.time == U.time;
+        if (!same) return false;
+        F.sfid[F.ns] = fid;
+        F.S[F.ns] = (const char*)x.data;
+        F.ns++;
+    }
+    return true;
 }
 
 int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
@@ -1987,12 +2012,14 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
         bool fast_a = false, fast_c = false;  // a.fast / a.fastc share storage: at most one is filled
         size_t cgrid_lds = 0;
         const int ufast = (has_user && use_lds) ? user_fast_shape(prm, ctx->user_flags) : -1;
+        const bool user_samples = ctx->user_nsample > 0 || (ctx->user_flags & (PK_USER_SAMPLES_UV | PK_USER_SAMPLES_UVW));
         if (ufast >= 0 && !curv) {
             rc = fill_fast(ctx, prm, a, ufast == 1);
             if (rc) return rc;
+            if (a.fast.ok && !fill_fast_scalars(ctx, prm, a.fast, ctx->user_nsample, ctx->user_sample_fid)) a.fast.ok = 0;
             fast_a = a.fast.ok != 0;
             if (fast_a) prog = ufast ? PROG_RK4_3D : PROG_RK4;
-        } else if (ufast >= 0 && curv) {
+        } else if (ufast >= 0 && curv && !user_samples) {
             rc = fill_fastc(ctx, prm, a, ufast == 1, cgrid_lds);
             if (rc) return rc;
             fast_c = a.fastc.ok != 0;
@@ -2120,8 +2147,9 @@ int32_t pk_execute_end(pk_ctx* ctx, pk_exec_stats* stats) {
     return 0;
 }
 
-int32_t pk_generic_variant(pk_ctx* ctx, const pk_exec_params* prm, int32_t* key, int32_t* lds, int32_t* typed, int32_t* fast) {
-    if (!ctx || !prm || !key || !lds || !typed || !fast) return -2;
+int32_t pk_generic_variant(pk_ctx* ctx, const pk_exec_params* prm, int32_t sample_flags, int32_t nsample, const int32_t* sample_fids, int32_t* key,
+                           int32_t* lds, int32_t* typed, int32_t* fast) {
+    if (!ctx || !prm || !key || !lds || !typed || !fast || (nsample > 0 && !sample_fids)) return -2;
     KArgs a;
     size_t lds_bytes = 0;
     int use_lds = 0;
@@ -2132,12 +2160,14 @@ int32_t pk_generic_variant(pk_ctx* ctx, const pk_exec_params* prm, int32_t* key,
     *lds = use_lds;
     *typed = ctx_is_typed(ctx) ? 1 : 0;
     *fast = 0;
-    const int ufast = (use_lds && !*typed) ? user_fast_shape(prm, PK_USER_NOSAMPLE) : -1;
+    const int32_t sflags = PK_USER_RIDE | (sample_flags & (PK_USER_SAMPLES_UV | PK_USER_SAMPLES_UVW));
+    const bool samples = nsample > 0 || (sample_flags & (PK_USER_SAMPLES_UV | PK_USER_SAMPLES_UVW));
+    const int ufast = (use_lds && !*typed) ? user_fast_shape(prm, sflags) : -1;
     if (ufast >= 0 && ctx->grids[a.main_grid].d.kind != 1) {
         const int32_t rc2 = fill_fast(ctx, prm, a, ufast == 1);
         if (rc2) return rc2;
-        if (a.fast.ok) *fast = 1 + ufast;
-    } else if (ufast >= 0) {  // the dedicated curvilinear C-grid kernel (a first launch without `ei` guesses still runs the interpreter)
+        if (a.fast.ok && fill_fast_scalars(ctx, prm, a.fast, nsample, sample_fids)) *fast = 1 + ufast;
+    } else if (ufast >= 0 && !samples) {  // the dedicated curvilinear C-grid kernel (a first launch without `ei` guesses still runs the interpreter)
         pk_exec_params guessed = *prm;
         guessed.have_guess0 = 1;
         size_t cl = 0;
@@ -2147,11 +2177,14 @@ int32_t pk_generic_variant(pk_ctx* ctx, const pk_exec_params* prm, int32_t* key,
     }
     return 0;
 }
-int32_t pk_set_user_program(pk_ctx* ctx, void* launcher, int32_t flags) {
+int32_t pk_set_user_program(pk_ctx* ctx, void* launcher, int32_t flags, int32_t nsample, const int32_t* sample_fids) {
     if (!ctx) return -2;
     if (ctx->in_flight) return ctx->fail("pk_set_user_program: a launch is in flight (call pk_execute_end)");
+    if (nsample < 0 || nsample > 4 || (nsample > 0 && !sample_fids)) return ctx->fail("pk_set_user_program: 0 .. 4 sampled scalar fields");
     ctx->user_launch = (void (*)(const void*, int32_t, int32_t, int32_t, uint64_t, void*))launcher;
     ctx->user_flags = launcher ? flags : 0;
+    ctx->user_nsample = launcher ? nsample : 0;
+    for (int k = 0; k < 4; k++) ctx->user_sample_fid[k] = (launcher && k < nsample) ? sample_fids[k] : 0;
     return 0;
 }
 

@@ -113,6 +113,11 @@ struct FastA {
     const double* tab;                          // global copy of the interleaved coordinate tables: time | depth | lat | lon
     double tlen, t0, t1, z0, z1, y0, y1, x0, x1;
     double deg2m, inv_deg2m;
+    // scalar fields a compiled user kernel samples while it rides in the dedicated kernel (parcels_amd/jit.py): same grid, dtype, layout,
+    // time axis and ring as U -- only the base pointer differs -- and XLinear; sfid: their field ids (what Request::fidx names)
+    int32_t ns, pad1;
+    int32_t sfid[4];
+    const char* S[4];
 };
 
 // Wave-uniform constants of the fast path for CGrid_Velocity on a spherical curvilinear C-grid with float64 node coordinates

@@ -314,4 +314,73 @@ PK_DEV void eval_uvw_fast(const KArgs& a, const FastTabs& T, FCtx& c, double t, 
     w = ww;
 }
 
+#ifdef PK_USER_KERNELS
+// Field.eval (field.py:145-185) with XLinear for scalar field `slot` of FastA::S at the same evaluation site: the searches, hints, memo
+// and state rules of eval_uvw_fast, one gather, no unit conversion.  Only in run-time compiled modules (a user kernel that samples a
+// scalar field rides in the dedicated kernel); the arithmetic is xlinear<FT>'s, which the parity tests compare it with at rtol 0.
+template <class FT, bool PF>
+PK_DEV double eval_scalar_fast(const KArgs& a, const FastTabs& T, FCtx& c, int slot, double t, double z, double y, double x) {
+    const FastA& F = a.fast;
+    int ti = 0;
+    double tau = 0.0;
+    if (F.has_ti) {
+        if (!(0 <= t) || !(t <= F.tlen)) {
+            c.state = PK_ERROROUTSIDETIMEINTERVAL;
+            return 0.0;
+        }
+        if (t != c.mt) {
+            int idx;
+            fast_search(T.time, F.nt, F.t0, F.t1, t, c.ht, idx, c.mtau);
+            c.mt = t;
+        }
+        ti = c.ht;
+        tau = c.mtau;
+    }
+    int zi = 0, yi = 0, xi = 0;
+    double zeta = 0.0, eta = 0.0, xsi = 0.0;
+    if (F.has_z) {
+        if (!(z == c.mz)) {
+            fast_search(T.depth, F.gnz, F.z0, F.z1, z, c.hz, c.zi, c.mzeta);
+            c.mz = z;
+        }
+        zi = c.zi;
+        zeta = c.mzeta;
+    }
+    if (F.has_y) fast_search(T.lat, F.gny, F.y0, F.y1, y, c.hy, yi, eta);
+    if (F.has_x) fast_search(T.lon, F.gnx, F.x0, F.x1, x, c.hx, xi, xsi);
+    c.ei = (int32_t)((uint32_t)xi * F.ex + (uint32_t)yi * F.ey + (uint32_t)zi * F.ez);
+    if ((xi | yi | zi) < 0) {
+        int s = c.state;
+        if ((xi == RIGHT_OUT_OF_BOUNDS || yi == RIGHT_OUT_OF_BOUNDS || zi == RIGHT_OUT_OF_BOUNDS) && s < PK_ERROROUTOFBOUNDS) s = PK_ERROROUTOFBOUNDS;
+        if (zi == LEFT_OUT_OF_BOUNDS && s < PK_ERRORTHROUGHSURFACE) s = PK_ERRORTHROUGHSURFACE;
+        const bool bad = !(isfinite(xsi) && isfinite(eta) && isfinite(zeta) && isfinite(tau));
+        if (bad && s < PK_ERRORINTERPOLATION) s = PK_ERRORINTERPOLATION;
+        c.state = s;
+        return 0.0;
+    }
+    const bool lenT = tau > 0, lenZ = !(zeta <= 0);
+    const uint32_t b00 = ((uint32_t)zi * F.st_z + (uint32_t)yi * F.st_y + (uint32_t)xi) * (uint32_t)sizeof(FT);
+    const double omt = 1 - tau, omz = 1 - zeta, omx = 1 - xsi, ome = 1 - eta;
+    const double w00 = omx * ome, w01 = xsi * ome, w10 = omx * eta, w11 = xsi * eta;
+    int s0 = ti, s1 = ti + 1;
+    if (F.nslots < F.nt) {
+        s0 = (int)((uint32_t)s0 % (uint32_t)F.nslots);
+        s1 = (int)((uint32_t)s1 % (uint32_t)F.nslots);
+    }
+    const char* base = F.S[slot];
+    const char* l0 = base + (int64_t)s0 * F.lvl_b;
+    const char* l1 = base + (int64_t)s1 * F.lvl_b;
+    Rows r;
+    double val;
+    if (lenT && lenZ) { load_rows<FT, true, true>(r, l0, l1, b00, F.dyb, F.dzb); val = interp_rows<true, true>(r, tau, omt, zeta, omz, w00, w01, w10, w11); }
+    else if (lenT) { load_rows<FT, true, false>(r, l0, l1, b00, F.dyb, F.dzb); val = interp_rows<true, false>(r, tau, omt, zeta, omz, w00, w01, w10, w11); }
+    else if (lenZ) { load_rows<FT, false, true>(r, l0, l1, b00, F.dyb, F.dzb); val = interp_rows<false, true>(r, tau, omt, zeta, omz, w00, w01, w10, w11); }
+    else { load_rows<FT, false, false>(r, l0, l1, b00, F.dyb, F.dzb); val = interp_rows<false, false>(r, tau, omt, zeta, omz, w00, w01, w10, w11); }
+    if (__builtin_expect(val != val, 0)) {
+        if (c.state < PK_ERRORINTERPOLATION) c.state = PK_ERRORINTERPOLATION;
+    }
+    return val;
+}
+#endif
+
 }  // namespace pk

@@ -600,7 +600,8 @@ __global__ void __launch_bounds__(wg_size(KIND, LDS), (KIND == 1 || INTERP != 0)
 
 #ifdef PK_USER_KERNELS
 // A kernel of the list that rides along in a DEDICATED kernel (pk_fast_agrid.h / pk_fast_cgrid.h): a sampling-free recovery kernel or a
-// user kernel that samples no field (the host checks: pk_set_user_program flag PK_USER_NOSAMPLE), so its stage machine ends in stage 0.
+// user kernel that samples no field (the host checks what the module's kernels sample: pk_set_user_program), so its stage machine ends in
+// stage 0.
 PK_DEV void side_kernel(const KArgs& a, int kid, int kslot, int& state, bool pf, int64_t row, double& t, double& z, double& y, double& x,
                         double& dz, double& dy, double& dx, double& dt) {
     if (kid == PK_KERNEL_DELETE_ON_ERROR) {
@@ -631,6 +632,53 @@ PK_DEV void side_kernel(const KArgs& a, int kid, int kslot, int& state, bool pf,
     state = c.state;
 }
 PK_DEV bool is_rk4_id(int kid) { return kid == PK_KERNEL_ADVECTION_RK4 || kid == PK_KERNEL_ADVECTION_RK4_3D; }
+
+// The same inside the dedicated A-grid kernel, where a user kernel may also SAMPLE: the velocity field (eval_uvw_fast) or a scalar field of
+// FastA::S (eval_scalar_fast; the host lists there what the module's kernels sample and checks that they share U's layout).  The stage
+// machine of the kernel runs to its end here; every sample shares the search hints and the time / depth memo of the advection kernel.
+template <class FT, bool PF, bool D3>
+PK_DEV void side_kernel_fast(const KArgs& a, const FastTabs& ft, FCtx& fc, int kid, int kslot, int64_t row, double& t, double& z, double& y,
+                             double& x, double& dz, double& dy, double& dx, double& dt) {
+    if (kid == PK_KERNEL_DELETE_ON_ERROR) {
+        if (fc.state >= PK_ERROR) fc.state = PK_DELETE;
+        return;
+    }
+    if (kid == PK_KERNEL_DELETE_OUT_OF_BOUNDS) {
+        if (fc.state == PK_ERROROUTOFBOUNDS || fc.state == PK_ERRORTHROUGHSURFACE) fc.state = PK_DELETE;
+        return;
+    }
+    PState p;
+    p.t = t; p.z = z; p.y = y; p.x = x; p.dz = dz; p.dy = dy; p.dx = dx; p.dt = dt;
+    p.next_dt = 0.0;
+    p.id = a.p.particle_id[row];
+    PCtx c;
+    c.state = fc.state;
+    c.pf = PF;
+    c.row = row;
+    c.hz = c.hy = c.hx = c.ht = 0;
+    c.hyx_valid = false;
+    c.first_eval = 0u;
+    c.u32 = c.v32 = c.oob = false;
+    c.ei0 = c.ei1 = c.ei2 = c.ei3 = 0;
+    KLocal L;
+    Request rq;
+#pragma unroll 1
+    for (int stage = 0; !user_prepare(a, kid - PK_KERNEL_USER0, stage, kslot, c, p, L, rq); stage++) {
+        double u = 0.0, v = 0.0, w = 0.0;
+        fc.state = c.state;
+        if (rq.kind == RQ_SCALAR) {
+            int slot = 0;
+            for (int k = 1; k < a.fast.ns; k++) slot = a.fast.sfid[k] == rq.fidx ? k : slot;
+            u = eval_scalar_fast<FT, PF>(a, ft, fc, slot, rq.t, rq.z, rq.y, rq.x);
+        } else {
+            eval_uvw_fast<FT, PF, D3>(a, ft, fc, rq.t, rq.z, rq.y, rq.x, PF && rq.f32, u, v, w);
+        }
+        c.state = fc.state;
+        L.r[3] = u; L.r[4] = v; L.r[5] = w;
+    }
+    t = p.t; z = p.z; y = p.y; x = p.x; dz = p.dz; dy = p.dy; dx = p.dx; dt = p.dt;
+    fc.state = c.state;
+}
 #endif
 
 // ---- the headline kernel: AdvectionRK4 / AdvectionRK4_3D on a rectilinear A-grid with float64 coordinates -----------------
@@ -696,7 +744,7 @@ __global__ void __launch_bounds__(256, PK_MIN_WAVES_FAST) advect_fast_kernel(con
                 int adv = 0;
                 for (; adv < prm.nk && !is_rk4_id(prm.kernels[adv]); adv++) {
                     attempts++;
-                    side_kernel(a, prm.kernels[adv], adv, c.state, pf, row(), pt, pz, py, px, pdz, pdy, pdx, pdt);
+                    side_kernel_fast<FT, pf, D3>(a, ft, c, prm.kernels[adv], adv, row(), pt, pz, py, px, pdz, pdy, pdx, pdt);
                 }
 #else
                 constexpr int adv = 0;
@@ -729,7 +777,7 @@ __global__ void __launch_bounds__(256, PK_MIN_WAVES_FAST) advect_fast_kernel(con
                     attempts++;
 #ifdef PK_USER_KERNELS
                     if (kid >= PK_KERNEL_USER0) {
-                        side_kernel(a, kid, k, c.state, pf, row(), pt, pz, py, px, pdz, pdy, pdx, pdt);
+                        side_kernel_fast<FT, pf, D3>(a, ft, c, kid, k, row(), pt, pz, py, px, pdz, pdy, pdx, pdt);
                         continue;
                     }
 #endif

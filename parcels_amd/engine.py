@@ -526,8 +526,10 @@ class DeviceEngine:
         cur = getattr(self, "_user_program", None)
         if program is cur:
             return
+        fids = (C.c_int32 * 4)(*(list(program.sample_fids) + [0] * 4)[:4]) if program is not None else (C.c_int32 * 4)()
         self.ctx.check(self.lib.pk_set_user_program(self.ctx.handle, C.c_void_p(program.launcher() if program is not None else None),
-                                                    int(program.flags) if program is not None else 0), "pk_set_user_program")
+                                                    int(program.flags) if program is not None else 0,
+                                                    len(program.sample_fids) if program is not None else 0, fids), "pk_set_user_program")
         self._user_program = program
 
     def execute(self, kernel_ids, *, endtime, dt0, context=None, seed=0, have_guess0=0, sort_by_cell=0, t_start=None, samples=None,

@@ -162,6 +162,7 @@ class _Translator(ast.NodeVisitor):
         self.decl: list[str] = []  # members of PkUserLocals
         self.stages: list[list[str]] = [[]]
         self.touched: set[str] = set()
+        self.sampled: list = []  # ('UV' | 'UVW' | scalar field id) of every sample, in order
         self.aliases: set[str] = set()  # locals bound to a bare `particles.<var>`: a write-through view on the host, not a temporary
         self.nslot = 0
 
@@ -288,10 +289,12 @@ class _Translator(ast.NodeVisitor):
             if fld is not self.fieldset.fields.get(name):
                 raise NotTranslatable("vector field alias")
             kind, n, fid = ("RQ_UVW", 3, 0) if name == "UVW" else ("RQ_UV", 2, 0)
+            self.sampled.append(name)
         else:
             if name in ("U", "V", "W"):
                 raise NotTranslatable("sampling a velocity component by itself (the reference warns: host path)")
             kind, n, fid = "RQ_SCALAR", 1, self.field_ids[name]
+            self.sampled.append(int(fid))
         self.emit(f"rq.kind = {kind}; rq.fidx = {fid}; rq.f32 = c.pf; rq.t = p.t; rq.z = p.z; rq.y = p.y; rq.x = p.x; return false;")
         self.stages.append([])
         out = []
@@ -586,8 +589,8 @@ class _Translator(ast.NodeVisitor):
 
 
 class UserKernelSource:
-    def __init__(self, name, decl, stages, touched):
-        self.name, self.decl, self.stages, self.touched = name, decl, stages, touched
+    def __init__(self, name, decl, stages, touched, sampled=()):
+        self.name, self.decl, self.stages, self.touched, self.sampled = name, decl, stages, touched, list(sampled)
 
     def case_body(self) -> str:
         out = ["switch (stage) {"]
@@ -607,7 +610,7 @@ def translate(func, pclass, fieldset, var_slot, field_ids, next_dt_f32=False, sl
     except (OSError, TypeError, SyntaxError, IndentationError) as e:
         raise NotTranslatable(f"source of {getattr(func, '__name__', func)!r} is not available: {e}") from None
     tr.run()
-    return UserKernelSource(func.__name__, tr.decl, tr.stages, tr.touched)
+    return UserKernelSource(func.__name__, tr.decl, tr.stages, tr.touched, tr.sampled)
 
 
 def candidate_variables(func, pclass):
@@ -692,10 +695,14 @@ class UserProgram:
         cases = "\n".join(f"        case {k}: {{\n" + textwrap.indent(s.case_body(), "            ") + "\n        }" for k, s in enumerate(sources))
         ft = "float" if key >= 6 else "double"
         kind, interp = (key % 6) // 3, key % 3
-        nosample = all(len(s.stages) == 1 and "next_dt" not in s.touched for s in sources)
-        self.flags = 1 if (nosample and fast) else 0  # PK_USER_NOSAMPLE: the library may choose the dedicated kernel
+        # what the kernels sample decides whether the list may ride in a dedicated kernel (pk_generic_variant was asked with the same lists)
+        sampled = [x for src in sources for x in src.sampled]
+        self.sample_fids = sorted({x for x in sampled if isinstance(x, int)})
+        self.sample_flags = (2 if "UV" in sampled else 0) | (4 if "UVW" in sampled else 0)  # PK_USER_SAMPLES_UV / _UVW
+        rides = fast and all("next_dt" not in src.touched for src in sources) and len(self.sample_fids) <= 4
+        self.flags = (1 | self.sample_flags) if rides else self.sample_flags  # PK_USER_RIDE: the module carries the dedicated kernel
         fast_launch = ""
-        if self.flags:
+        if self.flags & 1:
             fkey = (2 if key >= 6 else 0) + (1 if particles_f32 else 0)
             d3 = "true" if fast in (2, 4) else "false"
             pfm = 1 if particles_f32 else 0
@@ -708,7 +715,12 @@ class UserProgram:
             fast_launch = f"        if (prog == {int(fast)} && key == {fkey}) {{\n            {launch}\n            return;\n        }}"
         self.source = _TEMPLATE.format(names=", ".join(s.name for s in sources), decl=decl, cases=cases, key=key, lds=lds, ft=ft, kind=kind,
                                        interp=interp, ldsb="true" if lds else "false", fast_launch=fast_launch)
-        self.digest = hashlib.sha256((self.source + _csrc_hash()).encode()).hexdigest()[:20]
+        # (measured on C2 with a sampling kernel riding in the dedicated A-grid kernel, tools/bench_user_kernels.py: 4 waves per SIMD 12.6 ms,
+        # 3 waves 13.8 ms, 2 waves 12.5 ms -- the library's own occupancy target stays; PARCELS_AMD_JIT_FAST_WAVES overrides for A/B runs)
+        self.defines = []
+        if os.environ.get("PARCELS_AMD_JIT_FAST_WAVES"):
+            self.defines.append("-DPK_MIN_WAVES_FAST=" + os.environ["PARCELS_AMD_JIT_FAST_WAVES"])
+        self.digest = hashlib.sha256((self.source + " ".join(self.defines) + _csrc_hash()).encode()).hexdigest()[:20]
         self.path = os.path.join(cache_dir(), f"user_{self.digest}.so")
         self._lib = None
 
@@ -722,7 +734,7 @@ class UserProgram:
         with open(src, "w") as f:
             f.write(self.source)
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unused-function",
+        cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unused-function", *self.defines,
                f"-I{_CSRC}", f"-I{_INCLUDE}", src, "-o", tmp]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
@@ -772,12 +784,16 @@ def compile_kernel_list(functions, builtin_id, pclass, fieldset, engine, samples
     # which programs this list runs as on this FieldSet: the variant of the kernel-list interpreter, and whether the dedicated A-grid kernel
     # would take it if the user kernels sample nothing
     prm = engine.make_params(ids, endtime=0.0, dt0=1.0, context=fieldset.context, samples=samples or {})
+    sampled = [x for src in sources for x in src.sampled]
+    fids = sorted({x for x in sampled if isinstance(x, int)})
+    sflags = (2 if "UV" in sampled else 0) | (4 if "UVW" in sampled else 0)
     key, lds, typed, fast = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
-    engine.ctx.check(engine.lib.pk_generic_variant(engine.ctx.handle, C.byref(prm), C.byref(key), C.byref(lds), C.byref(typed), C.byref(fast)),
-                     "pk_generic_variant")
+    cf = (C.c_int32 * 4)(*(fids + [0] * 4)[:4])
+    engine.ctx.check(engine.lib.pk_generic_variant(engine.ctx.handle, C.byref(prm), sflags, min(len(fids), 4), cf, C.byref(key), C.byref(lds), C.byref(typed),
+                                                   C.byref(fast)), "pk_generic_variant")
     if typed.value:
         raise NotTranslatable("float32 coordinate arrays (NumPy dtype propagation of the typed program)")
-    prog = UserProgram(sources, key.value, lds.value, fast=fast.value, particles_f32=np.dtype(names["x"].dtype) == np.float32)
+    prog = UserProgram(sources, key.value, lds.value, fast=(fast.value if len(fids) <= 4 else 0), particles_f32=np.dtype(names["x"].dtype) == np.float32)
     prog.launcher()  # builds (or finds in the cache) and loads the module
     return ids, prog, dev_vars
 

@@ -109,6 +109,10 @@ def SampleT(particles, fieldset):
     particles.temp = fieldset.T[particles]
 
 
+def SampleS32(particles, fieldset):
+    particles.temp = fieldset.S[particles]
+
+
 def SampleExpr(particles, fieldset):
     t = fieldset.T[particles]
     s = fieldset.S[particles]
@@ -175,7 +179,10 @@ def test_periodic_boundary_and_accumulator(gpu):
 
 def test_scalar_and_vector_samples(gpu):
     p, _ = _both([pa.AdvectionRK4, SampleT])
-    assert p._last_stats["program"] == 2 and p._kernel.user_program.flags == 0  # a sampling kernel: the kernel-list interpreter
+    # T shares U's grid, dtype and layout: the sampling kernel rides in the dedicated A-grid kernel (FastA::S, eval_scalar_fast)
+    assert p._last_stats["program"] == 100 and p._kernel.user_program.flags & 1 and p._kernel.user_program.sample_fids
+    p, _ = _both([pa.AdvectionRK4, SampleS32])
+    assert p._last_stats["program"] == 2 and not p._kernel.user_program.flags & 1  # S is float32, U float64: the kernel-list interpreter
     _both([Age, SampleExpr, pa.AdvectionRK4], spatial=np.float64)
     _both([SampleSpeed, pa.AdvectionRK2], mesh="spherical")
 
