@@ -347,3 +347,36 @@ def test_what_the_translator_refuses():
         with pytest.raises(jit.NotTranslatable, match=word):
             jit.translate(f, P, fs, {"age": (0, "f32")}, {})
     assert jit.candidate_variables(k_unknown, P) == [] and jit.candidate_variables(k_trig, P) == ["age"]
+
+
+def test_ranks_of_one_node_can_compile_the_same_module_at_once(tmp_path):
+    """One process per GPU: every rank translates the same kernel list and builds the same module into the same cache directory at the same
+    time.  Private temporaries + an atomic rename: every build succeeds, one module remains, and it exports the launcher."""
+    script = tmp_path / "build_one.py"
+    script.write_text(f"""
+import sys
+sys.path.insert(0, {repr(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))})
+sys.path.insert(0, {repr(os.path.dirname(os.path.abspath(__file__)))})
+import numpy as np
+import parcels_amd as pa
+from parcels_amd import jit
+import test_jit_translator as T
+P = pa.get_default_particle(np.float32).add_variable(pa.Variable("age", dtype=np.float32, initial=0))
+src = jit.translate(T.InPlaceAge, P, T._FakeFieldSet({{}}, {{}}), {{"age": (0, "f32")}}, {{}}, slot_prefix="k0_")
+prog = jit.UserProgram([src], 0, 1, fast=1, particles_f32=True)
+print(prog.build())
+""")
+    env = dict(os.environ, PARCELS_AMD_JIT_CACHE=str(tmp_path / "cache"))
+    procs = [subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for _ in range(4)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-500:] for o in outs]
+    paths = {o[0].strip().split("\\n")[-1] for o in outs}
+    assert len(paths) == 1
+    files = sorted(os.listdir(tmp_path / "cache"))
+    assert [f for f in files if f.endswith(".so")] == [os.path.basename(paths.pop())] and not [f for f in files if f.endswith(".tmp")]
+    sym = subprocess.run(["nm", "-D", str(tmp_path / "cache" / [f for f in files if f.endswith(".so")][0])], capture_output=True, text=True).stdout
+    assert " T pk_user_launch" in sym
+
+
+def InPlaceAge(particles, fieldset):
+    particles.age += particles.dt
