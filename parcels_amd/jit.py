@@ -242,7 +242,7 @@ class _Translator(ast.NodeVisitor):
             setattr(ctx, k, v)
         env[self.fname] = ctx
         try:
-            val = eval(compile(ast.Expression(body=node), "<kernel>", "eval"), env)  # noqa: S307 -- the user's own kernel source
+            val = eval(compile(ast.fix_missing_locations(ast.Expression(body=node)), "<kernel>", "eval"), env)  # noqa: S307 -- the user's own kernel source
         except Exception:
             return None
         if isinstance(val, (bool, int, float, np.generic)):
@@ -390,8 +390,29 @@ class _Translator(ast.NodeVisitor):
         name = self.np_func(node)
         if name is None or node.keywords:
             raise NotTranslatable("call of something other than a supported numpy function")
+        # the ufuncs behind the operators, called by name
+        binop = {"add": ast.Add, "subtract": ast.Sub, "multiply": ast.Mult, "divide": ast.Div, "true_divide": ast.Div, "mod": ast.Mod, "remainder": ast.Mod}
+        cmpop = {"less": ast.Lt, "less_equal": ast.LtE, "greater": ast.Gt, "greater_equal": ast.GtE, "equal": ast.Eq, "not_equal": ast.NotEq}
+        if name in binop and len(node.args) == 2:
+            return self.e_BinOp(ast.BinOp(left=node.args[0], op=binop[name](), right=node.args[1]))
+        if name in cmpop and len(node.args) == 2:
+            return self.e_Compare(ast.Compare(left=node.args[0], ops=[cmpop[name]()], comparators=[node.args[1]]))
+        if name == "negative" and len(node.args) == 1:
+            return self.e_UnaryOp(ast.UnaryOp(op=ast.USub(), operand=node.args[0]))
+        if name == "square" and len(node.args) == 1:
+            return self.e_BinOp(ast.BinOp(left=node.args[0], op=ast.Pow(), right=ast.Constant(2)))
         args = [self.expr(a) for a in node.args]
         arr = any(a.array for a in args)
+        if name == "sign" and len(args) == 1:  # -1 / 0 / +1 in the argument's dtype, NaN stays NaN
+            v = args[0]
+            ty = _strong(v.ty)
+            if ty == "b":
+                raise NotTranslatable("np.sign of a boolean")
+            t = self.new_slot(ty)
+            self.emit(f"{t} = {_cast(v, ty)};")
+            one = f"(({_CT[ty]})1)"
+            nanpart = f"({t} != {t}) ? {t} : " if ty[0] == "f" else ""
+            return _V(f"({nanpart}(({t} > 0) ? {one} : (({t} < 0) ? -{one} : (({_CT[ty]})0))))", ty, array=arr)
         if name == "where" and len(args) == 3:
             c, a, b = args
             ty = _strong(_promote(a, b))

@@ -287,6 +287,20 @@ def test_transcendental_functions_only_on_request(tmp_path, monkeypatch):
     np.testing.assert_allclose(got["age"], ref["age"], rtol=5e-7)
 
 
+def ByName(particles, fieldset):
+    a = np.add(particles.age, particles.count)            # f32 + int32 -> f64
+    b = np.multiply(np.subtract(particles.x, 0.5), np.negative(particles.age))
+    particles.acc = np.divide(a, 3) + b - np.mod(particles.acc, 2) + np.remainder(particles.age, -1.5)
+    particles.age = np.square(particles.age) - particles.dy**2 + np.sign(particles.dx) * np.sign(particles.acc)
+    particles.flag = np.sign(particles.flag) * 4 + np.where(np.less_equal(particles.count, 2) | np.not_equal(particles.state, 0), 1, 0)
+    particles.count = np.where(np.greater(particles.acc, particles.age) & np.equal(particles.count, particles.count), 5, particles.count)
+
+
+@pytest.mark.parametrize("spatial", [np.float32, np.float64])
+def test_ufuncs_called_by_name(tmp_path, spatial):
+    _check(ByName, tmp_path, spatial=spatial, seed=11)
+
+
 def Branches(particles, fieldset):
     if fieldset.mode == 1:
         particles.acc += 1
