@@ -375,3 +375,16 @@ def test_bench_gpus_flag_decides_the_world_size():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_integration_notes_name_every_entry_point():
+    """INTEGRATION.md maps the C ABI to the reference interfaces it replaces: no exported function may be missing from it."""
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "parcels_hip.h")).read()
+    notes = open(os.path.join(root, "INTEGRATION.md")).read()
+    names = set(re.findall(r"^(?:int32_t|void|double|const char\*)\s+\*?(pk_[a-z0-9_]+)\s*\(", header, flags=re.M))
+    assert len(names) > 30
+    missing = sorted(n for n in names if n not in notes)
+    assert not missing, missing
