@@ -358,13 +358,16 @@ class _Translator(ast.NodeVisitor):
             ca, cb = (_cast(a, ty), _cast(b, ty)) if ty not in _WEAK else (f"((double)({a.code}))", f"((double)({b.code}))")
             return _V(f"({ca} / {cb})", ty, array=arr)
         if isinstance(op, ast.Mod):  # np.remainder on floats: fmod, then the sign of the divisor (npy_divmod)
+            rty = ty
+            if ty == "wf":  # two Python floats: float.__mod__ is the same rule in double precision
+                ty = "f64"
             if ty not in ("f32", "f64"):
                 raise NotTranslatable("% on integers")
             fm = "fmodf" if ty == "f32" else "fmod"
             ta, tb, tm = self.new_slot(ty), self.new_slot(ty), self.new_slot(ty)
-            self.emit(f"{ta} = {_cast(a, ty)}; {tb} = {_cast(b, ty)}; {tm} = {fm}({ta}, {tb});")
+            self.emit(f"{ta} = {_cast(a, ty) if a.ty not in _WEAK else f'(({_CT[ty]})({a.code}))'}; {tb} = {_cast(b, ty) if b.ty not in _WEAK else f'(({_CT[ty]})({b.code}))'}; {tm} = {fm}({ta}, {tb});")
             self.emit(f"if ({tb} != 0) {{ if ({tm} != 0) {{ if (({tb} < 0) != ({tm} < 0)) {tm} += {tb}; }} else {{ {tm} = __builtin_copysign{'f' if ty == 'f32' else ''}(({_CT[ty]})0, {tb}); }} }}")
-            return _V(tm, ty, array=arr)
+            return _V(tm, rty if rty == "wf" else ty, array=arr)
         raise NotTranslatable(f"operator {type(op).__name__}")
 
     def e_Compare(self, node):
@@ -445,7 +448,9 @@ class _Translator(ast.NodeVisitor):
                 raise NotTranslatable(f"np.{name} on booleans")
             ta, tb = self.new_slot(ty), self.new_slot(ty)
             self.emit(f"{ta} = {_cast(args[0], ty)}; {tb} = {_cast(args[1], ty)};")
-            cmp_ = "<=" if name == "minimum" else ">="
+            # NumPy's loops (SIMD min / max with NaN propagation) return the SECOND operand when both compare equal: maximum(-0.0, 0.0) is
+            # 0.0, maximum(0.0, -0.0) is -0.0 -- visible as the sign of a later division by it (found by tests/test_jit_translator_fuzz.py)
+            cmp_ = "<" if name == "minimum" else ">"
             nan = f" || {ta} != {ta}" if ty[0] == "f" else ""
             return _V(f"(({ta} {cmp_} {tb}{nan}) ? {ta} : {tb})", ty, array=arr)
         if name == "clip" and len(args) == 3:  # np.clip(a, lo, hi) == np.minimum(np.maximum(a, lo), hi) (the ufunc's definition)
