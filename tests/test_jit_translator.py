@@ -145,21 +145,23 @@ def _check(func, tmp_path, *, spatial=np.float32, context=None, fields=None, n=4
     data = _columns(P, n, seed, finite)
     var_slot = {"age": (0, "f32"), "acc": (1, "f64"), "count": (2, "i32"), "flag": (3, "i64")}
     rng = np.random.default_rng(seed + 100)
-    fields = fields or {}
-    fake_fields, field_ids, sample_arrays = {}, {}, []
-    for k, (name, ncomp) in enumerate(fields.items()):
-        comps = [rng.normal(size=n) for _ in range(ncomp)]
-        f = _FakeField(comps)
+    # fields: {name: ncomp} (each sampled once, in this order) or [(name, ncomp), ...] = the samples in the order the kernel takes them
+    order = list(fields.items()) if isinstance(fields, dict) else list(fields or [])
+    fake_fields, field_ids = {}, {}
+    for name, ncomp in order:
+        if name in fake_fields:
+            continue
+        f = _FakeField([rng.normal(size=n) for _ in range(ncomp)])
         if ncomp > 1:
             f.U = f.V = None  # what marks a VectorField for the translator
         fake_fields[name] = f
-        field_ids[name] = k
+        field_ids[name] = len(field_ids)
     fs = _FakeFieldSet(context or {}, fake_fields)
-    # the order in which the function samples the fields is the order of `fields` (the tests are written that way)
-    sam = np.zeros((max(len(fields), 1), 3, n))
-    for k, name in enumerate(fields):
+    sam = np.zeros((max(len(order), 1), 3, n))
+    for k, (name, _) in enumerate(order):
         for j, comp in enumerate(fake_fields[name].values):
             sam[k, j] = comp
+    fields = order
     got, nsamples, src = _run_translated(func, P, fs, data, var_slot, field_ids, sam, tmp_path)
     assert nsamples == len(fields)
     ref = {k: v.copy() for k, v in data.items()}

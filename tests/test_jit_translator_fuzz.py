@@ -1,9 +1,10 @@
 """CPU: differential fuzzing of the kernel translator (parcels_amd/jit.py).  Every seed writes a random elementwise kernel -- arithmetic
 over float32 / float64 / int32 / int64 Variables, Python and NumPy scalars, comparisons, np.where / abs / minimum / maximum / floor / sqrt,
-%, ** 2, plain and in-place and masked assignments, local temporaries -- into a module, translates it, compiles the emitted C++ for the HOST
+%, ** 2, plain and in-place and masked assignments, local temporaries, scalar and vector field samples (the stage boundaries of the generated
+kernel, answered by arrays the test supplies) -- into a module, translates it, compiles the emitted C++ for the HOST
 (tests/test_jit_translator.py: the shim of the device structs) and demands the columns NumPy produces from the same Python function, bit
 for bit.  What is undefined in C and NumPy alike (float -> integer casts of NaN / out-of-range values, integer overflow) is not generated.
-An offline sweep of 10 000 seeds (PARCELS_JIT_FUZZ_SEEDS=10000, 4 minutes on 8 cores) found one real difference -- np.maximum / np.minimum
+Offline sweeps of 10 000 + 6 000 seeds (PARCELS_JIT_FUZZ_SEEDS=10000, 4 minutes on 8 cores) found one real difference -- np.maximum / np.minimum
 return their SECOND operand when both compare equal (the sign of a zero, visible after a division) -- fixed; 7 kernels were refused
 (`%` of integer constants), none differed."""
 import importlib.util
@@ -122,14 +123,38 @@ class Gen:
         return st
 
     def kernel(self, name):
-        body = [self.statement() for _ in range(int(self.rng.integers(3, 8)))]
-        return f"import numpy as np\n\n\ndef {name}(particles, fieldset):\n" + "".join(f"    {s}\n" for s in body)
+        """-> (source, [(field name, components), ...] in sampling order)"""
+        nst = int(self.rng.integers(3, 8))
+        nsam = int(self.rng.choice([0, 0, 1, 2, 3]))
+        where = sorted(int(v) for v in self.rng.integers(0, nst + 1, size=nsam))
+        body, samples = [], []
+        for k in range(nst + 1):
+            for _ in range(where.count(k)):  # a field sample: a stage boundary of the kernel; its value is a local from here on
+                j = len(samples)
+                kind = self.rng.random()
+                if kind < 0.6:
+                    fname = self.pick(["T", "S"])
+                    body.append(f"s{j} = fieldset.{fname}[particles]" if self.rng.random() < 0.6 else f"particles.{self.pick(['age', 'acc', 'dz'])} = fieldset.{fname}[particles] * 2 - s_prev".replace("s_prev", self.pick(self.locals_f + ["particles.age"])))
+                    if body[-1].startswith("s"):
+                        self.locals_f.append(f"s{j}")
+                    samples.append((fname, 1))
+                elif kind < 0.85:
+                    body.append(f"u{j}, v{j} = fieldset.UV[particles]")
+                    self.locals_f += [f"u{j}", f"v{j}"]
+                    samples.append(("UV", 2))
+                else:
+                    body.append(f"_, particles.dy, w{j} = fieldset.UVW[particles]")
+                    self.locals_f.append(f"w{j}")
+                    samples.append(("UVW", 3))
+            if k < nst:
+                body.append(self.statement())
+        return f"import numpy as np\n\n\ndef {name}(particles, fieldset):\n" + "".join(f"    {s}\n" for s in body), samples
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("PARCELS_JIT_FUZZ_SEEDS", "48"))))
 def test_random_kernel_equals_numpy(tmp_path, seed):
     name = f"K{seed}"
-    src = Gen(seed).kernel(name)
+    src, samples = Gen(seed).kernel(name)
     path = tmp_path / f"fuzz_kernel_{seed}.py"
     path.write_text(src)
     spec = importlib.util.spec_from_file_location(f"fuzz_kernel_{seed}", path)
@@ -137,7 +162,7 @@ def test_random_kernel_equals_numpy(tmp_path, seed):
     spec.loader.exec_module(mod)
     try:
         T._check(getattr(mod, name), tmp_path, spatial=np.float32 if seed % 2 else np.float64, context={"c1": 0.75, "c2": np.float32(1.5)},
-                 seed=1000 + seed, n=256)
+                 seed=1000 + seed, n=256, fields=samples)
     except ZeroDivisionError:
         pytest.skip("the generated kernel divides Python constants by zero: not a kernel")
     except T.jit.NotTranslatable as e:  # refusing is always safe (the kernel then runs on the host path); it must stay rare here
