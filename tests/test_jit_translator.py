@@ -68,7 +68,9 @@ class _FakeField:
         self.values = values  # list of component arrays (1 for a scalar field, 2 / 3 for UV / UVW)
 
     def __getitem__(self, particles):
-        rows = particles._rows
+        rows = vars(particles).get("_rows")
+        if rows is None:  # the reference's ParticleSetView: a boolean mask over the particle set
+            rows = np.flatnonzero(vars(particles)["_index"])
         out = tuple(v[rows] for v in self.values)
         return out[0] if len(out) == 1 else out
 

@@ -169,3 +169,55 @@ def test_random_kernel_equals_numpy(tmp_path, seed):
         pytest.skip(f"not translatable: {e}")
     except Exception as e:
         raise AssertionError(f"{type(e).__name__}: {e}\n--- kernel ---\n{src}") from None
+
+
+def _reference_view():
+    from oracle import ref_shim
+
+    if not ref_shim.reference_available():
+        return None
+    return ref_shim.load_reference()["particlesetview"].ParticleSetView
+
+
+@pytest.mark.skipif(_reference_view() is None, reason="reference tree not present")
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PARCELS_JIT_FUZZ_SEEDS", "48"))))
+def test_random_kernel_on_the_references_own_view(tmp_path, seed):
+    """The chain is anchored in the reference itself: the same random kernels, run on the REFERENCE's ParticleSetView
+    (src/parcels/_core/particlesetview.py, loaded unmodified) and on parcels_amd's HostParticles (what a Python kernel receives on the host
+    path, and what the translator is compared with above), leave the same columns, bit for bit."""
+    import parcels_amd as pa
+    from parcels_amd.hostkernels import HostParticles
+
+    View = _reference_view()
+    name = f"K{seed}"
+    src, samples = Gen(seed).kernel(name)
+    path = tmp_path / f"fuzz_kernel_{seed}.py"
+    path.write_text(src)
+    spec = importlib.util.spec_from_file_location(f"fuzz_kernel_ref_{seed}", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    func = getattr(mod, name)
+    n = 256
+    P = pa.get_default_particle(np.float32 if seed % 2 else np.float64).add_variable([
+        pa.Variable("age", dtype=np.float32, initial=0), pa.Variable("acc", dtype=np.float64, initial=0),
+        pa.Variable("count", dtype=np.int32, initial=0), pa.Variable("flag", dtype=np.int64, initial=0)])
+    data = T._columns(P, n, 1000 + seed)
+    rng = np.random.default_rng(seed + 100)
+    fields = {}
+    for fname, ncomp in samples:
+        if fname not in fields:
+            fields[fname] = T._FakeField([rng.normal(size=n) for _ in range(ncomp)])
+    fs = T._FakeFieldSet({"c1": 0.75, "c2": np.float32(1.5)}, fields)
+    a = {k: v.copy() for k, v in data.items()}
+    b = {k: v.copy() for k, v in data.items()}
+    try:
+        with np.errstate(all="ignore"):
+            try:
+                func(View(a, np.ones(n, dtype=bool), P), fs)
+            except TypeError as e:  # e.g. `particles.x % 1.5`: the reference's column proxy has no __mod__ (HostParticles is a superset)
+                pytest.skip(f"the reference's own view does not support this kernel: {e}")
+            func(HostParticles(b, np.arange(n)), fs)
+    except ZeroDivisionError:
+        pytest.skip("the generated kernel divides Python constants by zero: not a kernel")
+    for k in a:
+        assert a[k].dtype == b[k].dtype and np.array_equal(a[k], b[k], equal_nan=True), (k, src)
