@@ -141,7 +141,7 @@ def execute_hosted(kernel, pset, endtime, dt):
     from . import _hip, kernels as _k
     import ctypes as C
 
-    engine = pset._engine()
+    engine = None  # created when a built-in kernel of the list needs the device (a list of Python functions alone never does)
     fs = kernel.fieldset
     sign = 1 if dt > 0 else -1
     rk45_mode = "RK45_tol" in fs.context
@@ -153,7 +153,9 @@ def execute_hosted(kernel, pset, endtime, dt):
     ev_states = (int(StatusCode.Evaluate), int(StatusCode.Repeat))
 
     def device_segment(ids, samples, mask):
-        nonlocal body_launches, first_body
+        nonlocal body_launches, first_body, engine
+        if engine is None:
+            engine = pset._engine()
         data = pset._data
         engine.device_variables = list(kernel.device_variables)
         engine.bind_particles(data)
