@@ -19,12 +19,15 @@ class ParticleSetWarning(UserWarning):  # _core/warnings.py:14-17
     pass
 
 
-def _convert_dt_to_float(dt):  # particleset.py:488-505
-    if isinstance(dt, (datetime.timedelta, np.timedelta64)):
-        dt = to_seconds(dt)
-    dt = float(dt)
-    if not np.isfinite(dt) or dt == 0:
-        raise ValueError(f"dt must be a non-zero datetime.timedelta or np.timedelta64 object, got {dt=!r}")
+def _convert_dt_to_float(dt):  # particleset.py:497-506
+    try:
+        if isinstance(dt, (datetime.timedelta, np.timedelta64)):
+            dt = to_seconds(dt)
+        dt = float(dt)
+        if not np.isfinite(dt) or dt == 0:
+            raise ValueError("zero or non-finite")
+    except (ValueError, TypeError) as e:
+        raise ValueError(f"dt must be a non-zero datetime.timedelta or np.timedelta64 object, got {dt=!r}") from e
     return dt, (1 if dt > 0 else -1)
 
 
