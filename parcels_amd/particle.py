@@ -11,10 +11,27 @@ __all__ = ["Particle", "ParticleClass", "Variable", "get_default_particle"]
 
 class Variable:  # particle.py:20-76
     def __init__(self, name, dtype=np.float32, initial=0, to_write=True, attrs=None):
-        if not isinstance(name, str) or not name.isidentifier():
-            raise ValueError(f"Particle variable has to be a valid Python variable name. Got {name!r}")
+        # the reference's checks, in its order (particle.py:36-60, utils/string.py:4-16)
+        if not isinstance(name, str):
+            raise TypeError(f"Expected a string for variable name, got {type(name).__name__} instead.")
+        if not name.isidentifier():
+            raise ValueError(f"Received invalid Python variable name {name!r}: not a valid identifier. HINT: avoid using spaces, special characters, "
+                             "and starting with a number.")
+        import keyword
+
+        if keyword.iskeyword(name):
+            raise ValueError(f"Received invalid Python variable name {name!r}: it is a reserved keyword. HINT: avoid using the following names: "
+                             f"{', '.join(keyword.kwlist)}")
+        try:
+            dt = np.dtype(dtype)
+        except (TypeError, ValueError) as e:
+            raise TypeError(f"Variable dtype must be a valid numpy dtype. Got {dtype=!r}") from e
+        if to_write not in (True, False):
+            raise ValueError(f"to_write must be one of {[True, False]!r}. Got {to_write=!r}")
+        if not to_write and attrs:
+            raise ValueError(f"Attributes cannot be set if {to_write=!r}.")
         self.name = name
-        self.dtype = np.dtype(dtype).type
+        self.dtype = dt.type
         self.initial = initial
         self.to_write = to_write
         self.attrs = dict(attrs or {})
