@@ -23,6 +23,7 @@ from .interpolators import (
     XLinear_Velocity,
 )
 from .interpolators import CGrid_Tracer, XLinearInvdistLandTracer, XNearest  # noqa: E402
+from .statuscodes import StatusCode
 from .xgrid import XGrid
 
 _FIELD_DATA_ORDERING = ("T", "Z", "Y", "X")
@@ -243,7 +244,7 @@ class Field:
         if self.name in ("U", "V", "W"):  # field.py:134-143
             warnings.warn("Sampling of velocities should normally be done using fieldset.UV or fieldset.UVW object; tread carefully",
                           RuntimeWarning, stacklevel=2)
-        return self.eval(*_unpack_key(key))
+        return _eval_key(self, key)
 
 
 def _sample_points(t, z, y, x):
@@ -280,6 +281,18 @@ def _unpack_key(key):
         return d["t"][idx], d["z"][idx], d["y"][idx], d["x"][idx], None
     key = tuple(key)
     return key[0], key[1], key[2], key[3], (key[4] if len(key) > 4 else None)
+
+
+def _eval_key(field, key):
+    """field[key] (field.py:187-195, 297-304).  A sample outside the field's time interval is an error of the particles it was taken for; with
+    no particles in the key there is nobody to carry it: the reference raises (field.py:31-37), and so does this."""
+    t, z, y, x, particles = _unpack_key(key)
+    val = field.eval(t, z, y, x, particles)
+    if particles is None and isinstance(key, tuple):
+        st = getattr(field._fieldset._engine_or_create(), "last_sample_state", None)
+        if st is not None and np.any(np.asarray(st) == int(StatusCode.ErrorOutsideTimeInterval)):
+            raise RuntimeError(f"Field {field.name} sampled outside its time interval. Error could not be handled because particles was not part of the Field Sampling.")
+    return val
 
 
 def _mark_particles(particles, eng, field=None, z=None, y=None, x=None):
@@ -340,4 +353,4 @@ class VectorField:
         return (u, v, w) if self.vector_type == "3D" else (u, v)
 
     def __getitem__(self, key):
-        return self.eval(*_unpack_key(key))
+        return _eval_key(self, key)

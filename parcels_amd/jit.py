@@ -163,6 +163,7 @@ class _Translator(ast.NodeVisitor):
         self.stages: list[list[str]] = [[]]
         self.touched: set[str] = set()
         self.sampled: list = []  # ('UV' | 'UVW' | scalar field id) of every sample, in order
+        self.detached = False  # some sample is taken without the particles (state and `ei` untouched)
         self.aliases: set[str] = set()  # locals bound to a bare `particles.<var>`: a write-through view on the host, not a temporary
         self.nslot = 0
 
@@ -273,11 +274,41 @@ class _Translator(ast.NodeVisitor):
         raise NotTranslatable(f"attribute .{node.attr}")
 
     def is_sample(self, node):
-        return (isinstance(node, ast.Subscript) and isinstance(node.value, ast.Attribute) and isinstance(node.value.value, ast.Name)
-                and node.value.value.id == self.fname and isinstance(node.slice, ast.Name) and node.slice.id == self.pname)
+        """`fieldset.F[particles]`, `fieldset.F[t, z, y, x, particles]` or `fieldset.F[t, z, y, x]` (field.py:187-195, 297-304)"""
+        if not (isinstance(node, ast.Subscript) and isinstance(node.value, ast.Attribute) and isinstance(node.value.value, ast.Name)
+                and node.value.value.id == self.fname):
+            return False
+        sl = node.slice
+        if isinstance(sl, ast.Name):
+            return sl.id == self.pname
+        if isinstance(sl, ast.Tuple) and len(sl.elts) == 5:
+            return isinstance(sl.elts[4], ast.Name) and sl.elts[4].id == self.pname
+        return isinstance(sl, ast.Tuple) and len(sl.elts) == 4
+
+    def sample_point(self, node, fld):
+        """-> (code of t, z, y, x as doubles, whether y is a float32 array, attached to the particles)."""
+        sl = node.slice
+        if isinstance(sl, ast.Name):
+            return ("p.t", "p.z", "p.y", "p.x"), "c.pf", True
+        pts = [self.expr(e) for e in sl.elts[:4]]  # (evaluated left to right, like the subscript tuple)
+        for v, what in zip(pts, "tzyx"):
+            if not v.array or v.ty in ("b", "wb"):
+                raise NotTranslatable(f"sample coordinate {what} that is not a numeric array over the particles")
+        attached = len(sl.elts) == 5
+        if not attached:
+            # field.py:173-176: no guess from `ei`, no state update, `ei` stays.  On a rectilinear grid the search does not depend on the
+            # guess; a curvilinear search that starts from the hash returns float32-rounded cell coordinates (index_search.py:242-295)
+            ufld = getattr(fld, "U", None)
+            curv = getattr(getattr(ufld if ufld is not None else fld, "grid", None), "is_curvilinear", None)
+            if curv is None:
+                raise NotTranslatable("sample without particles on a field whose grid is not known here")
+            if curv:
+                raise NotTranslatable("sample without particles on a curvilinear grid (the search starts from the hash, not from `ei`)")
+        # the velocity conversion on a spherical mesh is a float32 cosine when y is a float32 array (_xinterpolators.py:183-187)
+        return tuple(f"(double)({v.code})" for v in pts), ("true" if pts[2].ty == "f32" else "false"), attached
 
     def sample(self, node):
-        """`fieldset.F[particles]` -> a stage boundary; returns the tuple of sampled components (float64 arrays)."""
+        """`fieldset.F[...]` -> a stage boundary; returns the tuple of sampled components (float64 arrays)."""
         name = node.value.attr
         fld = self.fieldset.fields.get(name)
         if fld is None:
@@ -289,14 +320,24 @@ class _Translator(ast.NodeVisitor):
             if fld is not self.fieldset.fields.get(name):
                 raise NotTranslatable("vector field alias")
             kind, n, fid = ("RQ_UVW", 3, 0) if name == "UVW" else ("RQ_UV", 2, 0)
-            self.sampled.append(name)
         else:
             if name in ("U", "V", "W"):
                 raise NotTranslatable("sampling a velocity component by itself (the reference warns: host path)")
             kind, n, fid = "RQ_SCALAR", 1, self.field_ids[name]
-            self.sampled.append(int(fid))
-        self.emit(f"rq.kind = {kind}; rq.fidx = {fid}; rq.f32 = c.pf; rq.t = p.t; rq.z = p.z; rq.y = p.y; rq.x = p.x; return false;")
+        (pt, pz, py, px), yf32, attached = self.sample_point(node, fld)
+        self.sampled.append(name if vector else int(fid))
+        saved = None
+        if not attached:
+            self.detached = True
+            saved = [self.new_slot("i32", "k") for _ in range(5)]
+            self.emit(f"{saved[0]} = c.state; {saved[1]} = c.ei0; {saved[2]} = c.ei1; {saved[3]} = c.ei2; {saved[4]} = c.ei3;")
+        self.emit(f"rq.kind = {kind}; rq.fidx = {fid}; rq.f32 = {yf32}; rq.t = {pt}; rq.z = {pz}; rq.y = {py}; rq.x = {px}; return false;")
         self.stages.append([])
+        if saved:
+            # (a sample outside the field's time interval stops the reference with a RuntimeError when no particles came along,
+            # field.py:31-37: here the particle keeps the error code, which stops the run as well)
+            self.emit(f"c.state = c.state == {int(StatusCode.ErrorOutsideTimeInterval)} ? c.state : {saved[0]}; c.ei0 = {saved[1]}; c.ei1 = {saved[2]}; "
+                      f"c.ei2 = {saved[3]}; c.ei3 = {saved[4]};")
         out = []
         for j in range(n):
             slot = self.new_slot("f64", "s")
@@ -546,6 +587,9 @@ class _Translator(ast.NodeVisitor):
                 continue
             if isinstance(st, ast.Pass):
                 continue
+            if isinstance(st, ast.Expr) and self.is_sample(st.value):  # a sample for its effect on the particles' state
+                self.sample(st.value)
+                continue
             if isinstance(st, ast.Assign):
                 if len(st.targets) != 1:
                     raise NotTranslatable("chained assignment")
@@ -615,8 +659,9 @@ class _Translator(ast.NodeVisitor):
 
 
 class UserKernelSource:
-    def __init__(self, name, decl, stages, touched, sampled=()):
+    def __init__(self, name, decl, stages, touched, sampled=(), detached=False):
         self.name, self.decl, self.stages, self.touched, self.sampled = name, decl, stages, touched, list(sampled)
+        self.detached = detached  # samples without the particles: restores PCtx::state / ei, which the dedicated kernels keep elsewhere
 
     def case_body(self) -> str:
         out = ["switch (stage) {"]
@@ -636,7 +681,7 @@ def translate(func, pclass, fieldset, var_slot, field_ids, next_dt_f32=False, sl
     except (OSError, TypeError, SyntaxError, IndentationError) as e:
         raise NotTranslatable(f"source of {getattr(func, '__name__', func)!r} is not available: {e}") from None
     tr.run()
-    return UserKernelSource(func.__name__, tr.decl, tr.stages, tr.touched, tr.sampled)
+    return UserKernelSource(func.__name__, tr.decl, tr.stages, tr.touched, tr.sampled, tr.detached)
 
 
 def candidate_variables(func, pclass):
@@ -716,6 +761,7 @@ class UserProgram:
         the user kernels riding along -- only for modules whose kernels sample no field and leave next_dt alone."""
         if not (1 <= len(sources) <= PK_MAX_USER_KERNELS):
             raise NotTranslatable(f"1 .. {PK_MAX_USER_KERNELS} user kernels per kernel list")
+        self.sources = list(sources)
         decl = "\n".join("    " + d for s in sources for d in s.decl) or "    char unused;"
         # the locals of different kernels never live at the same time, but they are few: one struct, distinct names
         cases = "\n".join(f"        case {k}: {{\n" + textwrap.indent(s.case_body(), "            ") + "\n        }" for k, s in enumerate(sources))
@@ -725,7 +771,7 @@ class UserProgram:
         sampled = [x for src in sources for x in src.sampled]
         self.sample_fids = sorted({x for x in sampled if isinstance(x, int)})
         self.sample_flags = (2 if "UV" in sampled else 0) | (4 if "UVW" in sampled else 0)  # PK_USER_SAMPLES_UV / _UVW
-        rides = fast and all("next_dt" not in src.touched for src in sources) and len(self.sample_fids) <= 4
+        rides = fast and all("next_dt" not in src.touched and not src.detached for src in sources) and len(self.sample_fids) <= 4
         self.flags = (1 | self.sample_flags) if rides else self.sample_flags  # PK_USER_RIDE: the module carries the dedicated kernel
         fast_launch = ""
         if self.flags & 1:

@@ -319,3 +319,56 @@ def SixVariables(particles, fieldset):
 def test_up_to_eight_user_variables_are_device_columns(gpu):
     p, d = _both([SixVariables, pa.AdvectionRK4])
     assert len(p._kernel.device_variables) == 6 and (d["count"] >= 12).any()
+
+
+def MidpointAdvection(particles, fieldset):
+    """The tutorials' hand-written RK2 (explanation_kernelloop.md, tutorial_nemo): the second sample at a computed point, particles attached."""
+    u1, v1 = fieldset.UV[particles]
+    x1 = particles.x + u1 * 0.5 * particles.dt
+    y1 = particles.y + v1 * 0.5 * particles.dt
+    u2, v2 = fieldset.UV[particles.t + 0.5 * particles.dt, particles.z, y1, x1, particles]
+    particles.dx += u2 * particles.dt
+    particles.dy += v2 * particles.dt
+
+
+def SampleAhead(particles, fieldset):
+    particles.temp = fieldset.T[particles.t, particles.z, particles.y, particles.x + fieldset.h, particles]
+
+
+def GradientT(particles, fieldset):
+    """Central difference of a tracer around the particle: samples WITHOUT the particles (value only; state and `ei` stay, field.py:173-176)."""
+    east = fieldset.T[particles.t, particles.z, particles.y, particles.x + fieldset.h]
+    west = fieldset.T[particles.t, particles.z, particles.y, particles.x - fieldset.h]
+    particles.acc = (east - west) / (2 * fieldset.h)
+    particles.temp = fieldset.T[particles.t, particles.z, particles.y, particles.x]
+
+
+@pytest.mark.parametrize("mesh", ["flat", "spherical"])
+@pytest.mark.parametrize("spatial", [np.float32, np.float64])
+def test_samples_at_computed_points(gpu, mesh, spatial):
+    """fieldset.F[t, z, y, x, particles]: the hand-written mid-point scheme as the ONLY advection kernel (the kernel-list interpreter), and a
+    look-ahead tracer sample riding in the dedicated A-grid kernel; on the spherical mesh the velocity conversion of the second sample is a
+    float64 cosine (y1 is a float64 array) where the first one's is the particles' dtype."""
+    h = 300.0 if mesh == "flat" else 0.25
+    p, d = _both([MidpointAdvection, Age], mesh=mesh, spatial=spatial)
+    assert np.abs(d["x"] - d["x"][0]).max() > 0
+    p, d = _both([pa.AdvectionRK4, SampleAhead], mesh=mesh, spatial=spatial, context={"h": h})
+    assert p._last_stats["program"] == 100 and p._kernel.user_program.flags & 1
+    # leaving the domain through a sample at a computed point marks the particle like any other sample
+    p, d = _both([pa.AdvectionRK4, SampleAhead, DeleteErrorParticle], mesh=mesh, spatial=spatial, context={"h": 40 * h}, margin=0.02, n=400)
+    assert len(p) < 400
+
+
+@pytest.mark.parametrize("mesh", ["flat", "spherical"])
+def test_samples_without_the_particles(gpu, mesh):
+    """fieldset.F[t, z, y, x]: neither the state nor `ei` changes -- a particle whose +-h neighbour lies outside the domain gets 0 from that
+    side and goes on; the list runs in the kernel-list interpreter (the dedicated kernels keep state / ei where the restore cannot reach)."""
+    h = 300.0 if mesh == "flat" else 0.25
+    p, d = _both([pa.AdvectionRK4, GradientT], mesh=mesh, context={"h": h})
+    assert p._kernel.user_program.sources[0].detached and not p._kernel.user_program.flags & 1 and np.abs(d["acc"]).max() > 0
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # (the host path warns about values masked to 0, field.py:359-370)
+        p, d = _both([GradientT, pa.AdvectionEE], mesh=mesh, context={"h": 60 * h}, margin=0.02, n=200, runtime=3 * 600.0)
+    assert len(p) == 200 and np.all(d["state"] < 50)

@@ -25,7 +25,7 @@ SHIM = r"""
 enum { RQ_UV = 0, RQ_UVW = 1, RQ_SCALAR = 2 };
 enum { PK_ERROR = 50 };
 struct PState { double t, z, y, x, dz, dy, dx, dt, next_dt; int64_t id; };
-struct PCtx { int state; bool pf; int64_t row; };
+struct PCtx { int state; bool pf; int64_t row; int32_t ei0, ei1, ei2, ei3; };
 struct Request { int kind, fidx; double t, z, y, x; bool f32; };
 struct DParticles { void* extra[4]; };
 struct KArgs { DParticles p; };
@@ -42,21 +42,29 @@ PK_DEV bool user_prepare(const KArgs& a, int uk, int stage, int kslot, PCtx& c, 
     }
 }
 // cols: t z y x dz dy dx dt (double each, spatial ones hold float values when pf), state (int32), id (int64), 4 extra columns;
-// samples[k * 3 * n + j * n + i]: component j of the k-th sample of particle i
+// samples[k * 3 * n + j * n + i]: component j of the k-th sample of particle i; a sample also does what the library's does to the particle:
+// state = max(state, sstate[k * n + i]) and ei0 = sei[k * n + i]; req[(k * 6 + j) * n + i]: t, z, y, x, f32 flag, kind * 100 + fidx of the request
 extern "C" void run(int64_t n, int pf, double* t, double* z, double* y, double* x, double* dz, double* dy, double* dx, double* dt,
-                    int32_t* state, int64_t* id, void* e0, void* e1, void* e2, void* e3, const double* samples, int32_t* nsamples) {
+                    int32_t* state, int64_t* id, void* e0, void* e1, void* e2, void* e3, const double* samples, int32_t* nsamples,
+                    const int32_t* sstate, const int32_t* sei, int32_t* ei0, double* req) {
     KArgs a;
     a.p.extra[0] = e0; a.p.extra[1] = e1; a.p.extra[2] = e2; a.p.extra[3] = e3;
     for (int64_t i = 0; i < n; i++) {
         PState p = {t[i], z[i], y[i], x[i], dz[i], dy[i], dx[i], dt[i], 0.0, id[i]};
-        PCtx c = {state[i], pf != 0, i};
+        PCtx c = {state[i], pf != 0, i, ei0[i], 0, 0, 0};
         KLocal L;
         memset(&L, 0, sizeof(L));
         Request rq;
         int k = 0;
-        for (int stage = 0; !user_prepare(a, 0, stage, 0, c, p, L, rq); stage++, k++)
+        for (int stage = 0; !user_prepare(a, 0, stage, 0, c, p, L, rq); stage++, k++) {
             for (int j = 0; j < 3; j++) L.r[3 + j] = samples[((int64_t)k * 3 + j) * n + i];
+            const double r6[6] = {rq.t, rq.z, rq.y, rq.x, rq.f32 ? 1.0 : 0.0, (double)(rq.kind * 100 + rq.fidx)};
+            for (int j = 0; j < 6; j++) req[((int64_t)k * 6 + j) * n + i] = r6[j];
+            if (sstate[(int64_t)k * n + i] > c.state) c.state = sstate[(int64_t)k * n + i];
+            c.ei0 = sei[(int64_t)k * n + i];
+        }
         *nsamples = k;
+        ei0[i] = c.ei0;
         t[i] = p.t; z[i] = p.z; y[i] = p.y; x[i] = p.x; dz[i] = p.dz; dy[i] = p.dy; dx[i] = p.dx; dt[i] = p.dt; state[i] = c.state;
     }
 }
@@ -64,13 +72,30 @@ extern "C" void run(int64_t n, int pf, double* t, double* z, double* y, double* 
 
 
 class _FakeField:
-    def __init__(self, values):
-        self.values = values  # list of component arrays (1 for a scalar field, 2 / 3 for UV / UVW)
+    """Answers a sample from arrays, logs the sample point, and does to the particles what the library's sampling does (when it is handed
+    them): raises the state to `sstate` and writes `ei`."""
 
-    def __getitem__(self, particles):
-        rows = vars(particles).get("_rows")
-        if rows is None:  # the reference's ParticleSetView: a boolean mask over the particle set
-            rows = np.flatnonzero(vars(particles)["_index"])
+    def __init__(self, values, log=None, effects=None):
+        self.values = values  # list of component arrays (1 for a scalar field, 2 / 3 for UV / UVW)
+        self.log = log if log is not None else []
+        self.effects = effects  # (sstate[k], sei[k]) per sample of the run, or None
+
+    def __getitem__(self, key):
+        particles = key[4] if isinstance(key, tuple) and len(key) == 5 else (None if isinstance(key, tuple) else key)
+        if particles is not None:
+            rows = vars(particles).get("_rows")
+            if rows is None:  # the reference's ParticleSetView: a boolean mask over the particle set
+                rows = np.flatnonzero(vars(particles)["_index"])
+        else:
+            rows = np.arange(len(self.values[0]))
+        t, z, y, x = key[:4] if isinstance(key, tuple) else (particles.t, particles.z, particles.y, particles.x)
+        k = len(self.log)
+        self.log.append({"t": np.asarray(t, dtype=np.float64), "z": np.asarray(z, dtype=np.float64), "y": np.asarray(y, dtype=np.float64),
+                         "x": np.asarray(x, dtype=np.float64), "f32": np.asarray(y).dtype == np.float32, "attached": particles is not None, "implicit": not isinstance(key, tuple)})
+        if particles is not None and self.effects is not None:
+            sstate, sei = self.effects
+            particles.state = np.maximum(np.asarray(particles.state), sstate[k][rows])
+            vars(particles)["_data"]["ei"][rows, 0] = sei[k][rows]
         out = tuple(v[rows] for v in self.values)
         return out[0] if len(out) == 1 else out
 
@@ -109,10 +134,11 @@ def _columns(pclass, n, seed, finite=False):
         else:
             data[v.name] = rng.integers(-5, 9, size=n).astype(dt)
     data["dt"] = np.full(n, 600.0)
+    data.setdefault("ei", np.zeros((n, 1), np.int32))
     return data
 
 
-def _run_translated(func, pclass, fieldset, data, var_slot, field_ids, samples, tmp_path):
+def _run_translated(func, pclass, fieldset, data, var_slot, field_ids, samples, tmp_path, effects=None):
     src = jit.translate(func, pclass, fieldset, var_slot, field_ids)
     body = "\n".join("            " + ln for ln in src.case_body().split("\n"))
     code = SHIM % {"decl": "\n".join("    " + d for d in src.decl) or "    char unused;", "body": body}
@@ -130,17 +156,24 @@ def _run_translated(func, pclass, fieldset, data, var_slot, field_ids, samples, 
         extras[slot] = data[name].copy()
     sam = np.ascontiguousarray(samples, dtype=np.float64) if samples is not None else np.zeros(3 * n)
     ns = C.c_int32(0)
+    nsam = max(sam.size // (3 * n), 1)
+    sstate, sei = effects if effects is not None else (np.zeros((nsam, n), np.int32), np.zeros((nsam, n), np.int32))
+    sstate, sei = np.ascontiguousarray(sstate, dtype=np.int32), np.ascontiguousarray(sei, dtype=np.int32)
+    ei0 = np.array(data["ei"][:, 0], dtype=np.int32)
+    req = np.zeros((nsam, 6, n))
     ptr = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None  # noqa: E731
     lib.run(C.c_int64(n), C.c_int(int(pf)), *[ptr(cols[k]) for k in ("t", "z", "y", "x", "dz", "dy", "dx", "dt")], ptr(state), ptr(pid),
-            *[ptr(e) for e in extras], ptr(sam), C.byref(ns))
+            *[ptr(e) for e in extras], ptr(sam), C.byref(ns), ptr(sstate), ptr(sei), ptr(ei0), ptr(req))
+    src.requests = req
     out = {k: cols[k].astype(data[k].dtype) for k in cols}
     out["state"] = state
+    out["ei"] = ei0.reshape(-1, 1)
     for name, (slot, _) in var_slot.items():
         out[name] = extras[slot]
     return out, ns.value, src
 
 
-def _check(func, tmp_path, *, spatial=np.float32, context=None, fields=None, n=400, seed=0, finite=False):
+def _check(func, tmp_path, *, spatial=np.float32, context=None, fields=None, n=400, seed=0, finite=False, grid=None, codes=(51, 60, 61, 70)):
     P = pa.get_default_particle(spatial).add_variable([
         pa.Variable("age", dtype=np.float32, initial=0), pa.Variable("acc", dtype=np.float64, initial=0),
         pa.Variable("count", dtype=np.int32, initial=0), pa.Variable("flag", dtype=np.int64, initial=0)])
@@ -150,10 +183,15 @@ def _check(func, tmp_path, *, spatial=np.float32, context=None, fields=None, n=4
     # fields: {name: ncomp} (each sampled once, in this order) or [(name, ncomp), ...] = the samples in the order the kernel takes them
     order = list(fields.items()) if isinstance(fields, dict) else list(fields or [])
     fake_fields, field_ids = {}, {}
+    log = []
+    effects = (np.where(rng.random((max(len(order), 1), n)) < 0.1, rng.choice(list(codes), size=(max(len(order), 1), n)), 0).astype(np.int32),
+               rng.integers(0, 1000, size=(max(len(order), 1), n)).astype(np.int32))
     for name, ncomp in order:
         if name in fake_fields:
             continue
-        f = _FakeField([rng.normal(size=n) for _ in range(ncomp)])
+        f = _FakeField([rng.normal(size=n) for _ in range(ncomp)], log, effects)
+        if grid is not None:
+            f.grid = grid
         if ncomp > 1:
             f.U = f.V = None  # what marks a VectorField for the translator
         fake_fields[name] = f
@@ -164,7 +202,7 @@ def _check(func, tmp_path, *, spatial=np.float32, context=None, fields=None, n=4
         for j, comp in enumerate(fake_fields[name].values):
             sam[k, j] = comp
     fields = order
-    got, nsamples, src = _run_translated(func, P, fs, data, var_slot, field_ids, sam, tmp_path)
+    got, nsamples, src = _run_translated(func, P, fs, data, var_slot, field_ids, sam, tmp_path, effects)
     assert nsamples == len(fields)
     ref = {k: v.copy() for k, v in data.items()}
     with np.errstate(all="ignore"):
@@ -172,6 +210,15 @@ def _check(func, tmp_path, *, spatial=np.float32, context=None, fields=None, n=4
     for k in got:
         assert got[k].dtype == ref[k].dtype, k
         assert np.array_equal(got[k], ref[k], equal_nan=True), (func.__name__, k, np.flatnonzero(~((got[k] == ref[k]) | (np.isnan(got[k].astype(float)) & np.isnan(ref[k].astype(float)))))[:5])
+    # every sample: same field, same point (bit for bit), same float32-ness of y
+    assert len(log) == len(fields)
+    for k, ((name, ncomp), entry) in enumerate(zip(fields, log)):
+        for j, c in enumerate("tzyx"):
+            assert np.array_equal(src.requests[k, j], entry[c], equal_nan=True), (func.__name__, "sample", k, c)
+        assert np.all(src.requests[k, 4] == float(entry["f32"])), (func.__name__, k)
+        kind = {1: 2, 2: 0, 3: 1}[ncomp]
+        assert np.all(src.requests[k, 5] == kind * 100 + (field_ids[name] if ncomp == 1 else 0))
+    src.log = log
     return src
 
 
@@ -250,6 +297,80 @@ def test_masks_and_states(tmp_path):
 def test_field_samples_are_stage_boundaries(tmp_path):
     src = _check(Samples, tmp_path, spatial=np.float64, fields={"T": 1, "UV": 2, "UVW": 3, "T2": 1}, seed=4)
     assert len(src.stages) == 5  # four samples: five stages
+
+
+def RK2AtPoints(particles, fieldset):
+    """The tutorials' hand-written mid-point scheme: the second sample is taken at a computed point, with the particles attached."""
+    u1, v1 = fieldset.UV[particles]
+    x1 = particles.x + u1 * 0.5 * particles.dt          # spatial dtype + f64 -> f64
+    y1 = particles.y + v1 * 0.5 * particles.dt
+    u2, v2 = fieldset.UV[particles.t + 0.5 * particles.dt, particles.z, y1, x1, particles]
+    particles.dx += u2 * particles.dt
+    particles.dy += v2 * particles.dt
+    particles.acc = fieldset.T[particles.t, particles.z, particles.y, particles.x + 0.01, particles]   # y stays the stored dtype: f32 flag
+
+
+def DetachedSamples(particles, fieldset):
+    """`fieldset.F[t, z, y, x]` without the particles: the value only -- state and `ei` are left alone (field.py:173-176)."""
+    particles.acc = fieldset.T[particles.t, particles.z, particles.y, particles.x]
+    east = fieldset.T[particles.t, particles.z, particles.y, particles.x + fieldset.h]
+    west = fieldset.T[particles.t + particles.dt, particles.z * 1.0, particles.y - particles.age, particles.x - fieldset.h]
+    particles.age = (east - west) / (2 * fieldset.h)
+    u, v = fieldset.UV[particles.t, particles.z, particles.y, particles.x]
+    particles.dz = u + v + fieldset.T2[particles]
+
+
+class _RectGrid:
+    is_curvilinear = False
+
+
+class _CurvGrid:
+    is_curvilinear = True
+
+
+@pytest.mark.parametrize("spatial", [np.float32, np.float64])
+def test_samples_at_computed_points(tmp_path, spatial):
+    src = _check(RK2AtPoints, tmp_path, spatial=spatial, fields=[("UV", 2), ("UV", 2), ("T", 1)], seed=21, finite=True)
+    assert not src.detached and [e["attached"] for e in src.log] == [True, True, True]
+    assert [bool(e["f32"]) for e in src.log] == [spatial == np.float32, False, spatial == np.float32]
+
+
+@pytest.mark.parametrize("spatial", [np.float32, np.float64])
+def test_samples_without_the_particles_leave_state_and_ei_alone(tmp_path, spatial):
+    src = _check(DetachedSamples, tmp_path, spatial=spatial, context={"h": 0.25}, fields=[("T", 1), ("T", 1), ("T", 1), ("UV", 2), ("T2", 1)],
+                 seed=22, finite=True, grid=_RectGrid(), codes=(51, 60, 61))
+    assert src.detached and [e["attached"] for e in src.log] == [False, False, False, False, True]
+
+
+def BareSample(particles, fieldset):
+    fieldset.UV[particles.t + 400 * 86400, particles.z, particles.y, particles.x, particles]   # (the reference's FieldAccessOutsideTime)
+    particles.acc = 1
+
+
+def test_a_sample_for_its_effect_on_the_state(tmp_path):
+    src = _check(BareSample, tmp_path, fields=[("UV", 2)], seed=23, finite=True)
+    assert len(src.stages) == 2
+
+
+def test_sample_without_particles_needs_a_rectilinear_grid(tmp_path):
+    P = pa.get_default_particle(np.float32).add_variable([pa.Variable("acc", dtype=np.float64, initial=0)])
+
+    def K(particles, fieldset):
+        particles.acc = fieldset.T[particles.t, particles.z, particles.y, particles.x]
+
+    f = _FakeField([np.zeros(3)])
+    f.grid = _CurvGrid()
+    with pytest.raises(jit.NotTranslatable, match="curvilinear"):
+        jit.translate(K, P, _FakeFieldSet({}, {"T": f}), {"acc": (0, "f64")}, {"T": 0})
+    f2 = _FakeField([np.zeros(3)])
+    with pytest.raises(jit.NotTranslatable, match="not known"):
+        jit.translate(K, P, _FakeFieldSet({}, {"T": f2}), {"acc": (0, "f64")}, {"T": 0})
+
+    def Scalar(particles, fieldset):
+        particles.acc = fieldset.T[particles.t, 0.5, particles.y, particles.x, particles]
+
+    with pytest.raises(jit.NotTranslatable, match="not a numeric array"):
+        jit.translate(Scalar, P, _FakeFieldSet({}, {"T": f}), {"acc": (0, "f64")}, {"T": 0})
 
 
 def Trig(particles, fieldset):
