@@ -110,6 +110,8 @@ class HostParticles:
             sub = np.asarray(sub)
         sub = np.asarray(sub) if isinstance(sub, (list, np.ndarray)) else sub
         if isinstance(sub, np.ndarray) and sub.dtype == bool and sub.shape[0] != len(self._rows):
+            if sub.shape[0] == len(self._data["particle_id"]):  # a mask over the WHOLE set selects from it, whatever this selection was
+                return HostParticles(self._data, np.flatnonzero(sub))  # (particlesetview.py:48-52: `new_index = arr`)
             raise IndexError(f"boolean index of length {sub.shape[0]} for a selection of {len(self._rows)} particles")
         rows = self._rows[sub]
         return HostParticles(self._data, np.atleast_1d(rows))

@@ -65,10 +65,26 @@ def _ty_of_dtype(dt) -> str:
 class _V:
     """A typed elementwise expression: C++ code, NumPy dtype tag (or weak Python scalar tag), constant value, array-ness."""
 
-    __slots__ = ("code", "ty", "const", "array")
+    __slots__ = ("code", "ty", "const", "array", "dom", "explicit")
 
-    def __init__(self, code, ty, const=None, array=False):
+    def __init__(self, code, ty, const=None, array=False, dom=None, explicit=False):
         self.code, self.ty, self.const, self.array = code, ty, const, array
+        # dom: the sub-selection of the particles an array is defined on -- None: all of them; otherwise the code of the boolean slot that
+        # selects them (`particles[mask].x`, `view.x`, `column[mask]`).  NumPy needs equal shapes to combine arrays: equal domains here.
+        self.dom, self.explicit = dom, explicit
+
+
+class _View:
+    """`particles`, `particles[mask]`, `view[mask2]`, `particles[np.where(cond)]`: a selection of the particles; mask None = all."""
+
+    __slots__ = ("mask",)
+
+    def __init__(self, mask):
+        self.mask = mask
+
+    @property
+    def dom(self):
+        return self.mask.code if self.mask is not None else None
 
 
 def _lit(v, ty) -> str:
@@ -130,6 +146,7 @@ def _strong(ty: str) -> str:
 
 
 _SPATIAL = ("x", "y", "z", "dx", "dy", "dz")
+_NEXT_STAGE = "/*next-stage*/ "  # where a request is made: case_body writes the stage counter of kernels with conditional samples here
 # numpy name -> (C function, arity) of the transcendental functions accepted under PARCELS_AMD_JIT_LIBM=1
 _LIBM = {"sin": ("sin", 1), "cos": ("cos", 1), "tan": ("tan", 1), "arcsin": ("asin", 1), "arccos": ("acos", 1), "arctan": ("atan", 1),
          "arctan2": ("atan2", 2), "exp": ("exp", 1), "log": ("log", 1), "log10": ("log10", 1), "sinh": ("sinh", 1), "cosh": ("cosh", 1),
@@ -163,6 +180,12 @@ class _Translator(ast.NodeVisitor):
         self.stages: list[list[str]] = [[]]
         self.touched: set[str] = set()
         self.sampled: list = []  # ('UV' | 'UVW' | scalar field id) of every sample, in order
+        self.views: dict[str, _View] = {}  # locals bound to a selection of the particles
+        self.index_locals: dict[str, _V] = {}  # locals bound to np.where(cond) / np.flatnonzero(cond): usable as particles[<local>] only
+        self._kids: list[list[_V]] = []  # operands of the expression being translated (their domains combine into the result's)
+        self._stmt_masks: dict[str, _V] = {}  # mask expression -> its slot, within the statement being translated
+        self._combined: dict[tuple, _V] = {}  # (view domain, mask code) -> the slot of their conjunction
+        self.conditional = False  # some sample is taken for a sub-selection: the stage machine keeps its own counter (case_body)
         self.detached = False  # some sample is taken without the particles (state and `ei` untouched)
         self.aliases: set[str] = set()  # locals bound to a bare `particles.<var>`: a write-through view on the host, not a temporary
         self.nslot = 0
@@ -258,7 +281,86 @@ class _Translator(ast.NodeVisitor):
         m = getattr(self, "e_" + type(node).__name__, None)
         if m is None:
             raise NotTranslatable(f"expression {type(node).__name__}")
-        return m(node)
+        self._kids.append([])
+        try:
+            v = m(node)
+        finally:
+            kids = self._kids.pop()
+        if kids and not v.explicit:
+            v.dom = self.common_domain(kids)
+        if self._kids:
+            self._kids[-1].append(v)
+        return v
+
+    @staticmethod
+    def common_domain(vs):
+        """Arrays combine only on one selection of the particles (NumPy: equal shapes); scalars go with anything."""
+        arrays = [v for v in vs if v.array]
+        doms = {v.dom for v in arrays}
+        if len(doms) > 1:
+            raise NotTranslatable("arrays over different selections of the particles in one expression (NumPy would need equal shapes)")
+        return doms.pop() if doms else None
+
+    # ---- selections of the particles -----------------------------------------------------------------------------------------------
+    def mask_slot(self, m: _V) -> _V:
+        """A boolean array as a slot (kept as it is when it already is one: a named mask gives ONE domain wherever it is used)."""
+        if m.ty not in ("b", "wb") or not m.array:
+            raise NotTranslatable("a selection that is not a boolean mask over the particles")
+        if m.code.startswith("L.ul.") and m.code.replace("L.ul.", "").replace("_", "").isalnum() and m.ty == "b":
+            return m
+        if m.code in self._stmt_masks:  # the same mask expression again within ONE statement (nothing is stored in between): one domain
+            return self._stmt_masks[m.code]
+        t = self.new_slot("b")
+        self.emit(f"{t} = {m.code};")
+        self._stmt_masks[m.code] = _V(t, "b", array=True, dom=m.dom, explicit=True)
+        return self._stmt_masks[m.code]
+
+    def select(self, view: _View, m: _V) -> _View:
+        """view[m]: m is a mask over `view`."""
+        if m.dom != view.dom:
+            raise NotTranslatable("a mask over another selection of the particles than the one it indexes")
+        m = self.mask_slot(m)
+        if view.mask is None:
+            return _View(_V(m.code, "b", array=True, dom=None, explicit=True))
+        key = (view.mask.code, m.code)
+        if key not in self._combined:
+            t = self.new_slot("b")
+            self.emit(f"{t} = {view.mask.code} && {m.code};")
+            self._combined[key] = _V(t, "b", array=True, dom=None, explicit=True)
+        return _View(self._combined[key])
+
+    def index_mask(self, node):
+        """np.where(cond) / np.nonzero(cond) / np.flatnonzero(cond) / np.argwhere(cond).flatten(): the rows where cond holds, in order --
+        as a selection of the particles the same thing as the mask itself.  -> the mask or None."""
+        if isinstance(node, ast.Name) and node.id in self.index_locals:
+            return self.index_locals[node.id]
+        if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr in ("flatten", "ravel") and not node.args \
+                and isinstance(node.func.value, ast.Call) and self.np_func(node.func.value) == "argwhere" and len(node.func.value.args) == 1:
+            return self.mask_slot(self.expr(node.func.value.args[0]))
+        if isinstance(node, ast.Call) and self.np_func(node) in ("where", "nonzero", "flatnonzero") and len(node.args) == 1 and not node.keywords:
+            return self.mask_slot(self.expr(node.args[0]))
+        return None
+
+    def view_of(self, node):
+        """The selection an expression denotes, or None when it is not one."""
+        if isinstance(node, ast.Name):
+            if node.id == self.pname:
+                return _View(None)
+            return self.views.get(node.id)
+        if isinstance(node, ast.Subscript):
+            base = self.view_of(node.value)
+            if base is None:
+                return None
+            m = self.index_mask(node.slice)
+            if m is None:
+                depth = len(self._kids)
+                self._kids.append([])
+                try:
+                    m = self.expr(node.slice)
+                finally:
+                    del self._kids[depth:]
+            return self.select(base, m)
+        return None
 
     def e_Constant(self, node):
         return _const(node.value)
@@ -266,35 +368,55 @@ class _Translator(ast.NodeVisitor):
     def e_Name(self, node):
         if node.id in self.locals:
             return self.locals[node.id]
+        if node.id in self.views or node.id in self.index_locals:
+            raise NotTranslatable(f"'{node.id}' (a selection of the particles) used as a value")
         raise NotTranslatable(f"name '{node.id}'")
 
     def e_Attribute(self, node):
-        if isinstance(node.value, ast.Name) and node.value.id == self.pname:
-            return self.load_var(node.attr)
+        view = self.view_of(node.value)
+        if view is not None:
+            v = self.load_var(node.attr)
+            v.dom, v.explicit = view.dom, True
+            return v
         raise NotTranslatable(f"attribute .{node.attr}")
 
     def is_sample(self, node):
-        """`fieldset.F[particles]`, `fieldset.F[t, z, y, x, particles]` or `fieldset.F[t, z, y, x]` (field.py:187-195, 297-304)"""
+        """`fieldset.F[particles]`, `fieldset.F[t, z, y, x, particles]` or `fieldset.F[t, z, y, x]` (field.py:187-195, 297-304); `particles`
+        may be any selection of them (`particles[mask]`, a local bound to one)."""
         if not (isinstance(node, ast.Subscript) and isinstance(node.value, ast.Attribute) and isinstance(node.value.value, ast.Name)
                 and node.value.value.id == self.fname):
             return False
         sl = node.slice
-        if isinstance(sl, ast.Name):
-            return sl.id == self.pname
-        if isinstance(sl, ast.Tuple) and len(sl.elts) == 5:
-            return isinstance(sl.elts[4], ast.Name) and sl.elts[4].id == self.pname
-        return isinstance(sl, ast.Tuple) and len(sl.elts) == 4
+        if isinstance(sl, ast.Tuple):
+            return len(sl.elts) == 4 or (len(sl.elts) == 5 and self.is_selection(sl.elts[4]))
+        return self.is_selection(sl)
+
+    def is_selection(self, node):
+        while isinstance(node, ast.Subscript):
+            node = node.value
+        return isinstance(node, ast.Name) and (node.id == self.pname or node.id in self.views)
 
     def sample_point(self, node, fld):
-        """-> (code of t, z, y, x as doubles, whether y is a float32 array, attached to the particles)."""
+        """-> (code of t, z, y, x as doubles, whether y is a float32 array, attached to the particles, mask of the selection or None)."""
         sl = node.slice
-        if isinstance(sl, ast.Name):
-            return ("p.t", "p.z", "p.y", "p.x"), "c.pf", True
-        pts = [self.expr(e) for e in sl.elts[:4]]  # (evaluated left to right, like the subscript tuple)
+        if not isinstance(sl, ast.Tuple):
+            view = self.view_of(sl)
+            return ("p.t", "p.z", "p.y", "p.x"), "c.pf", True, view.mask
+        attached = len(sl.elts) == 5
+        view = self.view_of(sl.elts[4]) if attached else None
+        depth = len(self._kids)
+        self._kids.append([])
+        try:
+            pts = [self.expr(e) for e in sl.elts[:4]]  # (evaluated left to right, like the subscript tuple)
+        finally:
+            del self._kids[depth:]
         for v, what in zip(pts, "tzyx"):
             if not v.array or v.ty in ("b", "wb"):
                 raise NotTranslatable(f"sample coordinate {what} that is not a numeric array over the particles")
-        attached = len(sl.elts) == 5
+        dom = self.common_domain(pts)
+        if attached and dom != view.dom:
+            raise NotTranslatable("sample coordinates over another selection of the particles than the one passed along")
+        mask = view.mask if attached else (None if dom is None else _V(dom, "b", array=True))
         if not attached:
             # field.py:173-176: no guess from `ei`, no state update, `ei` stays.  On a rectilinear grid the search does not depend on the
             # guess; a curvilinear search that starts from the hash returns float32-rounded cell coordinates (index_search.py:242-295)
@@ -305,10 +427,10 @@ class _Translator(ast.NodeVisitor):
             if curv:
                 raise NotTranslatable("sample without particles on a curvilinear grid (the search starts from the hash, not from `ei`)")
         # the velocity conversion on a spherical mesh is a float32 cosine when y is a float32 array (_xinterpolators.py:183-187)
-        return tuple(f"(double)({v.code})" for v in pts), ("true" if pts[2].ty == "f32" else "false"), attached
+        return tuple(f"(double)({v.code})" for v in pts), ("true" if pts[2].ty == "f32" else "false"), attached, mask
 
     def sample(self, node):
-        """`fieldset.F[...]` -> a stage boundary; returns the tuple of sampled components (float64 arrays)."""
+        """`fieldset.F[...]` -> a stage boundary; returns the tuple of sampled components (float64 arrays on the selection sampled)."""
         name = node.value.attr
         fld = self.fieldset.fields.get(name)
         if fld is None:
@@ -324,14 +446,18 @@ class _Translator(ast.NodeVisitor):
             if name in ("U", "V", "W"):
                 raise NotTranslatable("sampling a velocity component by itself (the reference warns: host path)")
             kind, n, fid = "RQ_SCALAR", 1, self.field_ids[name]
-        (pt, pz, py, px), yf32, attached = self.sample_point(node, fld)
+        (pt, pz, py, px), yf32, attached, mask = self.sample_point(node, fld)
         self.sampled.append(name if vector else int(fid))
         saved = None
         if not attached:
             self.detached = True
             saved = [self.new_slot("i32", "k") for _ in range(5)]
             self.emit(f"{saved[0]} = c.state; {saved[1]} = c.ei0; {saved[2]} = c.ei1; {saved[3]} = c.ei2; {saved[4]} = c.ei3;")
-        self.emit(f"rq.kind = {kind}; rq.fidx = {fid}; rq.f32 = {yf32}; rq.t = {pt}; rq.z = {pz}; rq.y = {py}; rq.x = {px}; return false;")
+        request = f"rq.kind = {kind}; rq.fidx = {fid}; rq.f32 = {yf32}; rq.t = {pt}; rq.z = {pz}; rq.y = {py}; rq.x = {px}; return false;"
+        if mask is not None:  # only the selected particles sample (the others would take the sample's error codes): they go straight on
+            self.conditional = True
+            request = f"if ({mask.code}) {{ {request} }}"
+        self.emit(_NEXT_STAGE + request)
         self.stages.append([])
         if saved:
             # (a sample outside the field's time interval stops the reference with a RuntimeError when no particles came along,
@@ -339,10 +465,11 @@ class _Translator(ast.NodeVisitor):
             self.emit(f"c.state = c.state == {int(StatusCode.ErrorOutsideTimeInterval)} ? c.state : {saved[0]}; c.ei0 = {saved[1]}; c.ei1 = {saved[2]}; "
                       f"c.ei2 = {saved[3]}; c.ei3 = {saved[4]};")
         out = []
+        dom = mask.code if mask is not None else None
         for j in range(n):
             slot = self.new_slot("f64", "s")
             self.emit(f"{slot} = L.r[{3 + j}];")
-            out.append(_V(slot, "f64", array=True))
+            out.append(_V(slot, "f64", array=True, dom=dom, explicit=True))
         return out if vector else out[0]
 
     def e_Subscript(self, node):
@@ -351,6 +478,17 @@ class _Translator(ast.NodeVisitor):
             if isinstance(r, list):
                 raise NotTranslatable("a vector sample must be unpacked: u, v = fieldset.UV[particles]")
             return r
+        if self.view_of(node.value) is None:  # column[mask] / array[mask]: the array on the sub-selection
+            depth = len(self._kids)
+            self._kids.append([])
+            try:
+                arr = self.expr(node.value)
+                m = self.index_mask(node.slice) or self.expr(node.slice)
+            finally:
+                del self._kids[depth:]
+            if arr.array and m.array and m.ty in ("b", "wb"):
+                sub = self.select(_View(None if arr.dom is None else _V(arr.dom, "b", array=True)), m)
+                return _V(arr.code, arr.ty, array=True, dom=sub.dom, explicit=True)
         raise NotTranslatable("subscript in an expression")
 
     def e_UnaryOp(self, node):
@@ -445,6 +583,20 @@ class _Translator(ast.NodeVisitor):
             return self.e_UnaryOp(ast.UnaryOp(op=ast.USub(), operand=node.args[0]))
         if name == "square" and len(node.args) == 1:
             return self.e_BinOp(ast.BinOp(left=node.args[0], op=ast.Pow(), right=ast.Constant(2)))
+        if name == "isin" and len(node.args) == 2:  # membership in a constant list (e.g. a list of status codes): an OR of equalities
+            try:
+                test = np.asarray(eval(compile(ast.fix_missing_locations(ast.Expression(body=node.args[1])), "<kernel>", "eval"), dict(self.env)))  # noqa: S307
+            except Exception:
+                raise NotTranslatable("np.isin with test elements that are not constants of the module") from None
+            if test.ndim != 1 or test.size == 0 or test.size > 16 or test.dtype.kind not in "biuf":
+                raise NotTranslatable("np.isin with test elements other than a short list of numbers")
+            v = self.expr(node.args[0])
+            tty = _ty_of_dtype(test.dtype if test.dtype.kind != "u" else np.int64)
+            ct = _strong(_promote(v, _V("0", tty)))
+            t = self.new_slot(ct)
+            self.emit(f"{t} = {_cast(v, ct)};")
+            alts = " || ".join(f"({t} == {_cast(_V(_lit(e.item(), 'wf' if tty[0] == 'f' else ('wb' if tty == 'b' else 'wi')), tty), ct)})" for e in test)
+            return _V(f"({alts})", "b", array=v.array)
         args = [self.expr(a) for a in node.args]
         arr = any(a.array for a in args)
         if name == "sign" and len(args) == 1:  # -1 / 0 / +1 in the argument's dtype, NaN stays NaN
@@ -537,29 +689,34 @@ class _Translator(ast.NodeVisitor):
 
     # ---- statements ----------------------------------------------------------------------------------------------------------
     def target(self, node):
-        """-> ('local', name) | ('var', name, mask or None) | ('skip',)"""
+        """-> ('local', name) | ('var', name, mask or None): mask = the selection of the particles the store goes to (its code is the
+        domain an array value must have)."""
         if isinstance(node, ast.Name):
             if node.id in (self.pname, self.fname):
                 raise NotTranslatable("rebinding a kernel argument")
             return ("local", node.id)
-        if isinstance(node, ast.Attribute):
-            base = node.value
-            if isinstance(base, ast.Name) and base.id == self.pname:
-                return ("var", node.attr, None)
-            if isinstance(base, ast.Subscript) and isinstance(base.value, ast.Name) and base.value.id == self.pname:  # particles[mask].v
-                return ("var", node.attr, self.mask(base.slice))
-        if isinstance(node, ast.Subscript) and isinstance(node.value, ast.Attribute) and isinstance(node.value.value, ast.Name) \
-                and node.value.value.id == self.pname:  # particles.v[mask]
-            return ("var", node.value.attr, self.mask(node.slice))
+        if isinstance(node, ast.Attribute):  # particles.v, particles[mask].v, view.v
+            view = self.view_of(node.value)
+            if view is not None:
+                return ("var", node.attr, view.mask)
+        if isinstance(node, ast.Subscript) and isinstance(node.value, ast.Attribute):  # particles.v[mask], view.v[mask]
+            view = self.view_of(node.value.value)
+            if view is not None:
+                m = self.index_mask(node.slice)
+                if m is None:
+                    depth = len(self._kids)
+                    self._kids.append([])
+                    try:
+                        m = self.expr(node.slice)
+                    finally:
+                        del self._kids[depth:]
+                return ("var", node.value.attr, self.select(view, m).mask)
         raise NotTranslatable("assignment target")
 
-    def mask(self, node) -> _V:
-        m = self.expr(node)
-        if m.ty not in ("b", "wb") or not m.array:
-            raise NotTranslatable("a selection that is not a boolean mask over the particles")
-        t = self.new_slot("b")
-        self.emit(f"{t} = {m.code};")
-        return _V(t, "b", array=True)
+    @staticmethod
+    def check_store_domain(value: _V, mask):
+        if value.array and value.dom != (mask.code if mask is not None else None):
+            raise NotTranslatable("assignment of an array over another selection of the particles (NumPy would need matching shapes)")
 
     def assign(self, tgt, value: _V, alias=False):
         if tgt[0] == "local":
@@ -567,14 +724,15 @@ class _Translator(ast.NodeVisitor):
             if value.array:
                 slot = self.new_slot(ty)
                 self.emit(f"{slot} = {_cast(value, ty)};")
-                self.locals[tgt[1]] = _V(slot, ty, array=True)
+                self.locals[tgt[1]] = _V(slot, ty, array=True, dom=value.dom, explicit=True)
             else:
                 self.locals[tgt[1]] = value  # a scalar stays a (weak) scalar
             (self.aliases.add if alias else self.aliases.discard)(tgt[1])
+            self.views.pop(tgt[1], None)
+            self.index_locals.pop(tgt[1], None)
         else:
             _, name, mask = tgt
-            if mask is not None and value.array:
-                raise NotTranslatable("masked assignment of an array (NumPy would need matching shapes)")
+            self.check_store_domain(value, mask)
             self.store_var(name, value, mask)
 
     def run(self):
@@ -583,6 +741,7 @@ class _Translator(ast.NodeVisitor):
 
     def run_body(self, body, top):
         for i, st in enumerate(body):
+            self._stmt_masks = {}
             if isinstance(st, ast.Expr) and isinstance(st.value, ast.Constant) and isinstance(st.value.value, str):
                 continue
             if isinstance(st, ast.Pass):
@@ -605,8 +764,22 @@ class _Translator(ast.NodeVisitor):
                             continue
                         self.assign(self.target(el), comp)
                 else:
+                    if isinstance(t, ast.Name) and t.id not in (self.pname, self.fname):
+                        if isinstance(st.value, ast.Subscript):
+                            view = self.view_of(st.value)  # ptcls = particles[mask]
+                            if view is not None:
+                                self.views[t.id] = view
+                                self.locals.pop(t.id, None)
+                                self.index_locals.pop(t.id, None)
+                                continue
+                        im = self.index_mask(st.value) if isinstance(st.value, ast.Call) else None  # inds = np.where(cond)
+                        if im is not None:
+                            self.index_locals[t.id] = im
+                            self.locals.pop(t.id, None)
+                            self.views.pop(t.id, None)
+                            continue
                     tgt = self.target(t)  # (the mask, if any, is evaluated first: it cannot depend on the value)
-                    bare = isinstance(st.value, ast.Attribute) and isinstance(st.value.value, ast.Name) and st.value.value.id == self.pname
+                    bare = isinstance(st.value, ast.Attribute) and self.view_of(st.value.value) is not None
                     self.assign(tgt, self.expr(st.value), alias=bare)
                 continue
             if isinstance(st, ast.If):  # only a condition that is a constant of the run (fieldset.<context>, module constants): one branch
@@ -625,6 +798,8 @@ class _Translator(ast.NodeVisitor):
                     if not isinstance(st.op, (ast.Add, ast.Sub, ast.Mult, ast.Div)):
                         raise NotTranslatable(f"in-place {type(st.op).__name__}")
                     cur, val = self.locals[lname], self.expr(st.value)
+                    if val.array and val.dom != cur.dom:
+                        raise NotTranslatable("in-place operator with an array over another selection of the particles")
                     ty = _promote(cur, val)
                     if isinstance(st.op, ast.Div) and ty in ("i32", "i64"):
                         ty = "f64"
@@ -634,13 +809,12 @@ class _Translator(ast.NodeVisitor):
                     ct = _strong(ty)
                     slot = self.new_slot(cur.ty)
                     self.emit(f"{slot} = {_cast(_V(f'({_cast(cur, ct)} {sym} {_cast(val, ct)})', ct), cur.ty)};")
-                    self.locals[lname] = _V(slot, cur.ty, array=True)
+                    self.locals[lname] = _V(slot, cur.ty, array=True, dom=cur.dom, explicit=True)
                     continue
                 _, name, mask = tgt
                 cur = self.load_var(name)
                 val = self.expr(st.value)
-                if mask is not None and val.array:
-                    raise NotTranslatable("masked in-place operator with an array operand")
+                self.check_store_domain(val, mask)
                 if not isinstance(st.op, (ast.Add, ast.Sub, ast.Mult, ast.Div)):
                     raise NotTranslatable(f"in-place {type(st.op).__name__}")
                 ty = _promote(cur, val)
@@ -659,16 +833,20 @@ class _Translator(ast.NodeVisitor):
 
 
 class UserKernelSource:
-    def __init__(self, name, decl, stages, touched, sampled=(), detached=False):
+    def __init__(self, name, decl, stages, touched, sampled=(), detached=False, counter=None):
         self.name, self.decl, self.stages, self.touched, self.sampled = name, decl, stages, touched, list(sampled)
         self.detached = detached  # samples without the particles: restores PCtx::state / ei, which the dedicated kernels keep elsewhere
+        # kernels that sample for a sub-selection of the particles: a lane outside it goes straight on to the statements behind the sample,
+        # so the stage the caller counts (one per request) is not the place in the kernel any more -- the kernel keeps its own (this slot)
+        self.counter = counter
 
     def case_body(self) -> str:
-        out = ["switch (stage) {"]
+        out = ["switch (stage) {"] if self.counter is None else [f"if (stage == 0) {self.counter} = 0;", f"switch ({self.counter}) {{"]
         for k, lines in enumerate(self.stages):
             out.append(f"    case {k}: {{")
-            out += ["        " + ln for ln in lines]
-            out.append("    }")
+            mark = "" if self.counter is None else f"{self.counter} = {k + 1}; "
+            out += ["        " + ln.replace(_NEXT_STAGE, mark) for ln in lines]
+            out.append("    }" if self.counter is None else "    }  // fall through")
         out.append("    default: return true;")
         out.append("}")
         return "\n".join(out)
@@ -681,7 +859,8 @@ def translate(func, pclass, fieldset, var_slot, field_ids, next_dt_f32=False, sl
     except (OSError, TypeError, SyntaxError, IndentationError) as e:
         raise NotTranslatable(f"source of {getattr(func, '__name__', func)!r} is not available: {e}") from None
     tr.run()
-    return UserKernelSource(func.__name__, tr.decl, tr.stages, tr.touched, tr.sampled, tr.detached)
+    counter = tr.new_slot("i32", "stage") if tr.conditional else None
+    return UserKernelSource(func.__name__, tr.decl, tr.stages, tr.touched, tr.sampled, tr.detached, counter)
 
 
 def candidate_variables(func, pclass):

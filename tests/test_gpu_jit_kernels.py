@@ -372,3 +372,79 @@ def test_samples_without_the_particles(gpu, mesh):
         warnings.simplefilter("ignore")  # (the host path warns about values masked to 0, field.py:359-370)
         p, d = _both([GradientT, pa.AdvectionEE], mesh=mesh, context={"h": 60 * h}, margin=0.02, n=200, runtime=3 * 600.0)
     assert len(p) == 200 and np.all(d["state"] < 50)
+
+
+# ---- selections of the particles (the reference's ParticleSetView, particlesetview.py) ----------------------------------------------------
+CYCLE_SPEED, DRIFT_DEPTH, MAX_DEPTH, MIN_DEPTH, DRIFT_TIME, CYCLE_TIME = 0.002, 2.0, 4.0, 0.5, 1800.0, 5400.0
+
+
+def ArgoCycle(particles, fieldset):
+    """tutorial_Argofloats.ipynb (its ArgoVerticalMovement, `count` as the phase): selections bound to locals, masks within them, a tracer
+    sample at the positions of the floats in ONE phase."""
+    ptcls0 = particles[particles.count == 0]
+    ptcls1 = particles[particles.count == 1]
+    ptcls2 = particles[particles.count == 2]
+    ptcls3 = particles[particles.count == 3]
+    ptcls4 = particles[particles.count == 4]
+    ptcls0.dz += CYCLE_SPEED * ptcls0.dt
+    next_phase = ptcls0.z + ptcls0.dz >= DRIFT_DEPTH
+    ptcls0.count[next_phase] = 1
+    ptcls0.dz[next_phase] = DRIFT_DEPTH - ptcls0.z[next_phase]
+    ptcls1.age += ptcls1.dt
+    next_phase = ptcls1.age >= DRIFT_TIME
+    ptcls1.count[next_phase] = 2
+    ptcls1.age[next_phase] = 0
+    ptcls2.dz += CYCLE_SPEED * ptcls2.dt
+    next_phase = ptcls2.z + ptcls2.dz >= MAX_DEPTH
+    ptcls2.count[next_phase] = 3
+    ptcls2.dz[next_phase] = MAX_DEPTH - ptcls2.z[next_phase]
+    ptcls3.dz -= CYCLE_SPEED * ptcls3.dt
+    ptcls3.temp = fieldset.T[ptcls3.t, ptcls3.z, ptcls3.y, ptcls3.x]
+    next_phase = ptcls3.z + ptcls3.dz <= MIN_DEPTH
+    ptcls3.count[next_phase] = 4
+    ptcls3.dz[next_phase] = MIN_DEPTH - ptcls3.z[next_phase]
+    next_phase = ptcls4.acc >= CYCLE_TIME
+    ptcls4.count[next_phase] = 0
+    ptcls4.acc[next_phase] = 0
+    ptcls4.temp = np.nan
+    particles.acc += particles.dt
+
+
+def WarmWaterDrift(particles, fieldset):
+    """tutorial_unstuck_Agrid.ipynb's SetDisplacement: a second sample only for the particles the first one selects."""
+    particles.temp = fieldset.T[particles]
+    warm = particles[particles.temp > 10.0]
+    dU, dV = fieldset.UV[warm]
+    warm.dx += dU * warm.dt * 0.5
+    warm.dy += dV * warm.dt * 0.5
+    particles[particles.temp <= 10.0].age += 1.0
+
+
+def BounceBack(particles, fieldset):
+    """tests/test_particleset_execute.py's MoveLeft / tutorial_statuscodes.md: recovery through an index selection."""
+    inds = np.where(particles.state == StatusCode.ErrorOutOfBounds)
+    particles[inds].dx = -particles[inds].dx
+    particles[inds].dy = -particles[inds].dy
+    particles[inds].count += 1
+    particles[inds].state = StatusCode.Evaluate
+
+
+@pytest.mark.parametrize("spatial", [np.float32, np.float64])
+def test_argo_cycle_over_selections(gpu, spatial):
+    p, d = _both([ArgoCycle, pa.AdvectionRK4], spatial=spatial, runtime=40 * 600.0)
+    prog = p._kernel.user_program
+    assert prog.sources[0].counter is not None and prog.sources[0].detached
+    assert (d["acc"] > 0).all() and (d["z"] != 0).any()  # the floats moved through their phases
+
+
+@pytest.mark.parametrize("mesh", ["flat", "spherical"])
+def test_a_sample_for_the_particles_an_earlier_sample_selects(gpu, mesh):
+    p, d = _both([pa.AdvectionRK4, WarmWaterDrift], mesh=mesh)
+    assert p._kernel.user_program.sources[0].counter is not None and p._last_stats["program"] == 100  # rides in the dedicated A-grid kernel
+    assert 0 < (d["age"] > 0).sum() < len(d["age"])  # some particles were warm, some were not
+    _both([WarmWaterDrift, pa.AdvectionEE, Age], mesh=mesh, spatial=np.float64)
+
+
+def test_recovery_through_an_index_selection(gpu):
+    p, d = _both([pa.AdvectionRK4, BounceBack], margin=0.01, runtime=60 * 600.0, n=400)
+    assert len(p) == 400 and d["count"].max() >= 1

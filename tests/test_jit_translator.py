@@ -46,8 +46,9 @@ PK_DEV bool user_prepare(const KArgs& a, int uk, int stage, int kslot, PCtx& c, 
 // state = max(state, sstate[k * n + i]) and ei0 = sei[k * n + i]; req[(k * 6 + j) * n + i]: t, z, y, x, f32 flag, kind * 100 + fidx of the request
 extern "C" void run(int64_t n, int pf, double* t, double* z, double* y, double* x, double* dz, double* dy, double* dx, double* dt,
                     int32_t* state, int64_t* id, void* e0, void* e1, void* e2, void* e3, const double* samples, int32_t* nsamples,
-                    const int32_t* sstate, const int32_t* sei, int32_t* ei0, double* req) {
+                    const int32_t* sstate, const int32_t* sei, int32_t* ei0, double* req, uint8_t* asked, const int32_t* positional) {
     KArgs a;
+    *nsamples = 0;
     a.p.extra[0] = e0; a.p.extra[1] = e1; a.p.extra[2] = e2; a.p.extra[3] = e3;
     for (int64_t i = 0; i < n; i++) {
         PState p = {t[i], z[i], y[i], x[i], dz[i], dy[i], dx[i], dt[i], 0.0, id[i]};
@@ -56,14 +57,18 @@ extern "C" void run(int64_t n, int pf, double* t, double* z, double* y, double* 
         memset(&L, 0, sizeof(L));
         Request rq;
         int k = 0;
-        for (int stage = 0; !user_prepare(a, 0, stage, 0, c, p, L, rq); stage++, k++) {
-            for (int j = 0; j < 3; j++) L.r[3 + j] = samples[((int64_t)k * 3 + j) * n + i];
+        for (int stage = 0; !user_prepare(a, 0, stage, 0, c, p, L, rq); stage++) {
+            // which sample of the kernel this is: the stage, or -- in a kernel whose samples are conditional -- its own counter
+            k = %(ordinal)s;
+            for (int j = 0; j < 3; j++)
+                L.r[3 + j] = positional[k] ? (((rq.x * 1.25 + rq.y * 0.5) - rq.z * 0.25) + rq.t * 0.001) * (j + 1) : samples[((int64_t)k * 3 + j) * n + i];
             const double r6[6] = {rq.t, rq.z, rq.y, rq.x, rq.f32 ? 1.0 : 0.0, (double)(rq.kind * 100 + rq.fidx)};
             for (int j = 0; j < 6; j++) req[((int64_t)k * 6 + j) * n + i] = r6[j];
+            asked[(int64_t)k * n + i] = 1;
             if (sstate[(int64_t)k * n + i] > c.state) c.state = sstate[(int64_t)k * n + i];
             c.ei0 = sei[(int64_t)k * n + i];
+            if (k + 1 > *nsamples) *nsamples = k + 1;
         }
-        *nsamples = k;
         ei0[i] = c.ei0;
         t[i] = p.t; z[i] = p.z; y[i] = p.y; x[i] = p.x; dz[i] = p.dz; dy[i] = p.dy; dx[i] = p.dx; dt[i] = p.dt; state[i] = c.state;
     }
@@ -75,8 +80,9 @@ class _FakeField:
     """Answers a sample from arrays, logs the sample point, and does to the particles what the library's sampling does (when it is handed
     them): raises the state to `sstate` and writes `ei`."""
 
-    def __init__(self, values, log=None, effects=None):
+    def __init__(self, values, log=None, effects=None, positional=False):
         self.values = values  # list of component arrays (1 for a scalar field, 2 / 3 for UV / UVW)
+        self.positional = positional  # the value is a function of the sample point instead (samples without particles on a sub-selection)
         self.log = log if log is not None else []
         self.effects = effects  # (sstate[k], sei[k]) per sample of the run, or None
 
@@ -87,16 +93,21 @@ class _FakeField:
             if rows is None:  # the reference's ParticleSetView: a boolean mask over the particle set
                 rows = np.flatnonzero(vars(particles)["_index"])
         else:
-            rows = np.arange(len(self.values[0]))
+            rows = np.arange(len(self.values[0])) if not self.positional else None  # (positional: whichever particles the points belong to)
         t, z, y, x = key[:4] if isinstance(key, tuple) else (particles.t, particles.z, particles.y, particles.x)
         k = len(self.log)
-        self.log.append({"t": np.asarray(t, dtype=np.float64), "z": np.asarray(z, dtype=np.float64), "y": np.asarray(y, dtype=np.float64),
+        self.log.append({"rows": np.asarray(rows),"t": np.asarray(t, dtype=np.float64), "z": np.asarray(z, dtype=np.float64), "y": np.asarray(y, dtype=np.float64),
                          "x": np.asarray(x, dtype=np.float64), "f32": np.asarray(y).dtype == np.float32, "attached": particles is not None, "implicit": not isinstance(key, tuple)})
         if particles is not None and self.effects is not None:
             sstate, sei = self.effects
             particles.state = np.maximum(np.asarray(particles.state), sstate[k][rows])
             vars(particles)["_data"]["ei"][rows, 0] = sei[k][rows]
-        out = tuple(v[rows] for v in self.values)
+        if self.positional:
+            e = self.log[-1]
+            base = ((e["x"] * 1.25 + e["y"] * 0.5) - e["z"] * 0.25) + e["t"] * 0.001
+            out = tuple(base * (j + 1) for j in range(len(self.values)))
+        else:
+            out = tuple(v[rows] for v in self.values)
         return out[0] if len(out) == 1 else out
 
 
@@ -138,10 +149,11 @@ def _columns(pclass, n, seed, finite=False):
     return data
 
 
-def _run_translated(func, pclass, fieldset, data, var_slot, field_ids, samples, tmp_path, effects=None):
+def _run_translated(func, pclass, fieldset, data, var_slot, field_ids, samples, tmp_path, effects=None, positional=None):
     src = jit.translate(func, pclass, fieldset, var_slot, field_ids)
     body = "\n".join("            " + ln for ln in src.case_body().split("\n"))
-    code = SHIM % {"decl": "\n".join("    " + d for d in src.decl) or "    char unused;", "body": body}
+    code = SHIM % {"decl": "\n".join("    " + d for d in src.decl) or "    char unused;", "body": body,
+                   "ordinal": "stage" if src.counter is None else f"{src.counter} - 1"}
     cpp = tmp_path / f"{func.__name__}.cpp"
     so = tmp_path / f"{func.__name__}.so"
     cpp.write_text(code)
@@ -161,10 +173,12 @@ def _run_translated(func, pclass, fieldset, data, var_slot, field_ids, samples, 
     sstate, sei = np.ascontiguousarray(sstate, dtype=np.int32), np.ascontiguousarray(sei, dtype=np.int32)
     ei0 = np.array(data["ei"][:, 0], dtype=np.int32)
     req = np.zeros((nsam, 6, n))
+    asked = np.zeros((nsam, n), np.uint8)
+    positional = np.ascontiguousarray(positional if positional is not None else np.zeros(nsam), dtype=np.int32)
     ptr = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None  # noqa: E731
     lib.run(C.c_int64(n), C.c_int(int(pf)), *[ptr(cols[k]) for k in ("t", "z", "y", "x", "dz", "dy", "dx", "dt")], ptr(state), ptr(pid),
-            *[ptr(e) for e in extras], ptr(sam), C.byref(ns), ptr(sstate), ptr(sei), ptr(ei0), ptr(req))
-    src.requests = req
+            *[ptr(e) for e in extras], ptr(sam), C.byref(ns), ptr(sstate), ptr(sei), ptr(ei0), ptr(req), ptr(asked), ptr(positional))
+    src.requests, src.asked = req, asked.astype(bool)
     out = {k: cols[k].astype(data[k].dtype) for k in cols}
     out["state"] = state
     out["ei"] = ei0.reshape(-1, 1)
@@ -173,7 +187,7 @@ def _run_translated(func, pclass, fieldset, data, var_slot, field_ids, samples, 
     return out, ns.value, src
 
 
-def _check(func, tmp_path, *, spatial=np.float32, context=None, fields=None, n=400, seed=0, finite=False, grid=None, codes=(51, 60, 61, 70)):
+def _check(func, tmp_path, *, spatial=np.float32, context=None, fields=None, n=400, seed=0, finite=False, grid=None, codes=(51, 60, 61, 70), positional=(), check_nsamples=True):
     P = pa.get_default_particle(spatial).add_variable([
         pa.Variable("age", dtype=np.float32, initial=0), pa.Variable("acc", dtype=np.float64, initial=0),
         pa.Variable("count", dtype=np.int32, initial=0), pa.Variable("flag", dtype=np.int64, initial=0)])
@@ -189,7 +203,7 @@ def _check(func, tmp_path, *, spatial=np.float32, context=None, fields=None, n=4
     for name, ncomp in order:
         if name in fake_fields:
             continue
-        f = _FakeField([rng.normal(size=n) for _ in range(ncomp)], log, effects)
+        f = _FakeField([rng.normal(size=n) for _ in range(ncomp)], log, effects, positional=name in positional)
         if grid is not None:
             f.grid = grid
         if ncomp > 1:
@@ -202,8 +216,8 @@ def _check(func, tmp_path, *, spatial=np.float32, context=None, fields=None, n=4
         for j, comp in enumerate(fake_fields[name].values):
             sam[k, j] = comp
     fields = order
-    got, nsamples, src = _run_translated(func, P, fs, data, var_slot, field_ids, sam, tmp_path, effects)
-    assert nsamples == len(fields)
+    got, nsamples, src = _run_translated(func, P, fs, data, var_slot, field_ids, sam, tmp_path, effects, [int(name in positional) for name, _ in order])
+    assert nsamples == len(fields) or not check_nsamples  # (a conditional sample nobody takes is not counted)
     ref = {k: v.copy() for k, v in data.items()}
     with np.errstate(all="ignore"):
         func(HostParticles(ref, np.arange(n)), fs)
@@ -212,12 +226,19 @@ def _check(func, tmp_path, *, spatial=np.float32, context=None, fields=None, n=4
         assert np.array_equal(got[k], ref[k], equal_nan=True), (func.__name__, k, np.flatnonzero(~((got[k] == ref[k]) | (np.isnan(got[k].astype(float)) & np.isnan(ref[k].astype(float)))))[:5])
     # every sample: same field, same point (bit for bit), same float32-ness of y
     assert len(log) == len(fields)
+    assert nsamples <= len(fields)
     for k, ((name, ncomp), entry) in enumerate(zip(fields, log)):
+        rows = entry["rows"]
+        if rows.ndim == 0:  # (a positional fake sampled without particles: the points must be those of the lanes that asked, in order)
+            rows = np.flatnonzero(src.asked[k])
+            assert len(rows) == len(entry["x"])
+            entry["rows"] = rows
+        assert np.array_equal(np.flatnonzero(src.asked[k]), rows), (func.__name__, "which particles take sample", k)
         for j, c in enumerate("tzyx"):
-            assert np.array_equal(src.requests[k, j], entry[c], equal_nan=True), (func.__name__, "sample", k, c)
-        assert np.all(src.requests[k, 4] == float(entry["f32"])), (func.__name__, k)
+            assert np.array_equal(src.requests[k, j][rows], np.broadcast_to(entry[c], rows.shape), equal_nan=True), (func.__name__, "sample", k, c)
+        assert np.all(src.requests[k, 4][rows] == float(entry["f32"])), (func.__name__, k)
         kind = {1: 2, 2: 0, 3: 1}[ncomp]
-        assert np.all(src.requests[k, 5] == kind * 100 + (field_ids[name] if ncomp == 1 else 0))
+        assert np.all(src.requests[k, 5][rows] == kind * 100 + (field_ids[name] if ncomp == 1 else 0))
     src.log = log
     return src
 
@@ -519,3 +540,125 @@ print(prog.build())
 
 def InPlaceAge(particles, fieldset):
     particles.age += particles.dt
+
+
+# ---- selections of the particles (ParticleSetView of the reference: particlesetview.py) --------------------------------------------------
+OUT_OF_BOUNDS_STATES = [StatusCode.ErrorOutOfBounds, StatusCode.ErrorThroughSurface]
+SPEED, DRIFT_DEPTH, MAX_DEPTH, MIN_DEPTH, DRIFT_TIME, CYCLE_TIME = 0.1, 2.0, 4.0, -1.0, 1800.0, 3000.0
+
+
+def ArgoLike(particles, fieldset):
+    """tutorial_Argofloats.ipynb: a state machine over sub-selections of the particles bound to locals, masks within them, a sample
+    at the positions of one of them."""
+    ptcls0 = particles[particles.count == 0]
+    ptcls1 = particles[particles.count == 1]
+    ptcls2 = particles[particles.count == 2]
+    ptcls3 = particles[particles.count == 3]
+    ptcls4 = particles[particles.count == 4]
+    ptcls0.dz += SPEED * ptcls0.dt
+    next_phase = ptcls0.z + ptcls0.dz >= DRIFT_DEPTH
+    ptcls0.count[next_phase] = 1
+    ptcls0.dz[next_phase] = DRIFT_DEPTH - ptcls0.z[next_phase]
+    ptcls1.age += ptcls1.dt
+    next_phase = ptcls1.age >= DRIFT_TIME
+    ptcls1.count[next_phase] = 2
+    ptcls1.age[next_phase] = 0
+    ptcls2.dz += SPEED * ptcls2.dt
+    next_phase = ptcls2.z + ptcls2.dz >= MAX_DEPTH
+    ptcls2.count[next_phase] = 3
+    ptcls2.dz[next_phase] = MAX_DEPTH - ptcls2.z[next_phase]
+    ptcls3.dz -= SPEED * ptcls3.dt
+    ptcls3.acc = fieldset.T[ptcls3.t, ptcls3.z, ptcls3.y, ptcls3.x]
+    next_phase = ptcls3.z + ptcls3.dz <= MIN_DEPTH
+    ptcls3.count[next_phase] = 4
+    ptcls3.dz[next_phase] = MIN_DEPTH - ptcls3.z[next_phase]
+    next_phase = ptcls4.acc >= CYCLE_TIME
+    ptcls4.count[next_phase] = 0
+    ptcls4.acc[next_phase] = 0
+    ptcls4.age = np.nan
+    particles.acc += particles.dt
+
+
+def NearShore(particles, fieldset):
+    """tutorial_unstuck_Agrid.ipynb: a second sample for the particles the first one selects."""
+    particles.age = fieldset.T[particles]
+    near = particles[particles.age < 0.5]
+    dU, dV = fieldset.UV[near]
+    near.dx += dU * near.dt
+    near.dy += dV * near.dt
+    particles.acc = fieldset.T2[particles.t, particles.z, particles.y, particles.x, particles]
+
+
+def Recovery(particles, fieldset):
+    """tutorial_statuscodes.md / tutorial_schism.ipynb / tests: recovery kernels over selections."""
+    through_surface = particles.state == StatusCode.ErrorThroughSurface
+    particles[through_surface].dz = fieldset.surface - particles[through_surface].z
+    particles[through_surface].state = StatusCode.Evaluate
+    oob = np.isin(particles.state, OUT_OF_BOUNDS_STATES)
+    particles[oob].flag = 1
+    particles[oob].state = StatusCode.Delete
+    inds = np.where(particles.state == StatusCode.ErrorOutsideTimeInterval)
+    particles[inds].dx -= 1.0
+    particles[inds].state = StatusCode.Success
+    rows = np.argwhere(particles.state == StatusCode.Success).flatten()
+    u, v = fieldset.UV[particles[rows]]
+    particles[rows].dx = u * particles[rows].dt
+    particles[rows].dy = v * particles[rows].dt
+    particles[rows].state = StatusCode.Evaluate
+
+
+def Heating(particles, fieldset):
+    """tests/test_particlesetview.py: in-place operators through inline selections, groups chosen by earlier stores."""
+    particles[particles.x < 0.5].age += 1.0
+    particles[particles.x >= 0.5].age -= 0.5
+    particles[particles.x < -0.33].count = 1
+    particles[(particles.x >= -0.33) & (particles.x < 0.67)].count = 2
+    particles[particles.x >= 0.67].count = 3
+    particles[particles.count == 1].flag += 1
+    particles[particles.count == 2].flag += 2
+    sel = particles[particles.count == 3]
+    sel[sel.flag < 0].acc = sel[sel.flag < 0].acc * 2 + sel[sel.flag < 0].x
+
+
+@pytest.mark.parametrize("spatial", [np.float32, np.float64])
+def test_state_machine_over_selections(tmp_path, spatial):
+    src = _check(ArgoLike, tmp_path, spatial=spatial, fields=[("T", 1)], seed=31, finite=True, grid=_RectGrid(), codes=(51, 60, 61), positional=("T",))
+    assert src.counter is not None and src.detached and 0 < len(src.log[0]["rows"]) < 400  # only the particles in phase 3 take the sample
+
+
+@pytest.mark.parametrize("spatial", [np.float32, np.float64])
+def test_a_sample_for_the_particles_an_earlier_sample_selects(tmp_path, spatial):
+    src = _check(NearShore, tmp_path, spatial=spatial, fields=[("T", 1), ("UV", 2), ("T2", 1)], seed=32, finite=True)
+    assert src.counter is not None and 0 < len(src.log[1]["rows"]) < 400 and len(src.log[2]["rows"]) == 400
+
+
+def test_recovery_kernels_over_selections(tmp_path):
+    src = _check(Recovery, tmp_path, context={"surface": 0.25}, fields=[("UV", 2)], seed=33, finite=True)
+    assert 0 < len(src.log[0]["rows"]) < 400
+
+
+@pytest.mark.parametrize("spatial", [np.float32, np.float64])
+def test_inline_selections(tmp_path, spatial):
+    _check(Heating, tmp_path, spatial=spatial, seed=34, finite=True)
+
+
+def test_arrays_over_different_selections_do_not_mix(tmp_path):
+    P = pa.get_default_particle(np.float32).add_variable([pa.Variable("acc", dtype=np.float64, initial=0)])
+    fs = _FakeFieldSet({}, {})
+
+    def Mixed(particles, fieldset):
+        a = particles[particles.x > 0]
+        particles.acc = a.x * 2            # (NumPy: shapes differ)
+
+    def Mixed2(particles, fieldset):
+        a = particles[particles.x > 0]
+        b = particles[particles.y > 0]
+        a.acc = a.x + b.x
+
+    def AsValue(particles, fieldset):
+        a = particles[particles.x > 0]
+        particles.acc = a
+
+    for k, pat in ((Mixed, "another selection"), (Mixed2, "different selections"), (AsValue, "used as a value")):
+        with pytest.raises(jit.NotTranslatable, match=pat):
+            jit.translate(k, P, fs, {"acc": (0, "f64")}, {})

@@ -221,3 +221,169 @@ def test_random_kernel_on_the_references_own_view(tmp_path, seed):
         pytest.skip("the generated kernel divides Python constants by zero: not a kernel")
     for k in a:
         assert a[k].dtype == b[k].dtype and np.array_equal(a[k], b[k], equal_nan=True), (k, src)
+
+
+# ---- selections of the particles ---------------------------------------------------------------------------------------------------------
+class GenViews(Gen):
+    """Random kernels over SELECTIONS of the particles: locals bound to particles[cond], stores / in-place operators / masked stores through
+    them, inline selections, np.where(cond) index selections, samples for a selection (conditional requests: the kernel keeps its own stage
+    counter) and samples at computed points."""
+
+    def __init__(self, seed):
+        super().__init__(seed)
+        self.view_names = []
+        self.view_locals = {}  # view name -> float locals that live on it
+
+    def over(self, view, text):
+        return text.replace("particles.", f"{view}.")
+
+    def vexpr(self, view, depth, integer=False):
+        keep = (self.locals_f, self.locals_i)
+        self.locals_f, self.locals_i = list(self.view_locals.get(view, [])), []  # (full-length temporaries do not combine with a selection)
+        try:
+            e = self.iexpr(depth) if integer else self.fexpr(depth)
+        finally:
+            self.locals_f, self.locals_i = keep
+        return self.over(view, e)
+
+    def vcond(self, view, depth):
+        keep = (self.locals_f, self.locals_i)
+        self.locals_f, self.locals_i = list(self.view_locals.get(view, [])), []
+        try:
+            c = self.cond(depth)
+        finally:
+            self.locals_f, self.locals_i = keep
+        return self.over(view, c)
+
+    def view_statement(self):
+        fvars, ivars = ["age", "acc", "dx", "dy", "dz"], ["count", "flag"]
+        r = self.rng.random()
+        if not self.view_names or r < 0.22:
+            name = f"sel{len(self.view_names)}"
+            if self.view_names and self.rng.random() < 0.3:  # a selection within a selection
+                parent = self.pick(self.view_names)
+                st = f"{name} = {parent}[{self.vcond(parent, 1)}]"
+            elif self.rng.random() < 0.25:
+                st = f"{name} = particles[np.where({self.vcond('particles', 1)})]"
+            else:
+                st = f"{name} = particles[{self.vcond('particles', 1)}]"
+            self.view_names.append(name)
+            self.view_locals[name] = []
+            return st
+        v = self.pick(self.view_names)
+        if r < 0.45:
+            return f"{v}.{self.pick(fvars)} = {self.pick([self.vexpr(v, 2), self.const(False)])}"
+        if r < 0.6:
+            return f"{v}.{self.pick(fvars)} {self.pick(['+=', '-=', '*='])} {self.pick([self.vexpr(v, 1), self.const(False)])}"
+        if r < 0.7:
+            return f"{v}.{self.pick(ivars)} = {self.pick([self.vexpr(v, 1, integer=True), self.const(True)])}"
+        if r < 0.8:
+            return f"{v}.{self.pick(fvars)}[{self.vcond(v, 1)}] = {self.const(False)}"
+        if r < 0.88:
+            return f"{v}.{self.pick(ivars)}[{self.vcond(v, 1)}] += {self.const(True)}"
+        name = f"g{sum(len(x) for x in self.view_locals.values())}_{v}"
+        st = f"{name} = {self.vexpr(v, 2)} * 1"
+        self.view_locals[v].append(name)
+        return st
+
+    def kernel(self, name):
+        nst = int(self.rng.integers(4, 10))
+        body, samples = [], []
+        for k in range(nst):
+            r = self.rng.random()
+            if r < 0.5:
+                body.append(self.view_statement())
+            elif r < 0.65 and self.view_names:  # a sample for a selection
+                v = self.pick(self.view_names)
+                j = len(samples)
+                if self.rng.random() < 0.5:
+                    fname = self.pick(["T", "S"])
+                    key = v if self.rng.random() < 0.5 else f"{v}.t, {v}.z, {v}.y + 0.25, {v}.x - {v}.dx, {v}"
+                    body.append(f"q{j}_{v} = fieldset.{fname}[{key}]")
+                    self.view_locals[v].append(f"q{j}_{v}")
+                    samples.append((fname, 1))
+                else:
+                    body.append(f"uu{j}_{v}, vv{j}_{v} = fieldset.UV[{v}]")
+                    self.view_locals[v] += [f"uu{j}_{v}", f"vv{j}_{v}"]
+                    samples.append(("UV", 2))
+            elif r < 0.75:  # a sample at a computed point, for all particles
+                j = len(samples)
+                fname = self.pick(["T", "S"])
+                body.append(f"p{j} = fieldset.{fname}[particles.t + particles.dt, particles.z, particles.y * 1, particles.x + {self.fexpr(1)}, particles]")
+                self.locals_f.append(f"p{j}")
+                samples.append((fname, 1))
+            else:
+                body.append(self.statement())
+        return f"import numpy as np\n\n\ndef {name}(particles, fieldset):\n" + "".join(f"    {s}\n" for s in body), samples
+
+
+def _load(tmp_path, src, name, tag):
+    path = tmp_path / f"{tag}.py"
+    path.write_text(src)
+    spec = importlib.util.spec_from_file_location(tag, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return getattr(mod, name)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PARCELS_JIT_FUZZ_SEEDS", "48"))))
+def test_random_kernel_over_selections_equals_numpy(tmp_path, seed):
+    name = f"V{seed}"
+    src, samples = GenViews(seed).kernel(name)
+    func = _load(tmp_path, src, name, f"fuzz_views_{seed}")
+    try:
+        T._check(func, tmp_path, spatial=np.float32 if seed % 2 else np.float64, context={"c1": 0.75, "c2": np.float32(1.5)},
+                 seed=2000 + seed, n=256, fields=samples, check_nsamples=False)
+    except ZeroDivisionError:
+        pytest.skip("the generated kernel divides Python constants by zero: not a kernel")
+    except T.jit.NotTranslatable as e:
+        pytest.skip(f"not translatable: {e}")
+    except Exception as e:
+        raise AssertionError(f"{type(e).__name__}: {e}\n--- kernel ---\n{src}") from None
+
+
+@pytest.mark.skipif(_reference_view() is None, reason="reference tree not present")
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PARCELS_JIT_FUZZ_SEEDS", "48"))))
+def test_random_kernel_over_selections_on_the_references_own_view(tmp_path, seed):
+    """Selections of selections, masks within them, np.where index selections and samples for a selection: the REFERENCE's ParticleSetView
+    and HostParticles leave the same columns (and hand the fields the same points, in the same order)."""
+    import parcels_amd as pa
+    from parcels_amd.hostkernels import HostParticles
+
+    View = _reference_view()
+    name = f"V{seed}"
+    src, samples = GenViews(seed).kernel(name)
+    func = _load(tmp_path, src, name, f"fuzz_views_ref_{seed}")
+    n = 256
+    P = pa.get_default_particle(np.float32 if seed % 2 else np.float64).add_variable([
+        pa.Variable("age", dtype=np.float32, initial=0), pa.Variable("acc", dtype=np.float64, initial=0),
+        pa.Variable("count", dtype=np.int32, initial=0), pa.Variable("flag", dtype=np.int64, initial=0)])
+    data = T._columns(P, n, 2000 + seed)
+    out, logs = [], []
+    for make in (lambda d: View(d, np.ones(n, dtype=bool), P), lambda d: HostParticles(d, np.arange(n))):
+        rng = np.random.default_rng(seed + 100)
+        log, fields = [], {}
+        for fname, ncomp in samples:
+            if fname not in fields:
+                fields[fname] = T._FakeField([rng.normal(size=n) for _ in range(ncomp)], log)
+                if ncomp > 1:
+                    fields[fname].U = fields[fname].V = None
+        fs = T._FakeFieldSet({"c1": 0.75, "c2": np.float32(1.5)}, fields)
+        d = {k: v.copy() for k, v in data.items()}
+        try:
+            with np.errstate(all="ignore"):
+                func(make(d), fs)
+        except ZeroDivisionError:
+            pytest.skip("the generated kernel divides Python constants by zero: not a kernel")
+        except TypeError as e:
+            if not out:  # e.g. `%`: the reference's column proxy has no __mod__ (HostParticles is a superset)
+                pytest.skip(f"the reference's own view does not support this kernel: {e}")
+            raise
+        out.append(d)
+        logs.append(log)
+    a, b = out
+    for k in a:
+        assert a[k].dtype == b[k].dtype and np.array_equal(a[k], b[k], equal_nan=True), (k, src)
+    assert len(logs[0]) == len(logs[1])
+    for ea, eb in zip(*logs):
+        assert np.array_equal(ea["rows"], eb["rows"]) and ea["f32"] == eb["f32"] and all(np.array_equal(ea[c], eb[c], equal_nan=True) for c in "tzyx"), src

@@ -52,12 +52,17 @@ def kernel_defs(path):
                 yield node.name, ast.unparse(node)
 
 
+class _Grid:
+    is_curvilinear = False
+
+
 class _Field:
-    pass
+    grid = _Grid()
 
 
 class _Vector:
-    U = V = None
+    U = _Field()
+    V = _Field()
 
 
 class _FS:
@@ -65,25 +70,43 @@ class _FS:
         self.fields, self.context = fields, context
 
 
+def _root(node):
+    while isinstance(node, (ast.Subscript, ast.Attribute)):
+        node = node.value
+    return node.id if isinstance(node, ast.Name) else None
+
+
 def permissive_context(src):
+    """Everything the kernel mentions exists: `particles.<name>` (also through selections bound to locals) are float32 Variables,
+    `fieldset.<name>[...]` fields on a rectilinear grid (vector fields when unpacked into a tuple), other `fieldset.<name>` constants."""
     import parcels_amd as pa
 
     tree = ast.parse(src)
     fdef = tree.body[0]
     pname, fname = fdef.args.args[0].arg, fdef.args.args[1].arg
     core = {v.name for v in pa.get_default_particle(np.float32).variables} | {"ei"}
+    selections = {pname}
+    for _ in range(3):
+        for n in ast.walk(tree):
+            if isinstance(n, ast.Assign) and len(n.targets) == 1 and isinstance(n.targets[0], ast.Name) and isinstance(n.value, ast.Subscript) \
+                    and _root(n.value) in selections:
+                selections.add(n.targets[0].id)
     variables, fields, consts = [], {}, {}
-    sampled = set()
+    sampled, vectors = set(), set()
     for n in ast.walk(tree):
         if isinstance(n, ast.Subscript) and isinstance(n.value, ast.Attribute) and isinstance(n.value.value, ast.Name) and n.value.value.id == fname:
             sampled.add(n.value.attr)
+        if isinstance(n, ast.Assign) and isinstance(n.targets[0], ast.Tuple) and isinstance(n.value, ast.Subscript) and isinstance(n.value.value, ast.Attribute) \
+                and _root(n.value.value) == fname:
+            vectors.add(n.value.value.attr)
     for n in ast.walk(tree):
-        if isinstance(n, ast.Attribute) and isinstance(n.value, ast.Name):
-            if n.value.id == pname and n.attr not in core and n.attr not in variables and not n.attr.startswith("_"):
+        if isinstance(n, ast.Attribute):
+            if _root(n.value) in selections and not (isinstance(n.value, ast.Name) and n.value.id == fname) and n.attr not in core \
+                    and n.attr not in variables and not n.attr.startswith("_") and n.attr not in ("shape", "flatten", "size"):
                 variables.append(n.attr)
-            if n.value.id == fname:
+            if isinstance(n.value, ast.Name) and n.value.id == fname:
                 if n.attr in sampled:
-                    fields[n.attr] = _Vector() if n.attr in ("UV", "UVW") else _Field()
+                    fields[n.attr] = _Vector() if (n.attr in ("UV", "UVW") or n.attr in vectors) else _Field()
                 else:
                     consts[n.attr] = 1.0
     pclass = pa.get_default_particle(np.float32).add_variable(
@@ -93,10 +116,30 @@ def permissive_context(src):
     return pclass, _FS(fields, consts), var_slot, field_ids
 
 
+def free_names(src):
+    """Module-level names the kernel reads that the snippet does not define (constants of the tutorial's notebook): given a value here."""
+    import builtins
+
+    tree = ast.parse(src)
+    fdef = tree.body[0]
+    bound = {a.arg for a in fdef.args.args} | {"np", "math", "parcels", "StatusCode"} | set(dir(builtins))
+    for n in ast.walk(tree):
+        if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Store):
+            bound.add(n.id)
+        if isinstance(n, (ast.FunctionDef, ast.Lambda)) and n is not fdef:
+            bound.add(getattr(n, "name", ""))
+    out = {}
+    for n in ast.walk(tree):
+        if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load) and n.id not in bound:
+            out[n.id] = "[60, 61]" if n.id.isupper() and n.id.endswith("STATES") else "1.5"
+    return out
+
+
 def load_function(name, src, tmpdir, k):
     path = os.path.join(tmpdir, f"k{k}.py")
     with open(path, "w") as f:
-        f.write("import math\nimport numpy as np\nimport parcels_amd as parcels\nfrom parcels_amd import StatusCode\n\n" + src + "\n")
+        f.write("import math\nimport numpy as np\nimport parcels_amd as parcels\nfrom parcels_amd import StatusCode\n\n"
+                + "".join(f"{k} = {v}\n" for k, v in free_names(src).items()) + "\n" + src + "\n")
     spec = importlib.util.spec_from_file_location(f"_survey_k{k}", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
