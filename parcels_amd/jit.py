@@ -65,10 +65,13 @@ def _ty_of_dtype(dt) -> str:
 class _V:
     """A typed elementwise expression: C++ code, NumPy dtype tag (or weak Python scalar tag), constant value, array-ness."""
 
-    __slots__ = ("code", "ty", "const", "array", "dom", "explicit")
+    __slots__ = ("code", "ty", "const", "array", "dom", "explicit", "values")
 
-    def __init__(self, code, ty, const=None, array=False, dom=None, explicit=False):
+    def __init__(self, code, ty, const=None, array=False, dom=None, explicit=False, values=None):
         self.code, self.ty, self.const, self.array = code, ty, const, array
+        # values: the set of values the expression can take where that is known statically (constants, `particles.state` itself -- the
+        # string "state" --, np.where over such): what a kernel may store into `state` is checked on it (store_var)
+        self.values = values if values is not None else ({const} if const is not None and not isinstance(const, float) else None)
         # dom: the sub-selection of the particles an array is defined on -- None: all of them; otherwise the code of the boolean slot that
         # selects them (`particles[mask].x`, `view.x`, `column[mask]`).  NumPy needs equal shapes to combine arrays: equal domains here.
         self.dom, self.explicit = dom, explicit
@@ -225,7 +228,7 @@ class _Translator(ast.NodeVisitor):
         if name in _SPATIAL or name in ("t", "dt", "next_dt"):
             code = f"p.{name}" if ty == "f64" else f"((float)p.{name})"
         elif name == "state":
-            code = "((int32_t)c.state)"
+            return _V("((int32_t)c.state)", ty, array=True, values={"state"})
         elif name == "particle_id":
             code = "((int64_t)p.id)"
         else:
@@ -243,6 +246,13 @@ class _Translator(ast.NodeVisitor):
         if name in _SPATIAL or name in ("t", "dt", "next_dt"):
             stmt = f"p.{name} = (double)({val});"
         elif name == "state":
+            # kernel.py:190-193: a particle in state Success is still evaluated, for as long as ANY particle of the set is in state Evaluate -- a
+            # property of the whole set at every iteration, which lanes that run their step loops independently cannot know
+            if value.values is None:
+                raise NotTranslatable("a computed value stored into particles.state (only status codes, particles.state and np.where over them)")
+            if int(StatusCode.Success) in {int(v) for v in value.values if v != "state"}:
+                raise NotTranslatable("StatusCode.Success stored into particles.state: the reference's loop keeps such particles running while any "
+                                      "other particle is (kernel.py:190-193) -- the host path does that")
             stmt = f"c.state = (int)({val});"
         else:
             stmt = f"(({_CT[ty]}*)a.p.extra[{self.var_slot[name][0]}])[c.row] = {val};"
@@ -613,7 +623,8 @@ class _Translator(ast.NodeVisitor):
             c, a, b = args
             ty = _strong(_promote(a, b))
             cond = c.code if c.ty in ("b", "wb") else f"(({c.code}) != 0)"
-            return _V(f"(({cond}) ? {_cast(a, ty)} : {_cast(b, ty)})", ty, array=arr)
+            return _V(f"(({cond}) ? {_cast(a, ty)} : {_cast(b, ty)})", ty, array=arr,
+                      values=(a.values | b.values) if a.values is not None and b.values is not None else None)
         if name in ("abs", "absolute", "fabs") and len(args) == 1:
             v = args[0]
             ty = _strong(v.ty)

@@ -599,7 +599,7 @@ def Recovery(particles, fieldset):
     particles[oob].state = StatusCode.Delete
     inds = np.where(particles.state == StatusCode.ErrorOutsideTimeInterval)
     particles[inds].dx -= 1.0
-    particles[inds].state = StatusCode.Success
+    particles[inds].state = StatusCode.StopExecution
     rows = np.argwhere(particles.state == StatusCode.Success).flatten()
     u, v = fieldset.UV[particles[rows]]
     particles[rows].dx = u * particles[rows].dt
@@ -662,3 +662,30 @@ def test_arrays_over_different_selections_do_not_mix(tmp_path):
     for k, pat in ((Mixed, "another selection"), (Mixed2, "different selections"), (AsValue, "used as a value")):
         with pytest.raises(jit.NotTranslatable, match=pat):
             jit.translate(k, P, fs, {"acc": (0, "f64")}, {})
+
+
+def test_kernels_that_set_success_stay_on_the_host_path():
+    """kernel.py:190-193: a particle in state Success is evaluated for as long as ANY particle is in state Evaluate -- a property of the whole
+    set (tests/test_particleset_execute.py's MoveLeft relies on it); so are states the translator cannot bound."""
+    P = pa.get_default_particle(np.float32).add_variable([pa.Variable("count", dtype=np.int32, initial=0)])
+    fs = _FakeFieldSet({}, {})
+
+    def MoveLeft(particles, fieldset):
+        inds = np.where(particles.state == StatusCode.ErrorOutOfBounds)
+        particles[inds].dx -= 1.0
+        particles[inds].state = StatusCode.Success
+
+    def ViaWhere(particles, fieldset):
+        particles.state = np.where(particles.x > 0, 0, particles.state)
+
+    def Computed(particles, fieldset):
+        particles.state = particles.count + 10
+
+    def Fine(particles, fieldset):
+        particles.state = np.where(particles.x > 0, StatusCode.Delete, np.where(particles.y > 0, StatusCode.StopExecution, particles.state))
+        particles[particles.state == StatusCode.ErrorOutOfBounds].state = StatusCode.Evaluate
+
+    for k, pat in ((MoveLeft, "StatusCode.Success"), (ViaWhere, "StatusCode.Success"), (Computed, "computed value")):
+        with pytest.raises(jit.NotTranslatable, match=pat):
+            jit.translate(k, P, fs, {"count": (0, "i32")}, {})
+    jit.translate(Fine, P, fs, {"count": (0, "i32")}, {})
