@@ -165,6 +165,11 @@ class Kernel:
             warnings.warn(f"user kernels could not be compiled for the device ({self.jit_report.splitlines()[0]}); running them on the host path",
                           KernelWarning, stacklevel=3)
             return
+        except Exception as e:  # noqa: BLE001 -- a construct the translator trips over must not take the run down: the host path runs any kernel
+            self.jit_report = f"translator error {type(e).__name__}: {e}"
+            warnings.warn(f"user kernels were not compiled for the device ({self.jit_report}); running them on the host path -- please report this kernel",
+                          KernelWarning, stacklevel=3)
+            return
         self.user_program = prog
         self.kernel_ids = ids
         self.device_variables = dev_vars
