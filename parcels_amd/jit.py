@@ -65,10 +65,13 @@ def _ty_of_dtype(dt) -> str:
 class _V:
     """A typed elementwise expression: C++ code, NumPy dtype tag (or weak Python scalar tag), constant value, array-ness."""
 
-    __slots__ = ("code", "ty", "const", "array", "dom", "explicit", "values")
+    __slots__ = ("code", "ty", "const", "array", "dom", "explicit", "values", "lazy")
 
-    def __init__(self, code, ty, const=None, array=False, dom=None, explicit=False, values=None):
+    def __init__(self, code, ty, const=None, array=False, dom=None, explicit=False, values=None, lazy=False):
         self.code, self.ty, self.const, self.array = code, ty, const, array
+        # lazy: a bare `particles.state` -- a write-through proxy on the host, read when an OPERATION consumes it (expr() materialises the
+        # operation's result there and then: a field sample later in the statement may change the state, field.py:307-378)
+        self.lazy = lazy
         # values: the set of values the expression can take where that is known statically (constants, `particles.state` itself -- the
         # string "state" --, np.where over such): what a kernel may store into `state` is checked on it (store_var)
         self.values = values if values is not None else ({const} if const is not None and not isinstance(const, float) else None)
@@ -228,7 +231,7 @@ class _Translator(ast.NodeVisitor):
         if name in _SPATIAL or name in ("t", "dt", "next_dt"):
             code = f"p.{name}" if ty == "f64" else f"((float)p.{name})"
         elif name == "state":
-            return _V("((int32_t)c.state)", ty, array=True, values={"state"})
+            return _V("((int32_t)c.state)", ty, array=True, values={"state"}, lazy=True)
         elif name == "particle_id":
             code = "((int64_t)p.id)"
         else:
@@ -298,6 +301,11 @@ class _Translator(ast.NodeVisitor):
             kids = self._kids.pop()
         if kids and not v.explicit:
             v.dom = self.common_domain(kids)
+        if any(k.lazy for k in kids):  # an operation on the state column: it reads the column here (code is emitted where it is used)
+            ty = _strong(v.ty)
+            slot = self.new_slot(ty, "st")
+            self.emit(f"{slot} = {_cast(v, ty)};")
+            v = _V(slot, ty, const=None, array=v.array, dom=v.dom, explicit=v.explicit, values=v.values)
         if self._kids:
             self._kids[-1].append(v)
         return v
@@ -469,6 +477,7 @@ class _Translator(ast.NodeVisitor):
             request = f"if ({mask.code}) {{ {request} }}"
         self.emit(_NEXT_STAGE + request)
         self.stages.append([])
+        self._stmt_masks = {}  # (a mask expression evaluated again behind the sample may see other states: not the same selection)
         if saved:
             # (a sample outside the field's time interval stops the reference with a RuntimeError when no particles came along,
             # field.py:31-37: here the particle keeps the error code, which stops the run as well)
@@ -789,9 +798,9 @@ class _Translator(ast.NodeVisitor):
                             self.locals.pop(t.id, None)
                             self.views.pop(t.id, None)
                             continue
-                    tgt = self.target(t)  # (the mask, if any, is evaluated first: it cannot depend on the value)
                     bare = isinstance(st.value, ast.Attribute) and self.view_of(st.value.value) is not None
-                    self.assign(tgt, self.expr(st.value), alias=bare)
+                    value = self.expr(st.value)  # Python's order: the value, then the target's selection (a sample in the value may change states)
+                    self.assign(self.target(t), value, alias=bare)
                 continue
             if isinstance(st, ast.If):  # only a condition that is a constant of the run (fieldset.<context>, module constants): one branch
                 c = self.try_const(st.test)

@@ -689,3 +689,34 @@ def test_kernels_that_set_success_stay_on_the_host_path():
         with pytest.raises(jit.NotTranslatable, match=pat):
             jit.translate(k, P, fs, {"count": (0, "i32")}, {})
     jit.translate(Fine, P, fs, {"count": (0, "i32")}, {})
+
+
+def StateAroundSample(particles, fieldset):
+    before = particles.state * 1
+    particles.acc = particles.state + fieldset.T[particles]      # the state as it was BEFORE the sample marked the particles it fails on
+    particles.flag = particles.state - before                    # ... and after
+    particles.count = np.where(particles.state >= 50, 1, 0) + fieldset.T2[particles] * 0
+
+
+def test_state_is_read_where_the_statement_reads_it(tmp_path):
+    """A sample may change particles.state (field.py:307-378); an expression that read the state before the sample keeps that value."""
+    src = _check(StateAroundSample, tmp_path, fields=[("T", 1), ("T2", 1)], seed=41, finite=True)
+    assert len(src.stages) == 3
+
+
+def test_a_selection_written_twice_around_a_sample_is_not_one_selection():
+    """Python evaluates the value first -- the sample for the inline selection -- and the target's selection afterwards, when states may have
+    changed: NumPy would need equal shapes.  (A selection bound to a name is evaluated once, and fine.)"""
+    P = pa.get_default_particle(np.float32).add_variable([pa.Variable("age", dtype=np.float32, initial=0)])
+    f = _FakeField([np.zeros(3)])
+
+    def Inline(particles, fieldset):
+        particles[particles.state == 10].age = fieldset.T[particles[particles.state == 10]]
+
+    def Named(particles, fieldset):
+        ok = particles[particles.state == 10]
+        ok.age = fieldset.T[ok]
+
+    with pytest.raises(jit.NotTranslatable, match="another selection"):
+        jit.translate(Inline, P, _FakeFieldSet({}, {"T": f}), {"age": (0, "f32")}, {"T": 0})
+    assert jit.translate(Named, P, _FakeFieldSet({}, {"T": f}), {"age": (0, "f32")}, {"T": 0}).counter is not None
