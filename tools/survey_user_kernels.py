@@ -146,11 +146,8 @@ def load_function(name, src, tmpdir, k):
     return getattr(mod, name)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--verbose", action="store_true")
-    ap.add_argument("--json")
-    a = ap.parse_args()
+def survey():
+    """-> [(file, kernel name, 'translated' | 'host path' | 'error', reason)] over the distinct kernels of the reference's tests and docs."""
     from parcels_amd import jit
 
     files = sorted(glob.glob(os.path.join(REF, "tests", "**", "*.py"), recursive=True)
@@ -173,6 +170,15 @@ def main():
                     rows.append((rel, name, "host path", str(e)))
                 except Exception as e:  # noqa: BLE001 -- a survey: report, do not stop
                     rows.append((rel, name, "error", f"{type(e).__name__}: {e}"))
+    return rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--json")
+    a = ap.parse_args()
+    rows = survey()
     tally = collections.Counter(r[2] for r in rows)
     reasons = collections.Counter(r[3] for r in rows if r[2] != "translated")
     print(f"{len(rows)} distinct kernels: " + ", ".join(f"{k} {v}" for k, v in tally.items()))
