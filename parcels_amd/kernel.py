@@ -108,6 +108,19 @@ class Kernel:
     def pclass(self):
         return self._pclass
 
+    def remove_deleted(self, pset):  # kernel.py:98-106
+        """Remove all particles that signalled deletion."""
+        indices = np.where(pset._data["state"] == StatusCode.Delete)[0]
+        if len(indices) > 0:
+            pset.remove_indices(indices)
+
+    def merge(self, kernel):  # kernel.py:161-172
+        if not isinstance(kernel, type(self)):
+            raise TypeError(f"Cannot merge {type(kernel)} with {type(self)}. Both should be of type {type(self)}.")
+        assert self.fieldset == kernel.fieldset, "Cannot merge kernels with different fieldsets"
+        assert self.pclass == kernel.pclass, "Cannot merge kernels with different particle types"
+        return type(self)(self._kernels + kernel._kernels, types.SimpleNamespace(fieldset=self.fieldset, _pclass=self.pclass))
+
     def check_fieldsets_in_kernels(self, kernel):
         """kernel.py:122-159, including its context side effects (RK45 defaults; the tolerance is divided by
         deg2m on a spherical mesh on EVERY Kernel construction, as in the reference)."""

@@ -222,6 +222,26 @@ class ParticleSet:
     def size(self):
         return len(self)
 
+    @classmethod
+    def from_particlefile(cls, fieldset, pclass, filename, restart=True, restarttime=None, **kwargs):  # particleset.py:264-292
+        raise NotImplementedError("ParticleSet.from_particlefile is not yet implemented in v4.")
+
+    def data_indices(self, variable_name, compare_values, invert=False):
+        """Rows whose `variable_name` equals (one of) `compare_values` -- or does not, with invert (particleset.py:294-319)."""
+        compare_values = np.array([compare_values]) if type(compare_values) not in [list, dict, np.ndarray] else compare_values
+        return np.where(np.isin(self._data[variable_name], compare_values, invert=invert))[0]
+
+    def set_variable_write_status(self, var, write_status):
+        """Whether the Variable `var` is written by a ParticleFile (particleset.py:343-353).  The particle class is shared between
+        sets: this set gets its own copy with the changed Variable."""
+        from .particle import ParticleClass, Variable
+
+        if not any(v.name == var for v in self._pclass.variables):
+            raise KeyError(f"particles have no Variable {var!r}")
+        changed = [Variable(v.name, dtype=v.dtype, initial=v.initial, to_write=write_status, attrs=(v.attrs if write_status else None))
+                   if v.name == var else v for v in self._pclass.variables]
+        self._pclass = ParticleClass(changed)
+
     def remove_indices(self, indices):  # particleset.py:247-250
         for d in self._data:
             self._data[d] = np.delete(self._data[d], indices, axis=0)

@@ -124,3 +124,51 @@ def test_particleset_construction(which):
     a = _outcome(lambda: m["particleset"].ParticleSet(ref_fs, pclass=rclass, **rkw))
     b = _outcome(lambda: pa.ParticleSet(my_fs, pclass=mclass, **mkw))
     _same(a, b, compare_message=False, same_type=which != "ids_length")  # the reference trips over list.shape there
+
+
+def test_data_indices_and_remove_deleted_like_the_reference():
+    import parcels_amd as pa
+    from parcels_amd.kernel import Kernel as MyKernel
+
+    m = ref_shim.load_reference()
+    ref_fs, my_fs = _fieldsets()
+    x = np.linspace(0.5, 3.0, 8)
+    rset = m["particleset"].ParticleSet(ref_fs, x=x, y=np.ones(8))
+    mset = pa.ParticleSet(my_fs, x=x, y=np.ones(8))
+    for s in (rset, mset):
+        s._data["state"][:] = [10, 30, 10, 60, 30, 0, 10, 41]
+    for args in (("state", 30), ("state", [30, 60]), ("state", np.array([10])), ("particle_id", [0, 7, 99]), ("state", 10, True)):
+        assert np.array_equal(rset.data_indices(*args), mset.data_indices(*args)), args
+    m["kernel"].Kernel([m["kernels"].AdvectionRK4], rset).remove_deleted(rset)
+    MyKernel([pa.AdvectionRK4], mset).remove_deleted(mset)
+    assert len(rset) == len(mset) == 6
+    for k in ("particle_id", "state", "x"):
+        assert np.array_equal(rset._data[k], mset._data[k])
+    a = _outcome(lambda: m["kernel"].Kernel([m["kernels"].AdvectionRK4], rset).merge(3))
+    b = _outcome(lambda: MyKernel([pa.AdvectionRK4], mset).merge(3))
+    assert a[0] == b[0] == "TypeError"
+    a = _outcome(lambda: m["particleset"].ParticleSet.from_particlefile(ref_fs, None, "x"))
+    b = _outcome(lambda: pa.ParticleSet.from_particlefile(my_fs, None, "x"))
+    assert a == b and a[0] == "NotImplementedError"
+
+
+def test_kernel_merge_and_write_status():
+    """Kernel.merge raises a TypeError about its own constructor in the reference (kernel.py:168-172 passes three arguments to a two-argument
+    __init__) and set_variable_write_status an AttributeError (an ndarray has no such method): here both do what their docstrings say."""
+    import parcels_amd as pa
+    from parcels_amd.kernel import Kernel as MyKernel
+
+    _, my_fs = _fieldsets()
+    P = pa.get_default_particle(np.float32).add_variable([pa.Variable("age", dtype=np.float32, initial=0)])
+    pset = pa.ParticleSet(my_fs, pclass=P, x=[1.0], y=[1.0])
+    k = MyKernel([pa.AdvectionRK4], pset).merge(MyKernel([Good], pset))
+    assert [f.__name__ for f in k._kernels] == ["AdvectionRK4", "Good"] and k.fieldset is my_fs and k.pclass is P
+    other = pa.ParticleSet(my_fs, x=[1.0], y=[1.0])
+    with pytest.raises(AssertionError, match="different particle types"):
+        MyKernel([pa.AdvectionRK4], pset).merge(MyKernel([pa.AdvectionRK4], other))
+    assert [v.to_write for v in pset._pclass.variables if v.name == "age"] == [True]
+    pset.set_variable_write_status("age", False)
+    assert [v.to_write for v in pset._pclass.variables if v.name == "age"] == [False]
+    assert [v.to_write for v in P.variables if v.name == "age"] == [True]  # the shared class is untouched
+    with pytest.raises(KeyError):
+        pset.set_variable_write_status("nope", False)
