@@ -169,6 +169,22 @@ class XGrid:
             ei = ei + idx[i] * stride
         return ei
 
+    def unravel_index(self, ei) -> dict:  # basegrid.py:120-152, 219-252
+        """The `ei` of a particle column back into one index per axis of this grid (NumPy floor division: negative codes unravel the way
+        the reference's do)."""
+        dims = np.array([self.get_axis_dim(a) for a in self.axes], dtype=int)
+        strides = np.cumprod(dims[::-1])[::-1]
+        rest = np.asarray(ei)
+        out = np.empty((len(dims), len(rest)), dtype=int)
+        for i in range(len(dims) - 1):
+            out[i, :] = rest // strides[i + 1]
+            rest = rest % strides[i + 1]
+        out[-1, :] = rest
+        return dict(zip(self.axes, out, strict=True))
+
+    def zonal_periodic(self):  # xgrid.py:294 (a v3 left-over without a body there too)
+        return None
+
     def get_spatial_hash(self) -> SpatialHash:
         if self._spatialhash is None:
             self._spatialhash = SpatialHash(self.lon, self.lat, self._mesh.is_spherical())

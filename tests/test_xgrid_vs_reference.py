@@ -46,6 +46,11 @@ def test_grid_properties_and_ravel_index(case):
     ra = np.asarray(rg.ravel_index(full)).astype(np.int32)
     rb = np.asarray(mg.ravel_index(full)).astype(np.int32)
     assert np.array_equal(ra, rb)
+    # ... and back (what a kernel does with particles.ei: tests/test_particlefile.py's Get_XiYi), error codes included
+    ua, ub = rg.unravel_index(ra), mg.unravel_index(rb)
+    assert list(ua) == list(ub)
+    for ax in ua:
+        assert np.array_equal(ua[ax], ub[ax]), ax
     # which axis of the grid each dimension of a field lies on
     for name, dims in case["field_dims"].items():
         real = [d for d in dims if not str(d).startswith("mock") and d != "time"]
