@@ -55,6 +55,7 @@ class DeviceEngine:
                  hash_build: str | None = None, neighbour_probe: int = 0):
         # hash_build: "device" (default) builds the Morton table of a curvilinear grid on the GPU (csrc/pk_hashbuild.hip);
         # "host" uploads parcels_amd.spatialhash.SpatialHash's table.  A grid whose host table already exists uploads it.
+        self.nslots_request = nslots  # (FieldSet.to_windowed_arrays compares it with a later request)
         self.hash_build = hash_build or os.environ.get("PARCELS_AMD_HASH_BUILD", "device")
         if self.hash_build not in ("device", "host"):
             raise ValueError("hash_build must be 'device' or 'host'")

@@ -162,13 +162,61 @@ class FieldSet:
         from .engine import DeviceEngine
 
         if self._engine is None or (device is not None and self._engine.device != device):
-            self.__dict__["_engine"] = DeviceEngine(self, device=0 if device is None else device)
+            self.__dict__["_engine"] = DeviceEngine(self, device=0 if device is None else device, nslots=self.__dict__.get("_window_slots"))
         return self._engine
+
+    def to_windowed_arrays(self, *, max_levels: int | None = None):
+        """fieldset.py:142-173: keep a rolling window of time levels resident instead of the whole series -- here: in HBM, as a ring per field
+        that the copy stream refills behind the clock.  The reference's default window is the two levels a step
+        brackets; the ring holds those plus the level being prefetched, so ``max_levels`` below 3 gives 3 slots.  Takes effect when the
+        device copy is created (the first execute / to_device); idempotent; returns self."""
+        if max_levels is not None and (not isinstance(max_levels, (int, np.integer)) or max_levels < 1):
+            raise ValueError(f"max_levels must be a positive integer or None. Got {max_levels!r}")
+        self.__dict__["_window_slots"] = 3 if max_levels is None else max(3, int(max_levels))
+        if self._engine is not None and getattr(self._engine, "nslots_request", None) != self.__dict__["_window_slots"]:
+            self.__dict__["_engine"] = None  # rebuilt with the ring on the next use
+        return self
+
+    def describe(self, buf=None) -> None:
+        """fieldset.py:315-330: fields, their interpolators and where their data lives, context values, mesh and time interval."""
+        import sys
+
+        (sys.stdout if buf is None else buf).write(_describe(self))
 
     def to_device(self, device: int = 0, nslots: int | None = None):
         """Create the device copy now (grids, hash tables, field-level rings).  ``nslots`` bounds the number of
         device-resident time levels per field (the analogue of FieldSet.to_windowed_arrays, fieldset.py:142-173)."""
         from .engine import DeviceEngine
 
+        if nslots is None:
+            nslots = self.__dict__.get("_window_slots")
         self.__dict__["_engine"] = DeviceEngine(self, device=device, nslots=nslots)
         return self
+
+
+def _describe(fieldset) -> str:
+    """The table of FieldSet.describe (_repr_utils.py:193-281): one row per field / vector field / context value, sorted by grid number,
+    type and name; "Parcels backend" says where the levels come from and, once the device copy exists, how many of them are resident."""
+    grids = fieldset.gridset
+    eng = fieldset.__dict__.get("_engine")
+    rows = []
+    for f in fieldset.fields.values():
+        vector = isinstance(f, VectorField)
+        grid = (f.U if vector else f).grid
+        backend = "-"
+        if not vector:
+            data = getattr(getattr(f, "data", None), "data", None)
+            backend = "NumPy" if isinstance(data, np.ndarray) else type(data).__name__
+            if eng is not None and f.name in getattr(eng, "field_nslots", {}):
+                ns, nt = eng.field_nslots[f.name], eng.field_host[f.name].shape[0]
+                backend += f" -> HBM ({'all ' + str(nt) + ' levels resident' if ns >= nt else 'ring of ' + str(ns) + ' of ' + str(nt) + ' levels'})"
+        rows.append((f.name, "VectorField" if vector else "Field", str(grids.index(grid)), repr(f.interp_method), backend))
+    for k, v in fieldset.context.items():
+        rows.append((k, "Context", "-", repr(v), "-"))
+    rows.sort(key=lambda r: (r[2], r[1], r[0]))
+    head = ("Name", "Type", "Grid number", "Interp method / value", "Parcels backend")
+    width = [max(len(head[i]), *(len(r[i]) for r in rows)) if rows else len(head[i]) for i in range(5)]
+    line = lambda r: "| " + " | ".join(c.ljust(w) for c, w in zip(r, width)) + " |"  # noqa: E731
+    table = "\n".join([line(head), "|" + "|".join(":" + "-" * (w + 1) for w in width) + "|"] + [line(r) for r in rows])
+    ti = fieldset.time_interval
+    return f"{table}\n\n\nmesh: {fieldset.models[0].grid._mesh}\ntime interval: {None if ti is None else (ti.left, ti.right)!r}\n"

@@ -8,9 +8,15 @@ exactly as assigning ``Field.interp_method`` does in the reference (field.py:130
 class ScalarInterpolator:
     kind = None
 
+    def __repr__(self):  # interpolators/_base.py:10-11
+        return f"{self.__class__.__name__}(...)"
+
 
 class VectorInterpolator:
     kind = None
+
+    def __repr__(self):  # interpolators/_base.py:19-20
+        return f"{self.__class__.__name__}(...)"
 
 
 class XLinear(ScalarInterpolator):  # _xinterpolators.py:112-153

@@ -388,3 +388,32 @@ def test_integration_notes_name_every_entry_point():
     assert len(names) > 30
     missing = sorted(n for n in names if n not in notes)
     assert not missing, missing
+
+
+def test_fieldset_describe_and_windowed_arrays():
+    """fieldset.py:142-173, 315-330: to_windowed_arrays is a request for the device ring (no device needed to make it, idempotent, chains),
+    describe writes one row per field / vector field / context value plus mesh and time interval."""
+    import io
+
+    from case_utils import build_fieldset
+    from oracle import cases
+
+    case = cases.rect_agrid_case("desc", mesh="spherical", kernels=["AdvectionRK4"], seed=1, npart=4, nx=6, ny=5, nz=2, nt=3)
+    fs = build_fieldset(case)
+    fs.add_constant_field("Kh_zonal", 10.0, mesh="spherical")
+    fs.add_context("max_age", 3.5)
+    assert fs.to_windowed_arrays() is fs and fs.__dict__["_window_slots"] == 3
+    assert fs.to_windowed_arrays(max_levels=2).__dict__["_window_slots"] == 3 and fs.to_windowed_arrays(max_levels=5).__dict__["_window_slots"] == 5
+    with pytest.raises(ValueError):
+        fs.to_windowed_arrays(max_levels=0)
+    buf = io.StringIO()
+    fs.describe(buf)
+    text = buf.getvalue()
+    lines = text.splitlines()
+    assert lines[0].split("|")[1].strip() == "Name" and "Parcels backend" in lines[0]
+    names = [ln.split("|")[1].strip() for ln in lines[2:] if ln.startswith("|")]
+    assert set(names) == {"U", "V", "UV", "Kh_zonal", "max_age"}
+    row = {ln.split("|")[1].strip(): [c.strip() for c in ln.split("|")[2:-1]] for ln in lines[2:] if ln.startswith("|")}
+    assert row["U"][0] == "Field" and row["UV"][0] == "VectorField" and row["max_age"] == ["Context", "-", "3.5", "-"]
+    assert row["U"][3] == "NumPy" and row["Kh_zonal"][1] != row["U"][1]  # the constant field lives on its own 1 x 1 grid
+    assert "mesh: " in text and "time interval: " in text
