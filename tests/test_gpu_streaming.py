@@ -122,3 +122,28 @@ def test_field_eval_at_explicit_points_through_a_ring(gpu):
     for a, b in zip(res[3], res[None]):
         assert np.array_equal(a, b, equal_nan=True) if a.dtype.kind == "f" else np.array_equal(a, b)
     assert np.any(res[None][4] == 70) and np.any(res[None][0] != 0)
+
+
+def test_to_windowed_arrays_is_the_three_slot_ring(gpu):
+    """FieldSet.to_windowed_arrays() (fieldset.py:142-173): the reference's opt-in rolling window -- here the device ring, requested before
+    any device exists -- leaves the trajectories of a fully resident FieldSet, bit for bit, and describe() reports the ring."""
+    import io
+
+    from oracle import cases
+
+    case = cases.rect_agrid_case("ring_api", mesh="spherical", kernels=["AdvectionRK4"], seed=11, nt=8, npart=1500, level_dt=86400.0)
+    res = {}
+    for windowed in (False, True):
+        fs = build_fieldset(case)
+        if windowed:
+            assert fs.to_windowed_arrays() is fs
+        pset = pa.ParticleSet(fs, pclass=pa.get_default_particle(np.float64), x=case["x"], y=case["y"], z=case["z"], t=np.zeros(len(case["x"])))
+        pset.execute([pa.AdvectionRK4, pa.kernels.DeleteParticle], dt=3600.0, runtime=6.5 * 86400.0)
+        res[windowed] = _soa(pset)
+        buf = io.StringIO()
+        fs.describe(buf)
+        if windowed:
+            assert fs._engine.field_nslots["U"] == 3 and pset._last_stats["launches"] > 1 and "ring of 3 of 8 levels" in buf.getvalue()
+        else:
+            assert "all 8 levels resident" in buf.getvalue()
+    compare(res[True], res[False], rtol=0.0, check_state="all", label="to_windowed_arrays", skip=())
