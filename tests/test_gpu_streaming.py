@@ -129,6 +129,7 @@ def test_to_windowed_arrays_is_the_three_slot_ring(gpu):
     any device exists -- leaves the trajectories of a fully resident FieldSet, bit for bit, and describe() reports the ring."""
     import io
 
+    import parcels_amd as pa
     from oracle import cases
 
     case = cases.rect_agrid_case("ring_api", mesh="spherical", kernels=["AdvectionRK4"], seed=11, nt=8, npart=1500, level_dt=86400.0)
