@@ -172,3 +172,44 @@ def test_kernel_merge_and_write_status():
     assert [v.to_write for v in P.variables if v.name == "age"] == [True]  # the shared class is untouched
     with pytest.raises(KeyError):
         pset.set_variable_write_status("nope", False)
+
+
+@pytest.mark.parametrize("which", ["dt_zero", "dt_type", "dt_none", "runtime_negative", "runtime_type", "runtime_and_endtime", "neither", "endtime_type",
+                                   "kernel_not_a_function", "endtime_outside_fields"])
+def test_execute_refuses_what_the_reference_refuses(which):
+    """ParticleSet.execute's checks of dt / runtime / endtime (particleset.py:405-420, 473-560) run before anything touches a device: the
+    same wrong calls raise the same exception -- same type, same message -- from the reference's real ParticleSet and from this one."""
+    import warnings
+
+    import parcels_amd as pa
+
+    m = ref_shim.load_reference()
+    ref_fs, my_fs = _fieldsets()
+    left = ref_fs.time_interval.left
+    s = lambda v: np.timedelta64(int(v), "s")  # noqa: E731
+    kw = {
+        "dt_zero": dict(dt=s(0), runtime=s(10)),
+        "dt_type": dict(dt="fast", runtime=s(10)),
+        "dt_none": dict(dt=None, runtime=s(10)),
+        "runtime_negative": dict(dt=s(1), runtime=s(-5)),
+        "runtime_type": dict(dt=s(1), runtime="long"),
+        "runtime_and_endtime": dict(dt=s(1), runtime=s(5), endtime=left + s(5)),
+        "neither": dict(dt=s(1)),
+        "endtime_type": dict(dt=s(1), endtime=5.0),
+        "kernel_not_a_function": dict(dt=s(1), runtime=s(5)),
+        "endtime_outside_fields": dict(dt=s(1), endtime=left + s(10**9)),
+    }[which]
+    out = []
+    for mod, fs, kernels in ((m, ref_fs, m["kernels"]), (pa, my_fs, pa)):
+        PS = mod["particleset"].ParticleSet if isinstance(mod, dict) else mod.ParticleSet
+        t = [left + s(10), left + s(20)] if isinstance(mod, dict) else [10.0, 20.0]
+        pset = PS(fs, x=[1.0, 2.0], y=[1.0, 1.0], t=np.array(t))
+        kern = 3 if which == "kernel_not_a_function" else kernels.AdvectionRK4
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out.append(_outcome(lambda: pset.execute(kern, **kw)))  # noqa: B023
+    assert out[0][0] != "ok", out
+    if out[0] == ("TypeError", "__repr__ returned non-string (type _Any)"):  # the message prints a TimeInterval, whose repr module is a stub here
+        assert out[1][0] == "ValueError", out
+        return
+    _same(out[0], out[1], compare_message="object at 0x" not in out[0][1])
