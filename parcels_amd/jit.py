@@ -191,6 +191,7 @@ class _Translator(ast.NodeVisitor):
         self._kids: list[list[_V]] = []  # operands of the expression being translated (their domains combine into the result's)
         self._stmt_masks: dict[str, _V] = {}  # mask expression -> its slot, within the statement being translated
         self._combined: dict[tuple, _V] = {}  # (view domain, mask code) -> the slot of their conjunction
+        self.confined: list[_V] = []  # selections whose emptiness an `if` tested: stores and samples must stay inside them
         self.conditional = False  # some sample is taken for a sub-selection: the stage machine keeps its own counter (case_body)
         self.detached = False  # some sample is taken without the particles (state and `ei` untouched)
         self.aliases: set[str] = set()  # locals bound to a bare `particles.<var>`: a write-through view on the host, not a temporary
@@ -245,6 +246,7 @@ class _Translator(ast.NodeVisitor):
             raise NotTranslatable(f"assignment to particles.{name}")
         ty = self.var_type(name)
         self.touched.add(name)
+        self.check_confined(mask, f"a store into particles.{name}")
         val = _cast(value, ty)
         if name in _SPATIAL or name in ("t", "dt", "next_dt"):
             stmt = f"p.{name} = (double)({val});"
@@ -465,6 +467,8 @@ class _Translator(ast.NodeVisitor):
                 raise NotTranslatable("sampling a velocity component by itself (the reference warns: host path)")
             kind, n, fid = "RQ_SCALAR", 1, self.field_ids[name]
         (pt, pz, py, px), yf32, attached, mask = self.sample_point(node, fld)
+        if attached:  # (a sample without the particles changes nothing: it may be taken anywhere)
+            self.check_confined(mask, f"a sample of fieldset.{name}")
         self.sampled.append(name if vector else int(fid))
         saved = None
         if not attached:
@@ -733,6 +737,66 @@ class _Translator(ast.NodeVisitor):
                 return ("var", node.value.attr, self.select(view, m).mask)
         raise NotTranslatable("assignment target")
 
+    def emptiness_test(self, test):
+        """`len(S) == 0`, `not len(S)`, `S.size == 0` -> (S, True); `len(S) > 0`, `len(S)`, `np.any(mask)`, `mask.any()` -> (S, False), S the mask
+        of the selection (None: all particles); anything else -> None."""
+        def selection(node):
+            if isinstance(node, ast.Call) and isinstance(node.func, ast.Name) and node.func.id == "len" and "len" not in self.env and len(node.args) == 1:
+                node = node.args[0]
+            elif isinstance(node, ast.Attribute) and node.attr == "size":
+                node = node.value
+            else:
+                return False
+            if isinstance(node, ast.Name) and node.id in self.index_locals:
+                return self.index_locals[node.id]
+            view = self.view_of(node.value if isinstance(node, ast.Attribute) and self.view_of(node.value) is not None else node)
+            return view.mask if view is not None else False
+
+        if isinstance(test, ast.Compare) and len(test.ops) == 1 and isinstance(test.comparators[0], ast.Constant):
+            sel, k, op = selection(test.left), test.comparators[0].value, type(test.ops[0]).__name__
+            if sel is not False and ((op == "Eq" and k == 0) or (op == "Lt" and k == 1) or (op == "LtE" and k == 0)):
+                return sel, True
+            if sel is not False and ((op == "Gt" and k == 0) or (op == "GtE" and k == 1) or (op == "NotEq" and k == 0)):
+                return sel, False
+            return None
+        if isinstance(test, ast.UnaryOp) and isinstance(test.op, ast.Not):
+            sel = selection(test.operand)
+            return (sel, True) if sel is not False else None
+        sel = selection(test)
+        if sel is not False:
+            return sel, False
+        mask_node = None
+        if isinstance(test, ast.Call) and self.np_func(test) == "any" and len(test.args) == 1 and not test.keywords:
+            mask_node = test.args[0]
+        elif isinstance(test, ast.Call) and isinstance(test.func, ast.Attribute) and test.func.attr == "any" and not test.args and not test.keywords:
+            mask_node = test.func.value
+        if mask_node is not None:
+            depth = len(self._kids)
+            self._kids.append([])
+            try:
+                m = self.expr(mask_node)
+            finally:
+                del self._kids[depth:]
+            if m.array and m.ty in ("b", "wb"):
+                return self.select(_View(None if m.dom is None else _V(m.dom, "b", array=True)), m).mask, False
+        return None
+
+    def within(self, mask, sel) -> bool:
+        """Is the selection `mask` (None: all particles) a sub-selection of `sel`?"""
+        if mask is None:
+            return False
+        if mask.code == sel.code:
+            return True
+        for (parent, _), combined in self._combined.items():
+            if combined.code == mask.code:
+                return self.within(_V(parent, "b", array=True), sel)
+        return False
+
+    def check_confined(self, mask, what):
+        for sel in self.confined:
+            if not self.within(mask, sel):
+                raise NotTranslatable(f"{what} outside the selection whose emptiness an `if` tests (the test then decides for the whole set)")
+
     @staticmethod
     def check_store_domain(value: _V, mask):
         if value.array and value.dom != (mask.code if mask is not None else None):
@@ -802,12 +866,29 @@ class _Translator(ast.NodeVisitor):
                     value = self.expr(st.value)  # Python's order: the value, then the target's selection (a sample in the value may change states)
                     self.assign(self.target(t), value, alias=bare)
                 continue
-            if isinstance(st, ast.If):  # only a condition that is a constant of the run (fieldset.<context>, module constants): one branch
+            if isinstance(st, ast.If):
                 c = self.try_const(st.test)
-                if c is None or c.array:
-                    raise NotTranslatable("`if` on something other than a constant of the run (elementwise code has no control flow)")
-                self.run_body(st.body if c.const else st.orelse, top=False)
-                continue
+                if c is not None and not c.array:  # a condition that is a constant of the run (fieldset.<context>, module constants): one branch
+                    self.run_body(st.body if c.const else st.orelse, top=False)
+                    continue
+                # `if len(inds) == 0: return` / `if len(inds) > 0: ...` / `if np.any(mask): ...`: whether a SELECTION is empty is a property of
+                # the whole set -- but code that only touches that selection does nothing when it is empty, so the test can go
+                emptiness = self.emptiness_test(st.test)
+                if emptiness is not None and not st.orelse:
+                    sel, when_empty = emptiness
+                    only_return = len(st.body) == 1 and isinstance(st.body[0], ast.Return) and st.body[0].value is None
+                    if when_empty and only_return and top:
+                        if sel is not None:  # (len(particles.x) == 0 never holds: a kernel is called with particles)
+                            self.confined.append(sel)  # ... everything from here on must stay inside the selection
+                        continue
+                    if not when_empty and sel is not None:
+                        self.confined.append(sel)
+                        try:
+                            self.run_body(st.body, top=False)
+                        finally:
+                            self.confined.pop()
+                        continue
+                raise NotTranslatable("`if` on something other than a constant of the run (elementwise code has no control flow)")
             if isinstance(st, ast.AugAssign):
                 tgt = self.target(st.target)
                 if tgt[0] == "local":

@@ -20,6 +20,8 @@ KNOWN_REASONS = (
     "np.zeros_like", "np.argwhere", "expression ListComp",       # array construction / Python loops
     "PARCELS_AMD_JIT_LIBM",                                      # transcendental functions: only on request
     "StatusCode.Success stored into particles.state",
+    "outside the selection whose emptiness an `if` tests",       # `if np.any(mask): <something for ALL particles>`
+    "arrays over different selections of the particles",         # (works in the reference's test because it has ONE particle)
 )
 
 
