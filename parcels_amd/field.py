@@ -300,10 +300,10 @@ def _mark_particles(particles, eng, field=None, z=None, y=None, x=None):
     the sample point (_update_particles_ei, :307-317), the points it fails on get the error codes (:327-378)."""
     from .hostkernels import HostParticles, _apply_sample_states
 
-    if field is not None and isinstance(particles, HostParticles) and len(particles) > 0:
+    if field is not None and isinstance(particles, HostParticles) and len(particles._rows) > 0:
         igrid = eng.grids.index(field.grid)
         _, zz, yy, xx = _sample_points(0.0, z, y, x)
-        n = len(particles)
+        n = len(particles._rows)
         zz, yy, xx = (np.broadcast_to(np.asarray(v, dtype=np.float64), (n,)) for v in (zz, yy, xx))
         particles._data["ei"][particles._rows, igrid] = eng.search(igrid, zz, yy, xx)
     _apply_sample_states(particles, getattr(eng, "last_sample_state", None))

@@ -86,9 +86,13 @@ class _Column(np.lib.mixins.NDArrayOperatorsMixin):
 class HostParticles:
     """The ``particles`` argument of a Python kernel: a selection of rows of the particle set's columns."""
 
-    def __init__(self, data: dict, rows):
+    def __init__(self, data: dict, rows, by_mask=False):
         object.__setattr__(self, "_data", data)
         object.__setattr__(self, "_rows", np.asarray(rows, dtype=np.int64))
+        # len() in the reference is `len(self._index)` (particlesetview.py:83-84), and what a kernel receives is a BOOLEAN mask over the whole
+        # set -- as is every selection made from it, by mask or by integer indices (:44-74: `new_index[sel] = True`): len(particles) and
+        # len(particles[anything]) are the size of the whole set there.  (len(particles.x) is the number of rows.)
+        object.__setattr__(self, "_by_mask", bool(by_mask))
 
     def __getattr__(self, name):
         data = object.__getattribute__(self, "_data")
@@ -111,13 +115,13 @@ class HostParticles:
         sub = np.asarray(sub) if isinstance(sub, (list, np.ndarray)) else sub
         if isinstance(sub, np.ndarray) and sub.dtype == bool and sub.shape[0] != len(self._rows):
             if sub.shape[0] == len(self._data["particle_id"]):  # a mask over the WHOLE set selects from it, whatever this selection was
-                return HostParticles(self._data, np.flatnonzero(sub))  # (particlesetview.py:48-52: `new_index = arr`)
+                return HostParticles(self._data, np.flatnonzero(sub), by_mask=self._by_mask)  # (particlesetview.py:48-52: `new_index = arr`)
             raise IndexError(f"boolean index of length {sub.shape[0]} for a selection of {len(self._rows)} particles")
         rows = self._rows[sub]
-        return HostParticles(self._data, np.atleast_1d(rows))
+        return HostParticles(self._data, np.atleast_1d(rows), by_mask=self._by_mask)
 
     def __len__(self):
-        return len(self._rows)
+        return len(self._data["particle_id"]) if self._by_mask else len(self._rows)
 
     def __repr__(self):
         return f"HostParticles({len(self._rows)} of {len(self._data['particle_id'])} particles)"
@@ -206,10 +210,10 @@ def execute_hosted(kernel, pset, endtime, dt):
                     device_segment(seg[1], samples, ev)  # the device runs its own Repeat loop per kernel
                     d = pset._data
                 else:
-                    seg[1](HostParticles(d, rows), fs)
+                    seg[1](HostParticles(d, rows, by_mask=True), fs)
                     rep = d["state"] == int(StatusCode.Repeat)
                     while rep.any():
-                        seg[1](HostParticles(d, np.flatnonzero(rep)), fs)
+                        seg[1](HostParticles(d, np.flatnonzero(rep), by_mask=True), fs)
                         rep = d["state"] == int(StatusCode.Repeat)
         upd = ev & np.isin(d["state"], (int(StatusCode.Evaluate), int(StatusCode.Success)))  # :219-222
         if upd.any():  # _position_update (:108-120), storage-dtype arithmetic of the columns

@@ -42,8 +42,9 @@ PK_DEV bool user_prepare(const KArgs& a, int uk, int stage, int kslot, PCtx& c, 
     }
 }
 // cols: t z y x dz dy dx dt (double each, spatial ones hold float values when pf), state (int32), id (int64), 4 extra columns;
-// samples[k * 3 * n + j * n + i]: component j of the k-th sample of particle i; a sample also does what the library's does to the particle:
-// state = max(state, sstate[k * n + i]) and ei0 = sei[k * n + i]; req[(k * 6 + j) * n + i]: t, z, y, x, f32 flag, kind * 100 + fidx of the request
+// samples[(fk * 3 + j) * n + i]: component j of field fk = kind * 16 + fidx for particle i; a sample also does what the library's does to the
+// particle: state = max(state, sstate[fk * n + i]) and ei0 = sei[fk * n + i]; req[(k * 6 + j) * n + i]: t, z, y, x, f32 flag, kind * 100 + fidx
+// of the k-th request of the kernel
 extern "C" void run(int64_t n, int pf, double* t, double* z, double* y, double* x, double* dz, double* dy, double* dx, double* dt,
                     int32_t* state, int64_t* id, void* e0, void* e1, void* e2, void* e3, const double* samples, int32_t* nsamples,
                     const int32_t* sstate, const int32_t* sei, int32_t* ei0, double* req, uint8_t* asked, const int32_t* positional) {
@@ -60,13 +61,14 @@ extern "C" void run(int64_t n, int pf, double* t, double* z, double* y, double* 
         for (int stage = 0; !user_prepare(a, 0, stage, 0, c, p, L, rq); stage++) {
             // which sample of the kernel this is: the stage, or -- in a kernel whose samples are conditional -- its own counter
             k = %(ordinal)s;
+            const int fk = rq.kind * 16 + rq.fidx;  // the field asked for: values and side effects are the FIELD's, whichever sample of the kernel this is
             for (int j = 0; j < 3; j++)
-                L.r[3 + j] = positional[k] ? (((rq.x * 1.25 + rq.y * 0.5) - rq.z * 0.25) + rq.t * 0.001) * (j + 1) : samples[((int64_t)k * 3 + j) * n + i];
+                L.r[3 + j] = positional[fk] ? (((rq.x * 1.25 + rq.y * 0.5) - rq.z * 0.25) + rq.t * 0.001) * (j + 1) : samples[((int64_t)fk * 3 + j) * n + i];
             const double r6[6] = {rq.t, rq.z, rq.y, rq.x, rq.f32 ? 1.0 : 0.0, (double)(rq.kind * 100 + rq.fidx)};
             for (int j = 0; j < 6; j++) req[((int64_t)k * 6 + j) * n + i] = r6[j];
             asked[(int64_t)k * n + i] = 1;
-            if (sstate[(int64_t)k * n + i] > c.state) c.state = sstate[(int64_t)k * n + i];
-            c.ei0 = sei[(int64_t)k * n + i];
+            if (sstate[(int64_t)fk * n + i] > c.state) c.state = sstate[(int64_t)fk * n + i];
+            c.ei0 = sei[(int64_t)fk * n + i];
             if (k + 1 > *nsamples) *nsamples = k + 1;
         }
         ei0[i] = c.ei0;
@@ -80,7 +82,8 @@ class _FakeField:
     """Answers a sample from arrays, logs the sample point, and does to the particles what the library's sampling does (when it is handed
     them): raises the state to `sstate` and writes `ei`."""
 
-    def __init__(self, values, log=None, effects=None, positional=False):
+    def __init__(self, values, log=None, effects=None, positional=False, key=0):
+        self.key = key  # kind * 16 + field id, as the shim computes it from a request
         self.values = values  # list of component arrays (1 for a scalar field, 2 / 3 for UV / UVW)
         self.positional = positional  # the value is a function of the sample point instead (samples without particles on a sub-selection)
         self.log = log if log is not None else []
@@ -96,12 +99,12 @@ class _FakeField:
             rows = np.arange(len(self.values[0])) if not self.positional else None  # (positional: whichever particles the points belong to)
         t, z, y, x = key[:4] if isinstance(key, tuple) else (particles.t, particles.z, particles.y, particles.x)
         k = len(self.log)
-        self.log.append({"rows": np.asarray(rows),"t": np.asarray(t, dtype=np.float64), "z": np.asarray(z, dtype=np.float64), "y": np.asarray(y, dtype=np.float64),
+        self.log.append({"field": getattr(self, "name", None), "rows": np.asarray(rows),"t": np.asarray(t, dtype=np.float64), "z": np.asarray(z, dtype=np.float64), "y": np.asarray(y, dtype=np.float64),
                          "x": np.asarray(x, dtype=np.float64), "f32": np.asarray(y).dtype == np.float32, "attached": particles is not None, "implicit": not isinstance(key, tuple)})
         if particles is not None and self.effects is not None:
             sstate, sei = self.effects
-            particles.state = np.maximum(np.asarray(particles.state), sstate[k][rows])
-            vars(particles)["_data"]["ei"][rows, 0] = sei[k][rows]
+            particles.state = np.maximum(np.asarray(particles.state), sstate[self.key][rows])
+            vars(particles)["_data"]["ei"][rows, 0] = sei[self.key][rows]
         if self.positional:
             e = self.log[-1]
             base = ((e["x"] * 1.25 + e["y"] * 0.5) - e["z"] * 0.25) + e["t"] * 0.001
@@ -149,7 +152,12 @@ def _columns(pclass, n, seed, finite=False):
     return data
 
 
-def _run_translated(func, pclass, fieldset, data, var_slot, field_ids, samples, tmp_path, effects=None, positional=None):
+NKEY = 48  # kind (UV 0, UVW 1, scalar 2) * 16 + field id
+
+
+def _run_translated(func, pclass, fieldset, data, var_slot, field_ids, samples, tmp_path, effects=None, positional=None, nord=1):
+    """samples: [NKEY, 3, n] values per field key, effects: ([NKEY, n] state codes, [NKEY, n] ei), positional: [NKEY] flags; nord: how many
+    samples the kernel names (the request log is per sample of the kernel)."""
     src = jit.translate(func, pclass, fieldset, var_slot, field_ids)
     body = "\n".join("            " + ln for ln in src.case_body().split("\n"))
     code = SHIM % {"decl": "\n".join("    " + d for d in src.decl) or "    char unused;", "body": body,
@@ -166,15 +174,17 @@ def _run_translated(func, pclass, fieldset, data, var_slot, field_ids, samples, 
     extras = [None] * 4
     for name, (slot, _) in var_slot.items():
         extras[slot] = data[name].copy()
-    sam = np.ascontiguousarray(samples, dtype=np.float64) if samples is not None else np.zeros(3 * n)
+    sam = np.ascontiguousarray(samples, dtype=np.float64) if samples is not None else np.zeros((NKEY, 3, n))
+    assert sam.shape == (NKEY, 3, n)
     ns = C.c_int32(0)
-    nsam = max(sam.size // (3 * n), 1)
-    sstate, sei = effects if effects is not None else (np.zeros((nsam, n), np.int32), np.zeros((nsam, n), np.int32))
+    nsam = max(int(nord), 1)
+    sstate, sei = effects if effects is not None else (np.zeros((NKEY, n), np.int32), np.zeros((NKEY, n), np.int32))
     sstate, sei = np.ascontiguousarray(sstate, dtype=np.int32), np.ascontiguousarray(sei, dtype=np.int32)
     ei0 = np.array(data["ei"][:, 0], dtype=np.int32)
     req = np.zeros((nsam, 6, n))
     asked = np.zeros((nsam, n), np.uint8)
-    positional = np.ascontiguousarray(positional if positional is not None else np.zeros(nsam), dtype=np.int32)
+    positional = np.ascontiguousarray(positional if positional is not None else np.zeros(NKEY), dtype=np.int32)
+    assert sstate.shape == sei.shape == (NKEY, n) and positional.shape == (NKEY,)
     ptr = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None  # noqa: E731
     lib.run(C.c_int64(n), C.c_int(int(pf)), *[ptr(cols[k]) for k in ("t", "z", "y", "x", "dz", "dy", "dx", "dt")], ptr(state), ptr(pid),
             *[ptr(e) for e in extras], ptr(sam), C.byref(ns), ptr(sstate), ptr(sei), ptr(ei0), ptr(req), ptr(asked), ptr(positional))
@@ -198,25 +208,32 @@ def _check(func, tmp_path, *, spatial=np.float32, context=None, fields=None, n=4
     order = list(fields.items()) if isinstance(fields, dict) else list(fields or [])
     fake_fields, field_ids = {}, {}
     log = []
-    effects = (np.where(rng.random((max(len(order), 1), n)) < 0.1, rng.choice(list(codes), size=(max(len(order), 1), n)), 0).astype(np.int32),
-               rng.integers(0, 1000, size=(max(len(order), 1), n)).astype(np.int32))
+    effects = (np.where(rng.random((NKEY, n)) < 0.1, rng.choice(list(codes), size=(NKEY, n)), 0).astype(np.int32),
+               rng.integers(0, 1000, size=(NKEY, n)).astype(np.int32))
+    nscalar = 0
     for name, ncomp in order:
         if name in fake_fields:
             continue
-        f = _FakeField([rng.normal(size=n) for _ in range(ncomp)], log, effects, positional=name in positional)
+        if ncomp == 1:
+            field_ids[name] = nscalar
+            nscalar += 1
+        key = 2 * 16 + field_ids[name] if ncomp == 1 else (0 if ncomp == 2 else 16)
+        f = _FakeField([rng.normal(size=n) for _ in range(ncomp)], log, effects, positional=name in positional, key=key)
+        f.name = name
         if grid is not None:
             f.grid = grid
         if ncomp > 1:
             f.U = f.V = None  # what marks a VectorField for the translator
         fake_fields[name] = f
-        field_ids[name] = len(field_ids)
     fs = _FakeFieldSet(context or {}, fake_fields)
-    sam = np.zeros((max(len(order), 1), 3, n))
-    for k, (name, _) in enumerate(order):
-        for j, comp in enumerate(fake_fields[name].values):
-            sam[k, j] = comp
+    sam = np.zeros((NKEY, 3, n))
+    pos = np.zeros(NKEY, np.int32)
+    for name, f in fake_fields.items():
+        for j, comp in enumerate(f.values):
+            sam[f.key, j] = comp
+        pos[f.key] = int(name in positional)
     fields = order
-    got, nsamples, src = _run_translated(func, P, fs, data, var_slot, field_ids, sam, tmp_path, effects, [int(name in positional) for name, _ in order])
+    got, nsamples, src = _run_translated(func, P, fs, data, var_slot, field_ids, sam, tmp_path, effects, pos, nord=len(order))
     assert nsamples == len(fields) or not check_nsamples  # (a conditional sample nobody takes is not counted)
     ref = {k: v.copy() for k, v in data.items()}
     with np.errstate(all="ignore"):
@@ -224,22 +241,32 @@ def _check(func, tmp_path, *, spatial=np.float32, context=None, fields=None, n=4
     for k in got:
         assert got[k].dtype == ref[k].dtype, k
         assert np.array_equal(got[k], ref[k], equal_nan=True), (func.__name__, k, np.flatnonzero(~((got[k] == ref[k]) | (np.isnan(got[k].astype(float)) & np.isnan(ref[k].astype(float)))))[:5])
-    # every sample: same field, same point (bit for bit), same float32-ness of y
-    assert len(log) == len(fields) or not check_log  # (a kernel that returns early takes fewer samples than it names)
-    assert not src.asked[len(log):].any()  # ... and then no lane of the translated kernel asked for them either
+    # every sample NumPy took: same field, same particles, same point (bit for bit), same float32-ness of y.  The k-th sample the kernel
+    # names is the k-th entry of NumPy's log unless a guard skipped it there (`if np.any(mask): ...` with an empty selection, an early
+    # return) -- then no lane of the translated kernel asked for it either
+    assert len(log) == len(fields) or not check_log
     assert nsamples <= len(fields)
-    for k, ((name, ncomp), entry) in enumerate(zip(fields, log)):
+    j = 0
+    for k, (name, ncomp) in enumerate(fields):
+        lanes = np.flatnonzero(src.asked[k])
+        entry = log[j] if j < len(log) else None
+        if entry is not None and entry["field"] == name and (len(lanes) > 0 or np.size(entry["x"]) == 0):
+            j += 1
+        else:
+            assert len(lanes) == 0, (func.__name__, "a sample NumPy did not take", k)
+            continue
         rows = entry["rows"]
         if rows.ndim == 0:  # (a positional fake sampled without particles: the points must be those of the lanes that asked, in order)
-            rows = np.flatnonzero(src.asked[k])
+            rows = lanes
             assert len(rows) == len(entry["x"])
             entry["rows"] = rows
-        assert np.array_equal(np.flatnonzero(src.asked[k]), rows), (func.__name__, "which particles take sample", k)
-        for j, c in enumerate("tzyx"):
-            assert np.array_equal(src.requests[k, j][rows], np.broadcast_to(entry[c], rows.shape), equal_nan=True), (func.__name__, "sample", k, c)
+        assert np.array_equal(lanes, rows), (func.__name__, "which particles take sample", k)
+        for jj, c in enumerate("tzyx"):
+            assert np.array_equal(src.requests[k, jj][rows], np.broadcast_to(entry[c], rows.shape), equal_nan=True), (func.__name__, "sample", k, c)
         assert np.all(src.requests[k, 4][rows] == float(entry["f32"])), (func.__name__, k)
         kind = {1: 2, 2: 0, 3: 1}[ncomp]
         assert np.all(src.requests[k, 5][rows] == kind * 100 + (field_ids[name] if ncomp == 1 else 0))
+    assert j == len(log), (func.__name__, "samples NumPy took that the translated kernel did not", j, len(log))
     src.log = log
     return src
 

@@ -58,3 +58,28 @@ def test_same_particle_columns(spatial, with_t, with_z, nvars):
     assert [v.name for v in rclass.variables] == [v.name for v in mclass.variables]
     assert [np.dtype(v.dtype) for v in rclass.variables] == [np.dtype(v.dtype) for v in mclass.variables]
     assert [v.to_write for v in rclass.variables] == [v.to_write for v in mclass.variables]
+
+
+def test_len_of_selections_like_the_reference():
+    """particlesetview.py:83-84: `len(view)` is `len(view._index)` -- and a kernel's `particles` is a boolean mask over the WHOLE set, as is every
+    selection made from it (by mask or by integer indices, :44-74): their len() is the size of the whole set; `len(view.x)` is the number of
+    rows.  HostParticles, the `particles` of the host path, answers the same."""
+    import parcels_amd as pa
+    from parcels_amd.hostkernels import HostParticles
+
+    m = ref_shim.load_reference()
+    View = m["particlesetview"].ParticleSetView
+    P = pa.get_default_particle(np.float32)
+    n = 9
+    data = {v.name: np.zeros(n, dtype=v.dtype) for v in P.variables}
+    data["x"][:] = np.arange(n)
+    data["particle_id"][:] = np.arange(n)
+    ev = np.arange(n) % 3 != 0
+    a, b = View(data, ev.copy(), P), HostParticles(data, np.flatnonzero(ev), by_mask=True)
+    assert len(a) == len(b) == n and len(a.x) == len(b.x) == ev.sum()
+    big = np.asarray(a.x) > 4
+    assert len(a[big]) == len(b[np.asarray(b.x) > 4]) == n and len(a[big].x) == len(b[np.asarray(b.x) > 4].x) == 3
+    idx = np.where(big)
+    assert len(a[idx]) == len(b[idx]) == n and len(a[idx].x) == len(b[idx].x) == 3
+    whole = np.asarray(data["x"]) < 2  # a mask over the whole set, on a selection: selects from the whole set
+    assert list(np.asarray(a[whole].x)) == list(np.asarray(b[whole].x)) == [0.0, 1.0]
