@@ -6,7 +6,9 @@ kernel, answered by arrays the test supplies) -- into a module, translates it, c
 for bit.  What is undefined in C and NumPy alike (float -> integer casts of NaN / out-of-range values, integer overflow) is not generated.
 Offline sweeps of 10 000 + 6 000 seeds (PARCELS_JIT_FUZZ_SEEDS=10000, 4 minutes on 8 cores) found one real difference -- np.maximum / np.minimum
 return their SECOND operand when both compare equal (the sign of a zero, visible after a division) -- fixed; 7 kernels were refused
-(`%` of integer constants), none differed."""
+(`%` of integer constants), none differed.  A second generator (GenViews) writes kernels over SELECTIONS of the particles -- 12 000 seeds
+offline, none differed; run on the reference's own ParticleSetView next to HostParticles it showed that len() of a kernel's particles is the
+size of the whole set there."""
 import importlib.util
 import os
 
