@@ -203,6 +203,7 @@ class _Translator(ast.NodeVisitor):
         self._kids: list[list[_V]] = []  # operands of the expression being translated (their domains combine into the result's)
         self._stmt_masks: dict[str, _V] = {}  # mask expression -> its slot, within the statement being translated
         self._combined: dict[tuple, _V] = {}  # (view domain, mask code) -> the slot of their conjunction
+        self.shared_temps: set[str] = set()  # local arrays bound to a second name (`w = u`): ONE ndarray on the host
         self.confined: list[_V] = []  # selections whose emptiness an `if` tested: stores and samples must stay inside them
         self.conditional = False  # some sample is taken for a sub-selection: the stage machine keeps its own counter (case_body)
         self.detached = False  # some sample is taken without the particles (state and `ei` untouched)
@@ -595,6 +596,26 @@ class _Translator(ast.NodeVisitor):
         ct = _strong(ty)
         return _V(f"({_cast(a, ct)} {sym} {_cast(b, ct)})", "b", array=a.array or b.array)
 
+    def shape_source(self, node):
+        """`<array>.shape`, `<array>.size`, `len(<array>)`, also wrapped in a 1-tuple: the array whose shape is meant, or None."""
+        if isinstance(node, ast.Tuple) and len(node.elts) == 1:
+            node = node.elts[0]
+        if isinstance(node, ast.Attribute) and node.attr in ("shape", "size"):
+            inner = node.value
+        elif isinstance(node, ast.Call) and isinstance(node.func, ast.Name) and node.func.id == "len" and "len" not in self.env and len(node.args) == 1:
+            inner = node.args[0]
+        else:
+            return None
+        if self.view_of(inner) is not None:
+            return None  # (len() of a selection is not its number of rows in the reference: particlesetview.py:83-84)
+        depth = len(self._kids)
+        self._kids.append([])
+        try:
+            v = self.expr(inner)
+        finally:
+            del self._kids[depth:]
+        return v if v.array else None
+
     def np_func(self, node):
         f = node.func
         if isinstance(f, ast.Attribute) and isinstance(f.value, ast.Name) and self.env.get(f.value.id) is np:
@@ -618,6 +639,17 @@ class _Translator(ast.NodeVisitor):
             return self.e_UnaryOp(ast.UnaryOp(op=ast.USub(), operand=node.args[0]))
         if name == "square" and len(node.args) == 1:
             return self.e_BinOp(ast.BinOp(left=node.args[0], op=ast.Pow(), right=ast.Constant(2)))
+        if name in ("zeros", "ones", "full") and len(node.args) == (2 if name == "full" else 1):  # np.zeros(particles.x.shape), np.zeros(len(..))
+            like = self.shape_source(node.args[0])
+            if like is None:
+                raise NotTranslatable(f"np.{name} of a shape other than that of an array over the particles")
+            if name == "full":
+                fillv = self.expr(node.args[1])
+                if fillv.array:
+                    raise NotTranslatable("np.full with an array fill value")
+                ty = _strong(fillv.ty)
+                return _V(_cast(fillv, ty), ty, array=True, dom=like.dom, explicit=True)
+            return _V("0.0" if name == "zeros" else "1.0", "f64", array=True, dom=like.dom, explicit=True)
         if name == "isin" and len(node.args) == 2:  # membership in a constant list (e.g. a list of status codes): an OR of equalities
             try:
                 test = np.asarray(eval(compile(ast.fix_missing_locations(ast.Expression(body=node.args[1])), "<kernel>", "eval"), dict(self.env)))  # noqa: S307
@@ -721,6 +753,17 @@ class _Translator(ast.NodeVisitor):
         if name in ("float32", "float64", "int32", "int64") and len(args) == 1:
             ty = {"float32": "f32", "float64": "f64", "int32": "i32", "int64": "i64"}[name]
             return _V(f"(({_CT[ty]})({args[0].code}))", ty, array=arr)
+        if name in ("zeros_like", "ones_like", "empty_like") and len(args) == 1 or name == "full_like" and len(args) == 2:
+            like = args[0]  # a new array of the argument's dtype on the argument's selection
+            if not like.array:
+                raise NotTranslatable(f"np.{name} of a scalar")
+            ty = _strong(like.ty)
+            fill = {"zeros_like": "0", "ones_like": "1", "empty_like": "0"}.get(name)
+            if fill is None:
+                if args[1].array:
+                    raise NotTranslatable("np.full_like with an array fill value")
+                fill = f"({args[1].code})"
+            return _V(f"(({_CT[ty]})({fill}))", ty, array=True, dom=like.dom, explicit=True)
         raise NotTranslatable(f"np.{name}")
 
     # ---- statements ----------------------------------------------------------------------------------------------------------
@@ -735,6 +778,20 @@ class _Translator(ast.NodeVisitor):
             view = self.view_of(node.value)
             if view is not None:
                 return ("var", node.attr, view.mask)
+        if isinstance(node, ast.Subscript) and isinstance(node.value, ast.Name) and node.value.id in self.locals:  # temporary[mask]
+            cur = self.locals[node.value.id]
+            if not cur.array or node.value.id in self.aliases or node.value.id in self.shared_temps:
+                raise NotTranslatable("item assignment on a local that is a scalar, a particle column's view or one array under two names")
+            m = self.index_mask(node.slice)
+            if m is None:
+                depth = len(self._kids)
+                self._kids.append([])
+                try:
+                    m = self.expr(node.slice)
+                finally:
+                    del self._kids[depth:]
+            sub = self.select(_View(None if cur.dom is None else _V(cur.dom, "b", array=True)), m)
+            return ("item", node.value.id, sub.mask)
         if isinstance(node, ast.Subscript) and isinstance(node.value, ast.Attribute):  # particles.v[mask], view.v[mask]
             view = self.view_of(node.value.value)
             if view is not None:
@@ -824,8 +881,16 @@ class _Translator(ast.NodeVisitor):
             else:
                 self.locals[tgt[1]] = value  # a scalar stays a (weak) scalar
             (self.aliases.add if alias else self.aliases.discard)(tgt[1])
+            self.shared_temps.discard(tgt[1])
             self.views.pop(tgt[1], None)
             self.index_locals.pop(tgt[1], None)
+        elif tgt[0] == "item":  # temporary[mask] = value: the temporary with the masked elements replaced (cast to ITS dtype)
+            _, lname, mask = tgt
+            cur = self.locals[lname]
+            self.check_store_domain(value, mask)
+            slot = self.new_slot(cur.ty)
+            self.emit(f"{slot} = ({mask.code}) ? {_cast(value, cur.ty)} : {cur.code};")
+            self.locals[lname] = _V(slot, cur.ty, array=True, dom=cur.dom, explicit=True)
         else:
             _, name, mask = tgt
             self.check_store_domain(value, mask)
@@ -875,8 +940,16 @@ class _Translator(ast.NodeVisitor):
                             self.views.pop(t.id, None)
                             continue
                     bare = isinstance(st.value, ast.Attribute) and self.view_of(st.value.value) is not None
+                    if isinstance(st.value, ast.Name) and st.value.id in self.locals and self.locals[st.value.id].array and isinstance(t, ast.Name):
+                        twin = st.value.id  # w = u: two names for one ndarray -- in-place changes through either would show in both
+                    else:
+                        twin = None
                     value = self.expr(st.value)  # Python's order: the value, then the target's selection (a sample in the value may change states)
                     self.assign(self.target(t), value, alias=bare)
+                    if twin is not None:
+                        self.shared_temps.update((twin, t.id))
+                        if twin in self.aliases:
+                            self.aliases.add(t.id)
                 continue
             if isinstance(st, ast.If):
                 c = self.try_const(st.test)
@@ -906,8 +979,8 @@ class _Translator(ast.NodeVisitor):
                 if tgt[0] == "local":
                     # a local TEMPORARY (ndarray on the host): in-place ufunc, dtype kept, the result must cast back with 'same_kind'
                     lname = tgt[1]
-                    if lname not in self.locals or lname in self.aliases or not self.locals[lname].array:
-                        raise NotTranslatable("in-place operator on a local that is a particle column's view or a scalar")
+                    if lname not in self.locals or lname in self.aliases or lname in self.shared_temps or not self.locals[lname].array:
+                        raise NotTranslatable("in-place operator on a local that is a particle column's view, a scalar or one array under two names")
                     if not isinstance(st.op, (ast.Add, ast.Sub, ast.Mult, ast.Div)):
                         raise NotTranslatable(f"in-place {type(st.op).__name__}")
                     cur, val = self.locals[lname], self.expr(st.value)
@@ -922,6 +995,23 @@ class _Translator(ast.NodeVisitor):
                     ct = _strong(ty)
                     slot = self.new_slot(cur.ty)
                     self.emit(f"{slot} = {_cast(_V(f'({_cast(cur, ct)} {sym} {_cast(val, ct)})', ct), cur.ty)};")
+                    self.locals[lname] = _V(slot, cur.ty, array=True, dom=cur.dom, explicit=True)
+                    continue
+                if tgt[0] == "item":  # temporary[mask] += value
+                    _, lname, mask = tgt
+                    if not isinstance(st.op, (ast.Add, ast.Sub, ast.Mult, ast.Div)):
+                        raise NotTranslatable(f"in-place {type(st.op).__name__}")
+                    cur, val = self.locals[lname], self.expr(st.value)
+                    self.check_store_domain(val, mask)
+                    ty = _promote(cur, val)
+                    if isinstance(st.op, ast.Div) and ty in ("i32", "i64"):
+                        ty = "f64"
+                    if not np.can_cast(np.dtype(_NP[_strong(ty)]), np.dtype(_NP[cur.ty]), "same_kind"):
+                        raise NotTranslatable(f"in-place operator: {_strong(ty)} does not cast back to {cur.ty} (NumPy raises)")
+                    sym = {"Add": "+", "Sub": "-", "Mult": "*", "Div": "/"}[type(st.op).__name__]
+                    ct = _strong(ty)
+                    slot = self.new_slot(cur.ty)
+                    self.emit(f"{slot} = ({mask.code}) ? {_cast(_V(f'({_cast(cur, ct)} {sym} {_cast(val, ct)})', ct), cur.ty)} : {cur.code};")
                     self.locals[lname] = _V(slot, cur.ty, array=True, dom=cur.dom, explicit=True)
                     continue
                 _, name, mask = tgt

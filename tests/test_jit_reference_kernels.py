@@ -17,7 +17,7 @@ KNOWN_REASONS = (
     "vector field '",                                            # VectorFields under other names than UV / UVW
     "statement Expr",                                            # pfile.write(..) from inside the kernel
     "statement FunctionDef",                                     # (kernel factories of the tests: the survey sees the outer function)
-    "np.zeros_like", "np.argwhere", "expression ListComp",       # array construction / Python loops
+    "np.unique", "np.argwhere", "expression ListComp",           # Python loops over groups / rows
     "PARCELS_AMD_JIT_LIBM",                                      # transcendental functions: only on request
     "StatusCode.Success stored into particles.state",
     "outside the selection whose emptiness an `if` tests",       # `if np.any(mask): <something for ALL particles>`

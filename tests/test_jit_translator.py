@@ -814,3 +814,46 @@ def test_an_emptiness_test_decides_for_the_whole_set_when_the_code_behind_it_lea
     for k in (LeavesIt, LeavesIt2, ElseBranch):
         with pytest.raises(jit.NotTranslatable, match="outside the selection|`if` on something other"):
             jit.translate(k, P, fs, {"acc": (0, "f64")}, {"T": 0})
+
+
+def LocalArrays(particles, fieldset):
+    """Temporaries made by the array constructors and filled by masked item assignment (tutorial_nestedgrids.ipynb's u / v buffers)."""
+    u = np.zeros_like(particles.x)            # the spatial dtype
+    v = np.zeros(particles.x.shape)           # float64
+    w = np.full_like(particles.count, 7)      # int32
+    k = np.ones(len(particles.dt))
+    east = particles.x > 0
+    u[east] = particles.age[east] * 2         # float32 values into a spatial-dtype temporary
+    v[particles.y > 0] = 1.5
+    v[east] += particles.acc[east]
+    w[particles.flag < 0] -= 3
+    k[np.where(particles.count > 2)] *= 0.5
+    particles.dx += u * particles.dt
+    particles.acc = v + k + w
+    near = particles[particles.dy < 0]
+    buf = np.zeros_like(near.acc)             # on the selection
+    buf[near.count > 0] = near.dt[near.count > 0]
+    near.acc += buf
+    full = np.full(particles.age.shape, fieldset.c)
+    scratch = np.empty_like(particles.age)     # (contents undefined until written)
+    scratch[east] = 1
+    scratch[~east] = full[~east]
+    particles.age = scratch
+
+
+def SharedTemporary(particles, fieldset):
+    u = particles.x * 2
+    w = u
+    w[particles.y > 0] = 0     # changes u as well: one ndarray under two names
+    particles.acc = u
+
+
+@pytest.mark.parametrize("spatial", [np.float32, np.float64])
+def test_array_constructors_and_item_assignment_on_temporaries(tmp_path, spatial):
+    _check(LocalArrays, tmp_path, spatial=spatial, context={"c": 0.25}, seed=61, finite=True)
+
+
+def test_one_array_under_two_names_is_left_to_numpy():
+    P = pa.get_default_particle(np.float32).add_variable([pa.Variable("acc", dtype=np.float64, initial=0)])
+    with pytest.raises(jit.NotTranslatable, match="two names"):
+        jit.translate(SharedTemporary, P, _FakeFieldSet({}, {}), {"acc": (0, "f64")}, {})

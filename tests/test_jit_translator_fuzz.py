@@ -322,6 +322,15 @@ class GenViews(Gen):
                     samples.append((fname, 1))
                 guard = self.pick([f"np.any({m})", f"{m}.any()", f"len(particles[{m}]) > 0"])
                 body.append(f"if {guard}:\n" + "\n".join("        " + ln for ln in inner))
+            elif r < 0.74:  # a temporary made by an array constructor, filled through masks, used
+                b = f"b{k}"
+                src_col = self.pick(["particles.x", "particles.age", "particles.acc", "particles.count"])
+                ctor = self.pick([f"np.zeros_like({src_col})", f"np.zeros({src_col}.shape)", f"np.full_like({src_col}, {self.const(True)})", f"np.ones(len({src_col}))"])
+                body.append(f"{b} = {ctor}")
+                body.append(f"{b}[{self.vcond('particles', 1)}] = {self.pick([self.const(True), self.const(False) if 'count' not in src_col or 'like' not in ctor else self.const(True)])}")
+                if self.rng.random() < 0.6:
+                    body.append(f"{b}[{self.vcond('particles', 1)}] {self.pick(['+=', '-=', '*='])} {self.const(True)}")
+                body.append(f"particles.{self.pick(['acc', 'dz', 'age'])} += {b}")
             elif r < 0.78:  # a sample at a computed point, for all particles
                 j = len(samples)
                 fname = self.pick(["T", "S"])
@@ -376,7 +385,7 @@ def test_random_kernel_over_selections_on_the_references_own_view(tmp_path, seed
         pa.Variable("count", dtype=np.int32, initial=0), pa.Variable("flag", dtype=np.int64, initial=0)])
     data = T._columns(P, n, 2000 + seed)
     out, logs = [], []
-    for make in (lambda d: View(d, np.ones(n, dtype=bool), P), lambda d: HostParticles(d, np.arange(n))):
+    for make in (lambda d: View(d, np.ones(n, dtype=bool), P), lambda d: HostParticles(d, np.arange(n), by_mask=True)):  # (as the host loop hands it over)
         rng = np.random.default_rng(seed + 100)
         log, fields = [], {}
         for fname, ncomp in samples:
