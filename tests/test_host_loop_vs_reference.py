@@ -116,3 +116,101 @@ def test_host_loop_equals_the_references_loop(which, direction, spatial):
         assert a[key].dtype == b[key].dtype and np.array_equal(a[key], b[key], equal_nan=True), (which, key, a[key], b[key])
     if which == "delete":
         assert len(b["x"]) < n or direction < 0
+
+
+# ---- random kernel lists through both loops ------------------------------------------------------------------------------------------------
+def _random_list(seed, tmp_path):
+    """Two or three random elementwise kernels (tests/test_jit_translator_fuzz.py's generators, without field samples) plus statements that
+    drive the LOOP: deletions, StopExecution, Success (which the reference's loop keeps evaluating, kernel.py:190-193), error codes, a dt
+    that changes for a while."""
+    import importlib.util
+
+    import test_jit_translator_fuzz as F
+
+    rng = np.random.default_rng(900 + seed)
+    loop_statements = [
+        "particles.state = np.where((np.mod(particles.particle_id, 7) == 3) & (np.abs(particles.age) >= 1200), 30, particles.state)",
+        "particles[(np.mod(particles.particle_id, 5) == 1) & (np.abs(particles.age) >= 1800)].state = 40",
+        "particles[(np.mod(particles.particle_id, 4) == 2) & (np.abs(particles.age) >= 600) & (np.abs(particles.age) < 2400)].state = 0",
+        "particles.dt = np.where((np.abs(particles.age) > 1000) & (np.abs(particles.age) < 2000), particles.dt / 2, particles.dt)",
+        "particles.state = np.where((particles.particle_id == 5) & (np.abs(particles.age) >= 3000), 60, particles.state)",
+    ]
+    srcs, names = ["import numpy as np\n"], []
+    nk = int(rng.integers(2, 4))
+    for j in range(nk):
+        g = (F.GenViews if rng.random() < 0.5 else F.Gen)(seed * 10 + j)
+        body = []
+        for _ in range(int(rng.integers(2, 6))):
+            body.append(g.view_statement() if isinstance(g, F.GenViews) and rng.random() < 0.5 else g.statement())
+        if j == 0:
+            body.insert(0, "particles.age += particles.dt")
+        for st in rng.choice(loop_statements, size=int(rng.integers(0, 3)), replace=False):
+            body.append(str(st))
+        name = f"L{seed}_{j}"
+        names.append(name)
+        srcs.append(f"\n\ndef {name}(particles, fieldset):\n" + "".join(f"    {s}\n" for s in body))
+    path = tmp_path / f"loop_kernels_{seed}.py"
+    path.write_text("".join(srcs))
+    spec = importlib.util.spec_from_file_location(f"loop_kernels_{seed}", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return [getattr(mod, n) for n in names], "".join(srcs)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PARCELS_LOOP_FUZZ_SEEDS", "40"))))
+def test_random_kernel_lists_through_both_loops(tmp_path, seed):
+    """The whole of Kernel.execute on random lists of random kernels: the reference's REAL ParticleSet / Kernel.execute / ParticleSetView and
+    execute_hosted / HostParticles leave the same columns -- same survivors, same states, same times -- or raise the same error."""
+    import warnings
+
+    from parcels_amd.hostkernels import execute_hosted
+    from parcels_amd.kernel import Kernel
+
+    ref_fs, my_fs, pa = _fieldsets()
+    for fs in (ref_fs, my_fs):
+        fs.add_context("c1", 0.75)
+        fs.add_context("c2", np.float32(1.5))
+    m = ref_shim.load_reference()
+    funcs, src = _random_list(seed, tmp_path)
+    spatial = np.float32 if seed % 2 else np.float64
+    direction = 1 if seed % 3 else -1
+    n = 24
+    rng = np.random.default_rng(70 + seed)
+    x, y = rng.uniform(-2, 2, n), rng.uniform(-2, 2, n)
+    t0 = (np.where(np.arange(n) % 3 == 0, 600.0, 0.0) if direction > 0 else np.full(n, 4800.0))
+    dt, endtime = 600.0 * direction, (4800.0 if direction > 0 else 0.0)
+    extra = [("age", np.float32), ("acc", np.float64), ("count", np.int32), ("flag", np.int64)]
+    init = {"acc": rng.normal(size=n), "count": rng.integers(-3, 6, n).astype(np.int32), "flag": rng.integers(-3, 6, n)}
+
+    RP = m["particle"]
+    rclass = RP.get_default_particle(spatial).add_variable([RP.Variable(nm, dtype=dtp, initial=0) for nm, dtp in extra])
+    rset = m["particleset"].ParticleSet(ref_fs, pclass=rclass, x=x, y=y, z=np.zeros(n), t=(t0 * 1e9).round().astype("int64").astype("timedelta64[ns]"), **init)
+    pclass = pa.get_default_particle(spatial).add_variable([pa.Variable(nm, dtype=dtp, initial=0) for nm, dtp in extra])
+    pset = pa.ParticleSet(my_fs, pclass=pclass, x=x, y=y, z=np.zeros(n), t=t0, **init)
+    for s in (rset, pset):
+        s._data["dt"][:] = dt
+    out = []
+    with warnings.catch_warnings(), np.errstate(all="ignore"):
+        warnings.simplefilter("ignore")
+        try:
+            try:
+                m["kernel"].Kernel(list(funcs), rset).execute(rset, endtime, dt)
+                out.append(None)
+            except TypeError as e:  # e.g. `%`: the reference's column proxy has no __mod__
+                pytest.skip(f"the reference's own view does not support this list: {e}")
+            except ZeroDivisionError:
+                pytest.skip("a generated kernel divides Python constants by zero")
+            except Exception as e:  # noqa: BLE001
+                out.append(type(e).__name__)
+            try:
+                execute_hosted(Kernel(list(funcs), pset), pset, endtime, dt)
+                out.append(None)
+            except Exception as e:  # noqa: BLE001
+                out.append(type(e).__name__)
+        finally:
+            pass
+    assert out[0] == out[1], (out, src)
+    a, b = rset._data, pset._data
+    assert set(a) == set(b)
+    for key in a:
+        assert a[key].dtype == b[key].dtype and np.array_equal(a[key], b[key], equal_nan=True), (key, a[key], b[key], src)
