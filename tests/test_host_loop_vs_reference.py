@@ -214,3 +214,87 @@ def test_random_kernel_lists_through_both_loops(tmp_path, seed):
     assert set(a) == set(b)
     for key in a:
         assert a[key].dtype == b[key].dtype and np.array_equal(a[key], b[key], equal_nan=True), (key, a[key], b[key], src)
+
+
+# ---- kernels that SAMPLE: the oracle stands in for the device ------------------------------------------------------------------------------
+def SampleAndDrift(particles, fieldset):
+    u, v = fieldset.UV[particles]
+    particles.dx += u * particles.dt
+    particles.dy += v * particles.dt
+    particles.temp = fieldset.T[particles]
+
+
+def LookAhead(particles, fieldset):
+    particles.acc = fieldset.T[particles.t, particles.z, particles.y, particles.x + fieldset.h, particles]
+    near = particles[particles.temp > 0]
+    u, v, w = fieldset.UVW[near.t + 0.5 * near.dt, near.z, near.y, near.x, near]
+    near.dz += w * near.dt
+
+
+def DeleteErrors(particles, fieldset):
+    particles[particles.state >= 50].state = 30
+
+
+def _sampling_setup(mesh, seed, margin):
+    import parcels_amd as pa
+    import stub_engine
+    from case_utils import build_fieldset
+    from oracle import cases
+    from oracle.make_golden import build_ref_fieldset
+
+    case = cases.rect_agrid_case("host_sampling", mesh=mesh, kernels=["AdvectionRK4"], seed=seed, npart=60, nx=14, ny=11, nz=4, nt=3, with_w=True,
+                                 margin=margin, dt=3600.0, vel=(3.0 if mesh == "spherical" else 1.5))
+    rng = np.random.default_rng(seed + 5)
+    case["fields"]["T"] = cases.smooth_random_field(rng, case["fields"]["U"].shape, 2.0)
+    case["field_dims"]["T"] = case["field_dims"]["U"]
+    ref_fs, _ = build_ref_fieldset(case)
+    my_fs = build_fieldset(case)
+    eng = stub_engine.install(my_fs, case)
+    return case, ref_fs, my_fs, eng, pa
+
+
+@pytest.mark.parametrize("mesh", ["flat", "spherical"])
+@pytest.mark.parametrize("which", ["drift", "lookahead_recover", "error_stop"])
+def test_sampling_kernels_through_both_loops(mesh, which):
+    """Python kernels that sample fields -- for all particles, at computed points, for a selection -- through the reference's real loop on its
+    real fields and through execute_hosted with the CPU oracle answering Field.eval (tests/stub_engine.py): the same values, the same
+    particles marked out of bounds, the same `ei`, the same survivors."""
+    import warnings
+
+    from parcels_amd.hostkernels import execute_hosted
+    from parcels_amd.kernel import Kernel
+
+    case, ref_fs, my_fs, eng, pa = _sampling_setup(mesh, 3 if which == "drift" else 4, 0.3 if which == "drift" else 0.03)
+    h = 2.0e4 if mesh == "flat" else 15.0
+    for fs in (ref_fs, my_fs):
+        fs.add_context("h", h)
+    funcs = {"drift": [SampleAndDrift], "lookahead_recover": [SampleAndDrift, LookAhead, DeleteErrors], "error_stop": [SampleAndDrift, LookAhead]}[which]
+    m = ref_shim.load_reference()
+    n = len(case["x"])
+    t0 = np.where(np.arange(n) % 4 == 0, 1800.0, 0.0)
+    dt, endtime = 3600.0, 12 * 3600.0
+    extra = [("temp", np.float32), ("acc", np.float64)]
+    RP = m["particle"]
+    rclass = RP.get_default_particle(np.float64).add_variable([RP.Variable(nm, dtype=d, initial=0) for nm, d in extra])
+    rset = m["particleset"].ParticleSet(ref_fs, pclass=rclass, x=case["x"], y=case["y"], z=case["z"], t=(t0 * 1e9).round().astype("int64").astype("timedelta64[ns]"))
+    pclass = pa.get_default_particle(np.float64).add_variable([pa.Variable(nm, dtype=d, initial=0) for nm, d in extra])
+    pset = pa.ParticleSet(my_fs, pclass=pclass, x=case["x"], y=case["y"], z=case["z"], t=t0)
+    for s in (rset, pset):
+        s._data["dt"][:] = dt
+    out = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for run in (lambda: m["kernel"].Kernel(list(funcs), rset).execute(rset, endtime, dt), lambda: execute_hosted(Kernel(list(funcs), pset), pset, endtime, dt)):
+            try:
+                run()
+                out.append(None)
+            except Exception as e:  # noqa: BLE001
+                out.append(type(e).__name__)
+    assert out[0] == out[1], out
+    assert (out[0] is not None) == (which == "error_stop") and eng.samples > 0
+    a, b = rset._data, pset._data
+    assert set(a) == set(b)
+    for key in a:
+        assert a[key].dtype == b[key].dtype and np.array_equal(a[key], b[key], equal_nan=True), (key, np.flatnonzero(a[key] != b[key])[:5] if a[key].shape == b[key].shape else (a[key].shape, b[key].shape))
+    if which == "lookahead_recover":
+        assert 0 < len(b["x"]) < n
