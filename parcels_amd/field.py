@@ -286,8 +286,20 @@ def _unpack_key(key):
 def _eval_key(field, key):
     """field[key] (field.py:187-195, 297-304).  A sample outside the field's time interval is an error of the particles it was taken for; with
     no particles in the key there is nobody to carry it: the reference raises (field.py:31-37), and so does this."""
+    from .hostkernels import HostParticles
+    from .statuscodes import OutsideTimeInterval
+
     t, z, y, x, particles = _unpack_key(key)
-    val = field.eval(t, z, y, x, particles)
+    try:
+        val = field.eval(t, z, y, x, particles)
+    except OutsideTimeInterval:
+        if not isinstance(particles, HostParticles):
+            raise
+        # field.py:31-44 (_deal_with_errors): every particle the sample was taken for carries the error, and the sample is 0 -- a Python
+        # scalar per component, as there
+        particles.state = int(StatusCode.ErrorOutsideTimeInterval)
+        ncomp = {"3D": 3, "2D": 2}.get(getattr(field, "vector_type", None), 1)
+        return 0 if ncomp == 1 else (0,) * ncomp
     if particles is None and isinstance(key, tuple):
         st = getattr(field._fieldset._engine_or_create(), "last_sample_state", None)
         if st is not None and np.any(np.asarray(st) == int(StatusCode.ErrorOutsideTimeInterval)):
@@ -299,7 +311,13 @@ def _mark_particles(particles, eng, field=None, z=None, y=None, x=None):
     """What sampling does to the particles a kernel passed along (field.py:394-405): their `ei` on the field's grid becomes the cell of
     the sample point (_update_particles_ei, :307-317), the points it fails on get the error codes (:327-378)."""
     from .hostkernels import HostParticles, _apply_sample_states
+    from .statuscodes import OutsideTimeInterval
 
+    st = getattr(eng, "last_sample_state", None)
+    if isinstance(particles, HostParticles) and st is not None and np.any(np.asarray(st) == int(StatusCode.ErrorOutsideTimeInterval)):
+        # index_search.py:85-86: ONE point outside the field's time interval fails the whole call, before any `ei` or state of it is
+        # written (field.py:394-405); Field.__getitem__ turns that into code 70 for every particle of the view (_eval_key)
+        raise OutsideTimeInterval(None, field)
     if field is not None and isinstance(particles, HostParticles) and len(particles._rows) > 0:
         igrid = eng.grids.index(field.grid)
         _, zz, yy, xx = _sample_points(0.0, z, y, x)
