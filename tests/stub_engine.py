@@ -21,6 +21,7 @@ class OracleBackedEngine:
         self.ctx = types.SimpleNamespace(check=lambda rc, what=None: None, handle=None)
         self.lib = types.SimpleNamespace(pk_set_option=self._set_option)
         self.samples = 0
+        self.nonfinite_points = False  # some sample point was NaN / inf (the reference's answer then depends on the rest of the batch)
 
     def _set_option(self, handle, name, value):
         if name == b"eval_points_f32":
@@ -33,6 +34,7 @@ class OracleBackedEngine:
         t, z, y, x = np.broadcast_arrays(*(np.atleast_1d(np.asarray(v, dtype=np.float64)) for v in (t, z, y, x)))
         t, z, y, x = (np.ascontiguousarray(v) for v in (t, z, y, x))
         m = x.shape[0]
+        self.nonfinite_points |= not all(np.all(np.isfinite(a)) for a in (t, z, y, x))
         u, v, w, st = np.zeros(m), np.zeros(m), np.zeros(m), np.zeros(m, np.int32)
         what = {"UV": -1, "UVW": -2}.get(name, mc.field_index.get(name))
         prm = mc.params(kernels=[], endtime=0.0, dt0=1.0)
