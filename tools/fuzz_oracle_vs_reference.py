@@ -33,7 +33,13 @@ def run(seed, q):
             compare(got, out, rtol=tol, atol_pos=tol*scale, check_state="errors" if tstop is not None else "all", label=f"seed {seed}")
             q.put((seed,"ok",str(err),case['kernels']))
         except AssertionError as e:
-            q.put((seed,"MISMATCH",str(e)[:300],case['kernels']))
+            # a sample outside the time interval is an error of the whole call in the reference -- shows
+            # for staggered releases that run past the last time level
+            ts = case.get("time_s")
+            t0 = np.asarray(case["t0"]) if case.get("t0") is not None else np.zeros(1)
+            past = ts is not None and len(ts) > 1 and float(np.max(t0)) + case["runtime"] > float(ts[-1] - ts[0])
+            known = past and len(np.unique(t0)) > 1 and (err == "OutsideTimeInterval" or "particle count" in str(e))
+            q.put((seed,"MISMATCH (known, open: call-wide time error)" if known else "MISMATCH",str(e)[:300],case['kernels']))
     except Exception as e:
         q.put((seed,"EXC",traceback.format_exc()[-400:],None))
 if __name__=="__main__":
