@@ -203,7 +203,7 @@ def run_hip(case, endtime=None, nslots=None, async_output=None, fieldset=None, *
     return {k: np.array(v) for k, v in pset._data.items()}, err, pset._last_stats
 
 
-def run_oracle(case, endtime=None, nthreads=1):
+def run_oracle(case, endtime=None, nthreads=1, call_wide_time_error=False):
     from oracle import c_oracle as co
 
     c = dict(case)
@@ -212,7 +212,7 @@ def run_oracle(case, endtime=None, nthreads=1):
         c["runtime"] = None
     if is_curvilinear(c) and "hash_table" not in c:
         attach_hash_table(c)
-    return co.run_case(c, nthreads=nthreads)
+    return co.run_case(c, nthreads=nthreads, call_wide_time_error=call_wide_time_error)
 
 
 def max_rel(a, b):
