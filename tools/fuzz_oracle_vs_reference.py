@@ -1,6 +1,7 @@
 """Offline sweep (build container only): the reference under oracle/ref_shim.py vs the C oracle on configurations of the GPU fuzz
 generator (tests/test_gpu_fuzz.py), one subprocess per seed with a timeout (the reference can hang, DESIGN.md deviation 5).
-Usage: python tools/fuzz_oracle_vs_reference.py LO HI [decorate]   (decorate: with the user-kernel tokens of test_gpu_fuzz.decorate_case)"""
+Usage: python tools/fuzz_oracle_vs_reference.py LO HI [decorate]   (decorate: with the user-kernel tokens of test_gpu_fuzz.decorate_case)
+PARCELS_ORACLE_CALL_WIDE=1: the oracle with the reference's call-wide time error (c_oracle.execute(call_wide_time_error=True))."""
 import sys, time, multiprocessing as mp, traceback
 sys.path.insert(0,'/root/repo/tests'); sys.path.insert(0,'/root/repo')
 sys.dont_write_bytecode=True
@@ -19,7 +20,8 @@ def run(seed, q):
                 q.put((seed,"ok","undecorated",None)); return
         out, err, extras = mg.ref_run_case(case)
         tstop = stop_time_of_reference(case, out, err)
-        got, gerr, _ = run_oracle(case, endtime=tstop)
+        import os
+        got, gerr, _ = run_oracle(case, endtime=tstop, call_wide_time_error=os.environ.get("PARCELS_ORACLE_CALL_WIDE") == "1")
         tol=f.tolerance(case)
         # the classes of tests/test_oracle_golden.py::test_oracle_matches_reference_on_random_configurations: bit-identical for fp64
         # rectilinear cases, 1e-13 where NumPy's SIMD sin / cos and libm may differ by an ulp (curvilinear meshes, sampled velocities),
