@@ -25,12 +25,13 @@
 extern "C" {
 #endif
 
-#define PK_ABI_VERSION 6 /* 6: PK_MAX_FIELDS 64 (descriptors in device memory), PK_MAX_EXTRA 8, pk_particles_checkpoint / _restore, user kernels (PK_KERNEL_USER0 .., pk_generic_variant, pk_set_user_program), "eval_points_f32" option; 5: pk_exec_params.horizon_lo / horizon_hi / max_iters, pk_exec_stats.first_error_iter / program, pk_execute_rerun, "fast_cgrid" option; 4: pk_upload_stats, pk_host_stage_selftest, PK_KERNEL_DO_NOTHING / _MOVE_EAST / _MOVE_NORTH, vector PK_KERNEL_SAMPLE_FIELD, "cell_table" option */
+#define PK_ABI_VERSION 7 /* 7: the call-wide OutsideTimeInterval of the reference on the device (pk_exec_params.twe_n / twe_key, pk_exec_stats.first_time_error_key, pk_execute_rerun_keys); 6: PK_MAX_FIELDS 64 (descriptors in device memory), PK_MAX_EXTRA 8, pk_particles_checkpoint / _restore, user kernels (PK_KERNEL_USER0 .., pk_generic_variant, pk_set_user_program), "eval_points_f32" option; 5: pk_exec_params.horizon_lo / horizon_hi / max_iters, pk_exec_stats.first_error_iter / program, pk_execute_rerun, "fast_cgrid" option; 4: pk_upload_stats, pk_host_stage_selftest, PK_KERNEL_DO_NOTHING / _MOVE_EAST / _MOVE_NORTH, vector PK_KERNEL_SAMPLE_FIELD, "cell_table" option */
 #define PK_MAX_GRIDS 4
 #define PK_MAX_FIELDS 64
 #define PK_MAX_KERNELS 8
 #define PK_MAX_EXTRA 8 /* user Variables that device kernels write (PK_KERNEL_SAMPLE_FIELD, compiled user kernels) */
 #define PK_NUM_STATE_CODES 80
+#define PK_MAX_TWE 64 /* samples of one Kernel.execute call that fail call-wide with OutsideTimeInterval (pk_exec_params.twe_key) */
 
 typedef struct pk_ctx pk_ctx;
 
@@ -331,6 +332,20 @@ typedef struct pk_exec_params {
                             no position update, no EndofLoop, states neither reset nor interpreted -- the caller owns the loop of
                             kernel.py:190-245.  This is how arbitrary Python kernels run next to device
                             kernels (parcels_amd/hostkernels.py: the loop on the host columns, the built-in kernels' bodies here).   */
+    int32_t twe_n;     /* number of entries of twe_key (0: none known)                                                                */
+    int32_t reserved1;
+    int64_t twe_key[PK_MAX_TWE]; /* The call-wide OutsideTimeInterval (index_search.py:85-86, field.py:31-44,187-195,297-304): in the
+                            reference a field sample fails as a WHOLE when any particle of the view it was called with lies outside the
+                            field's time interval -- Field.__getitem__ then writes ErrorOutsideTimeInterval into the state of EVERY
+                            particle of that view and returns 0 for all of them; no `ei`, no other state of that call is written.  A
+                            sample of a Kernel.execute call is named by key = (iteration << 32) | (kernel slot * 1000 + number of the
+                            sample within that kernel's call(s) of the iteration) (iteration: 1-based index of the loop of kernel.py:190;
+                            the samples of a Repeat re-run of the kernel, kernel.py:211-216, count on).  A launch reports the smallest
+                            key at which some particle left a time interval (pk_exec_stats.first_time_error_key, only that particle got
+                            the code); the caller runs the call again from the state before it with that key listed here, and every
+                            particle that reaches a listed sample takes code 70 and the value 0 there -- and so on until a run reports
+                            no new key (parcels_amd/engine.py: DeviceEngine.execute; pk_execute_rerun_keys).  A launch with listed
+                            samples runs the general programs (same results as the dedicated kernels, which only report).             */
 } pk_exec_params;
 
 typedef struct pk_exec_stats {
@@ -347,6 +362,8 @@ typedef struct pk_exec_stats {
                         dedicated curvilinear C-grid kernels (csrc/pk_fast_cgrid.h)                                     */
     int64_t first_error_iter; /* 0 = no particle entered an error state (or StopAllExecution); else the smallest 1-based index of the
                         iteration of the loop of kernel.py:190 in which one did (kernel.py:236-245 raises after THAT iteration)          */
+    int64_t first_time_error_key; /* 0 = no sample of this launch left a field's time interval; else the smallest key (see
+                        pk_exec_params.twe_key) of a sample, not listed in twe_key, at which a particle did                                */
 } pk_exec_stats;
 int32_t pk_execute(pk_ctx* ctx, const pk_exec_params* params, pk_exec_stats* stats);
 /* kernel.py:236-245: the reference checks the error codes after every iteration of its batch loop, so when it raises, EVERY particle
@@ -374,6 +391,10 @@ int32_t pk_generic_variant(pk_ctx* ctx, const pk_exec_params* prm, int32_t sampl
                            int32_t* lds, int32_t* typed, int32_t* fast);
 int32_t pk_set_user_program(pk_ctx* ctx, void* launcher, int32_t flags, int32_t nsample, const int32_t* sample_fids);
 int32_t pk_execute_rerun(pk_ctx* ctx, int32_t max_iters, pk_exec_stats* stats);
+/* The same with the call-wide time errors known so far (pk_exec_params.twe_key): the launch is repeated from the state before it with
+ * max_iters (0 = no limit) and the n_keys <= PK_MAX_TWE listed samples failing for every particle that reaches them
+ * (field.py:31-44: _deal_with_errors writes the code into the whole view). */
+int32_t pk_execute_rerun_keys(pk_ctx* ctx, int32_t max_iters, int32_t n_keys, const int64_t* keys, pk_exec_stats* stats);
 /* The same in two halves: _begin enqueues the sort + advection kernel + statistics on the compute stream and returns;
  * the host can then stage and enqueue the NEXT field level (pk_field_upload_level async) while the RK sub-steps run;
  * _end waits and fills the statistics.  pk_execute == begin + end. */

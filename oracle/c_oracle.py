@@ -15,6 +15,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+PO_MAX_TWE = 64  # po_params.twe_key (parcels_oracle.c)
 
 KERNEL_IDS = {
     "AdvectionEE": 1,
@@ -144,7 +145,7 @@ class PoParams(C.Structure):
         ("rk45_max_dt", C.c_double),
         ("dres", C.c_double),
         ("seed", C.c_uint64),
-        ("twe_key", C.c_int64 * 8),
+        ("twe_key", C.c_int64 * PO_MAX_TWE),
     ]
 
 
@@ -468,39 +469,39 @@ def sample_names(vname):
 
 
 def execute(mc: MarshalledCase, data: dict, *, kernels, endtime, dt0, context=None, seed=0, have_guess0=0, nthreads=1, batch_stop=True,
-            _max_iters=0, call_wide_time_error=False, _twe_key=()):
+            _max_iters=0, call_wide_time_error=True, _twe_key=()):
     """One Kernel.execute(pset, endtime, dt) call on the SoA dict ``data`` (updated in place).
 
     Deleted particles are compacted afterwards like ``Kernel.remove_deleted`` (kernel.py:98-106).  ``batch_stop``: the reference
     checks the error codes after every iteration of its batch loop (kernel.py:236-245), so when some particle errs in its k-th
     iteration, every particle has made at most k iterations when the exception is raised: the per-particle C loop reports that k
     and the call is run again from the same inputs with ``max_iters = k`` (False: every other particle runs on to ``endtime``).
-    ``call_wide_time_error`` (opt-in until the HIP kernels do the same): a sample outside a field's time
+    ``call_wide_time_error`` (the reference's behaviour and the default; False = every particle on its own): a sample outside a field's time
     interval fails the whole call in the reference -- every particle evaluated in that iteration takes code 70 and the value 0 at that
     sample (index_search.py:85-86, field.py:31-44); a first pass finds the first such sample, the call then runs with it.
     """
     if call_wide_time_error:
         saved = {k: np.array(v, copy=True) for k, v in data.items()}
         keys = []
-        while len(keys) < 8:  # every pass applies the events found so far and reports the next sample at which somebody leaves a time interval
+        while len(keys) < PO_MAX_TWE:  # every pass applies the events found so far and reports the next sample at which somebody leaves a time interval
             st = execute(mc, data, kernels=kernels, endtime=endtime, dt0=dt0, context=context, seed=seed, have_guess0=have_guess0,
-                         nthreads=nthreads, batch_stop=batch_stop, _twe_key=tuple(keys))
+                         nthreads=nthreads, batch_stop=batch_stop, call_wide_time_error=False, _twe_key=tuple(keys))
             if not st["first_time_error_key"]:
                 return st
             keys.append(st["first_time_error_key"])
             for k in list(data):
                 data[k] = np.array(saved[k], copy=True)
-        raise RuntimeError("more than 8 call-wide time errors in one Kernel.execute")
+        raise RuntimeError(f"more than {PO_MAX_TWE} call-wide time errors in one Kernel.execute")
     if batch_stop:
         saved = {k: np.array(v, copy=True) for k, v in data.items()}
         st = execute(mc, data, kernels=kernels, endtime=endtime, dt0=dt0, context=context, seed=seed, have_guess0=have_guess0,
-                     nthreads=nthreads, batch_stop=False, _twe_key=_twe_key)
+                     nthreads=nthreads, batch_stop=False, call_wide_time_error=False, _twe_key=_twe_key)
         if not st["first_error_iter"]:
             return st
         for k in list(data):
             data[k] = saved[k]
         return execute(mc, data, kernels=kernels, endtime=endtime, dt0=dt0, context=context, seed=seed, have_guess0=have_guess0,
-                       nthreads=nthreads, batch_stop=False, _max_iters=st["first_error_iter"], _twe_key=_twe_key)
+                       nthreads=nthreads, batch_stop=False, call_wide_time_error=False, _max_iters=st["first_error_iter"], _twe_key=_twe_key)
     n = data["x"].shape[0]
     sdt = data["x"].dtype
     w = {k: np.ascontiguousarray(data[k], dtype=np.float64) for k in ("t", "z", "y", "x", "dz", "dy", "dx", "dt")}
@@ -518,7 +519,7 @@ def execute(mc: MarshalledCase, data: dict, *, kernels, endtime, dt0, context=No
     P.state, P.ei, P.particle_id = _ptr(state), _ptr(ei), _ptr(pid)
     prm = mc.params(kernels=kernels, endtime=endtime, dt0=dt0, context=context, seed=seed, have_guess0=have_guess0)
     prm.max_iters = int(_max_iters)
-    for k, key in enumerate(tuple(_twe_key)[:8]):
+    for k, key in enumerate(tuple(_twe_key)[:PO_MAX_TWE]):
         prm.twe_key[k] = int(key)
     xw = {}
     for k, vname in enumerate(getattr(mc, "sample_vars", [])):
@@ -603,7 +604,7 @@ ERRORS_TO_THROW = [  # kernel.py:31-38 (order matters)
 ]
 
 
-def run_case(case: dict, nthreads: int = 1, call_wide_time_error: bool = False):
+def run_case(case: dict, nthreads: int = 1, call_wide_time_error: bool = True):
     """ParticleSet.execute (particleset.py:355-470) without output file: one Kernel.execute to the end time."""
     mc = MarshalledCase(case)
     data = initial_particles(case, mc.ngrids)

@@ -812,4 +812,60 @@ def all_cases() -> dict:
     pc["t0"] = np.round(_rng(74).uniform(0, 6, len(pc["x"]))) * 1800.0
     add(pc)
 
+    # --- the call-wide OutsideTimeInterval (index_search.py:85-86 raises for the whole call; field.py:31-44 writes code 70 into EVERY
+    #     particle of the view and returns 0): releases staggered by half a step and a run that ends past the last time level, so that in
+    #     the iteration in which the first particle leaves the time interval the others are still inside it.  With a recovery kernel
+    #     the reference deletes every particle evaluated in that iteration; without one the columns at the raise show it; AdvectionRK45
+    #     overwrites the code (_advection.py:146) and goes on with the zeros.  (Found by tools/fuzz_oracle_vs_reference.py, seeds 6102 / 6650.)
+    def past_the_end(case, extra_steps=1.0):
+        """Stagger the releases by half steps (unless the case already does) and let the run end `extra_steps` steps past the last level."""
+        n = len(np.atleast_1d(case["x"]))
+        dt = float(case["dt"])
+        if case.get("t0") is None:
+            case["t0"] = _rng(case["seed"] + 500).integers(0, 6, n) * abs(dt) * 0.5
+        tl = float(case["time_s"][-1] - case["time_s"][0])
+        if dt < 0:
+            case["t0"] = tl - np.asarray(case["t0"])
+            case["runtime"] = tl + extra_steps * abs(dt) - float(np.min(tl - case["t0"]))
+        else:
+            case["runtime"] = tl + extra_steps * abs(dt) - float(np.min(case["t0"]))
+        return case
+
+    add(past_the_end(rect_agrid_case("twe_agrid_sph_ee_delete", mesh="spherical", kernels=["AdvectionEE", "DeleteParticle"], seed=91, nt=2,
+                                     stagger=True)))
+    add(past_the_end(rect_agrid_case("twe_agrid_sph_rk4_raise", mesh="spherical", kernels=["AdvectionRK4"], seed=92, nt=2, stagger=True)))
+    add(past_the_end(rect_agrid_case("twe_agrid_flat_rk4_3d_delete_f32part", mesh="flat", kernels=["AdvectionRK4_3D", "DeleteParticle"], seed=93,
+                                     nt=2, with_w=True, stagger=True, spatial_dtype="float32")))
+    add(past_the_end(rect_agrid_case("twe_agrid_sph_rk2_3d_oob_raise", mesh="spherical", kernels=["AdvectionRK2_3D", "DeleteOutOfBounds"], seed=94,
+                                     nt=2, with_w=True, stagger=True)))
+    add(past_the_end(rect_agrid_case("twe_agrid_sph_rk4_backward_delete", mesh="spherical", kernels=["AdvectionRK4", "DeleteParticle"], seed=95,
+                                     nt=2, stagger=True, dt=-3600.0)))
+    rc = past_the_end(rect_agrid_case("twe_agrid_sph_rk45", mesh="spherical", kernels=["AdvectionRK45"], seed=96, nt=2, stagger=True), 2.0)
+    rc["context"] = {"RK45_tol": 500.0, "RK45_min_dt": 10.0, "RK45_max_dt": 7200.0}
+    add(rc)
+    oc = past_the_end(rect_agrid_case("twe_agrid_sph_rk4_outputdt_delete", mesh="spherical", kernels=["AdvectionRK4", "DeleteParticle"], seed=97,
+                                      nt=2, stagger=True, npart=100))
+    oc["outputdt"] = 7.5 * 3600.0
+    add(oc)
+    cs = past_the_end(rect_agrid_case("twe_agrid_sph_rk4_sample_p_delete", mesh="spherical", kernels=["AdvectionRK4", "SampleP", "DeleteParticle"],
+                                      seed=98, nt=2, stagger=True))
+    cs["fields"]["P"] = smooth_random_field(_rng(1098), cs["fields"]["U"].shape, 5.0, np.float64)
+    cs["field_dims"]["P"] = TZYX_NODE
+    cs["sample_into"] = {"SampleP": ["P", "p", "float64"]}
+    add(cs)
+    # the dedicated curvilinear C-grid kernels (populated: every evaluation has a guess): RK4_3D, RK45, M1
+    for nm, kern, seed, kw in (("twe_cgrid_curv_sph_rk4_3d_delete", ["AdvectionRK4_3D", "DeleteParticle"], 101, {}),
+                               ("twe_cgrid_curv_sph_rk4_3d_raise", ["AdvectionRK4_3D"], 102, {"vel": 0.03}),  # (slow: nobody leaves the mesh first)
+                               ("twe_cgrid_curv_sph_rk45_delete", ["AdvectionRK45", "DeleteParticle"], 103, {})):
+        pc = dict(curv_cgrid_case(nm, mesh="spherical", kernels=kern, seed=seed, nt=2, **kw))
+        pc["populate"] = True
+        pc["t0"] = np.round(_rng(seed + 500).uniform(0, 5, len(pc["x"]))) * 900.0
+        if "AdvectionRK45" in kern:
+            pc["context"] = {"RK45_tol": 10.0, "RK45_min_dt": 1.0, "RK45_max_dt": 86400.0}
+        add(past_the_end(pc, 2.0 if "AdvectionRK45" in kern else 1.0))
+    pc = dict(curv_cgrid_diffusion_case("twe_cgrid_curv_sph_m1_delete", mesh="spherical", kernels=["AdvectionDiffusionM1", "DeleteParticle"], seed=104))
+    pc["populate"] = True
+    pc["t0"] = np.round(_rng(604).uniform(0, 5, len(pc["x"]))) * 900.0
+    add(past_the_end(pc))
+
     return c

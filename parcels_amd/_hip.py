@@ -13,10 +13,11 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PARCELS_HIP_LIB", os.path.join(_HERE, "libparcels_hip.so"))  # override: A/B builds
 
-PK_ABI_VERSION = 6
+PK_ABI_VERSION = 7
 PK_F32, PK_F64 = 0, 1
 PK_MAX_GRIDS, PK_MAX_FIELDS, PK_MAX_KERNELS, PK_NUM_STATE_CODES = 4, 64, 8, 80
 PK_MAX_EXTRA = 8
+PK_MAX_TWE = 64
 PK_KERNEL_SAMPLE_FIELD = 10
 PK_EVAL_MASKED = 0x10000  # pk_eval: or'ed into out_state where the value was zeroed for an out-of-bounds index
 PK_COL_EXTRA0 = 0x1000
@@ -154,6 +155,9 @@ class ExecParams(C.Structure):
         ("horizon_hi", C.c_double),
         ("max_iters", C.c_int32),
         ("body_only", C.c_int32),
+        ("twe_n", C.c_int32),
+        ("reserved1", C.c_int32),
+        ("twe_key", C.c_int64 * PK_MAX_TWE),
     ]
 
 
@@ -170,6 +174,7 @@ class ExecStats(C.Structure):
         ("launches", C.c_int32),
         ("program", C.c_int32),
         ("first_error_iter", C.c_int64),
+        ("first_time_error_key", C.c_int64),
     ]
 
 
@@ -210,6 +215,7 @@ ABI_SYMBOLS = [
     "pk_execute_begin",
     "pk_execute_end",
     "pk_execute_rerun",
+    "pk_execute_rerun_keys",
     "pk_eval",
     "pk_search",
     "pk_measure_copy_bandwidth",
@@ -276,6 +282,7 @@ def load():
     lib.pk_execute_begin.argtypes = [C.c_void_p, C.POINTER(ExecParams)]
     lib.pk_execute_end.argtypes = [C.c_void_p, C.POINTER(ExecStats)]
     lib.pk_execute_rerun.argtypes = [C.c_void_p, C.c_int32, C.POINTER(ExecStats)]
+    lib.pk_execute_rerun_keys.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(ExecStats)]
     lib.pk_eval.argtypes = [C.c_void_p, C.POINTER(ExecParams), C.c_int32, C.c_int64] + [C.c_void_p] * 8
     lib.pk_search.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pk_measure_copy_bandwidth.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_double)]

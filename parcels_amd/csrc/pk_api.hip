@@ -107,6 +107,7 @@ struct pk_ctx {
     bool fl_sorted = false;
     int64_t fl_n = 0;
     DCounters* h_counters = nullptr;          // pinned: the async D2H of the counters must not block the host
+    DCounters h_counters0;                    // initial values of a launch's counters (pageable: the H2D copy stages it at once)
     unsigned long long* h_summary = nullptr;  // pinned
     int sort_horizontal_major = -1;  // tuning knobs (environment: PK_SORT_HORIZONTAL = 0/1 forces, PK_NO_SPECIAL, PK_NO_CELL_CACHE)
     int no_special = 0;
@@ -214,6 +215,8 @@ __global__ void __launch_bounds__(256) eval_kernel(const KArgs a, int what, int6
     c.u32 = c.v32 = false;
     c.oob = false;
     c.ei0 = c.ei1 = c.ei2 = c.ei3 = 0;
+    c.it = 0u;  // not inside the loop of kernel.py:190: the caller of pk_eval owns the batch (parcels_amd/field.py: _eval_key)
+    c.klo = 0;
     const bool pos_f32 = a.prm.reset_state != 0;  // (pk_eval's own use of the field: option "eval_points_f32")
     if (what < 0) {
         double u, v, w;
@@ -1987,7 +1990,10 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
         if (f >= 0 && ctx->fields[f].d.dtype != U.d.dtype) return ctx->fail("U, V, W must share one dtype");
     const int curv = ctx->grids[a.main_grid].d.kind == 1;
     const int64_t n = ctx->dev.n;
-    static const DCounters counters0 = {0ull, 0ull, 0ull, 0xFFFFFFFFu, 0u};
+    if (prm->twe_n < 0 || prm->twe_n > PK_MAX_TWE) return ctx->fail("params.twe_n out of range");
+    DCounters& counters0 = ctx->h_counters0;
+    counters0 = DCounters{0ull, 0ull, 0ull, 0xFFFFFFFFu, 0u, ~0ull, {}};
+    for (int k = 0; k < prm->twe_n; k++) counters0.twe_listed[k] = (unsigned long long)prm->twe_key[k];
     PK_HIP(ctx, hipMemcpyAsync(ctx->d_counters, &counters0, sizeof(DCounters), hipMemcpyHostToDevice, ctx->compute));
     PK_HIP(ctx, hipMemsetAsync(ctx->d_summary, 0, sizeof(unsigned long long) * PK_NUM_STATE_CODES, ctx->compute));
     const unsigned long long init_mm[2] = {~0ull, 0ull};
@@ -2011,7 +2017,11 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
         if (has_user && prog != PROG_GENERIC) return ctx->fail("user kernels run in the plain kernel-list interpreter only (float32 coordinate arrays are not supported)");
         bool fast_a = false, fast_c = false;  // a.fast / a.fastc share storage: at most one is filled
         size_t cgrid_lds = 0;
-        const int ufast = (has_user && use_lds) ? user_fast_shape(prm, ctx->user_flags) : -1;
+        // A launch that knows samples which fail call-wide (pk_exec_params.twe_key: the repeat of a call in which some particle left a
+        // field's time interval) runs the general programs: only they test the list (the dedicated kernels report such samples and pay
+        // nothing else for it); same results otherwise, which the parity tests hold them to at rtol 0.
+        const bool listed = prm->twe_n > 0;
+        const int ufast = (has_user && use_lds && !listed) ? user_fast_shape(prm, ctx->user_flags) : -1;
         const bool user_samples = ctx->user_nsample > 0 || (ctx->user_flags & (PK_USER_SAMPLES_UV | PK_USER_SAMPLES_UVW));
         if (ufast >= 0 && !curv) {
             rc = fill_fast(ctx, prm, a, ufast == 1);
@@ -2024,6 +2034,8 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
             if (rc) return rc;
             fast_c = a.fastc.ok != 0;
             if (fast_c) prog = ufast ? PROG_RK4_3D : PROG_RK4;
+        } else if (listed) {
+            // (general program)
         } else if ((prog == PROG_RK4 || prog == PROG_RK4_3D) && !curv) {
             rc = fill_fast(ctx, prm, a, prog == PROG_RK4_3D);
             if (rc) return rc;
@@ -2143,6 +2155,7 @@ int32_t pk_execute_end(pk_ctx* ctx, pk_exec_stats* stats) {
         stats->launches = ctx->fl_launches;
         stats->program = ctx->fl_launches ? ctx->fl_program : 0;
         stats->first_error_iter = (ctx->fl_launches && hc.err_iter != 0xFFFFFFFFu) ? (int64_t)hc.err_iter : 0;
+        stats->first_time_error_key = (ctx->fl_launches && hc.twe_key != ~0ull) ? (int64_t)hc.twe_key : 0;
     }
     return 0;
 }
@@ -2202,6 +2215,23 @@ int32_t pk_execute_rerun(pk_ctx* ctx, int32_t max_iters, pk_exec_stats* stats) {
     return pk_execute_end(ctx, stats);
 }
 
+int32_t pk_execute_rerun_keys(pk_ctx* ctx, int32_t max_iters, int32_t n_keys, const int64_t* keys, pk_exec_stats* stats) {
+    if (!ctx) return -2;
+    if (ctx->in_flight) return ctx->fail("pk_execute_rerun_keys: a launch is in flight (call pk_execute_end)");
+    if (!ctx->rerun_valid) return ctx->fail("pk_execute_rerun_keys: the state before the last launch is gone (it must directly follow pk_execute / pk_execute_end)");
+    if (max_iters < 0) return ctx->fail("pk_execute_rerun_keys: max_iters must be >= 0");
+    if (n_keys < 0 || n_keys > PK_MAX_TWE || (n_keys > 0 && !keys)) return ctx->fail("pk_execute_rerun_keys: 0 .. PK_MAX_TWE keys");
+    swap_launch_outputs(ctx);  // (see pk_execute_rerun)
+    pk_exec_params prm = ctx->rerun_prm;
+    prm.sort_by_cell = 0;
+    prm.max_iters = max_iters;
+    prm.twe_n = n_keys;
+    for (int k = 0; k < PK_MAX_TWE; k++) prm.twe_key[k] = k < n_keys ? keys[k] : 0;
+    int32_t rc = pk_execute_begin(ctx, &prm);
+    if (rc) return rc;
+    return pk_execute_end(ctx, stats);
+}
+
 int32_t pk_execute(pk_ctx* ctx, const pk_exec_params* prm, pk_exec_stats* stats) {
     int32_t rc = pk_execute_begin(ctx, prm);
     if (rc) return rc;
@@ -2215,6 +2245,7 @@ int32_t pk_eval(pk_ctx* ctx, const pk_exec_params* prm, int32_t what, int64_t m,
     PK_HIP(ctx, hipSetDevice(ctx->device));
     if (m <= 0) return 0;
     pk_exec_params p2 = *prm;
+    p2.twe_n = 0;
     p2.reset_state = ctx->eval_points_f32 ? 1 : 0;  // read by eval_kernel as "sample points are float32 columns"
     if (what >= 0) {  // scalar sampling: the main grid is the sampled field's grid
         if (what >= (int)ctx->fields.size()) return ctx->fail("unknown field id");

@@ -94,6 +94,9 @@ struct DPOut {
 struct DCounters {
     unsigned long long steps, attempts, paused;
     unsigned int err_iter, pad;  // smallest iteration index (1-based) in which a particle entered an error state; 0xFFFFFFFF = none
+    unsigned long long twe_key;  // smallest key of a sample (pk_exec_params.twe_key) at which a particle left a time interval; ~0 = none
+    unsigned long long twe_listed[PK_MAX_TWE];  // the launch's copy of pk_exec_params.twe_key: read from memory on the (cold) path that
+                                                // needs it -- as kernel arguments the 32 SGPRs of the list were hoisted into every kernel
 };
 
 // Wave-uniform constants of the fast path for XLinear_Velocity on a rectilinear A-grid with float64 coordinates
@@ -173,6 +176,26 @@ struct KArgs {
 // descriptor g / f of the launch (the cast to the generic address space is undone by address-space inference once inlined)
 PK_DEV const DGrid& kgrid(const KArgs& a, int g) { return *(const DGrid*)(a.grids + g); }
 PK_DEV const DField& kfield(const KArgs& a, int f) { return *(const DField*)(a.fields + f); }
+// The call-wide OutsideTimeInterval (index_search.py:85-86 raises for the whole call; field.py:31-44 writes the code into every particle of
+// the view): a sample of a Kernel.execute call is named by (iteration `it`, kernel slot * 1000 + sample number `klo`), key = it << 32 | klo.  twe_listed: the
+// host knows that SOME particle leaves the field's time interval at this sample -- every particle that reaches it takes code 70 and the
+// value 0, nothing else of the call is written.  twe_note: this lane just left a time interval at a sample that is not listed; the
+// smallest such key of the launch goes back to the host, which repeats the call with it (include/parcels_hip.h: pk_exec_params.twe_key).
+// it == 0: not inside the loop of kernel.py:190 (pk_eval, body_only launches: the caller owns the batch there).
+PK_DEV unsigned long long twe_sample_key(unsigned it, int klo) { return ((unsigned long long)it << 32) | (unsigned long long)(unsigned)klo; }
+PK_DEV bool twe_listed(const KArgs& a, unsigned it, int klo) {
+    const int n = a.prm.twe_n;  // wave-uniform: one scalar compare per sample when nothing is listed
+    if (__builtin_expect(n == 0, 1)) return false;
+    const unsigned long long key = twe_sample_key(it, klo);
+    const volatile unsigned long long* lst = a.counters->twe_listed;
+    bool hit = false;
+    for (int k = 0; k < n; k++) hit = hit || (lst[k] == key);
+    return hit && it != 0;
+}
+PK_DEV void twe_note(const KArgs& a, unsigned it, int klo) {
+    if (it != 0) atomicMin(&a.counters->twe_key, twe_sample_key(it, klo));
+}
+
 // Scheduling fence between the gathers of two fields: without it the compiler hoists all 16 (32, 48) corner loads of
 // U, V (and W) above the first interpolation, which costs ~64 VGPRs per field and caps occupancy at 2 waves/SIMD.
 #ifndef PK_FIELD_FENCE
@@ -841,6 +864,8 @@ struct PCtx {
     bool u32, v32;  // the u / v ARRAYS of the last eval_uvw are float32 in the reference (AdvectionRK45's stage-1 products)
     bool oob;       // some sample of this context was masked to 0 by _mask_outofbounds_values (field.py:359-370); read by pk_eval only
     int64_t row;    // device row of the particle (kernels that write user Variables)
+    unsigned it;    // 1-based iteration of the loop of kernel.py:190 the particle is in (0: outside it) ...
+    int klo;        // ... and kernel slot * 1000 + samples taken so far in this iteration's call(s) of that kernel: the key of the next sample (twe_listed)
 };
 
 PK_DEV int32_t ei_get(const PCtx& c, int g) { return g == 0 ? c.ei0 : (g == 1 ? c.ei1 : (g == 2 ? c.ei2 : c.ei3)); }
@@ -1545,8 +1570,16 @@ PK_DEV void eval_uvw(const KArgs& a, const Coords& mc, PCtx& c, bool want_w, dou
     GPos p;
     u = v = w = 0.0;
     c.u32 = c.v32 = false;
+    const int klo = c.klo++;
+    if (U.has_time_interval) {
+        if (twe_listed(a, c.it, klo)) {  // somebody leaves the time interval at this sample: the whole view takes the code (field.py:31-44)
+            c.state = PK_ERROROUTSIDETIMEINTERVAL;
+            return;
+        }
+    }
     if (!time_search(U, mc.time, t, c.ht, p)) {  // field.py:303-304 -> _deal_with_errors: state := 70, zeros
         c.state = PK_ERROROUTSIDETIMEINTERVAL;
+        twe_note(a, c.it, klo);
         return;
     }
     c.ht = p.ti;
@@ -1603,8 +1636,16 @@ PK_DEV double eval_scalar(const KArgs& a, const Coords& mc, PCtx& c, int fidx, d
     const bool on_main = (f.grid == a.main_grid);
     GPos p;
     const double* time = (on_main && f.time == kfield(a, a.main_field).time) ? mc.time : f.time;
+    const int klo = c.klo++;
+    if (f.has_time_interval) {
+        if (twe_listed(a, c.it, klo)) {  // (see eval_uvw)
+            c.state = PK_ERROROUTSIDETIMEINTERVAL;
+            return 0.0;
+        }
+    }
     if (!time_search(f, time, t, on_main ? c.ht : 0, p)) {
         c.state = PK_ERROROUTSIDETIMEINTERVAL;
+        twe_note(a, c.it, klo);
         return 0.0;
     }
     const bool use_guess = take_first_eval(c, f.grid) ? (a.prm.have_guess0 != 0) : true;

@@ -230,14 +230,16 @@ PK_DEV void fctx_init(FCtx& c, int state, int32_t ei) {
 // straight from float32 particle storage (pos_f32); D3: sample W as well.
 template <class FT, bool PF, bool D3>
 PK_DEV void eval_uvw_fast(const KArgs& a, const FastTabs& T, FCtx& c, double t, double z, double y, double x, bool pos_f32, double& u,
-                          double& v, double& w) {
+                          double& v, double& w, unsigned it, int klo) {
     const FastA& F = a.fast;
     u = v = w = 0.0;
     int ti = 0;
     double tau = 0.0;
-    if (F.has_ti) {  // _search_time_index (index_search.py:65-91)
-        if (!(0 <= t) || !(t <= F.tlen)) {
+    if (F.has_ti) {  // _search_time_index (index_search.py:65-91); (it, klo): the key of this sample (pk_device.h: twe_note -- a launch with LISTED
+                     // samples runs the general program, pk_api.hip)
+        if (__builtin_expect(!(0 <= t) || !(t <= F.tlen), 0)) {
             c.state = PK_ERROROUTSIDETIMEINTERVAL;
+            twe_note(a, it, klo);
             return;
         }
         if (t != c.mt) {
@@ -319,13 +321,15 @@ PK_DEV void eval_uvw_fast(const KArgs& a, const FastTabs& T, FCtx& c, double t, 
 // and state rules of eval_uvw_fast, one gather, no unit conversion.  Only in run-time compiled modules (a user kernel that samples a
 // scalar field rides in the dedicated kernel); the arithmetic is xlinear<FT>'s, which the parity tests compare it with at rtol 0.
 template <class FT, bool PF>
-PK_DEV double eval_scalar_fast(const KArgs& a, const FastTabs& T, FCtx& c, int slot, double t, double z, double y, double x) {
+PK_DEV double eval_scalar_fast(const KArgs& a, const FastTabs& T, FCtx& c, int slot, double t, double z, double y, double x, unsigned it,
+                               int klo) {
     const FastA& F = a.fast;
     int ti = 0;
     double tau = 0.0;
     if (F.has_ti) {
         if (!(0 <= t) || !(t <= F.tlen)) {
             c.state = PK_ERROROUTSIDETIMEINTERVAL;
+            twe_note(a, it, klo);
             return 0.0;
         }
         if (t != c.mt) {

@@ -264,16 +264,17 @@ PK_DEV double cg_scalar_xlinear(const FastC& F, int k, int ti, double tau, int z
 // field's nodes; the value is returned in u.  One call site serves all seven samples of a step (sk is a run-time value there).
 template <class FT, bool PF, bool D3, bool WITH_SCALAR = false, int CM = 0>
 PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtxT<FT, CM>& c, double t, double z, double y, double x, bool pos_f32, double& u,
-                           double& v, double& w, int sk = -1) {
+                           double& v, double& w, unsigned it, int klo, int sk = -1) {
     const FastC& F = a.fastc;
     const bool scalar = WITH_SCALAR && sk >= 0;
     const int ks = scalar ? (sk & 1) : 0;
     u = v = w = 0.0;
     int ti = 0;
     double tau = 0.0;
-    if (scalar ? F.kh_has_ti[ks] != 0 : F.has_ti != 0) {  // _search_time_index (index_search.py:65-91)
-        if (!(0 <= t) || !(t <= F.tlen)) {
+    if (scalar ? F.kh_has_ti[ks] != 0 : F.has_ti != 0) {  // _search_time_index (index_search.py:65-91); (it, klo): pk_device.h, twe_note
+        if (__builtin_expect(!(0 <= t) || !(t <= F.tlen), 0)) {
             c.state = PK_ERROROUTSIDETIMEINTERVAL;
+            twe_note(a, it, klo);
             return;
         }
         if (t != c.mt) {

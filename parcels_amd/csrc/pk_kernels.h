@@ -470,6 +470,8 @@ __global__ void __launch_bounds__(wg_size(KIND, LDS), (KIND == 1 || INTERP != 0)
                               : c.state == PK_EVALUATE;
         if (run) {
             unsigned it = (prm.reset_state || body) ? 0u : (unsigned)P.iter[i];
+            c.it = 0u;
+            c.klo = 0;
             c.hz = c.hy = c.hx = c.ht = 0;
             c.hyx_valid = false;
             c.first_eval = prm.reset_state ? 0xFu : 0u;
@@ -512,9 +514,11 @@ __global__ void __launch_bounds__(wg_size(KIND, LDS), (KIND == 1 || INTERP != 0)
                     if (lo < a.win_lo || hi > a.win_hi) { paused = 1; break; }
                 }
                 it++;
+                c.it = body ? 0u : it;  // (a body_only launch is one iteration of the CALLER's loop: it handles the call-wide time error itself)
                 p.dt = dtc;
                 for (int k = 0; k < nk; k++) {  // :206-216
                     const int kid = KID >= 0 ? KID : prm.kernels[k];
+                    c.klo = k * 1000;  // key of the kernel's first sample; the samples of a Repeat re-run count on (pk_device.h: twe_listed)
                     do {
                         KLocal L;
                         L.u1f = L.v1f = false;
@@ -625,6 +629,8 @@ PK_DEV void side_kernel(const KArgs& a, int kid, int kslot, int& state, bool pf,
     c.first_eval = 0u;
     c.u32 = c.v32 = c.oob = false;
     c.ei0 = c.ei1 = c.ei2 = c.ei3 = 0;
+    c.it = 0u;
+    c.klo = 0;
     KLocal L;
     Request rq;
     (void)user_prepare(a, kid - PK_KERNEL_USER0, 0, kslot, c, p, L, rq);
@@ -637,8 +643,8 @@ PK_DEV bool is_rk4_id(int kid) { return kid == PK_KERNEL_ADVECTION_RK4 || kid ==
 // FastA::S (eval_scalar_fast; the host lists there what the module's kernels sample and checks that they share U's layout).  The stage
 // machine of the kernel runs to its end here; every sample shares the search hints and the time / depth memo of the advection kernel.
 template <class FT, bool PF, bool D3>
-PK_DEV void side_kernel_fast(const KArgs& a, const FastTabs& ft, FCtx& fc, int kid, int kslot, int64_t row, double& t, double& z, double& y,
-                             double& x, double& dz, double& dy, double& dx, double& dt) {
+PK_DEV void side_kernel_fast(const KArgs& a, const FastTabs& ft, FCtx& fc, int kid, int kslot, int64_t row, unsigned it, double& t, double& z,
+                             double& y, double& x, double& dz, double& dy, double& dx, double& dt) {
     if (kid == PK_KERNEL_DELETE_ON_ERROR) {
         if (fc.state >= PK_ERROR) fc.state = PK_DELETE;
         return;
@@ -660,6 +666,8 @@ PK_DEV void side_kernel_fast(const KArgs& a, const FastTabs& ft, FCtx& fc, int k
     c.first_eval = 0u;
     c.u32 = c.v32 = c.oob = false;
     c.ei0 = c.ei1 = c.ei2 = c.ei3 = 0;
+    c.it = it;
+    c.klo = kslot * 1000;
     KLocal L;
     Request rq;
 #pragma unroll 1
@@ -669,9 +677,9 @@ PK_DEV void side_kernel_fast(const KArgs& a, const FastTabs& ft, FCtx& fc, int k
         if (rq.kind == RQ_SCALAR) {
             int slot = 0;
             for (int k = 1; k < a.fast.ns; k++) slot = a.fast.sfid[k] == rq.fidx ? k : slot;
-            u = eval_scalar_fast<FT, PF>(a, ft, fc, slot, rq.t, rq.z, rq.y, rq.x);
+            u = eval_scalar_fast<FT, PF>(a, ft, fc, slot, rq.t, rq.z, rq.y, rq.x, it, kslot * 1000 + stage);
         } else {
-            eval_uvw_fast<FT, PF, D3>(a, ft, fc, rq.t, rq.z, rq.y, rq.x, PF && rq.f32, u, v, w);
+            eval_uvw_fast<FT, PF, D3>(a, ft, fc, rq.t, rq.z, rq.y, rq.x, PF && rq.f32, u, v, w, it, kslot * 1000 + stage);
         }
         c.state = fc.state;
         L.r[3] = u; L.r[4] = v; L.r[5] = w;
@@ -744,7 +752,7 @@ __global__ void __launch_bounds__(256, PK_MIN_WAVES_FAST) advect_fast_kernel(con
                 int adv = 0;
                 for (; adv < prm.nk && !is_rk4_id(prm.kernels[adv]); adv++) {
                     attempts++;
-                    side_kernel_fast<FT, pf, D3>(a, ft, c, prm.kernels[adv], adv, row(), pt, pz, py, px, pdz, pdy, pdx, pdt);
+                    side_kernel_fast<FT, pf, D3>(a, ft, c, prm.kernels[adv], adv, row(), it, pt, pz, py, px, pdz, pdy, pdx, pdt);
                 }
 #else
                 constexpr int adv = 0;
@@ -762,7 +770,7 @@ __global__ void __launch_bounds__(256, PK_MIN_WAVES_FAST) advect_fast_kernel(con
                         st = pt + cdt * pdt;
                     }
                     double u, v, w;
-                    eval_uvw_fast<FT, pf, D3>(a, ft, c, st, sz, sy, sx, pf && stage == 0, u, v, w);
+                    eval_uvw_fast<FT, pf, D3>(a, ft, c, st, sz, sy, sx, pf && stage == 0, u, v, w, it, adv * 1000 + stage);
                     if (stage == 0) { su = u; sv = v; sw = w; }
                     else if (stage == 3) { su = su + u; sv = sv + v; sw = sw + w; }
                     else { su = su + 2 * u; sv = sv + 2 * v; sw = sw + 2 * w; }
@@ -777,7 +785,7 @@ __global__ void __launch_bounds__(256, PK_MIN_WAVES_FAST) advect_fast_kernel(con
                     attempts++;
 #ifdef PK_USER_KERNELS
                     if (kid >= PK_KERNEL_USER0) {
-                        side_kernel_fast<FT, pf, D3>(a, ft, c, kid, k, row(), pt, pz, py, px, pdz, pdy, pdx, pdt);
+                        side_kernel_fast<FT, pf, D3>(a, ft, c, kid, k, row(), it, pt, pz, py, px, pdz, pdy, pdx, pdt);
                         continue;
                     }
 #endif
@@ -930,7 +938,7 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID) advect_cgrid_ker
                         st = pt + cdt * pdt;
                     }
                     double u, v, w;
-                    eval_uvw_cgrid<FT, pf, D3, false, CG_CACHE_RK4>(a, L, c, st, sz, sy, sx, pf && stage == 0, u, v, w);
+                    eval_uvw_cgrid<FT, pf, D3, false, CG_CACHE_RK4>(a, L, c, st, sz, sy, sx, pf && stage == 0, u, v, w, it, adv * 1000 + stage);
                     if (stage == 0) { su = u; sv = v; sw = w; }
                     else if (stage == 3) { su = su + u; sv = sv + v; sw = sw + w; }
                     else { su = su + 2 * u; sv = sv + 2 * v; sw = sw + 2 * w; }
@@ -1055,6 +1063,7 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID_RK45) advect_cgri
                 }
                 it++;
                 pdt = dtc;
+                int sno = 0;  // samples taken in this iteration: the Repeat re-runs count on (pk_device.h: twe_listed)
                 do {  // the Repeat loop of kernel.py:211-216
                     using namespace rk45c;
                     attempts++;
@@ -1084,7 +1093,7 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID_RK45) advect_cgri
                             default: break;
                         }
                         double u, v, w;
-                        eval_uvw_cgrid<FT, pf, false, false, CG_CACHE_RK45>(a, L, c, st, pzz, sy, sx, pf && stage == 0, u, v, w);
+                        eval_uvw_cgrid<FT, pf, false, false, CG_CACHE_RK45>(a, L, c, st, pzz, sy, sx, pf && stage == 0, u, v, w, it, sno + stage);
                         switch (stage) {
                             case 0: u1 = u; v1 = v; break;
                             case 1: u2 = u; v2 = v; break;
@@ -1113,6 +1122,7 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID_RK45) advect_cgri
                     if (fabs(ndt) < fabs(prm.rk45_min_dt)) ndt = prm.rk45_min_dt * sign_dt;
                     pdt = ndt;
                     if (!good) c.state = PK_REPEAT;
+                    sno += 6;
                 } while (c.state == PK_REPEAT);
                 for (int k = 1; k < prm.nk; k++) {  // the sampling-free recovery kernels that may follow (Delete*)
                     const int kid = prm.kernels[k];
@@ -1240,7 +1250,7 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID_M1) advect_cgrid_
                         default: break;
                     }
                     double r0, r1, r2;
-                    eval_uvw_cgrid<FT, pf, false, true, CG_CACHE_M1>(a, L, c, pt, pz, sy, sx, pf, r0, r1, r2, sk);
+                    eval_uvw_cgrid<FT, pf, false, true, CG_CACHE_M1>(a, L, c, pt, pz, sy, sx, pf, r0, r1, r2, it, stage, sk);
                     switch (stage) {
                         case 0: Kxp1 = r0; break;
                         case 1: Kxm1 = r0; break;

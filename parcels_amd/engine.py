@@ -482,7 +482,7 @@ class DeviceEngine:
 
     # ---- execution -------------------------------------------------------------------------------------------
     def make_params(self, kernel_ids, *, endtime, dt0, context=None, seed=0, reset_state=1, have_guess0=0, sort_by_cell=0, samples=None,
-                    horizon=None, max_iters=0):
+                    horizon=None, max_iters=0, twe_keys=()):
         fs = self.fieldset
         context = context or {}
         p = _hip.ExecParams()
@@ -515,12 +515,27 @@ class DeviceEngine:
         p.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         p.horizon_lo, p.horizon_hi = (-np.inf, np.inf) if horizon is None else (float(horizon[0]), float(horizon[1]))
         p.max_iters = int(max_iters)
+        p.twe_n = len(twe_keys)
+        for k, key in enumerate(twe_keys):
+            p.twe_key[k] = int(key)
         for slot in range(_hip.PK_MAX_KERNELS):
             p.sample_field[slot] = p.sample_var[slot] = -1
         for slot, (fname, var) in (samples or {}).items():
             p.sample_field[slot] = {"UV": -2, "UVW": -3}[fname] if fname in ("UV", "UVW") else self.field_ids[fname]  # PK_SAMPLE_UV / _UVW
             p.sample_var[slot] = int(var)
         return p
+
+    @staticmethod
+    def _repeat_decision(pass_err: int, pass_twk: int, cap: int):
+        """What a pass over a Kernel.execute call found -> "key" (a new sample fails call-wide), "cap" (a lower iteration limit) or None.
+        A sample that fails call-wide changes everything from that sample on -- the error iterations and later keys of the pass were
+        computed without it -- unless the batch stops before its iteration (kernel.py:236-245)."""
+        it_k = pass_twk >> 32
+        if pass_twk and (pass_err == 0 or it_k <= pass_err) and (cap == 0 or it_k <= cap):
+            return "key"
+        if pass_err > 0 and (cap == 0 or pass_err < cap):
+            return "cap"
+        return None
 
     def set_user_program(self, program):
         """Register (or, with None, unregister) the run-time compiled module that carries a kernel list's user kernels (jit.py)."""
@@ -541,16 +556,28 @@ class DeviceEngine:
         seconds -- particles pause untouched before a step that would cross it -- and the device rows are re-sorted by cell before the
         next piece, so that the gather locality of a long run does not decay.  Trajectories do not depend on it.
 
-        When a particle enters an error state the reference raises after THAT iteration of its batch loop (kernel.py:236-245), with
-        every other particle stopped there too: the launch is repeated from the state before it with that iteration limit
-        (``pk_execute_rerun``; ``self.exact_error_stop = False`` skips this and leaves the other particles at ``endtime``)."""
+        Two things are properties of the reference's BATCH and need a second look at the whole call (``self.exact_error_stop = False``
+        skips both and leaves every particle with its own, per-particle, outcome):
+
+        * when a particle enters an error state the reference raises after THAT iteration of its batch loop (kernel.py:236-245), with
+          every other particle stopped there too: the call is repeated from the state before it with that iteration limit;
+        * a field sample fails as a whole when ANY particle of the view lies outside the field's time interval
+          (index_search.py:85-86) and ``Field.__getitem__`` then writes ErrorOutsideTimeInterval into EVERY particle of the view and
+          returns 0 (field.py:31-44, 187-195, 297-304): a pass reports the first sample at which somebody left a time interval
+          (``first_time_error_key``), the call is repeated with that sample failing for everybody, reports the next one, ... until
+          a pass reports nothing new (include/parcels_hip.h: pk_exec_params.twe_key).
+
+        A single launch is repeated from the second column set (``pk_execute_rerun_keys``: the launch wrote there, the state before it
+        is intact); a call of several launches (streamed levels, re-sort horizons, user kernels that update Variables in place) from
+        the device checkpoint taken before its first launch.  ``self.agree_min`` (set for a sharded ParticleSet, distributed.py):
+        the batch is ALL shards, so the ranks agree on the smallest error iteration / sample key after every pass."""
         sign = 1 if dt0 > 0 else -1
         import time as _time
 
         # host-side split of a streamed run: commit = synchronous level uploads before a launch, prefetch = staging + enqueueing
         # the next level while the kernel runs, wait = pk_execute_end after the prefetch was enqueued
         total = {"steps": 0, "attempts": 0, "kernel_ms": 0.0, "sort_ms": 0.0, "launches": 0, "commit_s": 0.0, "prefetch_s": 0.0, "wait_s": 0.0,
-                 "first_error_iter": 0, "reran": 0}
+                 "first_error_iter": 0, "reran": 0, "time_error_keys": []}
         span0 = None
         if resort_every and sort_by_cell:
             ctx_ = context or {}
@@ -561,66 +588,53 @@ class DeviceEngine:
         # (a re-sort horizon only cuts runs longer than itself: the usual output interval is one launch and needs no checkpoint)
         several = self.windowed or (span0 is not None and not (t_start is not None and np.isfinite(t_start) and abs(float(endtime) - float(t_start)) <= span0))
         # user kernels update their Variables in place (they are not part of the column set a launch writes): repeating a launch from the
-        # columns it read would apply them twice, so an error stop of such a list always restarts from the checkpoint
+        # columns it read would apply them twice, so a repeat of such a list always restarts from the checkpoint
         several = several or in_place_variables
         if several and self.exact_error_stop:
             self.ctx.check(self.lib.pk_particles_checkpoint(self.ctx.handle), "pk_particles_checkpoint")
             checkpointed = True
         cap = 0  # iteration limit of the batch loop (0: none)
-        restart = True
-        while restart:
-            restart = False
+        keys: list[int] = []  # samples that fail call-wide with OutsideTimeInterval (pk_exec_params.twe_key)
+        rerun = False  # the next pass is a single launch repeated from the second column set
+        agree = getattr(self, "agree_min", None)
+        while True:  # passes over the whole call
             reset = 1
             t_live = t_start
             last_live = None
             span = span0
-            first_launch = True
-            while True:
-                nxt = None
-                if self.windowed:
-                    if t_live is None or not np.isfinite(t_live):
-                        t_live = 0.0 if sign > 0 else max(float(f.model.time_flt[-1]) for f in self._windowed_fields())
-                    _t = _time.perf_counter()
-                    nxt = self._commit_window(float(t_live), sign)
-                    total["commit_s"] += _time.perf_counter() - _t
-                horizon = None
-                if span is not None and t_live is not None and np.isfinite(t_live):
-                    horizon = (-np.inf, float(t_live) + span) if sign > 0 else (float(t_live) - span, np.inf)
-                prm = self.make_params(kernel_ids, endtime=endtime, dt0=dt0, context=context, seed=seed, reset_state=reset,
-                                       have_guess0=(have_guess0 if reset else 1), sort_by_cell=sort_by_cell, samples=samples, horizon=horizon,
-                                       max_iters=cap)
+            pass_err, pass_twk = 0, 0
+            total["steps"] = total["attempts"] = 0
+            while True:  # launches of one pass
                 st = _hip.ExecStats()
-                self.ctx.check(self.lib.pk_execute_begin(self.ctx.handle, C.byref(prm)), "pk_execute_begin")
                 prefetched = False
-                try:
-                    _t = _time.perf_counter()
-                    prefetched = self._prefetch(nxt)  # overlaps the kernel that was just launched
-                    total["prefetch_s"] += _time.perf_counter() - _t
-                finally:
-                    _t = _time.perf_counter()
-                    self.ctx.check(self.lib.pk_execute_end(self.ctx.handle, C.byref(st)), "pk_execute_end")
-                    total["wait_s"] += _time.perf_counter() - _t
+                if rerun:
+                    karr = (C.c_int64 * max(len(keys), 1))(*keys)
+                    self.ctx.check(self.lib.pk_execute_rerun_keys(self.ctx.handle, int(cap), len(keys), karr, C.byref(st)), "pk_execute_rerun_keys")
+                    rerun = False
+                else:
+                    nxt = None
+                    if self.windowed:
+                        if t_live is None or not np.isfinite(t_live):
+                            t_live = 0.0 if sign > 0 else max(float(f.model.time_flt[-1]) for f in self._windowed_fields())
+                        _t = _time.perf_counter()
+                        nxt = self._commit_window(float(t_live), sign)
+                        total["commit_s"] += _time.perf_counter() - _t
+                    horizon = None
+                    if span is not None and t_live is not None and np.isfinite(t_live):
+                        horizon = (-np.inf, float(t_live) + span) if sign > 0 else (float(t_live) - span, np.inf)
+                    prm = self.make_params(kernel_ids, endtime=endtime, dt0=dt0, context=context, seed=seed, reset_state=reset,
+                                           have_guess0=(have_guess0 if reset else 1), sort_by_cell=sort_by_cell, samples=samples, horizon=horizon,
+                                           max_iters=cap, twe_keys=keys)
+                    self.ctx.check(self.lib.pk_execute_begin(self.ctx.handle, C.byref(prm)), "pk_execute_begin")
+                    try:
+                        _t = _time.perf_counter()
+                        prefetched = self._prefetch(nxt)  # overlaps the kernel that was just launched
+                        total["prefetch_s"] += _time.perf_counter() - _t
+                    finally:
+                        _t = _time.perf_counter()
+                        self.ctx.check(self.lib.pk_execute_end(self.ctx.handle, C.byref(st)), "pk_execute_end")
+                        total["wait_s"] += _time.perf_counter() - _t
                 reset = 0
-                err_at = int(st.first_error_iter)
-                if err_at > 0 and self.exact_error_stop and (cap == 0 or err_at < cap):
-                    # kernel.py:236-245: stop every particle after the iteration in which the first one erred
-                    cap = err_at
-                    total["first_error_iter"] = cap
-                    total["reran"] += 1
-                    total["kernel_ms"] += st.kernel_ms
-                    total["sort_ms"] += st.sort_ms
-                    total["launches"] += st.launches
-                    if first_launch and not in_place_variables:  # the state before this launch still sits in the second column set
-                        st = _hip.ExecStats()
-                        self.ctx.check(self.lib.pk_execute_rerun(self.ctx.handle, cap, C.byref(st)), "pk_execute_rerun")
-                    else:
-                        if not checkpointed:
-                            raise _hip.HipLibraryError("error in a later launch of a run without a checkpoint (internal error)")
-                        self.ctx.check(self.lib.pk_particles_restore(self.ctx.handle), "pk_particles_restore")
-                        total["steps"] = total["attempts"] = 0
-                        restart = True
-                        break
-                first_launch = False
                 total["steps"] += st.steps
                 total["attempts"] += st.attempts
                 total["kernel_ms"] += st.kernel_ms
@@ -628,10 +642,17 @@ class DeviceEngine:
                 total["launches"] += st.launches
                 total["program"] = int(st.program)  # which device program the (last) launch ran: include/parcels_hip.h, pk_exec_stats
                 counts = {code: int(st.state_counts[code]) for code in range(_hip.PK_NUM_STATE_CODES) if st.state_counts[code]}
+                if st.first_error_iter > 0:
+                    pass_err = int(st.first_error_iter) if pass_err == 0 else min(pass_err, int(st.first_error_iter))
+                if st.first_time_error_key > 0:
+                    pass_twk = int(st.first_time_error_key) if pass_twk == 0 else min(pass_twk, int(st.first_time_error_key))
                 if st.paused == 0:
                     break
                 if not self.windowed and span is None:
                     raise _hip.HipLibraryError("particles paused although all time levels are resident (internal error)")
+                # (what this launch found already decides that the pass will be repeated: stop it here)
+                if self.exact_error_stop and agree is None and self._repeat_decision(pass_err, pass_twk, cap) is not None:
+                    break
                 t_live = st.t_min_live if sign > 0 else st.t_max_live
                 # no particle moved AND no new level is on its way (a small ring needs one launch per cycle just to bring in the
                 # level behind the window; the next commit makes it resident): the step itself does not fit
@@ -644,6 +665,30 @@ class DeviceEngine:
                             "increase nslots (FieldSet.to_device(nslots=...))"
                         )
                 last_live = t_live
+            if not self.exact_error_stop:
+                break
+            if agree is not None:  # the batch of the reference is every shard's particles
+                pass_err, pass_twk = agree(pass_err, pass_twk)
+            decision = self._repeat_decision(pass_err, pass_twk, cap)
+            if decision == "key":
+                keys = sorted(k for k in keys if k < pass_twk) + [pass_twk]
+                if len(keys) > _hip.PK_MAX_TWE:
+                    raise RuntimeError(f"more than {_hip.PK_MAX_TWE} call-wide time errors in one Kernel.execute")
+                cap = 0
+            elif decision == "cap":
+                cap = pass_err  # kernel.py:236-245: stop every particle after the iteration in which the first one erred
+            repeat = decision is not None
+            if not repeat:
+                break
+            total["reran"] += 1
+            if checkpointed:
+                self.ctx.check(self.lib.pk_particles_restore(self.ctx.handle), "pk_particles_restore")
+            elif several:
+                raise _hip.HipLibraryError("a call of several launches has to be repeated but has no checkpoint (internal error)")
+            else:
+                rerun = True  # the state before the (only) launch still sits in the second column set
+        total["first_error_iter"] = cap
+        total["time_error_keys"] = list(keys)
         total["state_counts"] = counts
         self.last_stats = total
         return total

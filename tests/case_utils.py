@@ -203,7 +203,7 @@ def run_hip(case, endtime=None, nslots=None, async_output=None, fieldset=None, *
     return {k: np.array(v) for k, v in pset._data.items()}, err, pset._last_stats
 
 
-def run_oracle(case, endtime=None, nthreads=1, call_wide_time_error=False):
+def run_oracle(case, endtime=None, nthreads=1, call_wide_time_error=True):
     from oracle import c_oracle as co
 
     c = dict(case)
