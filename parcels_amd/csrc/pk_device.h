@@ -1709,7 +1709,7 @@ PK_DEV void normal_pair(uint64_t seed, int kslot, int64_t particle_id, double t,
     const double r = sqrt(-2.0 * log(u1));
     const double th = 6.283185307179586476925286766559 * u2;
     double s, co;
-    sincos(th, &s, &co);
+    sincos_geo(th, s, co);  // (th in [0, 2 pi): < 1 ulp like the library's, without its large-argument path)
     z0 = r * co;
     z1 = r * s;
 }

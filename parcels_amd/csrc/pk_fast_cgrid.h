@@ -35,10 +35,21 @@ constexpr int CT2_STRIDE = 32;
 // in LDS are 232 B per lane = 10 workgroups per CU (160 KB), and ~170 VGPRs are 2 waves per SIMD.  Bit 0 (CG_FV_REGS): the 12 staggered
 // field values live in registers; bit 1 (CG_PXY_REGS): the 8 corner coordinates CGrid_Velocity reads (rows 16..23 of the record) do.
 // Both are read with compile-time indices only.  The 15 rows of the point-in-cell test always stay in LDS.
-constexpr int CG_FV_REGS = 1, CG_PXY_REGS = 2;
-constexpr int fc_rec_rows(int cm) { return (cm & CG_PXY_REGS) ? 15 : 23; }  // LDS rows of a lane's slot: record rows 0..14 (then 16..23)
+// Bit 2 (CG_PXY_GLOBAL): the corner coordinates are not cached at all -- the velocity sample reads them from the cell's record in the
+// table (rows 16..23, one more cache line of a record whose first lines the search just read).  For AdvectionDiffusionM1's program, where
+// six of the seven samples of a step are scalar samples that never look at them: 16 VGPRs less to carry around every one of them, and a
+// cell change fetches 128 B of the record instead of 192.
+constexpr int CG_FV_REGS = 1, CG_PXY_REGS = 2, CG_PXY_GLOBAL = 4;
+constexpr int fc_rec_rows(int cm) { return (cm & (CG_PXY_REGS | CG_PXY_GLOBAL)) ? 15 : 23; }  // LDS rows of a lane's slot: record rows 0..14 (then 16..23)
 constexpr int fc_fv_lds(int cm) { return (cm & CG_FV_REGS) ? 0 : 12; }       // field values of a lane kept in LDS
 constexpr int FC_LANES = 64;     // one-wavefront workgroups (see CC_LANES)
+#ifndef PK_CG_HOPS
+#define PK_CG_HOPS 0  // AdvectionRK45, after the guessed cell rejected the point: 0 = ONE probe of the cell floor(xsi, eta) cells away (its stages
+                      // with a dt of hours land a cell or two away, and on a smooth mesh the bilinear inverse of the guessed cell extrapolates
+                      // that far), 1 = the adjacent cell like every other kernel, 3 = up to three hops.  BASELINE config 5, same box
+                      // (profiles/r04_d_c5_variants_ab.txt, r04_e_c5_variants_ab.txt): 14.6 ms (1), 13.4 ms (0), 15.3 ms (3: the loop's
+                      // registers cost more than the table walks it saves)
+#endif
 
 struct CgLds {
     const pk_tab2* time;   // {a, 1/width} tables
@@ -58,9 +69,16 @@ struct CCtxT {
     int rc_cell;         // cell whose record sits in the lane's LDS slot, -1 = none
     int fv_cell, fv_zt;  // tags of the cached field values: cell, (ti << 13) | (zi << 1) | (level ti+1 cached)
     double mt, mtau, mz, mzeta;
-    // AdvectionDiffusionM1's program: its seven samples per step share latitudes (x +- dres, x) and longitudes (y +- dres, y) -- the
-    // sines / cosines of the query point are memoised on the bits of the coordinate (unused, and optimised away, elsewhere)
-    double qy, qx, q_sl, q_cl, q_so, q_co;
+    // AdvectionDiffusionM1's program: five of the seven samples of a step are taken at the particle's own latitude, five at its own
+    // longitude -- the kernel computes their sines / cosines once per step (cg_home_sincos) and a sample whose coordinate is bitwise the
+    // particle's takes them from here (unused, and optimised away, elsewhere)
+    double q_sl, q_cl, q_so, q_co;
+    // ... and the velocity sample of a step leaves the cell it found at the particle's own position and the float64 (xsi, eta) there
+    // (m_cell < 0: none): a scalar sample AT that position whose `ei` guess is that cell is the reference's guessed search hitting
+    // (index_search.py:269-285) -- the same point in the same cell gives the same coordinates, so the two Kh samples at (x, y) need no
+    // point-in-cell test of their own
+    int m_cell;
+    double m_xs, m_et;
     FT fvr[(CM & CG_FV_REGS) ? 12 : 1];      // the cached field values (CG_FV_REGS)
     double pxy[(CM & CG_PXY_REGS) ? 8 : 1];  // unwrapped corner longitudes, corner latitudes of rc_cell (CG_PXY_REGS)
 };
@@ -77,8 +95,9 @@ PK_DEV void cctx_init(CCtxT<FT, CM>& c, int state, int32_t ei, int gy, int gx) {
     c.fv_zt = 0;
     c.mt = c.mz = __builtin_nan("");
     c.mtau = c.mzeta = 0.0;
-    c.qy = c.qx = __builtin_nan("");
     c.q_sl = c.q_cl = c.q_so = c.q_co = 0.0;
+    c.m_cell = -1;
+    c.m_xs = c.m_et = 0.0;
 #pragma unroll
     for (int k = 0; k < ((CM & CG_FV_REGS) ? 12 : 1); k++) c.fvr[k] = (FT)0;
 #pragma unroll
@@ -151,9 +170,10 @@ PK_DEV bool cg_fields_cached(const CCtxT<FT, CM>& c, int cell, int zi, int ti, b
 template <class FT, bool D3, bool WITH_F, int CM>
 PK_DEV double cg_fetch_cell(const FastC& F, const CgLds& L, CCtxT<FT, CM>& c, int cell, int yi, int xi, int zi, int ti, bool lenT) {
     const double* g = F.ct2 + (int64_t)cell * CT2_STRIDE;
-    double r[24];
+    constexpr int NR = (CM & CG_PXY_GLOBAL) ? 16 : 24;  // rows of the record a lane keeps
+    double r[NR];
 #pragma unroll
-    for (int k = 0; k < 12; k++) ldpair(g + 2 * k, r[2 * k], r[2 * k + 1]);
+    for (int k = 0; k < NR / 2; k++) ldpair(g + 2 * k, r[2 * k], r[2 * k + 1]);
     FT raw[12];
     const bool wantf = WITH_F && zi >= 0 && !cg_fields_cached(c, cell, zi, ti, lenT);
     if (WITH_F) {
@@ -162,7 +182,9 @@ PK_DEV double cg_fetch_cell(const FastC& F, const CgLds& L, CCtxT<FT, CM>& c, in
     double* rec = L.rec;
 #pragma unroll
     for (int k = 0; k < 15; k++) rec[k * FC_LANES] = r[k];
-    if constexpr ((CM & CG_PXY_REGS) != 0) {
+    if constexpr ((CM & CG_PXY_GLOBAL) != 0) {
+        // (read where they are used)
+    } else if constexpr ((CM & CG_PXY_REGS) != 0) {
 #pragma unroll
         for (int k = 0; k < 8; k++) c.pxy[k] = r[16 + k];
     } else {
@@ -176,15 +198,22 @@ PK_DEV double cg_fetch_cell(const FastC& F, const CgLds& L, CCtxT<FT, CM>& c, in
     return r[15];
 }
 
+template <class FT, int CM>
+PK_DEV void cg_home_sincos(CCtxT<FT, CM>& c, double y, double x) {
+    sincos_geo(y * DEG2RAD, c.q_sl, c.q_cl);
+    sincos_geo(x * DEG2RAD, c.q_so, c.q_co);
+}
+
 // curvilinear_point_in_cell (index_search.py:94-177) on the record in the lane's LDS slot.  Bit for bit what point_in_cell ->
 // spherical_project_query -> bilinear_inverse of pk_device.h compute: the cell-only sub-expressions were formed by the table build
 // in the same order.  `cell`: for the degenerate branch (reads pv from the global record).
-PK_DEV bool cg_point_in_cell(const FastC& F, const double* rec, int cell, double qX, double qY, double qZ, double& xsi, double& eta) {
-    const double eu0 = rec[0 * FC_LANES], eu1 = rec[1 * FC_LANES], eu2 = rec[2 * FC_LANES];
-    const double ev0 = rec[3 * FC_LANES], ev1 = rec[4 * FC_LANES], ev2 = rec[5 * FC_LANES];
-    const double a0 = rec[6 * FC_LANES], a1 = rec[7 * FC_LANES], a2 = rec[8 * FC_LANES], a3 = rec[9 * FC_LANES];
-    const double b1 = rec[10 * FC_LANES], b3 = rec[11 * FC_LANES];
-    const double aa4 = rec[12 * FC_LANES], bb0 = rec[13 * FC_LANES], cc0 = rec[14 * FC_LANES];
+template <class Row>
+PK_DEV bool cg_point_in_cell_rows(const FastC& F, Row row, int cell, double qX, double qY, double qZ, double& xsi, double& eta) {
+    const double eu0 = row(0), eu1 = row(1), eu2 = row(2);
+    const double ev0 = row(3), ev1 = row(4), ev2 = row(5);
+    const double a0 = row(6), a1 = row(7), a2 = row(8), a3 = row(9);
+    const double b1 = row(10), b3 = row(11);
+    const double aa4 = row(12), bb0 = row(13), cc0 = row(14);
     const double xq = qX * eu0 + qY * eu1 + qZ * eu2;  // spherical_project_query
     const double yq = qX * ev0 + qY * ev1 + qZ * ev2;
     const double bb = bb0 + xq * b3 - yq * a3;
@@ -213,6 +242,9 @@ PK_DEV bool cg_point_in_cell(const FastC& F, const double* rec, int cell, double
     xsi = x;
     eta = e;
     return (x >= 0) && (x <= 1) && (e >= 0) && (e <= 1);
+}
+PK_DEV bool cg_point_in_cell(const FastC& F, const double* rec, int cell, double qX, double qY, double qZ, double& xsi, double& eta) {
+    return cg_point_in_cell_rows(F, [rec](int k) { return rec[k * FC_LANES]; }, cell, qX, qY, qZ, xsi, eta);
 }
 
 // XLinear.interp (_xinterpolators.py:112-153) of scalar field `k` (FastC::kh) at a grid position: xlinear<FT> of pk_device.h for a
@@ -262,9 +294,9 @@ PK_DEV double cg_scalar_xlinear(const FastC& F, int k, int ti, double tau, int z
 // WITH_SCALAR (AdvectionDiffusionM1's program): `sk` >= 0 asks for Field.eval (field.py:145-195) of scalar field FastC::kh[sk] instead --
 // same search on the same grid (the `ei` guess chain of the particle runs through velocity and scalar samples alike), XLinear on the
 // field's nodes; the value is returned in u.  One call site serves all seven samples of a step (sk is a run-time value there).
-template <class FT, bool PF, bool D3, bool WITH_SCALAR = false, int CM = 0>
+template <class FT, bool PF, bool D3, bool WITH_SCALAR = false, int CM = 0, int HOPS = 1>
 PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtxT<FT, CM>& c, double t, double z, double y, double x, bool pos_f32, double& u,
-                           double& v, double& w, unsigned it, int klo, int sk = -1) {
+                           double& v, double& w, unsigned it, int klo, int sk = -1, double home_y = 0.0, double home_x = 0.0, bool at_home = false) {
     const FastC& F = a.fastc;
     const bool scalar = WITH_SCALAR && sk >= 0;
     const int ks = scalar ? (sk & 1) : 0;
@@ -298,10 +330,9 @@ PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtxT<FT, CM>& c, dou
     const bool lenT = tau > 0;
     // the query point on the unit sphere (make_qpoint / latlon_rad_to_xyz)
     double sl, cl, so, co;
-    if (WITH_SCALAR) {
-        if (!(y == c.qy)) { sincos_geo(y * DEG2RAD, c.q_sl, c.q_cl); c.qy = y; }
-        if (!(x == c.qx)) { sincos_geo(x * DEG2RAD, c.q_so, c.q_co); c.qx = x; }
-        sl = c.q_sl; cl = c.q_cl; so = c.q_so; co = c.q_co;
+    if (WITH_SCALAR) {  // (home_y, home_x): the particle's own position, whose sines / cosines the kernel left in the context
+        if (y == home_y) { sl = c.q_sl; cl = c.q_cl; } else sincos_geo(y * DEG2RAD, sl, cl);
+        if (x == home_x) { so = c.q_so; co = c.q_co; } else sincos_geo(x * DEG2RAD, so, co);
     } else {
         sincos_geo(y * DEG2RAD, sl, cl);
         sincos_geo(x * DEG2RAD, so, co);
@@ -311,50 +342,116 @@ PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtxT<FT, CM>& c, dou
     int yi = GRID_SEARCH_ERROR, xi = GRID_SEARCH_ERROR;
     double xsi = -1.0, eta = -1.0;
     bool found = false;
-    const bool guess_ok = c.gy >= 0 && c.gy < F.gny - 1 && c.gx >= 0 && c.gx < F.gnx - 1;
-    if (__builtin_expect(guess_ok, 1)) {
-        const int cell = c.gy * F.gnx + c.gx;
-        if (c.rc_cell != cell) {  // (a scalar sample fetches the record only)
-            if (scalar) cg_fetch_cell<FT, D3, false, CM>(F, L, c, cell, c.gy, c.gx, zi, ti, lenT);
-            else cg_fetch_cell<FT, D3, true, CM>(F, L, c, cell, c.gy, c.gx, zi, ti, lenT);
+    {
+        const bool guess_ok = c.gy >= 0 && c.gy < F.gny - 1 && c.gx >= 0 && c.gx < F.gnx - 1;
+        bool memo_hit = false;
+        if constexpr (WITH_SCALAR) {
+            if (!scalar) c.m_cell = -1;  // (the velocity sample of a step: set below when it finds its cell on this path)
+            memo_hit = scalar && at_home && guess_ok && c.m_cell == c.gy * F.gnx + c.gx;
         }
-        double xs, et;
-        if (cg_point_in_cell(F, L.rec, cell, qX, qY, qZ, xs, et)) {
+        if (memo_hit) {  // the guessed cell is the one the velocity sample found at this very point (see CCtxT::m_cell)
             found = true;
             yi = c.gy;
             xi = c.gx;
-            xsi = xs;
-            eta = et;
-        } else if (F.walk_ok) {
-            // the particle left the guessed cell: the neighbour its barycentric coordinates point at (curvilinear_search)
-            const int dj = et < 0 ? -1 : (et > 1 ? 1 : 0), di = xs < 0 ? -1 : (xs > 1 ? 1 : 0);
-            const int nj = c.gy + dj, ni = c.gx + di;
-            if ((dj | di) != 0 && nj >= 0 && nj < F.gny - 1 && ni >= 0 && ni < F.gnx - 1) {
-                const int ncell = nj * F.gnx + ni;
-                const double boxd = scalar ? cg_fetch_cell<FT, D3, false, CM>(F, L, c, ncell, nj, ni, zi, ti, lenT) : cg_fetch_cell<FT, D3, true, CM>(F, L, c, ncell, nj, ni, zi, ti, lenT);
-                double xs2, et2;
-                const double m = 1e-9;
-                if (cg_point_in_cell(F, L.rec, ncell, qX, qY, qZ, xs2, et2) && xs2 > m && xs2 < 1 - m && et2 > m && et2 < 1 - m) {
-                    if (box_lists(kgrid(a, F.grid), (unsigned long long)__double_as_longlong(boxd), qX, qY, qZ, true)) {
-                        found = true;
-                        yi = nj;
-                        xi = ni;
-                        xsi = (double)(float)xs2;  // rounded like a hash hit (spatialhash.py:505)
-                        eta = (double)(float)et2;
+            xsi = c.m_xs;
+            eta = c.m_et;
+        } else if (__builtin_expect(guess_ok, 1)) {
+            const int cell = c.gy * F.gnx + c.gx;
+            if (c.rc_cell != cell) {  // (a scalar sample fetches the record only)
+                if (scalar) cg_fetch_cell<FT, D3, false, CM>(F, L, c, cell, c.gy, c.gx, zi, ti, lenT);
+                else cg_fetch_cell<FT, D3, true, CM>(F, L, c, cell, c.gy, c.gx, zi, ti, lenT);
+            }
+            double xs, et;
+            if (cg_point_in_cell(F, L.rec, cell, qX, qY, qZ, xs, et)) {
+                found = true;
+                yi = c.gy;
+                xi = c.gx;
+                xsi = xs;
+                eta = et;
+                if constexpr (WITH_SCALAR) {
+                    if (!scalar) { c.m_cell = cell; c.m_xs = xs; c.m_et = et; }
+                }
+            } else if (F.walk_ok) {
+                if constexpr (HOPS <= 1) {
+                    // the particle left the guessed cell: the neighbour its barycentric coordinates point at (curvilinear_search)
+                    int dj = et < 0 ? -1 : (et > 1 ? 1 : 0), di = xs < 0 ? -1 : (xs > 1 ? 1 : 0);
+                    if constexpr (HOPS == 0) {  // one probe, but of the cell floor(xsi, eta) cells away (AdvectionRK45's long stages)
+                        if (fabs(xs) < 64.0 && fabs(et) < 64.0) {
+                            dj = et < 0 ? (int)floor(et) : (et > 1 ? (int)ceil(et) - 1 : 0);
+                            di = xs < 0 ? (int)floor(xs) : (xs > 1 ? (int)ceil(xs) - 1 : 0);
+                        }
+                    }
+                    const int nj = c.gy + dj, ni = c.gx + di;
+                    if ((dj | di) != 0 && nj >= 0 && nj < F.gny - 1 && ni >= 0 && ni < F.gnx - 1) {
+                        const int ncell = nj * F.gnx + ni;
+                        const double boxd = scalar ? cg_fetch_cell<FT, D3, false, CM>(F, L, c, ncell, nj, ni, zi, ti, lenT) : cg_fetch_cell<FT, D3, true, CM>(F, L, c, ncell, nj, ni, zi, ti, lenT);
+                        double xs2, et2;
+                        const double m = 1e-9;
+                        if (cg_point_in_cell(F, L.rec, ncell, qX, qY, qZ, xs2, et2) && xs2 > m && xs2 < 1 - m && et2 > m && et2 < 1 - m) {
+                            if (box_lists(kgrid(a, F.grid), (unsigned long long)__double_as_longlong(boxd), qX, qY, qZ, true)) {
+                                found = true;
+                                yi = nj;
+                                xi = ni;
+                                xsi = (double)(float)xs2;  // rounded like a hash hit (spatialhash.py:505)
+                                eta = (double)(float)et2;
+                                if constexpr (WITH_SCALAR) {
+                                    if (!scalar) { c.m_cell = ncell; c.m_xs = xs2; c.m_et = et2; }
+                                }
+                            }
+                        }
+                    }
+                } else {
+                    // The particle left the guessed cell: test the cell its barycentric coordinates point at (curvilinear_search does this for
+                    // the adjacent cell).  Here the jump is floor() of the coordinates -- AdvectionRK45's stages with a dt of hours land several
+                    // cells away, and on a smooth mesh the bilinear inverse of the guessed cell extrapolates to within a cell of the truth -- and
+                    // a cell that rejects the point hands its own coordinates to the next hop (HOPS of them at most: one in the
+                    // kernels whose samples stay close, PK_CG_HOPS in AdvectionRK45's, pk_kernels.h).  Accepted exactly
+                    // like the neighbour probe: strictly inside by a margin (no tie that the table order would have to break) and listed in the
+                    // query's hash cell; on a mesh without coincident nodes at most one cell qualifies, so it is the face SpatialHash.query
+                    // finds (spatialhash.py:389-535), reached in one or two record fetches instead of a walk over the ~10-20 faces of the hash
+                    // cell.  Anything else falls through to that walk.
+                    int cj = c.gy, ci = c.gx;
+                    double cxs = xs, cet = et;
+        #pragma unroll 1
+                    for (int hop = 0; hop < HOPS; hop++) {  // (HOPS == 1: no loop is left)
+                        if (!(fabs(cxs) < 64.0 && fabs(cet) < 64.0)) break;  // (also NaN: the degenerate branches of the bilinear inverse)
+                        const int dj = cet < 0 ? (int)floor(cet) : (cet > 1 ? (int)ceil(cet) - 1 : 0);
+                        const int di = cxs < 0 ? (int)floor(cxs) : (cxs > 1 ? (int)ceil(cxs) - 1 : 0);
+                        const int nj = cj + dj, ni = ci + di;
+                        if ((dj | di) == 0 || nj < 0 || nj >= F.gny - 1 || ni < 0 || ni >= F.gnx - 1) break;
+                        const int ncell = nj * F.gnx + ni;
+                        const double boxd = scalar ? cg_fetch_cell<FT, D3, false, CM>(F, L, c, ncell, nj, ni, zi, ti, lenT) : cg_fetch_cell<FT, D3, true, CM>(F, L, c, ncell, nj, ni, zi, ti, lenT);
+                        double xs2, et2;
+                        const double m = 1e-9;
+                        if (cg_point_in_cell(F, L.rec, ncell, qX, qY, qZ, xs2, et2)) {
+                            if (xs2 > m && xs2 < 1 - m && et2 > m && et2 < 1 - m &&
+                                box_lists(kgrid(a, F.grid), (unsigned long long)__double_as_longlong(boxd), qX, qY, qZ, true)) {
+                                found = true;
+                                yi = nj;
+                                xi = ni;
+                                xsi = (double)(float)xs2;  // rounded like a hash hit (spatialhash.py:505)
+                                eta = (double)(float)et2;
+                            }
+                            break;
+                        }
+                        cj = nj;
+                        ci = ni;
+                        cxs = xs2;
+                        cet = et2;
                     }
                 }
             }
         }
-    }
-    if (__builtin_expect(!found, 0)) {
-        // the faces of the query's hash cell in table order (SpatialHash.query, spatialhash.py:389-535): the general routine
-        int wy, wx;
-        double wxs, wet;
-        curvilinear_search(kgrid(a, F.grid), y, x, false, 0, 0, wy, wx, wxs, wet);
-        yi = wy;
-        xi = wx;
-        xsi = wxs;
-        eta = wet;
+        if (__builtin_expect(!found, 0)) {
+            // the faces of the query's hash cell in table order (SpatialHash.query, spatialhash.py:389-535): the general routine
+            int wy, wx;
+            double wxs, wet;
+            curvilinear_search(kgrid(a, F.grid), y, x, false, 0, 0, wy, wx, wxs, wet);
+            yi = wy;
+            xi = wx;
+            xsi = wxs;
+            eta = wet;
+        }
     }
     // ravel_index (basegrid.py:83-152): the low 32 bits of the int64 sum are the wrapped 32-bit sum
     c.ei = (int32_t)((uint32_t)xi * F.ex + (uint32_t)yi * F.ey + (uint32_t)zi * F.ez);
@@ -393,7 +490,13 @@ PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtxT<FT, CM>& c, dou
     }
     // ---- CGrid_Velocity.interp (_xinterpolators.py:193-332), float64 coordinates and barycentric arrays ----
     double px[4], py[4];
-    if constexpr ((CM & CG_PXY_REGS) != 0) {
+    if constexpr ((CM & CG_PXY_GLOBAL) != 0) {
+        const double* g = F.ct2 + (int64_t)cell * CT2_STRIDE + 16;
+        ldpair(g, px[0], px[1]);
+        ldpair(g + 2, px[2], px[3]);
+        ldpair(g + 4, py[0], py[1]);
+        ldpair(g + 6, py[2], py[3]);
+    } else if constexpr ((CM & CG_PXY_REGS) != 0) {
 #pragma unroll
         for (int k = 0; k < 4; k++) { px[k] = c.pxy[k]; py[k] = c.pxy[4 + k]; }
     } else {

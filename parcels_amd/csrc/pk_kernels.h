@@ -63,7 +63,7 @@ PK_DEV double m2_to_deg2_zonal(bool pf, double v, double lat, double deg2m) {
         float a_ = (float)deg2m * cosf((float)lat * 3.14159265358979323846f / 180.0f);
         return v / (double)(a_ * a_);
     }
-    double a_ = deg2m * cos(lat * 3.14159265358979323846 / 180);
+    double a_ = deg2m * cos_lat(lat * 3.14159265358979323846 / 180);  // (pk_device.h: < 1 ulp, like the reference's libm)
     return v / (a_ * a_);
 }
 PK_DEV double m2_to_deg2_merid(double v, double deg2m) { return v / (deg2m * deg2m); }
@@ -858,7 +858,7 @@ __global__ void __launch_bounds__(256, PK_MIN_WAVES_FAST) advect_fast_kernel(con
 #define PK_CG_CACHE_RK45 2
 #endif
 #ifndef PK_CG_CACHE_M1
-#define PK_CG_CACHE_M1 2
+#define PK_CG_CACHE_M1 4
 #endif
 constexpr int CG_CACHE_RK4 = PK_CG_CACHE, CG_CACHE_RK45 = PK_CG_CACHE_RK45, CG_CACHE_M1 = PK_CG_CACHE_M1;
 template <class FT, int PFM, bool D3>
@@ -1093,7 +1093,7 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID_RK45) advect_cgri
                             default: break;
                         }
                         double u, v, w;
-                        eval_uvw_cgrid<FT, pf, false, false, CG_CACHE_RK45>(a, L, c, st, pzz, sy, sx, pf && stage == 0, u, v, w, it, sno + stage);
+                        eval_uvw_cgrid<FT, pf, false, false, CG_CACHE_RK45, PK_CG_HOPS>(a, L, c, st, pzz, sy, sx, pf && stage == 0, u, v, w, it, sno + stage);
                         switch (stage) {
                             case 0: u1 = u; v1 = v; break;
                             case 1: u2 = u; v2 = v; break;
@@ -1237,6 +1237,8 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID_M1) advect_cgrid_
                 attempts++;
                 // seven samples at one call site (_advectiondiffusion.py:44-57): Kxp1, Kxm1, UV, khz, Kyp1, Kym1, khm
                 double Kxp1 = 0, Kxm1 = 0, khz = 0, Kyp1 = 0, Kym1 = 0, khm = 0, u = 0, v = 0;
+                cg_home_sincos(c, py, px);
+                c.m_cell = -1;  // (the velocity sample's cell at the particle's position: set by this step's third sample)
 #pragma unroll 1
                 for (int stage = 0; stage < 7; stage++) {
                     double sx = px, sy = py;
@@ -1250,7 +1252,7 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID_M1) advect_cgrid_
                         default: break;
                     }
                     double r0, r1, r2;
-                    eval_uvw_cgrid<FT, pf, false, true, CG_CACHE_M1>(a, L, c, pt, pz, sy, sx, pf, r0, r1, r2, it, stage, sk);
+                    eval_uvw_cgrid<FT, pf, false, true, CG_CACHE_M1>(a, L, c, pt, pz, sy, sx, pf, r0, r1, r2, it, stage, sk, py, px, stage == 3 || stage == 6);
                     switch (stage) {
                         case 0: Kxp1 = r0; break;
                         case 1: Kxm1 = r0; break;
