@@ -176,6 +176,30 @@ def user_kernel_runs(n):
     return res
 
 
+def long_run(case, fs, steps):
+    """The headline workload over ALL its time levels in one Kernel.execute (552 steps of 1 h through the 24 daily levels, one cell sort,
+    one fused launch; DeleteParticle because a few particles reach the edge of the domain in 23 days): the headline's 9 ms window is 4 %
+    of it.  Through the product path (ParticleSet.execute: H2D of the columns, sort, launch, D2H)."""
+    import torch
+
+    import parcels_amd as pa
+    from tests.case_utils import build_pset
+
+    pset = build_pset(case, fs, sort_by_cell=True, resort_every=0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pset.execute([pa.AdvectionRK4, pa.DeleteParticle], dt=case["dt"], runtime=steps * case["dt"])
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    st = pset._last_stats
+    ks = st["kernel_ms"] * 1e-3
+    return {"workload": f"the headline FieldSet and particles, AdvectionRK4 + DeleteParticle, {steps} steps of {case['dt']:.0f} s through all "
+                        f"{len(case['time_s'])} levels, one cell sort, {st['launches']} launch(es)",
+            "particle_steps": int(st["steps"]), "kernel_ms": st["kernel_ms"], "cell_sort_ms": st["sort_ms"], "remaining_particles": len(pset),
+            "value": st["steps"] / ks, "unit": "particle-steps/s (kernel time)", "value_incl_sort": st["steps"] / (ks + st["sort_ms"] * 1e-3),
+            "value_end_to_end": st["steps"] / wall, "wall_s_incl_h2d_d2h": wall}
+
+
 def secondary_runs(args):
     """BASELINE configs 3 and 5 at full size on this GPU (tools/bench_configs.py builds them), outside the timed region of the
     headline: per run the particle-steps/s of the fused launch (HIP events on the compute stream), the algorithmic-byte roofline
@@ -197,12 +221,12 @@ def secondary_runs(args):
         t0 = time.perf_counter()
         try:
             res = bc.run_config(config, scale=args.secondary_scale, particles=args.secondary_particles, steps=24, nt=4, nslots=3, nz=75,
-                                check=int(args.secondary_check), emit=lambda o: None)
+                                check=int(args.secondary_check), emit=lambda o: None, reps=int(args.secondary_reps))
         except AssertionError as e:  # the subset check failed: report it, do not hide it
             out.append({"config": config, "check": {"passed": False, "error": str(e)[:2000]}})
             continue
         for r in res:
-            ks = r["kernel_ms"] * 1e-3
+            ks = r["kernel_ms"] * 1e-3  # (the MEDIAN of the timed launches: tools/bench_configs.py)
             units = r["attempts"] if r["kernels"] == "AdvectionRK45" else r["particle_steps"]  # RK45: bytes move per attempt
             if r["kernels"] == "AdvectionRK45":
                 units = units / 2  # `attempts` counts the DeleteParticle slot of every attempt too
@@ -210,6 +234,7 @@ def secondary_runs(args):
             e = {"config": config, "workload": f"{config.upper()}: curvilinear C-grid {r['grid'][0]}x{r['grid'][1]}x{r['grid'][2]} f32 U,V,W, "
                                                f"{r['nslots']}-slot ring, {r['particles']} fp64 particles, {r['kernels']} + DeleteParticle, 24 steps of 3600 s",
                  "kernels": r["kernels"], "particle_steps": r["particle_steps"], "attempts": r["attempts"], "kernel_ms": r["kernel_ms"],
+                 "kernel_ms_stats": r.get("kernel_ms_stats"),
                  "value": r["particle_steps_per_s_kernel"], "unit": "particle-steps/s (kernel time, levels resident)",
                  "cell_sort_ms": r["sort_ms"], "wall_s_incl_h2d_d2h": r["wall_s"],
                  "roofline": {"bound": "hbm", "algorithmic_bytes_per_unit": ab, "units": units,
@@ -246,6 +271,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reps", type=int, default=7,
+                    help="the timed region (barrier, EXACTLY --steps steps, barrier) is repeated this many times, each from the device checkpoint taken "
+                         "after the warm-up; `value`, `ms_per_step` and `roofline` use the MEDIAN repetition, min / max are reported next to it")
+    ap.add_argument("--long-run", type=int, default=552,
+                    help="N = 1 only: also run the headline workload over ALL its time levels (this many steps, one launch) as `long_run`; 0 = off")
+    ap.add_argument("--secondary-reps", type=int, default=5, help="timed launches per secondary kernel list after one cold launch")
+    ap.add_argument("--c4", type=float, default=0,
+                    help="also run BASELINE config 4 after the headline, on the same ranks: the NEMO-size curvilinear C-grid with this many particles PER "
+                         "GPU (1e7 -> 8e7 on 8 GPUs), AdvectionRK4_3D, one id space sharded by id, ParticleFile on rank 0 fed by the gather of the "
+                         "to-write columns (tools/bench_configs.py::run_c4); attached as `c4`; 0 = off")
     ap.add_argument("--particles", type=float, default=1e7, help="particles per GPU")
     ap.add_argument("--sort", type=int, default=1, help="cell-sort the device copy of the particles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -293,6 +328,8 @@ def main():
     from parcels_amd.distributed import shard_slice
     from tests.case_utils import build_fieldset, build_pset
 
+    t_start_wall = time.perf_counter()
+    legs = {}  # wall seconds of every leg of this run (rank 0): where the minutes of a default run go
     npart = int(args.particles)
     K, W = args.steps, args.warmup
     shard = shard_slice(world * npart, rank, world)  # one id space, sharded by id
@@ -320,6 +357,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    legs["setup_fieldset_particles_h2d"] = time.perf_counter() - t_start_wall
     # measured device-to-device copy bandwidth (float4 copy of 1 GiB): the practical HBM ceiling, and the calibration dispatch of
     # the FETCH_SIZE / WRITE_SIZE counter passes (tools/pmc_summary.py)
     copy_gbps = eng.ctx.copy_bandwidth(1 << 30, 5) if rank == 0 else 0.0
@@ -329,15 +367,30 @@ def main():
     if W > 0:
         st_w = eng.execute(kern.kernel_ids, endtime=W * dt, dt0=dt, sort_by_cell=int(args.sort), t_start=0.0)
         sort_ms = st_w["sort_ms"]
-    sync()
-    t0 = time.perf_counter()
-    st = eng.execute(kern.kernel_ids, endtime=(W + K) * dt, dt0=dt, sort_by_cell=0, t_start=W * dt)
-    sync()
-    el = time.perf_counter() - t0
-    # the write-out exchange (not a step): all-gather of the output columns straight from the device columns
-    t_ag = 0.0
+    # The timed region, repeated: every repetition restores the device columns to the state after the warm-up (pk_particles_checkpoint /
+    # _restore, outside the timed region) and times EXACTLY K steps between two barriers.  One repetition of the headline is a 9 ms
+    # launch: a single sample of it says little (clock ramp, first touch), the median of several is what is quoted.
+    import ctypes as C
+
+    eng.ctx.check(eng.lib.pk_particles_checkpoint(eng.ctx.handle), "pk_particles_checkpoint")
+    reps = max(int(args.reps), 1)
+    rep_el, rep_kms, rep_steps = [], [], []
+    for r in range(reps):
+        if r > 0:
+            eng.ctx.check(eng.lib.pk_particles_restore(eng.ctx.handle), "pk_particles_restore")
+        sync()
+        t0 = time.perf_counter()
+        st = eng.execute(kern.kernel_ids, endtime=(W + K) * dt, dt0=dt, sort_by_cell=0, t_start=W * dt)
+        sync()
+        rep_el.append(time.perf_counter() - t0)
+        rep_kms.append(st["kernel_ms"])
+        rep_steps.append(float(st["steps"]))
+    # the write-out exchange (not a step), straight from the device columns: the all-gather of the to-write columns that the north star
+    # names, and the gather-to-rank-0 that ParticleFile.write uses (parcels_amd/distributed.py) -- both timed, neither in `value`
+    t_ag = t_g0 = 0.0
+    comm = {}
     if dist is not None:
-        from parcels_amd.distributed import allgather_output
+        from parcels_amd.distributed import allgather_output, device_write_rows, gather_write_columns
 
         t1 = time.perf_counter()
         gathered = allgather_output(eng, world)
@@ -345,24 +398,45 @@ def main():
         t_ag = time.perf_counter() - t1
         assert gathered["particle_id"].shape[0] == world * npart
         del gathered
-    elt = torch.tensor([el], device="cuda", dtype=torch.float64)
-    steps_t = torch.tensor([float(st["steps"])], device="cuda", dtype=torch.float64)
-    kms = torch.tensor([st["kernel_ms"]], device="cuda", dtype=torch.float64)
+        cols = device_write_rows(eng, ["particle_id", "t", "z", "y", "x"], (W + K) * dt)  # the product's write filter, on the device
+        sync()
+        t1 = time.perf_counter()
+        rooted = gather_write_columns(cols, device=local_rank)  # (what ParticleFile.write calls: device tensors over RCCL, host tensors over gloo)
+        sync()
+        t_g0 = time.perf_counter() - t1
+        if rank == 0:
+            assert rooted["particle_id"].shape[0] == world * npart, rooted["particle_id"].shape
+        del rooted, cols
+        try:
+            ver = torch.cuda.nccl.version()
+        except Exception:
+            ver = None
+        comm = {"backend": dist.get_backend(), "n_ranks_seen": dist.get_world_size(), "rccl_version": ".".join(str(v) for v in ver) if ver else None}
+    elt = torch.tensor(rep_el, device="cuda", dtype=torch.float64)  # per repetition: the MAX over ranks ...
+    steps_t = torch.tensor([rep_steps[-1]], device="cuda", dtype=torch.float64)
+    kmst = torch.tensor(rep_kms, device="cuda", dtype=torch.float64)
+    kmin = kmst.clone()
     if dist is not None:
         dist.all_reduce(elt, op=dist.ReduceOp.MAX)
         dist.all_reduce(steps_t, op=dist.ReduceOp.SUM)
-        dist.all_reduce(kms, op=dist.ReduceOp.MAX)
-    el = float(elt.item())
+        dist.all_reduce(kmst, op=dist.ReduceOp.MAX)
+        dist.all_reduce(kmin, op=dist.ReduceOp.MIN)
+    rep_el = [float(v) for v in elt.tolist()]
+    rep_kms_max = [float(v) for v in kmst.tolist()]
+    rep_kms_min = [float(v) for v in kmin.tolist()]
+    order = sorted(range(reps), key=lambda i: rep_el[i])
+    med = order[(reps - 1) // 2]  # ... and of those the median repetition (the lower one of an even count: an actual run, not an average)
+    el = rep_el[med]
+    kms = torch.tensor([rep_kms_max[med]], dtype=torch.float64)
     total_steps = float(steps_t.item())
-    agt = torch.tensor([t_ag], device="cuda", dtype=torch.float64)
+    agt = torch.tensor([t_ag, t_g0], device="cuda", dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(agt, op=dist.ReduceOp.MAX)
-    t_ag = float(agt.item())
+    t_ag, t_g0 = (float(v) for v in agt.tolist())
     t_d2h = time.perf_counter()
     eng.d2h()
     t_d2h = time.perf_counter() - t_d2h
     ok = bool(np.all(pset._data["state"] == pa.StatusCode.EndofLoop))
-
     if rank == 0:
         value = total_steps / el
         kernel_s = float(kms.item()) * 1e-3
@@ -419,6 +493,11 @@ def main():
             "steps": K,
             "warmup": W,
             "ms_per_step": el / K * 1e3,
+            # the timed region was repeated: `value`, `ms_per_step`, `roofline` are those of the median repetition
+            "timed_reps": {"n": reps, "statistic": "median", "wall_ms": {"min": min(rep_el) * 1e3, "median": el * 1e3, "max": max(rep_el) * 1e3},
+                           "kernel_ms": {"min": min(rep_kms_max), "median": sorted(rep_kms_max)[(reps - 1) // 2], "max": max(rep_kms_max), "n": reps},
+                           "spread": (max(rep_el) - min(rep_el)) / el,
+                           **({"kernel_ms_slowest_vs_fastest_rank_of_median_rep": [rep_kms_max[med], rep_kms_min[med]]} if world > 1 else {})},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -434,6 +513,8 @@ def main():
                               "value_pcie_inclusive": total_steps / (el + t_h2d + t_d2h)},
             "value_end_to_end": total_steps / t_all,  # H2D of the particle columns + cell sort + K steps + D2H
             "writeout_allgather_ms": t_ag * 1e3 if world > 1 else None,
+            "writeout_gather_to_root_ms": t_g0 * 1e3 if world > 1 else None,  # what ParticleFile.write does (rows of the write filter -> rank 0)
+            "comm": comm or None,
             "value_incl_writeout": total_steps / (el + t_ag) if world > 1 else None,
         }
         ref = os.path.join(ROOT, "profiles", "r02_cpu_reference.json")
@@ -447,23 +528,54 @@ def main():
                                                  "source": "profiles/r02_cpu_reference.json (tools/time_reference_cpu.py): NOT this box -- the reference is Python and does not travel"}
             except Exception:
                 pass
+        legs["headline_warmup_and_timed_reps"] = time.perf_counter() - t_start_wall - legs["setup_fieldset_particles_h2d"]
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is reported at N = 1 only
+            _t = time.perf_counter()
             out["cpu_baseline"] = cpu_baseline(case, steps=K, sample=min(args.cpu_sample, npart))
+            legs["cpu_baseline"] = time.perf_counter() - _t
+        if args.long_run and world == 1:
+            _t = time.perf_counter()
+            try:
+                out["long_run"] = long_run(case, fs, int(args.long_run))
+            except Exception as e:
+                out["long_run"] = {"error": repr(e)[:2000]}
+            legs["long_run"] = time.perf_counter() - _t
         if args.secondary and world == 1:
             # release the headline's device and host memory first: C3 needs 36 GB of HBM and 48 GB of host arrays
-            del pset, kern, eng, fs, case
+            pset = kern = eng = fs = case = None
             import gc
 
             gc.collect()
+            _t = time.perf_counter()
             try:
                 out["secondary"] = secondary_runs(args)
             except Exception as e:  # the headline line must survive a failing secondary leg
                 out["secondary"] = [{"error": repr(e)[:2000]}]
+            legs["secondary"] = time.perf_counter() - _t
             if args.user_kernels:
+                _t = time.perf_counter()
                 try:
                     out["user_kernels"] = user_kernel_runs(int(args.user_kernels))
                 except Exception as e:
                     out["user_kernels"] = {"error": repr(e)[:2000]}
+                legs["user_kernels"] = time.perf_counter() - _t
+    c4 = {}
+    if args.c4:  # every rank takes part; rank 0 holds the result
+        pset = kern = eng = fs = case = None  # (the headline's device and host memory: config 4 needs 36 GB of HBM per rank)
+        import gc
+
+        gc.collect()
+        try:
+            from tools import bench_configs as bc
+
+            bc.run_c4(particles=args.c4, emit=c4.update)
+        except Exception as e:
+            c4 = {"error": repr(e)[:2000]}
+    if rank == 0:
+        if args.c4:
+            out["c4"] = c4
+        legs["total_after_imports"] = time.perf_counter() - t_start_wall
+        out["legs_wall_s"] = legs
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

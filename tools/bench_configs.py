@@ -104,7 +104,7 @@ def seed_particles_block(lon, lat, depth, lo, hi, seed):
     return np.concatenate(xs), np.concatenate(ys), np.concatenate(zs)
 
 
-def run_c4(scale=1.0, particles=1e7, steps=24, nt=4, nslots=3, nz=75, output_every=6, verify_single=False, dt=3600.0, shared_dir=None):
+def run_c4(scale=1.0, particles=1e7, steps=24, nt=4, nslots=3, nz=75, output_every=6, verify_single=False, dt=3600.0, shared_dir=None, emit=None):
     """BASELINE config 4: the C3 grid, `particles` per GPU over all ranks of one node (launch with torch.distributed.run, one
     process per GPU), ONE id space sharded by id, fields replicated in HBM from one shared memory-mapped copy on the host, no
     collective on the data path, and a ParticleFile on rank 0 fed by the RCCL all-gather of the to-write columns every
@@ -120,7 +120,8 @@ def run_c4(scale=1.0, particles=1e7, steps=24, nt=4, nslots=3, nz=75, output_eve
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    own_group = world > 1 and not dist.is_initialized()  # (bench.py --c4 calls this inside its own process group)
+    if own_group:
         dist.init_process_group("gloo" if rehearsal else "nccl", **({} if rehearsal else {"device_id": torch.device("cuda", local_rank)}))
     shared_dir = shared_dir or os.environ.get("PK_C4_DIR", f"/dev/shm/pk_c4_{os.environ.get('MASTER_PORT', '0')}")
     nx, ny = max(int(4322 * scale), 32), max(int(3059 * scale), 32)
@@ -183,10 +184,14 @@ def run_c4(scale=1.0, particles=1e7, steps=24, nt=4, nslots=3, nz=75, output_eve
             one_run(0, world * n, single, False)
             out["byte_identical_to_single_process_file"] = open(single, "rb").read() == open(out_path, "rb").read()
             assert out["byte_identical_to_single_process_file"], "the gathered Parquet differs from the single-process file"
-        print(json.dumps(out), flush=True)
+        if emit is None:
+            print(json.dumps(out), flush=True)
+        else:
+            emit(out)
     if world > 1:
         dist.barrier()
-        dist.destroy_process_group()
+        if own_group:
+            dist.destroy_process_group()
     if rank == 0 and os.environ.get("PK_C4_KEEP") != "1":
         import shutil
 
@@ -233,7 +238,10 @@ def check_against_oracle(*, n_check, dsinfo, engine, pset, kernel_names, context
             "exact": ["particle ids of the survivors (= deleted set)", "state", "ei", "t"], "oracle_s": oracle_s}
 
 
-def run_config(config="c3", scale=1.0, particles=1e7, steps=24, nt=4, nslots=3, nz=75, hash="device", check=0, emit=print, dt=3600.0):
+def run_config(config="c3", scale=1.0, particles=1e7, steps=24, nt=4, nslots=3, nz=75, hash="device", check=0, emit=print, dt=3600.0, reps=5):
+    """reps: after one COLD run of a kernel list (the first launch after the FieldSet was built: first touch of the tables, clock ramp) the
+    same run is repeated `reps` times from fresh ParticleSets of the same positions; `kernel_ms` is the MEDIAN of those, the cold one and
+    min / max are reported next to it (`kernel_ms_stats`).  reps = 0: the cold run alone, like rounds 1-3."""
     import parcels_amd as pa
 
     nx, ny = max(int(4322 * scale), 32), max(int(3059 * scale), 32)
@@ -257,26 +265,33 @@ def run_config(config="c3", scale=1.0, particles=1e7, steps=24, nt=4, nslots=3, 
     ]
     results = []
     for label, kernels, kind in runs:
-        if kind != "rk45":  # RK45 mode is keyed on the context (kernel.py:118): do not leak it into the other runs
-            for key in ("RK45_tol", "RK45_min_dt", "RK45_max_dt"):
-                fs.context.pop(key, None)
         pclass = pa.get_default_particle(np.float64)
         if kind == "rk45":
             pclass = pclass.add_variable(pa.Variable("next_dt", dtype=np.float64, initial=dt))
-        pset = pa.ParticleSet(fs, pclass=pclass, x=x, y=y, z=z, t=np.zeros(n), sort_by_cell=True)
-        pset.populate_indices()
         import warnings
 
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            t0 = time.perf_counter()
-            pset.execute(kernels, dt=dt, runtime=steps * dt)
-            wall = time.perf_counter() - t0
-        st = pset._last_stats
+        kms_all = []
+        for r in range(1 + max(int(reps), 0)):
+            # RK45 mode is keyed on the context (kernel.py:118): do not leak it into the other runs -- and every Kernel construction
+            # divides RK45_tol by deg2m again (kernel.py:144-145, reproduced), so a repetition starts from the defaults as well
+            for key in ("RK45_tol", "RK45_min_dt", "RK45_max_dt"):
+                fs.context.pop(key, None)
+            pset = pa.ParticleSet(fs, pclass=pclass, x=x, y=y, z=z, t=np.zeros(n), sort_by_cell=True)
+            pset.populate_indices()
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                t0 = time.perf_counter()
+                pset.execute(kernels, dt=dt, runtime=steps * dt)
+                wall = time.perf_counter() - t0
+            kms_all.append(float(pset._last_stats["kernel_ms"]))
+        st = dict(pset._last_stats)
+        timed = sorted(kms_all[1:]) or kms_all
+        st["kernel_ms"] = timed[(len(timed) - 1) // 2]
         out = {
             "config": config, "kernels": label, "grid": [nx, ny, nz, nt], "nslots": nslots, "particles": n,
             "steps_requested": steps, "particle_steps": int(st["steps"]), "attempts": int(st["attempts"]),
             "kernel_ms": st["kernel_ms"], "sort_ms": st["sort_ms"], "launches": st["launches"],
+            "kernel_ms_stats": {"cold": kms_all[0], "min": timed[0], "median": st["kernel_ms"], "max": timed[-1], "n": len(timed), "statistic": "median of the timed launches" if len(kms_all) > 1 else "the cold launch"},
             "particle_steps_per_s_kernel": st["steps"] / (st["kernel_ms"] * 1e-3) if st["kernel_ms"] else None,
             "particle_steps_per_s_wall_incl_h2d_d2h": st["steps"] / wall, "wall_s": wall,
             "remaining_particles": len(pset), "state_counts": st["state_counts"],
@@ -305,13 +320,14 @@ def main():
     ap.add_argument("--hash", default="device", choices=["device", "host"], help="where the Morton table of the grid is built")
     ap.add_argument("--dt", type=float, default=3600.0)
     ap.add_argument("--check", type=float, default=0, help="re-run the first N particles through the CPU oracle and compare (0 = off)")
+    ap.add_argument("--reps", type=int, default=5, help="c3 / c5: timed repetitions after the cold run (kernel_ms = their median)")
     ap.add_argument("--output-every", type=int, default=6, help="c4: steps between write-outs")
     ap.add_argument("--verify-single", action="store_true", help="c4: rank 0 re-runs the whole id space alone and compares the files")
     a = ap.parse_args()
     if a.config == "c4":
         run_c4(a.scale, a.particles, a.steps, a.nt, a.nslots, a.nz, a.output_every, a.verify_single, a.dt)
         return
-    run_config(a.config, a.scale, a.particles, a.steps, a.nt, a.nslots, a.nz, a.hash, int(a.check), dt=a.dt)
+    run_config(a.config, a.scale, a.particles, a.steps, a.nt, a.nslots, a.nz, a.hash, int(a.check), dt=a.dt, reps=a.reps)
 
 
 if __name__ == "__main__":
