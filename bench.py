@@ -375,8 +375,15 @@ def main():
     eng.ctx.check(eng.lib.pk_particles_checkpoint(eng.ctx.handle), "pk_particles_checkpoint")
     reps = max(int(args.reps), 1)
     rep_el, rep_kms, rep_steps = [], [], []
+    settle_ms = None
+    if reps > 1:  # one untimed run of the timed region first (the first launch after the sort runs on cold caches and a ramping clock)
+        sync()
+        t0 = time.perf_counter()
+        eng.execute(kern.kernel_ids, endtime=(W + K) * dt, dt0=dt, sort_by_cell=0, t_start=W * dt)
+        sync()
+        settle_ms = (time.perf_counter() - t0) * 1e3
     for r in range(reps):
-        if r > 0:
+        if r > 0 or settle_ms is not None:
             eng.ctx.check(eng.lib.pk_particles_restore(eng.ctx.handle), "pk_particles_restore")
         sync()
         t0 = time.perf_counter()
@@ -496,7 +503,7 @@ def main():
             # the timed region was repeated: `value`, `ms_per_step`, `roofline` are those of the median repetition
             "timed_reps": {"n": reps, "statistic": "median", "wall_ms": {"min": min(rep_el) * 1e3, "median": el * 1e3, "max": max(rep_el) * 1e3},
                            "kernel_ms": {"min": min(rep_kms_max), "median": sorted(rep_kms_max)[(reps - 1) // 2], "max": max(rep_kms_max), "n": reps},
-                           "spread": (max(rep_el) - min(rep_el)) / el,
+                           "spread": (max(rep_el) - min(rep_el)) / el, "untimed_settling_rep_wall_ms": settle_ms,
                            **({"kernel_ms_slowest_vs_fastest_rank_of_median_rep": [rep_kms_max[med], rep_kms_min[med]]} if world > 1 else {})},
             "higher_is_better": True,
             "scaling": "weak",

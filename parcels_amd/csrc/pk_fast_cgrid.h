@@ -73,12 +73,6 @@ struct CCtxT {
     // longitude -- the kernel computes their sines / cosines once per step (cg_home_sincos) and a sample whose coordinate is bitwise the
     // particle's takes them from here (unused, and optimised away, elsewhere)
     double q_sl, q_cl, q_so, q_co;
-    // ... and the velocity sample of a step leaves the cell it found at the particle's own position and the float64 (xsi, eta) there
-    // (m_cell < 0: none): a scalar sample AT that position whose `ei` guess is that cell is the reference's guessed search hitting
-    // (index_search.py:269-285) -- the same point in the same cell gives the same coordinates, so the two Kh samples at (x, y) need no
-    // point-in-cell test of their own
-    int m_cell;
-    double m_xs, m_et;
     FT fvr[(CM & CG_FV_REGS) ? 12 : 1];      // the cached field values (CG_FV_REGS)
     double pxy[(CM & CG_PXY_REGS) ? 8 : 1];  // unwrapped corner longitudes, corner latitudes of rc_cell (CG_PXY_REGS)
 };
@@ -96,8 +90,6 @@ PK_DEV void cctx_init(CCtxT<FT, CM>& c, int state, int32_t ei, int gy, int gx) {
     c.mt = c.mz = __builtin_nan("");
     c.mtau = c.mzeta = 0.0;
     c.q_sl = c.q_cl = c.q_so = c.q_co = 0.0;
-    c.m_cell = -1;
-    c.m_xs = c.m_et = 0.0;
 #pragma unroll
     for (int k = 0; k < ((CM & CG_FV_REGS) ? 12 : 1); k++) c.fvr[k] = (FT)0;
 #pragma unroll
@@ -296,7 +288,7 @@ PK_DEV double cg_scalar_xlinear(const FastC& F, int k, int ti, double tau, int z
 // field's nodes; the value is returned in u.  One call site serves all seven samples of a step (sk is a run-time value there).
 template <class FT, bool PF, bool D3, bool WITH_SCALAR = false, int CM = 0, int HOPS = 1>
 PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtxT<FT, CM>& c, double t, double z, double y, double x, bool pos_f32, double& u,
-                           double& v, double& w, unsigned it, int klo, int sk = -1, double home_y = 0.0, double home_x = 0.0, bool at_home = false) {
+                           double& v, double& w, unsigned it, int klo, int sk = -1, double home_y = 0.0, double home_x = 0.0) {
     const FastC& F = a.fastc;
     const bool scalar = WITH_SCALAR && sk >= 0;
     const int ks = scalar ? (sk & 1) : 0;
@@ -330,6 +322,7 @@ PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtxT<FT, CM>& c, dou
     const bool lenT = tau > 0;
     // the query point on the unit sphere (make_qpoint / latlon_rad_to_xyz)
     double sl, cl, so, co;
+    const bool guess_ok = c.gy >= 0 && c.gy < F.gny - 1 && c.gx >= 0 && c.gx < F.gnx - 1;
     if (WITH_SCALAR) {  // (home_y, home_x): the particle's own position, whose sines / cosines the kernel left in the context
         if (y == home_y) { sl = c.q_sl; cl = c.q_cl; } else sincos_geo(y * DEG2RAD, sl, cl);
         if (x == home_x) { so = c.q_so; co = c.q_co; } else sincos_geo(x * DEG2RAD, so, co);
@@ -343,19 +336,7 @@ PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtxT<FT, CM>& c, dou
     double xsi = -1.0, eta = -1.0;
     bool found = false;
     {
-        const bool guess_ok = c.gy >= 0 && c.gy < F.gny - 1 && c.gx >= 0 && c.gx < F.gnx - 1;
-        bool memo_hit = false;
-        if constexpr (WITH_SCALAR) {
-            if (!scalar) c.m_cell = -1;  // (the velocity sample of a step: set below when it finds its cell on this path)
-            memo_hit = scalar && at_home && guess_ok && c.m_cell == c.gy * F.gnx + c.gx;
-        }
-        if (memo_hit) {  // the guessed cell is the one the velocity sample found at this very point (see CCtxT::m_cell)
-            found = true;
-            yi = c.gy;
-            xi = c.gx;
-            xsi = c.m_xs;
-            eta = c.m_et;
-        } else if (__builtin_expect(guess_ok, 1)) {
+        if (__builtin_expect(guess_ok, 1)) {
             const int cell = c.gy * F.gnx + c.gx;
             if (c.rc_cell != cell) {  // (a scalar sample fetches the record only)
                 if (scalar) cg_fetch_cell<FT, D3, false, CM>(F, L, c, cell, c.gy, c.gx, zi, ti, lenT);
@@ -368,9 +349,6 @@ PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtxT<FT, CM>& c, dou
                 xi = c.gx;
                 xsi = xs;
                 eta = et;
-                if constexpr (WITH_SCALAR) {
-                    if (!scalar) { c.m_cell = cell; c.m_xs = xs; c.m_et = et; }
-                }
             } else if (F.walk_ok) {
                 if constexpr (HOPS <= 1) {
                     // the particle left the guessed cell: the neighbour its barycentric coordinates point at (curvilinear_search)
@@ -394,9 +372,6 @@ PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtxT<FT, CM>& c, dou
                                 xi = ni;
                                 xsi = (double)(float)xs2;  // rounded like a hash hit (spatialhash.py:505)
                                 eta = (double)(float)et2;
-                                if constexpr (WITH_SCALAR) {
-                                    if (!scalar) { c.m_cell = ncell; c.m_xs = xs2; c.m_et = et2; }
-                                }
                             }
                         }
                     }

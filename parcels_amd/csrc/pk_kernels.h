@@ -1238,7 +1238,6 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID_M1) advect_cgrid_
                 // seven samples at one call site (_advectiondiffusion.py:44-57): Kxp1, Kxm1, UV, khz, Kyp1, Kym1, khm
                 double Kxp1 = 0, Kxm1 = 0, khz = 0, Kyp1 = 0, Kym1 = 0, khm = 0, u = 0, v = 0;
                 cg_home_sincos(c, py, px);
-                c.m_cell = -1;  // (the velocity sample's cell at the particle's position: set by this step's third sample)
 #pragma unroll 1
                 for (int stage = 0; stage < 7; stage++) {
                     double sx = px, sy = py;
@@ -1252,7 +1251,7 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID_M1) advect_cgrid_
                         default: break;
                     }
                     double r0, r1, r2;
-                    eval_uvw_cgrid<FT, pf, false, true, CG_CACHE_M1>(a, L, c, pt, pz, sy, sx, pf, r0, r1, r2, it, stage, sk, py, px, stage == 3 || stage == 6);
+                    eval_uvw_cgrid<FT, pf, false, true, CG_CACHE_M1>(a, L, c, pt, pz, sy, sx, pf, r0, r1, r2, it, stage, sk, py, px);
                     switch (stage) {
                         case 0: Kxp1 = r0; break;
                         case 1: Kxm1 = r0; break;

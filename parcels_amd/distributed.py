@@ -63,6 +63,38 @@ def allreduce_scalars(values, op: str, group=None, device=None) -> list:
     return t.cpu().tolist()
 
 
+def batch_agreement(group=None, device=None):
+    """The two hooks that make a sharded ParticleSet ONE batch for the batch-wide rules of ``Kernel.execute`` (DeviceEngine.execute):
+
+    * ``agree_min(first_error_iter, first_time_error_key)`` -> the smallest non-zero value of each over all ranks (0 = none anywhere):
+      the reference stops EVERY particle after the iteration in which the first one errs (kernel.py:236-245), and a field sample
+      outside the time interval fails for every particle of the call (index_search.py:85-86, field.py:31-44) -- on whichever shard the
+      erring / leaving particle lives;
+    * ``agree_codes(present)`` -> element-wise "present on any rank" of a 0/1 list: the error codes the call ended with, so that every
+      rank raises what the reference raises (kernel.py:236-245), not only the rank that holds the particle.
+
+    Two int64 scalars / a handful of int64 flags per Kernel.execute pass: device tensors under RCCL, host tensors under gloo."""
+    import torch
+    import torch.distributed as dist
+
+    on_gpu = dist.get_backend(group) == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device() if device is None else int(device)) if on_gpu else torch.device("cpu")
+    big = (1 << 62)
+
+    def agree_min(err, key):
+        t = torch.tensor([int(err) or big, int(key) or big], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        e, k = (int(v) for v in t.tolist())
+        return (0 if e == big else e), (0 if k == big else k)
+
+    def agree_codes(present):
+        t = torch.tensor([int(bool(p)) for p in present], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        return [int(v) for v in t.tolist()]
+
+    return agree_min, agree_codes
+
+
 def gather_write_columns(columns: dict, group=None, device=None) -> dict | None:
     """The write-out exchange of ParticleFile.write (particlefile.py:142-180) across ranks: every rank passes the columns of ITS
     particles that pass the write filter -- NumPy arrays, or torch tensors that already live on the device (gather_device_rows) --

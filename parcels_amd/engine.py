@@ -81,6 +81,9 @@ class DeviceEngine:
         self._bound_sig = None
         self._next_dt_f32 = None
         self.device_variables: list[str] = []  # user Variables bound as extra device columns (set by Kernel: SampleField targets)
+        # a sharded ParticleSet is one batch: hooks of parcels_amd.distributed.batch_agreement (set by ParticleSet.execute for a collective run)
+        self.agree_min = None
+        self.agree_codes = None
         self.last_stats: dict | None = None
 
     # ---- grids -----------------------------------------------------------------------------------------------
@@ -690,7 +693,39 @@ class DeviceEngine:
         total["first_error_iter"] = cap
         total["time_error_keys"] = list(keys)
         total["state_counts"] = counts
+        if self.agree_codes is not None and self.exact_error_stop:
+            total["codes_any_shard"] = self._agree_on_codes(counts)
         self.last_stats = total
+        return total
+
+    _RAISING_CODES = (70, 60, 61, 51, 52, 50)  # statuscodes.ErrorsToThrow, in its order (kernel.py:31-38)
+
+    def _agree_on_codes(self, counts):
+        present = self.agree_codes([1 if counts.get(code) else 0 for code in self._RAISING_CODES])
+        return [code for code, p in zip(self._RAISING_CODES, present) if p]
+
+    def execute_idle(self) -> dict:
+        """The part an EMPTY shard takes in a collective Kernel.execute: the same sequence of agreements as `execute` (one per pass over
+        the call, one on the final error codes), with nothing of its own to report."""
+        total = {"steps": 0, "attempts": 0, "kernel_ms": 0.0, "sort_ms": 0.0, "launches": 0, "first_error_iter": 0, "reran": 0,
+                 "time_error_keys": [], "state_counts": {}}
+        if not self.exact_error_stop or self.agree_min is None:
+            return total
+        cap, keys = 0, []
+        while True:
+            pass_err, pass_twk = self.agree_min(0, 0)
+            decision = self._repeat_decision(pass_err, pass_twk, cap)
+            if decision == "key":
+                keys = sorted(k for k in keys if k < pass_twk) + [pass_twk]
+                cap = 0
+            elif decision == "cap":
+                cap = pass_err
+            else:
+                break
+            total["reran"] += 1
+        total["first_error_iter"], total["time_error_keys"] = cap, keys
+        if self.agree_codes is not None:
+            total["codes_any_shard"] = self._agree_on_codes({})
         return total
 
     # ---- sampling (Field.eval / VectorField.eval) ---------------------------------------------------------------

@@ -35,8 +35,8 @@ def _take_rows(data, names, idx):
     """The to-write columns of the selected rows; when EVERY row is selected (the usual output step of a run whose particles move in
     lock-step) the columns themselves, not 1e7-row copies of them."""
     n = len(data[names[0]]) if names else 0
-    if isinstance(idx, np.ndarray) and idx.dtype != bool and len(idx) == n and (n == 0 or (idx[0] == 0 and idx[-1] == n - 1)):
-        return {k: data[k] for k in names}
+    if isinstance(idx, np.ndarray) and idx.dtype != bool and len(idx) == n and (n == 0 or (idx[0] == 0 and idx[-1] == n - 1 and np.all(idx[1:] > idx[:-1]))):
+        return {k: data[k] for k in names}  # (strictly increasing from 0 to n-1: the identity, not a permutation of it)
     return {k: data[k][idx] for k in names}
 
 
@@ -57,7 +57,8 @@ class ParticleFile:
     ParticleSet(shard=...)) every rank calls ``write`` collectively: the rows passing the write filter are gathered (RCCL
     all-gather over xGMI under backend "nccl", gloo in the CPU tests -- parcels_amd.distributed.gather_write_columns) and rank 0
     appends the one table; the file is byte-identical to the one a single process writes for the whole id space.
-    ``distributed=False`` keeps a ParticleFile rank-local."""
+    ``distributed=False`` keeps a ParticleFile rank-local; ``distributed="always"`` takes the collective path even in a group of ONE rank
+    (device write filter -> gather to rank 0 -> one table; the preflight of the multi-GPU write-out on a single GPU)."""
 
     def __init__(self, path, outputdt, compression="zstd", mode=None, distributed=None, group=None, use_dictionary=False, writer="auto",
                  encode_threads=None):
@@ -88,8 +89,17 @@ class ParticleFile:
 
         self._group = group
         self._rank, self._world = dist_rank_world(group) if distributed is not False else (0, 1)
-        if distributed and self._world == 1:
+        if distributed not in (None, True, False, "always"):
+            raise ValueError(f"distributed must be None, True, False or 'always'. Got {distributed!r}")
+        if distributed is True and self._world == 1:
             raise ValueError("ParticleFile(distributed=True) needs an initialised torch.distributed group")
+        self._collective = self._world > 1
+        if distributed == "always":
+            import torch.distributed as dist
+
+            if not (dist.is_available() and dist.is_initialized()):
+                raise ValueError("ParticleFile(distributed='always') needs an initialised torch.distributed group (one rank is enough)")
+            self._collective = True
         if self._rank == 0:  # the file belongs to rank 0; the other ranks only contribute rows
             if path.exists():
                 if mode is None:
@@ -147,7 +157,7 @@ class ParticleFile:
         if isinstance(t, (np.timedelta64, np.datetime64)):
             t = to_seconds(t - fieldset.time_interval.left)
         names = [v.name for v in _get_vars_to_write(pset._pclass)]
-        if self._world > 1:
+        if self._collective:
             import time as _time
 
             from .distributed import device_write_rows, gather_write_columns
@@ -184,7 +194,7 @@ class ParticleFile:
     def async_writer(self, pset, engine, out_cols):
         """Writer that takes the output step off the critical path of ParticleSet.execute (None for a collective multi-rank file:
         its all-gather must stay on the thread that drives the launches)."""
-        if self._world > 1:
+        if self._collective:
             return None
         return _AsyncWriter(self, pset, engine, out_cols)
 
@@ -229,8 +239,13 @@ class _AsyncWriter:
         if self.pending[slot] is not None:  # its pinned columns are about to be reused
             self.pending[slot].result()
         self.engine.snapshot_begin(self.cols, slot)
-        # host-only Variables: replaced, never mutated, by later intervals
-        host_only = {k: v for k, v in data.items() if k not in self.engine._SNAP_COLS and k not in self.engine.device_variables}
+        # host-only Variables: a device kernel list replaces them (compaction), never mutates them -- the writer thread may read the arrays
+        # themselves.  With Python kernels on the host path (hostkernels.execute_hosted: `particles.age += particles.dt` works IN PLACE on
+        # these very arrays during the next interval) the table needs its own copy, or it would pair this output time's t / x / y with
+        # later values of the Variable.
+        mutable = bool(getattr(getattr(self.pset, "_kernel", None), "host_functions", None))
+        host_only = {k: (np.array(v, copy=True) if mutable else v) for k, v in data.items()
+                     if k not in self.engine._SNAP_COLS and k not in self.engine.device_variables}
         self.pending[slot] = self.pool.submit(self._task, slot, host_only, float(t))
 
     def _task(self, slot, host_only, t):

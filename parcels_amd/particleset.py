@@ -259,7 +259,7 @@ class ParticleSet:
     def execute(self, kernels, dt, endtime=None, runtime=None, output_file=None, verbose_progress=False):
         # A multi-rank ParticleFile makes write() a collective: every rank must then make the SAME sequence of write() calls at the
         # SAME output times, whatever its own shard looks like (empty from the start, emptied by deletions, later releases).
-        collective = output_file is not None and getattr(output_file, "_world", 1) > 1
+        collective = output_file is not None and bool(getattr(output_file, "_collective", getattr(output_file, "_world", 1) > 1))
         if len(self) == 0 and not collective:
             return
         if isinstance(kernels, types.FunctionType):
@@ -321,6 +321,13 @@ class ParticleSet:
             make = getattr(output_file, "async_writer", None)
             writer = make(self, engine, out_cols) if make is not None and self.async_output else None
         synced = True
+        if collective and not kern.host_functions and hasattr(engine, "execute_idle"):
+            # One batch over all shards (DeviceEngine.execute): the ranks agree on the first erring iteration and on the first sample outside
+            # a field's time interval of every Kernel.execute, and on the error codes it ends with.  (The schedule of a collective run is
+            # lock-step -- every rank makes every interval -- which is what lets an agreement sit inside it.)
+            from .distributed import batch_agreement
+
+            engine.agree_min, engine.agree_codes = batch_agreement(output_file._group, engine.device)
         try:
             with output_file if output_file is not None else nullcontext():  # the Parquet footer is written on error too
                 try:
@@ -329,7 +336,10 @@ class ParticleSet:
                             next_time = (min if sign_dt > 0 else max)(next_output, end_time)
                         else:
                             next_time = end_time
-                        if len(self) > 0:  # (an empty shard of a collective run only keeps the write() schedule)
+                        stats = None
+                        if len(self) == 0 and getattr(engine, "agree_min", None) is not None:
+                            stats = engine.execute_idle()  # (an empty shard of a collective run keeps the schedule of agreements and of write())
+                        if len(self) > 0:
                             stats = kern.launch(self, next_time, dt, have_guess0=have_guess0)
                             have_guess0 = 1
                             synced = False
@@ -345,6 +355,19 @@ class ParticleSet:
                                 if len(self) > 0:
                                     engine.bind_particles(self._data)
                                     engine.h2d()
+                        if stats is not None and stats.get("codes_any_shard"):
+                            # a particle of ANOTHER shard ended the call in an error state: the reference raises for the batch (kernel.py:
+                            # 236-245) -- this rank had nothing to raise above, so it raises the same exception here
+                            from .statuscodes import ErrorsToThrow
+
+                            code = stats["codes_any_shard"][0]
+                            empty = np.empty(0)
+                            if not synced and len(self) > 0:
+                                engine.d2h()
+                                synced = True
+                            if code == StatusCode.ErrorOutsideTimeInterval:
+                                ErrorsToThrow[StatusCode(code)](empty)
+                            ErrorsToThrow[StatusCode(code)](empty, empty, empty)
                         if collective:  # the reference's `if len(pset) == 0: break`, decided over all shards
                             from .distributed import allreduce_scalars
 
@@ -379,6 +402,7 @@ class ParticleSet:
                     if writer is not None:
                         writer.close()
         finally:
+            engine.agree_min = engine.agree_codes = None
             if not synced and len(self) > 0:
                 engine.d2h()
             self._t_live = None

@@ -263,3 +263,113 @@ def test_execute_keeps_the_collective_write_schedule_on_every_rank(tmp_path, wor
     counts = dict(q.get(timeout=10) for _ in range(world))
     assert sum(counts.values()) == left and counts[world - 1] == 0  # the last shard lost every particle
     assert one.read_bytes() == many.read_bytes()
+
+
+# ---- the batch-wide rules of Kernel.execute across shards (DeviceEngine.execute's passes, parcels_amd.distributed.batch_agreement) ----
+class _ScriptedLib:
+    """What DeviceEngine.execute calls of the library, answering from a script: one (first_error_iter, first_time_error_key) per pass."""
+
+    def __init__(self, script):
+        self.script, self.passes = list(script), []
+
+    def _fill(self, st_ref, cap, keys):
+        err, key = self.script[len(self.passes)]
+        self.passes.append((int(cap), [int(k) for k in keys]))
+        st = st_ref._obj
+        st.first_error_iter, st.first_time_error_key, st.paused, st.launches = err, key, 0, 1
+        st.steps = 100
+        if err and (cap == 0 or err <= cap):
+            st.state_counts[70] = 3  # (somebody ends the pass in an error state)
+        return 0
+
+    def pk_execute_begin(self, h, prm_ref):
+        p = prm_ref._obj
+        self._next = (p.max_iters, [p.twe_key[k] for k in range(p.twe_n)])
+        return 0
+
+    def pk_execute_end(self, h, st_ref):
+        return self._fill(st_ref, *self._next)
+
+    def pk_execute_rerun_keys(self, h, cap, n, keys, st_ref):
+        return self._fill(st_ref, cap, [keys[k] for k in range(n)])
+
+
+def _scripted_engine(script):
+    import types
+
+    from parcels_amd import _hip
+    from parcels_amd.engine import DeviceEngine
+
+    eng = object.__new__(DeviceEngine)
+    eng.lib = _ScriptedLib(script)
+    eng.ctx = types.SimpleNamespace(check=lambda rc, what=None: None, handle=None)
+    eng.windowed, eng.exact_error_stop, eng.agree_min, eng.agree_codes, eng.device = False, True, None, None, None
+
+    def make_params(kernel_ids, *, max_iters=0, twe_keys=(), **kw):
+        p = _hip.ExecParams()
+        p.max_iters, p.twe_n = int(max_iters), len(twe_keys)
+        for k, key in enumerate(twe_keys):
+            p.twe_key[k] = int(key)
+        return p
+
+    eng.make_params = make_params
+    return eng
+
+
+def test_execute_passes_follow_the_reference_batch_rules():
+    """DeviceEngine.execute's second look at a call: a sample outside the time interval in iteration 5 is listed and the call repeated
+    BEFORE the error stop of the same iteration is applied (kernel.py:236-245 acts on what the iteration left behind); an error stop in an
+    earlier iteration wins, and the time error behind it never happens."""
+    k5 = (5 << 32) | 2003
+    eng = _scripted_engine([(5, k5), (5, 0), (5, 0)])
+    st = eng.execute([4], endtime=10.0, dt0=1.0)
+    assert eng.lib.passes == [(0, []), (0, [k5]), (5, [k5])]
+    assert st["reran"] == 2 and st["first_error_iter"] == 5 and st["time_error_keys"] == [k5]
+    eng = _scripted_engine([(3, (7 << 32) | 1), (3, 0)])
+    st = eng.execute([4], endtime=10.0, dt0=1.0)
+    assert eng.lib.passes == [(0, []), (3, [])] and st["time_error_keys"] == [] and st["first_error_iter"] == 3
+    # a later pass finds an EARLIER sample: the later key was found on a trajectory that no longer exists and is dropped
+    a, b = (9 << 32) | 1, (4 << 32) | 2
+    eng = _scripted_engine([(0, a), (0, b), (0, 0)])
+    st = eng.execute([4], endtime=10.0, dt0=1.0)
+    assert eng.lib.passes == [(0, []), (0, [a]), (0, [b])] and st["time_error_keys"] == [b]
+
+
+def _agree_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from parcels_amd.distributed import batch_agreement
+
+        k5 = (5 << 32) | 2003
+        # rank 0 holds the particle that leaves the time interval (iteration 5) and errs; rank 1 steps happily; rank 2 (if any) is empty
+        script = {0: [(5, k5), (5, 0), (5, 0)], 1: [(0, 0), (0, 0), (0, 0)]}.get(rank)
+        eng = _scripted_engine(script or [])
+        eng.agree_min, eng.agree_codes = batch_agreement()
+        st = eng.execute([4], endtime=10.0, dt0=1.0) if script else eng.execute_idle()
+        q.put((rank, eng.lib.passes, st["first_error_iter"], st["time_error_keys"], st["codes_any_shard"], st["reran"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_shards_are_one_batch_for_the_error_stop_and_the_time_error(world):
+    """world 2 / 3 over gloo: the shard WITHOUT the offending particle repeats its call with the same listed sample and the same iteration
+    limit as the shard with it, an empty shard keeps the schedule of agreements, and every rank learns the error code to raise."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_agree_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0, "a rank hung or failed"
+    res = {r[0]: r[1:] for r in (q.get(timeout=10) for _ in range(world))}
+    k5 = (5 << 32) | 2003
+    for rank in range(world):
+        passes, cap, keys, codes, reran = res[rank]
+        assert cap == 5 and keys == [k5] and codes == [70] and reran == 2, (rank, res[rank])
+        if rank < 2:
+            assert passes == [(0, []), (0, [k5]), (5, [k5])], (rank, passes)

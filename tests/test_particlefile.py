@@ -113,3 +113,64 @@ def test_async_write_out_equals_the_inline_path(gpu, tmp_path, sort):
         assert np.array_equal(files["async"][2][k], v), k
     df = pa.read_particlefile(tmp_path / f"async_{sort}.parquet")
     assert "tag" in df.columns and len(df["t"].unique()) >= 16
+
+
+def test_take_rows_shortcut_only_for_the_identity_selection():
+    """particlefile.py:142-180 indexes particle_data[v][indices]: an index array that merely LOOKS like `all rows` (same length, starts
+    at 0, ends at n - 1) but permutes them must permute the columns."""
+    from parcels_amd.particlefile import _take_rows
+
+    data = {"a": np.arange(4.0), "b": np.arange(4) * 10}
+    same = _take_rows(data, ["a", "b"], np.arange(4))
+    assert same["a"] is data["a"] and same["b"] is data["b"]  # the columns themselves, no copy
+    perm = _take_rows(data, ["a", "b"], np.array([0, 2, 1, 3]))
+    assert perm["a"].tolist() == [0.0, 2.0, 1.0, 3.0] and perm["b"].tolist() == [0, 20, 10, 30]
+
+
+def test_async_writer_copies_host_only_variables_of_hosted_kernel_lists():
+    """A Python kernel on the host path updates user Variables IN PLACE during the next interval (hostkernels.execute_hosted), while
+    the writer thread still encodes the previous output time: its table must hold that output time's values."""
+    import threading
+
+    from parcels_amd.particlefile import _AsyncWriter
+
+    gate = threading.Event()
+    written = []
+
+    class Engine:
+        _SNAP_COLS = ("t", "x")
+        device_variables = []
+
+        def snapshot_begin(self, cols, slot):
+            pass
+
+        def snapshot_wait(self, slot):
+            gate.wait(5)  # the encode of this table starts only after the caller has gone on
+            return {"t": np.zeros(3), "x": np.zeros(3)}
+
+    class File:
+        def write(self, view, t):
+            written.append((t, view._data["age"].copy()))
+
+    class Kern:
+        host_functions = ["Age"]
+
+    class PSet:
+        _pclass, fieldset, _kernel = None, None, Kern()
+
+    w = _AsyncWriter(File(), PSet(), Engine(), ["t", "x", "age"])
+    age = np.array([1.0, 2.0, 3.0])
+    w.submit({"t": np.zeros(3), "x": np.zeros(3), "age": age}, 10.0)
+    age += 100.0  # the next interval's Python kernel, in place
+    gate.set()
+    w.close()
+    assert written and written[0][0] == 10.0 and written[0][1].tolist() == [1.0, 2.0, 3.0]
+    # a device kernel list never mutates host-only columns: no copy is made for it
+    Kern.host_functions = []
+    gate.clear()
+    w2 = _AsyncWriter(File(), PSet(), Engine(), ["t", "x", "age"])
+    age2 = np.array([5.0, 6.0, 7.0])
+    w2.submit({"t": np.zeros(3), "x": np.zeros(3), "age": age2}, 20.0)
+    gate.set()
+    w2.close()
+    assert written[-1][1].tolist() == [5.0, 6.0, 7.0]
