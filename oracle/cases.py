@@ -812,6 +812,18 @@ def all_cases() -> dict:
     pc["t0"] = np.round(_rng(74).uniform(0, 6, len(pc["x"]))) * 1800.0
     add(pc)
 
+    # --- 2-D kernels on float32 COORDINATES with float32 particles: `particles.z` is handed to every stage unchanged, so on a float32 depth
+    #     axis zeta stays a float32 array in ALL stages (index_search.py:51) while the stage positions y1, x1 are float64 -- found by seed 7163
+    #     of tools/fuzz_oracle_vs_reference.py (a float32 ulp in stage 2 that a shear flow grew to 1 m), float64 and float32 field data ------
+    add(rect_agrid_case("agrid_flat_rk2_f32coords_f32part", mesh="flat", kernels=["AdvectionRK2", "DeleteParticle"], seed=111, coord_dtype=np.float32,
+                        spatial_dtype="float32", stagger=True, vel=2.0, runtime=28 * 3600.0))
+    add(rect_agrid_case("agrid_sph_rk4_f32coords_f32part", mesh="spherical", kernels=["AdvectionRK4"], seed=112, coord_dtype=np.float32,
+                        spatial_dtype="float32", field_dtype=np.float32))
+    rc = rect_agrid_case("agrid_flat_rk45_f32coords_f32part", mesh="flat", kernels=["AdvectionRK45"], seed=113, coord_dtype=np.float32,
+                         spatial_dtype="float32", runtime=12 * 3600.0)
+    rc["context"] = {"RK45_tol": 0.5, "RK45_min_dt": 10.0, "RK45_max_dt": 7200.0}
+    add(rc)
+
     # --- the call-wide OutsideTimeInterval (index_search.py:85-86 raises for the whole call; field.py:31-44 writes code 70 into EVERY
     #     particle of the view and returns 0): releases staggered by half a step and a run that ends past the last time level, so that in
     #     the iteration in which the first particle leaves the time interval the others are still inside it.  With a recovery kernel

@@ -218,6 +218,7 @@ __global__ void __launch_bounds__(256) eval_kernel(const KArgs a, int what, int6
     c.it = 0u;  // not inside the loop of kernel.py:190: the caller of pk_eval owns the batch (parcels_amd/field.py: _eval_key)
     c.klo = 0;
     const bool pos_f32 = a.prm.reset_state != 0;  // (pk_eval's own use of the field: option "eval_points_f32")
+    c.zpos_f32 = pos_f32;
     if (what < 0) {
         double u, v, w;
         eval_uvw<FT, -1, INTERP, TYPED>(a, mc, c, what == -2, t[i], z[i], y[i], x[i], pos_f32, u, v, w);
@@ -257,6 +258,7 @@ __global__ void __launch_bounds__(256) search_kernel(const DGrid g, int64_t m, c
     c.pf = false;
     c.hz = c.hy = c.hx = c.ht = 0;
     c.hyx_valid = false;
+    c.zpos_f32 = false;
     GPos p;
     int32_t ei = 0;
     grid_search<-1, false>(g, nullptr, z[i], y[i], x[i], false, &ei, c, false, p);  // indices only: dtype emulation of the bcoords is irrelevant

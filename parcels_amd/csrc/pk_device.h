@@ -864,6 +864,9 @@ struct PCtx {
     bool u32, v32;  // the u / v ARRAYS of the last eval_uvw are float32 in the reference (AdvectionRK45's stage-1 products)
     bool oob;       // some sample of this context was masked to 0 by _mask_outofbounds_values (field.py:359-370); read by pk_eval only
     int64_t row;    // device row of the particle (kernels that write user Variables)
+    bool zpos_f32;  // the z of the NEXT sample is a float32 particle column (set by the caller next to the sample's pos_f32, which speaks for
+                    // y and x): the 2-D kernels hand `particles.z` to every stage unchanged -- on a float32 depth axis its zeta stays a
+                    // float32 array (index_search.py:51) while the stage positions y1, x1 are float64
     unsigned it;    // 1-based iteration of the loop of kernel.py:190 the particle is in (0: outside it) ...
     int klo;        // ... and kernel slot * 1000 + samples taken so far in this iteration's call(s) of that kernel: the key of the next sample (twe_listed)
 };
@@ -930,10 +933,11 @@ PK_DEV void grid_search(const DGrid& g, const Coords* mc, double z, double y, do
     const double* lon = mc ? mc->lon : g.lon;
     const bool hint = mc != nullptr;
     const bool zf32 = TYPED && g.depth_f32, yf32 = TYPED && g.lat_f32, xf32 = TYPED && g.lon_f32;
-    if (g.has_z) search_1d(depth, g.nz, mc ? mc->z0 : g.depth[0], mc ? mc->z1 : g.depth[g.nz - 1], z, zf32, pos_f32, hint ? c.hz : 0, p.zi, p.zeta);
+    const bool zpos_f32 = TYPED && c.zpos_f32;
+    if (g.has_z) search_1d(depth, g.nz, mc ? mc->z0 : g.depth[0], mc ? mc->z1 : g.depth[g.nz - 1], z, zf32, zpos_f32, hint ? c.hz : 0, p.zi, p.zeta);
     else { p.zi = 0; p.zeta = 0.0; }
     p.w32 = curv && !use_guess;
-    p.z32 = g.has_z && zf32 && pos_f32 && g.nz >= 2;
+    p.z32 = g.has_z && zf32 && zpos_f32 && g.nz >= 2;
     p.x32 = curv ? p.w32 : (g.has_x && xf32 && pos_f32 && g.nx >= 2);
     p.e32 = curv ? p.w32 : (g.has_y && yf32 && pos_f32 && g.ny >= 2);
     if (curv) {

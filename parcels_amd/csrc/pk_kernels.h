@@ -43,7 +43,8 @@ enum { RQ_UV = 0, RQ_UVW = 1, RQ_SCALAR = 2 };
 struct Request {
     int kind, fidx;
     double t, z, y, x;
-    bool f32;    // sample point comes straight from float32 particle storage
+    bool f32;    // sample point (y, x) comes straight from float32 particle storage
+    bool zf32;   // its z does: every sample at `particles.z` (all stages of the 2-D kernels), whatever y and x are (PCtx::zpos_f32)
     bool reuse;  // scalar sample at the point of this kernel's velocity sample: the grid position may be re-used (SearchMemo)
 };
 
@@ -94,6 +95,7 @@ PK_DEV bool prepare(const KArgs& a, int kid, int stage, int kslot, PCtx& c, PSta
     rq.kind = RQ_UV;
     rq.fidx = 0;
     rq.f32 = false;
+    rq.zf32 = pf;  // (rq.z = p.z below: a kernel that samples at another depth says so)
     rq.reuse = false;
     rq.t = p.t; rq.z = p.z; rq.y = p.y; rq.x = p.x;
     switch (kid) {
@@ -111,7 +113,7 @@ PK_DEV bool prepare(const KArgs& a, int kid, int stage, int kslot, PCtx& c, PSta
             const double cdt = stage == 3 ? 1.0 : 0.5;  // u*1.0 == u and 1.0*dt == dt exactly
             rq.x = p.x + L.r[3] * cdt * p.dt;
             rq.y = p.y + L.r[4] * cdt * p.dt;
-            if (d3) rq.z = p.z + L.r[5] * cdt * p.dt;
+            if (d3) { rq.z = p.z + L.r[5] * cdt * p.dt; rq.zf32 = false; }
             rq.t = p.t + cdt * p.dt;
             return false;
         }
@@ -128,7 +130,7 @@ PK_DEV bool prepare(const KArgs& a, int kid, int stage, int kslot, PCtx& c, PSta
             }
             rq.x = p.x + L.r[3] * 0.5 * p.dt;
             rq.y = p.y + L.r[4] * 0.5 * p.dt;
-            if (d3) rq.z = p.z + L.r[5] * 0.5 * p.dt;
+            if (d3) { rq.z = p.z + L.r[5] * 0.5 * p.dt; rq.zf32 = false; }
             rq.t = p.t + 0.5 * p.dt;
             return false;
         }
@@ -531,6 +533,7 @@ __global__ void __launch_bounds__(wg_size(KIND, LDS), (KIND == 1 || INTERP != 0)
                         attempts++;
                         for (int stage = 0; !prepare(a, kid, stage, k, c, p, L, rq); stage++) {
                             double u, v = 0.0, w = 0.0;
+                            c.zpos_f32 = rq.zf32;
                             if (rq.kind == RQ_SCALAR) {
                                 u = eval_scalar<FT, TYPED>(a, mc, c, rq.fidx, rq.t, rq.z, rq.y, rq.x, rq.f32, (MEMO && rq.reuse) ? &memo : nullptr);
                             } else {
@@ -631,6 +634,7 @@ PK_DEV void side_kernel(const KArgs& a, int kid, int kslot, int& state, bool pf,
     c.ei0 = c.ei1 = c.ei2 = c.ei3 = 0;
     c.it = 0u;
     c.klo = 0;
+    c.zpos_f32 = false;
     KLocal L;
     Request rq;
     (void)user_prepare(a, kid - PK_KERNEL_USER0, 0, kslot, c, p, L, rq);
@@ -668,6 +672,7 @@ PK_DEV void side_kernel_fast(const KArgs& a, const FastTabs& ft, FCtx& fc, int k
     c.ei0 = c.ei1 = c.ei2 = c.ei3 = 0;
     c.it = it;
     c.klo = kslot * 1000;
+    c.zpos_f32 = false;
     KLocal L;
     Request rq;
 #pragma unroll 1

@@ -260,6 +260,16 @@ def compare(got, ref, *, rtol, atol_pos=0.0, check_state="all", err_mask=None, s
 UNGUESSED_CURVILINEAR_RTOL = 1e-7
 
 
+def count_outside(got, ref, rtol, scale=0.0):
+    """Particles (rows present in both, same order) with a position component further than rtol * (|ref| + scale) from the reference."""
+    bad = np.zeros(len(ref["x"]), bool)
+    for k in ("x", "y", "z"):
+        a, b = np.asarray(got[k], np.float64), np.asarray(ref[k], np.float64)
+        with np.errstate(invalid="ignore"):
+            bad |= np.abs(a - b) > rtol * (np.abs(b) + scale)
+    return int(bad.sum())
+
+
 def tolerance_for(name, case):
     if case.get("spatial_dtype", "float64") == "float32":
         # one float32 ulp of the stored position: the float32 cos() of the first stage (device cosf vs NumPy's) may differ by an
