@@ -245,6 +245,22 @@ PK_DEV bool cg_point_in_cell(const FastC& F, const double* rec, int cell, double
 template <class FT>
 PK_DEV double cg_scalar_xlinear(const FastC& F, int k, int ti, double tau, int zi, double zeta, int yi, int xi, double xsi, double eta) {
     const bool lenT = tau > 0, lenZ = !(zeta <= 0);
+    if (F.kh_nt[k] == 1 && F.kh_nz[k] == 1) {
+        // a field without time and depth axes (the 2-D Kh fields of BASELINE config 5): both "depth levels" are the same two rows -- the
+        // same operations on the same values as below (c * (1 - zeta) + c * zeta is still formed), without the level / plane addressing
+        // and with two row loads instead of four: M1 43.3 -> 38.9 ms on config 5 (profiles/r04_m_kh2d_rk45g_c3g_ab.txt)
+        const char* d0 = F.kh[k];
+        const int64_t oy0 = (int64_t)yi * F.kh_sy[k], oy1 = (int64_t)mini(yi + 1, F.kh_ny[k] - 1) * F.kh_sy[k];
+        const int64_t ox = (int64_t)xi * (int64_t)sizeof(FT);
+        double c00, c01, c10, c11;
+        ldpair(reinterpret_cast<const FT*>(d0 + oy0 + ox), c00, c01);
+        ldpair(reinterpret_cast<const FT*>(d0 + oy1 + ox), c10, c11);
+        if (lenZ) {
+            c00 = c00 * (1 - zeta) + c00 * zeta; c01 = c01 * (1 - zeta) + c01 * zeta;
+            c10 = c10 * (1 - zeta) + c10 * zeta; c11 = c11 * (1 - zeta) + c11 * zeta;
+        }
+        return (1 - xsi) * (1 - eta) * c00 + xsi * (1 - eta) * c01 + (1 - xsi) * eta * c10 + xsi * eta * c11;
+    }
     const int nt = F.kh_nt[k], ns = F.kh_nslots[k];
     int s0 = ti, s1 = mini(ti + 1, nt - 1);
     if (ns < nt) { s0 = (int)((uint32_t)s0 % (uint32_t)ns); s1 = (int)((uint32_t)s1 % (uint32_t)ns); }

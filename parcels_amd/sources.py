@@ -96,16 +96,35 @@ class NpyLevels(LevelSource):
         return np.load(self.paths[k], mmap_mode="r").reshape(self.shape[1:])
 
 
+def _choose_float_dtype(dtype: np.dtype, sf, ao) -> np.dtype:
+    """The float dtype xarray's CF decoding gives a variable (xarray/coding/variables.py: _choose_float_dtype) -- the reference's fields
+    are whatever `xr.open_dataset` decodes: the type of scale_factor / add_offset when both are given as the same float type (float64 for
+    int32 data: 24 bits of mantissa do not hold it); float64 as soon as an offset comes without such a partner; the scale factor's type
+    alone; without packing attributes float32 for float16 / float32 and for integers of at most 2 bytes, float64 for everything else."""
+    f32, f64 = np.dtype(np.float32), np.dtype(np.float64)
+    if sf is not None or ao is not None:
+        st = np.asarray(sf).dtype if sf is not None else None
+        ot = np.asarray(ao).dtype if ao is not None else None
+        if sf is not None and ao is not None and st == ot and st in (f32, f64):
+            return f64 if (dtype.kind in "iu" and dtype.itemsize == 4) else st
+        if ao is not None:
+            return f64
+        return st if st in (f32, f64) else f64
+    if dtype.kind == "f" and dtype.itemsize <= 4:
+        return f32
+    if dtype.kind in "iu" and dtype.itemsize <= 2:
+        return f32
+    return f64
+
+
 def cf_unpack(a: np.ndarray, attrs: dict, fill_dtype=None) -> np.ndarray:
-    """CF conventions: _FillValue / missing_value -> NaN, then packed * scale_factor + add_offset in the dtype of those attributes
-    (what xarray's decode_cf does for the reference, convert.py:308-408 via xr.open_dataset).  Integer data without packing
-    attributes becomes float64."""
+    """CF conventions: _FillValue / missing_value -> NaN, then packed * scale_factor + add_offset, in the float dtype xarray's decode_cf
+    chooses (what the reference gets, convert.py:308-408 via xr.open_dataset; _choose_float_dtype above)."""
     sf, ao = attrs.get("scale_factor"), attrs.get("add_offset")
     fv = [np.asarray(attrs[k]).ravel() for k in ("_FillValue", "missing_value") if k in attrs]
     if a.dtype.kind == "f" and sf is None and ao is None and not fv:
         return a
-    out_dt = np.result_type(*[np.asarray(v).dtype for v in (sf, ao) if v is not None], np.float32) if (sf is not None or ao is not None) else (
-        a.dtype if a.dtype.kind == "f" else np.dtype(np.float64))
+    out_dt = _choose_float_dtype(a.dtype, sf, ao)
     if a.dtype.kind == "f" and a.dtype.itemsize > np.dtype(out_dt).itemsize:
         out_dt = a.dtype
     mask = None

@@ -319,3 +319,26 @@ def test_zarr_levels_unpack_cf_packed_integers(tmp_path):
     lv = src.read_level(1)
     assert np.isnan(lv[:, 4:, :]).all() and np.allclose(lv[:, :4, :], raw[1, :, :4, :].astype(np.float32) * np.float32(0.001) + np.float32(2.0), rtol=1e-6)
     assert np.all(src.level(1)[:, 4:, :] == 0.0)
+
+
+def test_cf_unpack_chooses_the_float_dtype_xarray_chooses():
+    """xarray/coding/variables.py::_choose_float_dtype decides the dtype of a decoded field in the reference (xr.open_dataset): the
+    device field precision must be the same."""
+    from parcels_amd.sources import cf_unpack
+
+    f32, f64 = np.float32, np.float64
+    i16, i32, i8 = np.arange(4, dtype=np.int16), np.arange(4, dtype=np.int32), np.arange(4, dtype=np.int8)
+    # both attributes, same float type: that type -- except for int32 data (24 bits of mantissa do not hold it)
+    assert cf_unpack(i16, {"scale_factor": f32(0.5), "add_offset": f32(1.0)}).dtype == f32
+    assert cf_unpack(i32, {"scale_factor": f32(0.5), "add_offset": f32(1.0)}).dtype == f64
+    assert cf_unpack(i16, {"scale_factor": f64(0.5), "add_offset": f64(1.0)}).dtype == f64
+    # an offset without a partner of its type: float64; a scale factor alone: its type
+    assert cf_unpack(i16, {"add_offset": f32(1.0)}).dtype == f64
+    assert cf_unpack(i16, {"scale_factor": f32(0.5), "add_offset": f64(1.0)}).dtype == f64
+    assert cf_unpack(i16, {"scale_factor": f32(0.5)}).dtype == f32
+    # no packing attributes, only a fill value: float32 for integers of at most 2 bytes, float64 beyond
+    assert cf_unpack(i8, {"_FillValue": np.int8(3)}).dtype == f32
+    assert cf_unpack(i16, {"_FillValue": np.int16(3)}).dtype == f32
+    assert cf_unpack(i32, {"_FillValue": np.int32(3)}).dtype == f64
+    out = cf_unpack(i16, {"scale_factor": f32(0.5), "add_offset": f32(1.0), "_FillValue": np.int16(2)})
+    assert np.isnan(out[2]) and out[3] == f32(2.5) and out[0] == f32(1.0)
