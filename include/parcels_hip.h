@@ -31,7 +31,7 @@ extern "C" {
 #define PK_MAX_KERNELS 8
 #define PK_MAX_EXTRA 8 /* user Variables that device kernels write (PK_KERNEL_SAMPLE_FIELD, compiled user kernels) */
 #define PK_NUM_STATE_CODES 80
-#define PK_MAX_TWE 64 /* samples of one Kernel.execute call that fail call-wide with OutsideTimeInterval (pk_exec_params.twe_key) */
+#define PK_MAX_TWE 1024 /* samples of one Kernel.execute call that fail call-wide with OutsideTimeInterval (pk_exec_params.twe_key) */
 
 typedef struct pk_ctx pk_ctx;
 
@@ -334,7 +334,7 @@ typedef struct pk_exec_params {
                             kernels (parcels_amd/hostkernels.py: the loop on the host columns, the built-in kernels' bodies here).   */
     int32_t twe_n;     /* number of entries of twe_key (0: none known)                                                                */
     int32_t reserved1;
-    int64_t twe_key[PK_MAX_TWE]; /* The call-wide OutsideTimeInterval (index_search.py:85-86, field.py:31-44,187-195,297-304): in the
+    const int64_t* twe_key; /* twe_n <= PK_MAX_TWE keys in ASCENDING order (host memory, read by pk_execute_begin).  The call-wide OutsideTimeInterval (index_search.py:85-86, field.py:31-44,187-195,297-304): in the
                             reference a field sample fails as a WHOLE when any particle of the view it was called with lies outside the
                             field's time interval -- Field.__getitem__ then writes ErrorOutsideTimeInterval into the state of EVERY
                             particle of that view and returns 0 for all of them; no `ei`, no other state of that call is written.  A

@@ -15,7 +15,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
-PO_MAX_TWE = 64  # po_params.twe_key (parcels_oracle.c)
+PO_MAX_TWE = 1024  # po_params.twe_key (parcels_oracle.c)
 
 KERNEL_IDS = {
     "AdvectionEE": 1,

@@ -17,7 +17,7 @@ PK_ABI_VERSION = 7
 PK_F32, PK_F64 = 0, 1
 PK_MAX_GRIDS, PK_MAX_FIELDS, PK_MAX_KERNELS, PK_NUM_STATE_CODES = 4, 64, 8, 80
 PK_MAX_EXTRA = 8
-PK_MAX_TWE = 64
+PK_MAX_TWE = 1024
 PK_KERNEL_SAMPLE_FIELD = 10
 PK_EVAL_MASKED = 0x10000  # pk_eval: or'ed into out_state where the value was zeroed for an out-of-bounds index
 PK_COL_EXTRA0 = 0x1000
@@ -157,7 +157,7 @@ class ExecParams(C.Structure):
         ("body_only", C.c_int32),
         ("twe_n", C.c_int32),
         ("reserved1", C.c_int32),
-        ("twe_key", C.c_int64 * PK_MAX_TWE),
+        ("twe_key", C.POINTER(C.c_int64)),
     ]
 
 

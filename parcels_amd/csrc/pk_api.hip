@@ -108,6 +108,8 @@ struct pk_ctx {
     int64_t fl_n = 0;
     DCounters* h_counters = nullptr;          // pinned: the async D2H of the counters must not block the host
     DCounters h_counters0;                    // initial values of a launch's counters (pageable: the H2D copy stages it at once)
+    unsigned long long* d_twe = nullptr;      // PK_MAX_TWE keys: the failing samples a launch knows (pk_exec_params.twe_key)
+    std::vector<int64_t> rerun_keys;          // the keys of the last launch (pk_execute_rerun repeats it with them)
     unsigned long long* h_summary = nullptr;  // pinned
     int sort_horizontal_major = -1;  // tuning knobs (environment: PK_SORT_HORIZONTAL = 0/1 forces, PK_NO_SPECIAL, PK_NO_CELL_CACHE)
     int no_special = 0;
@@ -544,6 +546,7 @@ int32_t pk_init(int32_t device, pk_ctx** out) {
     PK_HIP(ctx, hipEventCreate(&ctx->ev2));
     for (int k = 0; k < PK_STAGE_BUFFERS; k++) PK_HIP(ctx, hipEventCreateWithFlags(&ctx->stage_ev[k], hipEventDisableTiming));
     PK_HIP(ctx, hipMalloc((void**)&ctx->d_counters, sizeof(DCounters)));
+    PK_HIP(ctx, hipMalloc((void**)&ctx->d_twe, sizeof(unsigned long long) * PK_MAX_TWE));
     PK_HIP(ctx, hipMalloc((void**)&ctx->d_summary, sizeof(unsigned long long) * (PK_NUM_STATE_CODES + 2)));
     PK_HIP(ctx, hipHostMalloc((void**)&ctx->h_counters, sizeof(DCounters), hipHostMallocDefault));
     PK_HIP(ctx, hipHostMalloc((void**)&ctx->h_summary, sizeof(unsigned long long) * (PK_NUM_STATE_CODES + 2), hipHostMallocDefault));
@@ -637,6 +640,7 @@ int32_t pk_destroy(pk_ctx* ctx) {
     if (ctx->d_cg_tab) (void)hipFree(ctx->d_cg_tab);
     if (ctx->d_ct2) (void)hipFree(ctx->d_ct2);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    if (ctx->d_twe) (void)hipFree(ctx->d_twe);
     if (ctx->d_desc) (void)hipFree(ctx->d_desc);
     if (ctx->h_desc) (void)hipHostFree(ctx->h_desc);
     if (ctx->d_summary) (void)hipFree(ctx->d_summary);
@@ -1564,6 +1568,7 @@ static int32_t fill_args(pk_ctx* ctx, const pk_exec_params* prm, KArgs& a, size_
     a.p = ctx->dev;
     a.prm = *prm;
     a.counters = ctx->d_counters;
+    a.twe_listed = ctx->d_twe;
     const int nf = (int)ctx->fields.size();
     auto valid = [&](int f) { return f >= 0 && f < nf; };
     if (!valid(prm->fU) || !valid(prm->fV)) return ctx->fail("params.fU/fV must name existing fields");
@@ -1992,11 +1997,15 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
         if (f >= 0 && ctx->fields[f].d.dtype != U.d.dtype) return ctx->fail("U, V, W must share one dtype");
     const int curv = ctx->grids[a.main_grid].d.kind == 1;
     const int64_t n = ctx->dev.n;
-    if (prm->twe_n < 0 || prm->twe_n > PK_MAX_TWE) return ctx->fail("params.twe_n out of range");
+    if (prm->twe_n < 0 || prm->twe_n > PK_MAX_TWE || (prm->twe_n > 0 && !prm->twe_key)) return ctx->fail("params.twe_n / twe_key out of range");
+    for (int k = 1; k < prm->twe_n; k++)
+        if (!(prm->twe_key[k - 1] < prm->twe_key[k])) return ctx->fail("params.twe_key must be ascending");
     DCounters& counters0 = ctx->h_counters0;
-    counters0 = DCounters{0ull, 0ull, 0ull, 0xFFFFFFFFu, 0u, ~0ull, {}};
-    for (int k = 0; k < prm->twe_n; k++) counters0.twe_listed[k] = (unsigned long long)prm->twe_key[k];
+    counters0 = DCounters{0ull, 0ull, 0ull, 0xFFFFFFFFu, 0u, ~0ull};
     PK_HIP(ctx, hipMemcpyAsync(ctx->d_counters, &counters0, sizeof(DCounters), hipMemcpyHostToDevice, ctx->compute));
+    if (prm->twe_key != ctx->rerun_keys.data()) ctx->rerun_keys.assign(prm->twe_key, prm->twe_key + prm->twe_n);  // (kept for pk_execute_rerun)
+    if (prm->twe_n > 0)
+        PK_HIP(ctx, hipMemcpyAsync(ctx->d_twe, ctx->rerun_keys.data(), sizeof(int64_t) * prm->twe_n, hipMemcpyHostToDevice, ctx->compute));
     PK_HIP(ctx, hipMemsetAsync(ctx->d_summary, 0, sizeof(unsigned long long) * PK_NUM_STATE_CODES, ctx->compute));
     const unsigned long long init_mm[2] = {~0ull, 0ull};
     PK_HIP(ctx, hipMemcpyAsync(ctx->d_summary + PK_NUM_STATE_CODES, init_mm, sizeof(init_mm), hipMemcpyHostToDevice, ctx->compute));
@@ -2112,6 +2121,7 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
         swap_launch_outputs(ctx);
         ctx->rerun_valid = true;
         ctx->rerun_prm = *prm;
+        ctx->rerun_prm.twe_key = nullptr;  // (the caller's array may be gone: the keys live in ctx->rerun_keys)
         const unsigned sgrid = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
         hipLaunchKernelGGL(summarize_kernel, dim3(sgrid), dim3(256), 0, ctx->compute, ctx->dev.state, ctx->dev.t, n, ctx->d_summary);
         PK_HIP(ctx, hipGetLastError());
@@ -2212,6 +2222,7 @@ int32_t pk_execute_rerun(pk_ctx* ctx, int32_t max_iters, pk_exec_stats* stats) {
     pk_exec_params prm = ctx->rerun_prm;
     prm.sort_by_cell = 0;
     prm.max_iters = max_iters;
+    prm.twe_key = ctx->rerun_keys.data();  // (twe_n is the launch's)
     int32_t rc = pk_execute_begin(ctx, &prm);
     if (rc) return rc;
     return pk_execute_end(ctx, stats);
@@ -2228,7 +2239,7 @@ int32_t pk_execute_rerun_keys(pk_ctx* ctx, int32_t max_iters, int32_t n_keys, co
     prm.sort_by_cell = 0;
     prm.max_iters = max_iters;
     prm.twe_n = n_keys;
-    for (int k = 0; k < PK_MAX_TWE; k++) prm.twe_key[k] = k < n_keys ? keys[k] : 0;
+    prm.twe_key = keys;
     int32_t rc = pk_execute_begin(ctx, &prm);
     if (rc) return rc;
     return pk_execute_end(ctx, stats);

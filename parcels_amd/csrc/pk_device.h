@@ -95,8 +95,6 @@ struct DCounters {
     unsigned long long steps, attempts, paused;
     unsigned int err_iter, pad;  // smallest iteration index (1-based) in which a particle entered an error state; 0xFFFFFFFF = none
     unsigned long long twe_key;  // smallest key of a sample (pk_exec_params.twe_key) at which a particle left a time interval; ~0 = none
-    unsigned long long twe_listed[PK_MAX_TWE];  // the launch's copy of pk_exec_params.twe_key: read from memory on the (cold) path that
-                                                // needs it -- as kernel arguments the 32 SGPRs of the list were hoisted into every kernel
 };
 
 // Wave-uniform constants of the fast path for XLinear_Velocity on a rectilinear A-grid with float64 coordinates
@@ -160,6 +158,7 @@ struct KArgs {
     pk_exec_params prm;
     double win_lo, win_hi;  // resident time window of the time-varying fields (seconds)
     DCounters* counters;
+    const unsigned long long* twe_listed;  // the launch's copy of pk_exec_params.twe_key (ascending; device memory, read on the cold path only)
     // LDS layout of the main grid's 1-D arrays (element offsets into the dynamic shared array, -1 = global)
     int32_t lds_time, lds_depth, lds_lat, lds_lon, lds_total;
     int32_t lds_cc_nodes, lds_cc_keys, lds_cc_fvals;  // cell cache (CellCache) offsets in doubles from the LDS base, -1 = off
@@ -187,10 +186,13 @@ PK_DEV bool twe_listed(const KArgs& a, unsigned it, int klo) {
     const int n = a.prm.twe_n;  // wave-uniform: one scalar compare per sample when nothing is listed
     if (__builtin_expect(n == 0, 1)) return false;
     const unsigned long long key = twe_sample_key(it, klo);
-    const volatile unsigned long long* lst = a.counters->twe_listed;
-    bool hit = false;
-    for (int k = 0; k < n; k++) hit = hit || (lst[k] == key);
-    return hit && it != 0;
+    const unsigned long long* lst = a.twe_listed;  // ascending: bisection
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (lst[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return it != 0 && lo < n && lst[lo] == key;
 }
 PK_DEV void twe_note(const KArgs& a, unsigned it, int klo) {
     if (it != 0) atomicMin(&a.counters->twe_key, twe_sample_key(it, klo));

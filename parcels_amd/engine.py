@@ -519,8 +519,9 @@ class DeviceEngine:
         p.horizon_lo, p.horizon_hi = (-np.inf, np.inf) if horizon is None else (float(horizon[0]), float(horizon[1]))
         p.max_iters = int(max_iters)
         p.twe_n = len(twe_keys)
-        for k, key in enumerate(twe_keys):
-            p.twe_key[k] = int(key)
+        if twe_keys:  # ascending, alive as long as the params object
+            p._twe_keys = (C.c_int64 * len(twe_keys))(*sorted(int(k) for k in twe_keys))
+            p.twe_key = C.cast(p._twe_keys, C.POINTER(C.c_int64))
         for slot in range(_hip.PK_MAX_KERNELS):
             p.sample_field[slot] = p.sample_var[slot] = -1
         for slot, (fname, var) in (samples or {}).items():

@@ -307,9 +307,12 @@ def _scripted_engine(script):
 
     def make_params(kernel_ids, *, max_iters=0, twe_keys=(), **kw):
         p = _hip.ExecParams()
+        import ctypes as C
+
         p.max_iters, p.twe_n = int(max_iters), len(twe_keys)
-        for k, key in enumerate(twe_keys):
-            p.twe_key[k] = int(key)
+        if twe_keys:
+            p._twe_keys = (C.c_int64 * len(twe_keys))(*[int(k) for k in twe_keys])
+            p.twe_key = C.cast(p._twe_keys, C.POINTER(C.c_int64))
         return p
 
     eng.make_params = make_params
