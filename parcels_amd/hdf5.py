@@ -638,9 +638,25 @@ class NetCDF3File:
     def __init__(self, path):
         self.path = str(path)
         self.fd = os.open(self.path, os.O_RDONLY)
-        head = os.pread(self.fd, min(os.fstat(self.fd).st_size, 1 << 22), 0)
-        if head[:3] != b"CDF" or head[3] not in (1, 2, 5):
-            raise ValueError(f"{self.path}: not a classic NetCDF file")
+        size = os.fstat(self.fd).st_size
+        want = 1 << 22
+        while True:  # the header has no length field: parse a prefix of the file, a longer one when it does not fit
+            head = os.pread(self.fd, min(size, want), 0)
+            if head[:3] != b"CDF" or head[3] not in (1, 2, 5):
+                raise ValueError(f"{self.path}: not a classic NetCDF file")
+            try:
+                self._parse_header(head)
+                break
+            except (struct.error, IndexError, KeyError, UnicodeDecodeError):
+                if want >= size:
+                    raise ValueError(f"{self.path}: truncated or malformed classic NetCDF header") from None
+                want *= 8
+        if self.numrecs in (0xFFFFFFFF, -1) or (self.ver == 5 and self.numrecs == 0xFFFFFFFFFFFFFFFF):
+            # the "streaming" sentinel (the writer did not go back to fill in the record count): what the file size holds
+            first = min((v["begin"] for v in self.vars.values() if v["dimids"] and v["dimids"][0] == self.recdim), default=None)
+            self.numrecs = 0 if first is None or not self.recsize else max((size - first) // self.recsize, 0)
+
+    def _parse_header(self, head):
         self.ver = head[3]
         self._b, self._p = head, 4
         nn = self._int if self.ver < 5 else self._int64

@@ -1130,8 +1130,16 @@ def _csrc_hash() -> str:
 
 
 def cache_dir() -> str:
-    d = os.environ.get("PARCELS_AMD_JIT_CACHE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "_jit_cache")
-    os.makedirs(d, exist_ok=True)
+    # (next to the package by default so that modules built in the build container travel to the GPU box with it; the name sorts behind
+    # libparcels_hip.so in a listing of the shared objects a process loaded.  A read-only package directory falls back to a per-user one.)
+    d = os.environ.get("PARCELS_AMD_JIT_CACHE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "user_kernel_cache")
+    try:
+        os.makedirs(d, exist_ok=True)
+        if not os.access(d, os.W_OK):
+            raise PermissionError(d)
+    except OSError:
+        d = os.path.join(os.path.expanduser("~"), ".cache", "parcels_amd", "user_kernel_cache")
+        os.makedirs(d, mode=0o700, exist_ok=True)
     return d
 
 
@@ -1178,9 +1186,13 @@ class UserProgram:
         self.path = os.path.join(cache_dir(), f"user_{self.digest}.so")
         self._lib = None
 
+    _failed: dict = {}  # digest -> compiler message: a module that did not compile is not compiled again by every pset.execute
+
     def build(self):
         if os.path.exists(self.path):
             return self.path
+        if self.digest in UserProgram._failed:
+            raise RuntimeError(UserProgram._failed[self.digest])
         # several ranks of one node compile the same module at the same time: private temporaries, atomic rename
         tag = f"{os.getpid()}"
         src = self.path[:-3] + f".{tag}.hip"
@@ -1192,7 +1204,8 @@ class UserProgram:
                f"-I{_CSRC}", f"-I{_INCLUDE}", src, "-o", tmp]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
-            raise RuntimeError(f"hipcc failed on the generated user-kernel module {src}:\n{r.stderr[-4000:]}")
+            UserProgram._failed[self.digest] = f"hipcc failed on the generated user-kernel module {src}:\n{r.stderr[-4000:]}"
+            raise RuntimeError(UserProgram._failed[self.digest])
         os.replace(src, self.path[:-3] + ".hip")  # (kept next to the module: what was compiled)
         os.replace(tmp, self.path)
         return self.path

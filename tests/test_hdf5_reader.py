@@ -114,6 +114,34 @@ def test_classic_netcdf3_files(tmp_path, version):
     assert np.array_equal(pa.NetCDFLevels(p, "U").level(4), F32[4])
 
 
+def test_classic_netcdf3_long_header_and_streaming_record_count(tmp_path):
+    """A header beyond the first 4 MiB (many / long attributes) is parsed from a longer prefix, and the "streaming" record count
+    0xFFFFFFFF (a writer that never went back to fill it in) is replaced by what the file size holds."""
+    from scipy.io import netcdf_file
+
+    p = str(tmp_path / "long.nc")
+    with netcdf_file(p, "w", version=2) as nc:
+        nc.createDimension("time", None)
+        nc.createDimension("x", NX)
+        nc.history = "h" * (5 << 20)  # 5 MiB of global attribute in FRONT of the variable list
+        u = nc.createVariable("U", "f4", ("time", "x"))
+        for k in range(NT):
+            u[k] = F32[k, 0, 0]
+    f = NetCDF3File(p)
+    assert f.numrecs == NT and np.array_equal(f.read("U"), F32[:, 0, 0])
+    f.close()
+    raw = bytearray(open(p, "rb").read())
+    raw[4:8] = b"\xff\xff\xff\xff"
+    open(p, "wb").write(bytes(raw))
+    g = NetCDF3File(p)
+    assert g.numrecs == NT and np.array_equal(g.read("U", NT - 1), F32[NT - 1, 0, 0])
+    g.close()
+    q = tmp_path / "cut.nc"
+    q.write_bytes(bytes(raw[:1000]))
+    with pytest.raises(ValueError, match="truncated or malformed"):
+        NetCDF3File(str(q))
+
+
 def test_unsupported_features_say_so(tmp_path):
     with pytest.raises(ValueError, match="not an HDF5 file"):
         p = tmp_path / "x.h5"
