@@ -361,6 +361,12 @@ def main():
     # measured device-to-device copy bandwidth (float4 copy of 1 GiB): the practical HBM ceiling, and the calibration dispatch of
     # the FETCH_SIZE / WRITE_SIZE counter passes (tools/pmc_summary.py)
     copy_gbps = eng.ctx.copy_bandwidth(1 << 30, 5) if rank == 0 else 0.0
+    try:
+        di = eng.ctx.device_info()
+        device = {"name": di["name"], "arch": di["arch"], "compute_units": di["compute_units"], "clock_mhz": di["clock_khz"] / 1e3,
+                  "hbm_gb": di["total_mem"] / 1e9}
+    except Exception:
+        device = None
 
     # warmup: W steps (also pays the one-off cell sort)
     sort_ms = 0.0
@@ -522,6 +528,7 @@ def main():
             "writeout_allgather_ms": t_ag * 1e3 if world > 1 else None,
             "writeout_gather_to_root_ms": t_g0 * 1e3 if world > 1 else None,  # what ParticleFile.write does (rows of the write filter -> rank 0)
             "comm": comm or None,
+            "device": device,
             "value_incl_writeout": total_steps / (el + t_ag) if world > 1 else None,
         }
         ref = os.path.join(ROOT, "profiles", "r02_cpu_reference.json")
