@@ -47,8 +47,9 @@ constexpr int FC_LANES = 64;     // one-wavefront workgroups (see CC_LANES)
 #define PK_CG_HOPS 0  // AdvectionRK45, after the guessed cell rejected the point: 0 = ONE probe of the cell floor(xsi, eta) cells away (its stages
                       // with a dt of hours land a cell or two away, and on a smooth mesh the bilinear inverse of the guessed cell extrapolates
                       // that far), 1 = the adjacent cell like every other kernel, 3 = up to three hops.  BASELINE config 5, same box
-                      // (profiles/r04_d_c5_variants_ab.txt, r04_e_c5_variants_ab.txt): 14.6 ms (1), 13.4 ms (0), 15.3 ms (3: the loop's
-                      // registers cost more than the table walks it saves)
+                      // (profiles/r04_d_c5_variants_ab.txt, r04_e_c5_variants_ab.txt): 14.6 ms (1), 13.4 ms (0), 15.3 ms (a loop of up to
+                      // three hops: its registers cost more than the table walks it saves -- removed, like an affine predictor of the first
+                      // cell from the corner coordinates: 15.1 vs 13.5 ms, profiles/r04_p_rk45_predictor_ab.txt)
 #endif
 
 struct CgLds {
@@ -366,7 +367,7 @@ PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtxT<FT, CM>& c, dou
                 xsi = xs;
                 eta = et;
             } else if (F.walk_ok) {
-                if constexpr (HOPS <= 1) {
+                {
                     // the particle left the guessed cell: the neighbour its barycentric coordinates point at (curvilinear_search)
                     int dj = et < 0 ? -1 : (et > 1 ? 1 : 0), di = xs < 0 ? -1 : (xs > 1 ? 1 : 0);
                     if constexpr (HOPS == 0) {  // one probe, but of the cell floor(xsi, eta) cells away (AdvectionRK45's long stages)
@@ -390,45 +391,6 @@ PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtxT<FT, CM>& c, dou
                                 eta = (double)(float)et2;
                             }
                         }
-                    }
-                } else {
-                    // The particle left the guessed cell: test the cell its barycentric coordinates point at (curvilinear_search does this for
-                    // the adjacent cell).  Here the jump is floor() of the coordinates -- AdvectionRK45's stages with a dt of hours land several
-                    // cells away, and on a smooth mesh the bilinear inverse of the guessed cell extrapolates to within a cell of the truth -- and
-                    // a cell that rejects the point hands its own coordinates to the next hop (HOPS of them at most: one in the
-                    // kernels whose samples stay close, PK_CG_HOPS in AdvectionRK45's, pk_kernels.h).  Accepted exactly
-                    // like the neighbour probe: strictly inside by a margin (no tie that the table order would have to break) and listed in the
-                    // query's hash cell; on a mesh without coincident nodes at most one cell qualifies, so it is the face SpatialHash.query
-                    // finds (spatialhash.py:389-535), reached in one or two record fetches instead of a walk over the ~10-20 faces of the hash
-                    // cell.  Anything else falls through to that walk.
-                    int cj = c.gy, ci = c.gx;
-                    double cxs = xs, cet = et;
-        #pragma unroll 1
-                    for (int hop = 0; hop < HOPS; hop++) {  // (HOPS == 1: no loop is left)
-                        if (!(fabs(cxs) < 64.0 && fabs(cet) < 64.0)) break;  // (also NaN: the degenerate branches of the bilinear inverse)
-                        const int dj = cet < 0 ? (int)floor(cet) : (cet > 1 ? (int)ceil(cet) - 1 : 0);
-                        const int di = cxs < 0 ? (int)floor(cxs) : (cxs > 1 ? (int)ceil(cxs) - 1 : 0);
-                        const int nj = cj + dj, ni = ci + di;
-                        if ((dj | di) == 0 || nj < 0 || nj >= F.gny - 1 || ni < 0 || ni >= F.gnx - 1) break;
-                        const int ncell = nj * F.gnx + ni;
-                        const double boxd = scalar ? cg_fetch_cell<FT, D3, false, CM>(F, L, c, ncell, nj, ni, zi, ti, lenT) : cg_fetch_cell<FT, D3, true, CM>(F, L, c, ncell, nj, ni, zi, ti, lenT);
-                        double xs2, et2;
-                        const double m = 1e-9;
-                        if (cg_point_in_cell(F, L.rec, ncell, qX, qY, qZ, xs2, et2)) {
-                            if (xs2 > m && xs2 < 1 - m && et2 > m && et2 < 1 - m &&
-                                box_lists(kgrid(a, F.grid), (unsigned long long)__double_as_longlong(boxd), qX, qY, qZ, true)) {
-                                found = true;
-                                yi = nj;
-                                xi = ni;
-                                xsi = (double)(float)xs2;  // rounded like a hash hit (spatialhash.py:505)
-                                eta = (double)(float)et2;
-                            }
-                            break;
-                        }
-                        cj = nj;
-                        ci = ni;
-                        cxs = xs2;
-                        cet = et2;
                     }
                 }
             }
