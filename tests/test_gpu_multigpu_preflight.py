@@ -102,3 +102,40 @@ def test_batch_agreements_run_over_rccl(gpu, rccl_world1, tmp_path, name):
     for k in local._data:
         assert np.array_equal(local._data[k], coll._data[k], equal_nan=True), k
     assert (tmp_path / "local.parquet").read_bytes() == (tmp_path / "collective.parquet").read_bytes()
+
+
+@pytest.mark.parametrize("name", ["twe_agrid_sph_rk4_raise", "twe_agrid_sph_ee_delete"])
+def test_two_shards_are_one_batch_on_the_real_kernels(gpu, tmp_path, name):
+    """Two ranks (sharing this box's one GPU, gloo) run ONE id space sharded by id through the real kernels.  The particles are ordered
+    so that the LATE releases -- the ones that leave the field's time interval first -- all live on shard 0: in the iteration in which
+    they do, the particles of shard 1 are still inside it.  The reference fails that sample for every particle of the call
+    (field.py:31-44), so shard 1 must repeat its launch with the sample listed although none of ITS particles ever left the interval
+    (parcels_amd.distributed.batch_agreement) -- the concatenated shards equal the reference fixture, rank 1 raises the same exception."""
+    import subprocess
+    import sys
+
+    from case_utils import ROOT_DIR, compare, tolerance_for
+
+    case, out, err = load_golden(name)
+    t0 = np.asarray(case["t0"], dtype=np.float64)
+    order = np.argsort(-t0, kind="stable")
+    np.save(tmp_path / "order.npy", order)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT_DIR, "tests", "_twe_two_rank_worker.py"), name, str(tmp_path)]
+    r = subprocess.run(cmd, cwd=ROOT_DIR, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    ranks = [np.load(tmp_path / f"rank{k}.npz") for k in range(2)]
+    for k in range(2):
+        assert str(ranks[k]["err"]) == (err or ""), (k, str(ranks[k]["err"]), err)
+        assert int(ranks[k]["reran"]) >= 1 and len(ranks[k]["keys"]) >= 1  # BOTH shards repeated the call with the listed sample
+    assert np.array_equal(ranks[0]["keys"], ranks[1]["keys"])
+    got = {k: np.concatenate([ranks[0][k], ranks[1][k]]) for k in ("x", "y", "z", "t", "dx", "dy", "dz", "dt", "state", "ei", "particle_id")}
+    if len(out["x"]):  # the fixture keeps its particles: row i of the sharded run is input row order[i]
+        ref = {k: np.asarray(out[k])[order] for k in out if k != "particle_id"}
+        ref["particle_id"] = got["particle_id"]
+        compare(got, ref, rtol=tolerance_for(name, case), check_state="all", label=name)
+    else:  # the reference deleted every particle of the call -- per particle, shard 1 would have kept its own
+        assert len(got["x"]) == 0
