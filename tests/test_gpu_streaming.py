@@ -148,3 +148,28 @@ def test_to_windowed_arrays_is_the_three_slot_ring(gpu):
         else:
             assert "all 8 levels resident" in buf.getvalue()
     compare(res[True], res[False], rtol=0.0, check_state="all", label="to_windowed_arrays", skip=())
+
+
+@pytest.mark.parametrize("kernels", [["AdvectionRK4"], ["AdvectionEE", "DeleteParticle"], ["AdvectionRK45"]], ids=lambda k: "+".join(k))
+@pytest.mark.parametrize("nslots", [None, 3, 4])  # (a ring of 2 cannot hold a step that straddles a level: these releases are staggered by quarter steps)
+def test_call_wide_time_error_through_a_level_ring(gpu, kernels, nslots):
+    """The reference's call-wide OutsideTimeInterval (field.py:31-44) in a call that takes SEVERAL launches: six 2-hour levels stream
+    through a ring of 3 / 4 slots, staggered releases run one step past the last level.  The sample that fails shows up in the LAST
+    launch of a pass; the call restarts from the device checkpoint with it listed (DeviceEngine.execute) -- same columns, same
+    exception, same survivors as the oracle's batch loop (pinned to the reference on this class by the twe_* fixtures), for every ring."""
+    from case_utils import compare, run_hip, run_oracle
+    from oracle import cases
+
+    case = cases.rect_agrid_case("twe_ring", mesh="spherical", kernels=kernels, seed=77, nt=6, level_dt=7200.0, stagger=True, npart=200, dt=1800.0)
+    case["t0"] = np.asarray(case["t0"]) * 0.5  # (stagger in units of the half step of THIS dt)
+    tl = float(case["time_s"][-1])
+    case["runtime"] = tl + (2.0 if "AdvectionRK45" in kernels else 1.0) * 1800.0 - float(np.min(case["t0"]))
+    if "AdvectionRK45" in kernels:
+        case["context"] = {"RK45_tol": 500.0, "RK45_min_dt": 10.0, "RK45_max_dt": 3600.0}
+    ref, oerr, _ = run_oracle(case)
+    got, gerr, st = run_hip(case, nslots=nslots)
+    assert gerr == oerr
+    assert st["reran"] >= 1 and len(st["time_error_keys"]) >= 1
+    if nslots is not None:
+        assert st["launches"] > 2  # streamed: several launches per pass, and at least one repeated pass
+    compare(got, ref, rtol=1e-11, check_state="all", label=f"ring {nslots} {kernels}", skip=("dt",) if "AdvectionRK45" in kernels else ())
