@@ -80,6 +80,13 @@ def test_bench_py_runs_under_torchrun_with_two_ranks(gpu):
     assert out["value"] > 0 and out["config"]["all_states_endofloop"] is True and out["config"]["rehearsal_shared_gpu_gloo"] is True
     assert out["writeout_allgather_ms"] is not None and out["writeout_allgather_ms"] > 0
     assert abs(out["value"] * out["ms_per_step"] * 1e-3 * out["steps"] - 2 * 200000 * 4) < 1e-6 * 2 * 200000 * 4  # value x time = all ranks' steps
+    # round 4: the timed region is repeated (median quoted), both write-out collectives are timed, the line says what it ran on
+    tr = out["timed_reps"]
+    assert tr["n"] == 7 and tr["statistic"] == "median" and tr["wall_ms"]["min"] <= tr["wall_ms"]["median"] <= tr["wall_ms"]["max"]
+    assert abs(tr["wall_ms"]["median"] - out["ms_per_step"] * out["steps"]) < 1e-9 * tr["wall_ms"]["median"] + 1e-12
+    assert len(tr["kernel_ms_slowest_vs_fastest_rank_of_median_rep"]) == 2
+    assert out["writeout_gather_to_root_ms"] is not None and out["writeout_gather_to_root_ms"] > 0
+    assert out["comm"]["n_ranks_seen"] == 2 and out["comm"]["backend"] == "gloo" and out["device"]["compute_units"] > 0
 
 
 @pytest.mark.gpu
@@ -127,3 +134,8 @@ def test_bench_py_secondary_configs_carry_the_oracle_check(gpu):
     for e in sec:
         assert e["check"]["passed"] is True and e["check"]["n_check"] == 5000 and e["value"] > 0
         assert e["roofline"]["bound"] == "hbm" and 0 < e["roofline"]["frac"] < 1
+        ks = e["kernel_ms_stats"]  # one cold launch, then the median of the timed ones
+        assert ks["n"] == 5 and ks["min"] <= ks["median"] <= ks["max"] and e["kernel_ms"] == ks["median"] and ks["cold"] > 0
+    lr = out["long_run"]
+    assert lr["particle_steps"] > 0.9 * 200000 * 552 and lr["value"] > 0 and "error" not in lr
+    assert out["timed_reps"]["n"] == 7 and set(out["legs_wall_s"]) >= {"secondary", "long_run", "total_after_imports"}
