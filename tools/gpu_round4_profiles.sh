@@ -17,8 +17,8 @@ for l in open('$OUT/$1_run.json'):
 bash tools/gpu_profile_cfg.sh ${N}_c3 c3 --reps 0 > /dev/null
 python tools/pmc_summary.py ${N}_c3 ${N}_c3 --no-latest --psteps $(psteps ${N}_c3 AdvectionRK4_3D) --secondary AdvectionRK4_3D > /dev/null
 bash tools/gpu_profile_cfg.sh ${N}_c5 c5 --reps 0 > /dev/null
-python tools/pmc_summary.py ${N}_c5 ${N}_c5_rk45 --no-latest --match rk45_kernel --psteps $(psteps ${N}_c5 AdvectionRK45) --secondary AdvectionRK45 > /dev/null
-python tools/pmc_summary.py ${N}_c5 ${N}_c5_m1 --no-latest --match m1_kernel --psteps $(psteps ${N}_c5 AdvectionDiffusionM1) --secondary AdvectionDiffusionM1 > /dev/null
+python tools/pmc_summary.py ${N}_c5 ${N}_c5_rk45 --no-latest --match rk45_kernel --evals-per-step 6 --psteps $(psteps ${N}_c5 AdvectionRK45) --secondary AdvectionRK45 > /dev/null
+python tools/pmc_summary.py ${N}_c5 ${N}_c5_m1 --no-latest --match m1_kernel --evals-per-step 7 --psteps $(psteps ${N}_c5 AdvectionDiffusionM1) --secondary AdvectionDiffusionM1 > /dev/null
 cp profiles/${N}_* profiles/pmc_latest.json profiles/pmc_secondary_latest.json $OUT/r04_profiles/
 rm -rf $OUT/${N}_*_trace $OUT/${N}_*_pmc_*
 ls -la $OUT/r04_profiles | head -40; du -sh $OUT
