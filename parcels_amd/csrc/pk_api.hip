@@ -45,6 +45,7 @@ struct HostField {
     int pack_used = 1;       // leader: components handed out so far
     std::vector<int32_t> slot_level;    // committed (usable) level per ring slot, -1 = empty
     std::vector<int32_t> slot_pending;  // level being copied into the slot (async upload), -1 = none
+    std::vector<uint64_t> slot_gen;     // stamp of the last upload into the slot (pk_ctx::upload_counter): tells a re-upload of the same level apart
 };
 
 constexpr int PK_STAGE_BUFFERS = 3;  // pinned staging chunks of the level stream (see stage_acquire)
@@ -142,6 +143,14 @@ struct pk_ctx {
     // fast C-grid path (pk_fast_cgrid.h): per-cell records of one grid + {a, 1/width} tables of time | depth, cached per (grid, field)
     double* d_ct2 = nullptr;
     int ct2_grid = -1;
+    // cell-packed pair copies of the staggered velocity for the 2-D dedicated C-grid kernels (pk_device.h: FastC::vp)
+    char* d_vp = nullptr;
+    size_t vp_bytes = 0;
+    int vp_fU = -1, vp_fV = -1;
+    std::vector<int32_t> vp_level;        // pair held by every pair slot, -1 = none
+    std::vector<uint64_t> vp_gen;         // 4 stamps per pair slot: U and V uploads of both levels it was packed from
+    int no_velocity_pairs = 0;
+    uint64_t upload_counter = 0;
     double* d_cg_tab = nullptr;
     size_t cg_tab_cap = 0;
     int cg_tab_grid = -1, cg_tab_field = -1;
@@ -343,6 +352,35 @@ __global__ void __launch_bounds__(256) compact_perm_kernel(const int64_t* __rest
 }
 
 // scatter one contiguous field level into its component slot of a packed (array-of-structs) group buffer
+// Cell-packed pair copy of the staggered velocity (FastC::vp): for every element e = (zi, yi, xi) of a level the four values the 2-D
+// C-grid kernels read for cell e -- U at e + dU0 / dU1, V at e + dV0 / dV1 (byte offsets into the level rings, pk_fast_cgrid.h) -- of
+// level slot `o0`, then of level slot `o1`.  Elements in the last row / column are no cells (their offsets leave the level): zeros.
+template <class T>
+__global__ void __launch_bounds__(256) cg_pack_pairs_kernel(const char* __restrict__ U, const char* __restrict__ V, int64_t dU0, int64_t dU1,
+                                                            int64_t dV0, int64_t dV1, int64_t cb, int64_t o0, int64_t o1, int64_t n, int32_t ny,
+                                                            int32_t nx, T* __restrict__ out) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const int xi = (int)(e % nx), yi = (int)((e / nx) % ny);
+        T v[8];
+        if (xi < nx - 1 && yi < ny - 1) {
+            const int64_t b0 = e * cb + o0, b1 = e * cb + o1;
+            v[0] = *reinterpret_cast<const T*>(U + dU0 + b0);
+            v[1] = *reinterpret_cast<const T*>(U + dU1 + b0);
+            v[2] = *reinterpret_cast<const T*>(V + dV0 + b0);
+            v[3] = *reinterpret_cast<const T*>(V + dV1 + b0);
+            v[4] = *reinterpret_cast<const T*>(U + dU0 + b1);
+            v[5] = *reinterpret_cast<const T*>(U + dU1 + b1);
+            v[6] = *reinterpret_cast<const T*>(V + dV0 + b1);
+            v[7] = *reinterpret_cast<const T*>(V + dV1 + b1);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = (T)0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) out[e * 8 + k] = v[k];
+    }
+}
+
 template <class T>
 __global__ void __launch_bounds__(256) interleave_kernel(const T* __restrict__ src, T* __restrict__ dst, int64_t n, int ncomp) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i * ncomp] = src[i];
@@ -536,6 +574,7 @@ int32_t pk_init(int32_t device, pk_ctx** out) {
     if (const char* e = getenv("PK_NO_CELL_TABLE")) ctx->no_cell_table = atoi(e);
     if (const char* e = getenv("PK_NO_FAST")) ctx->no_fast = atoi(e);
     if (const char* e = getenv("PK_NO_FAST_CGRID")) ctx->no_fast_cgrid = atoi(e);
+    if (const char* e = getenv("PK_NO_VELOCITY_PAIRS")) ctx->no_velocity_pairs = atoi(e);
     *out = ctx;
     PK_HIP(ctx, hipSetDevice(device));
     PK_HIP(ctx, hipGetDeviceProperties(&ctx->prop, device));
@@ -558,6 +597,7 @@ int32_t pk_set_option(pk_ctx* ctx, const char* name, int32_t value) {
     const std::string n(name);
     if (n == "fast_path") ctx->no_fast = !value;
     else if (n == "fast_cgrid") ctx->no_fast_cgrid = !value;
+    else if (n == "velocity_pairs") ctx->no_velocity_pairs = !value;
     else if (n == "special_programs") ctx->no_special = !value;
     else if (n == "cell_cache") ctx->no_cell_cache = !value;
     else if (n == "hash_directory") ctx->no_hash_dir = !value;
@@ -639,6 +679,7 @@ int32_t pk_destroy(pk_ctx* ctx) {
     if (ctx->d_fast_tab) (void)hipFree(ctx->d_fast_tab);
     if (ctx->d_cg_tab) (void)hipFree(ctx->d_cg_tab);
     if (ctx->d_ct2) (void)hipFree(ctx->d_ct2);
+    if (ctx->d_vp) (void)hipFree(ctx->d_vp);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_twe) (void)hipFree(ctx->d_twe);
     if (ctx->d_desc) (void)hipFree(ctx->d_desc);
@@ -848,6 +889,7 @@ int32_t pk_field_create(pk_ctx* ctx, const pk_field_desc* desc, int32_t* field_i
     if (nslots < desc->nt && nslots < 2) nslots = 2;
     f.slot_level.assign(nslots, -1);
     f.slot_pending.assign(nslots, -1);
+    f.slot_gen.assign(nslots, 0);
     int ncomp = 1, comp = 0;
     if (desc->pack_leader >= 0) {  // follower: share the leader's interleaved buffer
         if (desc->pack_leader >= (int)ctx->fields.size() - 1) return ctx->fail("pack_leader must be an existing field");
@@ -965,6 +1007,7 @@ int32_t pk_field_upload_level(pk_ctx* ctx, int32_t field_id, int32_t level, cons
         }
         if (int32_t rc = interleave()) return rc;
     }
+    f.slot_gen[slot] = ++ctx->upload_counter;
     if (async) {  // usable only after pk_field_sync(); the level that lived in this slot is gone as of now
         f.slot_level[slot] = -1;
         f.slot_pending[slot] = level;
@@ -1015,6 +1058,7 @@ int32_t pk_field_upload_group_level(pk_ctx* ctx, int32_t leader_id, int32_t leve
     for (size_t f = 0; f < ctx->fields.size(); f++) {  // the leader and its followers change slot state together
         HostField& F = ctx->fields[f];
         if ((int)f != leader_id && F.desc.pack_leader != leader_id) continue;
+        F.slot_gen[slot] = ++ctx->upload_counter;
         F.slot_level[slot] = async ? -1 : level;
         F.slot_pending[slot] = async ? level : -1;
     }
@@ -1751,6 +1795,75 @@ static int32_t fill_fast(pk_ctx* ctx, const pk_exec_params* prm, KArgs& a, bool 
 // path (pk_device.h: FastC, pk_fast_cgrid.h).  a.fastc.ok == 0 when a precondition fails (the general program runs): float64 node
 // coordinates, spherical mesh, per-cell table present, U / V (/ W) of one shape on the grid's own node counts with staggering offsets
 // in {0, 1} (then no staggered index needs clipping), a level below 2^31 elements, every search of the launch guessed.
+// The pair copies of FastC::vp for the levels that are resident right now: allocated on first use (no memory for them: the kernels read
+// the level rings), (re)packed on the compute stream -- ahead of the launch that is being prepared -- for every pair of adjacent
+// committed levels whose copy is missing or older than one of the four uploads it was made from.
+static void ensure_velocity_pairs(pk_ctx* ctx, const pk_exec_params* prm, FastC& F) {
+    F.vp = nullptr;
+    F.vp_slot_b = 0;
+    F.vp_hi = 0;
+    if (ctx->no_velocity_pairs) return;
+    const HostField& U = ctx->fields[prm->fU];
+    const HostField& V = ctx->fields[prm->fV];
+    const DField& f = U.d;
+    if (!f.has_time_interval || f.nt < 2 || f.st_t <= 0) return;
+    const size_t esz = f.dtype == PK_F64 ? 8 : 4;
+    const int ns = f.nslots;
+    const size_t slot_b = (size_t)f.st_t * 8 * esz;
+    const size_t need = slot_b * (size_t)ns;
+    if (ctx->vp_fU != prm->fU || ctx->vp_fV != prm->fV || ctx->vp_bytes != need || (int)ctx->vp_level.size() != ns) {
+        if (ctx->d_vp) {
+            (void)hipStreamSynchronize(ctx->compute);
+            (void)hipFree(ctx->d_vp);
+            ctx->d_vp = nullptr;
+        }
+        ctx->vp_fU = prm->fU;
+        ctx->vp_fV = prm->fV;
+        ctx->vp_bytes = need;
+        ctx->vp_level.assign(ns, -1);
+        ctx->vp_gen.assign((size_t)ns * 4, 0);
+        if (hipMalloc((void**)&ctx->d_vp, need) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->d_vp = nullptr;
+        }
+    }
+    if (!ctx->d_vp) return;
+    const int64_t cb = F.cb;
+    // the resident levels must be ONE run lo..hi of at least two (a ring in steady state, or everything): else the level rings serve
+    int lo = -1, hi = -1, count = 0;
+    for (int L = 0; L < f.nt; L++) {
+        const int sl = L % ns;
+        if (U.slot_level[sl] != L || V.slot_level[sl] != L) continue;
+        if (lo < 0) lo = L;
+        hi = L;
+        count++;
+    }
+    if (lo < 0 || hi == lo || count != hi - lo + 1) return;
+    for (int L = lo; L < hi; L++) {
+        const int s0 = L % ns, s1 = (L + 1) % ns, ps = L % ns;
+        const uint64_t g[4] = {U.slot_gen[s0], U.slot_gen[s1], V.slot_gen[s0], V.slot_gen[s1]};
+        uint64_t* have = &ctx->vp_gen[(size_t)ps * 4];
+        if (ctx->vp_level[ps] == L && have[0] == g[0] && have[1] == g[1] && have[2] == g[2] && have[3] == g[3]) continue;
+        const int64_t n = f.st_t;
+        const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 256 * 64);
+        char* out = ctx->d_vp + (size_t)ps * slot_b;
+        const int64_t o0 = (int64_t)s0 * F.lvl_b, o1 = (int64_t)s1 * F.lvl_b;
+        if (esz == 8)
+            hipLaunchKernelGGL((cg_pack_pairs_kernel<double>), dim3(grid), dim3(256), 0, ctx->compute, F.U, F.V, F.dU0, F.dU1, F.dV0, F.dV1, cb, o0, o1, n,
+                               (int32_t)f.ny, (int32_t)f.nx, (double*)out);
+        else
+            hipLaunchKernelGGL((cg_pack_pairs_kernel<float>), dim3(grid), dim3(256), 0, ctx->compute, F.U, F.V, F.dU0, F.dU1, F.dV0, F.dV1, cb, o0, o1, n,
+                               (int32_t)f.ny, (int32_t)f.nx, (float*)out);
+        if (hipGetLastError() != hipSuccess) return;  // (the level rings serve)
+        ctx->vp_level[ps] = L;
+        for (int k = 0; k < 4; k++) have[k] = g[k];
+    }
+    F.vp_hi = hi;
+    // every pair inside the window a launch may touch is packed now: the resident window is made of committed levels only
+    F.vp = ctx->d_vp;
+    F.vp_slot_b = (int64_t)slot_b;
+}
+
 static int32_t fill_fastc(pk_ctx* ctx, const pk_exec_params* prm, KArgs& a, bool want_w, size_t& lds_bytes, bool rk45 = false, bool m1 = false) {
     FastC& F = a.fastc;
     memset(&F, 0, sizeof(F));
@@ -1905,6 +2018,7 @@ static int32_t fill_fastc(pk_ctx* ctx, const pk_exec_params* prm, KArgs& a, bool
     F.tlen = f.tlen; F.t0 = f.tfirst; F.t1 = f.tlast;
     F.z0 = g.d.zfirst; F.z1 = g.d.zlast;
     F.deg2m = g.d.deg2m;
+    if (!W) ensure_velocity_pairs(ctx, prm, F);
     F.ok = 1;
     return 0;
 }

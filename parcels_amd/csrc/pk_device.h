@@ -136,6 +136,12 @@ struct FastC {
     int64_t lvl_b;                       // bytes per time-level slot
     int64_t dU0, dU1, dV0, dV1, dW0, dW1;  // byte offsets of the six staggered values relative to the struct of cell (zi, yi, xi)
     const char *U, *V, *W;               // level rings (component offset folded into dU0.. for packed groups; W may be NULL)
+    // 2-D kernels: cell-packed copies of the staggered values, one group per cell and PAIR of adjacent levels --
+    // {U0, U1, V0, V1}(level L), {U0, U1, V0, V1}(level L + 1) -- so that a cell change reads ONE line for both levels instead of four
+    // (pk_api.hip: ensure_velocity_pairs; pair L lives in slot L % nslots; NULL = not available, read the level rings)
+    const char* vp;
+    int64_t vp_slot_b;                   // bytes per pair slot
+    int32_t vp_hi, vp_pad;               // highest resident level: a sample exactly ON it reads the upper half of the pair below
     // AdvectionDiffusionM1: the two scalar fields Kh_zonal / Kh_meridional on the nodes of the SAME grid (XLinear): base, byte strides of
     // their axes (0 for an axis the field does not have), extents, and whether they share the velocity's time axis (else: no time axis)
     const char* kh[2];
@@ -444,6 +450,7 @@ PK_DEV void search_1d(const double* arr, int n, double first, double last, doubl
 // 8-byte (fp32) load.  Element alignment is enough: gfx950 global loads handle unaligned dwordx4.
 typedef double pk_double2 __attribute__((ext_vector_type(2), aligned(8)));
 typedef float pk_float2 __attribute__((ext_vector_type(2), aligned(4)));
+typedef float pk_float4 __attribute__((ext_vector_type(4), aligned(16)));
 PK_DEV void ldpair(const double* p, double& a, double& b) {
     const pk_double2 v = *reinterpret_cast<const pk_double2*>(p);
     a = v.x;

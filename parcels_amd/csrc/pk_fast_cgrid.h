@@ -102,6 +102,44 @@ PK_DEV void cctx_init(CCtxT<FT, CM>& c, int state, int32_t ei, int gy, int gx) {
 template <class FT, bool D3>
 PK_DEV void cg_issue_fields(const FastC& F, int zi, int yi, int xi, int ti, bool lenT, FT raw[12]) {
     const uint32_t e = (uint32_t)zi * (uint32_t)F.st_z + (uint32_t)yi * (uint32_t)F.st_y + (uint32_t)xi;  // < 2^31 elements per level (host check)
+    if constexpr (!D3) {
+        if (F.vp) {  // (wave-uniform) the cell-packed pair copy: both levels of the cell in one 8-value group
+            // pair L holds levels (L, L + 1); a sample exactly on the highest resident level (tau == 0: !lenT) has no pair of its own
+            // and reads the upper half of the pair below
+            const bool last = ti >= F.vp_hi;
+            const int pair = last ? ti - 1 : ti;
+            int64_t off = 0;
+            for (bool done = false; !done;) {
+                const int up = uniform_i32(pair);
+                const int64_t u = (int64_t)(F.nslots < F.nt ? (int)((uint32_t)up % (uint32_t)F.nslots) : up) * F.vp_slot_b;
+                if (pair == up) {
+                    off = u;
+                    done = true;
+                }
+            }
+            const FT* g = reinterpret_cast<const FT*>(F.vp + off) + (int64_t)e * 8 + (last ? 4 : 0);
+            if constexpr (sizeof(FT) == 4) {
+                const pk_float4 a = *reinterpret_cast<const pk_float4*>(g);
+                raw[0] = a.x; raw[1] = a.y; raw[2] = a.z; raw[3] = a.w;
+            } else {
+                const pk_double2 a = *reinterpret_cast<const pk_double2*>(g), b = *reinterpret_cast<const pk_double2*>(g + 2);
+                raw[0] = a.x; raw[1] = a.y; raw[2] = b.x; raw[3] = b.y;
+            }
+            raw[4] = raw[5] = (FT)0;
+#pragma unroll
+            for (int k = 6; k < 12; k++) raw[k] = (FT)0;
+            if (lenT) {
+                if constexpr (sizeof(FT) == 4) {
+                    const pk_float4 a = *reinterpret_cast<const pk_float4*>(g + 4);
+                    raw[6] = a.x; raw[7] = a.y; raw[8] = a.z; raw[9] = a.w;
+                } else {
+                    const pk_double2 a = *reinterpret_cast<const pk_double2*>(g + 4), b = *reinterpret_cast<const pk_double2*>(g + 6);
+                    raw[6] = a.x; raw[7] = a.y; raw[8] = b.x; raw[9] = b.y;
+                }
+            }
+            return;
+        }
+    }
     const int64_t vb = (int64_t)((uint64_t)e * (uint64_t)(uint32_t)F.cb);
     // byte offsets of the slots of levels ti and ti+1 (slot_off of pk_device.h).  A ring needs `level % nslots`: the level is
     // wave-uniform unless particles of one wavefront sit on different levels, so the modulo runs on the scalar unit, once per
