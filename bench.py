@@ -249,7 +249,7 @@ def secondary_runs(args):
                 e["roofline"]["counters_source"] = pp.get("source")
                 e["roofline"]["valu_insts_per_wave_evaluation"] = pp.get("valu_insts_per_wave_eval")
                 e["roofline"]["scratch_bytes_per_lane"] = pp.get("scratch")
-                e["roofline"]["counters_stale"] = pp.get("source_hash") != kernel_source_hash()  # kernels changed since the PMC passes
+                e["roofline"]["counters_stale"] = counters_stale(r["kernels"], pp)  # the kernel changed since the PMC passes
             if r.get("check"):
                 c = r["check"]
                 e["check"] = {"passed": True, "n_check": c["n_check"], "deleted": c["deleted"], "exact": c["exact"],
@@ -264,6 +264,20 @@ def kernel_source_hash():
     for f in sorted(glob.glob(os.path.join(ROOT, "parcels_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "parcels_amd", "csrc", "*.hip"))):
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
+
+
+def counters_stale(key, entry):
+    """Were the PMC counters of `entry` (profiles/pmc_*latest.json) collected on another kernel than the one this library runs?  By the
+    hash of the kernel's MACHINE CODE when both sides have one (tools/kernel_code_hash.py writes parcels_amd/kernel_code_hashes.json at
+    build time, tools/pmc_summary.py records it with the counters): a source change that leaves the kernel's instructions alone does
+    not make its counters stale.  Otherwise by the hash of all kernel sources."""
+    try:
+        cur = json.load(open(os.path.join(ROOT, "parcels_amd", "kernel_code_hashes.json"))).get(key, {}).get("code_hash")
+    except Exception:
+        cur = None
+    if cur and entry.get("code_hash"):
+        return cur != entry["code_hash"]
+    return entry.get("source_hash") != kernel_source_hash()
 
 
 def main():
@@ -478,7 +492,7 @@ def main():
                     roof["hbm"] = {"achieved": traffic / kernel_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                    "frac": traffic / kernel_s / 1e9 / HBM_PEAK_GBPS, "bytes_per_particle_step": pp["fetch_bytes"] + pp["write_bytes"]}
                 roof["counters_source"] = pj.get("source")
-                roof["counters_stale"] = pj.get("source_hash") != kernel_source_hash()  # kernels changed since the PMC passes
+                roof["counters_stale"] = counters_stale("AdvectionRK4", pj)  # the kernel changed since the PMC passes
                 isa = os.path.join(ROOT, "profiles", "isa_latest.json")
                 if os.path.exists(isa):
                     # what the VALU-busy fraction above is made of (tools/isa_histogram.py: instruction classes of the kernel's inner loops

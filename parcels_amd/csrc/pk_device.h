@@ -134,14 +134,17 @@ struct FastC {
     int32_t st_z, st_y;                  // element strides of the fields inside a level (cells)
     int32_t cb;                          // bytes per cell struct of the (possibly packed) field buffers
     int64_t lvl_b;                       // bytes per time-level slot
-    int64_t dU0, dU1, dV0, dV1, dW0, dW1;  // byte offsets of the six staggered values relative to the struct of cell (zi, yi, xi)
-    const char *U, *V, *W;               // level rings (component offset folded into dU0.. for packed groups; W may be NULL)
-    // 2-D kernels: cell-packed copies of the staggered values, one group per cell and PAIR of adjacent levels --
-    // {U0, U1, V0, V1}(level L), {U0, U1, V0, V1}(level L + 1) -- so that a cell change reads ONE line for both levels instead of four
-    // (pk_api.hip: ensure_velocity_pairs; pair L lives in slot L % nslots; NULL = not available, read the level rings)
-    const char* vp;
-    int64_t vp_slot_b;                   // bytes per pair slot
-    int32_t vp_hi, vp_pad;               // highest resident level: a sample exactly ON it reads the upper half of the pair below
+    // byte offsets of the six staggered values relative to the struct of cell (zi, yi, xi); level rings (component offset folded into
+    // dU0.. for packed groups).  The 2-D kernels have no W: its three members carry, for them, the CELL-PACKED PAIR COPY of the
+    // staggered values -- one group per cell and pair of adjacent levels, {U0, U1, V0, V1}(level L), {U0, U1, V0, V1}(level L + 1), so
+    // that a cell change reads ONE line for both levels instead of four (pk_api.hip: ensure_velocity_pairs; pair L lives in slot
+    // L % nslots; vp == NULL: not available, read the level rings).  Same members, so the kernel arguments keep their size and the 3-D
+    // and A-grid kernels their code.
+    int64_t dU0, dU1, dV0, dV1;
+    union { int64_t dW0; int64_t vp_slot_b; };  // 2-D: bytes per pair slot
+    union { int64_t dW1; int64_t vp_hi; };      // 2-D: highest resident level -- a sample exactly ON it reads the upper half of the pair below
+    const char *U, *V;
+    union { const char* W; const char* vp; };   // W may be NULL
     // AdvectionDiffusionM1: the two scalar fields Kh_zonal / Kh_meridional on the nodes of the SAME grid (XLinear): base, byte strides of
     // their axes (0 for an axis the field does not have), extents, and whether they share the velocity's time axis (else: no time axis)
     const char* kh[2];

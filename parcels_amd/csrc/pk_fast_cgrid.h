@@ -106,7 +106,7 @@ PK_DEV void cg_issue_fields(const FastC& F, int zi, int yi, int xi, int ti, bool
         if (F.vp) {  // (wave-uniform) the cell-packed pair copy: both levels of the cell in one 8-value group
             // pair L holds levels (L, L + 1); a sample exactly on the highest resident level (tau == 0: !lenT) has no pair of its own
             // and reads the upper half of the pair below
-            const bool last = ti >= F.vp_hi;
+            const bool last = ti >= (int)F.vp_hi;
             const int pair = last ? ti - 1 : ti;
             int64_t off = 0;
             for (bool done = false; !done;) {

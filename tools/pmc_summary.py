@@ -33,6 +33,17 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+def code_hash(kernel_name):
+    """machine-code hash of the profiled kernel in the library that was profiled (tools/kernel_code_hash.py, written by `make`)"""
+    try:
+        for v in json.load(open(os.path.join(ROOT, "parcels_amd", "kernel_code_hashes.json"))).values():
+            if v.get("kernel") == kernel_name:
+                return v.get("code_hash")
+    except Exception:
+        pass
+    return None
+
+
 MATCH = "advect"  # --match: substring that selects the advection kernel of interest (a run of config c5 launches two programs)
 
 
@@ -118,7 +129,7 @@ def main():
     cyc_xcd = c.get("GRBM_GUI_ACTIVE", 0.0) / N_XCD
     valu_busy_cyc = c.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0
     out = {
-        "source": f"profiles/{a.name}_pmc.md", "source_hash": source_hash(), "particles_per_gpu": npart, "steps": K, **meta,
+        "source": f"profiles/{a.name}_pmc.md", "source_hash": source_hash(), "code_hash": code_hash(meta.get("kernel")), "particles_per_gpu": npart, "steps": K, **meta,
         "per_particle_step": {
             "valu_busy_simd_cycles": valu_busy_cyc / psteps,
             "valu_insts_per_wave_eval": c.get("SQ_INSTS_VALU", 0.0) / wave_evals,
@@ -138,7 +149,7 @@ def main():
         sp = os.path.join(ROOT, "profiles", "pmc_secondary_latest.json")
         sec = json.load(open(sp)) if os.path.exists(sp) else {}
         pps = out["per_particle_step"]
-        sec[a.secondary] = {"source": out["source"], "source_hash": out["source_hash"], "kernel": meta.get("kernel"), "scratch": meta.get("scratch"),
+        sec[a.secondary] = {"source": out["source"], "source_hash": out["source_hash"], "code_hash": out.get("code_hash"), "kernel": meta.get("kernel"), "scratch": meta.get("scratch"),
                             "hbm_bytes_per_particle_step": (pps["fetch_bytes"] + pps["write_bytes"]) if pps["fetch_bytes"] is not None and pps["write_bytes"] is not None else None,
                             "valu_insts_per_wave_eval": pps["valu_insts_per_wave_eval"], "salu_insts_per_wave_eval": pps["salu_insts_per_wave_eval"],
                             "valu_utilisation_at_measured_clock": out["profiled_launch"]["valu_utilisation_at_measured_clock"]}
