@@ -417,3 +417,23 @@ def test_fieldset_describe_and_windowed_arrays():
     assert row["U"][0] == "Field" and row["UV"][0] == "VectorField" and row["max_age"] == ["Context", "-", "3.5", "-"]
     assert row["U"][3] == "NumPy" and row["Kh_zonal"][1] != row["U"][1]  # the constant field lives on its own 1 x 1 grid
     assert "mesh: " in text and "time interval: " in text
+
+
+def test_counters_are_stale_by_machine_code_not_by_source_text(tmp_path, monkeypatch):
+    """bench.py marks the committed PMC counters of a kernel stale when the library's kernel has OTHER MACHINE CODE than the profiled one
+    (tools/kernel_code_hash.py, written next to the library by make); without a code hash on either side, by the hash of the sources."""
+    import json
+
+    import bench
+
+    cur = os.path.join(bench.ROOT, "parcels_amd", "kernel_code_hashes.json")
+    if not os.path.exists(cur):
+        pytest.skip("no kernel_code_hashes.json (library not built with the ROCm LLVM tools)")
+    hashes = json.load(open(cur))
+    assert set(hashes) == {"AdvectionRK4", "AdvectionRK4_3D", "AdvectionRK45", "AdvectionDiffusionM1"}
+    for key, v in hashes.items():
+        assert len(v["code_hash"]) == 16 and v["code_bytes"] > 1000 and "advect" in v["kernel"]
+        assert bench.counters_stale(key, {"code_hash": v["code_hash"], "source_hash": "something else"}) is False
+        assert bench.counters_stale(key, {"code_hash": "0" * 16, "source_hash": bench.kernel_source_hash()}) is True
+        assert bench.counters_stale(key, {"source_hash": bench.kernel_source_hash()}) is False  # (old summaries: sources decide)
+        assert bench.counters_stale(key, {"source_hash": "something else"}) is True
