@@ -100,6 +100,9 @@ const char* pk_last_error(const pk_ctx* ctx); /* ctx may be NULL: error of the l
  *   "fast_cgrid"       1 (default) AdvectionRK4 / AdvectionRK4_3D with CGrid_Velocity on a spherical curvilinear grid with float64
  *                      node coordinates run the dedicated kernels of csrc/pk_fast_cgrid.h (needs "cell_table"; 256 B more per
  *                      cell); 0 = the general program
+ *   "velocity_pairs"   1 (default) the 2-D kernels of "fast_cgrid" read cell-packed copies of the staggered velocity, one 8-value group
+ *                      per cell and pair of adjacent resident time levels (32 B per cell and ring slot more for float32 fields; made on
+ *                      the device ahead of a launch; without the memory for them, or with 0, the kernels read the level rings)
  *   "special_programs" 1 (default) single-kernel programs for AdvectionRK45 / AdvectionDiffusionM1; 0 = kernel-list interpreter
  *   "cell_cache"       1 (default) per-lane LDS cache of the curvilinear cell;  "hash_directory" 1 (default) key directory;
  *                      "cell_table" 1 (default) per-cell table of the query-independent part of the point-in-cell test (192 B per
@@ -108,7 +111,7 @@ const char* pk_last_error(const pk_ctx* ctx); /* ctx may be NULL: error of the l
  *   "eval_points_f32"  0 (default); 1 = the y / x / z handed to pk_eval are float32 particle columns widened to double: the reference then
  *                      forms np.cos(np.deg2rad(y)) -- and, with float32 coordinate arrays, the barycentric coordinates -- in float32
  *                      (what a fused launch does for the default float32 Particle); set around the pk_eval calls it applies to
- * Environment variables PK_NO_FAST, PK_NO_FAST_CGRID, PK_NO_SPECIAL, PK_NO_CELL_CACHE, PK_NO_HASH_DIR, PK_NO_CELL_TABLE, PK_SORT_HORIZONTAL give the initial
+ * Environment variables PK_NO_FAST, PK_NO_FAST_CGRID, PK_NO_VELOCITY_PAIRS, PK_NO_SPECIAL, PK_NO_CELL_CACHE, PK_NO_HASH_DIR, PK_NO_CELL_TABLE, PK_SORT_HORIZONTAL give the initial
  * values. */
 int32_t pk_set_option(pk_ctx* ctx, const char* name, int32_t value);
 
