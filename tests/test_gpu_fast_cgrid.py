@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 PROGRAM_FAST_CGRID = 101
 
 
-def _run(case, fast, nslots=None, endtime=None, probe=None, sort=False):
+def _run(case, fast, nslots=None, endtime=None, probe=None, sort=False, pairs=True):
     import warnings
 
     import parcels_amd as pa
@@ -26,6 +26,8 @@ def _run(case, fast, nslots=None, endtime=None, probe=None, sort=False):
     fs = build_fieldset(case)
     fs.__dict__["_engine"] = DeviceEngine(fs, nslots=nslots, neighbour_probe=probe or 0)  # what FieldSet.to_device does, plus the probe switch
     fs._engine.ctx.set_option("fast_cgrid", 1 if fast else 0)
+    if not pairs:  # the 2-D kernels read the level rings instead of the cell-packed pair copies (include/parcels_hip.h: "velocity_pairs")
+        fs._engine.ctx.set_option("velocity_pairs", 0)
     pset = build_pset(case, fs, sort_by_cell=sort)
     if case.get("populate", True):
         pset.populate_indices()
@@ -83,6 +85,37 @@ def test_rk45_on_the_fast_evaluation_equals_the_general_program(gpu, sdt, delete
     case["context"] = {"RK45_tol": 30.0, "RK45_min_dt": 60.0, "RK45_max_dt": 4 * 3600.0}
     fast, st = _check(case, rtol=5e-7 if sdt == "float32" else 1e-12)
     assert st["attempts"] > st["steps"], "no attempt was rejected: the test does not test the Repeat loop"
+
+
+def test_velocity_pairs_and_level_rings_give_the_same_bits(gpu):
+    """The 2-D kernels read the staggered velocity from cell-packed pair copies (FastC::vp: both levels of a cell in one line) or, without
+    the memory for them / with the option off, from the level rings: same values, same trajectories.  AdvectionRK45 on resident levels;
+    AdvectionRK4 through a ring of 3 with release times spread over the levels, some exactly ON a level (the highest resident level has
+    no pair of its own: upper half of the pair below), several launches."""
+    from oracle import cases
+
+    case = cases.curv_cgrid_case("fastc_pairs", mesh="spherical", kernels=["AdvectionRK45", "DeleteParticle"], seed=22, npart=2500, with_w=False,
+                                 dt=1800.0, runtime=20 * 3600.0, vel=2.5)
+    case["context"] = {"RK45_tol": 30.0, "RK45_min_dt": 60.0, "RK45_max_dt": 4 * 3600.0}
+    on, err_on, st_on = _run(case, True)
+    off, err_off, st_off = _run(case, True, pairs=False)
+    assert err_on == err_off
+    assert st_on["program"] == PROGRAM_FAST_CGRID and st_off["program"] == PROGRAM_FAST_CGRID
+    assert st_on["steps"] == st_off["steps"] and st_on["attempts"] == st_off["attempts"]
+    compare(on, off, rtol=0.0, check_state="all", label="pair copies vs level rings", skip=())
+
+    case = cases.curv_cgrid_case("fastc_pairs_ring", mesh="spherical", kernels=["AdvectionRK4", "DeleteParticle"], seed=23, nt=6, npart=4000, dt=3600.0,
+                                 runtime=None, vel=1.5)
+    n = len(case["x"])
+    case["t0"] = np.random.default_rng(3).uniform(0, 3 * 86400.0, n)
+    case["t0"][::5] = 86400.0 * (np.arange(len(case["t0"][::5])) % 3)  # some exactly on a level
+    case["endtime"] = 4.5 * 86400.0
+    case["runtime"] = None
+    on, err_on, st_on = _run(case, True, nslots=3, endtime=case["endtime"], sort=True)
+    off, err_off, st_off = _run(case, True, nslots=3, endtime=case["endtime"], sort=True, pairs=False)
+    assert err_on is None and err_off is None and st_on["launches"] > 1
+    assert st_on["program"] == PROGRAM_FAST_CGRID and st_off["program"] == PROGRAM_FAST_CGRID
+    compare(on, off, rtol=0.0, check_state="all", label="pair copies vs level rings, ring of 3", skip=())
 
 
 @pytest.mark.parametrize("kh", ["node4d", "node2d"])
