@@ -718,6 +718,8 @@ class DeviceEngine:
             decision = self._repeat_decision(pass_err, pass_twk, cap)
             if decision == "key":
                 keys = sorted(k for k in keys if k < pass_twk) + [pass_twk]
+                if len(keys) > _hip.PK_MAX_TWE:  # (the same stop, at the same agreement, as the shards that hold particles)
+                    raise RuntimeError(f"more than {_hip.PK_MAX_TWE} call-wide time errors in one Kernel.execute")
                 cap = 0
             elif decision == "cap":
                 cap = pass_err
@@ -819,14 +821,17 @@ def _engine_search(self, igrid, z, y, x):
 DeviceEngine.search = _engine_search
 
 
-def raise_particle_errors(data: dict):
-    """kernel.py:236-245: raise for the first error code present, in ErrorsToThrow order."""
+def raise_particle_errors(data: dict, first_code=None):
+    """kernel.py:236-245: raise for the first error code present, in ErrorsToThrow order.  ``first_code`` (a sharded ParticleSet): the
+    first code of the WHOLE batch -- every rank raises that one, with the particles of its own shard that carry it (possibly none)."""
     from .statuscodes import ErrorsToThrow
 
     state = data["state"]
     for code, fn in ErrorsToThrow.items():
         inds = state == code
-        if np.any(inds):
+        if first_code is not None and code != int(first_code):
+            continue
+        if np.any(inds) or first_code is not None:
             if code == StatusCode.ErrorOutsideTimeInterval:
                 fn(data["t"][inds])
             else:

@@ -646,6 +646,10 @@ class NetCDF3File:
                 raise ValueError(f"{self.path}: not a classic NetCDF file")
             try:
                 self._parse_header(head)
+                # byte slices (names, attribute values) never raise when the prefix ends inside them: an item that straddles the end of
+                # the prefix shows as a parse offset beyond it
+                if self._p > len(head):
+                    raise IndexError("header item beyond the prefix")
                 break
             except (struct.error, IndexError, KeyError, UnicodeDecodeError):
                 if want >= size:

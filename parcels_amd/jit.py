@@ -1188,6 +1188,11 @@ class UserProgram:
 
     _failed: dict = {}  # digest -> compiler message: a module that did not compile is not compiled again by every pset.execute
 
+    @classmethod
+    def clear_failed(cls):
+        """Forget remembered compilation failures (e.g. after fixing the toolchain of a long-running process)."""
+        cls._failed.clear()
+
     def build(self):
         if os.path.exists(self.path):
             return self.path
@@ -1204,8 +1209,12 @@ class UserProgram:
                f"-I{_CSRC}", f"-I{_INCLUDE}", src, "-o", tmp]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
-            UserProgram._failed[self.digest] = f"hipcc failed on the generated user-kernel module {src}:\n{r.stderr[-4000:]}"
-            raise RuntimeError(UserProgram._failed[self.digest])
+            msg = f"hipcc failed on the generated user-kernel module {src}:\n{r.stderr[-4000:]}"
+            # only a verdict of the COMPILER on this source is remembered; a transient failure (no space left in the cache directory, a
+            # signal, hipcc itself missing -> OSError above) is tried again by the next pset.execute
+            if r.returncode > 0 and "error:" in r.stderr and "No space left" not in r.stderr:
+                UserProgram._failed[self.digest] = msg
+            raise RuntimeError(msg)
         os.replace(src, self.path[:-3] + ".hip")  # (kept next to the module: what was compiled)
         os.replace(tmp, self.path)
         return self.path

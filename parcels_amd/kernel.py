@@ -241,13 +241,14 @@ class Kernel:
         sc = stats["state_counts"]
         return StatusCode.Delete in sc and StatusCode.StopAllExecution not in sc and not any(c >= StatusCode.Error for c in sc)
 
-    def finish_on_host(self, pset):
-        """kernel.py:233-245 after the columns are back on the host: compact deleted particles, raise error codes."""
+    def finish_on_host(self, pset, first_code=None):
+        """kernel.py:233-245 after the columns are back on the host: compact deleted particles, raise error codes (``first_code``: the
+        first code to raise over ALL shards of a collective run, so that every rank raises the same exception type)."""
         data = pset._data
         deleted = data["state"] == StatusCode.Delete
         if np.any(deleted):
             pset.remove_indices(np.where(deleted)[0])
-        raise_particle_errors(pset._data)
+        raise_particle_errors(pset._data, first_code=first_code)
 
     def execute(self, pset, endtime, dt):
         """Advance every particle to ``endtime`` on the device (kernel.py:174-247), host columns in, host columns out."""

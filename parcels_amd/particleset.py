@@ -351,23 +351,25 @@ class ParticleSet:
                             elif kern.needs_host_pass(stats):
                                 engine.d2h()
                                 synced = True
-                                kern.finish_on_host(self)  # compacts / raises
+                                shard_codes = stats.get("codes_any_shard") if stats is not None else None
+                                kern.finish_on_host(self, first_code=shard_codes[0] if shard_codes else None)  # compacts / raises
                                 if len(self) > 0:
                                     engine.bind_particles(self._data)
                                     engine.h2d()
                         if stats is not None and stats.get("codes_any_shard"):
                             # a particle of ANOTHER shard ended the call in an error state: the reference raises for the batch (kernel.py:
                             # 236-245) -- this rank had nothing to raise above, so it raises the same exception here
-                            from .statuscodes import ErrorsToThrow
+                            from .statuscodes import ErrorsToThrow, StatusCode
 
-                            code = stats["codes_any_shard"][0]
+                            code = int(stats["codes_any_shard"][0])  # (StatusCode is a table of integers, not an enum)
                             empty = np.empty(0)
                             if not synced and len(self) > 0:
                                 engine.d2h()
                                 synced = True
                             if code == StatusCode.ErrorOutsideTimeInterval:
-                                ErrorsToThrow[StatusCode(code)](empty)
-                            ErrorsToThrow[StatusCode(code)](empty, empty, empty)
+                                ErrorsToThrow[code](empty)
+                            else:
+                                ErrorsToThrow[code](empty, empty, empty)
                         if collective:  # the reference's `if len(pset) == 0: break`, decided over all shards
                             from .distributed import allreduce_scalars
 

@@ -376,3 +376,75 @@ def test_shards_are_one_batch_for_the_error_stop_and_the_time_error(world):
         assert cap == 5 and keys == [k5] and codes == [70] and reran == 2, (rank, res[rank])
         if rank < 2:
             assert passes == [(0, []), (0, [k5]), (5, [k5])], (rank, passes)
+
+
+# ---- every rank raises the exception of the BATCH (round-4 ADVICE: the rank without the erring particle raised TypeError) ----------
+def _raise_launch_factory(codes_by_rank):
+    def launch(self, pset, endtime, dt, have_guess0=0):
+        from parcels_amd import StatusCode
+        from parcels_amd.distributed import batch_agreement
+        from parcels_amd.engine import DeviceEngine
+
+        d = pset._engine().data
+        d["state"][:] = StatusCode.Evaluate
+        mine = codes_by_rank.get(dist.get_rank(), [])
+        for k, code in enumerate(mine):
+            d["state"][k] = code
+        counts = {int(c): 1 for c in mine}
+        _, agree_codes = batch_agreement()
+        present = agree_codes([1 if counts.get(code) else 0 for code in DeviceEngine._RAISING_CODES])
+        return {"state_counts": counts or {int(StatusCode.Evaluate): len(d["state"])}, "steps": 1, "kernel_ms": 0.0, "sort_ms": 0.0, "launches": 1,
+                "attempts": 0, "codes_any_shard": [c for c, p in zip(DeviceEngine._RAISING_CODES, present) if p]}
+
+    return launch
+
+
+def _raise_worker(rank, world, port, path, codes_by_rank, q):
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import warnings
+
+        import parcels_amd as pa
+        from parcels_amd.kernel import Kernel
+
+        fs = _make_fieldset()
+        ids = np.arange(40)
+        pset = pa.ParticleSet(fs, x=ids * 0.1, y=ids * 0.0, z=ids * 0.0, t=np.zeros(40), shard="auto")
+        eng = _HostEngine()
+        pset._engine = lambda: eng
+        pset.async_output = False
+        Kernel.launch = _raise_launch_factory(codes_by_rank)
+        raised = None
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                pset.execute([pa.AdvectionRK4], dt=600.0, runtime=3600.0, output_file=pa.ParticleFile(path, outputdt=600.0))
+        except Exception as e:  # noqa: BLE001 -- the test compares the TYPE every rank ends with
+            raised = type(e).__name__
+        q.put((rank, raised))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("codes_by_rank,expect", [({0: [60]}, "FieldOutOfBoundError"), ({1: [70]}, "OutsideTimeInterval"),
+                                                    ({0: [60], 1: [70]}, "OutsideTimeInterval"), ({1: [52, 61]}, "FieldOutOfBoundSurfaceError")])
+def test_every_rank_raises_the_exception_of_the_batch(tmp_path, codes_by_rank, expect):
+    """Only one shard holds the erring particle (or the shards hold different codes): every rank must raise the SAME exception type, the
+    first of ErrorsToThrow over all shards (kernel.py:31-38, 236-245)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_raise_worker, args=(r, world, port, str(tmp_path / "o.parquet"), codes_by_rank, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0, "a rank hung or failed"
+    res = dict(q.get(timeout=10) for _ in range(world))
+    assert res == {0: expect, 1: expect}, res

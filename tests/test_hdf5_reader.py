@@ -136,6 +136,15 @@ def test_classic_netcdf3_long_header_and_streaming_record_count(tmp_path):
     g = NetCDF3File(p)
     assert g.numrecs == NT and np.array_equal(g.read("U", NT - 1), F32[NT - 1, 0, 0])
     g.close()
+    # a header whose LAST item is a byte slice that straddles the prefix (no variables behind the attribute): slices do not raise
+    # when cut short, the parse offset beyond the prefix is what asks for the longer read
+    p2 = str(tmp_path / "attr_only.nc")
+    with netcdf_file(p2, "w", version=2) as nc:
+        nc.createDimension("x", NX)
+        nc.history = "h" * (5 << 20)
+    h = NetCDF3File(p2)
+    assert len(h.gattrs["history"]) == 5 << 20
+    h.close()
     q = tmp_path / "cut.nc"
     q.write_bytes(bytes(raw[:1000]))
     with pytest.raises(ValueError, match="truncated or malformed"):
