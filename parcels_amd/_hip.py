@@ -13,7 +13,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PARCELS_HIP_LIB", os.path.join(_HERE, "libparcels_hip.so"))  # override: A/B builds
 
-PK_ABI_VERSION = 7
+PK_ABI_VERSION = 8
 PK_F32, PK_F64 = 0, 1
 PK_MAX_GRIDS, PK_MAX_FIELDS, PK_MAX_KERNELS, PK_NUM_STATE_CODES = 4, 64, 8, 80
 PK_MAX_EXTRA = 8
@@ -175,6 +175,10 @@ class ExecStats(C.Structure):
         ("program", C.c_int32),
         ("first_error_iter", C.c_int64),
         ("first_time_error_key", C.c_int64),
+        ("pack_ms", C.c_double),
+        ("packs", C.c_int32),
+        ("pad0", C.c_int32),
+        ("sclk_mhz", C.c_double),
     ]
 
 

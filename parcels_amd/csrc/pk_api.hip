@@ -54,6 +54,8 @@ struct pk_ctx {
     int device = 0;
     hipStream_t compute = nullptr, copy = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr;  // around the pair-copy packing of a launch (ensure_velocity_pairs)
+    int fl_packs = 0;                             // pairs packed ahead of the launch in flight
     bool copy_pending = false;
     std::string err;
     std::vector<HostGrid> grids;
@@ -112,6 +114,8 @@ struct pk_ctx {
     unsigned long long* d_twe = nullptr;      // PK_MAX_TWE keys: the failing samples a launch knows (pk_exec_params.twe_key)
     std::vector<int64_t> rerun_keys;          // the keys of the last launch (pk_execute_rerun repeats it with them)
     unsigned long long* h_summary = nullptr;  // pinned
+    unsigned long long* d_clk = nullptr;      // clock probes around the advection kernel: [before | after][XCD 0..7]{shader-clock counter, 100 MHz counter}
+    unsigned long long* h_clk = nullptr;      // pinned
     int sort_horizontal_major = -1;  // tuning knobs (environment: PK_SORT_HORIZONTAL = 0/1 forces, PK_NO_SPECIAL, PK_NO_CELL_CACHE)
     int no_special = 0;
     bool eval_points_f32 = false;  // pk_eval: the sample points are float32 particle columns (np.cos(np.deg2rad(y)) is then a float32 cosine)
@@ -149,7 +153,8 @@ struct pk_ctx {
     int vp_fU = -1, vp_fV = -1;
     std::vector<int32_t> vp_level;        // pair held by every pair slot, -1 = none
     std::vector<uint64_t> vp_gen;         // 4 stamps per pair slot: U and V uploads of both levels it was packed from
-    int no_velocity_pairs = 0;
+    int no_velocity_pairs = 1;  // OPT-IN since round 5 (option "velocity_pairs" / PK_VELOCITY_PAIRS=1): packing a pair costs more than the
+                                // launch it serves saves at BASELINE config 5 (pk_exec_stats.pack_ms)
     uint64_t upload_counter = 0;
     double* d_cg_tab = nullptr;
     size_t cg_tab_cap = 0;
@@ -182,6 +187,16 @@ PK_DEV unsigned long long order_double(double v) {  // order-preserving map doub
 }
 
 // histogram of `state` + min/max of t over particles still in Evaluate
+// Clock probe: one wavefront per XCD (workgroups are dealt round-robin over the 8 XCDs) reads the shader-clock cycle counter (s_memtime) and the
+// constant 100 MHz counter (s_memrealtime) of ITS XCD; two probes around a kernel give the average shader clock the kernel ran at --
+// which is what reconciles a bench line with a rocprofv3 trace taken at another clock (bench.py: `sclk_mhz`).
+__global__ void __launch_bounds__(64) clock_probe_kernel(unsigned long long* out) {
+    if (threadIdx.x != 0) return;
+    const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7u;  // HW_REG_XCC_ID[3:0]
+    out[xcc * 2] = __builtin_readcyclecounter();
+    out[xcc * 2 + 1] = __builtin_amdgcn_s_memrealtime();
+}
+
 __global__ void __launch_bounds__(256) summarize_kernel(const int32_t* state, const double* t, int64_t n,
                                                         unsigned long long* out) {
     __shared__ unsigned int hist[PK_NUM_STATE_CODES];
@@ -575,6 +590,7 @@ int32_t pk_init(int32_t device, pk_ctx** out) {
     if (const char* e = getenv("PK_NO_FAST")) ctx->no_fast = atoi(e);
     if (const char* e = getenv("PK_NO_FAST_CGRID")) ctx->no_fast_cgrid = atoi(e);
     if (const char* e = getenv("PK_NO_VELOCITY_PAIRS")) ctx->no_velocity_pairs = atoi(e);
+    if (const char* e = getenv("PK_VELOCITY_PAIRS")) ctx->no_velocity_pairs = !atoi(e);
     *out = ctx;
     PK_HIP(ctx, hipSetDevice(device));
     PK_HIP(ctx, hipGetDeviceProperties(&ctx->prop, device));
@@ -583,12 +599,16 @@ int32_t pk_init(int32_t device, pk_ctx** out) {
     PK_HIP(ctx, hipEventCreate(&ctx->ev0));
     PK_HIP(ctx, hipEventCreate(&ctx->ev1));
     PK_HIP(ctx, hipEventCreate(&ctx->ev2));
+    PK_HIP(ctx, hipEventCreate(&ctx->ev_p0));
+    PK_HIP(ctx, hipEventCreate(&ctx->ev_p1));
     for (int k = 0; k < PK_STAGE_BUFFERS; k++) PK_HIP(ctx, hipEventCreateWithFlags(&ctx->stage_ev[k], hipEventDisableTiming));
     PK_HIP(ctx, hipMalloc((void**)&ctx->d_counters, sizeof(DCounters)));
     PK_HIP(ctx, hipMalloc((void**)&ctx->d_twe, sizeof(unsigned long long) * PK_MAX_TWE));
     PK_HIP(ctx, hipMalloc((void**)&ctx->d_summary, sizeof(unsigned long long) * (PK_NUM_STATE_CODES + 2)));
     PK_HIP(ctx, hipHostMalloc((void**)&ctx->h_counters, sizeof(DCounters), hipHostMallocDefault));
     PK_HIP(ctx, hipHostMalloc((void**)&ctx->h_summary, sizeof(unsigned long long) * (PK_NUM_STATE_CODES + 2), hipHostMallocDefault));
+    PK_HIP(ctx, hipMalloc((void**)&ctx->d_clk, sizeof(unsigned long long) * 32));
+    PK_HIP(ctx, hipHostMalloc((void**)&ctx->h_clk, sizeof(unsigned long long) * 32, hipHostMallocDefault));
     return 0;
 }
 
@@ -687,6 +707,8 @@ int32_t pk_destroy(pk_ctx* ctx) {
     if (ctx->d_summary) (void)hipFree(ctx->d_summary);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->h_summary) (void)hipHostFree(ctx->h_summary);
+    if (ctx->d_clk) (void)hipFree(ctx->d_clk);
+    if (ctx->h_clk) (void)hipHostFree(ctx->h_clk);
     for (int k = 0; k < PK_STAGE_BUFFERS; k++) {
         if (ctx->stage[k]) (void)hipHostFree(ctx->stage[k]);
         if (ctx->stage_ev[k]) (void)hipEventDestroy(ctx->stage_ev[k]);
@@ -694,6 +716,8 @@ int32_t pk_destroy(pk_ctx* ctx) {
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
+    if (ctx->ev_p0) (void)hipEventDestroy(ctx->ev_p0);
+    if (ctx->ev_p1) (void)hipEventDestroy(ctx->ev_p1);
     if (ctx->compute) (void)hipStreamDestroy(ctx->compute);
     if (ctx->copy) (void)hipStreamDestroy(ctx->copy);
     delete ctx;
@@ -1822,7 +1846,13 @@ static void ensure_velocity_pairs(pk_ctx* ctx, const pk_exec_params* prm, FastC&
         ctx->vp_bytes = need;
         ctx->vp_level.assign(ns, -1);
         ctx->vp_gen.assign((size_t)ns * 4, 0);
-        if (hipMalloc((void**)&ctx->d_vp, need) != hipSuccess) {
+        // an opportunistic allocation must not starve what the run needs later (checkpoints, snapshots, further fields): it is made only
+        // while it leaves a quarter of the device memory -- and at least its own size again -- free
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + std::max(need, total_b / 4)) {
+            (void)hipGetLastError();
+            ctx->d_vp = nullptr;
+        } else if (hipMalloc((void**)&ctx->d_vp, need) != hipSuccess) {
             (void)hipGetLastError();
             ctx->d_vp = nullptr;
         }
@@ -1839,6 +1869,7 @@ static void ensure_velocity_pairs(pk_ctx* ctx, const pk_exec_params* prm, FastC&
         count++;
     }
     if (lo < 0 || hi == lo || count != hi - lo + 1) return;
+    bool timing = false;
     for (int L = lo; L < hi; L++) {
         const int s0 = L % ns, s1 = (L + 1) % ns, ps = L % ns;
         const uint64_t g[4] = {U.slot_gen[s0], U.slot_gen[s1], V.slot_gen[s0], V.slot_gen[s1]};
@@ -1847,6 +1878,10 @@ static void ensure_velocity_pairs(pk_ctx* ctx, const pk_exec_params* prm, FastC&
         const int64_t n = f.st_t;
         const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 256 * 64);
         char* out = ctx->d_vp + (size_t)ps * slot_b;
+        if (!timing) {
+            (void)hipEventRecord(ctx->ev_p0, ctx->compute);
+            timing = true;
+        }
         const int64_t o0 = (int64_t)s0 * F.lvl_b, o1 = (int64_t)s1 * F.lvl_b;
         if (esz == 8)
             hipLaunchKernelGGL((cg_pack_pairs_kernel<double>), dim3(grid), dim3(256), 0, ctx->compute, F.U, F.V, F.dU0, F.dU1, F.dV0, F.dV1, cb, o0, o1, n,
@@ -1857,7 +1892,9 @@ static void ensure_velocity_pairs(pk_ctx* ctx, const pk_exec_params* prm, FastC&
         if (hipGetLastError() != hipSuccess) return;  // (the level rings serve)
         ctx->vp_level[ps] = L;
         for (int k = 0; k < 4; k++) have[k] = g[k];
+        ctx->fl_packs++;
     }
+    if (timing) (void)hipEventRecord(ctx->ev_p1, ctx->compute);
     F.vp_hi = hi;
     // every pair inside the window a launch may touch is packed now: the resident window is made of committed levels only
     F.vp = ctx->d_vp;
@@ -2203,8 +2240,16 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
             for (const auto& c : cp)
                 if (c.dst && c.src) PK_HIP(ctx, hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyDeviceToDevice, ctx->compute));
         }
+        PK_HIP(ctx, hipMemsetAsync(ctx->d_clk, 0, sizeof(unsigned long long) * 32, ctx->compute));
+        hipLaunchKernelGGL(clock_probe_kernel, dim3(16), dim3(64), 0, ctx->compute, ctx->d_clk);
         PK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->compute));
-        const size_t fast_lds = fast_a ? (size_t)a.fast.lds_n * 2 * sizeof(double) : 0;
+        // the A-grid kernel's LDS: the coordinate tables and, behind them (2-D kernels), 64 bytes per lane of corner-block cache
+        size_t fast_lds = fast_a ? (size_t)a.fast.lds_n * 2 * sizeof(double) : 0;
+        if (fast_a) {
+            const bool blk = prog != PROG_RK4_3D && fast_lds + (size_t)FAST_BLK_BYTES <= 64 * 1024 && !getenv("PK_NO_BLOCK_CACHE");
+            a.fast.lds_blk = blk ? a.fast.lds_n : 0;
+            if (blk) fast_lds += (size_t)FAST_BLK_BYTES;
+        }
         const int pf32 = ctx->dev.spatial_f32;
         if (has_user && fast_a) ctx->user_launch(&a, prog == PROG_RK4_3D ? 2 : 1, field_f32 * 2 + pf32, 1, (uint64_t)fast_lds, (void*)ctx->compute);
         else if (has_user && fast_c) ctx->user_launch(&a, prog == PROG_RK4_3D ? 4 : 3, field_f32 * 2 + pf32, 1, (uint64_t)cgrid_lds, (void*)ctx->compute);
@@ -2230,6 +2275,8 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
         }
         PK_HIP(ctx, hipGetLastError());
         PK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->compute));
+        hipLaunchKernelGGL(clock_probe_kernel, dim3(16), dim3(64), 0, ctx->compute, ctx->d_clk + 16);
+        PK_HIP(ctx, hipMemcpyAsync(ctx->h_clk, ctx->d_clk, sizeof(unsigned long long) * 32, hipMemcpyDeviceToHost, ctx->compute));
         launches = 1;
         ctx->fl_program = fast_a ? 100 : (fast_c ? 101 : prog);
         swap_launch_outputs(ctx);
@@ -2282,7 +2329,25 @@ int32_t pk_execute_end(pk_ctx* ctx, pk_exec_stats* stats) {
         stats->program = ctx->fl_launches ? ctx->fl_program : 0;
         stats->first_error_iter = (ctx->fl_launches && hc.err_iter != 0xFFFFFFFFu) ? (int64_t)hc.err_iter : 0;
         stats->first_time_error_key = (ctx->fl_launches && hc.twe_key != ~0ull) ? (int64_t)hc.twe_key : 0;
+        // average shader clock of the advection kernel: cycle-counter / 100 MHz-counter deltas of the XCDs both probes reached
+        double sclk = 0.0;
+        int nx = 0;
+        if (ctx->fl_launches) {
+            for (int x = 0; x < 8; x++) {
+                const unsigned long long c0 = ctx->h_clk[x * 2], r0 = ctx->h_clk[x * 2 + 1], c1 = ctx->h_clk[16 + x * 2], r1 = ctx->h_clk[16 + x * 2 + 1];
+                if (c0 && c1 && r1 > r0 && c1 > c0) {
+                    sclk += (double)(c1 - c0) / (double)(r1 - r0) * 100.0;
+                    nx++;
+                }
+            }
+        }
+        stats->sclk_mhz = nx ? sclk / nx : 0.0;
+        float pms = 0.f;
+        if (ctx->fl_packs) PK_HIP(ctx, hipEventElapsedTime(&pms, ctx->ev_p0, ctx->ev_p1));
+        stats->pack_ms = pms;
+        stats->packs = ctx->fl_packs;
     }
+    ctx->fl_packs = 0;
     return 0;
 }
 

@@ -108,7 +108,7 @@ struct FastA {
     uint32_t st_z, st_y;                        // element strides of the fields inside a level (st_x == 1)
     uint32_t dyb, dzb;                          // byte strides to the yi+1 row / zi+1 plane, 0 if the fields have no such neighbour
     int32_t lds_time, lds_depth, lds_lat, lds_lon, lds_n;  // offsets (in pairs) of the {a, 1/width} tables inside `tab`
-    int32_t pad0;
+    int32_t lds_blk;                            // offset (in pairs) of the per-lane corner-block cache behind the tables, 0 = none (pk_fast_agrid.h)
     int64_t lvl_b;                              // bytes per time level (< 2^32)
     const char *U, *V, *W;                      // level rings (W may be NULL)
     const double* tab;                          // global copy of the interleaved coordinate tables: time | depth | lat | lon

@@ -26,7 +26,10 @@ struct FastTabs {  // LDS-resident {a, 1/width} tables of the main grid and the 
     const pk_tab2* depth;
     const pk_tab2* lat;
     const pk_tab2* lon;
+    pk_tab2* blk;  // this lane's corner-block cache (FCtx::bei): 4 x 16 bytes at stride FAST_WG, NULL = none
 };
+constexpr int FAST_WG = 256;                          // lanes per workgroup of advect_fast_kernel
+constexpr int FAST_BLK_BYTES = FAST_WG * 8 * 8;       // LDS of the corner-block cache per workgroup (8 doubles per lane)
 
 // clip(searchsorted(arr, x, "left") - 1, 0, n-2) over the interleaved table (same walk + bisect as cell_index)
 PK_DEV int cell_index_tab(const pk_tab2* tab, int n, double x, int i) {
@@ -147,9 +150,10 @@ PK_DEV void load_rows(Rows& r, const char* l0, const char* l1, uint32_t b00, uin
     }
 }
 // lerp in t, then z, then bilinear in (eta, xsi) with the weights (1-xsi)(1-eta), xsi(1-eta), (1-xsi)eta, xsi*eta shared by U, V, W
+// (lerp_rows: the t / z part -- a function of the cell and of (t, z) only; interp_rows: all of it)
 template <bool LT, bool LZ>
-PK_DEV double interp_rows(const Rows& r, double tau, double omt, double zeta, double omz, double w00, double w01, double w10, double w11) {
-    double c00 = r.c00, c01 = r.c01, c10 = r.c10, c11 = r.c11;
+PK_DEV void lerp_rows(const Rows& r, double tau, double omt, double zeta, double omz, double& c00, double& c01, double& c10, double& c11) {
+    c00 = r.c00; c01 = r.c01; c10 = r.c10; c11 = r.c11;
     if (LT) {
         c00 = c00 * omt + r.t00 * tau; c01 = c01 * omt + r.t01 * tau;
         c10 = c10 * omt + r.t10 * tau; c11 = c11 * omt + r.t11 * tau;
@@ -163,6 +167,11 @@ PK_DEV double interp_rows(const Rows& r, double tau, double omt, double zeta, do
         c00 = c00 * omz + d00 * zeta; c01 = c01 * omz + d01 * zeta;
         c10 = c10 * omz + d10 * zeta; c11 = c11 * omz + d11 * zeta;
     }
+}
+template <bool LT, bool LZ>
+PK_DEV double interp_rows(const Rows& r, double tau, double omt, double zeta, double omz, double w00, double w01, double w10, double w11) {
+    double c00, c01, c10, c11;
+    lerp_rows<LT, LZ>(r, tau, omt, zeta, omz, c00, c01, c10, c11);
     return w00 * c00 + w01 * c01 + w10 * c10 + w11 * c11;
 }
 
@@ -172,9 +181,12 @@ PK_DEV double interp_rows(const Rows& r, double tau, double omt, double zeta, do
 #ifndef PK_FAST_BATCH
 #define PK_FAST_BATCH 8
 #endif
+#ifndef PK_FAST_BLOCK_CACHE
+#define PK_FAST_BLOCK_CACHE 1  // FCtx::bei (0: A/B builds without the corner-block cache)
+#endif
 template <class FT, bool D3, bool LT, bool LZ>
 PK_DEV void uvw_fast(const FastA& F, int64_t o0, int64_t o1, uint32_t b00, double tau, double omt, double zeta, double omz, double w00,
-                     double w01, double w10, double w11, double& uu, double& vv, double& ww) {
+                     double w01, double w10, double w11, double& uu, double& vv, double& ww, pk_tab2* blk) {
     // keep the 32-bit lane offset opaque up to here: its zero-extension must sit in the basic block of the loads for the
     // instruction selector to fold it into the `saddr + voffset` addressing mode (otherwise one 64-bit VALU add per load)
     uint32_t bo = b00;
@@ -187,14 +199,28 @@ PK_DEV void uvw_fast(const FastA& F, int64_t o0, int64_t o1, uint32_t b00, doubl
 #if PK_FAST_BATCH >= 8
     PK_FIELD_FENCE();
 #endif
-    uu = interp_rows<LT, LZ>(ru, tau, omt, zeta, omz, w00, w01, w10, w11);
+    // the t / z-lerped corner blocks of U and V go to the lane's block cache (FCtx::bei) as soon as they exist; blk: wave-uniform NULL or not
+    double c00, c01, c10, c11;
+    lerp_rows<LT, LZ>(ru, tau, omt, zeta, omz, c00, c01, c10, c11);
+    if (!D3 && blk) {
+        pk_tab2 b;
+        b.x = c00; b.y = c01; blk[0] = b;
+        b.x = c10; b.y = c11; blk[FAST_WG] = b;
+    }
+    uu = w00 * c00 + w01 * c01 + w10 * c10 + w11 * c11;
 #if PK_FAST_BATCH != 16
     load_rows<FT, LT, LZ>(rv, F.V + o0, F.V + o1, bo, F.dyb, F.dzb);
 #if PK_FAST_BATCH >= 8
     PK_FIELD_FENCE();
 #endif
 #endif
-    vv = interp_rows<LT, LZ>(rv, tau, omt, zeta, omz, w00, w01, w10, w11);
+    lerp_rows<LT, LZ>(rv, tau, omt, zeta, omz, c00, c01, c10, c11);
+    if (!D3 && blk) {
+        pk_tab2 b;
+        b.x = c00; b.y = c01; blk[2 * FAST_WG] = b;
+        b.x = c10; b.y = c11; blk[3 * FAST_WG] = b;
+    }
+    vv = w00 * c00 + w01 * c01 + w10 * c10 + w11 * c11;
     if (D3) {
         load_rows<FT, LT, LZ>(rw, F.W + o0, F.W + o1, bo, F.dyb, F.dzb);
 #if PK_FAST_BATCH >= 8
@@ -216,7 +242,15 @@ struct FCtx {
     int ht, hz, hy, hx;
     int zi;                      // memo: index (or out-of-bounds code) of the last depth searched
     double mt, mtau, mz, mzeta;  // memo keys (bitwise-equal coordinate => same answer) and barycentric values
+    // Corner-block cache (2-D kernels): the t / z-lerped corner values c00..c11 of U and V -- 8 doubles in the lane's LDS slot FastTabs::blk
+    // -- are a function of the cell and of (t, z) only.  Stages 2 and 3 of a Runge-Kutta step share t, stage 4 and stage 1 of the next
+    // step too, their sample points lie a fraction of a cell apart and z does not move: when EVERY lane of the wavefront samples the
+    // cell (`bei`, its ravelled index) at the (mt, mz) its cached block was formed at, the 16 corner loads and the level lerps are skipped
+    // and the bilinear sum runs on the same values -- the same operations, so the same bits (measured: 0.998 / 1.000 of the wave-evaluations
+    // of those two stage pairs on BASELINE config 2).  Invariant: bei >= 0 => the slot holds the block of cell bei at (mt, mz).
+    int32_t bei;
 };
+constexpr int32_t FAST_NO_BLOCK = -0x7fffffff - 1;
 PK_DEV void fctx_init(FCtx& c, int state, int32_t ei) {
     c.state = state;
     c.ei = ei;
@@ -224,13 +258,15 @@ PK_DEV void fctx_init(FCtx& c, int state, int32_t ei) {
     c.zi = 0;
     c.mt = c.mz = __builtin_nan("");  // equal to nothing
     c.mtau = c.mzeta = 0.0;
+    c.bei = FAST_NO_BLOCK;
 }
 
 // VectorField.eval (field.py:250-304) + XLinear_Velocity.interp (_xinterpolators.py:169-190).  PF: the sample point may come
-// straight from float32 particle storage (pos_f32); D3: sample W as well.
+// straight from float32 particle storage (pos_f32); D3: sample W as well.  bmode (wave-uniform; FCtx::bei): bit 0 = this sample may
+// share (t, z) with the previous one -- test the cached corner block; bit 1 = the next one may share them with this one -- keep the block.
 template <class FT, bool PF, bool D3>
 PK_DEV void eval_uvw_fast(const KArgs& a, const FastTabs& T, FCtx& c, double t, double z, double y, double x, bool pos_f32, double& u,
-                          double& v, double& w, unsigned it, int klo) {
+                          double& v, double& w, unsigned it, int klo, int bmode = 0) {
     const FastA& F = a.fast;
     u = v = w = 0.0;
     int ti = 0;
@@ -246,6 +282,7 @@ PK_DEV void eval_uvw_fast(const KArgs& a, const FastTabs& T, FCtx& c, double t, 
             int idx;
             fast_search(T.time, F.nt, F.t0, F.t1, t, c.ht, idx, c.mtau);  // level times start at 0 (host check): idx == c.ht
             c.mt = t;
+            c.bei = FAST_NO_BLOCK;
         }
         ti = c.ht;
         tau = c.mtau;
@@ -256,6 +293,7 @@ PK_DEV void eval_uvw_fast(const KArgs& a, const FastTabs& T, FCtx& c, double t, 
         if (!(z == c.mz)) {
             fast_search(T.depth, F.gnz, F.z0, F.z1, z, c.hz, c.zi, c.mzeta);
             c.mz = z;
+            c.bei = FAST_NO_BLOCK;
         }
         zi = c.zi;
         zeta = c.mzeta;
@@ -280,26 +318,39 @@ PK_DEV void eval_uvw_fast(const KArgs& a, const FastTabs& T, FCtx& c, double t, 
     const double omt = 1 - tau, omz = 1 - zeta, omx = 1 - xsi, ome = 1 - eta;
     const double w00 = omx * ome, w01 = xsi * ome, w10 = omx * eta, w11 = xsi * eta;
     double uu = 0.0, vv = 0.0, ww = 0.0;
-    for (bool done = false; !done;) {
-        // everything derived from the wave-uniform key is formed BEFORE the lane test: inside `if (key == uk)` the optimiser
-        // may substitute the (divergent) key for uk, which would move the level arithmetic back into vector registers
-        const int uk = uniform_i32(key);
-        const int uti = uk >> 2;
-        int s0 = uti, s1 = uti + 1;  // has_ti: 0 <= ti <= nt-2; otherwise ti == 0 and the second level is never read
-        if (F.nslots < F.nt) {       // ring of time levels: level L lives in slot L % nslots
-            s0 = (int)((uint32_t)s0 % (uint32_t)F.nslots);
-            s1 = (int)((uint32_t)s1 % (uint32_t)F.nslots);
+    const bool bc = !D3 && PK_FAST_BLOCK_CACHE && F.lds_blk != 0;
+    // (in-bounds indices ravel to a non-negative `ei` that names the cell; the memo updates above already dropped a block of another (t, z))
+    bool reuse = false;
+    if (bc && (bmode & 1)) reuse = __builtin_amdgcn_ballot_w64(c.ei != c.bei) == 0;  // every active lane: same cell, same (t, z)
+    if (reuse) {
+        const pk_tab2 b0 = T.blk[0], b1 = T.blk[FAST_WG], b2 = T.blk[2 * FAST_WG], b3 = T.blk[3 * FAST_WG];
+        uu = w00 * b0.x + w01 * b0.y + w10 * b1.x + w11 * b1.y;
+        vv = w00 * b2.x + w01 * b2.y + w10 * b3.x + w11 * b3.y;
+    } else {
+        const bool keep = bc && (bmode & 2);
+        pk_tab2* const blk = keep ? T.blk : nullptr;
+        for (bool done = false; !done;) {
+            // everything derived from the wave-uniform key is formed BEFORE the lane test: inside `if (key == uk)` the optimiser
+            // may substitute the (divergent) key for uk, which would move the level arithmetic back into vector registers
+            const int uk = uniform_i32(key);
+            const int uti = uk >> 2;
+            int s0 = uti, s1 = uti + 1;  // has_ti: 0 <= ti <= nt-2; otherwise ti == 0 and the second level is never read
+            if (F.nslots < F.nt) {       // ring of time levels: level L lives in slot L % nslots
+                s0 = (int)((uint32_t)s0 % (uint32_t)F.nslots);
+                s1 = (int)((uint32_t)s1 % (uint32_t)F.nslots);
+            }
+            int64_t o0 = (int64_t)s0 * F.lvl_b, o1 = (int64_t)s1 * F.lvl_b;
+            int lens = uk & 3;
+            asm volatile("" : "+s"(o0), "+s"(o1), "+s"(lens));  // opaque scalars: no path back to the divergent key
+            if (key == uk) {
+                if (lens == 3) uvw_fast<FT, D3, true, true>(F, o0, o1, b00, tau, omt, zeta, omz, w00, w01, w10, w11, uu, vv, ww, blk);
+                else if (lens == 2) uvw_fast<FT, D3, true, false>(F, o0, o1, b00, tau, omt, zeta, omz, w00, w01, w10, w11, uu, vv, ww, blk);
+                else if (lens == 1) uvw_fast<FT, D3, false, true>(F, o0, o1, b00, tau, omt, zeta, omz, w00, w01, w10, w11, uu, vv, ww, blk);
+                else uvw_fast<FT, D3, false, false>(F, o0, o1, b00, tau, omt, zeta, omz, w00, w01, w10, w11, uu, vv, ww, blk);
+                done = true;
+            }
         }
-        int64_t o0 = (int64_t)s0 * F.lvl_b, o1 = (int64_t)s1 * F.lvl_b;
-        int lens = uk & 3;
-        asm volatile("" : "+s"(o0), "+s"(o1), "+s"(lens));  // opaque scalars: no path back to the divergent key
-        if (key == uk) {
-            if (lens == 3) uvw_fast<FT, D3, true, true>(F, o0, o1, b00, tau, omt, zeta, omz, w00, w01, w10, w11, uu, vv, ww);
-            else if (lens == 2) uvw_fast<FT, D3, true, false>(F, o0, o1, b00, tau, omt, zeta, omz, w00, w01, w10, w11, uu, vv, ww);
-            else if (lens == 1) uvw_fast<FT, D3, false, true>(F, o0, o1, b00, tau, omt, zeta, omz, w00, w01, w10, w11, uu, vv, ww);
-            else uvw_fast<FT, D3, false, false>(F, o0, o1, b00, tau, omt, zeta, omz, w00, w01, w10, w11, uu, vv, ww);
-            done = true;
-        }
+        if (keep) c.bei = c.ei;
     }
     if (F.spherical) {  // _xinterpolators.py:183-187
         double conv;
@@ -336,6 +387,7 @@ PK_DEV double eval_scalar_fast(const KArgs& a, const FastTabs& T, FCtx& c, int s
             int idx;
             fast_search(T.time, F.nt, F.t0, F.t1, t, c.ht, idx, c.mtau);
             c.mt = t;
+            c.bei = FAST_NO_BLOCK;
         }
         ti = c.ht;
         tau = c.mtau;
@@ -346,6 +398,7 @@ PK_DEV double eval_scalar_fast(const KArgs& a, const FastTabs& T, FCtx& c, int s
         if (!(z == c.mz)) {
             fast_search(T.depth, F.gnz, F.z0, F.z1, z, c.hz, c.zi, c.mzeta);
             c.mz = z;
+            c.bei = FAST_NO_BLOCK;
         }
         zi = c.zi;
         zeta = c.mzeta;

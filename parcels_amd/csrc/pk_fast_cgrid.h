@@ -103,9 +103,12 @@ template <class FT, bool D3>
 PK_DEV void cg_issue_fields(const FastC& F, int zi, int yi, int xi, int ti, bool lenT, FT raw[12]) {
     const uint32_t e = (uint32_t)zi * (uint32_t)F.st_z + (uint32_t)yi * (uint32_t)F.st_y + (uint32_t)xi;  // < 2^31 elements per level (host check)
     if constexpr (!D3) {
-        if (F.vp) {  // (wave-uniform) the cell-packed pair copy: both levels of the cell in one 8-value group
-            // pair L holds levels (L, L + 1); a sample exactly on the highest resident level (tau == 0: !lenT) has no pair of its own
-            // and reads the upper half of the pair below
+        // (F.vp: wave-uniform) the cell-packed pair copy: both levels of the cell in one 8-value group.
+        // pair L holds levels (L, L + 1); a sample exactly on the highest resident level (tau == 0: !lenT) has no pair of its own
+        // and reads the upper half of the pair below.  A sample BETWEEN the highest resident level and the next one cannot exist (the
+        // window pause of the step loop keeps it out); should that invariant ever break, the lane reads the level rings below instead
+        // of the bytes behind its group.
+        if (F.vp && !(ti >= (int)F.vp_hi && lenT)) {
             const bool last = ti >= (int)F.vp_hi;
             const int pair = last ? ti - 1 : ti;
             int64_t off = 0;

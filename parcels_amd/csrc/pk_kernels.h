@@ -715,6 +715,7 @@ __global__ void __launch_bounds__(256, PK_MIN_WAVES_FAST) advect_fast_kernel(con
         ft.depth = s_tab + a.fast.lds_depth;
         ft.lat = s_tab + a.fast.lds_lat;
         ft.lon = s_tab + a.fast.lds_lon;
+        ft.blk = s_tab + a.fast.lds_blk + threadIdx.x;  // (read only where lds_blk != 0)
     }
     // the row index is re-derived where it is needed (entry and exit) instead of living in two registers across the step loop
     auto row = [&]() { return (int64_t)xcd_swizzle(blockIdx.x, gridDim.x) * 256 + threadIdx.x; };
@@ -775,7 +776,9 @@ __global__ void __launch_bounds__(256, PK_MIN_WAVES_FAST) advect_fast_kernel(con
                         st = pt + cdt * pdt;
                     }
                     double u, v, w;
-                    eval_uvw_fast<FT, pf, D3>(a, ft, c, st, sz, sy, sx, pf && stage == 0, u, v, w, it, adv * 1000 + stage);
+                    // stages 2 / 3 share t, stage 4 and stage 1 of the next step too: the odd evaluations keep their corner block, the even
+                    // ones test it (pk_fast_agrid.h: FCtx::bei)
+                    eval_uvw_fast<FT, pf, D3>(a, ft, c, st, sz, sy, sx, pf && stage == 0, u, v, w, it, adv * 1000 + stage, (stage & 1) ? 2 : 1);
                     if (stage == 0) { su = u; sv = v; sw = w; }
                     else if (stage == 3) { su = su + u; sv = sv + v; sw = sw + w; }
                     else { su = su + 2 * u; sv = sv + 2 * v; sw = sw + 2 * w; }

@@ -581,7 +581,7 @@ class DeviceEngine:
         # host-side split of a streamed run: commit = synchronous level uploads before a launch, prefetch = staging + enqueueing
         # the next level while the kernel runs, wait = pk_execute_end after the prefetch was enqueued
         total = {"steps": 0, "attempts": 0, "kernel_ms": 0.0, "sort_ms": 0.0, "launches": 0, "commit_s": 0.0, "prefetch_s": 0.0, "wait_s": 0.0,
-                 "first_error_iter": 0, "reran": 0, "time_error_keys": []}
+                 "first_error_iter": 0, "reran": 0, "time_error_keys": [], "pack_ms": 0.0, "packs": 0}
         span0 = None
         if resort_every and sort_by_cell:
             ctx_ = context or {}
@@ -643,7 +643,10 @@ class DeviceEngine:
                 total["attempts"] += st.attempts
                 total["kernel_ms"] += st.kernel_ms
                 total["sort_ms"] += st.sort_ms
+                total["pack_ms"] += getattr(st, "pack_ms", 0.0)
+                total["packs"] += getattr(st, "packs", 0)
                 total["launches"] += st.launches
+                total["sclk_mhz"] = float(getattr(st, "sclk_mhz", 0.0))  # shader clock of the (last) launch's kernel
                 total["program"] = int(st.program)  # which device program the (last) launch ran: include/parcels_hip.h, pk_exec_stats
                 counts = {code: int(st.state_counts[code]) for code in range(_hip.PK_NUM_STATE_CODES) if st.state_counts[code]}
                 if st.first_error_iter > 0:

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 PROGRAM_FAST_CGRID = 101
 
 
-def _run(case, fast, nslots=None, endtime=None, probe=None, sort=False, pairs=True):
+def _run(case, fast, nslots=None, endtime=None, probe=None, sort=False, pairs=False):
     import warnings
 
     import parcels_amd as pa
@@ -26,8 +26,8 @@ def _run(case, fast, nslots=None, endtime=None, probe=None, sort=False, pairs=Tr
     fs = build_fieldset(case)
     fs.__dict__["_engine"] = DeviceEngine(fs, nslots=nslots, neighbour_probe=probe or 0)  # what FieldSet.to_device does, plus the probe switch
     fs._engine.ctx.set_option("fast_cgrid", 1 if fast else 0)
-    if not pairs:  # the 2-D kernels read the level rings instead of the cell-packed pair copies (include/parcels_hip.h: "velocity_pairs")
-        fs._engine.ctx.set_option("velocity_pairs", 0)
+    # the 2-D kernels read the level rings or (opt-in since round 5) the cell-packed pair copies (include/parcels_hip.h: "velocity_pairs")
+    fs._engine.ctx.set_option("velocity_pairs", 1 if pairs else 0)
     pset = build_pset(case, fs, sort_by_cell=sort)
     if case.get("populate", True):
         pset.populate_indices()
@@ -97,9 +97,10 @@ def test_velocity_pairs_and_level_rings_give_the_same_bits(gpu):
     case = cases.curv_cgrid_case("fastc_pairs", mesh="spherical", kernels=["AdvectionRK45", "DeleteParticle"], seed=22, npart=2500, with_w=False,
                                  dt=1800.0, runtime=20 * 3600.0, vel=2.5)
     case["context"] = {"RK45_tol": 30.0, "RK45_min_dt": 60.0, "RK45_max_dt": 4 * 3600.0}
-    on, err_on, st_on = _run(case, True)
+    on, err_on, st_on = _run(case, True, pairs=True)
     off, err_off, st_off = _run(case, True, pairs=False)
     assert err_on == err_off
+    assert st_on["packs"] > 0 and st_on["pack_ms"] > 0 and st_off["packs"] == 0, (st_on, st_off)  # the copies were made (and timed) / were not
     assert st_on["program"] == PROGRAM_FAST_CGRID and st_off["program"] == PROGRAM_FAST_CGRID
     assert st_on["steps"] == st_off["steps"] and st_on["attempts"] == st_off["attempts"]
     compare(on, off, rtol=0.0, check_state="all", label="pair copies vs level rings", skip=())
@@ -111,8 +112,9 @@ def test_velocity_pairs_and_level_rings_give_the_same_bits(gpu):
     case["t0"][::5] = 86400.0 * (np.arange(len(case["t0"][::5])) % 3)  # some exactly on a level
     case["endtime"] = 4.5 * 86400.0
     case["runtime"] = None
-    on, err_on, st_on = _run(case, True, nslots=3, endtime=case["endtime"], sort=True)
+    on, err_on, st_on = _run(case, True, nslots=3, endtime=case["endtime"], sort=True, pairs=True)
     off, err_off, st_off = _run(case, True, nslots=3, endtime=case["endtime"], sort=True, pairs=False)
+    assert st_on["packs"] >= 2 and st_off["packs"] == 0
     assert err_on is None and err_off is None and st_on["launches"] > 1
     assert st_on["program"] == PROGRAM_FAST_CGRID and st_off["program"] == PROGRAM_FAST_CGRID
     compare(on, off, rtol=0.0, check_state="all", label="pair copies vs level rings, ring of 3", skip=())

@@ -238,8 +238,12 @@ def check_against_oracle(*, n_check, dsinfo, engine, pset, kernel_names, context
             "exact": ["particle ids of the survivors (= deleted set)", "state", "ei", "t"], "oracle_s": oracle_s}
 
 
-def run_config(config="c3", scale=1.0, particles=1e7, steps=24, nt=4, nslots=3, nz=75, hash="device", check=0, emit=print, dt=3600.0, reps=5):
-    """reps: after one COLD run of a kernel list (the first launch after the FieldSet was built: first touch of the tables, clock ramp) the
+def run_config(config="c3", scale=1.0, particles=1e7, steps=24, nt=4, nslots=3, nz=75, hash="device", check=0, emit=print, dt=3600.0, reps=5,
+               pairs_leg=True):
+    """pairs_leg (c5): after the default runs (the 2-D kernels read the level rings), the same launches once more with the OPT-IN cell-packed pair
+    copies of the staggered velocity ("velocity_pairs"): their kernel time, the HIP-event time of packing one level pair (pk_exec_stats.pack_ms)
+    and the sum -- at config 5 one pair serves one 24 h launch, so `kernel_plus_pack_ms` is what a level of model time costs with them.
+    reps: after one COLD run of a kernel list (the first launch after the FieldSet was built: first touch of the tables, clock ramp) the
     same run is repeated `reps` times from fresh ParticleSets of the same positions; `kernel_ms` is the MEDIAN of those, the cold one and
     min / max are reported next to it (`kernel_ms_stats`).  reps = 0: the cold run alone, like rounds 1-3."""
     import parcels_amd as pa
@@ -299,6 +303,33 @@ def run_config(config="c3", scale=1.0, particles=1e7, steps=24, nt=4, nslots=3, 
             "upload_stats": fs._engine.ctx.upload_stats() if getattr(fs, "_engine", None) is not None else None,
             "dataset_generation_s": gen_s, "hash_build": hash, "host_hash_build_s": hash_s, "device_create_s": upload_s,
         }
+        if config == "c5" and pairs_leg:
+            eng = fs._engine
+            eng.ctx.set_option("velocity_pairs", 1)
+            pk, packs, pack_ms = [], 0, 0.0
+            try:
+                for r in range(3):
+                    for key in ("RK45_tol", "RK45_min_dt", "RK45_max_dt"):
+                        fs.context.pop(key, None)
+                    p2 = pa.ParticleSet(fs, pclass=pclass, x=x, y=y, z=z, t=np.zeros(n), sort_by_cell=True)
+                    p2.populate_indices()
+                    with warnings.catch_warnings():
+                        warnings.simplefilter("ignore")
+                        p2.execute(kernels, dt=dt, runtime=steps * dt)
+                    s2 = p2._last_stats
+                    pk.append(float(s2["kernel_ms"]))
+                    if s2.get("packs"):
+                        packs, pack_ms = int(s2["packs"]), float(s2["pack_ms"])
+                    del p2
+            finally:
+                eng.ctx.set_option("velocity_pairs", 0)
+            kp = sorted(pk[1:])[(len(pk[1:]) - 1) // 2]
+            per_pair = pack_ms / packs if packs else None
+            out["velocity_pairs"] = {
+                "default": "off", "kernel_ms": kp, "kernel_ms_all": pk, "packs_first_launch": packs, "pack_ms_first_launch": pack_ms,
+                "pack_ms_per_pair": per_pair, "kernel_plus_pack_ms": (kp + per_pair) if per_pair is not None else None,
+                "note": "one level pair serves the 24 h of model time this launch covers: kernel + pack is the cost per level WITH the copies, "
+                        "`kernel_ms` of the parent object the cost WITHOUT them"}
         if check:
             out["check"] = check_against_oracle(n_check=min(int(check), n), dsinfo=({k: (v.dims, v.data) for k, v in ds.data_vars.items()}, lon, lat, depth), engine=fs._engine,
                                                 pset=pset, kernel_names=[label, "DeleteParticle"], context=fs.context, x=x, y=y, z=z, dt=dt,
@@ -323,11 +354,12 @@ def main():
     ap.add_argument("--reps", type=int, default=5, help="c3 / c5: timed repetitions after the cold run (kernel_ms = their median)")
     ap.add_argument("--output-every", type=int, default=6, help="c4: steps between write-outs")
     ap.add_argument("--verify-single", action="store_true", help="c4: rank 0 re-runs the whole id space alone and compares the files")
+    ap.add_argument("--pairs-leg", type=int, default=1, help="c5: also time the opt-in pair copies (kernel + pack per level pair)")
     a = ap.parse_args()
     if a.config == "c4":
         run_c4(a.scale, a.particles, a.steps, a.nt, a.nslots, a.nz, a.output_every, a.verify_single, a.dt)
         return
-    run_config(a.config, a.scale, a.particles, a.steps, a.nt, a.nslots, a.nz, a.hash, int(a.check), dt=a.dt, reps=a.reps)
+    run_config(a.config, a.scale, a.particles, a.steps, a.nt, a.nslots, a.nz, a.hash, int(a.check), dt=a.dt, reps=a.reps, pairs_leg=bool(a.pairs_leg))
 
 
 if __name__ == "__main__":
