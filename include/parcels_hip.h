@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PK_ABI_VERSION 8 /* 8: pk_exec_stats.pack_ms / packs (the pair-copy packing ahead of a launch, timed) / sclk_mhz, "velocity_pairs" opt-in; 7: the call-wide OutsideTimeInterval of the reference on the device (pk_exec_params.twe_n / twe_key, pk_exec_stats.first_time_error_key, pk_execute_rerun_keys); 6: PK_MAX_FIELDS 64 (descriptors in device memory), PK_MAX_EXTRA 8, pk_particles_checkpoint / _restore, user kernels (PK_KERNEL_USER0 .., pk_generic_variant, pk_set_user_program), "eval_points_f32" option; 5: pk_exec_params.horizon_lo / horizon_hi / max_iters, pk_exec_stats.first_error_iter / program, pk_execute_rerun, "fast_cgrid" option; 4: pk_upload_stats, pk_host_stage_selftest, PK_KERNEL_DO_NOTHING / _MOVE_EAST / _MOVE_NORTH, vector PK_KERNEL_SAMPLE_FIELD, "cell_table" option */
+#define PK_ABI_VERSION 8 /* 8: pk_particles_h2d_columns / _fill_f64 / _t_stats (device-resident columns across execute calls), pk_exec_stats.pack_ms / packs (the pair-copy packing ahead of a launch, timed) / sclk_mhz, "velocity_pairs" opt-in; 7: the call-wide OutsideTimeInterval of the reference on the device (pk_exec_params.twe_n / twe_key, pk_exec_stats.first_time_error_key, pk_execute_rerun_keys); 6: PK_MAX_FIELDS 64 (descriptors in device memory), PK_MAX_EXTRA 8, pk_particles_checkpoint / _restore, user kernels (PK_KERNEL_USER0 .., pk_generic_variant, pk_set_user_program), "eval_points_f32" option; 5: pk_exec_params.horizon_lo / horizon_hi / max_iters, pk_exec_stats.first_error_iter / program, pk_execute_rerun, "fast_cgrid" option; 4: pk_upload_stats, pk_host_stage_selftest, PK_KERNEL_DO_NOTHING / _MOVE_EAST / _MOVE_NORTH, vector PK_KERNEL_SAMPLE_FIELD, "cell_table" option */
 #define PK_MAX_GRIDS 4
 #define PK_MAX_FIELDS 64
 #define PK_MAX_KERNELS 8
@@ -270,6 +270,15 @@ int32_t pk_particles_d2h(pk_ctx* ctx);
 #define PK_COL_PARTICLE_ID 0x800u
 #define PK_COL_EXTRA0 0x1000u /* extra column k: PK_COL_EXTRA0 << k */
 int32_t pk_particles_d2h_columns(pk_ctx* ctx, uint32_t column_mask);
+/* The particle columns stay on the device from one ParticleSet.execute to the next (particleset.py:355-470 re-reads every column from the
+ * host arrays on every call; here only what the host touched in between crosses PCIe -- parcels_amd/columns.py):
+ * _h2d_columns uploads the selected host columns into the device rows they belong to (through the row order of the cell sort, which is
+ * kept -- unlike pk_particles_h2d, which uploads everything in host order); _fill_f64 sets a float64 column (t, dt, next_dt) to one
+ * value on the device (`particles.dt = dt` at the start of execute, particleset.py:381); _t_stats reduces the `t` column: smallest and
+ * largest finite value (NaN when there is none) and the number of NaNs (unset release times, particleset.py:523-585). */
+int32_t pk_particles_h2d_columns(pk_ctx* ctx, uint32_t column_mask);
+int32_t pk_particles_fill_f64(pk_ctx* ctx, uint32_t column_mask, double value);
+int32_t pk_particles_t_stats(pk_ctx* ctx, double* t_min, double* t_max, int64_t* n_nan);
 /* Selection of a pk_exec_params.body_only launch: mask[i] != 0 <=> host row i takes part (n int32 values in host row order). */
 int32_t pk_particles_set_mask(pk_ctx* ctx, const int32_t* mask);
 /* Device-side checkpoint of every particle column (and of the row order of the cell sort): _checkpoint keeps a copy, _restore puts

@@ -206,6 +206,9 @@ ABI_SYMBOLS = [
     "pk_particles_h2d",
     "pk_particles_d2h",
     "pk_particles_d2h_columns",
+    "pk_particles_h2d_columns",
+    "pk_particles_fill_f64",
+    "pk_particles_t_stats",
     "pk_particles_set_mask",
     "pk_particles_checkpoint",
     "pk_particles_restore",
@@ -272,6 +275,9 @@ def load():
     lib.pk_particles_h2d.argtypes = [C.c_void_p]
     lib.pk_particles_d2h.argtypes = [C.c_void_p]
     lib.pk_particles_d2h_columns.argtypes = [C.c_void_p, C.c_uint32]
+    lib.pk_particles_h2d_columns.argtypes = [C.c_void_p, C.c_uint32]
+    lib.pk_particles_fill_f64.argtypes = [C.c_void_p, C.c_uint32, C.c_double]
+    lib.pk_particles_t_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.pk_particles_set_mask.argtypes = [C.c_void_p, C.c_void_p]
     lib.pk_particles_checkpoint.argtypes = [C.c_void_p]
     lib.pk_generic_variant.argtypes = [C.c_void_p, C.POINTER(ExecParams), C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),

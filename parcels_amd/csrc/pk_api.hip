@@ -325,6 +325,43 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const T* __restrict__ 
     const int64_t src = perm[i];
     for (int k = 0; k < width; k++) out[i * width + k] = in[src * width + k];
 }
+// out[i] = in[perm[i]] with the int64 device-row -> host-row map of the cell sort (pk_particles_h2d_columns)
+template <class T>
+__global__ void __launch_bounds__(256) gather_rows64_kernel(const T* __restrict__ in, T* __restrict__ out,
+                                                            const int64_t* __restrict__ perm, int64_t n, int width) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t src = perm[i];
+    for (int k = 0; k < width; k++) out[i * width + k] = in[src * width + k];
+}
+__global__ void __launch_bounds__(256) fill_f64_kernel(double* __restrict__ out, int64_t n, double v) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = v;
+}
+// smallest / largest finite-or-infinite (non-NaN) t as order-preserving integers, and the NaN count: out[0] = min, out[1] = max, out[2] = NaNs
+__global__ void __launch_bounds__(256) t_stats_kernel(const double* __restrict__ t, int64_t n, unsigned long long* __restrict__ out) {
+    unsigned long long lo = ~0ull, hi = 0ull, nn = 0ull;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double v = t[i];
+        if (v != v) { nn++; continue; }
+        unsigned long long b;
+        memcpy(&b, &v, 8);
+        b = (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);  // order-preserving map of the doubles
+        lo = b < lo ? b : lo;
+        hi = b > hi ? b : hi;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o), n2 = __shfl_xor(nn, o);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+        nn += n2;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&out[0], lo);
+        atomicMax(&out[1], hi);
+        if (nn) atomicAdd(&out[2], nn);
+    }
+}
 template <class T>
 __global__ void __launch_bounds__(256) scatter_rows_kernel(const T* __restrict__ in, T* __restrict__ out,
                                                            const int64_t* __restrict__ perm, int64_t n, int width) {
@@ -1424,6 +1461,87 @@ int32_t pk_particles_restore(pk_ctx* ctx) {
 int32_t pk_particles_d2h_columns(pk_ctx* ctx, uint32_t mask) {
     if (!ctx) return -2;
     return copy_particles(ctx, false, mask);
+}
+
+int32_t pk_particles_h2d_columns(pk_ctx* ctx, uint32_t mask) {
+    if (!ctx) return -2;
+    if (!ctx->bound) return ctx->fail("no particles bound");
+    if (ctx->in_flight) return ctx->fail("pk_particles_h2d_columns: a launch is in flight (call pk_execute_end)");
+    PK_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t n = ctx->host.n;
+    ctx->rerun_valid = false;  // the staging below goes through the second column set
+    ctx->chk_valid = false;    // a checkpoint no longer describes these columns
+    if (n == 0) return 0;
+    if (ctx->has_perm) {
+        const int32_t rc = ensure_alt(ctx);
+        if (rc) return rc;
+    }
+    int bit = 0;
+    for (const ColRef& c : particle_columns(ctx)) {
+        const bool selected = (mask >> bit++) & 1u;
+        if (!c.h || !c.d || !selected) continue;
+        const size_t bytes = (size_t)n * c.elem * c.width;
+        if (!ctx->has_perm) {
+            PK_HIP(ctx, hipMemcpyAsync(c.d, c.h, bytes, hipMemcpyHostToDevice, ctx->compute));
+        } else {  // device row i holds host row perm[i]
+            PK_HIP(ctx, hipMemcpyAsync(c.a, c.h, bytes, hipMemcpyHostToDevice, ctx->compute));
+            const dim3 grid((unsigned)((n + 255) / 256));
+            if (c.elem == 8) hipLaunchKernelGGL((gather_rows64_kernel<unsigned long long>), grid, dim3(256), 0, ctx->compute, (const unsigned long long*)c.a, (unsigned long long*)c.d, ctx->d_perm, n, c.width);
+            else hipLaunchKernelGGL((gather_rows64_kernel<uint32_t>), grid, dim3(256), 0, ctx->compute, (const uint32_t*)c.a, (uint32_t*)c.d, ctx->d_perm, n, c.width);
+            PK_HIP(ctx, hipGetLastError());
+        }
+    }
+    PK_HIP(ctx, hipStreamSynchronize(ctx->compute));
+    return 0;
+}
+
+int32_t pk_particles_fill_f64(pk_ctx* ctx, uint32_t mask, double value) {
+    if (!ctx) return -2;
+    if (!ctx->bound) return ctx->fail("no particles bound");
+    if (ctx->in_flight) return ctx->fail("pk_particles_fill_f64: a launch is in flight (call pk_execute_end)");
+    if (mask & ~(PK_COL_T | PK_COL_DT | PK_COL_NEXT_DT)) return ctx->fail("pk_particles_fill_f64: float64 columns only (t, dt, next_dt)");
+    PK_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t n = ctx->dev.n;
+    ctx->rerun_valid = false;
+    ctx->chk_valid = false;
+    if (n == 0) return 0;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    double* cols[3] = {(mask & PK_COL_T) ? ctx->dev.t : nullptr, (mask & PK_COL_DT) ? ctx->dev.dt : nullptr, (mask & PK_COL_NEXT_DT) ? ctx->dev.next_dt : nullptr};
+    for (double* c : cols)
+        if (c) hipLaunchKernelGGL(fill_f64_kernel, grid, dim3(256), 0, ctx->compute, c, n, value);
+    PK_HIP(ctx, hipGetLastError());
+    return 0;  // (stream order: the next launch sees it)
+}
+
+int32_t pk_particles_t_stats(pk_ctx* ctx, double* t_min, double* t_max, int64_t* n_nan) {
+    if (!ctx || !t_min || !t_max || !n_nan) return -2;
+    if (!ctx->bound) return ctx->fail("no particles bound");
+    if (ctx->in_flight) return ctx->fail("pk_particles_t_stats: a launch is in flight (call pk_execute_end)");
+    PK_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t n = ctx->dev.n;
+    *t_min = *t_max = NAN;
+    *n_nan = 0;
+    if (n == 0) return 0;
+    const unsigned long long init[3] = {~0ull, 0ull, 0ull};
+    PK_HIP(ctx, hipMemcpyAsync(ctx->d_clk, init, sizeof(init), hipMemcpyHostToDevice, ctx->compute));  // (the clock-probe buffer is idle between launches)
+    const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(t_stats_kernel, dim3(grid), dim3(256), 0, ctx->compute, ctx->dev.t, n, ctx->d_clk);
+    PK_HIP(ctx, hipGetLastError());
+    unsigned long long got[3];
+    PK_HIP(ctx, hipMemcpyAsync(got, ctx->d_clk, sizeof(got), hipMemcpyDeviceToHost, ctx->compute));
+    PK_HIP(ctx, hipStreamSynchronize(ctx->compute));
+    auto unmap = [](unsigned long long b) {
+        b = (b & 0x8000000000000000ull) ? (b & 0x7fffffffffffffffull) : ~b;
+        double v;
+        memcpy(&v, &b, 8);
+        return v;
+    };
+    if (got[0] != ~0ull || got[1] != 0ull) {
+        *t_min = unmap(got[0]);
+        *t_max = unmap(got[1]);
+    }
+    *n_nan = (int64_t)got[2];
+    return 0;
 }
 
 // ---- asynchronous write-out (particleset.py:436-459 / particlefile.py:142-180 overlapped with the next interval) -------------

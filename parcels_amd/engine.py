@@ -21,6 +21,7 @@ import warnings
 import numpy as np
 
 from . import _hip
+from .columns import LazyColumns
 from .field import Field, VectorField
 from .interpolators import CGrid_Velocity, XConstantField
 from .statuscodes import StatusCode
@@ -28,6 +29,22 @@ from .statuscodes import StatusCode
 
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class _RawView:
+    """dict-like access to the arrays of a LazyColumns set as they are (no download, no dirty mark)."""
+
+    def __init__(self, lc):
+        self.lc = lc
+
+    def __getitem__(self, k):
+        return self.lc.raw(k)
+
+    def __setitem__(self, k, v):
+        self.lc.set_raw(k, v)
+
+    def get(self, k, default=None):
+        return self.lc.raw(k) if k in self.lc else default
 
 
 class _LazyLevels:
@@ -79,6 +96,8 @@ class DeviceEngine:
         self.field_nslots: dict[str, int] = {}
         self._plan_and_create_fields(nslots, memory_fraction)
         self._bound_sig = None
+        self._bound = None
+        self._sorted_t = None  # model time at which the device rows were last cell-sorted (None: host order / unknown)
         self._next_dt_f32 = None
         self.device_variables: list[str] = []  # user Variables bound as extra device columns (set by Kernel: SampleField targets)
         # a sharded ParticleSet is one batch: hooks of parcels_amd.distributed.batch_agreement (set by ParticleSet.execute for a collective run)
@@ -342,6 +361,9 @@ class DeviceEngine:
     # ---- particles -------------------------------------------------------------------------------------------
     def _particles_desc(self, data: dict):
         """Validate the SoA dict (particle.py:182-222) and describe it for the library (pk_particles_desc)."""
+        if isinstance(data, LazyColumns):  # (the arrays as they are: no download, no dirty mark -- bind_particles released the set)
+            src = data
+            data = _RawView(src)
         n = data["x"].shape[0]
         for k in ("t", "z", "y", "x", "dz", "dy", "dx", "dt", "state", "ei", "particle_id"):
             a = data[k]
@@ -392,35 +414,113 @@ class DeviceEngine:
         return _hip.COLUMN_BITS.get(name, 0)  # other user Variables live on the host only (no kernel writes them)
 
     def bind_particles(self, data: dict):
+        """Describe the host columns to the library (device columns sized, nothing copied).  A LazyColumns set that was resident -- this
+        one or another ParticleSet's -- first gets its stale columns back: from here on the HOST arrays are what counts, until h2d()."""
+        prev = getattr(self, "_bound", None)
+        for lc in {id(prev): prev, id(data): data}.values():
+            if isinstance(lc, LazyColumns):
+                lc.release()
         d = self._particles_desc(data)
         self.ctx.check(self.lib.pk_particles_bind(self.ctx.handle, C.byref(d)), "pk_particles_bind")
         self._bound = data
+        self._bound_devvars = tuple(self.device_variables)
+
+    def attach(self, data) -> bool:
+        """Make the device rows current for `data` with as little PCIe traffic as the host's accesses since the last launch allow
+        (parcels_amd/columns.py).  True: the set was still resident -- only the columns the host touched were uploaded."""
+        if (isinstance(data, LazyColumns) and data.resident() and data._engine is self and tuple(self.device_variables) == getattr(self, "_bound_devvars", None)
+                and not os.environ.get("PARCELS_AMD_NO_RESIDENT")):
+            dirty = sorted(k for k in data._dirty if self._column_bit(k))
+            if dirty:
+                self.h2d_columns(dirty)
+            data._dirty.clear()
+            return True
+        self.bind_particles(data)
+        self.h2d()
+        return False
+
+    def h2d_columns(self, columns):
+        """Upload the named host columns into the device rows they belong to (the row order of the cell sort is kept)."""
+        mask = 0
+        for name in columns:
+            mask |= self._column_bit(name)
+        if self._next_dt_f32 is not None and "next_dt" in columns:
+            self._next_dt_f32[1][:] = self._next_dt_f32[0]
+        if mask:
+            self.ctx.check(self.lib.pk_particles_h2d_columns(self.ctx.handle, mask), "pk_particles_h2d_columns")
+        if any(k in ("x", "y", "z") for k in columns):
+            self._sorted_t = None  # the host moved particles: the next launch sorts again
+
+    def fill_column(self, name, value):
+        """`particles.<name> = value` on the device (float64 columns t / dt / next_dt); the host array becomes stale."""
+        self.ctx.check(self.lib.pk_particles_fill_f64(self.ctx.handle, self._column_bit(name), float(value)), "pk_particles_fill_f64")
+        if isinstance(self._bound, LazyColumns):
+            self._bound.mark_launched([name])
+
+    def t_stats(self):
+        """(smallest, largest non-NaN t, number of NaNs) of the device column."""
+        lo, hi, nn = C.c_double(), C.c_double(), C.c_int64()
+        self.ctx.check(self.lib.pk_particles_t_stats(self.ctx.handle, C.byref(lo), C.byref(hi), C.byref(nn)), "pk_particles_t_stats")
+        return lo.value, hi.value, int(nn.value)
+
+    def device_column_names(self, data):
+        """The columns of `data` that live on the device and that a launch may write."""
+        return [k for k in dict.keys(data) if k != "particle_id" and self._column_bit(k)]
+
+    def mark_launched(self, data=None):
+        """After launches: the host mirror of the written columns is stale (nothing is copied; LazyColumns downloads on access)."""
+        data = self._bound if data is None else data
+        if isinstance(data, LazyColumns) and data._engine is self:
+            data.mark_launched(self.device_column_names(data))
+            return True
+        return False
 
     def compact_deleted(self, data: dict) -> dict:
         """Kernel.remove_deleted (kernel.py:98-106) without moving the columns: the rows in state Delete are removed from
         the device-resident columns (pk_particles_compact); only the `state` column comes back, to tell the host which rows
         survive.  Returns the new SoA dict: `state` and host-only user Variables are compacted here, the device-bound columns
         are fresh arrays of the surviving length that the next d2h() fills."""
-        self.d2h(["state"])
-        keep = data["state"] != StatusCode.Delete
+        if isinstance(data, LazyColumns):
+            state = data.peek("state") if data._engine is self else data.raw("state")
+            pairs = [(k, data.raw(k)) for k in dict.keys(data)]  # (arrays as they are: the device columns are not downloaded)
+        else:
+            self.d2h(["state"])
+            state = data["state"]
+            pairs = list(data.items())
+        keep = state != StatusCode.Delete
         n_new = int(np.count_nonzero(keep))
         new = {}
-        for name, arr in data.items():
+        for name, arr in pairs:
             if name != "state" and (name in _hip.COLUMN_BITS or name in self.device_variables):
                 new[name] = np.empty((n_new,) + arr.shape[1:], dtype=arr.dtype)
             else:
                 new[name] = np.ascontiguousarray(arr[keep])
+        lazy = isinstance(data, LazyColumns)
+        if lazy:
+            new = LazyColumns(new)
         d = self._particles_desc(new)
         got = C.c_int64(-1)
         self.ctx.check(self.lib.pk_particles_compact(self.ctx.handle, C.byref(d), C.byref(got)), "pk_particles_compact")
         assert got.value == n_new
         self._bound = new
+        if lazy:  # the surviving rows live on the device; every device column but `state` is a fresh host array the next access fills
+            data._engine = None
+            data._stale.clear()
+            data._dirty.clear()
+            new._engine = self
+            new._stale = {k for k in dict.keys(new) if k != "state" and (k in _hip.COLUMN_BITS or k in self.device_variables)}
         return new
 
     def h2d(self):
         if self._next_dt_f32 is not None:
             self._next_dt_f32[1][:] = self._next_dt_f32[0]
         self.ctx.check(self.lib.pk_particles_h2d(self.ctx.handle), "pk_particles_h2d")
+        self._sorted_t = None  # host row order again
+        b = self._bound
+        if isinstance(b, LazyColumns):  # host and device agree: the set is resident from here on
+            b._engine = self
+            b._stale.clear()
+            b._dirty.clear()
 
     def d2h(self, columns=None):
         """Copy the particle columns back to the bound NumPy arrays (all, or only the named ones)."""
@@ -433,6 +533,12 @@ class DeviceEngine:
             self.ctx.check(self.lib.pk_particles_d2h_columns(self.ctx.handle, mask), "pk_particles_d2h_columns")
         if self._next_dt_f32 is not None and (columns is None or "next_dt" in columns):
             self._next_dt_f32[0][:] = self._next_dt_f32[1]
+        b = self._bound
+        if isinstance(b, LazyColumns):
+            if columns is None:
+                b._stale.clear()
+            else:
+                b._stale -= set(columns)
 
     # ---- asynchronous write-out snapshots ------------------------------------------------------------------------
     _SNAP_COLS = ("t", "z", "y", "x", "dz", "dy", "dx", "dt", "next_dt", "state", "ei", "particle_id")
@@ -444,7 +550,9 @@ class DeviceEngine:
             mask |= self._column_bit(name)
         self._snap_extra = list(self.device_variables)
         self.ctx.check(self.lib.pk_particles_snapshot_begin(self.ctx.handle, mask, int(slot)), "pk_particles_snapshot_begin")
-        self._snap_dtypes = {k: self._bound[k].dtype for k in self._bound if k in _hip.COLUMN_BITS or k in self.device_variables}
+        b = self._bound
+        raw = b.raw if isinstance(b, LazyColumns) else b.__getitem__  # (dtypes only: no download, no dirty mark)
+        self._snap_dtypes = {k: raw(k).dtype for k in dict.keys(b) if k in _hip.COLUMN_BITS or k in self.device_variables}
 
     def snapshot_wait(self, slot: int) -> dict:
         """Block until snapshot ``slot`` has landed; NumPy views of its pinned columns (valid until the slot is reused).  Callable
@@ -597,6 +705,12 @@ class DeviceEngine:
         if several and self.exact_error_stop:
             self.ctx.check(self.lib.pk_particles_checkpoint(self.ctx.handle), "pk_particles_checkpoint")
             checkpointed = True
+        # Rows that are still in the cell order of an earlier call (device-resident columns, parcels_amd/columns.py) are not sorted again
+        # before `resort_every` of model time has passed: the order of ONE sort holds for weeks of a smooth flow, and a
+        # sort costs a third of a 24-step launch.  Locality only -- trajectories do not depend on the row order.
+        sorted_t = getattr(self, "_sorted_t", None)
+        skip_first_sort = bool(sort_by_cell and sorted_t is not None and t_start is not None and np.isfinite(t_start)
+                               and abs(float(t_start) - sorted_t) < (float(resort_every) if resort_every else np.inf))
         cap = 0  # iteration limit of the batch loop (0: none)
         keys: list[int] = []  # samples that fail call-wide with OutsideTimeInterval (pk_exec_params.twe_key)
         rerun = False  # the next pass is a single launch repeated from the second column set
@@ -626,9 +740,14 @@ class DeviceEngine:
                     horizon = None
                     if span is not None and t_live is not None and np.isfinite(t_live):
                         horizon = (-np.inf, float(t_live) + span) if sign > 0 else (float(t_live) - span, np.inf)
+                    sort_now = 0 if (reset and skip_first_sort) else sort_by_cell
                     prm = self.make_params(kernel_ids, endtime=endtime, dt0=dt0, context=context, seed=seed, reset_state=reset,
-                                           have_guess0=(have_guess0 if reset else 1), sort_by_cell=sort_by_cell, samples=samples, horizon=horizon,
+                                           have_guess0=(have_guess0 if reset else 1), sort_by_cell=sort_now, samples=samples, horizon=horizon,
                                            max_iters=cap, twe_keys=keys)
+                    if sort_now and t_live is not None and np.isfinite(t_live):
+                        self._sorted_t = float(t_live)
+                    elif sort_now:
+                        self._sorted_t = None
                     self.ctx.check(self.lib.pk_execute_begin(self.ctx.handle, C.byref(prm)), "pk_execute_begin")
                     try:
                         _t = _time.perf_counter()

@@ -152,8 +152,10 @@ class ParticleFile:
             self._writer.write_table(pa.table({n: pa.array(np.asarray(columns[n])) for n in names}, schema=self._writer.schema))
 
     def write(self, pset, t, fieldset=None, indices=None):
+        from .columns import readonly
+
         fieldset = fieldset or pset.fieldset
-        data = pset._data
+        data = readonly(pset._data)  # (reads only: a device-resident set downloads the columns touched here and stays clean)
         if isinstance(t, (np.timedelta64, np.datetime64)):
             t = to_seconds(t - fieldset.time_interval.left)
         names = [v.name for v in _get_vars_to_write(pset._pclass)]
@@ -244,7 +246,9 @@ class _AsyncWriter:
         # these very arrays during the next interval) the table needs its own copy, or it would pair this output time's t / x / y with
         # later values of the Variable.
         mutable = bool(getattr(getattr(self.pset, "_kernel", None), "host_functions", None))
-        host_only = {k: (np.array(v, copy=True) if mutable else v) for k, v in data.items()
+        from .columns import raw_items
+
+        host_only = {k: (np.array(v, copy=True) if mutable else v) for k, v in raw_items(data)
                      if k not in self.engine._SNAP_COLS and k not in self.engine.device_variables}
         self.pending[slot] = self.pool.submit(self._task, slot, host_only, float(t))
 

@@ -8,6 +8,7 @@ import warnings
 
 import numpy as np
 
+from .columns import LazyColumns
 from .field import to_seconds
 from .kernel import Kernel
 from .particle import Particle, create_particle_data
@@ -178,10 +179,13 @@ class ParticleSet:
         if name != "_data" and isinstance(data, dict) and name in data:
             data[name][:] = value
         else:
+            if name == "_data" and isinstance(value, dict) and not isinstance(value, LazyColumns):
+                value = LazyColumns(value)  # the host mirror of columns that may live on the device (parcels_amd/columns.py)
             object.__setattr__(self, name, value)
 
     def __len__(self):
-        return len(self._data["particle_id"])
+        d = self._data
+        return len(d.raw("particle_id") if isinstance(d, LazyColumns) else d["particle_id"])  # (the length is never stale)
 
     def __iter__(self):  # particleset.py:143-153
         self._index = 0
@@ -266,7 +270,22 @@ class ParticleSet:
             kernels = [kernels]
         self._kernel = Kernel(kernels, self)
         dt, sign_dt = _convert_dt_to_float(dt)
-        self._data["dt"][:] = dt
+        # Columns that are still device-resident from the previous call stay there (parcels_amd/columns.py): `particles.dt = dt` and the
+        # reductions over the release times below run on the device, nothing crosses PCIe unless the host touched the set in between.
+        data = self._data
+        eng0 = data._engine if isinstance(data, LazyColumns) and data.resident() and hasattr(data._engine, "fill_column") else None
+        if eng0 is not None and eng0 is not getattr(self.fieldset, "_engine", None):
+            eng0 = None  # (resident on an engine the FieldSet no longer uses: the host path below downloads what it touches)
+        if eng0 is not None:
+            eng0.fill_column("dt", dt)
+        else:
+            self._data["dt"][:] = dt
+        t_on_device = eng0 is not None and "t" in data._stale
+        t_lo = t_hi = None
+        t_nan = 0
+        if t_on_device and len(self) > 0:
+            t_lo, t_hi, t_nan = eng0.t_stats()
+        t_ro = (lambda: data.peek("t")) if isinstance(data, LazyColumns) else (lambda: self._data["t"])  # read-only look at the release times
         if runtime is not None:  # _convert_runtime_to_float (particleset.py:508-520)
             try:
                 runtime = to_seconds(runtime) if isinstance(runtime, (datetime.timedelta, np.timedelta64)) else float(runtime)
@@ -279,17 +298,23 @@ class ParticleSet:
             # the first release over ALL shards (NaN-propagating like rel.min(): one unset release time anywhere => fieldset start)
             from .distributed import allreduce_scalars
 
-            rel = self._data["t"]
-            mine = (rel.min() if sign_dt == 1 else rel.max()) if len(rel) else np.nan
-            unset = bool(len(rel)) and bool(np.isnan(mine))
+            if t_lo is not None:
+                mine = np.nan if t_nan else (t_lo if sign_dt == 1 else t_hi)
+            else:
+                rel = t_ro()
+                mine = (rel.min() if sign_dt == 1 else rel.max()) if len(rel) else np.nan
+            unset = bool(len(self)) and bool(np.isnan(mine))
             lo_hi = allreduce_scalars([sign_dt * mine if np.isfinite(mine) else np.inf, -1.0 if unset else -0.0], "min", output_file._group,
                                       device=getattr(getattr(self.fieldset, "_engine", None), "device", None))
             first = np.nan if (lo_hi[1] < 0 or not np.isfinite(lo_hi[0])) else sign_dt * lo_hi[0]
+        if first is None and t_lo is not None:
+            first = np.nan if t_nan else (t_lo if sign_dt == 1 else t_hi)  # NaN-propagating like rel.min() (one unset release time => fieldset start)
         start_time, end_time = self._start_and_end_times(runtime, endtime, sign_dt, first=first)
-        if np.isnan(self._data["t"]).any():
+        if (t_nan > 0) if t_lo is not None else bool(np.isnan(t_ro()).any()):
             self._data["t"][:] = start_time
         outputdt = output_file.outputdt if output_file else None
-        _warn_outputdt_release_desync(outputdt, start_time, self._data["t"])
+        if outputdt and np.isfinite(outputdt):
+            _warn_outputdt_release_desync(outputdt, start_time, t_ro())
         next_output = None
         if output_file:
             output_file.set_metadata(self.fieldset.gridset[0]._mesh)
@@ -304,14 +329,20 @@ class ParticleSet:
         # through ParticleSetView on every step, particlesetview.py:97-301.)
         engine = self._engine()
         kern = self._kernel
-        self._t_live = None
+        self._t_live = start_time if np.isfinite(start_time) else None  # (= the first release: what Kernel.launch would reduce from `t`)
         if kern.host_functions and not kern._jit_tried:
             kern._try_jit(self)  # elementwise Python kernels are compiled into the device program here (parcels_amd/jit.py)
         engine.device_variables = list(kern.device_variables)  # user Variables that device kernels write live on the device
+        lazy = isinstance(self._data, LazyColumns) and hasattr(engine, "attach")  # (stand-in engines of the CPU suite: the eager path)
         if len(self) > 0:
-            engine.bind_particles(self._data)
-            engine.h2d()
-        have_guess0 = kern._have_guess0(self._data) if len(self) > 0 else 1
+            if lazy:
+                engine.attach(self._data)  # uploads what the host touched since the last launch (everything the first time)
+            else:
+                engine.bind_particles(self._data)
+                engine.h2d()
+        from .columns import readonly
+
+        have_guess0 = kern._have_guess0(readonly(self._data)) if len(self) > 0 else 1
         out_cols = None
         writer = None
         if output_file is not None:
@@ -343,19 +374,27 @@ class ParticleSet:
                             stats = kern.launch(self, next_time, dt, have_guess0=have_guess0)
                             have_guess0 = 1
                             synced = False
+                            if lazy and not kern.host_functions:
+                                engine.mark_launched(self._data)  # the host arrays are stale now; whoever reads one downloads it
                             self._t_live = next_time if not np.isnan(next_time) else None
                             if kern.only_deletions(stats) and self.device_compaction:
                                 # Kernel.remove_deleted on the device: the columns do not leave HBM (pk_particles_compact)
                                 self._data = engine.compact_deleted(self._data)
                                 synced = len(self) == 0
                             elif kern.needs_host_pass(stats):
-                                engine.d2h()
+                                if lazy:
+                                    self._data.sync()
+                                else:
+                                    engine.d2h()
                                 synced = True
                                 shard_codes = stats.get("codes_any_shard") if stats is not None else None
                                 kern.finish_on_host(self, first_code=shard_codes[0] if shard_codes else None)  # compacts / raises
                                 if len(self) > 0:
-                                    engine.bind_particles(self._data)
-                                    engine.h2d()
+                                    if lazy:
+                                        engine.attach(self._data)
+                                    else:
+                                        engine.bind_particles(self._data)
+                                        engine.h2d()
                         if stats is not None and stats.get("codes_any_shard"):
                             # a particle of ANOTHER shard ended the call in an error state: the reference raises for the batch (kernel.py:
                             # 236-245) -- this rank had nothing to raise above, so it raises the same exception here
@@ -364,7 +403,10 @@ class ParticleSet:
                             code = int(stats["codes_any_shard"][0])  # (StatusCode is a table of integers, not an enum)
                             empty = np.empty(0)
                             if not synced and len(self) > 0:
-                                engine.d2h()
+                                if lazy:
+                                    self._data.sync()
+                                else:
+                                    engine.d2h()
                                 synced = True
                             if code == StatusCode.ErrorOutsideTimeInterval:
                                 ErrorsToThrow[code](empty)
@@ -389,7 +431,10 @@ class ParticleSet:
                                 probe = getattr(output_file, "_device_gather_ok", None)
                                 on_device = bool(collective and not synced and len(self) > 0 and probe is not None and probe(engine, names))
                                 if not synced and not on_device:
-                                    engine.d2h(out_cols)
+                                    if lazy:
+                                        self._data.sync(out_cols)
+                                    else:
+                                        engine.d2h(out_cols)
                                 self._device_rows_current = on_device  # a collective file filters and gathers the DEVICE rows
                                 try:
                                     output_file.write(self, next_output)
@@ -405,8 +450,10 @@ class ParticleSet:
                         writer.close()
         finally:
             engine.agree_min = engine.agree_codes = None
-            if not synced and len(self) > 0:
+            if not synced and len(self) > 0 and not lazy:
                 engine.d2h()
+            # (lazy: the columns stay on the device; the host arrays are refreshed column by column when somebody reads them, and the
+            # next execute() uploads only what the host touched -- parcels_amd/columns.py)
             self._t_live = None
 
     def _start_and_end_times(self, runtime, endtime, sign_dt, first=None):  # particleset.py:523-585
@@ -417,8 +464,9 @@ class ParticleSet:
             raise ValueError("The runtime must be provided when the time_interval is not defined for a fieldset.")
         if runtime is None and endtime is None:
             raise ValueError("Either runtime or endtime must be provided.")
-        rel = self._data["t"]
-        if first is None:  # (given: the first release over all shards of a collective run)
+        if first is None:  # (given: the first release over all shards of a collective run, or reduced on the device)
+            d = self._data
+            rel = d.peek("t") if isinstance(d, LazyColumns) else d["t"]
             first = rel.min() if sign_dt == 1 else rel.max()  # NaN-propagating like the reference: one unset release time => fieldset start
         if ti is not None and endtime is not None:
             if type(endtime) != type(ti.left):  # noqa: E721
