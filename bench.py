@@ -20,9 +20,11 @@ Prints ONE JSON line (rank 0).  What the objects mean:
 
 `roofline` -- the advection kernel is bound by fp64-rate VALU issue, not by HBM (its gathers are served by L2 / Infinity Cache):
   bound     "valu_fp64"
-  achieved  VALU-busy SIMD-cycles per second = (SQ_ACTIVE_INST_VALU x 4 per particle-step, from the rocprofv3 PMC pass summarised
-            in profiles/pmc_latest.json) x particle-steps of the timed launch / kernel time measured HERE with HIP events on the
-            compute stream;  peak = 1024 SIMDs x 2.4 GHz;  frac = VALU utilisation at peak clock
+  achieved  ALGORITHMIC fp64 TFLOP/s = 143.46 flops per velocity evaluation (ALGO_FLOPS_PER_EVAL_C2 below) x 4 evaluations x particle-steps
+            of the timed launch / kernel time measured HERE with HIP events on the compute stream;  peak = 78.6 TFLOP/s (fp64 vector FMA);
+            frac = achieved / peak.  `valu_busy_frac` (what rounds 1-4 printed as `frac`) = SQ_ACTIVE_INST_VALU x 4 per particle-step of
+            the rocprofv3 PMC pass in profiles/pmc_latest.json x particle-steps / kernel time / (1024 SIMDs x 2.4 GHz): utilisation, not a
+            roof.  `sclk_mhz` = the shader clock the timed launch ran at (cycle-counter probes around the kernel)
   traffic   HBM bytes of the timed launch (FETCH_SIZE + WRITE_SIZE passes, calibrated on the 1 GiB copy kernel), scaled per
             particle-step to this run;  `hbm` = that traffic over the kernel time against the 8 TB/s peak
   algorithmic  SURVEY.md 8(d)'s byte model (1112 B per particle-step = 4 stages x 2 fields x 16 corners x 8 B + 88 B state) over
@@ -56,6 +58,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_STEP_C2_RK4 = 4 * 2 * 16 * 8 + 88
+# fp64 flops one velocity evaluation of the reference's algorithm asks for (an FMA counts 2): time / depth / lat / lon barycentric
+# coordinates, the t- and z-lerps of 2 x 16 corners, the bilinear sums, the metres -> degrees conversion with one cosine -- counted on
+# the kernel that executes every one of them (PMC instruction count x static instruction mix of the round-4 binary,
+# profiles/r04q_c2_pmc.md x profiles/r03_c2_isa.json).  ALGORITHMIC like the byte model: the corner-block cache of
+# round 5 executes fewer (it re-uses the lerped corners between stages that share t), which must not lower the work it is credited with.
+ALGO_FLOPS_PER_EVAL_C2 = 143.46
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs x 16 lanes x 2 (FMA) x 2.4 GHz
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md
 N_SIMD, PEAK_CLOCK_GHZ = 1024, 2.4  # 256 CUs x 4 SIMDs; one fp64-rate VALU instruction occupies a SIMD for 4 cycles
 POS_BLOCK = 1 << 20  # particles per generator block (positions do not depend on how the id space is sharded)
@@ -200,6 +209,42 @@ def long_run(case, fs, steps):
             "value_end_to_end": st["steps"] / wall, "wall_s_incl_h2d_d2h": wall}
 
 
+def repeat_execute(case, fs, calls, steps):
+    """The usual script loop: `calls` x pset.execute(AdvectionRK4, runtime = steps x dt) on the headline FieldSet, through the product path.
+    The particle columns stay device-resident between the calls (parcels_amd/columns.py): the first call uploads them and sorts, the others
+    move nothing across PCIe unless the script touches the set -- what each call costs end to end, next to the kernel time of the same steps."""
+    import torch
+
+    import parcels_amd as pa
+    from tests.case_utils import build_pset
+
+    pset = build_pset(case, fs, sort_by_cell=True, resort_every=0)
+    eng = fs._engine_or_create()
+    walls, kms, moved = [], [], []
+    nsteps = 0
+    for k in range(calls):
+        before = dict(eng.transfers)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pset.execute([pa.AdvectionRK4], dt=case["dt"], runtime=steps * case["dt"])
+        torch.cuda.synchronize()
+        walls.append(time.perf_counter() - t0)
+        st = pset._last_stats
+        kms.append(st["kernel_ms"])
+        nsteps = int(st["steps"])
+        moved.append({key: eng.transfers[key] - before[key] for key in before if eng.transfers[key] != before[key]})
+    t0 = time.perf_counter()
+    x_sum = float(np.sum(pset._data.peek("x") if hasattr(pset._data, "peek") else pset._data["x"]))  # the first host read: one column comes down
+    t_read = time.perf_counter() - t0
+    later = sorted(walls[1:])
+    med = later[(len(later) - 1) // 2]
+    kmed = sorted(kms[1:])[(len(kms[1:]) - 1) // 2]
+    return {"workload": f"{calls} x ParticleSet.execute(AdvectionRK4, {steps} steps of {case['dt']:.0f} s) on the headline FieldSet and particles",
+            "particle_steps_per_call": nsteps, "wall_ms_first_call": walls[0] * 1e3, "wall_ms_later_calls": {"min": later[0] * 1e3, "median": med * 1e3, "max": later[-1] * 1e3},
+            "kernel_ms_later_calls_median": kmed, "value_end_to_end_later_calls": nsteps / med, "value_kernel_later_calls": nsteps / (kmed * 1e-3),
+            "unit": "particle-steps/s", "pcie_transfers_per_call": moved, "first_host_read_of_x_ms": t_read * 1e3, "checksum_x": x_sum}
+
+
 def secondary_runs(args):
     """BASELINE configs 3 and 5 at full size on this GPU (tools/bench_configs.py builds them), outside the timed region of the
     headline: per run the particle-steps/s of the fused launch (HIP events on the compute stream), the algorithmic-byte roofline
@@ -250,6 +295,12 @@ def secondary_runs(args):
                 e["roofline"]["valu_insts_per_wave_evaluation"] = pp.get("valu_insts_per_wave_eval")
                 e["roofline"]["scratch_bytes_per_lane"] = pp.get("scratch")
                 e["roofline"]["counters_stale"] = counters_stale(r["kernels"], pp)  # the kernel changed since the PMC passes
+            vp = r.get("velocity_pairs")
+            if vp:  # the opt-in pair copies, timed: what a level pair costs with them (kernel + packing) against `kernel_ms` without
+                e["velocity_pairs"] = dict(vp)
+                if vp.get("kernel_plus_pack_ms"):
+                    e["velocity_pairs"]["frac_kernel_only"] = ab * units / (vp["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
+                    e["velocity_pairs"]["frac_incl_pack"] = ab * units / (vp["kernel_plus_pack_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
             if r.get("check"):
                 c = r["check"]
                 e["check"] = {"passed": True, "n_check": c["n_check"], "deleted": c["deleted"], "exact": c["exact"],
@@ -290,6 +341,9 @@ def main():
                          "after the warm-up; `value`, `ms_per_step` and `roofline` use the MEDIAN repetition, min / max are reported next to it")
     ap.add_argument("--long-run", type=int, default=552,
                     help="N = 1 only: also run the headline workload over ALL its time levels (this many steps, one launch) as `long_run`; 0 = off")
+    ap.add_argument("--repeat-execute", type=int, default=10,
+                    help="N = 1 only: also run the headline steps as this many consecutive pset.execute calls (device-resident columns between the calls) as "
+                         "`repeat_execute`; 0 = off")
     ap.add_argument("--secondary-reps", type=int, default=5, help="timed launches per secondary kernel list after one cold launch")
     ap.add_argument("--c4", type=float, default=0,
                     help="also run BASELINE config 4 after the headline, on the same ranks: the NEMO-size curvilinear C-grid with this many particles PER "
@@ -470,8 +524,16 @@ def main():
         per_gpu_steps = total_steps / world
         algo_gbps = ALGO_BYTES_PER_STEP_C2_RK4 * per_gpu_steps / kernel_s / 1e9 if kernel_s > 0 else 0.0
         peak_cycles = N_SIMD * PEAK_CLOCK_GHZ  # G SIMD-cycles per second
-        roof = {"bound": "valu_fp64", "achieved": None, "peak": peak_cycles, "unit": "G VALU-busy SIMD-cycles/s", "frac": None, "traffic": None,
+        evals_s = per_gpu_steps * 4 / kernel_s if kernel_s > 0 else 0.0  # RK4: 4 evaluations per particle-step; per lane
+        algo_tflops = ALGO_FLOPS_PER_EVAL_C2 * evals_s / 1e12
+        # `frac` is a fraction of a ROOF: algorithmic fp64 flops over the launch time against the fp64 vector peak (the kernel is bound by
+        # fp64-rate VALU issue, its gathers are served by L2 / Infinity Cache).  `valu_busy_frac` (rounds 1-4 quoted it as `frac`) is the share
+        # of SIMD cycles with a VALU instruction in flight -- utilisation, not a roof: moves, selects and address arithmetic count in it.
+        roof = {"bound": "valu_fp64", "achieved": algo_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": algo_tflops / FP64_VECTOR_PEAK_TFLOPS,
+                "traffic": None, "algorithmic_fp64_flops_per_evaluation": ALGO_FLOPS_PER_EVAL_C2,
+                "frac_no_fma_peak": algo_tflops / (FP64_VECTOR_PEAK_TFLOPS / 2) * (121.59 / ALGO_FLOPS_PER_EVAL_C2),  # one op per lane and slot: NumPy never fuses (-ffp-contract=off)
                 "kernel": "pk::advect_fast_kernel<double, 0, false> (csrc/pk_kernels.h, pk_fast_agrid.h)", "kernel_ms_per_launch": float(kms.item()),
+                "sclk_mhz": st.get("sclk_mhz"),  # shader clock of the last timed launch (cycle counter / 100 MHz counter around the kernel): reconciles this line with a trace taken at another clock
                 "hbm": None,
                 "algorithmic": {"note": "SURVEY 8(d) byte model; these bytes are served by L2 / Infinity Cache, this is NOT an HBM fraction",
                                 "bytes_per_particle_step": ALGO_BYTES_PER_STEP_C2_RK4, "bytes_per_launch": ALGO_BYTES_PER_STEP_C2_RK4 * per_gpu_steps,
@@ -483,8 +545,7 @@ def main():
                 pj = json.load(open(pmc))
                 pp = pj["per_particle_step"]
                 busy = pp["valu_busy_simd_cycles"] * per_gpu_steps  # SIMD-cycles
-                roof["achieved"] = busy / kernel_s / 1e9
-                roof["frac"] = roof["achieved"] / peak_cycles
+                roof["valu_busy_frac"] = busy / kernel_s / 1e9 / peak_cycles  # at the 2.4 GHz peak clock
                 roof["valu_insts_per_wave_evaluation"] = pp["valu_insts_per_wave_eval"]
                 if pp.get("fetch_bytes") is not None and pp.get("write_bytes") is not None:
                     traffic = (pp["fetch_bytes"] + pp["write_bytes"]) * per_gpu_steps
@@ -495,16 +556,14 @@ def main():
                 roof["counters_stale"] = counters_stale("AdvectionRK4", pj)  # the kernel changed since the PMC passes
                 isa = os.path.join(ROOT, "profiles", "isa_latest.json")
                 if os.path.exists(isa):
-                    # what the VALU-busy fraction above is made of (tools/isa_histogram.py: instruction classes of the kernel's inner loops
-                    # from hipcc -S): only the fp64 add / mul / fma / division / sqrt instructions are arithmetic the algorithm asks for
+                    # what the busy share is made of (tools/isa_histogram.py: instruction classes of the kernel's inner loops from hipcc -S):
+                    # EXECUTED fp64 arithmetic of this binary, next to the algorithmic figure `frac` is built on
                     ij = json.load(open(isa))
-                    evals_s = per_gpu_steps * 4 / kernel_s  # RK4: 4 evaluations per particle-step; per lane
                     ops = pp["valu_insts_per_wave_eval"] * ij["fp64_arith_fraction_of_valu"]
                     flops = pp["valu_insts_per_wave_eval"] * ij["fp64_flops_per_valu_instruction_per_lane"]
-                    roof["fp64_ops_per_evaluation"] = ops  # fp64 arithmetic wave-instructions per evaluation
-                    roof["fp64_flops_per_evaluation"] = flops  # per lane, an FMA counts 2
-                    roof["frac_fp64_peak"] = flops * evals_s / 78.6e12  # of the 78.6 TFLOP/s fp64 FMA peak
-                    roof["frac_fp64_peak_no_fma"] = ops * evals_s / 39.3e12  # one operation per lane and issue slot (-ffp-contract=off: NumPy never fuses)
+                    roof["executed_fp64_ops_per_evaluation"] = ops  # fp64 arithmetic wave-instructions per evaluation
+                    roof["executed_fp64_flops_per_evaluation"] = flops  # per lane, an FMA counts 2
+                    roof["frac_executed_fp64"] = flops * evals_s / (FP64_VECTOR_PEAK_TFLOPS * 1e12)
                     roof["valu_class_fractions"] = ij["valu_class_fractions"]
                     roof["valu_cycles_per_instruction_model"] = ij["valu_cycles_per_instruction"]  # fp64 / conversions 4 cycles, everything else 2
                     roof["frac_issue_model"] = pp["valu_insts_per_wave_eval"] * ij["valu_cycles_per_instruction"] * (evals_s / 64) / (peak_cycles * 1e9)
@@ -568,6 +627,13 @@ def main():
             except Exception as e:
                 out["long_run"] = {"error": repr(e)[:2000]}
             legs["long_run"] = time.perf_counter() - _t
+        if args.repeat_execute and world == 1:
+            _t = time.perf_counter()
+            try:
+                out["repeat_execute"] = repeat_execute(case, fs, int(args.repeat_execute), K)
+            except Exception as e:
+                out["repeat_execute"] = {"error": repr(e)[:2000]}
+            legs["repeat_execute"] = time.perf_counter() - _t
         if args.secondary and world == 1:
             # release the headline's device and host memory first: C3 needs 36 GB of HBM and 48 GB of host arrays
             pset = kern = eng = fs = case = None

@@ -80,18 +80,31 @@ def batch_agreement(group=None, device=None):
     on_gpu = dist.get_backend(group) == "nccl"
     dev = torch.device("cuda", torch.cuda.current_device() if device is None else int(device)) if on_gpu else torch.device("cpu")
     big = (1 << 62)
+    import time as _time
+
+    # what the lock-step points cost: calls and wall seconds spent inside the two all-reduces (including the wait for the slowest rank);
+    # ParticleSet.execute copies it to `pset._agreement_stats`, bench.py --c4 prints it
+    stats = {"calls": 0, "seconds": 0.0}
 
     def agree_min(err, key):
+        t0 = _time.perf_counter()
         t = torch.tensor([int(err) or big, int(key) or big], dtype=torch.int64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
         e, k = (int(v) for v in t.tolist())
+        stats["calls"] += 1
+        stats["seconds"] += _time.perf_counter() - t0
         return (0 if e == big else e), (0 if k == big else k)
 
     def agree_codes(present):
+        t0 = _time.perf_counter()
         t = torch.tensor([int(bool(p)) for p in present], dtype=torch.int64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-        return [int(v) for v in t.tolist()]
+        out = [int(v) for v in t.tolist()]
+        stats["calls"] += 1
+        stats["seconds"] += _time.perf_counter() - t0
+        return out
 
+    agree_min.stats = agree_codes.stats = stats
     return agree_min, agree_codes
 
 

@@ -98,6 +98,8 @@ class DeviceEngine:
         self._bound_sig = None
         self._bound = None
         self._sorted_t = None  # model time at which the device rows were last cell-sorted (None: host order / unknown)
+        # what crossed PCIe for the particle columns: calls and column counts (tests and bench.py's `repeat_execute` leg read it)
+        self.transfers = {"h2d_full": 0, "h2d_columns": 0, "d2h_full": 0, "d2h_columns": 0, "columns_up": 0, "columns_down": 0}
         self._next_dt_f32 = None
         self.device_variables: list[str] = []  # user Variables bound as extra device columns (set by Kernel: SampleField targets)
         # a sharded ParticleSet is one batch: hooks of parcels_amd.distributed.batch_agreement (set by ParticleSet.execute for a collective run)
@@ -448,6 +450,8 @@ class DeviceEngine:
             self._next_dt_f32[1][:] = self._next_dt_f32[0]
         if mask:
             self.ctx.check(self.lib.pk_particles_h2d_columns(self.ctx.handle, mask), "pk_particles_h2d_columns")
+            self.transfers["h2d_columns"] += 1
+            self.transfers["columns_up"] += bin(mask).count("1")
         if any(k in ("x", "y", "z") for k in columns):
             self._sorted_t = None  # the host moved particles: the next launch sorts again
 
@@ -515,6 +519,7 @@ class DeviceEngine:
         if self._next_dt_f32 is not None:
             self._next_dt_f32[1][:] = self._next_dt_f32[0]
         self.ctx.check(self.lib.pk_particles_h2d(self.ctx.handle), "pk_particles_h2d")
+        self.transfers["h2d_full"] += 1
         self._sorted_t = None  # host row order again
         b = self._bound
         if isinstance(b, LazyColumns):  # host and device agree: the set is resident from here on
@@ -526,11 +531,14 @@ class DeviceEngine:
         """Copy the particle columns back to the bound NumPy arrays (all, or only the named ones)."""
         if columns is None:
             self.ctx.check(self.lib.pk_particles_d2h(self.ctx.handle), "pk_particles_d2h")
+            self.transfers["d2h_full"] += 1
         else:
             mask = 0
             for name in columns:
                 mask |= self._column_bit(name)
             self.ctx.check(self.lib.pk_particles_d2h_columns(self.ctx.handle, mask), "pk_particles_d2h_columns")
+            self.transfers["d2h_columns"] += 1
+            self.transfers["columns_down"] += bin(mask).count("1")
         if self._next_dt_f32 is not None and (columns is None or "next_dt" in columns):
             self._next_dt_f32[0][:] = self._next_dt_f32[1]
         b = self._bound

@@ -449,6 +449,8 @@ class ParticleSet:
                     if writer is not None:
                         writer.close()
         finally:
+            if getattr(engine, "agree_min", None) is not None:
+                self._agreement_stats = dict(getattr(engine.agree_min, "stats", {}) or {})  # calls / seconds inside the batch agreements of this execute
             engine.agree_min = engine.agree_codes = None
             if not synced and len(self) > 0 and not lazy:
                 engine.d2h()

@@ -1,0 +1,137 @@
+"""Particle columns stay device-resident from one ParticleSet.execute to the next (parcels_amd/columns.py): the
+trajectories of a script that calls execute() repeatedly -- untouched, read, written, shrunk, interleaved with another ParticleSet -- are
+bit for bit those of the eager path (PARCELS_AMD_NO_RESIDENT=1: every call uploads and downloads everything, like rounds 1-4), and the
+calls that the host did not touch move no column across PCIe."""
+
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import pytest
+
+from case_utils import build_fieldset, build_pset, compare
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(npart=6000, kernels=("AdvectionRK4", "DeleteParticle"), curv=False, seed=11):
+    from oracle import cases
+
+    if curv:
+        return cases.curv_cgrid_case("resident_c", mesh="spherical", kernels=list(kernels), seed=seed, npart=npart, with_w=False, dt=1800.0,
+                                     runtime=None, vel=1.5)
+    return cases.rect_agrid_case("resident_a", mesh="spherical", kernels=list(kernels), seed=seed, npart=npart, runtime=None)
+
+
+def _script(case, calls, steps, between=None, eager=False, sort=True, two_sets=False):
+    """`calls` x pset.execute(steps); between(pset, k) runs on the host after call k.  Returns (final columns, transfer counters per call)."""
+    import parcels_amd as pa
+
+    old = os.environ.get("PARCELS_AMD_NO_RESIDENT")
+    if eager:
+        os.environ["PARCELS_AMD_NO_RESIDENT"] = "1"
+    try:
+        fs = build_fieldset(case)
+        fs.to_device(0)
+        pset = build_pset(case, fs, sort_by_cell=sort)
+        other = build_pset(dict(case, x=np.asarray(case["x"])[:100] + 0.01, y=np.asarray(case["y"])[:100], z=None if case.get("z") is None else np.asarray(case["z"])[:100]), fs,
+                           sort_by_cell=False) if two_sets else None
+        kernels = [getattr(pa.kernels, k) for k in case["kernels"]]
+        eng = fs._engine
+        log = []
+        for k in range(calls):
+            before = dict(eng.transfers)
+            pset.execute(kernels, dt=float(case["dt"]), runtime=steps * float(case["dt"]))
+            log.append({key: eng.transfers[key] - before[key] for key in before})
+            if other is not None and k % 2 == 0:
+                other.execute(kernels, dt=float(case["dt"]), runtime=steps * float(case["dt"]))
+            if between is not None:
+                between(pset, k)
+        return {k: np.array(v) for k, v in pset._data.items()}, log, (None if other is None else {k: np.array(v) for k, v in other._data.items()})
+    finally:
+        if old is None:
+            os.environ.pop("PARCELS_AMD_NO_RESIDENT", None)
+        else:
+            os.environ["PARCELS_AMD_NO_RESIDENT"] = old
+
+
+@pytest.mark.parametrize("curv", [False, True])
+def test_repeated_execute_equals_the_eager_path_and_moves_nothing(gpu, curv):
+    case = _case(curv=curv)
+    lazy, log, _ = _script(case, calls=6, steps=4)
+    eager, elog, _ = _script(case, calls=6, steps=4, eager=True)
+    compare(lazy, eager, rtol=0.0, check_state="all", label="resident vs eager", skip=())
+    assert log[0]["h2d_full"] == 1
+    for k, entry in enumerate(log[1:], 1):
+        # rectilinear: nothing at all; curvilinear: the batch-wide guess test of the reference reads `ei` (one column down), nothing up
+        assert entry["h2d_full"] == 0 and entry["h2d_columns"] == 0 and entry["d2h_full"] == 0, (k, entry)
+        assert entry["columns_down"] <= (1 if curv else 0), (k, entry)
+    assert all(e["h2d_full"] == 1 for e in elog)
+
+
+def test_one_long_call_equals_many_short_ones(gpu):
+    case = _case(kernels=("AdvectionRK4",))
+    many, _, _ = _script(case, calls=8, steps=3)
+    one, _, _ = _script(case, calls=1, steps=24)
+    compare(many, one, rtol=0.0, check_state="all", label="8 x 3 steps vs 24 steps", skip=())
+
+
+def test_host_reads_and_writes_between_calls(gpu):
+    case = _case()
+
+    def between(pset, k):
+        if k == 1:
+            assert np.isfinite(pset.x).all()  # a read: x comes down (and goes up again: the array was handed out)
+        if k == 2:
+            pset._data["y"][::7] += 0.25  # an in-place write
+            pset._data["x"][::5] -= 0.125
+        if k == 3:
+            pset[3].x = 12.5  # through the one-row view
+
+    lazy, log, _ = _script(case, calls=6, steps=3, between=between)
+    eager, _, _ = _script(case, calls=6, steps=3, between=between, eager=True)
+    compare(lazy, eager, rtol=0.0, check_state="all", label="host access between calls", skip=())
+    assert log[2]["columns_up"] == 1 and log[2]["h2d_full"] == 0  # call 3 uploads x, the column the read handed out
+    assert log[3]["columns_up"] == 2 and log[4]["columns_up"] == 1 and log[5]["columns_up"] == 0
+
+
+def test_shrinking_the_set_and_a_second_set_on_the_same_engine(gpu):
+    case = _case()
+
+    def between(pset, k):
+        if k == 1:
+            pset.remove_indices(np.arange(0, len(pset), 9))
+
+    lazy, log, other = _script(case, calls=5, steps=3, between=between, two_sets=True)
+    eager, _, eother = _script(case, calls=5, steps=3, between=between, two_sets=True, eager=True)
+    compare(lazy, eager, rtol=0.0, check_state="all", label="remove_indices + second set", skip=())
+    compare(other, eother, rtol=0.0, check_state="all", label="the second set", skip=())
+
+
+def test_deletions_and_output_file_with_resident_columns(gpu, tmp_path):
+    """DeleteParticle compacts on the device, a ParticleFile snapshots on the device: both with columns that never went back to the host."""
+    import parcels_amd as pa
+
+    from oracle import cases
+
+    case = cases.rect_agrid_case("resident_out", mesh="spherical", kernels=["AdvectionRK4", "DeleteParticle"], seed=5, npart=4000, runtime=None, vel=8.0)
+    outs = {}
+    for eager in (False, True):
+        if eager:
+            os.environ["PARCELS_AMD_NO_RESIDENT"] = "1"
+        try:
+            fs = build_fieldset(case)
+            fs.to_device(0)
+            pset = build_pset(case, fs, sort_by_cell=True)
+            path = tmp_path / f"o{int(eager)}.parquet"
+            for k in range(3):
+                pf = pa.ParticleFile(tmp_path / f"o{int(eager)}_{k}.parquet", outputdt=2 * float(case["dt"]))
+                pset.execute([pa.AdvectionRK4, pa.DeleteParticle], dt=float(case["dt"]), runtime=6 * float(case["dt"]), output_file=pf)
+            outs[eager] = ({k: np.array(v) for k, v in pset._data.items()}, [pa.read_particlefile(tmp_path / f"o{int(eager)}_{k}.parquet") for k in range(3)])
+        finally:
+            os.environ.pop("PARCELS_AMD_NO_RESIDENT", None)
+    compare(outs[False][0], outs[True][0], rtol=0.0, check_state="all", label="resident vs eager with output", skip=())
+    assert len(outs[False][0]["x"]) < 4000, "nothing was deleted: the test does not test the compaction"
+    for a, b in zip(outs[False][1], outs[True][1]):
+        assert a.equals(b)

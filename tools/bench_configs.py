@@ -161,15 +161,16 @@ def run_c4(scale=1.0, particles=1e7, steps=24, nt=4, nslots=3, nz=75, output_eve
     sl = shard_slice(world * n, rank, world)
     pset, pf, wall = one_run(sl.start, sl.stop, out_path, True)
     st = pset._last_stats
-    vals = torch.tensor([wall, float(len(pset)), pf.gather_seconds], dtype=torch.float64)
+    ag = getattr(pset, "_agreement_stats", None) or {}  # the per-pass batch agreements of a collective run (parcels_amd.distributed.batch_agreement)
+    vals = torch.tensor([wall, float(len(pset)), pf.gather_seconds, float(ag.get("seconds", 0.0))], dtype=torch.float64)
     if world > 1:
         mx = vals.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = vals.clone()
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        wall, remaining, gather_s = float(mx[0]), int(sm[1]), float(mx[2])
+        wall, remaining, gather_s, agree_s = float(mx[0]), int(sm[1]), float(mx[2]), float(mx[3])
     else:
-        remaining, gather_s = len(pset), pf.gather_seconds
+        remaining, gather_s, agree_s = len(pset), pf.gather_seconds, float(ag.get("seconds", 0.0))
     if rank == 0:
         import pyarrow.parquet as pq
 
@@ -178,6 +179,8 @@ def run_c4(scale=1.0, particles=1e7, steps=24, nt=4, nslots=3, nz=75, output_eve
                "particles_total": world * n, "steps": steps, "output_every_steps": output_every, "wall_s_incl_writeout": wall,
                "particle_steps_per_s_wall": world * n * steps / wall, "writeout_gather_s_max_rank": gather_s, "parquet_rows": rows,
                "remaining_particles": remaining, "last_interval_kernel_ms_rank0": st["kernel_ms"], "dataset_generation_s": gen_s,
+               "batch_agreements": {"calls_rank0": int(ag.get("calls", 0)), "seconds_max_rank": agree_s,
+                                    "note": "all-reduces that make the shards one batch for the error stop / call-wide time error: inside wall_s_incl_writeout"},
                "shared_fields": shared_dir, **({"rehearsal_shared_gpu_gloo": True} if rehearsal else {})}
         if verify_single:
             single = os.path.join(shared_dir, "c4_single.parquet")
@@ -268,6 +271,7 @@ def run_config(config="c3", scale=1.0, particles=1e7, steps=24, nt=4, nslots=3, 
         ("AdvectionDiffusionM1", [pa.AdvectionDiffusionM1, pa.DeleteParticle], "m1"),
     ]
     results = []
+    pack_per_pair = None  # (the copies packed for the first 2-D kernel list serve the next one: one measurement of the packing)
     for label, kernels, kind in runs:
         pclass = pa.get_default_particle(np.float64)
         if kind == "rk45":
@@ -324,7 +328,9 @@ def run_config(config="c3", scale=1.0, particles=1e7, steps=24, nt=4, nslots=3, 
             finally:
                 eng.ctx.set_option("velocity_pairs", 0)
             kp = sorted(pk[1:])[(len(pk[1:]) - 1) // 2]
-            per_pair = pack_ms / packs if packs else None
+            if packs:
+                pack_per_pair = pack_ms / packs
+            per_pair = pack_per_pair
             out["velocity_pairs"] = {
                 "default": "off", "kernel_ms": kp, "kernel_ms_all": pk, "packs_first_launch": packs, "pack_ms_first_launch": pack_ms,
                 "pack_ms_per_pair": per_pair, "kernel_plus_pack_ms": (kp + per_pair) if per_pair is not None else None,
