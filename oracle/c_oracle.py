@@ -636,12 +636,27 @@ def run_case(case: dict, nthreads: int = 1, call_wide_time_error: bool = True):
             stops.append(time)
             if abs(time - next_output) < 0.001:
                 next_output += float(case["outputdt"]) * sign
+    # what the loop hands a ParticleFile (particleset.py:401-403, 436-457): the whole set at the start and at every output time
+    obs = []
+    snap = lambda tm: obs.append((float(tm), {k: np.array(data[k], copy=True) for k in ("particle_id", "t", "z", "y", "x")}))  # noqa: E731
+    next_output = None
+    if case.get("outputdt"):
+        snap(start)
+        next_output = start + float(case["outputdt"]) * sign
+    stats = {}
     for stop in stops:
-        stats = execute(mc, data, kernels=case["kernels"], endtime=stop, dt0=dt, context=ctx, seed=case.get("seed", 0),
-                        have_guess0=have_guess0, nthreads=nthreads, call_wide_time_error=call_wide_time_error)
-        have_guess0 = 1
-        if len(data["state"]) == 0 or np.any(data["state"] >= 50):
+        if len(data["state"]) > 0:  # (an emptied set: the reference's loop goes on to the end time, writing empty tables, particleset.py:444-462)
+            stats = execute(mc, data, kernels=case["kernels"], endtime=stop, dt0=dt, context=ctx, seed=case.get("seed", 0),
+                            have_guess0=have_guess0, nthreads=nthreads, call_wide_time_error=call_wide_time_error)
+            have_guess0 = 1
+        if np.any(data["state"] >= 50) or (len(data["state"]) == 0 and next_output is None):
             break
+        if next_output is not None and abs(stop - next_output) < 0.001:
+            snap(next_output)
+            next_output += float(case["outputdt"]) * sign
+    if obs:
+        stats = dict(stats)
+        stats["observations"] = obs
     err = None
     for code, name in ERRORS_TO_THROW:
         if np.any(data["state"] == code):

@@ -880,4 +880,17 @@ def all_cases() -> dict:
     pc["t0"] = np.round(_rng(604).uniform(0, 5, len(pc["x"]))) * 900.0
     add(past_the_end(pc))
 
+    # --- the `_delete` cases above end with NO particle left (everyone evaluated in the fatal iteration is deleted): they pin the
+    #     discrete outcome but not a single position.  Siblings with an output interval: the positions, ids and times of the doomed
+    #     particles at every output time before the sample that fails call-wide (and the interval structure: one Kernel.execute per
+    #     interval, the keys of the failing samples counted per call) are compared too.
+    for nm in ("twe_agrid_sph_ee_delete", "twe_agrid_flat_rk4_3d_delete_f32part", "twe_agrid_sph_rk4_backward_delete",
+               "twe_agrid_sph_rk4_sample_p_delete", "twe_cgrid_curv_sph_rk4_3d_delete", "twe_cgrid_curv_sph_m1_delete"):
+        import copy
+
+        sib = copy.deepcopy(c[nm])
+        sib["name"] = nm + "_outputdt"
+        sib["outputdt"] = 5.0 * 3600.0
+        add(sib)
+
     return c

@@ -407,4 +407,10 @@ def run_reference(fieldset, kernels, *, x, y, z, t=None, dt, runtime=None, endti
         out["obs_time"] = np.array(stub.times)
         for k in ("particle_id", "t", "z", "y", "x"):
             out["obs_" + k] = np.stack([o[k] for o in stub.obs])
+    elif stub is not None and stub.obs:
+        # deletions between the output times: ragged -- the observations back to back, observation k = rows obs_offsets[k] : obs_offsets[k + 1]
+        out["obs_time"] = np.array(stub.times)
+        out["obs_offsets"] = np.concatenate([[0], np.cumsum([len(o["x"]) for o in stub.obs])]).astype(np.int64)
+        for k in ("particle_id", "t", "z", "y", "x"):
+            out["obs_" + k] = np.concatenate([o[k] for o in stub.obs])
     return out, err

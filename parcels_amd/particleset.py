@@ -417,8 +417,9 @@ class ParticleSet:
 
                             if allreduce_scalars([float(len(self))], "sum", output_file._group, device=engine.device)[0] == 0:
                                 break
-                        elif len(self) == 0:
-                            break
+                        elif len(self) == 0 and next_output is None:
+                            break  # (with an output file the reference's loop goes on to the end time and writes an (empty) table at every
+                            #         remaining output time, particleset.py:444-462: same calls here)
                         if next_output is not None and np.abs(next_time - next_output) < 0.001:
                             if writer is not None and not synced:
                                 # snapshot on the device, D2H on the copy stream, filter + Parquet encode on the writer thread --

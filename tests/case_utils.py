@@ -135,6 +135,15 @@ def build_pset(case, fs, **kw):
                           seed=int(case.get("seed", 0)), **kw)
 
 
+def golden_observation(out, k):
+    """Observation k of a fixture: (ids, t, z, y, x) -- rectangular arrays, or ragged ones (deletions between the output times) stored back
+    to back with `obs_offsets` (oracle/ref_shim.py)."""
+    if "obs_offsets" in out:
+        sl = slice(int(out["obs_offsets"][k]), int(out["obs_offsets"][k + 1]))
+        return tuple(out["obs_" + c][sl] for c in ("particle_id", "t", "z", "y", "x"))
+    return tuple(out["obs_" + c][k] for c in ("particle_id", "t", "z", "y", "x"))
+
+
 class OutputRecorder:
     """Duck-typed ParticleFile: makes ParticleSet.execute split the run into output intervals (particleset.py:419-462) and
     records the observations in memory."""
