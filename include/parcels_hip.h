@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PK_ABI_VERSION 8 /* 8: pk_particles_h2d_columns / _fill_f64 / _t_stats (device-resident columns across execute calls), pk_exec_stats.pack_ms / packs (the pair-copy packing ahead of a launch, timed) / sclk_mhz, "velocity_pairs" opt-in; 7: the call-wide OutsideTimeInterval of the reference on the device (pk_exec_params.twe_n / twe_key, pk_exec_stats.first_time_error_key, pk_execute_rerun_keys); 6: PK_MAX_FIELDS 64 (descriptors in device memory), PK_MAX_EXTRA 8, pk_particles_checkpoint / _restore, user kernels (PK_KERNEL_USER0 .., pk_generic_variant, pk_set_user_program), "eval_points_f32" option; 5: pk_exec_params.horizon_lo / horizon_hi / max_iters, pk_exec_stats.first_error_iter / program, pk_execute_rerun, "fast_cgrid" option; 4: pk_upload_stats, pk_host_stage_selftest, PK_KERNEL_DO_NOTHING / _MOVE_EAST / _MOVE_NORTH, vector PK_KERNEL_SAMPLE_FIELD, "cell_table" option */
+#define PK_ABI_VERSION 8 /* 8: pk_execute_twe_report (all failing samples of a pass at once), pk_particles_h2d_columns / _fill_f64 / _t_stats (device-resident columns across execute calls), pk_exec_stats.pack_ms / packs (the pair-copy packing ahead of a launch, timed) / sclk_mhz, "velocity_pairs" opt-in; 7: the call-wide OutsideTimeInterval of the reference on the device (pk_exec_params.twe_n / twe_key, pk_exec_stats.first_time_error_key, pk_execute_rerun_keys); 6: PK_MAX_FIELDS 64 (descriptors in device memory), PK_MAX_EXTRA 8, pk_particles_checkpoint / _restore, user kernels (PK_KERNEL_USER0 .., pk_generic_variant, pk_set_user_program), "eval_points_f32" option; 5: pk_exec_params.horizon_lo / horizon_hi / max_iters, pk_exec_stats.first_error_iter / program, pk_execute_rerun, "fast_cgrid" option; 4: pk_upload_stats, pk_host_stage_selftest, PK_KERNEL_DO_NOTHING / _MOVE_EAST / _MOVE_NORTH, vector PK_KERNEL_SAMPLE_FIELD, "cell_table" option */
 #define PK_MAX_GRIDS 4
 #define PK_MAX_FIELDS 64
 #define PK_MAX_KERNELS 8
@@ -389,6 +389,13 @@ int32_t pk_execute(pk_ctx* ctx, const pk_exec_params* params, pk_exec_stats* sta
  * pk_exec_stats.first_error_iter is non-zero, this call restores the particle columns to their state before that launch (the launch
  * wrote into the second column set: nothing was copied) and runs it again with max_iters = that index.  Must directly follow the
  * pk_execute / pk_execute_end of the launch (before any pk_particles_* call); stats replace those of the launch. */
+/* The call-wide OutsideTimeInterval in few passes (field.py:31-44, index_search.py:85-86).  After pk_execute / pk_execute_end / pk_execute_rerun*:
+ * found[0 .. *n_found) = every sample key (ascending; see pk_exec_params.twe_key) NOT in the launch's list at which a particle left a field's time
+ * interval, as far as the general programs reported them (the dedicated kernels report only the smallest: pk_exec_stats.first_time_error_key);
+ * *n_found = -1 when there were more distinct keys than the device-side set holds.  listed_hit[k] = 1 when at LISTED sample k some particle really
+ * was outside the interval -- a listed sample nobody justifies was listed on a trajectory that no longer exists and has to go.  The host lists
+ * all found keys at once and validates the listing with the next pass, instead of finding one key per pass (parcels_amd/engine.py). */
+int32_t pk_execute_twe_report(pk_ctx* ctx, int64_t* found, int32_t cap, int32_t* n_found, uint8_t* listed_hit, int32_t n_listed);
 /* User kernels (PK_KERNEL_USER0 ..), compiled at run time (parcels_amd/jit.py).
  * pk_generic_variant: what a launch with `prm` (the real kernel list, user ids included) runs on this context, given what the user kernels
  * sample (sample_flags: PK_USER_SAMPLES_UV / _UVW; sample_fids: nsample <= 4 scalar field ids) -- key = (float32 fields ? 6 : 0) +

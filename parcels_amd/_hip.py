@@ -223,6 +223,7 @@ ABI_SYMBOLS = [
     "pk_execute_end",
     "pk_execute_rerun",
     "pk_execute_rerun_keys",
+    "pk_execute_twe_report",
     "pk_eval",
     "pk_search",
     "pk_measure_copy_bandwidth",
@@ -293,6 +294,7 @@ def load():
     lib.pk_execute_end.argtypes = [C.c_void_p, C.POINTER(ExecStats)]
     lib.pk_execute_rerun.argtypes = [C.c_void_p, C.c_int32, C.POINTER(ExecStats)]
     lib.pk_execute_rerun_keys.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(ExecStats)]
+    lib.pk_execute_twe_report.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_uint8), C.c_int32]
     lib.pk_eval.argtypes = [C.c_void_p, C.POINTER(ExecParams), C.c_int32, C.c_int64] + [C.c_void_p] * 8
     lib.pk_search.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pk_measure_copy_bandwidth.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_double)]

@@ -112,6 +112,12 @@ struct pk_ctx {
     DCounters* h_counters = nullptr;          // pinned: the async D2H of the counters must not block the host
     DCounters h_counters0;                    // initial values of a launch's counters (pageable: the H2D copy stages it at once)
     unsigned long long* d_twe = nullptr;      // PK_MAX_TWE keys: the failing samples a launch knows (pk_exec_params.twe_key)
+    unsigned long long* d_twe_found = nullptr;  // TWE_FOUND_SLOTS: hash set of the unlisted failing samples of a launch (pk_device.h: twe_note_all)
+    unsigned int* d_twe_hit = nullptr;          // PK_MAX_TWE: listed sample k was justified by a lane of the launch (twe_justify)
+    std::vector<int64_t> twe_found_host;        // ... of the last completed launch, ascending (pk_execute_twe_report)
+    std::vector<uint8_t> twe_hit_host;
+    bool twe_overflow_host = false;
+    int fl_twe_n = 0;                           // listed keys of the launch in flight
     std::vector<int64_t> rerun_keys;          // the keys of the last launch (pk_execute_rerun repeats it with them)
     unsigned long long* h_summary = nullptr;  // pinned
     unsigned long long* d_clk = nullptr;      // clock probes around the advection kernel: [before | after][XCD 0..7]{shader-clock counter, 100 MHz counter}
@@ -641,6 +647,8 @@ int32_t pk_init(int32_t device, pk_ctx** out) {
     for (int k = 0; k < PK_STAGE_BUFFERS; k++) PK_HIP(ctx, hipEventCreateWithFlags(&ctx->stage_ev[k], hipEventDisableTiming));
     PK_HIP(ctx, hipMalloc((void**)&ctx->d_counters, sizeof(DCounters)));
     PK_HIP(ctx, hipMalloc((void**)&ctx->d_twe, sizeof(unsigned long long) * PK_MAX_TWE));
+    PK_HIP(ctx, hipMalloc((void**)&ctx->d_twe_found, sizeof(unsigned long long) * TWE_FOUND_SLOTS));
+    PK_HIP(ctx, hipMalloc((void**)&ctx->d_twe_hit, sizeof(unsigned int) * PK_MAX_TWE));
     PK_HIP(ctx, hipMalloc((void**)&ctx->d_summary, sizeof(unsigned long long) * (PK_NUM_STATE_CODES + 2)));
     PK_HIP(ctx, hipHostMalloc((void**)&ctx->h_counters, sizeof(DCounters), hipHostMallocDefault));
     PK_HIP(ctx, hipHostMalloc((void**)&ctx->h_summary, sizeof(unsigned long long) * (PK_NUM_STATE_CODES + 2), hipHostMallocDefault));
@@ -739,6 +747,8 @@ int32_t pk_destroy(pk_ctx* ctx) {
     if (ctx->d_vp) (void)hipFree(ctx->d_vp);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_twe) (void)hipFree(ctx->d_twe);
+    if (ctx->d_twe_found) (void)hipFree(ctx->d_twe_found);
+    if (ctx->d_twe_hit) (void)hipFree(ctx->d_twe_hit);
     if (ctx->d_desc) (void)hipFree(ctx->d_desc);
     if (ctx->h_desc) (void)hipHostFree(ctx->h_desc);
     if (ctx->d_summary) (void)hipFree(ctx->d_summary);
@@ -1755,6 +1765,8 @@ static int32_t fill_args(pk_ctx* ctx, const pk_exec_params* prm, KArgs& a, size_
     a.prm = *prm;
     a.counters = ctx->d_counters;
     a.twe_listed = ctx->d_twe;
+    a.twe_found = ctx->d_twe_found;
+    a.twe_hit = ctx->d_twe_hit;
     const int nf = (int)ctx->fields.size();
     auto valid = [&](int f) { return f >= 0 && f < nf; };
     if (!valid(prm->fU) || !valid(prm->fV)) return ctx->fail("params.fU/fV must name existing fields");
@@ -2270,8 +2282,11 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
     for (int k = 1; k < prm->twe_n; k++)
         if (!(prm->twe_key[k - 1] < prm->twe_key[k])) return ctx->fail("params.twe_key must be ascending");
     DCounters& counters0 = ctx->h_counters0;
-    counters0 = DCounters{0ull, 0ull, 0ull, 0xFFFFFFFFu, 0u, ~0ull};
+    counters0 = DCounters{0ull, 0ull, 0ull, 0xFFFFFFFFu, 0u, ~0ull, 0u, 0u};
     PK_HIP(ctx, hipMemcpyAsync(ctx->d_counters, &counters0, sizeof(DCounters), hipMemcpyHostToDevice, ctx->compute));
+    PK_HIP(ctx, hipMemsetAsync(ctx->d_twe_found, 0, sizeof(unsigned long long) * TWE_FOUND_SLOTS, ctx->compute));
+    if (prm->twe_n > 0) PK_HIP(ctx, hipMemsetAsync(ctx->d_twe_hit, 0, sizeof(unsigned int) * prm->twe_n, ctx->compute));
+    ctx->fl_twe_n = prm->twe_n;
     if (prm->twe_key != ctx->rerun_keys.data()) ctx->rerun_keys.assign(prm->twe_key, prm->twe_key + prm->twe_n);  // (kept for pk_execute_rerun)
     if (prm->twe_n > 0)
         PK_HIP(ctx, hipMemcpyAsync(ctx->d_twe, ctx->rerun_keys.data(), sizeof(int64_t) * prm->twe_n, hipMemcpyHostToDevice, ctx->compute));
@@ -2447,6 +2462,23 @@ int32_t pk_execute_end(pk_ctx* ctx, pk_exec_stats* stats) {
         stats->program = ctx->fl_launches ? ctx->fl_program : 0;
         stats->first_error_iter = (ctx->fl_launches && hc.err_iter != 0xFFFFFFFFu) ? (int64_t)hc.err_iter : 0;
         stats->first_time_error_key = (ctx->fl_launches && hc.twe_key != ~0ull) ? (int64_t)hc.twe_key : 0;
+        // the cold path of the call-wide time error: every unlisted failing sample the general programs reported, and which listed samples a lane
+        // justified (pk_execute_twe_report hands them out) -- copied only when there is something to report
+        ctx->twe_found_host.clear();
+        ctx->twe_hit_host.assign((size_t)ctx->fl_twe_n, 0);
+        ctx->twe_overflow_host = hc.twe_overflow != 0;
+        if (ctx->fl_launches && hc.twe_key != ~0ull) {
+            std::vector<unsigned long long> slots(TWE_FOUND_SLOTS);
+            PK_HIP(ctx, hipMemcpy(slots.data(), ctx->d_twe_found, sizeof(unsigned long long) * TWE_FOUND_SLOTS, hipMemcpyDeviceToHost));
+            for (unsigned long long k : slots)
+                if (k) ctx->twe_found_host.push_back((int64_t)k);
+            std::sort(ctx->twe_found_host.begin(), ctx->twe_found_host.end());
+        }
+        if (ctx->fl_launches && ctx->fl_twe_n > 0) {
+            std::vector<unsigned int> hit((size_t)ctx->fl_twe_n);
+            PK_HIP(ctx, hipMemcpy(hit.data(), ctx->d_twe_hit, sizeof(unsigned int) * ctx->fl_twe_n, hipMemcpyDeviceToHost));
+            for (int k = 0; k < ctx->fl_twe_n; k++) ctx->twe_hit_host[k] = hit[k] ? 1 : 0;
+        }
         // average shader clock of the advection kernel: cycle-counter / 100 MHz-counter deltas of the XCDs both probes reached
         double sclk = 0.0;
         int nx = 0;
@@ -2466,6 +2498,16 @@ int32_t pk_execute_end(pk_ctx* ctx, pk_exec_stats* stats) {
         stats->packs = ctx->fl_packs;
     }
     ctx->fl_packs = 0;
+    return 0;
+}
+
+int32_t pk_execute_twe_report(pk_ctx* ctx, int64_t* found, int32_t cap, int32_t* n_found, uint8_t* listed_hit, int32_t n_listed) {
+    if (!ctx || !n_found || cap < 0 || n_listed < 0 || (cap > 0 && !found) || (n_listed > 0 && !listed_hit)) return -2;
+    if (ctx->in_flight) return ctx->fail("pk_execute_twe_report: a launch is in flight (call pk_execute_end)");
+    const int32_t nf = (int32_t)ctx->twe_found_host.size();
+    *n_found = ctx->twe_overflow_host ? -1 : nf;  // -1: more distinct keys than the set holds (trust pk_exec_stats.first_time_error_key only)
+    for (int32_t k = 0; k < nf && k < cap; k++) found[k] = ctx->twe_found_host[k];
+    for (int32_t k = 0; k < n_listed; k++) listed_hit[k] = k < (int32_t)ctx->twe_hit_host.size() ? ctx->twe_hit_host[k] : 0;
     return 0;
 }
 

@@ -95,6 +95,7 @@ struct DCounters {
     unsigned long long steps, attempts, paused;
     unsigned int err_iter, pad;  // smallest iteration index (1-based) in which a particle entered an error state; 0xFFFFFFFF = none
     unsigned long long twe_key;  // smallest key of a sample (pk_exec_params.twe_key) at which a particle left a time interval; ~0 = none
+    unsigned int twe_overflow, pad2;  // keys that found no slot in KArgs::twe_found (the host then trusts only twe_key)
 };
 
 // Wave-uniform constants of the fast path for XLinear_Velocity on a rectilinear A-grid with float64 coordinates
@@ -168,6 +169,8 @@ struct KArgs {
     double win_lo, win_hi;  // resident time window of the time-varying fields (seconds)
     DCounters* counters;
     const unsigned long long* twe_listed;  // the launch's copy of pk_exec_params.twe_key (ascending; device memory, read on the cold path only)
+    unsigned long long* twe_found;         // hash set (TWE_FOUND_SLOTS slots, 0 = empty) of the unlisted samples at which a lane left a time interval
+    unsigned int* twe_hit;                 // [twe_n] listed sample k: some lane really was outside the interval there (the listing is justified)
     // LDS layout of the main grid's 1-D arrays (element offsets into the dynamic shared array, -1 = global)
     int32_t lds_time, lds_depth, lds_lat, lds_lon, lds_total;
     int32_t lds_cc_nodes, lds_cc_keys, lds_cc_fvals;  // cell cache (CellCache) offsets in doubles from the LDS base, -1 = off
@@ -205,6 +208,44 @@ PK_DEV bool twe_listed(const KArgs& a, unsigned it, int klo) {
 }
 PK_DEV void twe_note(const KArgs& a, unsigned it, int klo) {
     if (it != 0) atomicMin(&a.counters->twe_key, twe_sample_key(it, klo));
+}
+// The general programs report EVERY unlisted sample at which a lane left a time interval, not only the smallest (twe_note, which is all the
+// dedicated kernels do: their hot loops carry nothing else): a particle past the last time level fails every later sample as well, and its
+// own trajectory does not depend on whether those samples are listed -- it takes code 70 and zeros either way -- so the host can list them all
+// at once and VALIDATE the listing with the next pass (twe_justify) instead of finding one key per pass (DeviceEngine.execute).
+constexpr int TWE_FOUND_SLOTS = 4096;  // open addressing, linear probing; counters->twe_overflow counts the keys that found no slot
+PK_DEV void twe_note_all(const KArgs& a, unsigned it, int klo) {
+    if (it == 0) return;
+    const unsigned long long key = twe_sample_key(it, klo);
+    atomicMin(&a.counters->twe_key, key);
+    unsigned h = (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 52);  // 12 bits
+    for (int probe = 0; probe < TWE_FOUND_SLOTS; probe++) {
+        unsigned long long* slot = a.twe_found + ((h + probe) & (TWE_FOUND_SLOTS - 1));
+        unsigned long long cur = *(volatile unsigned long long*)slot;
+        if (cur == key) return;
+        if (cur == 0ull) {
+            cur = atomicCAS(slot, 0ull, key);
+            if (cur == 0ull || cur == key) return;
+        }
+    }
+    atomicAdd(&a.counters->twe_overflow, 1u);
+}
+// index of the sample in the launch's list, -1 = not listed
+PK_DEV int twe_listed_index(const KArgs& a, unsigned it, int klo) {
+    const int n = a.prm.twe_n;  // wave-uniform: one scalar compare per sample when nothing is listed
+    if (__builtin_expect(n == 0, 1)) return -1;
+    const unsigned long long key = twe_sample_key(it, klo);
+    const unsigned long long* lst = a.twe_listed;  // ascending: bisection
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (lst[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return (it != 0 && lo < n && lst[lo] == key) ? lo : -1;
+}
+// a lane at listed sample `idx` that IS outside the interval [0, tlen]: the listing stands (plain store of a constant: benign race)
+PK_DEV void twe_justify(const KArgs& a, int idx, double t, double tlen) {
+    if (!(0 <= t) || !(t <= tlen)) a.twe_hit[idx] = 1u;
 }
 
 // Scheduling fence between the gathers of two fields: without it the compiler hoists all 16 (32, 48) corner loads of
@@ -1588,14 +1629,16 @@ PK_DEV void eval_uvw(const KArgs& a, const Coords& mc, PCtx& c, bool want_w, dou
     c.u32 = c.v32 = false;
     const int klo = c.klo++;
     if (U.has_time_interval) {
-        if (twe_listed(a, c.it, klo)) {  // somebody leaves the time interval at this sample: the whole view takes the code (field.py:31-44)
+        const int li = twe_listed_index(a, c.it, klo);
+        if (li >= 0) {  // somebody leaves the time interval at this sample: the whole view takes the code (field.py:31-44)
+            twe_justify(a, li, t, U.tlen);
             c.state = PK_ERROROUTSIDETIMEINTERVAL;
             return;
         }
     }
     if (!time_search(U, mc.time, t, c.ht, p)) {  // field.py:303-304 -> _deal_with_errors: state := 70, zeros
         c.state = PK_ERROROUTSIDETIMEINTERVAL;
-        twe_note(a, c.it, klo);
+        twe_note_all(a, c.it, klo);
         return;
     }
     c.ht = p.ti;
@@ -1654,14 +1697,16 @@ PK_DEV double eval_scalar(const KArgs& a, const Coords& mc, PCtx& c, int fidx, d
     const double* time = (on_main && f.time == kfield(a, a.main_field).time) ? mc.time : f.time;
     const int klo = c.klo++;
     if (f.has_time_interval) {
-        if (twe_listed(a, c.it, klo)) {  // (see eval_uvw)
+        const int li = twe_listed_index(a, c.it, klo);
+        if (li >= 0) {  // (see eval_uvw)
+            twe_justify(a, li, t, f.tlen);
             c.state = PK_ERROROUTSIDETIMEINTERVAL;
             return 0.0;
         }
     }
     if (!time_search(f, time, t, on_main ? c.ht : 0, p)) {
         c.state = PK_ERROROUTSIDETIMEINTERVAL;
-        twe_note(a, c.it, klo);
+        twe_note_all(a, c.it, klo);
         return 0.0;
     }
     const bool use_guess = take_first_eval(c, f.grid) ? (a.prm.have_guess0 != 0) : true;

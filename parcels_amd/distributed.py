@@ -104,6 +104,42 @@ def batch_agreement(group=None, device=None):
         stats["seconds"] += _time.perf_counter() - t0
         return out
 
+    from . import _hip
+
+    NF = 4096  # capacity of the device-side set of found keys (csrc/pk_device.h: TWE_FOUND_SLOTS)
+
+    def agree_keys(found, hits):
+        """The failing samples of a pass over ALL shards: the union of the unlisted keys the ranks found (all-gather of count + keys), and per
+        listed key whether a particle of ANY shard justified it (element-wise max).  -> (sorted union, flags); found = None: this rank
+        could not validate its pass (DeviceEngine._twe_report) -- then EVERY rank gets (None, None) and falls back to one key per pass."""
+        t0 = _time.perf_counter()
+        mine = torch.zeros(NF + 1, dtype=torch.int64, device=dev)
+        f = [int(k) for k in (found or [])][:NF]
+        mine[0] = len(f) if found is not None else -1
+        if f:
+            mine[1:1 + len(f)] = torch.tensor(f, dtype=torch.int64, device=dev)
+        world = dist.get_world_size(group)
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        union = set()
+        unvalidated = False
+        for p in parts:
+            n = int(p[0])
+            if n < 0:
+                unvalidated = True
+                continue
+            union.update(int(v) for v in p[1:1 + n].tolist())
+        h = torch.zeros(_hip.PK_MAX_TWE, dtype=torch.int64, device=dev)
+        if hits:
+            h[:len(hits)] = torch.tensor([int(bool(x)) for x in hits], dtype=torch.int64, device=dev)
+        dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
+        stats["calls"] += 2
+        stats["seconds"] += _time.perf_counter() - t0
+        if unvalidated:
+            return None, None
+        return sorted(union), [bool(v) for v in h[:len(hits)].tolist()]
+
+    agree_min.keys = agree_keys
     agree_min.stats = agree_codes.stats = stats
     return agree_min, agree_codes
 

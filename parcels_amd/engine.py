@@ -657,6 +657,60 @@ class DeviceEngine:
             return "cap"
         return None
 
+    TWE_SPECULATIVE_PASSES = 64  # after that many repeats of one call: one key per pass (the round-4 scheme), which provably ends
+
+    @staticmethod
+    def _twe_step(keys, cap, pass_err, found, hits, speculative=True):
+        """One pass over a Kernel.execute call is over; `keys` (ascending) were listed as failing call-wide, `cap` was the iteration limit.
+        The pass reports: pass_err (first erring iteration, 0 = none), found (ascending: unlisted samples at which a particle left a time
+        interval) and hits (per listed key: some particle really was outside there).  -> (decision, keys, cap) with decision "key" (the
+        list changed: repeat without iteration limit), "cap" (a lower iteration limit: repeat) or None (the call stands).
+
+        Everything before the first PROBLEM -- the smallest new or unjustified key -- is exact: the trajectories up to there were
+        computed with exactly the samples failing that the reference fails (induction over the key order).  The problem itself is fixed (a
+        new key is listed: it was found on valid trajectories; an unjustified one is dropped: nobody leaves the interval there).  What lies
+        BEHIND it was computed on trajectories that change now; `speculative` keeps the later keys of this pass anyway -- a particle past
+        the last time level fails every later sample too, whatever the others do, so they usually all stand -- and the next pass validates
+        them the same way.  Keys beyond the iteration at which the batch stops (error stop, iteration limit) are never reached and do not
+        count.  Ends: the first problem moves up with every pass."""
+        limit = min(cap or (1 << 62), pass_err or (1 << 62))
+        it = lambda k: int(k) >> 32  # noqa: E731
+        new = [k for k in found if it(k) <= limit]
+        unjust = [k for k, h in zip(keys, hits) if not h and it(k) <= limit]
+        if new or unjust:
+            p = min(new + unjust)
+            out = [k for k in keys if k < p]
+            if p in new:
+                out.append(p)
+            if len(out) > _hip.PK_MAX_TWE:
+                raise RuntimeError(f"more than {_hip.PK_MAX_TWE} call-wide time errors in one Kernel.execute")
+            if speculative:
+                tail = sorted({k for k, h in zip(keys, hits) if k > p and h} | {k for k in found if k > p})
+                out += tail[: _hip.PK_MAX_TWE - len(out)]
+            return "key", out, 0
+        if pass_err > 0 and (cap == 0 or pass_err < cap):
+            return "cap", list(keys), pass_err
+        return None, list(keys), cap
+
+    def _twe_report(self, keys, pass_twk):
+        """(found, hits) of the launch that just ended: every unlisted failing sample and the justification flags of the listed ones
+        (pk_execute_twe_report) and True; a library without the entry point (scripted stand-ins of the CPU suite) or an overflowing device
+        set: the smallest key only, every listed key taken as justified, and False -- nothing validates a listing then, so the caller must not
+        keep keys speculatively (the one-key-per-pass scheme of round 4)."""
+        fn = getattr(self.lib, "pk_execute_twe_report", None)
+        if fn is not None:
+            cap = 4096
+            found = (C.c_int64 * cap)()
+            nf = C.c_int32(0)
+            hit = (C.c_uint8 * max(len(keys), 1))()
+            self.ctx.check(fn(self.ctx.handle, found, cap, C.byref(nf), hit, len(keys)), "pk_execute_twe_report")
+            if nf.value >= 0:
+                fl = [int(found[k]) for k in range(min(nf.value, cap))]
+                if pass_twk and pass_twk not in fl:  # (reported by a dedicated kernel: it names the smallest key only)
+                    fl = sorted(fl + [int(pass_twk)])
+                return fl, [bool(hit[k]) for k in range(len(keys))], True
+        return ([int(pass_twk)] if pass_twk else []), [True] * len(keys), False
+
     def set_user_program(self, program):
         """Register (or, with None, unregister) the run-time compiled module that carries a kernel list's user kernels (jit.py)."""
         cur = getattr(self, "_user_program", None)
@@ -729,6 +783,9 @@ class DeviceEngine:
             last_live = None
             span = span0
             pass_err, pass_twk = 0, 0
+            pass_found: set = set()          # unlisted failing samples of this pass (all launches)
+            pass_hits = [False] * len(keys)  # listed samples some particle justified in this pass
+            validated = True                 # every launch of the pass reported real justification flags
             total["steps"] = total["attempts"] = 0
             while True:  # launches of one pass
                 st = _hip.ExecStats()
@@ -780,12 +837,17 @@ class DeviceEngine:
                     pass_err = int(st.first_error_iter) if pass_err == 0 else min(pass_err, int(st.first_error_iter))
                 if st.first_time_error_key > 0:
                     pass_twk = int(st.first_time_error_key) if pass_twk == 0 else min(pass_twk, int(st.first_time_error_key))
+                if self.exact_error_stop and (st.first_time_error_key > 0 or keys):
+                    fl, hl, real = self._twe_report(keys, int(st.first_time_error_key))
+                    pass_found.update(fl)
+                    pass_hits = [a or b for a, b in zip(pass_hits, hl)]
+                    validated = validated and real
                 if st.paused == 0:
                     break
                 if not self.windowed and span is None:
                     raise _hip.HipLibraryError("particles paused although all time levels are resident (internal error)")
                 # (what this launch found already decides that the pass will be repeated: stop it here)
-                if self.exact_error_stop and agree is None and self._repeat_decision(pass_err, pass_twk, cap) is not None:
+                if self.exact_error_stop and agree is None and (pass_found or self._repeat_decision(pass_err, pass_twk, cap) is not None):
                     break
                 t_live = st.t_min_live if sign > 0 else st.t_max_live
                 # no particle moved AND no new level is on its way (a small ring needs one launch per cycle just to bring in the
@@ -801,16 +863,21 @@ class DeviceEngine:
                 last_live = t_live
             if not self.exact_error_stop:
                 break
+            found = sorted(pass_found)
             if agree is not None:  # the batch of the reference is every shard's particles
                 pass_err, pass_twk = agree(pass_err, pass_twk)
-            decision = self._repeat_decision(pass_err, pass_twk, cap)
-            if decision == "key":
-                keys = sorted(k for k in keys if k < pass_twk) + [pass_twk]
-                if len(keys) > _hip.PK_MAX_TWE:
-                    raise RuntimeError(f"more than {_hip.PK_MAX_TWE} call-wide time errors in one Kernel.execute")
-                cap = 0
-            elif decision == "cap":
-                cap = pass_err  # kernel.py:236-245: stop every particle after the iteration in which the first one erred
+                agree_keys = getattr(agree, "keys", None)
+                got = agree_keys(found if validated else None, pass_hits) if agree_keys is not None else None
+                if got is not None and got[0] is not None:
+                    found, pass_hits = got
+                else:  # (an agreement of the round-4 form, or a rank without validation: the smallest key only, one key per pass)
+                    validated = False
+            if not validated:
+                found, pass_hits = ([pass_twk] if pass_twk else []), [True] * len(keys)
+            # kernel.py:236-245 / field.py:31-44: what the pass found decides whether the call is repeated -- with the failing samples listed
+            # (all that were found, validated by the next pass) or with the iteration limit of the first error
+            decision, keys, cap = self._twe_step(keys, cap, pass_err, found, pass_hits,
+                                                 speculative=validated and total["reran"] < self.TWE_SPECULATIVE_PASSES)
             repeat = decision is not None
             if not repeat:
                 break
@@ -845,15 +912,13 @@ class DeviceEngine:
         cap, keys = 0, []
         while True:
             pass_err, pass_twk = self.agree_min(0, 0)
-            decision = self._repeat_decision(pass_err, pass_twk, cap)
-            if decision == "key":
-                keys = sorted(k for k in keys if k < pass_twk) + [pass_twk]
-                if len(keys) > _hip.PK_MAX_TWE:  # (the same stop, at the same agreement, as the shards that hold particles)
-                    raise RuntimeError(f"more than {_hip.PK_MAX_TWE} call-wide time errors in one Kernel.execute")
-                cap = 0
-            elif decision == "cap":
-                cap = pass_err
-            else:
+            agree_keys = getattr(self.agree_min, "keys", None)
+            got = agree_keys([], [False] * len(keys)) if agree_keys is not None else None
+            validated = got is not None and got[0] is not None
+            found, hits = got if validated else (([pass_twk] if pass_twk else []), [True] * len(keys))
+            # (the same decision, from the same agreed values, as the shards that hold particles -- also its RuntimeError at PK_MAX_TWE)
+            decision, keys, cap = self._twe_step(keys, cap, pass_err, found, hits, speculative=validated and total["reran"] < self.TWE_SPECULATIVE_PASSES)
+            if decision is None:
                 break
             total["reran"] += 1
         total["first_error_iter"], total["time_error_keys"] = cap, keys

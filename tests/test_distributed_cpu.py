@@ -448,3 +448,78 @@ def test_every_rank_raises_the_exception_of_the_batch(tmp_path, codes_by_rank, e
         assert p.exitcode == 0, "a rank hung or failed"
     res = dict(q.get(timeout=10) for _ in range(world))
     assert res == {0: expect, 1: expect}, res
+
+
+# ---- round 5: all failing samples of a pass are listed at once and VALIDATED by the next pass (DeviceEngine._twe_step) ----------------
+def _k(it, s):
+    return (it << 32) | s
+
+
+def test_twe_step_lists_everything_found_and_validates_it():
+    from parcels_amd.engine import DeviceEngine as E
+
+    found = [_k(5, 0), _k(5, 1), _k(6, 0), _k(6, 1)]
+    # pass 1: nothing listed, four samples fail for somebody -> all four listed at once
+    d, keys, cap = E._twe_step([], 0, 0, found, [], speculative=True)
+    assert (d, keys, cap) == ("key", found, 0)
+    # pass 2: every listed key justified, nothing new -> the call stands
+    assert E._twe_step(keys, 0, 0, [], [True] * 4, speculative=True) == (None, found, 0)
+    # ... or: the third key was found on a trajectory that no longer exists -> dropped, the later justified one stays (speculatively)
+    d, keys2, _ = E._twe_step(keys, 0, 0, [], [True, True, False, True], speculative=True)
+    assert d == "key" and keys2 == [_k(5, 0), _k(5, 1), _k(6, 1)]
+    # without validation (speculative=False) only the first problem is fixed and everything behind it goes: the round-4 scheme
+    assert E._twe_step([], 0, 0, found, [], speculative=False) == ("key", [_k(5, 0)], 0)
+    assert E._twe_step([_k(9, 1)], 0, 0, [_k(4, 2)], [True], speculative=False) == ("key", [_k(4, 2)], 0)
+
+
+def test_twe_step_error_stop_and_iteration_limit():
+    from parcels_amd.engine import DeviceEngine as E
+
+    # an error in iteration 3 stops the batch before the sample of iteration 7 fails: the key never happens
+    assert E._twe_step([], 0, 3, [_k(7, 1)], [], speculative=True) == ("cap", [], 3)
+    # same iteration: the failing sample is listed BEFORE the error stop of that iteration is applied (kernel.py:236-245 acts on what it left)
+    assert E._twe_step([], 0, 5, [_k(5, 2003)], [], speculative=True) == ("key", [_k(5, 2003)], 0)
+    assert E._twe_step([_k(5, 2003)], 0, 5, [], [True], speculative=True) == ("cap", [_k(5, 2003)], 5)
+    assert E._twe_step([_k(5, 2003)], 5, 5, [], [True], speculative=True) == (None, [_k(5, 2003)], 5)
+    # a listed key beyond the iteration limit is never reached: not "unjustified"
+    assert E._twe_step([_k(2, 0), _k(9, 0)], 4, 4, [], [True, False], speculative=True) == (None, [_k(2, 0), _k(9, 0)], 4)
+
+
+class _ReportingLib(_ScriptedLib):
+    """_ScriptedLib whose passes also answer pk_execute_twe_report: script entries (err, found keys, hits of the listed keys)."""
+
+    def _fill(self, st_ref, cap, keys):
+        err, found, hits = self.script[len(self.passes)]
+        self.passes.append((int(cap), [int(k) for k in keys]))
+        self._last = (found, hits)
+        st = st_ref._obj
+        st.first_error_iter, st.first_time_error_key, st.paused, st.launches = err, (min(found) if found else 0), 0, 1
+        st.steps = 100
+        return 0
+
+    def pk_execute_twe_report(self, h, found, cap, nf, hit, n_listed):
+        f, hits = self._last
+        for i, k in enumerate(f):
+            found[i] = k
+        nf._obj.value = len(f)
+        for i in range(n_listed):
+            hit[i] = int(bool(hits[i]))
+        return 0
+
+
+def test_execute_needs_two_passes_for_many_keys_not_one_per_key():
+    """The seed-9501 shape (profiles/r04: 105 passes): a particle past the last level fails EVERY later sample.  Pass 1 finds them all, pass 2
+    runs with all of them listed and reports every one justified: done."""
+    many = [_k(it, s) for it in range(20, 30) for s in range(6)]
+    eng = _scripted_engine([])
+    eng.lib = _ReportingLib([(0, many, []), (0, [], [True] * len(many))])
+    st = eng.execute([4], endtime=10.0, dt0=1.0)
+    assert st["reran"] == 1 and st["time_error_keys"] == many and eng.lib.passes == [(0, []), (0, many)]
+    # a speculative key that does not survive validation costs one more pass, not one per key
+    eng = _scripted_engine([])
+    hits2 = [True] * len(many)
+    hits2[30] = False
+    rest = many[:30] + many[31:]
+    eng.lib = _ReportingLib([(0, many, []), (0, [], hits2), (0, [], [True] * len(rest))])
+    st = eng.execute([4], endtime=10.0, dt0=1.0)
+    assert st["reran"] == 2 and st["time_error_keys"] == rest
