@@ -226,7 +226,7 @@ def repeat_execute(case, fs, calls, steps):
         before = dict(eng.transfers)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        pset.execute([pa.AdvectionRK4], dt=case["dt"], runtime=steps * case["dt"])
+        pset.execute([pa.AdvectionRK4, pa.DeleteParticle], dt=case["dt"], runtime=steps * case["dt"])  # (DeleteParticle: like `long_run`, a few particles reach the edge)
         torch.cuda.synchronize()
         walls.append(time.perf_counter() - t0)
         st = pset._last_stats
@@ -239,7 +239,7 @@ def repeat_execute(case, fs, calls, steps):
     later = sorted(walls[1:])
     med = later[(len(later) - 1) // 2]
     kmed = sorted(kms[1:])[(len(kms[1:]) - 1) // 2]
-    return {"workload": f"{calls} x ParticleSet.execute(AdvectionRK4, {steps} steps of {case['dt']:.0f} s) on the headline FieldSet and particles",
+    return {"workload": f"{calls} x ParticleSet.execute([AdvectionRK4, DeleteParticle], {steps} steps of {case['dt']:.0f} s) on the headline FieldSet and particles",
             "particle_steps_per_call": nsteps, "wall_ms_first_call": walls[0] * 1e3, "wall_ms_later_calls": {"min": later[0] * 1e3, "median": med * 1e3, "max": later[-1] * 1e3},
             "kernel_ms_later_calls_median": kmed, "value_end_to_end_later_calls": nsteps / med, "value_kernel_later_calls": nsteps / (kmed * 1e-3),
             "unit": "particle-steps/s", "pcie_transfers_per_call": moved, "first_host_read_of_x_ms": t_read * 1e3, "checksum_x": x_sum}

@@ -64,9 +64,10 @@ def test_repeated_execute_equals_the_eager_path_and_moves_nothing(gpu, curv):
     compare(lazy, eager, rtol=0.0, check_state="all", label="resident vs eager", skip=())
     assert log[0]["h2d_full"] == 1
     for k, entry in enumerate(log[1:], 1):
-        # rectilinear: nothing at all; curvilinear: the batch-wide guess test of the reference reads `ei` (one column down), nothing up
+        # rectilinear: nothing at all; curvilinear: the batch-wide guess test of the reference reads `ei` (one column down) and, in a call in
+        # which particles left the mesh, the device compaction needs `state` on the host to know which rows survive; nothing goes up
         assert entry["h2d_full"] == 0 and entry["h2d_columns"] == 0 and entry["d2h_full"] == 0, (k, entry)
-        assert entry["columns_down"] <= (1 if curv else 0), (k, entry)
+        assert entry["columns_down"] <= (2 if curv else 0), (k, entry)
     assert all(e["h2d_full"] == 1 for e in elog)
 
 
@@ -115,7 +116,8 @@ def test_deletions_and_output_file_with_resident_columns(gpu, tmp_path):
 
     from oracle import cases
 
-    case = cases.rect_agrid_case("resident_out", mesh="spherical", kernels=["AdvectionRK4", "DeleteParticle"], seed=5, npart=4000, runtime=None, vel=8.0)
+    case = cases.rect_agrid_case("resident_out", mesh="spherical", kernels=["AdvectionRK4", "DeleteParticle"], seed=5, npart=4000, runtime=None, vel=30.0,
+                                 margin=0.005)  # (36 of the 4000 leave the domain within 18 h: oracle)
     outs = {}
     for eager in (False, True):
         if eager:
