@@ -2182,7 +2182,6 @@ static int32_t fill_fastc(pk_ctx* ctx, const pk_exec_params* prm, KArgs& a, bool
     const int cm = m1 ? CG_CACHE_M1 : (rk45 ? CG_CACHE_RK45 : CG_CACHE_RK4);  // which parts of a lane's cell cache the kernel keeps in registers
     F.lds_fv = F.lds_rec + fc_rec_rows(cm) * FC_LANES;
     lds_bytes = (size_t)F.lds_fv * sizeof(double) + (size_t)fc_fv_lds(cm) * FC_LANES * (size_t)esz;
-    if (rk45) lds_bytes += 256;  // CgLds::dump (PK_CG_PREFETCH builds; a quarter of a kilobyte otherwise unused)
     F.tlen = f.tlen; F.t0 = f.tfirst; F.t1 = f.tlast;
     F.z0 = g.d.zfirst; F.z1 = g.d.zlast;
     F.deg2m = g.d.deg2m;

@@ -57,21 +57,7 @@ struct CgLds {
     const pk_tab2* depth;
     double* rec;           // [fc_rec_rows(CM)][64] + lane
     void* fv;              // [fc_fv_lds(CM)][64] of the field dtype + lane
-    void* dump;            // 256 bytes nobody reads: where the cache-warming loads of PK_CG_PREFETCH land (AdvectionRK45's kernel)
 };
-// PK_CG_PREFETCH (A/B builds; AdvectionRK45's kernel only): 14 % of its evaluations leave the guessed cell and then wait for the record and the
-// field values of the next one -- a dependent HBM round trip in practically every wave-evaluation.  1 = BEFORE the two
-// sincos and the point-in-cell test of the guessed cell, predict the cell the sample point lies in from the corner coordinates the lane holds
-// (affine, float32: a HINT, no result depends on it) and start loading the two lines of its record straight into an LDS dump slot
-// (global_load_lds_dword: no register, no wait -- the line is in L2 / L1 when the real fetch asks for it); 2 = the lines of its field values
-// too.  The search itself is untouched: same cells tested, same order, same bits.
-#ifndef PK_CG_PREFETCH
-#define PK_CG_PREFETCH 0
-#endif
-PK_DEV void cg_warm_line(const void* p, void* lds_dump) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p, (__attribute__((address_space(3))) void*)lds_dump, 4, 0, 0);
-}
-
 // per-particle evaluation context of the fast C-grid kernels (FT: dtype of the velocity fields)
 template <class FT, int CM>
 struct CCtxT {
@@ -394,43 +380,6 @@ PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtxT<FT, CM>& c, dou
     // the query point on the unit sphere (make_qpoint / latlon_rad_to_xyz)
     double sl, cl, so, co;
     const bool guess_ok = c.gy >= 0 && c.gy < F.gny - 1 && c.gx >= 0 && c.gx < F.gnx - 1;
-#if PK_CG_PREFETCH
-    if constexpr (HOPS == 0 && !WITH_SCALAR && (CM & CG_PXY_REGS) != 0) {
-        if (guess_ok && c.rc_cell == c.gy * F.gnx + c.gx) {
-            // corners 0..3 = (j, i), (j, i+1), (j+1, i+1), (j+1, i): lon in pxy[0..3], lat in pxy[4..7]
-            const float x0 = (float)c.pxy[0], y0 = (float)c.pxy[4];
-            const float ax = (float)c.pxy[1] - x0, ay = (float)c.pxy[5] - y0, bx = (float)c.pxy[3] - x0, by = (float)c.pxy[7] - y0;
-            const float dx = (float)x - x0, dy = (float)y - y0;
-            const float rdet = __builtin_amdgcn_rcpf(ax * by - bx * ay);
-            const float xs = (dx * by - bx * dy) * rdet, et = (ax * dy - dx * ay) * rdet;
-            if (fabsf(xs) < 64.0f && fabsf(et) < 64.0f) {
-                const int di = (int)floorf(xs), dj = (int)floorf(et);
-                const int nj = c.gy + dj, ni = c.gx + di;
-                if ((di | dj) != 0 && nj >= 0 && nj < F.gny - 1 && ni >= 0 && ni < F.gnx - 1) {
-                    const char* g = reinterpret_cast<const char*>(F.ct2 + (int64_t)(nj * F.gnx + ni) * CT2_STRIDE);
-                    cg_warm_line(g, L.dump);
-                    cg_warm_line(g + 128, L.dump);
-#if PK_CG_PREFETCH >= 2
-                    if (zi >= 0 && !F.vp) {  // the level rings: {U, V, W} structs of cell e, e + 1 (one line) and e + st_y (another), levels ti and ti + 1
-                        const uint32_t e = (uint32_t)zi * (uint32_t)F.st_z + (uint32_t)nj * (uint32_t)F.st_y + (uint32_t)ni;
-                        const int s0 = F.nslots < F.nt ? (int)((uint32_t)ti % (uint32_t)F.nslots) : ti;
-                        const int t1 = mini(ti + 1, F.nt - 1);
-                        const int s1 = F.nslots < F.nt ? (int)((uint32_t)t1 % (uint32_t)F.nslots) : t1;
-                        const char* f0 = F.U + F.dU0 + (int64_t)((uint64_t)e * (uint64_t)(uint32_t)F.cb) + (int64_t)s0 * F.lvl_b;
-                        const char* f1 = f0 + (int64_t)(s1 - s0) * F.lvl_b;
-                        cg_warm_line(f0, L.dump);
-                        cg_warm_line(F.V + F.dV1 + (f0 - (F.U + F.dU0)), L.dump);
-                        if (lenT) {
-                            cg_warm_line(f1, L.dump);
-                            cg_warm_line(F.V + F.dV1 + (f1 - (F.U + F.dU0)), L.dump);
-                        }
-                    }
-#endif
-                }
-            }
-        }
-    }
-#endif
     if (WITH_SCALAR) {  // (home_y, home_x): the particle's own position, whose sines / cosines the kernel left in the context
         if (y == home_y) { sl = c.q_sl; cl = c.q_cl; } else sincos_geo(y * DEG2RAD, sl, cl);
         if (x == home_x) { so = c.q_so; co = c.q_co; } else sincos_geo(x * DEG2RAD, so, co);

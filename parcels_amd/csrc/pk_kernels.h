@@ -1029,7 +1029,6 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID_RK45) advect_cgri
         L.depth = s_tab + F.lds_depth;
         L.rec = smem + F.lds_rec + threadIdx.x;
         L.fv = (void*)((FT*)(smem + F.lds_fv) + threadIdx.x);
-        L.dump = (void*)((FT*)(smem + F.lds_fv) + fc_fv_lds(CG_CACHE_RK45) * FC_LANES);  // behind the field values (pk_api.hip adds the 256 bytes)
     }
     auto row = [&]() { return (int64_t)xcd_swizzle(blockIdx.x, gridDim.x) * FC_LANES + threadIdx.x; };
     unsigned steps = 0, attempts = 0, paused = 0;

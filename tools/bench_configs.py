@@ -242,7 +242,7 @@ def check_against_oracle(*, n_check, dsinfo, engine, pset, kernel_names, context
 
 
 def run_config(config="c3", scale=1.0, particles=1e7, steps=24, nt=4, nslots=3, nz=75, hash="device", check=0, emit=print, dt=3600.0, reps=5,
-               pairs_leg=True):
+               pairs_leg=True, only=None):
     """pairs_leg (c5): after the default runs (the 2-D kernels read the level rings), the same launches once more with the OPT-IN cell-packed pair
     copies of the staggered velocity ("velocity_pairs"): their kernel time, the HIP-event time of packing one level pair (pk_exec_stats.pack_ms)
     and the sum -- at config 5 one pair serves one 24 h launch, so `kernel_plus_pack_ms` is what a level of model time costs with them.
@@ -270,6 +270,8 @@ def run_config(config="c3", scale=1.0, particles=1e7, steps=24, nt=4, nslots=3, 
         ("AdvectionRK45", [pa.AdvectionRK45, pa.DeleteParticle], "rk45"),
         ("AdvectionDiffusionM1", [pa.AdvectionDiffusionM1, pa.DeleteParticle], "m1"),
     ]
+    if only:  # (A/B runs: one kernel list of config 5)
+        runs = [r for r in runs if r[2] == only]
     results = []
     pack_per_pair = None  # (the copies packed for the first 2-D kernel list serve the next one: one measurement of the packing)
     for label, kernels, kind in runs:
@@ -360,12 +362,13 @@ def main():
     ap.add_argument("--reps", type=int, default=5, help="c3 / c5: timed repetitions after the cold run (kernel_ms = their median)")
     ap.add_argument("--output-every", type=int, default=6, help="c4: steps between write-outs")
     ap.add_argument("--verify-single", action="store_true", help="c4: rank 0 re-runs the whole id space alone and compares the files")
+    ap.add_argument("--only", default=None, choices=["rk45", "m1"], help="c5: run only this kernel list")
     ap.add_argument("--pairs-leg", type=int, default=1, help="c5: also time the opt-in pair copies (kernel + pack per level pair)")
     a = ap.parse_args()
     if a.config == "c4":
         run_c4(a.scale, a.particles, a.steps, a.nt, a.nslots, a.nz, a.output_every, a.verify_single, a.dt)
         return
-    run_config(a.config, a.scale, a.particles, a.steps, a.nt, a.nslots, a.nz, a.hash, int(a.check), dt=a.dt, reps=a.reps, pairs_leg=bool(a.pairs_leg))
+    run_config(a.config, a.scale, a.particles, a.steps, a.nt, a.nslots, a.nz, a.hash, int(a.check), dt=a.dt, reps=a.reps, pairs_leg=bool(a.pairs_leg), only=a.only)
 
 
 if __name__ == "__main__":
