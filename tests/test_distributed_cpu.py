@@ -523,3 +523,46 @@ def test_execute_needs_two_passes_for_many_keys_not_one_per_key():
     eng.lib = _ReportingLib([(0, many, []), (0, [], hits2), (0, [], [True] * len(rest))])
     st = eng.execute([4], endtime=10.0, dt0=1.0)
     assert st["reran"] == 2 and st["time_error_keys"] == rest
+
+
+def _agree_keys_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from parcels_amd.distributed import batch_agreement
+
+        a, b = [_k(it, s) for it in (7, 8) for s in range(4)], [_k(it, s) for it in (8, 9) for s in range(4)]
+        both = sorted(set(a) | set(b))
+        # rank 0 finds the samples of iterations 7-8, rank 1 those of 8-9 (its particles cross the last level an iteration later); in the
+        # validation pass rank 0 justifies its own keys only, rank 1 its own: together all of them.  Rank 2 (if any) is empty.
+        script = {0: [(0, a, []), (0, [], [k in a for k in both])], 1: [(0, b, []), (0, [], [k in b for k in both])]}.get(rank)
+        eng = _scripted_engine([])
+        if script:
+            eng.lib = _ReportingLib(script)
+        eng.agree_min, eng.agree_codes = batch_agreement()
+        st = eng.execute([4], endtime=10.0, dt0=1.0) if script else eng.execute_idle()
+        q.put((rank, st["time_error_keys"], st["reran"], eng.lib.passes if script else None, both))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_shards_agree_on_all_failing_samples_of_a_pass(world):
+    """world 2 / 3 over gloo: every rank lists the UNION of the failing samples the shards found, a key only another shard justifies stands,
+    and the call is over after the validation pass -- two passes, not one per key, on every rank (the empty one included)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_agree_keys_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0, "a rank hung or failed"
+    res = {r[0]: r[1:] for r in (q.get(timeout=10) for _ in range(world))}
+    for rank in range(world):
+        keys, reran, passes, both = res[rank]
+        assert keys == both and reran == 1, (rank, res[rank])
+        if passes is not None:
+            assert passes == [(0, []), (0, both)], (rank, passes)
