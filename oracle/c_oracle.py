@@ -605,55 +605,70 @@ ERRORS_TO_THROW = [  # kernel.py:31-38 (order matters)
 
 
 def run_case(case: dict, nthreads: int = 1, call_wide_time_error: bool = True):
-    """ParticleSet.execute (particleset.py:355-470) without output file: one Kernel.execute to the end time."""
+    """ParticleSet.execute (particleset.py:355-470): one Kernel.execute per output interval to the end time -- and, with case["more_calls"]
+    ([{"dt": .., "runtime": ..}, ...]), further execute() calls on the same set, as a script loop makes them: every call sets `dt` anew
+    (:381), takes its start time from the particles (:523-585) and constructs a Kernel -- which on a spherical mesh divides RK45_tol by deg2m
+    AGAIN (kernel.py:144-145 writes the converted value back into the context)."""
     mc = MarshalledCase(case)
     data = initial_particles(case, mc.ngrids)
-    dt = float(case["dt"])
-    sign = 1 if dt > 0 else -1
-    data["dt"][:] = dt
-    ctx = rk45_context_defaults(case)
-    tl = None
-    if case.get("time_s") is not None and len(case["time_s"]) > 1:
-        tl = float(case["time_s"][-1] - case["time_s"][0])
-    first = data["t"].min() if sign == 1 else data["t"].max()
-    start = first
-    if case.get("endtime") is not None:
-        end = float(case["endtime"])
-    else:
-        end = start + sign * float(case["runtime"])
+    ctx = dict(case.get("context") or {})
     have_guess0 = 0
     if case.get("populate"):  # ParticleSet.populate_indices (particleset.py:252-262)
         populate_indices(mc, data)
         have_guess0 = 1
-    # output intervals (particleset.py:440-462): one Kernel.execute per interval, dt is NOT reset in between
-    stops = [end]
-    if case.get("outputdt"):  # next_output accumulates (particleset.py:441,455): k * outputdt would round differently
-        stops = []
-        next_output = start + float(case["outputdt"]) * sign
-        time = start
-        while sign * (time - end) < 0:
-            time = (min if sign > 0 else max)(next_output, end)
-            stops.append(time)
-            if abs(time - next_output) < 0.001:
-                next_output += float(case["outputdt"]) * sign
-    # what the loop hands a ParticleFile (particleset.py:401-403, 436-457): the whole set at the start and at every output time
-    obs = []
-    snap = lambda tm: obs.append((float(tm), {k: np.array(data[k], copy=True) for k in ("particle_id", "t", "z", "y", "x")}))  # noqa: E731
-    next_output = None
-    if case.get("outputdt"):
-        snap(start)
-        next_output = start + float(case["outputdt"]) * sign
     stats = {}
-    for stop in stops:
-        if len(data["state"]) > 0:  # (an emptied set: the reference's loop goes on to the end time, writing empty tables, particleset.py:444-462)
-            stats = execute(mc, data, kernels=case["kernels"], endtime=stop, dt0=dt, context=ctx, seed=case.get("seed", 0),
-                            have_guess0=have_guess0, nthreads=nthreads, call_wide_time_error=call_wide_time_error)
-            have_guess0 = 1
-        if np.any(data["state"] >= 50) or (len(data["state"]) == 0 and next_output is None):
+    obs = []
+    calls = [dict(dt=float(case["dt"]), runtime=case.get("runtime"), endtime=case.get("endtime"), outputdt=case.get("outputdt"))]
+    calls += [dict(dt=float(c["dt"]), runtime=float(c["runtime"]), endtime=None, outputdt=None) for c in (case.get("more_calls") or ())]
+    for call in calls:
+        if len(data["state"]) == 0 and not call["outputdt"]:
+            break  # particleset.py:366: `if len(self) == 0: return`
+        ctx = rk45_context_defaults(dict(case, context=ctx))  # (one Kernel construction per execute)
+        if call is not calls[0]:  # np.any(xi) over the guesses the previous call left (index_search.py:269), like parcels_amd.Kernel._have_guess0
+            g0 = mc.grids[0]
+            have_guess0 = int(bool(g0.kind == 1 and g0.has_x and np.any(np.mod(data["ei"][:, 0].astype(np.int64), max(int(g0.xdim), 1)) != 0)))
+        dt = call["dt"]
+        sign = 1 if dt > 0 else -1
+        data["dt"][:] = dt
+        first = data["t"].min() if sign == 1 else data["t"].max()
+        start = first
+        if call["endtime"] is not None:
+            end = float(call["endtime"])
+        else:
+            end = start + sign * float(call["runtime"])
+        # output intervals (particleset.py:440-462): one Kernel.execute per interval, dt is NOT reset in between
+        stops = [end]
+        if call["outputdt"]:  # next_output accumulates (particleset.py:441,455): k * outputdt would round differently
+            stops = []
+            next_output = start + float(call["outputdt"]) * sign
+            time = start
+            while sign * (time - end) < 0:
+                time = (min if sign > 0 else max)(next_output, end)
+                stops.append(time)
+                if abs(time - next_output) < 0.001:
+                    next_output += float(call["outputdt"]) * sign
+        # what the loop hands a ParticleFile (particleset.py:401-403, 436-457): the whole set at the start and at every output time
+        snap = lambda tm: obs.append((float(tm), {k: np.array(data[k], copy=True) for k in ("particle_id", "t", "z", "y", "x")}))  # noqa: E731
+        next_output = None
+        if call["outputdt"]:
+            snap(start)
+            next_output = start + float(call["outputdt"]) * sign
+        stop_all = False
+        for stop in stops:
+            if len(data["state"]) > 0:  # (an emptied set: the reference's loop goes on to the end time, writing empty tables, particleset.py:444-462)
+                stats = execute(mc, data, kernels=case["kernels"], endtime=stop, dt0=dt, context=ctx, seed=case.get("seed", 0),
+                                have_guess0=have_guess0, nthreads=nthreads, call_wide_time_error=call_wide_time_error)
+                have_guess0 = 1
+            if np.any(data["state"] >= 50):
+                stop_all = True
+                break
+            if len(data["state"]) == 0 and next_output is None:
+                break
+            if next_output is not None and abs(stop - next_output) < 0.001:
+                snap(next_output)
+                next_output += float(call["outputdt"]) * sign
+        if stop_all:
             break
-        if next_output is not None and abs(stop - next_output) < 0.001:
-            snap(next_output)
-            next_output += float(case["outputdt"]) * sign
     if obs:
         stats = dict(stats)
         stats["observations"] = obs

@@ -880,6 +880,30 @@ def all_cases() -> dict:
     pc["t0"] = np.round(_rng(604).uniform(0, 5, len(pc["x"]))) * 900.0
     add(past_the_end(pc))
 
+    # --- SEVERAL execute() calls on one ParticleSet (the usual script loop; parcels_amd keeps the columns on the device between the calls):
+    #     every call sets dt anew (particleset.py:381), takes its start time from the particles (:523-585) and builds a Kernel (RK45_tol is
+    #     divided by deg2m again on a spherical mesh, kernel.py:144-145); next_dt, the positions and `ei` carry over, deleted particles stay away
+    mc = rect_agrid_case("multi_agrid_sph_rk4_three_calls", mesh="spherical", kernels=["AdvectionRK4", "DeleteParticle"], seed=121, vel=6.0, margin=0.02,
+                         runtime=7 * 3600.0)
+    mc["more_calls"] = [{"dt": 1800.0, "runtime": 5 * 3600.0}, {"dt": 3600.0, "runtime": 6 * 3600.0}]
+    add(mc)
+    mc = rect_agrid_case("multi_agrid_flat_rk45_two_calls", mesh="flat", kernels=["AdvectionRK45"], seed=122, runtime=6 * 3600.0)
+    mc["context"] = {"RK45_tol": 5.0, "RK45_min_dt": 10.0, "RK45_max_dt": 7200.0}
+    mc["more_calls"] = [{"dt": 900.0, "runtime": 6 * 3600.0}]
+    add(mc)
+    mc = dict(curv_cgrid_case("multi_cgrid_curv_sph_rk45_two_calls", mesh="spherical", kernels=["AdvectionRK45", "DeleteParticle"], seed=123, with_w=False,
+                              runtime=8 * 3600.0, vel=1.5))
+    mc["populate"] = True
+    mc["context"] = {"RK45_tol": 30.0, "RK45_min_dt": 60.0, "RK45_max_dt": 4 * 3600.0}
+    mc["more_calls"] = [{"dt": 1800.0, "runtime": 8 * 3600.0}]
+    add(mc)
+    mc = dict(curv_cgrid_case("multi_cgrid_curv_sph_rk4_3d_backward_then_forward", mesh="spherical", kernels=["AdvectionRK4_3D", "DeleteParticle"], seed=124,
+                              dt=-1800.0, runtime=6 * 3600.0, vel=1.0))
+    mc["populate"] = True
+    mc["t0"] = 12 * 3600.0
+    mc["more_calls"] = [{"dt": 1800.0, "runtime": 9 * 3600.0}]
+    add(mc)
+
     # --- the `_delete` cases above end with NO particle left (everyone evaluated in the fatal iteration is deleted): they pin the
     #     discrete outcome but not a single position.  Siblings with an output interval: the positions, ids and times of the doomed
     #     particles at every output time before the sample that fails call-wide (and the interval structure: one Kernel.execute per

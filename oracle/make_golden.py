@@ -207,6 +207,7 @@ def ref_run_case(case):
             fs, klist, x=np.asarray(case["x"]), y=np.asarray(case["y"]), z=z, t=case.get("t0"), dt=float(case["dt"]),
             runtime=case.get("runtime"), endtime_s=case.get("endtime"), spatial_dtype=np.dtype(case.get("spatial_dtype", "float64")).type,
             extra_vars=extra_vars, particle_kwargs=pkw, populate=bool(case.get("populate")), outputdt=case.get("outputdt"),
+            more_calls=case.get("more_calls") or (),
         )
     finally:
         np.random.normal = old_normal

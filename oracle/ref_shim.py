@@ -369,7 +369,7 @@ class _OutputStub:
 
 
 def run_reference(fieldset, kernels, *, x, y, z, t=None, dt, runtime=None, endtime_s=None, spatial_dtype=np.float64,
-                  extra_vars=None, particle_kwargs=None, populate=False, outputdt=None):
+                  extra_vars=None, particle_kwargs=None, populate=False, outputdt=None, more_calls=()):
     """Run the reference's own ParticleSet.execute and return a copy of its SoA dict (+ raised exception name)."""
     m = load_reference()
     P = m["particle"]
@@ -398,6 +398,8 @@ def run_reference(fieldset, kernels, *, x, y, z, t=None, dt, runtime=None, endti
         warnings.simplefilter("ignore")
         try:
             pset.execute(kernels, dt=dt, verbose_progress=False, **kw)
+            for call in more_calls:  # the usual script loop: further execute() calls on the same ParticleSet ({"dt": .., "runtime": ..})
+                pset.execute(kernels, dt=float(call["dt"]), runtime=float(call["runtime"]), verbose_progress=False)
         except Exception as e:  # per-particle error codes surface as exceptions (kernel.py:239-245)
             err = type(e).__name__
     out = {k: np.array(v, copy=True) for k, v in pset._data.items()}

@@ -206,6 +206,8 @@ def run_hip(case, endtime=None, nslots=None, async_output=None, fieldset=None, *
         warnings.simplefilter("ignore")
         try:
             pset.execute(kernels, dt=float(case["dt"]), **kw)
+            for call in case.get("more_calls") or ():  # further execute() calls on the same set (device-resident columns in between)
+                pset.execute(kernels, dt=float(call["dt"]), runtime=float(call["runtime"]))
         except (pa.FieldOutOfBoundError, pa.FieldOutOfBoundSurfaceError, pa.FieldInterpolationError, pa.GridSearchingError,
                 pa.OutsideTimeInterval, pa.GeneralError) as e:
             err = type(e).__name__
