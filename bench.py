@@ -411,6 +411,7 @@ def main():
     pset._data["particle_id"] += shard.start
     kern = pa.Kernel([pa.AdvectionRK4], pset)
     eng = fs._engine_or_create()
+    eng.ctx.set_option("clock_probe", 1)  # pk_exec_stats.sclk_mhz: the shader clock right behind every advection kernel (20 us per launch)
     dt = case["dt"]
     pset._data["dt"][:] = dt
     eng.bind_particles(pset._data)
@@ -448,7 +449,7 @@ def main():
 
     eng.ctx.check(eng.lib.pk_particles_checkpoint(eng.ctx.handle), "pk_particles_checkpoint")
     reps = max(int(args.reps), 1)
-    rep_el, rep_kms, rep_steps = [], [], []
+    rep_el, rep_kms, rep_steps, rep_sclk = [], [], [], []
     settle_ms = None
     if reps > 1:  # one untimed run of the timed region first (the first launch after the sort runs on cold caches and a ramping clock)
         sync()
@@ -466,6 +467,8 @@ def main():
         rep_el.append(time.perf_counter() - t0)
         rep_kms.append(st["kernel_ms"])
         rep_steps.append(float(st["steps"]))
+        if st.get("sclk_mhz"):
+            rep_sclk.append(float(st["sclk_mhz"]))
     # the write-out exchange (not a step), straight from the device columns: the all-gather of the to-write columns that the north star
     # names, and the gather-to-rank-0 that ParticleFile.write uses (parcels_amd/distributed.py) -- both timed, neither in `value`
     t_ag = t_g0 = 0.0
@@ -533,7 +536,9 @@ def main():
                 "traffic": None, "algorithmic_fp64_flops_per_evaluation": ALGO_FLOPS_PER_EVAL_C2,
                 "frac_no_fma_peak": algo_tflops / (FP64_VECTOR_PEAK_TFLOPS / 2) * (121.59 / ALGO_FLOPS_PER_EVAL_C2),  # one op per lane and slot: NumPy never fuses (-ffp-contract=off)
                 "kernel": "pk::advect_fast_kernel<double, 0, false> (csrc/pk_kernels.h, pk_fast_agrid.h)", "kernel_ms_per_launch": float(kms.item()),
-                "sclk_mhz": st.get("sclk_mhz"),  # shader clock of the last timed launch (cycle counter / 100 MHz counter around the kernel): reconciles this line with a trace taken at another clock
+                # shader clock right behind the timed launches (a 20 us cycle-counter / 100 MHz-counter probe after each kernel; median over the
+                # repetitions): reconciles this line with a trace taken at another clock
+                "sclk_mhz": (sorted(rep_sclk)[(len(rep_sclk) - 1) // 2] if rep_sclk else None), "sclk_mhz_reps": rep_sclk,
                 "hbm": None,
                 "algorithmic": {"note": "SURVEY 8(d) byte model; these bytes are served by L2 / Infinity Cache, this is NOT an HBM fraction",
                                 "bytes_per_particle_step": ALGO_BYTES_PER_STEP_C2_RK4, "bytes_per_launch": ALGO_BYTES_PER_STEP_C2_RK4 * per_gpu_steps,

@@ -100,9 +100,11 @@ const char* pk_last_error(const pk_ctx* ctx); /* ctx may be NULL: error of the l
  *   "fast_cgrid"       1 (default) AdvectionRK4 / AdvectionRK4_3D with CGrid_Velocity on a spherical curvilinear grid with float64
  *                      node coordinates run the dedicated kernels of csrc/pk_fast_cgrid.h (needs "cell_table"; 256 B more per
  *                      cell); 0 = the general program
- *   "velocity_pairs"   1 (default) the 2-D kernels of "fast_cgrid" read cell-packed copies of the staggered velocity, one 8-value group
- *                      per cell and pair of adjacent resident time levels (32 B per cell and ring slot more for float32 fields; made on
- *                      the device ahead of a launch; without the memory for them, or with 0, the kernels read the level rings)
+ *   "velocity_pairs"   0 (default since ABI 8; 1 = on) the 2-D kernels of "fast_cgrid" read cell-packed copies of the staggered velocity, one
+ *                      8-value group per cell and pair of adjacent resident time levels (32 B per cell and ring slot more for float32
+ *                      fields; made on the device ahead of a launch and timed: pk_exec_stats.pack_ms -- 14 ms per level pair at BASELINE
+ *                      config 5 for a kernel that gets 1.6 ms faster, hence off; without the memory for them the kernels read the rings)
+ *   "clock_probe"      0 (default) / 1: measure the shader clock right behind every advection kernel (pk_exec_stats.sclk_mhz; 20 us)
  *   "special_programs" 1 (default) single-kernel programs for AdvectionRK45 / AdvectionDiffusionM1; 0 = kernel-list interpreter
  *   "cell_cache"       1 (default) per-lane LDS cache of the curvilinear cell;  "hash_directory" 1 (default) key directory;
  *                      "cell_table" 1 (default) per-cell table of the query-independent part of the point-in-cell test (192 B per
@@ -380,8 +382,8 @@ typedef struct pk_exec_stats {
                         "velocity_pairs", off by default; csrc/pk_api.hip: ensure_velocity_pairs) -- NOT part of kernel_ms                  */
     int32_t packs;   /* level pairs packed for it */
     int32_t pad0;
-    double sclk_mhz; /* average shader clock during the advection kernel of the (last) launch: cycle-counter over 100 MHz-counter deltas of two
-                        probes around it, averaged over the XCDs both reached; 0 = not measured                                          */
+    double sclk_mhz; /* shader clock right behind the advection kernel of the (last) launch (option "clock_probe": sixteen wavefronts spin for 20
+                        microseconds of the 100 MHz counter and count shader-clock cycles; the median); 0 = not measured                     */
 } pk_exec_stats;
 int32_t pk_execute(pk_ctx* ctx, const pk_exec_params* params, pk_exec_stats* stats);
 /* kernel.py:236-245: the reference checks the error codes after every iteration of its batch loop, so when it raises, EVERY particle

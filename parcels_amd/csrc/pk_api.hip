@@ -159,6 +159,8 @@ struct pk_ctx {
     int vp_fU = -1, vp_fV = -1;
     std::vector<int32_t> vp_level;        // pair held by every pair slot, -1 = none
     std::vector<uint64_t> vp_gen;         // 4 stamps per pair slot: U and V uploads of both levels it was packed from
+    int clock_probe = 0;        // measure the shader clock behind every advection kernel (option "clock_probe"; bench.py switches it on)
+    bool fl_clock_probe = false;
     int no_velocity_pairs = 1;  // OPT-IN since round 5 (option "velocity_pairs" / PK_VELOCITY_PAIRS=1): packing a pair costs more than the
                                 // launch it serves saves at BASELINE config 5 (pk_exec_stats.pack_ms)
     uint64_t upload_counter = 0;
@@ -193,14 +195,20 @@ PK_DEV unsigned long long order_double(double v) {  // order-preserving map doub
 }
 
 // histogram of `state` + min/max of t over particles still in Evaluate
-// Clock probe: one wavefront per XCD (workgroups are dealt round-robin over the 8 XCDs) reads the shader-clock cycle counter (s_memtime) and the
-// constant 100 MHz counter (s_memrealtime) of ITS XCD; two probes around a kernel give the average shader clock the kernel ran at --
-// which is what reconciles a bench line with a rocprofv3 trace taken at another clock (bench.py: `sclk_mhz`).
+// Clock probe, launched right behind the advection kernel: 16 single-wavefront workgroups (dealt round-robin over the 8 XCDs) each spin for
+// 20 microseconds of the constant 100 MHz counter (s_memrealtime) and count the shader-clock cycles (s_memtime) that passed meanwhile -- both
+// read by the SAME wavefront, so no pairing of counters across XCDs or launches is involved (the first version of this round paired two
+// probes around the kernel by XCC id and produced 2.0 ... 6.0 GHz for one and the same launch).  The DVFS loop works on milliseconds: the
+// clock microseconds after the kernel is the clock the kernel ended on.
 __global__ void __launch_bounds__(64) clock_probe_kernel(unsigned long long* out) {
     if (threadIdx.x != 0) return;
-    const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7u;  // HW_REG_XCC_ID[3:0]
-    out[xcc * 2] = __builtin_readcyclecounter();
-    out[xcc * 2 + 1] = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long c0 = __builtin_readcyclecounter();
+    unsigned long long r = r0;
+    while (r - r0 < 2000ull) r = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long c1 = __builtin_readcyclecounter();
+    out[blockIdx.x * 2] = c1 - c0;
+    out[blockIdx.x * 2 + 1] = r - r0;
 }
 
 __global__ void __launch_bounds__(256) summarize_kernel(const int32_t* state, const double* t, int64_t n,
@@ -663,6 +671,7 @@ int32_t pk_set_option(pk_ctx* ctx, const char* name, int32_t value) {
     if (n == "fast_path") ctx->no_fast = !value;
     else if (n == "fast_cgrid") ctx->no_fast_cgrid = !value;
     else if (n == "velocity_pairs") ctx->no_velocity_pairs = !value;
+    else if (n == "clock_probe") ctx->clock_probe = value;
     else if (n == "special_programs") ctx->no_special = !value;
     else if (n == "cell_cache") ctx->no_cell_cache = !value;
     else if (n == "hash_directory") ctx->no_hash_dir = !value;
@@ -2373,8 +2382,6 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
             for (const auto& c : cp)
                 if (c.dst && c.src) PK_HIP(ctx, hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyDeviceToDevice, ctx->compute));
         }
-        PK_HIP(ctx, hipMemsetAsync(ctx->d_clk, 0, sizeof(unsigned long long) * 32, ctx->compute));
-        hipLaunchKernelGGL(clock_probe_kernel, dim3(16), dim3(64), 0, ctx->compute, ctx->d_clk);
         PK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->compute));
         // the A-grid kernel's LDS: the coordinate tables and, behind them (2-D kernels), 64 bytes per lane of corner-block cache
         size_t fast_lds = fast_a ? (size_t)a.fast.lds_n * 2 * sizeof(double) : 0;
@@ -2408,8 +2415,12 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
         }
         PK_HIP(ctx, hipGetLastError());
         PK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->compute));
-        hipLaunchKernelGGL(clock_probe_kernel, dim3(16), dim3(64), 0, ctx->compute, ctx->d_clk + 16);
-        PK_HIP(ctx, hipMemcpyAsync(ctx->h_clk, ctx->d_clk, sizeof(unsigned long long) * 32, hipMemcpyDeviceToHost, ctx->compute));
+        if (ctx->clock_probe) {  // (20 microseconds behind the kernel, outside ev0 .. ev1)
+            PK_HIP(ctx, hipMemsetAsync(ctx->d_clk, 0, sizeof(unsigned long long) * 32, ctx->compute));
+            hipLaunchKernelGGL(clock_probe_kernel, dim3(16), dim3(64), 0, ctx->compute, ctx->d_clk);
+            PK_HIP(ctx, hipMemcpyAsync(ctx->h_clk, ctx->d_clk, sizeof(unsigned long long) * 32, hipMemcpyDeviceToHost, ctx->compute));
+        }
+        ctx->fl_clock_probe = ctx->clock_probe != 0;
         launches = 1;
         ctx->fl_program = fast_a ? 100 : (fast_c ? 101 : prog);
         swap_launch_outputs(ctx);
@@ -2479,16 +2490,20 @@ int32_t pk_execute_end(pk_ctx* ctx, pk_exec_stats* stats) {
             PK_HIP(ctx, hipMemcpy(hit.data(), ctx->d_twe_hit, sizeof(unsigned int) * ctx->fl_twe_n, hipMemcpyDeviceToHost));
             for (int k = 0; k < ctx->fl_twe_n; k++) ctx->twe_hit_host[k] = hit[k] ? 1 : 0;
         }
-        // average shader clock of the advection kernel: cycle-counter / 100 MHz-counter deltas of the XCDs both probes reached
+        // shader clock right behind the advection kernel: cycles per 100 MHz tick of every probe wavefront (median: one wavefront that was
+        // descheduled mid-spin must not move it)
         double sclk = 0.0;
         int nx = 0;
-        if (ctx->fl_launches) {
-            for (int x = 0; x < 8; x++) {
-                const unsigned long long c0 = ctx->h_clk[x * 2], r0 = ctx->h_clk[x * 2 + 1], c1 = ctx->h_clk[16 + x * 2], r1 = ctx->h_clk[16 + x * 2 + 1];
-                if (c0 && c1 && r1 > r0 && c1 > c0) {
-                    sclk += (double)(c1 - c0) / (double)(r1 - r0) * 100.0;
-                    nx++;
-                }
+        if (ctx->fl_launches && ctx->fl_clock_probe) {
+            std::vector<double> v;
+            for (int k = 0; k < 16; k++) {
+                const unsigned long long dc = ctx->h_clk[k * 2], dr = ctx->h_clk[k * 2 + 1];
+                if (dc && dr) v.push_back((double)dc / (double)dr * 100.0);
+            }
+            if (!v.empty()) {
+                std::sort(v.begin(), v.end());
+                sclk = v[v.size() / 2];
+                nx = 1;
             }
         }
         stats->sclk_mhz = nx ? sclk / nx : 0.0;
