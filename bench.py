@@ -411,7 +411,7 @@ def main():
     pset._data["particle_id"] += shard.start
     kern = pa.Kernel([pa.AdvectionRK4], pset)
     eng = fs._engine_or_create()
-    eng.ctx.set_option("clock_probe", 1)  # pk_exec_stats.sclk_mhz: the shader clock right behind every advection kernel (20 us per launch)
+    eng.ctx.set_option("clock_probe", 1)  # pk_exec_stats.sclk_mhz: the shader clock while an advection kernel runs (16 wavefronts on a second stream spin 1 ms beside it)
     dt = case["dt"]
     pset._data["dt"][:] = dt
     eng.bind_particles(pset._data)
@@ -536,9 +536,9 @@ def main():
                 "traffic": None, "algorithmic_fp64_flops_per_evaluation": ALGO_FLOPS_PER_EVAL_C2,
                 "frac_no_fma_peak": algo_tflops / (FP64_VECTOR_PEAK_TFLOPS / 2) * (121.59 / ALGO_FLOPS_PER_EVAL_C2),  # one op per lane and slot: NumPy never fuses (-ffp-contract=off)
                 "kernel": "pk::advect_fast_kernel<double, 0, false> (csrc/pk_kernels.h, pk_fast_agrid.h)", "kernel_ms_per_launch": float(kms.item()),
-                # shader clock right behind the timed launches (a 20 us cycle-counter / 100 MHz-counter probe after each kernel; median over the
-                # repetitions): reconciles this line with a trace taken at another clock
-                "sclk_mhz": (sorted(rep_sclk)[(len(rep_sclk) - 1) // 2] if rep_sclk else None), "sclk_mhz_reps": rep_sclk,
+                # shader clock DURING the timed launches (a cycle-counter / 100 MHz-counter probe spinning beside each kernel for 1 ms; median over
+                # the first millisecond of it): reconciles this line with a trace taken at another clock
+                "sclk_mhz": (rep_sclk[med] if len(rep_sclk) == reps else None), "sclk_mhz_reps": rep_sclk,  # (of the median repetition; all of them beside it)
                 "hbm": None,
                 "algorithmic": {"note": "SURVEY 8(d) byte model; these bytes are served by L2 / Infinity Cache, this is NOT an HBM fraction",
                                 "bytes_per_particle_step": ALGO_BYTES_PER_STEP_C2_RK4, "bytes_per_launch": ALGO_BYTES_PER_STEP_C2_RK4 * per_gpu_steps,

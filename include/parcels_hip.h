@@ -104,7 +104,7 @@ const char* pk_last_error(const pk_ctx* ctx); /* ctx may be NULL: error of the l
  *                      8-value group per cell and pair of adjacent resident time levels (32 B per cell and ring slot more for float32
  *                      fields; made on the device ahead of a launch and timed: pk_exec_stats.pack_ms -- 14 ms per level pair at BASELINE
  *                      config 5 for a kernel that gets 1.6 ms faster, hence off; without the memory for them the kernels read the rings)
- *   "clock_probe"      0 (default) / 1: measure the shader clock right behind every advection kernel (pk_exec_stats.sclk_mhz; 20 us)
+ *   "clock_probe"      0 (default) / 1 / microseconds: measure the shader clock beside every advection kernel (pk_exec_stats.sclk_mhz)
  *   "special_programs" 1 (default) single-kernel programs for AdvectionRK45 / AdvectionDiffusionM1; 0 = kernel-list interpreter
  *   "cell_cache"       1 (default) per-lane LDS cache of the curvilinear cell;  "hash_directory" 1 (default) key directory;
  *                      "cell_table" 1 (default) per-cell table of the query-independent part of the point-in-cell test (192 B per
@@ -382,8 +382,8 @@ typedef struct pk_exec_stats {
                         "velocity_pairs", off by default; csrc/pk_api.hip: ensure_velocity_pairs) -- NOT part of kernel_ms                  */
     int32_t packs;   /* level pairs packed for it */
     int32_t pad0;
-    double sclk_mhz; /* shader clock right behind the advection kernel of the (last) launch (option "clock_probe": sixteen wavefronts spin for 20
-                        microseconds of the 100 MHz counter and count shader-clock cycles; the median); 0 = not measured                     */
+    double sclk_mhz; /* shader clock while the advection kernel of the (last) launch ran (option "clock_probe": sixteen wavefronts on a second
+                        stream spin beside it for 1 ms of the 100 MHz counter and count shader-clock cycles; the median); 0 = not measured  */
 } pk_exec_stats;
 int32_t pk_execute(pk_ctx* ctx, const pk_exec_params* params, pk_exec_stats* stats);
 /* kernel.py:236-245: the reference checks the error codes after every iteration of its batch loop, so when it raises, EVERY particle

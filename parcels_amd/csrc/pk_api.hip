@@ -53,6 +53,8 @@ constexpr int PK_STAGE_BUFFERS = 3;  // pinned staging chunks of the level strea
 struct pk_ctx {
     int device = 0;
     hipStream_t compute = nullptr, copy = nullptr;
+    hipStream_t probe = nullptr;     // the clock probe runs beside the advection kernel (created on first use)
+    hipEvent_t ev_probe = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr;  // around the pair-copy packing of a launch (ensure_velocity_pairs)
     int fl_packs = 0;                             // pairs packed ahead of the launch in flight
@@ -195,17 +197,20 @@ PK_DEV unsigned long long order_double(double v) {  // order-preserving map doub
 }
 
 // histogram of `state` + min/max of t over particles still in Evaluate
-// Clock probe, launched right behind the advection kernel: 16 single-wavefront workgroups (dealt round-robin over the 8 XCDs) each spin for
-// 20 microseconds of the constant 100 MHz counter (s_memrealtime) and count the shader-clock cycles (s_memtime) that passed meanwhile -- both
-// read by the SAME wavefront, so no pairing of counters across XCDs or launches is involved (the first version of this round paired two
-// probes around the kernel by XCC id and produced 2.0 ... 6.0 GHz for one and the same launch).  The DVFS loop works on milliseconds: the
-// clock microseconds after the kernel is the clock the kernel ended on.
-__global__ void __launch_bounds__(64) clock_probe_kernel(unsigned long long* out) {
+// Clock probe, running NEXT TO the advection kernel (its own stream): 16 single-wavefront workgroups (dealt round-robin over the 8 XCDs) each
+// spin for `ticks` of the constant 100 MHz counter (s_memrealtime) and count the shader-clock cycles (s_memtime) that passed meanwhile --
+// both read by the SAME wavefront, so no pairing of counters across XCDs or launches is involved (the first version of this round paired
+// two probes around the kernel by XCC id and produced 2.0 ... 6.0 GHz for one and the same launch; a probe BEHIND the kernel reads the idle
+// boost clock, 2.41-2.44 GHz, not the clock under the fp64 load).  One wavefront on 16 of the 1024 SIMDs: below the noise of the timed kernel.
+__global__ void __launch_bounds__(64) clock_probe_kernel(unsigned long long* out, unsigned long long ticks) {
     if (threadIdx.x != 0) return;
     const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long c0 = __builtin_readcyclecounter();
     unsigned long long r = r0;
-    while (r - r0 < 2000ull) r = __builtin_amdgcn_s_memrealtime();
+    while (r - r0 < ticks) {
+        __builtin_amdgcn_s_sleep(8);
+        r = __builtin_amdgcn_s_memrealtime();
+    }
     const unsigned long long c1 = __builtin_readcyclecounter();
     out[blockIdx.x * 2] = c1 - c0;
     out[blockIdx.x * 2 + 1] = r - r0;
@@ -776,6 +781,8 @@ int32_t pk_destroy(pk_ctx* ctx) {
     if (ctx->ev_p1) (void)hipEventDestroy(ctx->ev_p1);
     if (ctx->compute) (void)hipStreamDestroy(ctx->compute);
     if (ctx->copy) (void)hipStreamDestroy(ctx->copy);
+    if (ctx->probe) (void)hipStreamDestroy(ctx->probe);
+    if (ctx->ev_probe) (void)hipEventDestroy(ctx->ev_probe);
     delete ctx;
     return 0;
 }
@@ -2382,6 +2389,15 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
             for (const auto& c : cp)
                 if (c.dst && c.src) PK_HIP(ctx, hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyDeviceToDevice, ctx->compute));
         }
+        if (ctx->clock_probe) {  // the probe may start once everything queued before the advection kernel is done
+            if (!ctx->probe) {
+                PK_HIP(ctx, hipStreamCreateWithFlags(&ctx->probe, hipStreamNonBlocking));
+                PK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_probe, hipEventDisableTiming));
+            }
+            PK_HIP(ctx, hipMemsetAsync(ctx->d_clk, 0, sizeof(unsigned long long) * 32, ctx->compute));
+            PK_HIP(ctx, hipEventRecord(ctx->ev_probe, ctx->compute));
+            PK_HIP(ctx, hipStreamWaitEvent(ctx->probe, ctx->ev_probe, 0));
+        }
         PK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->compute));
         // the A-grid kernel's LDS: the coordinate tables and, behind them (2-D kernels), 64 bytes per lane of corner-block cache
         size_t fast_lds = fast_a ? (size_t)a.fast.lds_n * 2 * sizeof(double) : 0;
@@ -2415,10 +2431,10 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
         }
         PK_HIP(ctx, hipGetLastError());
         PK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->compute));
-        if (ctx->clock_probe) {  // (20 microseconds behind the kernel, outside ev0 .. ev1)
-            PK_HIP(ctx, hipMemsetAsync(ctx->d_clk, 0, sizeof(unsigned long long) * 32, ctx->compute));
-            hipLaunchKernelGGL(clock_probe_kernel, dim3(16), dim3(64), 0, ctx->compute, ctx->d_clk);
-            PK_HIP(ctx, hipMemcpyAsync(ctx->h_clk, ctx->d_clk, sizeof(unsigned long long) * 32, hipMemcpyDeviceToHost, ctx->compute));
+        if (ctx->clock_probe) {  // beside the kernel that was just queued: spins for clock_probe microseconds (1 -> 1000) of the 100 MHz counter
+            const unsigned long long us = ctx->clock_probe == 1 ? 1000ull : (unsigned long long)std::max(ctx->clock_probe, 20);
+            hipLaunchKernelGGL(clock_probe_kernel, dim3(16), dim3(64), 0, ctx->probe, ctx->d_clk, us * 100ull);
+            PK_HIP(ctx, hipMemcpyAsync(ctx->h_clk, ctx->d_clk, sizeof(unsigned long long) * 32, hipMemcpyDeviceToHost, ctx->probe));
         }
         ctx->fl_clock_probe = ctx->clock_probe != 0;
         launches = 1;
@@ -2446,6 +2462,7 @@ int32_t pk_execute_end(pk_ctx* ctx, pk_exec_stats* stats) {
     PK_HIP(ctx, hipSetDevice(ctx->device));
     ctx->in_flight = false;
     PK_HIP(ctx, hipStreamSynchronize(ctx->compute));
+    if (ctx->fl_clock_probe && ctx->probe) PK_HIP(ctx, hipStreamSynchronize(ctx->probe));
     if (stats) {
         memset(stats, 0, sizeof(*stats));
         const DCounters& hc = *ctx->h_counters;
@@ -2490,8 +2507,7 @@ int32_t pk_execute_end(pk_ctx* ctx, pk_exec_stats* stats) {
             PK_HIP(ctx, hipMemcpy(hit.data(), ctx->d_twe_hit, sizeof(unsigned int) * ctx->fl_twe_n, hipMemcpyDeviceToHost));
             for (int k = 0; k < ctx->fl_twe_n; k++) ctx->twe_hit_host[k] = hit[k] ? 1 : 0;
         }
-        // shader clock right behind the advection kernel: cycles per 100 MHz tick of every probe wavefront (median: one wavefront that was
-        // descheduled mid-spin must not move it)
+        // shader clock beside the advection kernel: cycles per 100 MHz tick of every probe wavefront (the median of the 16)
         double sclk = 0.0;
         int nx = 0;
         if (ctx->fl_launches && ctx->fl_clock_probe) {
