@@ -15,7 +15,9 @@ calls of the usual script loop.  Here the columns stay in HBM from one call to t
   arrays authoritative again (everything stale is downloaded first).
 
 ``peek(k)`` reads a column with the promise not to write to it (no dirty mark).  References to an array obtained BEFORE a launch are
-not refreshed by the launch; ask the dict again.
+not refreshed by the launch, and a write through such an old reference is not seen; ask the dict again.  For that reason the mirror is lazy
+only from ``ParticleSet.RESIDENT_MIN`` (1e5) particles on -- where the copies cost tens of milliseconds per call; smaller sets keep the eager
+protocol (every call uploads and downloads everything: well under a millisecond), i.e. exactly the reference's aliasing behaviour.
 """
 
 from __future__ import annotations

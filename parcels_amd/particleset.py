@@ -80,6 +80,11 @@ class ParticleSet:
     which a long fused launch is cut and re-sorted (measured on BASELINE config 2)."""
 
     SORT_AUTO_MIN = 100_000
+    # From this many particles on the columns stay in HBM between execute() calls and the host arrays become a lazy mirror
+    # (parcels_amd/columns.py).  Smaller sets keep the eager protocol of the reference -- every call uploads all columns and downloads them at
+    # its end (a millisecond at this size) -- so that code which holds on to a column array across calls, or writes through such an old
+    # reference, sees exactly what it sees with the reference.  `pset.resident_columns = True / False` forces either.
+    RESIDENT_MIN = 100_000
     RESORT_EVERY_DEFAULT = 30 * 86400.0  # profiles/r03_c2_long_run.json: over 23 days of C2 the locality of ONE sort does not decay (re-sorting only costs)
 
 
@@ -98,6 +103,7 @@ class ParticleSet:
         if isinstance(sort_by_cell, str) and sort_by_cell != "auto":
             raise ValueError(f"sort_by_cell must be True, False or 'auto'. Got {sort_by_cell!r}")
         self.resort_every = resort_every
+        self.resident_columns = "auto"  # see RESIDENT_MIN
         self.device_compaction = True  # deleted particles are removed on the device (False: through NumPy on the host)
         self.async_output = True  # ParticleFile tables are encoded on a writer thread behind the next interval (False: inline)
         self._last_stats = None
@@ -273,7 +279,8 @@ class ParticleSet:
         # Columns that are still device-resident from the previous call stay there (parcels_amd/columns.py): `particles.dt = dt` and the
         # reductions over the release times below run on the device, nothing crosses PCIe unless the host touched the set in between.
         data = self._data
-        eng0 = data._engine if isinstance(data, LazyColumns) and data.resident() and hasattr(data._engine, "fill_column") else None
+        want_resident = self.resident_columns if isinstance(self.resident_columns, bool) else len(self) >= self.RESIDENT_MIN
+        eng0 = data._engine if want_resident and isinstance(data, LazyColumns) and data.resident() and hasattr(data._engine, "fill_column") else None
         if eng0 is not None and eng0 is not getattr(self.fieldset, "_engine", None):
             eng0 = None  # (resident on an engine the FieldSet no longer uses: the host path below downloads what it touches)
         if eng0 is not None:
@@ -333,7 +340,7 @@ class ParticleSet:
         if kern.host_functions and not kern._jit_tried:
             kern._try_jit(self)  # elementwise Python kernels are compiled into the device program here (parcels_amd/jit.py)
         engine.device_variables = list(kern.device_variables)  # user Variables that device kernels write live on the device
-        lazy = isinstance(self._data, LazyColumns) and hasattr(engine, "attach")  # (stand-in engines of the CPU suite: the eager path)
+        lazy = want_resident and isinstance(self._data, LazyColumns) and hasattr(engine, "attach")  # (small sets, stand-in engines of the CPU suite: the eager path)
         if len(self) > 0:
             if lazy:
                 engine.attach(self._data)  # uploads what the host touched since the last launch (everything the first time)

@@ -35,8 +35,11 @@ def _script(case, calls, steps, between=None, eager=False, sort=True, two_sets=F
         fs = build_fieldset(case)
         fs.to_device(0)
         pset = build_pset(case, fs, sort_by_cell=sort)
+        pset.resident_columns = True  # (sets below ParticleSet.RESIDENT_MIN are eager by default)
         other = build_pset(dict(case, x=np.asarray(case["x"])[:100] + 0.01, y=np.asarray(case["y"])[:100], z=None if case.get("z") is None else np.asarray(case["z"])[:100]), fs,
                            sort_by_cell=False) if two_sets else None
+        if other is not None:
+            other.resident_columns = True
         kernels = [getattr(pa.kernels, k) for k in case["kernels"]]
         eng = fs._engine
         log = []
@@ -126,6 +129,7 @@ def test_deletions_and_output_file_with_resident_columns(gpu, tmp_path):
             fs = build_fieldset(case)
             fs.to_device(0)
             pset = build_pset(case, fs, sort_by_cell=True)
+            pset.resident_columns = True
             path = tmp_path / f"o{int(eager)}.parquet"
             for k in range(3):
                 pf = pa.ParticleFile(tmp_path / f"o{int(eager)}_{k}.parquet", outputdt=2 * float(case["dt"]))
@@ -137,3 +141,24 @@ def test_deletions_and_output_file_with_resident_columns(gpu, tmp_path):
     assert len(outs[False][0]["x"]) < 4000, "nothing was deleted: the test does not test the compaction"
     for a, b in zip(outs[False][1], outs[True][1]):
         assert a.equals(b)
+
+
+def test_small_sets_keep_the_eager_protocol(gpu):
+    """Below ParticleSet.RESIDENT_MIN every execute() uploads and downloads all columns: an array held across calls is refreshed in place and
+    a write through such an old reference reaches the device, exactly as with the reference (and with rounds 1-4)."""
+    import parcels_amd as pa
+
+    case = _case(npart=500, kernels=("AdvectionRK4",))
+    fs = build_fieldset(case)
+    fs.to_device(0)
+    pset = build_pset(case, fs)
+    x_ref = pset._data["x"]  # held across the calls
+    x0 = x_ref.copy()
+    pset.execute([pa.AdvectionRK4], dt=float(case["dt"]), runtime=2 * float(case["dt"]))
+    assert not np.array_equal(x_ref, x0), "the held array was not refreshed by the call"
+    x_ref[:10] += 0.5  # a write nobody announces
+    after_write = x_ref.copy()
+    before = dict(fs._engine.transfers)
+    pset.execute([pa.AdvectionRK4], dt=float(case["dt"]), runtime=float(case["dt"]))
+    assert fs._engine.transfers["h2d_full"] == before["h2d_full"] + 1 and fs._engine.transfers["d2h_full"] == before["d2h_full"] + 1
+    assert np.all(np.abs(x_ref[:10] - after_write[:10]) < 0.2) and np.all(np.abs(x_ref[:10] - (x0[:10] + 0.5)) < 0.3), "the write through the old reference was lost"
