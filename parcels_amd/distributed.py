@@ -63,6 +63,10 @@ def allreduce_scalars(values, op: str, group=None, device=None) -> list:
     return t.cpu().tolist()
 
 
+class CollectiveAbort(RuntimeError):
+    """Raised on the ranks of a collective run whose pass went fine when ANOTHER rank's pass raised (batch_agreement: agree_min)."""
+
+
 def batch_agreement(group=None, device=None):
     """The two hooks that make a sharded ParticleSet ONE batch for the batch-wide rules of ``Kernel.execute`` (DeviceEngine.execute):
 
@@ -86,13 +90,17 @@ def batch_agreement(group=None, device=None):
     # ParticleSet.execute copies it to `pset._agreement_stats`, bench.py --c4 prints it
     stats = {"calls": 0, "seconds": 0.0}
 
-    def agree_min(err, key):
+    def agree_min(err, key, failed=False):
+        """failed=True: this rank's pass raised (it re-raises after the agreement); every OTHER rank then raises CollectiveAbort here instead of
+        waiting in the next all-reduce for a rank that is gone (round-4 ADVICE: the schedule of agreements must not desynchronise)."""
         t0 = _time.perf_counter()
-        t = torch.tensor([int(err) or big, int(key) or big], dtype=torch.int64, device=dev)
+        t = torch.tensor([int(err) or big, int(key) or big, 0 if failed else 1], dtype=torch.int64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
-        e, k = (int(v) for v in t.tolist())
+        e, k, ok = (int(v) for v in t.tolist())
         stats["calls"] += 1
         stats["seconds"] += _time.perf_counter() - t0
+        if not ok and not failed:
+            raise CollectiveAbort("another rank of the collective run failed inside Kernel.execute (its own exception says why); this rank stops with it")
         return (0 if e == big else e), (0 if k == big else k)
 
     def agree_codes(present):

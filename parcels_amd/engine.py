@@ -787,80 +787,90 @@ class DeviceEngine:
             pass_hits = [False] * len(keys)  # listed samples some particle justified in this pass
             validated = True                 # every launch of the pass reported real justification flags
             total["steps"] = total["attempts"] = 0
-            while True:  # launches of one pass
-                st = _hip.ExecStats()
-                prefetched = False
-                if rerun:
-                    karr = (C.c_int64 * max(len(keys), 1))(*keys)
-                    self.ctx.check(self.lib.pk_execute_rerun_keys(self.ctx.handle, int(cap), len(keys), karr, C.byref(st)), "pk_execute_rerun_keys")
-                    rerun = False
-                else:
-                    nxt = None
-                    if self.windowed:
-                        if t_live is None or not np.isfinite(t_live):
-                            t_live = 0.0 if sign > 0 else max(float(f.model.time_flt[-1]) for f in self._windowed_fields())
-                        _t = _time.perf_counter()
-                        nxt = self._commit_window(float(t_live), sign)
-                        total["commit_s"] += _time.perf_counter() - _t
-                    horizon = None
-                    if span is not None and t_live is not None and np.isfinite(t_live):
-                        horizon = (-np.inf, float(t_live) + span) if sign > 0 else (float(t_live) - span, np.inf)
-                    sort_now = 0 if (reset and skip_first_sort) else sort_by_cell
-                    prm = self.make_params(kernel_ids, endtime=endtime, dt0=dt0, context=context, seed=seed, reset_state=reset,
-                                           have_guess0=(have_guess0 if reset else 1), sort_by_cell=sort_now, samples=samples, horizon=horizon,
-                                           max_iters=cap, twe_keys=keys)
-                    if sort_now and t_live is not None and np.isfinite(t_live):
-                        self._sorted_t = float(t_live)
-                    elif sort_now:
-                        self._sorted_t = None
-                    self.ctx.check(self.lib.pk_execute_begin(self.ctx.handle, C.byref(prm)), "pk_execute_begin")
-                    try:
-                        _t = _time.perf_counter()
-                        prefetched = self._prefetch(nxt)  # overlaps the kernel that was just launched
-                        total["prefetch_s"] += _time.perf_counter() - _t
-                    finally:
-                        _t = _time.perf_counter()
-                        self.ctx.check(self.lib.pk_execute_end(self.ctx.handle, C.byref(st)), "pk_execute_end")
-                        total["wait_s"] += _time.perf_counter() - _t
-                reset = 0
-                total["steps"] += st.steps
-                total["attempts"] += st.attempts
-                total["kernel_ms"] += st.kernel_ms
-                total["sort_ms"] += st.sort_ms
-                total["pack_ms"] += getattr(st, "pack_ms", 0.0)
-                total["packs"] += getattr(st, "packs", 0)
-                total["launches"] += st.launches
-                total["sclk_mhz"] = float(getattr(st, "sclk_mhz", 0.0))  # shader clock of the (last) launch's kernel
-                total["program"] = int(st.program)  # which device program the (last) launch ran: include/parcels_hip.h, pk_exec_stats
-                counts = {code: int(st.state_counts[code]) for code in range(_hip.PK_NUM_STATE_CODES) if st.state_counts[code]}
-                if st.first_error_iter > 0:
-                    pass_err = int(st.first_error_iter) if pass_err == 0 else min(pass_err, int(st.first_error_iter))
-                if st.first_time_error_key > 0:
-                    pass_twk = int(st.first_time_error_key) if pass_twk == 0 else min(pass_twk, int(st.first_time_error_key))
-                if self.exact_error_stop and (st.first_time_error_key > 0 or keys):
-                    fl, hl, real = self._twe_report(keys, int(st.first_time_error_key))
-                    pass_found.update(fl)
-                    pass_hits = [a or b for a, b in zip(pass_hits, hl)]
-                    validated = validated and real
-                if st.paused == 0:
-                    break
-                if not self.windowed and span is None:
-                    raise _hip.HipLibraryError("particles paused although all time levels are resident (internal error)")
-                # (what this launch found already decides that the pass will be repeated: stop it here)
-                if self.exact_error_stop and agree is None and (pass_found or self._repeat_decision(pass_err, pass_twk, cap) is not None):
-                    break
-                t_live = st.t_min_live if sign > 0 else st.t_max_live
-                # no particle moved AND no new level is on its way (a small ring needs one launch per cycle just to bring in the
-                # level behind the window; the next commit makes it resident): the step itself does not fit
-                if last_live is not None and t_live == last_live and not prefetched:
-                    if span is not None:
-                        span *= 2.0  # the soft horizon, not the ring, stopped every particle: widen it
+            try:
+                while True:  # launches of one pass
+                    st = _hip.ExecStats()
+                    prefetched = False
+                    if rerun:
+                        karr = (C.c_int64 * max(len(keys), 1))(*keys)
+                        self.ctx.check(self.lib.pk_execute_rerun_keys(self.ctx.handle, int(cap), len(keys), karr, C.byref(st)), "pk_execute_rerun_keys")
+                        rerun = False
                     else:
-                        raise RuntimeError(
-                            "field window too small: a single step does not fit into the resident time levels; "
-                            "increase nslots (FieldSet.to_device(nslots=...))"
-                        )
-                last_live = t_live
+                        nxt = None
+                        if self.windowed:
+                            if t_live is None or not np.isfinite(t_live):
+                                t_live = 0.0 if sign > 0 else max(float(f.model.time_flt[-1]) for f in self._windowed_fields())
+                            _t = _time.perf_counter()
+                            nxt = self._commit_window(float(t_live), sign)
+                            total["commit_s"] += _time.perf_counter() - _t
+                        horizon = None
+                        if span is not None and t_live is not None and np.isfinite(t_live):
+                            horizon = (-np.inf, float(t_live) + span) if sign > 0 else (float(t_live) - span, np.inf)
+                        sort_now = 0 if (reset and skip_first_sort) else sort_by_cell
+                        prm = self.make_params(kernel_ids, endtime=endtime, dt0=dt0, context=context, seed=seed, reset_state=reset,
+                                               have_guess0=(have_guess0 if reset else 1), sort_by_cell=sort_now, samples=samples, horizon=horizon,
+                                               max_iters=cap, twe_keys=keys)
+                        if sort_now and t_live is not None and np.isfinite(t_live):
+                            self._sorted_t = float(t_live)
+                        elif sort_now:
+                            self._sorted_t = None
+                        self.ctx.check(self.lib.pk_execute_begin(self.ctx.handle, C.byref(prm)), "pk_execute_begin")
+                        try:
+                            _t = _time.perf_counter()
+                            prefetched = self._prefetch(nxt)  # overlaps the kernel that was just launched
+                            total["prefetch_s"] += _time.perf_counter() - _t
+                        finally:
+                            _t = _time.perf_counter()
+                            self.ctx.check(self.lib.pk_execute_end(self.ctx.handle, C.byref(st)), "pk_execute_end")
+                            total["wait_s"] += _time.perf_counter() - _t
+                    reset = 0
+                    total["steps"] += st.steps
+                    total["attempts"] += st.attempts
+                    total["kernel_ms"] += st.kernel_ms
+                    total["sort_ms"] += st.sort_ms
+                    total["pack_ms"] += getattr(st, "pack_ms", 0.0)
+                    total["packs"] += getattr(st, "packs", 0)
+                    total["launches"] += st.launches
+                    total["sclk_mhz"] = float(getattr(st, "sclk_mhz", 0.0))  # shader clock of the (last) launch's kernel
+                    total["program"] = int(st.program)  # which device program the (last) launch ran: include/parcels_hip.h, pk_exec_stats
+                    counts = {code: int(st.state_counts[code]) for code in range(_hip.PK_NUM_STATE_CODES) if st.state_counts[code]}
+                    if st.first_error_iter > 0:
+                        pass_err = int(st.first_error_iter) if pass_err == 0 else min(pass_err, int(st.first_error_iter))
+                    if st.first_time_error_key > 0:
+                        pass_twk = int(st.first_time_error_key) if pass_twk == 0 else min(pass_twk, int(st.first_time_error_key))
+                    if self.exact_error_stop and (st.first_time_error_key > 0 or keys):
+                        fl, hl, real = self._twe_report(keys, int(st.first_time_error_key))
+                        pass_found.update(fl)
+                        pass_hits = [a or b for a, b in zip(pass_hits, hl)]
+                        validated = validated and real
+                    if st.paused == 0:
+                        break
+                    if not self.windowed and span is None:
+                        raise _hip.HipLibraryError("particles paused although all time levels are resident (internal error)")
+                    # (what this launch found already decides that the pass will be repeated: stop it here)
+                    if self.exact_error_stop and agree is None and (pass_found or self._repeat_decision(pass_err, pass_twk, cap) is not None):
+                        break
+                    t_live = st.t_min_live if sign > 0 else st.t_max_live
+                    # no particle moved AND no new level is on its way (a small ring needs one launch per cycle just to bring in the
+                    # level behind the window; the next commit makes it resident): the step itself does not fit
+                    if last_live is not None and t_live == last_live and not prefetched:
+                        if span is not None:
+                            span *= 2.0  # the soft horizon, not the ring, stopped every particle: widen it
+                        else:
+                            raise RuntimeError(
+                                "field window too small: a single step does not fit into the resident time levels; "
+                                "increase nslots (FieldSet.to_device(nslots=...))"
+                            )
+                    last_live = t_live
+            except Exception:
+                # a collective run: the other ranks are on their way to the agreement of this pass -- meet them there (they raise
+                # CollectiveAbort), then let this rank's own exception through
+                if agree is not None and self.exact_error_stop:
+                    try:
+                        agree(0, 0, failed=True)
+                    except Exception:  # noqa: BLE001 -- the original exception matters
+                        pass
+                raise
             if not self.exact_error_stop:
                 break
             found = sorted(pass_found)

@@ -566,3 +566,46 @@ def test_shards_agree_on_all_failing_samples_of_a_pass(world):
         assert keys == both and reran == 1, (rank, res[rank])
         if passes is not None:
             assert passes == [(0, []), (0, both)], (rank, passes)
+
+
+class _FailingLib(_ScriptedLib):
+    def pk_execute_end(self, h, st_ref):
+        raise RuntimeError("field window too small: a single step does not fit into the resident time levels")
+
+
+def _abort_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from parcels_amd.distributed import batch_agreement
+
+        eng = _scripted_engine([(0, 0), (0, 0)])
+        if rank == 1:
+            eng.lib = _FailingLib([])
+        eng.agree_min, eng.agree_codes = batch_agreement()
+        try:
+            eng.execute([4], endtime=10.0, dt0=1.0) if rank < 2 else eng.execute_idle()
+            q.put((rank, None))
+        except Exception as e:  # noqa: BLE001
+            q.put((rank, type(e).__name__))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_a_rank_that_raises_inside_a_pass_takes_the_others_with_it(world):
+    """Round-4 ADVICE: execute() may raise between two agreements (a ring too small for one step, too many failing samples); the other
+    ranks -- the idle one included -- must not wait in the next all-reduce for a rank that is gone: they raise CollectiveAbort at the agreement
+    the failing rank still attends."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_abort_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=90)
+        assert p.exitcode == 0, "a rank hung or failed"
+    res = dict(q.get(timeout=10) for _ in range(world))
+    assert res[1] == "RuntimeError" and all(res[r] == "CollectiveAbort" for r in range(world) if r != 1), res
