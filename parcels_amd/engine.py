@@ -485,7 +485,11 @@ class DeviceEngine:
         survive.  Returns the new SoA dict: `state` and host-only user Variables are compacted here, the device-bound columns
         are fresh arrays of the surviving length that the next d2h() fills."""
         if isinstance(data, LazyColumns):
-            state = data.peek("state") if data._engine is self else data.raw("state")
+            # `state` decides which rows survive: always fetched (a resident set has it marked stale; an eager one -- small sets, no marks --
+            # would otherwise read the host copy of before the launch)
+            if data._engine is self:
+                self.d2h(["state"])
+            state = data.raw("state")
             pairs = [(k, data.raw(k)) for k in dict.keys(data)]  # (arrays as they are: the device columns are not downloaded)
         else:
             self.d2h(["state"])
