@@ -881,11 +881,14 @@ class DeviceEngine:
             if agree is not None:  # the batch of the reference is every shard's particles
                 pass_err, pass_twk = agree(pass_err, pass_twk)
                 agree_keys = getattr(agree, "keys", None)
-                got = agree_keys(found if validated else None, pass_hits) if agree_keys is not None else None
-                if got is not None and got[0] is not None:
-                    found, pass_hits = got
-                else:  # (an agreement of the round-4 form, or a rank without validation: the smallest key only, one key per pass)
-                    validated = False
+                if not pass_twk and not keys:
+                    pass  # nobody found a failing sample and none is listed (both known to every rank): the common pass costs ONE all-reduce
+                else:
+                    got = agree_keys(found if validated else None, pass_hits) if agree_keys is not None else None
+                    if got is not None and got[0] is not None:
+                        found, pass_hits = got
+                    else:  # (an agreement of the round-4 form, or a rank without validation: the smallest key only, one key per pass)
+                        validated = False
             if not validated:
                 found, pass_hits = ([pass_twk] if pass_twk else []), [True] * len(keys)
             # kernel.py:236-245 / field.py:31-44: what the pass found decides whether the call is repeated -- with the failing samples listed
@@ -927,9 +930,12 @@ class DeviceEngine:
         while True:
             pass_err, pass_twk = self.agree_min(0, 0)
             agree_keys = getattr(self.agree_min, "keys", None)
-            got = agree_keys([], [False] * len(keys)) if agree_keys is not None else None
-            validated = got is not None and got[0] is not None
-            found, hits = got if validated else (([pass_twk] if pass_twk else []), [True] * len(keys))
+            if not pass_twk and not keys:  # (the same shortcut, from the same agreed values, as `execute`)
+                validated, found, hits = True, [], []
+            else:
+                got = agree_keys([], [False] * len(keys)) if agree_keys is not None else None
+                validated = got is not None and got[0] is not None
+                found, hits = got if validated else (([pass_twk] if pass_twk else []), [True] * len(keys))
             # (the same decision, from the same agreed values, as the shards that hold particles -- also its RuntimeError at PK_MAX_TWE)
             decision, keys, cap = self._twe_step(keys, cap, pass_err, found, hits, speculative=validated and total["reran"] < self.TWE_SPECULATIVE_PASSES)
             if decision is None:
