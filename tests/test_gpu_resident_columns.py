@@ -162,3 +162,31 @@ def test_small_sets_keep_the_eager_protocol(gpu):
     pset.execute([pa.AdvectionRK4], dt=float(case["dt"]), runtime=float(case["dt"]))
     assert fs._engine.transfers["h2d_full"] == before["h2d_full"] + 1 and fs._engine.transfers["d2h_full"] == before["d2h_full"] + 1
     assert np.all(np.abs(x_ref[:10] - after_write[:10]) < 0.2) and np.all(np.abs(x_ref[:10] - (x0[:10] + 0.5)) < 0.3), "the write through the old reference was lost"
+
+
+def test_sets_of_1e5_particles_and_more_are_resident_by_default(gpu):
+    """The automatic choice (ParticleSet.RESIDENT_MIN): 2e5 particles stay on the device between three calls -- nothing crosses PCIe in calls 2
+    and 3 -- and end where the eager protocol (resident_columns = False) ends, bit for bit; 5e4 particles are eager."""
+    import parcels_amd as pa
+
+    def run(n, resident):
+        case = _case(npart=n, kernels=("AdvectionRK4",))
+        fs = build_fieldset(case)
+        fs.to_device(0)
+        pset = build_pset(case, fs)
+        if resident is not None:
+            pset.resident_columns = resident
+        log = []
+        for _ in range(3):
+            before = dict(fs._engine.transfers)
+            pset.execute([pa.AdvectionRK4], dt=float(case["dt"]), runtime=4 * float(case["dt"]))
+            log.append({k: fs._engine.transfers[k] - before[k] for k in before})
+        return {k: np.array(v) for k, v in pset._data.items()}, log
+
+    auto, log = run(200_000, None)
+    eager, elog = run(200_000, False)
+    compare(auto, eager, rtol=0.0, check_state="all", label="2e5 particles: automatic (resident) vs eager", skip=())
+    assert log[0]["h2d_full"] == 1 and all(sum(e.values()) == 0 for e in log[1:]), log
+    assert all(e["h2d_full"] == 1 and e["d2h_full"] == 1 for e in elog), elog
+    _, slog = run(50_000, None)
+    assert all(e["h2d_full"] == 1 and e["d2h_full"] == 1 for e in slog), slog
