@@ -279,7 +279,7 @@ def secondary_runs(args):
             e = {"config": config, "workload": f"{config.upper()}: curvilinear C-grid {r['grid'][0]}x{r['grid'][1]}x{r['grid'][2]} f32 U,V,W, "
                                                f"{r['nslots']}-slot ring, {r['particles']} fp64 particles, {r['kernels']} + DeleteParticle, 24 steps of 3600 s",
                  "kernels": r["kernels"], "particle_steps": r["particle_steps"], "attempts": r["attempts"], "kernel_ms": r["kernel_ms"],
-                 "kernel_ms_stats": r.get("kernel_ms_stats"),
+                 "kernel_ms_stats": r.get("kernel_ms_stats"), "sclk_mhz": r.get("sclk_mhz"),
                  "value": r["particle_steps_per_s_kernel"], "unit": "particle-steps/s (kernel time, levels resident)",
                  "cell_sort_ms": r["sort_ms"], "wall_s_incl_h2d_d2h": r["wall_s"],
                  "roofline": {"bound": "hbm", "algorithmic_bytes_per_unit": ab, "units": units,

@@ -265,6 +265,7 @@ def run_config(config="c3", scale=1.0, particles=1e7, steps=24, nt=4, nslots=3, 
     t0 = time.perf_counter()
     fs.to_device(0, nslots=nslots)  # builds the spatial hash on the device unless the host table exists
     upload_s = time.perf_counter() - t0
+    fs._engine.ctx.set_option("clock_probe", 1)  # pk_exec_stats.sclk_mhz: the shader clock while a kernel runs (16 wavefronts spin 1 ms beside it)
     x, y, z = seed_particles(lon, lat, depth, n, seed=3)
     runs = [("AdvectionRK4_3D", [pa.AdvectionRK4_3D, pa.DeleteParticle], None)] if config == "c3" else [
         ("AdvectionRK45", [pa.AdvectionRK45, pa.DeleteParticle], "rk45"),
@@ -280,7 +281,7 @@ def run_config(config="c3", scale=1.0, particles=1e7, steps=24, nt=4, nslots=3, 
             pclass = pclass.add_variable(pa.Variable("next_dt", dtype=np.float64, initial=dt))
         import warnings
 
-        kms_all = []
+        kms_all, sclk_all = [], []
         for r in range(1 + max(int(reps), 0)):
             # RK45 mode is keyed on the context (kernel.py:118): do not leak it into the other runs -- and every Kernel construction
             # divides RK45_tol by deg2m again (kernel.py:144-145, reproduced), so a repetition starts from the defaults as well
@@ -294,6 +295,7 @@ def run_config(config="c3", scale=1.0, particles=1e7, steps=24, nt=4, nslots=3, 
                 pset.execute(kernels, dt=dt, runtime=steps * dt)
                 wall = time.perf_counter() - t0
             kms_all.append(float(pset._last_stats["kernel_ms"]))
+            sclk_all.append(float(pset._last_stats.get("sclk_mhz") or 0.0))
         st = dict(pset._last_stats)
         timed = sorted(kms_all[1:]) or kms_all
         st["kernel_ms"] = timed[(len(timed) - 1) // 2]
@@ -301,6 +303,7 @@ def run_config(config="c3", scale=1.0, particles=1e7, steps=24, nt=4, nslots=3, 
             "config": config, "kernels": label, "grid": [nx, ny, nz, nt], "nslots": nslots, "particles": n,
             "steps_requested": steps, "particle_steps": int(st["steps"]), "attempts": int(st["attempts"]),
             "kernel_ms": st["kernel_ms"], "sort_ms": st["sort_ms"], "launches": st["launches"],
+            "sclk_mhz": (sclk_all[kms_all.index(st["kernel_ms"])] or None), "sclk_mhz_all": sclk_all,  # shader clock beside the median launch / all launches (cold first)
             "kernel_ms_stats": {"cold": kms_all[0], "min": timed[0], "median": st["kernel_ms"], "max": timed[-1], "n": len(timed), "statistic": "median of the timed launches" if len(kms_all) > 1 else "the cold launch"},
             "particle_steps_per_s_kernel": st["steps"] / (st["kernel_ms"] * 1e-3) if st["kernel_ms"] else None,
             "particle_steps_per_s_wall_incl_h2d_d2h": st["steps"] / wall, "wall_s": wall,
