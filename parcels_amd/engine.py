@@ -851,8 +851,10 @@ class DeviceEngine:
                         break
                     if not self.windowed and span is None:
                         raise _hip.HipLibraryError("particles paused although all time levels are resident (internal error)")
-                    # (what this launch found already decides that the pass will be repeated: stop it here)
+                    # (what this launch found already decides that the pass will be repeated: stop it here.  The launches not made would have
+                    # reached listed samples too: a pass that was cut short says nothing against a listed key)
                     if self.exact_error_stop and agree is None and (pass_found or self._repeat_decision(pass_err, pass_twk, cap) is not None):
+                        pass_hits = [True] * len(keys)
                         break
                     t_live = st.t_min_live if sign > 0 else st.t_max_live
                     # no particle moved AND no new level is on its way (a small ring needs one launch per cycle just to bring in the
