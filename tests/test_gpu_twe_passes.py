@@ -84,3 +84,23 @@ def test_twe_fixtures_same_bits_both_schemes(gpu, name):
     assert nerr == oerr == err
     compare(new, old, rtol=0.0, check_state="all", label=name, skip=())
     assert nst["time_error_keys"] == ost["time_error_keys"] and nst["reran"] <= ost["reran"]
+
+
+def test_overshoot_through_a_level_ring_equals_the_resident_run(gpu):
+    """Many failing samples in a call of SEVERAL launches (4 levels through a ring of 3: lanes pause at the window edge, the call restarts from
+    the device checkpoint for every pass): the streamed run, the resident run and the oracle agree, and the passes stay bounded."""
+    from oracle import cases
+
+    case = cases.rect_agrid_case("twe_ring_rk45", mesh="spherical", kernels=["AdvectionRK45", "DeleteOutOfBounds"], seed=141, nt=4, npart=600, stagger=True)
+    case["context"] = {"RK45_tol": 500.0, "RK45_min_dt": 10.0, "RK45_max_dt": 7200.0}
+    tl = float(case["time_s"][-1] - case["time_s"][0])
+    case["runtime"] = tl + 3 * 3600.0 - float(np.min(case["t0"]))
+    resident, rerr, rst = run_hip(case)
+    ring, gerr, gst = run_hip(case, nslots=3)
+    assert rerr == gerr
+    assert len(rst["time_error_keys"]) > 10 and gst["time_error_keys"] == rst["time_error_keys"]
+    assert gst["launches"] >= 1 and gst["reran"] <= 8 and rst["reran"] <= 6, (gst["reran"], rst["reran"])
+    compare(ring, resident, rtol=0.0, check_state="all", label="ring of 3 vs resident levels", skip=())
+    ref, oerr, _ = run_oracle(case)
+    assert oerr == rerr
+    compare(resident, ref, rtol=tolerance_for("twe_ring_rk45", case), check_state="all", label="vs oracle")
