@@ -496,6 +496,27 @@ def main():
         except Exception:
             ver = None
         comm = {"backend": dist.get_backend(), "n_ranks_seen": dist.get_world_size(), "rccl_version": ".".join(str(v) for v in ver) if ver else None}
+    # what the lock-step points of a sharded ParticleSet cost (N > 1): four more steps through DeviceEngine.execute with the batch agreements
+    # installed (parcels_amd.distributed.batch_agreement: after every pass the ranks all-reduce the first erring iteration / failing sample, at
+    # the end the error codes) -- outside the timed region; calls and seconds inside the all-reduces, max over ranks
+    agreements = None
+    if dist is not None and (W + K + 4) * dt <= case["time_s"][-1]:
+        try:
+            from parcels_amd.distributed import batch_agreement
+
+            eng.agree_min, eng.agree_codes = batch_agreement(None, local_rank)
+            sync()
+            t1 = time.perf_counter()
+            st_a = eng.execute(kern.kernel_ids, endtime=(W + K + 4) * dt, dt0=dt, sort_by_cell=0, t_start=(W + K) * dt)
+            sync()
+            wall_a = time.perf_counter() - t1
+            ag = dict(eng.agree_min.stats)
+            agreements = [float(ag["calls"]), float(ag["seconds"]), wall_a, float(st_a["kernel_ms"])]
+        except Exception as e:  # the headline line must survive this leg
+            agreements = None
+            print(f"[bench] rank {rank}: agreement leg failed: {e!r}", file=sys.stderr)
+        finally:
+            eng.agree_min = eng.agree_codes = None
     elt = torch.tensor(rep_el, device="cuda", dtype=torch.float64)  # per repetition: the MAX over ranks ...
     steps_t = torch.tensor([rep_steps[-1]], device="cuda", dtype=torch.float64)
     kmst = torch.tensor(rep_kms, device="cuda", dtype=torch.float64)
@@ -513,10 +534,11 @@ def main():
     el = rep_el[med]
     kms = torch.tensor([rep_kms_max[med]], dtype=torch.float64)
     total_steps = float(steps_t.item())
-    agt = torch.tensor([t_ag, t_g0], device="cuda", dtype=torch.float64)
+    agt = torch.tensor([t_ag, t_g0] + (agreements or [-1.0, -1.0, -1.0, -1.0]), device="cuda", dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(agt, op=dist.ReduceOp.MAX)
-    t_ag, t_g0 = (float(v) for v in agt.tolist())
+    t_ag, t_g0 = (float(v) for v in agt.tolist()[:2])
+    ag_max = [float(v) for v in agt.tolist()[2:]]
     t_d2h = time.perf_counter()
     eng.d2h()
     t_d2h = time.perf_counter() - t_d2h
@@ -606,6 +628,10 @@ def main():
             "writeout_allgather_ms": t_ag * 1e3 if world > 1 else None,
             "writeout_gather_to_root_ms": t_g0 * 1e3 if world > 1 else None,  # what ParticleFile.write does (rows of the write filter -> rank 0)
             "comm": comm or None,
+            # 4 more steps with the batch agreements of a sharded ParticleSet installed (outside `value`): all-reduce calls per rank, seconds
+            # inside them / wall / kernel ms, each the max over ranks
+            "batch_agreements": ({"steps": 4, "calls": int(ag_max[0]), "seconds_in_allreduce_max_rank": ag_max[1], "wall_ms_max_rank": ag_max[2] * 1e3,
+                                  "kernel_ms_max_rank": ag_max[3]} if world > 1 and ag_max[0] >= 0 else None),
             "device": device,
             "value_incl_writeout": total_steps / (el + t_ag) if world > 1 else None,
         }
