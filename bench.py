@@ -35,6 +35,10 @@ Prints ONE JSON line (rank 0).  What the objects mean:
   traffic of profiles/pmc_secondary_latest.json, and `check`: 1e5 particle ids re-run through the CPU oracle on the same arrays.
 `user_kernels` (N = 1 only; `--user-kernels 0` switches it off) -- AdvectionRK4 + two user-written Python kernels on the headline FieldSet:
   compiled into the launch (parcels_amd/jit.py) vs the host path, 2e6 particles, 24 steps, wall seconds.
+`repeat_execute` (N = 1 only) -- the headline steps as ten consecutive pset.execute calls: the particle columns stay device-resident between them
+  (parcels_amd/columns.py); wall per later call, kernel ms, what crossed PCIe per call.
+`batch_agreements` (N > 1 only) -- four more steps with the agreements of a sharded ParticleSet installed (parcels_amd.distributed.batch_agreement):
+  all-reduce calls per rank, seconds inside them, wall and kernel ms (max over ranks); outside `value`.
 `cpu_baseline` -- oracle/fast_agrid_cpu.c (kind "port"): the headline workload restated the way one writes it for a CPU, bit-identical
   to the checker oracle, OpenMP on this box's host cores, bounded sample.
 `cpu_baseline_reference` -- the reference itself (Parcels under oracle/ref_shim.py).  It is Python and /root/reference does not exist
