@@ -24,7 +24,7 @@ Prints ONE JSON line (rank 0).  What the objects mean:
             of the timed launch / kernel time measured HERE with HIP events on the compute stream;  peak = 78.6 TFLOP/s (fp64 vector FMA);
             frac = achieved / peak.  `valu_busy_frac` (what rounds 1-4 printed as `frac`) = SQ_ACTIVE_INST_VALU x 4 per particle-step of
             the rocprofv3 PMC pass in profiles/pmc_latest.json x particle-steps / kernel time / (1024 SIMDs x 2.4 GHz): utilisation, not a
-            roof.  `sclk_mhz` = the shader clock the timed launch ran at (cycle-counter probes around the kernel)
+            roof.  `sclk_mhz` = the shader clock of ONE MORE, untimed repetition of the timed launch (a cycle-counter probe spins beside that one only)
   traffic   HBM bytes of the timed launch (FETCH_SIZE + WRITE_SIZE passes, calibrated on the 1 GiB copy kernel), scaled per
             particle-step to this run;  `hbm` = that traffic over the kernel time against the 8 TB/s peak
   algorithmic  SURVEY.md 8(d)'s byte model (1112 B per particle-step = 4 stages x 2 fields x 16 corners x 8 B + 88 B state) over
@@ -33,6 +33,9 @@ Prints ONE JSON line (rank 0).  What the objects mean:
   C5 AdvectionRK45 and AdvectionDiffusionM1 on the 4322 x 3059 x 75 curvilinear C-grid with 1e7 particles, each with kernel ms, value,
   a `roofline` by SURVEY 8(d)'s algorithmic bytes (536 / 672 / 568 B per unit; these working sets ARE beyond the caches) plus the counter
   traffic of profiles/pmc_secondary_latest.json, and `check`: 1e5 particle ids re-run through the CPU oracle on the same arrays.
+`check` -- the first 1e5 particle ids after the timed steps, re-run alone through the CPU oracle (test infrastructure; `--check 0` switches it off).
+`with_output` (N = 1 only; `--with-output 0` switches it off) -- the headline workload with a ParticleFile every 24 steps: value_incl_output,
+  output_hidden_frac (tools/bench_writeout.py has the sweep over cadences).
 `user_kernels` (N = 1 only; `--user-kernels 0` switches it off) -- AdvectionRK4 + two user-written Python kernels on the headline FieldSet:
   compiled into the launch (parcels_amd/jit.py) vs the host path, 2e6 particles, 24 steps, wall seconds.
 `repeat_execute` (N = 1 only) -- the headline steps as ten consecutive pset.execute calls: the particle columns stay device-resident between them
@@ -128,6 +131,30 @@ def cpu_baseline(case, steps: int, sample: int):
     return {"value": best[0], "unit": "particle-steps/s", "cores": best[1], "kind": "port",
             "sample": f"{sample} particles x {steps} RK4 steps of the same FieldSet, oracle/fast_agrid_cpu.c (OpenMP, cell-sorted, bit-identical to "
                       f"the checker oracle) on {best[1]} of {cores} hardware threads ({best[2]:.1f} s)"}
+
+
+def check_headline(case, data, n_check: int, endtime: float):
+    """The first `n_check` particle ids (of this rank's shard) after the timed steps against oracle/parcels_oracle.c run on those particles
+    alone -- the checker, not the thing measured."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from case_utils import compare, run_oracle
+
+    sub = dict(case)
+    sub["x"], sub["y"], sub["z"] = case["x"][:n_check], case["y"][:n_check], case["z"][:n_check]
+    sub["runtime"] = endtime
+    t0 = time.perf_counter()
+    ref, err, _ = run_oracle(sub, nthreads=os.cpu_count() or 1)
+    oracle_s = time.perf_counter() - t0
+    assert err is None, f"oracle raised {err}"
+    ids = np.asarray(data["particle_id"])
+    lo = int(ids.min()) if len(ids) else 0
+    sel = np.flatnonzero((ids >= lo) & (ids < lo + n_check))
+    sel = sel[np.argsort(ids[sel], kind="stable")]  # host rows are in id order already; a shard's ids start at its offset
+    got = {k: np.asarray(v)[sel] for k, v in data.items()}
+    got["particle_id"] = got["particle_id"] - lo
+    rep = compare(got, ref, rtol=1e-12, check_state="all", label="headline subset vs oracle", skip=())
+    return {"passed": True, "n_check": int(n_check), "max_rel_diff": rep, "tolerance": "1e-12 relative on x, y, z; state, ei, t, ids exact",
+            "steps": int(round(endtime / case["dt"])), "oracle_s": oracle_s}
 
 
 def self_launch(n: int, argv):
@@ -356,6 +383,7 @@ def main():
     ap.add_argument("--particles", type=float, default=1e7, help="particles per GPU")
     ap.add_argument("--sort", type=int, default=1, help="cell-sort the device copy of the particles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", type=float, default=1e5, help="headline: particle ids re-run through the CPU oracle after the timed steps (0 = off)")
     ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="particles of the CPU-baseline sample (~10-20 s on the host cores)")
     ap.add_argument("--secondary", type=int, default=1,
                     help="N = 1 only: also run BASELINE configs 3 and 5 (C3 RK4_3D, C5 RK45 + M1) at full size, each with a subset "
@@ -415,7 +443,8 @@ def main():
     pset._data["particle_id"] += shard.start
     kern = pa.Kernel([pa.AdvectionRK4], pset)
     eng = fs._engine_or_create()
-    eng.ctx.set_option("clock_probe", 1)  # pk_exec_stats.sclk_mhz: the shader clock while an advection kernel runs (16 wavefronts on a second stream spin 1 ms beside it)
+    # (the shader-clock probe -- 16 wavefronts on a second stream spinning 1 ms beside an advection kernel, pk_exec_stats.sclk_mhz -- runs on
+    # ONE extra, untimed repetition behind the timed ones: nothing spins beside a timed launch)
     dt = case["dt"]
     pset._data["dt"][:] = dt
     eng.bind_particles(pset._data)
@@ -471,8 +500,19 @@ def main():
         rep_el.append(time.perf_counter() - t0)
         rep_kms.append(st["kernel_ms"])
         rep_steps.append(float(st["steps"]))
-        if st.get("sclk_mhz"):
-            rep_sclk.append(float(st["sclk_mhz"]))
+    # one more repetition of the same launch, untimed, with the clock probe spinning beside it
+    probe_kms = None
+    try:
+        eng.ctx.set_option("clock_probe", 1)
+        eng.ctx.check(eng.lib.pk_particles_restore(eng.ctx.handle), "pk_particles_restore")
+        sync()
+        st_p = eng.execute(kern.kernel_ids, endtime=(W + K) * dt, dt0=dt, sort_by_cell=0, t_start=W * dt)
+        sync()
+        if st_p.get("sclk_mhz"):
+            rep_sclk.append(float(st_p["sclk_mhz"]))
+        probe_kms = float(st_p["kernel_ms"])
+    finally:
+        eng.ctx.set_option("clock_probe", 0)
     # the write-out exchange (not a step), straight from the device columns: the all-gather of the to-write columns that the north star
     # names, and the gather-to-rank-0 that ParticleFile.write uses (parcels_amd/distributed.py) -- both timed, neither in `value`
     t_ag = t_g0 = 0.0
@@ -547,6 +587,15 @@ def main():
     eng.d2h()
     t_d2h = time.perf_counter() - t_d2h
     ok = bool(np.all(pset._data["state"] == pa.StatusCode.EndofLoop))
+    # TEST INFRASTRUCTURE inside the measurement script (like `secondary[*].check`): the first ids of the timed run, re-run ALONE through the
+    # CPU oracle over the same W + K steps -- particles are independent, so the subset must reproduce: state, ei, t, ids exactly, positions to
+    # 1e-12 relative.  After the timed region; never part of `value`.
+    headline_check = None
+    if rank == 0 and args.check:
+        try:
+            headline_check = check_headline(case, pset._data, int(args.check), (W + K) * dt)
+        except AssertionError as e:
+            headline_check = {"passed": False, "error": str(e)[:2000]}
     if rank == 0:
         value = total_steps / el
         kernel_s = float(kms.item()) * 1e-3
@@ -559,12 +608,18 @@ def main():
         # fp64-rate VALU issue, its gathers are served by L2 / Infinity Cache).  `valu_busy_frac` (rounds 1-4 quoted it as `frac`) is the share
         # of SIMD cycles with a VALU instruction in flight -- utilisation, not a roof: moves, selects and address arithmetic count in it.
         roof = {"bound": "valu_fp64", "achieved": algo_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": algo_tflops / FP64_VECTOR_PEAK_TFLOPS,
+                # what `frac` is, spelled out so that trend lines across rounds compare like with like: rounds 1-4 printed the
+                # VALU-busy share there (now `valu_busy_frac`), rounds 5-6 ALGORITHMIC flops over the fp64 vector peak (= `algorithmic_frac`);
+                # the flops this binary really executes are `frac_executed_fp64` (PMC instruction count x static fp64 mix, below)
+                "frac_definition": "algorithmic fp64 flops (143.46 per velocity evaluation, an FMA = 2) / kernel time / 78.6 TFLOP/s",
+                "algorithmic_frac": algo_tflops / FP64_VECTOR_PEAK_TFLOPS,
                 "traffic": None, "algorithmic_fp64_flops_per_evaluation": ALGO_FLOPS_PER_EVAL_C2,
                 "frac_no_fma_peak": algo_tflops / (FP64_VECTOR_PEAK_TFLOPS / 2) * (121.59 / ALGO_FLOPS_PER_EVAL_C2),  # one op per lane and slot: NumPy never fuses (-ffp-contract=off)
                 "kernel": "pk::advect_fast_kernel<double, 0, false> (csrc/pk_kernels.h, pk_fast_agrid.h)", "kernel_ms_per_launch": float(kms.item()),
                 # shader clock DURING the timed launches (a cycle-counter / 100 MHz-counter probe spinning beside each kernel for 1 ms; median over
                 # the first millisecond of it): reconciles this line with a trace taken at another clock
-                "sclk_mhz": (rep_sclk[med] if len(rep_sclk) == reps else None), "sclk_mhz_reps": rep_sclk,  # (of the median repetition; all of them beside it)
+                "sclk_mhz": (rep_sclk[0] if rep_sclk else None),  # (of the untimed probe repetition that follows the timed ones; its kernel ms beside it)
+                "sclk_probe_rep_kernel_ms": probe_kms,
                 "hbm": None,
                 "algorithmic": {"note": "SURVEY 8(d) byte model; these bytes are served by L2 / Infinity Cache, this is NOT an HBM fraction",
                                 "bytes_per_particle_step": ALGO_BYTES_PER_STEP_C2_RK4, "bytes_per_launch": ALGO_BYTES_PER_STEP_C2_RK4 * per_gpu_steps,
@@ -624,6 +679,7 @@ def main():
                        "particles_per_gpu": npart, "particle_dtype": "f64", "cell_sorted": bool(args.sort),
                        "parallelism": f"one id space of {world * npart} particles sharded by id x{world}, fields replicated",
                        "all_states_endofloop": ok, **({"rehearsal_shared_gpu_gloo": True} if rehearsal else {})},
+            "check": headline_check,
             "roofline": roof,
             # boundary costs outside the timed steps (rank 0): host<->device copies of the particle columns, the one-off cell sort
             "host_boundary": {"h2d_ms": t_h2d * 1e3, "d2h_ms": t_d2h * 1e3, "cell_sort_ms": sort_ms,

@@ -122,6 +122,7 @@ struct pk_ctx {
     int fl_twe_n = 0;                           // listed keys of the launch in flight
     std::vector<int64_t> rerun_keys;          // the keys of the last launch (pk_execute_rerun repeats it with them)
     unsigned long long* h_summary = nullptr;  // pinned
+    unsigned long long* d_tstats = nullptr;   // pk_particles_t_stats: {ordered min, ordered max, NaN count} (its own 24 bytes: not the clock-probe buffer)
     unsigned long long* d_clk = nullptr;      // clock probes around the advection kernel: [before | after][XCD 0..7]{shader-clock counter, 100 MHz counter}
     unsigned long long* h_clk = nullptr;      // pinned
     int sort_horizontal_major = -1;  // tuning knobs (environment: PK_SORT_HORIZONTAL = 0/1 forces, PK_NO_SPECIAL, PK_NO_CELL_CACHE)
@@ -666,6 +667,7 @@ int32_t pk_init(int32_t device, pk_ctx** out) {
     PK_HIP(ctx, hipHostMalloc((void**)&ctx->h_counters, sizeof(DCounters), hipHostMallocDefault));
     PK_HIP(ctx, hipHostMalloc((void**)&ctx->h_summary, sizeof(unsigned long long) * (PK_NUM_STATE_CODES + 2), hipHostMallocDefault));
     PK_HIP(ctx, hipMalloc((void**)&ctx->d_clk, sizeof(unsigned long long) * 32));
+    PK_HIP(ctx, hipMalloc((void**)&ctx->d_tstats, sizeof(unsigned long long) * 3));
     PK_HIP(ctx, hipHostMalloc((void**)&ctx->h_clk, sizeof(unsigned long long) * 32, hipHostMallocDefault));
     return 0;
 }
@@ -769,6 +771,7 @@ int32_t pk_destroy(pk_ctx* ctx) {
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->h_summary) (void)hipHostFree(ctx->h_summary);
     if (ctx->d_clk) (void)hipFree(ctx->d_clk);
+    if (ctx->d_tstats) (void)hipFree(ctx->d_tstats);
     if (ctx->h_clk) (void)hipHostFree(ctx->h_clk);
     for (int k = 0; k < PK_STAGE_BUFFERS; k++) {
         if (ctx->stage[k]) (void)hipHostFree(ctx->stage[k]);
@@ -1549,12 +1552,12 @@ int32_t pk_particles_t_stats(pk_ctx* ctx, double* t_min, double* t_max, int64_t*
     *n_nan = 0;
     if (n == 0) return 0;
     const unsigned long long init[3] = {~0ull, 0ull, 0ull};
-    PK_HIP(ctx, hipMemcpyAsync(ctx->d_clk, init, sizeof(init), hipMemcpyHostToDevice, ctx->compute));  // (the clock-probe buffer is idle between launches)
+    PK_HIP(ctx, hipMemcpyAsync(ctx->d_tstats, init, sizeof(init), hipMemcpyHostToDevice, ctx->compute));
     const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
-    hipLaunchKernelGGL(t_stats_kernel, dim3(grid), dim3(256), 0, ctx->compute, ctx->dev.t, n, ctx->d_clk);
+    hipLaunchKernelGGL(t_stats_kernel, dim3(grid), dim3(256), 0, ctx->compute, ctx->dev.t, n, ctx->d_tstats);
     PK_HIP(ctx, hipGetLastError());
     unsigned long long got[3];
-    PK_HIP(ctx, hipMemcpyAsync(got, ctx->d_clk, sizeof(got), hipMemcpyDeviceToHost, ctx->compute));
+    PK_HIP(ctx, hipMemcpyAsync(got, ctx->d_tstats, sizeof(got), hipMemcpyDeviceToHost, ctx->compute));
     PK_HIP(ctx, hipStreamSynchronize(ctx->compute));
     auto unmap = [](unsigned long long b) {
         b = (b & 0x8000000000000000ull) ? (b & 0x7fffffffffffffffull) : ~b;
@@ -2253,6 +2256,7 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
     if (ctx->in_flight) return ctx->fail("pk_execute_begin: a launch is already in flight (call pk_execute_end)");
     if (prm->nk < 1 || prm->nk > PK_MAX_KERNELS) return ctx->fail("params.nk out of range");
     PK_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->fl_clock_probe = false;  // only the branch that launches a probe sets it: no launch path reports the clock of an older launch
     KArgs a;
     size_t lds_bytes = 0;
     int use_lds = 0;
@@ -2463,6 +2467,28 @@ int32_t pk_execute_end(pk_ctx* ctx, pk_exec_stats* stats) {
     ctx->in_flight = false;
     PK_HIP(ctx, hipStreamSynchronize(ctx->compute));
     if (ctx->fl_clock_probe && ctx->probe) PK_HIP(ctx, hipStreamSynchronize(ctx->probe));
+    {
+        // (whether or not the caller wants statistics -- ADVICE r5: pk_execute_twe_report after pk_execute_end(ctx, NULL) returned the keys of
+        // an older launch)
+        const DCounters& hc = *ctx->h_counters;
+        // the cold path of the call-wide time error: every unlisted failing sample the general programs reported, and which listed samples a lane
+        // justified (pk_execute_twe_report hands them out) -- copied only when there is something to report
+        ctx->twe_found_host.clear();
+        ctx->twe_hit_host.assign((size_t)ctx->fl_twe_n, 0);
+        ctx->twe_overflow_host = hc.twe_overflow != 0;
+        if (ctx->fl_launches && hc.twe_key != ~0ull) {
+            std::vector<unsigned long long> slots(TWE_FOUND_SLOTS);
+            PK_HIP(ctx, hipMemcpy(slots.data(), ctx->d_twe_found, sizeof(unsigned long long) * TWE_FOUND_SLOTS, hipMemcpyDeviceToHost));
+            for (unsigned long long k : slots)
+                if (k) ctx->twe_found_host.push_back((int64_t)k);
+            std::sort(ctx->twe_found_host.begin(), ctx->twe_found_host.end());
+        }
+        if (ctx->fl_launches && ctx->fl_twe_n > 0) {
+            std::vector<unsigned int> hit((size_t)ctx->fl_twe_n);
+            PK_HIP(ctx, hipMemcpy(hit.data(), ctx->d_twe_hit, sizeof(unsigned int) * ctx->fl_twe_n, hipMemcpyDeviceToHost));
+            for (int k = 0; k < ctx->fl_twe_n; k++) ctx->twe_hit_host[k] = hit[k] ? 1 : 0;
+        }
+    }
     if (stats) {
         memset(stats, 0, sizeof(*stats));
         const DCounters& hc = *ctx->h_counters;
@@ -2490,23 +2516,6 @@ int32_t pk_execute_end(pk_ctx* ctx, pk_exec_stats* stats) {
         stats->program = ctx->fl_launches ? ctx->fl_program : 0;
         stats->first_error_iter = (ctx->fl_launches && hc.err_iter != 0xFFFFFFFFu) ? (int64_t)hc.err_iter : 0;
         stats->first_time_error_key = (ctx->fl_launches && hc.twe_key != ~0ull) ? (int64_t)hc.twe_key : 0;
-        // the cold path of the call-wide time error: every unlisted failing sample the general programs reported, and which listed samples a lane
-        // justified (pk_execute_twe_report hands them out) -- copied only when there is something to report
-        ctx->twe_found_host.clear();
-        ctx->twe_hit_host.assign((size_t)ctx->fl_twe_n, 0);
-        ctx->twe_overflow_host = hc.twe_overflow != 0;
-        if (ctx->fl_launches && hc.twe_key != ~0ull) {
-            std::vector<unsigned long long> slots(TWE_FOUND_SLOTS);
-            PK_HIP(ctx, hipMemcpy(slots.data(), ctx->d_twe_found, sizeof(unsigned long long) * TWE_FOUND_SLOTS, hipMemcpyDeviceToHost));
-            for (unsigned long long k : slots)
-                if (k) ctx->twe_found_host.push_back((int64_t)k);
-            std::sort(ctx->twe_found_host.begin(), ctx->twe_found_host.end());
-        }
-        if (ctx->fl_launches && ctx->fl_twe_n > 0) {
-            std::vector<unsigned int> hit((size_t)ctx->fl_twe_n);
-            PK_HIP(ctx, hipMemcpy(hit.data(), ctx->d_twe_hit, sizeof(unsigned int) * ctx->fl_twe_n, hipMemcpyDeviceToHost));
-            for (int k = 0; k < ctx->fl_twe_n; k++) ctx->twe_hit_host[k] = hit[k] ? 1 : 0;
-        }
         // shader clock beside the advection kernel: cycles per 100 MHz tick of every probe wavefront (the median of the 16)
         double sclk = 0.0;
         int nx = 0;

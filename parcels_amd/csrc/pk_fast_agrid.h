@@ -27,51 +27,48 @@ struct FastTabs {  // LDS-resident {a, 1/width} tables of the main grid and the 
     const pk_tab2* lat;
     const pk_tab2* lon;
     pk_tab2* blk;  // this lane's corner-block cache (FCtx::bei): 4 x 16 bytes at stride FAST_WG, NULL = none
+    uint32_t fl;   // FA_* bits of the wave-uniform yes / no questions of one evaluation (fast_flags)
 };
+// The wave-uniform booleans of an evaluation as bits of ONE scalar register.  Kept as separate loop-invariant i1 values the compiler
+// holds each of them as a 64-bit lane mask (`s_cselect_b64 -1, 0`): two SGPRs per question, 46 SGPRs spilled to VGPR lanes in round 5's
+// kernel and a `v_readlane_b32` -- a VALU instruction -- for every use inside the stage loop.  eval_uvw_fast re-reads the word through
+// an opaque scalar at its top, so every test is an `s_bitcmp` + `s_cbranch_scc` where it is used.
+enum : uint32_t {
+    FA_TI = 1u, FA_Z = 2u, FA_Y = 4u, FA_X = 8u, FA_SPH = 16u, FA_RING = 32u, FA_BLK = 64u,
+    FA_NT2 = 128u, FA_NZ2 = 256u, FA_NY2 = 512u, FA_NX2 = 1024u,  // the axis has at least two nodes (index_search.py:45-46)
+    FA_WIN = 2048u, FA_FWD = 4096u, FA_MAXIT = 8192u               // step loop: some ring streams; dt0 > 0; an iteration limit is set
+};
+PK_DEV uint32_t fast_flags(const FastA& F) {
+    return (F.has_ti ? FA_TI : 0u) | (F.has_z ? FA_Z : 0u) | (F.has_y ? FA_Y : 0u) | (F.has_x ? FA_X : 0u) | (F.spherical ? FA_SPH : 0u) |
+           (F.nslots < F.nt ? FA_RING : 0u) | (F.lds_blk != 0 ? FA_BLK : 0u) | (F.nt >= 2 ? FA_NT2 : 0u) | (F.gnz >= 2 ? FA_NZ2 : 0u) |
+           (F.gny >= 2 ? FA_NY2 : 0u) | (F.gnx >= 2 ? FA_NX2 : 0u);
+}
 constexpr int FAST_WG = 256;                          // lanes per workgroup of advect_fast_kernel
 constexpr int FAST_BLK_BYTES = FAST_WG * 8 * 8;       // LDS of the corner-block cache per workgroup (8 doubles per lane)
 
-// clip(searchsorted(arr, x, "left") - 1, 0, n-2) over the interleaved table (same walk + bisect as cell_index)
+// clip(searchsorted(arr, x, "left") - 1, 0, n-2) over the interleaved table.  Cold (a lane that moved two cells or more, or holds a
+// NaN): one bisection loop -- the unrolled three-step walk of rounds 1-5 found the same index and cost the hot path seven nesting
+// levels of saved exec masks (14 SGPRs) at each of its four inlined copies.
 PK_DEV int cell_index_tab(const pk_tab2* tab, int n, double x, int i) {
+    (void)i;
+    asm volatile("" : "+s"(n));  // (wave-uniform; opaque so that `0 < n` of the loop entry is not hoisted into a saved lane mask)
     if (x != x) return n - 2;
-    if (tab[i].x < x) {
-        int k = 0;
-        while (i < n - 2 && tab[i + 1].x < x) {
-            ++i;
-            if (++k == 3) {
-                int lo = i + 1, hi = n;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (tab[mid].x < x) lo = mid + 1; else hi = mid;
-                }
-                i = clampi(lo - 1, 0, n - 2);
-                break;
-            }
-        }
-    } else {
-        int k = 0;
-        while (i > 0 && !(tab[i].x < x)) {
-            --i;
-            if (++k == 3) {
-                int lo = 0, hi = i + 1;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (tab[mid].x < x) lo = mid + 1; else hi = mid;
-                }
-                i = clampi(lo - 1, 0, n - 2);
-                break;
-            }
-        }
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (tab[mid].x < x) lo = mid + 1; else hi = mid;
     }
-    return i;
+    return clampi(lo - 1, 0, n - 2);
 }
 
 // _search_1d_array (index_search.py:20-62) for a float64 coordinate: the hinted cell is right for all but the lanes that just
 // crossed a cell edge.  `cell` (in / out): a valid cell index 0..n-2, the hint on entry and the cell found on exit; idx: that
 // cell or the out-of-bounds code.  The cell test is NaN-proof as written: a NaN fails it unless the hint already is the
 // last cell (NumPy sorts NaN last), and cell_index_tab answers n-2.
-PK_DEV void fast_search(const pk_tab2* tab, int n, double first, double last, double x, int& cell, int& idx, double& bc) {
-    if (n < 2) {  // :45-46
+// FLAGGED: the caller answers "n >= 2" itself (`two`, a bit of FastTabs::fl tested where it is used).
+template <bool FLAGGED = false>
+PK_DEV void fast_search(const pk_tab2* tab, int n, double first, double last, double x, int& cell, int& idx, double& bc, bool two = true) {
+    if (FLAGGED ? !two : n < 2) {  // :45-46
         idx = 0;
         bc = 0.0;
         return;
@@ -87,6 +84,7 @@ PK_DEV void fast_search(const pk_tab2* tab, int n, double first, double last, do
         int j = i + (hi_ok ? 0 : 1) - (lo_ok ? 0 : 1);
         pk_tab2 e2 = tab[j];
         double b1 = tab[j + 1].x;
+        asm volatile("" : "+v"(b1));  // both reads in flight together (not the second one behind the first compare's short circuit)
         if (__builtin_expect(!((e2.x < x || j == 0) && (x <= b1 || j == n - 2)), 0)) {
             j = cell_index_tab(tab, n, x, j);
             e2 = tab[j];
@@ -98,9 +96,58 @@ PK_DEV void fast_search(const pk_tab2* tab, int n, double first, double last, do
     }
     bc = div_by_recip(x - e.x, a1 - e.x, e.y);
     cell = i;
-    if (x < first) i = LEFT_OUT_OF_BOUNDS;
-    if (x > last) i = RIGHT_OUT_OF_BOUNDS;
+    // :55-58.  A point left of the first node is in cell 0, one right of the last node in cell n-2 (the clip of :47), so only lanes in
+    // an edge cell pay the two fp64 compares (a divergent block most wavefronts skip: the particles live in the interior)
+    if (__builtin_expect(i == 0 || i == n - 2, 0)) {
+        if (x < first) i = LEFT_OUT_OF_BOUNDS;
+        if (x > last) i = RIGHT_OUT_OF_BOUNDS;
+    }
     idx = i;
+}
+
+// Two axes at once (lat and lon of one evaluation; both with n >= 2): the same answers as two fast_search calls, but the LDS round trips of
+// the two axes overlap -- all four hint-cell reads are in flight together, and so are the four reads of the neighbour probes when some lane
+// crossed an edge on either axis (which happens in nearly every wave-evaluation: round 5's kernel walked through up to six dependent
+// ~100-cycle LDS round trips per evaluation here; the PMC pass showed 0.36 of its wave cycles in s_waitcnt and no gain from fewer VALU
+// instructions alone, profiles/r06a_c2_flags_pmc.md).
+PK_DEV void fast_search2(const pk_tab2* taba, int na, double firsta, double lasta, double xa, int& cella, int& idxa, double& bca,
+                         const pk_tab2* tabb, int nb, double firstb, double lastb, double xb, int& cellb, int& idxb, double& bcb) {
+    int ia = cella, ib = cellb;
+    pk_tab2 ea = taba[ia], eb = tabb[ib];
+    double a1a = taba[ia + 1].x, a1b = tabb[ib + 1].x;
+    const bool lo_a = ea.x < xa || ia == 0, hi_a = xa <= a1a || ia == na - 2;
+    const bool lo_b = eb.x < xb || ib == 0, hi_b = xb <= a1b || ib == nb - 2;
+    if (!(lo_a && hi_a && lo_b && hi_b)) {
+        // (an axis that passed keeps its cell: j == i, and the probe below re-reads the same entries)
+        int ja = ia + (hi_a ? 0 : 1) - (lo_a ? 0 : 1), jb = ib + (hi_b ? 0 : 1) - (lo_b ? 0 : 1);
+        pk_tab2 e2a = taba[ja], e2b = tabb[jb];
+        double b1a = taba[ja + 1].x, b1b = tabb[jb + 1].x;
+        asm volatile("" : "+v"(b1a), "+v"(b1b));  // all four reads issued before the first compare (not sunk behind its short circuit)
+        if (__builtin_expect(!((e2a.x < xa || ja == 0) && (xa <= b1a || ja == na - 2)), 0)) {
+            ja = cell_index_tab(taba, na, xa, ja);
+            e2a = taba[ja];
+            b1a = taba[ja + 1].x;
+        }
+        if (__builtin_expect(!((e2b.x < xb || jb == 0) && (xb <= b1b || jb == nb - 2)), 0)) {
+            jb = cell_index_tab(tabb, nb, xb, jb);
+            e2b = tabb[jb];
+            b1b = tabb[jb + 1].x;
+        }
+        ia = ja; ea = e2a; a1a = b1a;
+        ib = jb; eb = e2b; a1b = b1b;
+    }
+    bca = div_by_recip(xa - ea.x, a1a - ea.x, ea.y);
+    bcb = div_by_recip(xb - eb.x, a1b - eb.x, eb.y);
+    cella = ia;
+    cellb = ib;
+    if (__builtin_expect(ia == 0 || ia == na - 2 || ib == 0 || ib == nb - 2, 0)) {  // :55-58, see fast_search
+        if (xa < firsta) ia = LEFT_OUT_OF_BOUNDS;
+        if (xa > lasta) ia = RIGHT_OUT_OF_BOUNDS;
+        if (xb < firstb) ib = LEFT_OUT_OF_BOUNDS;
+        if (xb > lastb) ib = RIGHT_OUT_OF_BOUNDS;
+    }
+    idxa = ia;
+    idxb = ib;
 }
 
 // The two x-corners of one (level, z, y) row at byte offset `off` from a wave-uniform base: one wide load in saddr form.
@@ -268,10 +315,12 @@ template <class FT, bool PF, bool D3>
 PK_DEV void eval_uvw_fast(const KArgs& a, const FastTabs& T, FCtx& c, double t, double z, double y, double x, bool pos_f32, double& u,
                           double& v, double& w, unsigned it, int klo, int bmode = 0) {
     const FastA& F = a.fast;
+    uint32_t fl = T.fl;
+    asm volatile("" : "+s"(fl));  // opaque: every FA_* test below is a scalar bit test HERE, not a loop-invariant lane mask (FastTabs::fl)
     u = v = w = 0.0;
     int ti = 0;
     double tau = 0.0;
-    if (F.has_ti) {  // _search_time_index (index_search.py:65-91); (it, klo): the key of this sample (pk_device.h: twe_note -- a launch with LISTED
+    if (fl & FA_TI) {  // _search_time_index (index_search.py:65-91); (it, klo): the key of this sample (pk_device.h: twe_note -- a launch with LISTED
                      // samples runs the general program, pk_api.hip)
         if (__builtin_expect(!(0 <= t) || !(t <= F.tlen), 0)) {
             c.state = PK_ERROROUTSIDETIMEINTERVAL;
@@ -280,7 +329,7 @@ PK_DEV void eval_uvw_fast(const KArgs& a, const FastTabs& T, FCtx& c, double t, 
         }
         if (t != c.mt) {
             int idx;
-            fast_search(T.time, F.nt, F.t0, F.t1, t, c.ht, idx, c.mtau);  // level times start at 0 (host check): idx == c.ht
+            fast_search<true>(T.time, F.nt, F.t0, F.t1, t, c.ht, idx, c.mtau, (fl & FA_NT2) != 0);  // level times start at 0 (host check): idx == c.ht
             c.mt = t;
             c.bei = FAST_NO_BLOCK;
         }
@@ -289,17 +338,25 @@ PK_DEV void eval_uvw_fast(const KArgs& a, const FastTabs& T, FCtx& c, double t, 
     }
     int zi = 0, yi = 0, xi = 0;
     double zeta = 0.0, eta = 0.0, xsi = 0.0;
-    if (F.has_z) {
+    if (fl & FA_Z) {
         if (!(z == c.mz)) {
-            fast_search(T.depth, F.gnz, F.z0, F.z1, z, c.hz, c.zi, c.mzeta);
+            fast_search<true>(T.depth, F.gnz, F.z0, F.z1, z, c.hz, c.zi, c.mzeta, (fl & FA_NZ2) != 0);
             c.mz = z;
             c.bei = FAST_NO_BLOCK;
         }
         zi = c.zi;
         zeta = c.mzeta;
     }
-    if (F.has_y) fast_search(T.lat, F.gny, F.y0, F.y1, y, c.hy, yi, eta);
-    if (F.has_x) fast_search(T.lon, F.gnx, F.x0, F.x1, x, c.hx, xi, xsi);
+#ifndef PK_FAST_SEARCH2
+#define PK_FAST_SEARCH2 1
+#endif
+    constexpr uint32_t YX2 = FA_Y | FA_X | FA_NY2 | FA_NX2;
+    if (PK_FAST_SEARCH2 && (fl & YX2) == YX2) {
+        fast_search2(T.lat, F.gny, F.y0, F.y1, y, c.hy, yi, eta, T.lon, F.gnx, F.x0, F.x1, x, c.hx, xi, xsi);
+    } else {
+        if (fl & FA_Y) fast_search<true>(T.lat, F.gny, F.y0, F.y1, y, c.hy, yi, eta, (fl & FA_NY2) != 0);
+        if (fl & FA_X) fast_search<true>(T.lon, F.gnx, F.x0, F.x1, x, c.hx, xi, xsi, (fl & FA_NX2) != 0);
+    }
     // ravel_index (basegrid.py:83-152): the low 32 bits of the int64 sum are the wrapped 32-bit sum
     c.ei = (int32_t)((uint32_t)xi * F.ex + (uint32_t)yi * F.ey + (uint32_t)zi * F.ez);
     if (__builtin_expect((xi | yi | zi) < 0, 0)) {  // some index carries an out-of-bounds code (-1 right, -2 left)
@@ -318,7 +375,7 @@ PK_DEV void eval_uvw_fast(const KArgs& a, const FastTabs& T, FCtx& c, double t, 
     const double omt = 1 - tau, omz = 1 - zeta, omx = 1 - xsi, ome = 1 - eta;
     const double w00 = omx * ome, w01 = xsi * ome, w10 = omx * eta, w11 = xsi * eta;
     double uu = 0.0, vv = 0.0, ww = 0.0;
-    const bool bc = !D3 && PK_FAST_BLOCK_CACHE && F.lds_blk != 0;
+    const bool bc = !D3 && PK_FAST_BLOCK_CACHE && (fl & FA_BLK) != 0;
     // (in-bounds indices ravel to a non-negative `ei` that names the cell; the memo updates above already dropped a block of another (t, z))
     bool reuse = false;
     if (bc && (bmode & 1)) reuse = __builtin_amdgcn_ballot_w64(c.ei != c.bei) == 0;  // every active lane: same cell, same (t, z)
@@ -335,7 +392,7 @@ PK_DEV void eval_uvw_fast(const KArgs& a, const FastTabs& T, FCtx& c, double t, 
             const int uk = uniform_i32(key);
             const int uti = uk >> 2;
             int s0 = uti, s1 = uti + 1;  // has_ti: 0 <= ti <= nt-2; otherwise ti == 0 and the second level is never read
-            if (F.nslots < F.nt) {       // ring of time levels: level L lives in slot L % nslots
+            if (fl & FA_RING) {          // ring of time levels: level L lives in slot L % nslots
                 s0 = (int)((uint32_t)s0 % (uint32_t)F.nslots);
                 s1 = (int)((uint32_t)s1 % (uint32_t)F.nslots);
             }
@@ -352,14 +409,15 @@ PK_DEV void eval_uvw_fast(const KArgs& a, const FastTabs& T, FCtx& c, double t, 
         }
         if (keep) c.bei = c.ei;
     }
-    if (F.spherical) {  // _xinterpolators.py:183-187
+    if (fl & FA_SPH) {  // _xinterpolators.py:183-187
         double conv;
         if (PF && pos_f32) conv = (double)((float)F.deg2m * cosf((float)y * DEG2RADF));
         else conv = F.deg2m * cos_lat(y * DEG2RAD);
         uu /= conv;
         vv = div_by_recip(vv, F.deg2m, F.inv_deg2m);
     }
-    if (__builtin_expect(uu != uu || vv != vv || ww != ww, 0)) {  // field.py:373-378
+    // field.py:373-378 (one unordered compare answers "uu or vv is NaN")
+    if (__builtin_expect(__builtin_isunordered(uu, vv) || (D3 && ww != ww), 0)) {
         if (c.state < PK_ERRORINTERPOLATION) c.state = PK_ERRORINTERPOLATION;
     }
     u = uu;

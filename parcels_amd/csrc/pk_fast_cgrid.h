@@ -39,8 +39,18 @@ constexpr int CT2_STRIDE = 32;
 // table (rows 16..23, one more cache line of a record whose first lines the search just read).  For AdvectionDiffusionM1's program, where
 // six of the seven samples of a step are scalar samples that never look at them: 16 VGPRs less to carry around every one of them, and a
 // cell change fetches 128 B of the record instead of 192.
-constexpr int CG_FV_REGS = 1, CG_PXY_REGS = 2, CG_PXY_GLOBAL = 4;
-constexpr int fc_rec_rows(int cm) { return (cm & (CG_PXY_REGS | CG_PXY_GLOBAL)) ? 15 : 23; }  // LDS rows of a lane's slot: record rows 0..14 (then 16..23)
+// Bit 3 (CG_DMA, round 6): a cell change moves the record and -- for float32 fields -- the staggered field values from memory STRAIGHT
+// into the lane's LDS slot (`global_load_lds_dwordx4` / `_dword`: the LDS-DMA path of gfx950) instead of through registers.  Rounds 2-5
+// staged the 24 doubles of a record in 48 VGPRs (+ 12 field values) between the loads and the 23 + 12 `ds_write`s -- the register peak of
+// the whole evaluation, at the 168-VGPR ceiling of 3 waves per SIMD: 160 B / lane of scratch in the RK45 kernel, whose spill write-back
+// was 12 % of its HBM traffic.  The DMA lands lane L's 16 bytes of pair k at `base + k * 1024 + L * 16`, so the slot is laid out in PAIRS
+// of rows, [pair][lane][2] (the test reads them back with 16-byte LDS reads), and row 15 -- the quantised box -- lives there too; the
+// field values keep their [k][lane] layout (4-byte DMA).  Same values from the same addresses: same bits.  Lanes outside the exec mask
+// neither load nor write, so the slots of the lanes that stayed in their cell are untouched.
+constexpr int CG_FV_REGS = 1, CG_PXY_REGS = 2, CG_PXY_GLOBAL = 4, CG_DMA = 8;
+constexpr int fc_rec_rows(int cm) {  // LDS rows of a lane's slot: record rows 0..14 (then 16..23); CG_DMA: whole pairs, rows 0..15 (then 16..23)
+    return (cm & CG_DMA) ? ((cm & (CG_PXY_REGS | CG_PXY_GLOBAL)) ? 16 : 24) : ((cm & (CG_PXY_REGS | CG_PXY_GLOBAL)) ? 15 : 23);
+}
 constexpr int fc_fv_lds(int cm) { return (cm & CG_FV_REGS) ? 0 : 12; }       // field values of a lane kept in LDS
 constexpr int FC_LANES = 64;     // one-wavefront workgroups (see CC_LANES)
 #ifndef PK_CG_HOPS
@@ -55,9 +65,23 @@ constexpr int FC_LANES = 64;     // one-wavefront workgroups (see CC_LANES)
 struct CgLds {
     const pk_tab2* time;   // {a, 1/width} tables
     const pk_tab2* depth;
-    double* rec;           // [fc_rec_rows(CM)][64] + lane
+    double* rec;           // [fc_rec_rows(CM)][64] + lane      (CG_DMA: [pairs][64][2] + 2 * lane)
     void* fv;              // [fc_fv_lds(CM)][64] of the field dtype + lane
+    char* rec_w;           // wave-uniform bases of the same two regions: where the LDS-DMA of CG_DMA lands (it adds lane * size itself)
+    char* fv_w;
 };
+// row k (compile-time) of the record in the lane's slot
+template <int CM>
+PK_DEV double cg_rec_row(const double* rec, int k) {
+    if constexpr ((CM & CG_DMA) != 0) return rec[(k >> 1) * (2 * 64) + (k & 1)];
+    else return rec[k * 64];
+}
+PK_DEV void cg_dma16(const void* g, char* lds_w) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_w, 16, 0, 0);
+}
+PK_DEV void cg_dma4(const void* g, char* lds_w) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_w, 4, 0, 0);
+}
 // per-particle evaluation context of the fast C-grid kernels (FT: dtype of the velocity fields)
 template <class FT, int CM>
 struct CCtxT {
@@ -96,6 +120,29 @@ PK_DEV void cctx_init(CCtxT<FT, CM>& c, int state, int32_t ei, int gy, int gx) {
     for (int k = 0; k < ((CM & CG_PXY_REGS) ? 8 : 1); k++) c.pxy[k] = 0.0;
 }
 
+// Byte offsets (b0, b1) of cell element `e` inside the ring slots of levels ti and ti+1 (slot_off of pk_device.h).  A ring needs
+// `level % nslots`: the level is wave-uniform unless particles of one wavefront sit on different levels, so the modulo runs on the
+// scalar unit, once per distinct level of the wavefront (readfirstlane waterfall); every lane keeps the offsets of ITS level.
+PK_DEV void cg_level_offsets(const FastC& F, uint32_t e, int ti, int64_t& b0, int64_t& b1) {
+    const int64_t vb = (int64_t)((uint64_t)e * (uint64_t)(uint32_t)F.cb);
+    int64_t o0 = 0, o1 = 0;
+    for (bool done = false; !done;) {
+        const int uti = uniform_i32(ti);
+        int s0 = uti, s1 = mini(uti + 1, F.nt - 1);
+        if (F.nslots < F.nt) {  // level L lives in slot L % nslots
+            s0 = (int)((uint32_t)s0 % (uint32_t)F.nslots);
+            s1 = (int)((uint32_t)s1 % (uint32_t)F.nslots);
+        }
+        const int64_t u0 = (int64_t)s0 * F.lvl_b, u1 = (int64_t)s1 * F.lvl_b;  // derived from the uniform level BEFORE the lane test
+        if (ti == uti) {
+            o0 = u0;
+            o1 = u1;
+            done = true;
+        }
+    }
+    b0 = vb + o0;
+    b1 = vb + o1;
+}
 // Fetch the ct2 record of `cell` into the lane's LDS slot -- and, WITH_F, the staggered field values of (zi, yi, xi) at level ti
 // (and ti+1 if lenT) in the same memory round trip.  Returns the packed quantised box of the cell (row 15).
 template <class FT, bool D3>
@@ -142,26 +189,8 @@ PK_DEV void cg_issue_fields(const FastC& F, int zi, int yi, int xi, int ti, bool
             return;
         }
     }
-    const int64_t vb = (int64_t)((uint64_t)e * (uint64_t)(uint32_t)F.cb);
-    // byte offsets of the slots of levels ti and ti+1 (slot_off of pk_device.h).  A ring needs `level % nslots`: the level is
-    // wave-uniform unless particles of one wavefront sit on different levels, so the modulo runs on the scalar unit, once per
-    // distinct level of the wavefront (readfirstlane waterfall); every lane keeps the offsets of ITS level.
-    int64_t o0 = 0, o1 = 0;
-    for (bool done = false; !done;) {
-        const int uti = uniform_i32(ti);
-        int s0 = uti, s1 = mini(uti + 1, F.nt - 1);
-        if (F.nslots < F.nt) {  // level L lives in slot L % nslots
-            s0 = (int)((uint32_t)s0 % (uint32_t)F.nslots);
-            s1 = (int)((uint32_t)s1 % (uint32_t)F.nslots);
-        }
-        const int64_t u0 = (int64_t)s0 * F.lvl_b, u1 = (int64_t)s1 * F.lvl_b;  // derived from the uniform level BEFORE the lane test
-        if (ti == uti) {
-            o0 = u0;
-            o1 = u1;
-            done = true;
-        }
-    }
-    const int64_t b0 = vb + o0;
+    int64_t b0, b1;
+    cg_level_offsets(F, e, ti, b0, b1);
     raw[0] = *reinterpret_cast<const FT*>(F.U + F.dU0 + b0);
     raw[1] = *reinterpret_cast<const FT*>(F.U + F.dU1 + b0);
     raw[2] = *reinterpret_cast<const FT*>(F.V + F.dV0 + b0);
@@ -171,7 +200,6 @@ PK_DEV void cg_issue_fields(const FastC& F, int zi, int yi, int xi, int ti, bool
 #pragma unroll
     for (int k = 6; k < 12; k++) raw[k] = (FT)0;
     if (lenT) {  // per lane: a particle exactly on a time level reads that level only
-        const int64_t b1 = vb + o1;
         raw[6] = *reinterpret_cast<const FT*>(F.U + F.dU0 + b1);
         raw[7] = *reinterpret_cast<const FT*>(F.U + F.dU1 + b1);
         raw[8] = *reinterpret_cast<const FT*>(F.V + F.dV0 + b1);
@@ -179,6 +207,34 @@ PK_DEV void cg_issue_fields(const FastC& F, int zi, int yi, int xi, int ti, bool
         if (D3) {
             raw[10] = *reinterpret_cast<const FT*>(F.W + F.dW0 + b1);
             raw[11] = *reinterpret_cast<const FT*>(F.W + F.dW1 + b1);
+        }
+    }
+}
+// The same values by LDS-DMA (CG_DMA, 4-byte field dtypes): value k of lane L lands at fv_w + k * 256 + L * 4 -- the [k][lane] layout the
+// interpolation reads.  Slots the register path zero-fills (W in the 2-D kernels, level ti+1 of a sample ON a level) stay as they are:
+// the readers never use them (eval_uvw_cgrid reads 6..11 only if lenT, and W only if D3).
+template <class FT, bool D3>
+PK_DEV void cg_issue_fields_dma(const FastC& F, char* fv_w, int zi, int yi, int xi, int ti, bool lenT) {
+    static_assert(sizeof(FT) == 4, "LDS-DMA moves 4, 12 or 16 bytes per lane");
+    const uint32_t e = (uint32_t)zi * (uint32_t)F.st_z + (uint32_t)yi * (uint32_t)F.st_y + (uint32_t)xi;
+    int64_t b0, b1;
+    cg_level_offsets(F, e, ti, b0, b1);
+    cg_dma4(F.U + F.dU0 + b0, fv_w + 0 * 256);
+    cg_dma4(F.U + F.dU1 + b0, fv_w + 1 * 256);
+    cg_dma4(F.V + F.dV0 + b0, fv_w + 2 * 256);
+    cg_dma4(F.V + F.dV1 + b0, fv_w + 3 * 256);
+    if (D3) {
+        cg_dma4(F.W + F.dW0 + b0, fv_w + 4 * 256);
+        cg_dma4(F.W + F.dW1 + b0, fv_w + 5 * 256);
+    }
+    if (lenT) {
+        cg_dma4(F.U + F.dU0 + b1, fv_w + 6 * 256);
+        cg_dma4(F.U + F.dU1 + b1, fv_w + 7 * 256);
+        cg_dma4(F.V + F.dV0 + b1, fv_w + 8 * 256);
+        cg_dma4(F.V + F.dV1 + b1, fv_w + 9 * 256);
+        if (D3) {
+            cg_dma4(F.W + F.dW0 + b1, fv_w + 10 * 256);
+            cg_dma4(F.W + F.dW1 + b1, fv_w + 11 * 256);
         }
     }
 }
@@ -200,35 +256,75 @@ PK_DEV bool cg_fields_cached(const CCtxT<FT, CM>& c, int cell, int zi, int ti, b
     return c.fv_cell == cell && (c.fv_zt >> 1) == ((ti << 12) | zi) && (!lenT || (c.fv_zt & 1));
 }
 
+// the staggered field values of (zi, yi, xi) at level ti (and ti+1 if lenT) into the lane's cache, by whichever path the kernel uses;
+// WAIT: the caller reads them next (the DMA needs its own vmcnt wait -- nothing else orders an LDS read behind it)
+template <class FT, bool D3, int CM, bool WAIT>
+PK_DEV void cg_refresh_fields(const FastC& F, const CgLds& L, CCtxT<FT, CM>& c, int cell, int zi, int yi, int xi, int ti, bool lenT) {
+    if constexpr ((CM & CG_DMA) != 0 && !(CM & CG_FV_REGS) && sizeof(FT) == 4) {
+        if (D3 || !F.vp) {  // (F.vp: wave-uniform; the opt-in pair copies keep the register path)
+            cg_issue_fields_dma<FT, D3>(F, L.fv_w, zi, yi, xi, ti, lenT);
+            if (WAIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            c.fv_cell = cell;
+            c.fv_zt = (ti << 13) | (zi << 1) | (lenT ? 1 : 0);
+            return;
+        }
+    }
+    FT raw[12];
+    cg_issue_fields<FT, D3>(F, zi, yi, xi, ti, lenT, raw);
+    cg_store_fields<FT, CM>(c, L, cell, zi, ti, lenT, raw);
+}
+
 template <class FT, bool D3, bool WITH_F, int CM>
 PK_DEV double cg_fetch_cell(const FastC& F, const CgLds& L, CCtxT<FT, CM>& c, int cell, int yi, int xi, int zi, int ti, bool lenT) {
     const double* g = F.ct2 + (int64_t)cell * CT2_STRIDE;
-    constexpr int NR = (CM & CG_PXY_GLOBAL) ? 16 : 24;  // rows of the record a lane keeps
-    double r[NR];
+    if constexpr ((CM & CG_DMA) != 0) {
+        // record rows 0..15 (and 16..23 unless they live in registers / stay in the table) as 16-byte pairs straight into the slot
+        constexpr int NP = fc_rec_rows(CM) / 2;
 #pragma unroll
-    for (int k = 0; k < NR / 2; k++) ldpair(g + 2 * k, r[2 * k], r[2 * k + 1]);
-    FT raw[12];
-    const bool wantf = WITH_F && zi >= 0 && !cg_fields_cached(c, cell, zi, ti, lenT);
-    if (WITH_F) {
-        if (wantf) cg_issue_fields<FT, D3>(F, zi, yi, xi, ti, lenT, raw);
-    }
-    double* rec = L.rec;
+        for (int k = 0; k < 8; k++) cg_dma16(g + 2 * k, L.rec_w + k * 1024);
+        if constexpr (NP == 12) {
 #pragma unroll
-    for (int k = 0; k < 15; k++) rec[k * FC_LANES] = r[k];
-    if constexpr ((CM & CG_PXY_GLOBAL) != 0) {
-        // (read where they are used)
-    } else if constexpr ((CM & CG_PXY_REGS) != 0) {
+            for (int k = 8; k < 12; k++) cg_dma16(g + 2 * k, L.rec_w + k * 1024);
+        }
+        if constexpr ((CM & CG_PXY_REGS) != 0) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) c.pxy[k] = r[16 + k];
+            for (int k = 0; k < 4; k++) ldpair(g + 16 + 2 * k, c.pxy[2 * k], c.pxy[2 * k + 1]);
+        }
+        if (WITH_F) {
+            const bool wantf = zi >= 0 && !cg_fields_cached(c, cell, zi, ti, lenT);
+            if (wantf) cg_refresh_fields<FT, D3, CM, false>(F, L, c, cell, zi, yi, xi, ti, lenT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        c.rc_cell = cell;
+        return cg_rec_row<CM>(L.rec, 15);
     } else {
+        constexpr int NR = (CM & CG_PXY_GLOBAL) ? 16 : 24;  // rows of the record a lane keeps
+        double r[NR];
 #pragma unroll
-        for (int k = 0; k < 8; k++) rec[(15 + k) * FC_LANES] = r[16 + k];
+        for (int k = 0; k < NR / 2; k++) ldpair(g + 2 * k, r[2 * k], r[2 * k + 1]);
+        FT raw[12];
+        const bool wantf = WITH_F && zi >= 0 && !cg_fields_cached(c, cell, zi, ti, lenT);
+        if (WITH_F) {
+            if (wantf) cg_issue_fields<FT, D3>(F, zi, yi, xi, ti, lenT, raw);
+        }
+        double* rec = L.rec;
+#pragma unroll
+        for (int k = 0; k < 15; k++) rec[k * FC_LANES] = r[k];
+        if constexpr ((CM & CG_PXY_GLOBAL) != 0) {
+            // (read where they are used)
+        } else if constexpr ((CM & CG_PXY_REGS) != 0) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) c.pxy[k] = r[16 + k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) rec[(15 + k) * FC_LANES] = r[16 + k];
+        }
+        c.rc_cell = cell;
+        if (WITH_F) {
+            if (wantf) cg_store_fields<FT, CM>(c, L, cell, zi, ti, lenT, raw);
+        }
+        return r[15];
     }
-    c.rc_cell = cell;
-    if (WITH_F) {
-        if (wantf) cg_store_fields<FT, CM>(c, L, cell, zi, ti, lenT, raw);
-    }
-    return r[15];
 }
 
 template <class FT, int CM>
@@ -276,8 +372,9 @@ PK_DEV bool cg_point_in_cell_rows(const FastC& F, Row row, int cell, double qX, 
     eta = e;
     return (x >= 0) && (x <= 1) && (e >= 0) && (e <= 1);
 }
+template <int CM = 0>
 PK_DEV bool cg_point_in_cell(const FastC& F, const double* rec, int cell, double qX, double qY, double qZ, double& xsi, double& eta) {
-    return cg_point_in_cell_rows(F, [rec](int k) { return rec[k * FC_LANES]; }, cell, qX, qY, qZ, xsi, eta);
+    return cg_point_in_cell_rows(F, [rec](int k) { return cg_rec_row<CM>(rec, k); }, cell, qX, qY, qZ, xsi, eta);
 }
 
 // XLinear.interp (_xinterpolators.py:112-153) of scalar field `k` (FastC::kh) at a grid position: xlinear<FT> of pk_device.h for a
@@ -400,7 +497,7 @@ PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtxT<FT, CM>& c, dou
                 else cg_fetch_cell<FT, D3, true, CM>(F, L, c, cell, c.gy, c.gx, zi, ti, lenT);
             }
             double xs, et;
-            if (cg_point_in_cell(F, L.rec, cell, qX, qY, qZ, xs, et)) {
+            if (cg_point_in_cell<CM>(F, L.rec, cell, qX, qY, qZ, xs, et)) {
                 found = true;
                 yi = c.gy;
                 xi = c.gx;
@@ -422,7 +519,7 @@ PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtxT<FT, CM>& c, dou
                         const double boxd = scalar ? cg_fetch_cell<FT, D3, false, CM>(F, L, c, ncell, nj, ni, zi, ti, lenT) : cg_fetch_cell<FT, D3, true, CM>(F, L, c, ncell, nj, ni, zi, ti, lenT);
                         double xs2, et2;
                         const double m = 1e-9;
-                        if (cg_point_in_cell(F, L.rec, ncell, qX, qY, qZ, xs2, et2) && xs2 > m && xs2 < 1 - m && et2 > m && et2 < 1 - m) {
+                        if (cg_point_in_cell<CM>(F, L.rec, ncell, qX, qY, qZ, xs2, et2) && xs2 > m && xs2 < 1 - m && et2 > m && et2 < 1 - m) {
                             if (box_lists(kgrid(a, F.grid), (unsigned long long)__double_as_longlong(boxd), qX, qY, qZ, true)) {
                                 found = true;
                                 yi = nj;
@@ -477,9 +574,7 @@ PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtxT<FT, CM>& c, dou
     if (__builtin_expect(need_rec, 0)) {  // found by the table walk
         cg_fetch_cell<FT, D3, true, CM>(F, L, c, cell, yi, xi, zi, ti, lenT);
     } else if (need_f) {  // same cell, another depth or time level
-        FT raw[12];
-        cg_issue_fields<FT, D3>(F, zi, yi, xi, ti, lenT, raw);
-        cg_store_fields<FT, CM>(c, L, cell, zi, ti, lenT, raw);
+        cg_refresh_fields<FT, D3, CM, true>(F, L, c, cell, zi, yi, xi, ti, lenT);
     }
     // ---- CGrid_Velocity.interp (_xinterpolators.py:193-332), float64 coordinates and barycentric arrays ----
     double px[4], py[4];
@@ -493,9 +588,10 @@ PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtxT<FT, CM>& c, dou
 #pragma unroll
         for (int k = 0; k < 4; k++) { px[k] = c.pxy[k]; py[k] = c.pxy[4 + k]; }
     } else {
-        const double* rec = L.rec;
+        const double* rec = L.rec;  // (rows 16..23 of the record: slot rows 15..22, or the pairs 8..11 of CG_DMA)
+        constexpr int r0 = (CM & CG_DMA) ? 16 : 15;
 #pragma unroll
-        for (int k = 0; k < 4; k++) { px[k] = rec[(15 + k) * FC_LANES]; py[k] = rec[(19 + k) * FC_LANES]; }
+        for (int k = 0; k < 4; k++) { px[k] = cg_rec_row<CM>(rec, r0 + k); py[k] = cg_rec_row<CM>(rec, r0 + 4 + k); }
     }
     FT rawf[12];
     if constexpr ((CM & CG_FV_REGS) != 0) {

@@ -716,6 +716,8 @@ __global__ void __launch_bounds__(256, PK_MIN_WAVES_FAST) advect_fast_kernel(con
         ft.lat = s_tab + a.fast.lds_lat;
         ft.lon = s_tab + a.fast.lds_lon;
         ft.blk = s_tab + a.fast.lds_blk + threadIdx.x;  // (read only where lds_blk != 0)
+        ft.fl = fast_flags(a.fast) | ((a.win_lo > -INFINITY || a.win_hi < INFINITY) ? FA_WIN : 0u) | (a.prm.dt0 > 0 ? FA_FWD : 0u) |
+                (a.prm.max_iters > 0 ? FA_MAXIT : 0u);
     }
     // the row index is re-derived where it is needed (entry and exit) instead of living in two registers across the step loop
     auto row = [&]() { return (int64_t)xcd_swizzle(blockIdx.x, gridDim.x) * 256 + threadIdx.x; };
@@ -736,16 +738,17 @@ __global__ void __launch_bounds__(256, PK_MIN_WAVES_FAST) advect_fast_kernel(con
             double pdz = ldp(P.dz, i, pf), pdy = ldp(P.dy, i, pf), pdx = ldp(P.dx, i, pf);
             double pdt = P.dt[i];
             const double endtime = prm.endtime;
-            const int sign = prm.dt0 > 0 ? 1 : -1;  // kernel.py:186
-            const bool windowed = a.win_lo > -INFINITY || a.win_hi < INFINITY;  // some field streams through a ring of levels
             while (c.state == PK_EVALUATE) {  // :190 (no kernel of these programs sets Repeat)
-                const double tte = sign * (endtime - pt);
+                uint32_t fl = ft.fl;  // (FastTabs::fl: the step loop's yes / no questions as scalar bit tests, not as saved lane masks)
+                asm volatile("" : "+s"(fl));
+                const bool fwd = (fl & FA_FWD) != 0;                   // sign = 1 if dt0 > 0 else -1 (kernel.py:186)
+                const double tte = fwd ? endtime - pt : -(endtime - pt);  // sign * (endtime - t), the sign of a zero included
                 if (!(tte >= 0)) break;  // :193-197
-                if (prm.max_iters > 0 && it >= (unsigned)prm.max_iters) break;  // pk_execute_rerun: stop where the reference raised
+                if ((fl & FA_MAXIT) && it >= (unsigned)prm.max_iters) break;  // pk_execute_rerun: stop where the reference raised
                 double dtc;
-                if (sign == 1) dtc = fmax(fmin(pdt, tte), 0.0);  // :200-203
+                if (fwd) dtc = fmax(fmin(pdt, tte), 0.0);  // :200-203
                 else dtc = fmin(fmax(pdt, -tte), 0.0);
-                if (windowed) {  // field-slab streaming: step only inside the resident time window (advect_kernel)
+                if (fl & FA_WIN) {  // field-slab streaming (some field streams through a ring of levels): step only inside the resident time window (advect_kernel)
                     const double t1 = pt + dtc;
                     const double lo = fmin(pt, t1), hi = fmax(pt, t1);
                     if (lo < a.win_lo || hi > a.win_hi) { paused = 1; break; }
@@ -881,8 +884,10 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID) advect_cgrid_ker
         __syncthreads();
         L.time = s_tab + F.lds_time;
         L.depth = s_tab + F.lds_depth;
-        L.rec = smem + F.lds_rec + threadIdx.x;  // lane-private slots: no barrier needed
+        L.rec = smem + F.lds_rec + ((CG_CACHE_RK4 & CG_DMA) ? 2 * threadIdx.x : threadIdx.x);  // lane-private slots: no barrier needed
         L.fv = (void*)((FT*)(smem + F.lds_fv) + threadIdx.x);
+        L.rec_w = reinterpret_cast<char*>(smem + F.lds_rec);
+        L.fv_w = reinterpret_cast<char*>(smem + F.lds_fv);
     }
     auto row = [&]() { return (int64_t)xcd_swizzle(blockIdx.x, gridDim.x) * FC_LANES + threadIdx.x; };
     unsigned steps = 0, attempts = 0, paused = 0;
@@ -1027,8 +1032,10 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID_RK45) advect_cgri
         __syncthreads();
         L.time = s_tab + F.lds_time;
         L.depth = s_tab + F.lds_depth;
-        L.rec = smem + F.lds_rec + threadIdx.x;
+        L.rec = smem + F.lds_rec + ((CG_CACHE_RK45 & CG_DMA) ? 2 * threadIdx.x : threadIdx.x);  // lane-private slots: no barrier needed
         L.fv = (void*)((FT*)(smem + F.lds_fv) + threadIdx.x);
+        L.rec_w = reinterpret_cast<char*>(smem + F.lds_rec);
+        L.fv_w = reinterpret_cast<char*>(smem + F.lds_fv);
     }
     auto row = [&]() { return (int64_t)xcd_swizzle(blockIdx.x, gridDim.x) * FC_LANES + threadIdx.x; };
     unsigned steps = 0, attempts = 0, paused = 0;
@@ -1198,8 +1205,10 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID_M1) advect_cgrid_
         __syncthreads();
         L.time = s_tab + F.lds_time;
         L.depth = s_tab + F.lds_depth;
-        L.rec = smem + F.lds_rec + threadIdx.x;
+        L.rec = smem + F.lds_rec + ((CG_CACHE_M1 & CG_DMA) ? 2 * threadIdx.x : threadIdx.x);  // lane-private slots: no barrier needed
         L.fv = (void*)((FT*)(smem + F.lds_fv) + threadIdx.x);
+        L.rec_w = reinterpret_cast<char*>(smem + F.lds_rec);
+        L.fv_w = reinterpret_cast<char*>(smem + F.lds_fv);
     }
     auto row = [&]() { return (int64_t)xcd_swizzle(blockIdx.x, gridDim.x) * FC_LANES + threadIdx.x; };
     unsigned steps = 0, attempts = 0, paused = 0;

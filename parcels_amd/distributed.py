@@ -67,6 +67,64 @@ class CollectiveAbort(RuntimeError):
     """Raised on the ranks of a collective run whose pass went fine when ANOTHER rank's pass raised (batch_agreement: agree_min)."""
 
 
+_ABORT_KEY = "parcels_amd/collective_abort"
+
+
+def _store():
+    import torch.distributed as dist
+
+    try:
+        return dist.distributed_c10d._get_default_store()
+    except Exception:  # noqa: BLE001 -- no default group / private API moved: the side channel is best effort
+        return None
+
+
+def post_abort(exc) -> None:
+    """A rank-local failure OUTSIDE the launch loop of a collective run (a restore, the write, a compaction: no agreement sits there):
+    leave a note in the process group's key-value store.  The other ranks read it before they enter their next collective
+    (check_abort) and raise CollectiveAbort instead of waiting there for a rank that is gone.  A rank that already sits INSIDE a
+    collective is released by the process group's timeout only -- the store is a side channel, not a collective."""
+    import logging
+
+    logging.getLogger("parcels_amd").error("collective run: this rank failed outside the batch agreements: %r", exc)
+    st = _store()
+    if st is not None:
+        try:
+            st.set(_ABORT_KEY, repr(exc)[:500])
+            _posted[0] = True
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def check_abort() -> None:
+    st = _store()
+    if st is None:
+        return
+    try:
+        gone = st.check([_ABORT_KEY])
+    except Exception:  # noqa: BLE001
+        return
+    if gone:
+        raise CollectiveAbort("another rank of the collective run failed outside Kernel.execute: " + st.get(_ABORT_KEY).decode(errors="replace"))
+
+
+_posted = [False]
+
+
+def clear_abort() -> None:
+    """Called by the rank that posted the note when it starts its next collective execute(), BEFORE the all-reduce of the release times
+    that every rank attends first -- the others look at the store only behind that all-reduce."""
+    if not _posted[0]:
+        return
+    _posted[0] = False
+    st = _store()
+    if st is not None:
+        try:
+            st.delete_key(_ABORT_KEY)
+        except Exception:  # noqa: BLE001
+            pass
+
+
 def batch_agreement(group=None, device=None):
     """The two hooks that make a sharded ParticleSet ONE batch for the batch-wide rules of ``Kernel.execute`` (DeviceEngine.execute):
 
@@ -93,6 +151,8 @@ def batch_agreement(group=None, device=None):
     def agree_min(err, key, failed=False):
         """failed=True: this rank's pass raised (it re-raises after the agreement); every OTHER rank then raises CollectiveAbort here instead of
         waiting in the next all-reduce for a rank that is gone (round-4 ADVICE: the schedule of agreements must not desynchronise)."""
+        if not failed:
+            check_abort()
         t0 = _time.perf_counter()
         t = torch.tensor([int(err) or big, int(key) or big, 0 if failed else 1], dtype=torch.int64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
@@ -179,6 +239,7 @@ def gather_rows_to_root(columns: dict, group=None) -> dict | None:
     import torch
     import torch.distributed as dist
 
+    check_abort()
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     names = list(columns)
     n_local = int(columns[names[0]].shape[0]) if names else 0

@@ -363,8 +363,10 @@ class DeviceEngine:
     # ---- particles -------------------------------------------------------------------------------------------
     def _particles_desc(self, data: dict):
         """Validate the SoA dict (particle.py:182-222) and describe it for the library (pk_particles_desc)."""
+        src = None
         if isinstance(data, LazyColumns):  # (the arrays as they are: no download, no dirty mark -- bind_particles released the set)
             src = data
+            src._extra_refs.pop("next_dt", None)
             data = _RawView(src)
         n = data["x"].shape[0]
         for k in ("t", "z", "y", "x", "dz", "dy", "dx", "dt", "state", "ei", "particle_id"):
@@ -393,6 +395,8 @@ class DeviceEngine:
             # store to f32 (pk_exec_params.next_dt_f32), so this f64 shadow converts back exactly.
             self._next_dt_f32 = (nd, nd.astype(np.float64))
             nd = self._next_dt_f32[1]
+            if src is not None:
+                src._extra_refs["next_dt"] = 1  # (this tuple: not a holder outside the set, columns.py)
         elif nd is not None and nd.dtype != np.float64:
             raise TypeError("next_dt must be float32 or float64")
         d.next_dt = _ptr(nd) if nd is not None else None
@@ -469,7 +473,7 @@ class DeviceEngine:
 
     def device_column_names(self, data):
         """The columns of `data` that live on the device and that a launch may write."""
-        return [k for k in dict.keys(data) if k != "particle_id" and self._column_bit(k)]
+        return [k for k in data.keys() if k != "particle_id" and self._column_bit(k)]
 
     def mark_launched(self, data=None):
         """After launches: the host mirror of the written columns is stale (nothing is copied; LazyColumns downloads on access)."""
@@ -490,7 +494,7 @@ class DeviceEngine:
             if data._engine is self:
                 self.d2h(["state"])
             state = data.raw("state")
-            pairs = [(k, data.raw(k)) for k in dict.keys(data)]  # (arrays as they are: the device columns are not downloaded)
+            pairs = [(k, data.raw(k)) for k in data.raw_keys()]  # (arrays as they are: the device columns are not downloaded)
         else:
             self.d2h(["state"])
             state = data["state"]
@@ -516,7 +520,7 @@ class DeviceEngine:
             data._stale.clear()
             data._dirty.clear()
             new._engine = self
-            new._stale = {k for k in dict.keys(new) if k != "state" and (k in _hip.COLUMN_BITS or k in self.device_variables)}
+            new._stale = {k for k in new.raw_keys() if k != "state" and (k in _hip.COLUMN_BITS or k in self.device_variables)}
         return new
 
     def h2d(self):
@@ -564,7 +568,7 @@ class DeviceEngine:
         self.ctx.check(self.lib.pk_particles_snapshot_begin(self.ctx.handle, mask, int(slot)), "pk_particles_snapshot_begin")
         b = self._bound
         raw = b.raw if isinstance(b, LazyColumns) else b.__getitem__  # (dtypes only: no download, no dirty mark)
-        self._snap_dtypes = {k: raw(k).dtype for k in dict.keys(b) if k in _hip.COLUMN_BITS or k in self.device_variables}
+        self._snap_dtypes = {k: raw(k).dtype for k in b.keys() if k in _hip.COLUMN_BITS or k in self.device_variables}
 
     def snapshot_wait(self, slot: int) -> dict:
         """Block until snapshot ``slot`` has landed; NumPy views of its pinned columns (valid until the slot is reused).  Callable
@@ -874,8 +878,10 @@ class DeviceEngine:
                 if agree is not None and self.exact_error_stop:
                     try:
                         agree(0, 0, failed=True)
-                    except Exception:  # noqa: BLE001 -- the original exception matters
-                        pass
+                    except Exception as e2:  # noqa: BLE001 -- the original exception matters; the swallowed one is logged
+                        import logging
+
+                        logging.getLogger("parcels_amd").warning("the failure agreement of a collective run raised as well: %r", e2)
                 raise
             if not self.exact_error_stop:
                 break

@@ -80,11 +80,12 @@ class ParticleSet:
     which a long fused launch is cut and re-sorted (measured on BASELINE config 2)."""
 
     SORT_AUTO_MIN = 100_000
-    # From this many particles on the columns stay in HBM between execute() calls and the host arrays become a lazy mirror
-    # (parcels_amd/columns.py).  Smaller sets keep the eager protocol of the reference -- every call uploads all columns and downloads them at
-    # its end (a millisecond at this size) -- so that code which holds on to a column array across calls, or writes through such an old
-    # reference, sees exactly what it sees with the reference.  `pset.resident_columns = True / False` forces either.
-    RESIDENT_MIN = 100_000
+    # The columns stay in HBM between execute() calls and the host arrays are a lazy mirror (parcels_amd/columns.py) at EVERY size: the mirror
+    # hands out one persistent ndarray per column and follows references held outside the set (refreshed in place after a launch, uploaded
+    # before the next), so a script that keeps `x = pset.x` across calls, or writes through it, sees what it sees with the reference.
+    # RESIDENT_MIN is only a default one can raise: sets smaller than it use the eager protocol of rounds 1-4 (every call uploads and
+    # downloads everything).  `pset.resident_columns = True / False` forces either.
+    RESIDENT_MIN = 0
     RESORT_EVERY_DEFAULT = 30 * 86400.0  # profiles/r03_c2_long_run.json: over 23 days of C2 the locality of ONE sort does not decay (re-sorting only costs)
 
 
@@ -182,7 +183,7 @@ class ParticleSet:
 
     def __setattr__(self, name, value):
         data = self.__dict__.get("_data")
-        if name != "_data" and isinstance(data, dict) and name in data:
+        if name != "_data" and isinstance(data, (dict, LazyColumns)) and name in data:
             data[name][:] = value
         else:
             if name == "_data" and isinstance(value, dict) and not isinstance(value, LazyColumns):
@@ -303,8 +304,9 @@ class ParticleSet:
         first = None
         if collective:
             # the first release over ALL shards (NaN-propagating like rel.min(): one unset release time anywhere => fieldset start)
-            from .distributed import allreduce_scalars
+            from .distributed import allreduce_scalars, clear_abort
 
+            clear_abort()  # (a note this rank left in the store when an earlier call failed)
             if t_lo is not None:
                 mine = np.nan if t_nan else (t_lo if sign_dt == 1 else t_hi)
             else:
@@ -336,7 +338,17 @@ class ParticleSet:
         # through ParticleSetView on every step, particlesetview.py:97-301.)
         engine = self._engine()
         kern = self._kernel
-        self._t_live = start_time if np.isfinite(start_time) else None  # (= the first release: what Kernel.launch would reduce from `t`)
+        # (= the first release: what Kernel.launch would reduce from `t`.  In a collective run `start_time` is the first release over ALL
+        # shards; this shard's own may be later -- its launches then start from ITS first release, not from a level it never samples)
+        self._t_live = start_time if np.isfinite(start_time) else None
+        if collective and self._t_live is not None and len(self) > 0:
+            if t_lo is not None:
+                own = np.nan if t_nan else (t_lo if sign_dt == 1 else t_hi)
+            else:
+                rel = t_ro()
+                own = rel.min() if sign_dt == 1 else rel.max()
+            if np.isfinite(own):
+                self._t_live = float(own)
         if kern.host_functions and not kern._jit_tried:
             kern._try_jit(self)  # elementwise Python kernels are compiled into the device program here (parcels_amd/jit.py)
         engine.device_variables = list(kern.device_variables)  # user Variables that device kernels write live on the device
@@ -369,6 +381,8 @@ class ParticleSet:
         try:
             with output_file if output_file is not None else nullcontext():  # the Parquet footer is written on error too
                 try:
+                    if collective:
+                        from .distributed import CollectiveAbort, post_abort
                     while sign_dt * (time - end_time) < 0:
                         if next_output is not None:
                             next_time = (min if sign_dt > 0 else max)(next_output, end_time)
@@ -422,7 +436,9 @@ class ParticleSet:
                         if collective:  # the reference's `if len(pset) == 0: break`, decided over all shards
                             from .distributed import allreduce_scalars
 
-                            if allreduce_scalars([float(len(self))], "sum", output_file._group, device=engine.device)[0] == 0:
+                            # (with an output file the loop goes on over the emptied set like the single-process one below -- every rank
+                            # knows `next_output`, so the same row groups / observation times come out on 1 GPU and on N)
+                            if next_output is None and allreduce_scalars([float(len(self))], "sum", output_file._group, device=engine.device)[0] == 0:
                                 break
                         elif len(self) == 0 and next_output is None:
                             break  # (with an output file the reference's loop goes on to the end time and writes an (empty) table at every
@@ -451,6 +467,12 @@ class ParticleSet:
                             if np.isfinite(outputdt):
                                 next_output += outputdt * sign_dt
                         time = next_time
+                except BaseException as e:
+                    # a rank-local failure anywhere in an interval of a collective run (restore, key exchange, write, compaction): tell the
+                    # others through the store before they wait for this rank in their next collective (distributed.post_abort)
+                    if collective and not isinstance(e, CollectiveAbort):
+                        post_abort(e)
+                    raise
                 finally:
                     # pending tables are encoded BEFORE the file is closed (also when a kernel raised: the footer then covers
                     # every table submitted so far)

@@ -609,3 +609,72 @@ def test_a_rank_that_raises_inside_a_pass_takes_the_others_with_it(world):
         assert p.exitcode == 0, "a rank hung or failed"
     res = dict(q.get(timeout=10) for _ in range(world))
     assert res[1] == "RuntimeError" and all(res[r] == "CollectiveAbort" for r in range(world) if r != 1), res
+
+
+def _store_abort_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from parcels_amd import distributed as D
+
+        agree_min, _ = D.batch_agreement()
+        agree_min(0, 0)  # a first pass every rank attends
+        if rank == 1:
+            # fails OUTSIDE the launch loop (say, in its write): no agreement sits there -- it leaves the note and goes
+            D.post_abort(RuntimeError("disk full"))
+            q.put((rank, "RuntimeError"))
+            # ... the user catches, and the next collective execute() of this rank starts by withdrawing the note
+            dist.barrier()
+            D.clear_abort()
+            dist.barrier()
+            D.check_abort()
+            q.put((rank, "clean"))
+            return
+        import time as _t
+
+        for _ in range(200):  # (the note travels through the rank-0 store: poll instead of assuming an order)
+            try:
+                D.check_abort()
+            except D.CollectiveAbort as e:
+                q.put((rank, "CollectiveAbort:" + str("disk full" in str(e))))
+                break
+            _t.sleep(0.01)
+        else:
+            q.put((rank, "no note"))
+        # the same through the entry points that call it: the next agreement / the write gather raise instead of blocking
+        for fn in (lambda: agree_min(0, 0), lambda: D.gather_rows_to_root({})):
+            try:
+                fn()
+                q.put((rank, "entered a collective"))
+            except D.CollectiveAbort:
+                q.put((rank, "stopped"))
+        dist.barrier()
+        dist.barrier()
+        D.check_abort()
+        q.put((rank, "clean"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_a_rank_that_fails_outside_the_agreements_leaves_a_note(world):
+    """a rank-local failure after the per-pass agreement (restore, key exchange, write, compaction) must not leave the others
+    waiting in their next collective: post_abort() leaves a note in the group's store, agree_min / gather_rows_to_root read it first."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_store_abort_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=90)
+        assert p.exitcode == 0, "a rank hung or failed"
+    got = {}
+    while not q.empty():
+        r, v = q.get(timeout=10)
+        got.setdefault(r, []).append(v)
+    assert got[1] == ["RuntimeError", "clean"], got
+    for r in range(world):
+        if r != 1:
+            assert got[r] == ["CollectiveAbort:True", "stopped", "stopped", "clean"], got

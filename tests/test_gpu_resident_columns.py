@@ -35,7 +35,7 @@ def _script(case, calls, steps, between=None, eager=False, sort=True, two_sets=F
         fs = build_fieldset(case)
         fs.to_device(0)
         pset = build_pset(case, fs, sort_by_cell=sort)
-        pset.resident_columns = True  # (sets below ParticleSet.RESIDENT_MIN are eager by default)
+        pset.resident_columns = True
         other = build_pset(dict(case, x=np.asarray(case["x"])[:100] + 0.01, y=np.asarray(case["y"])[:100], z=None if case.get("z") is None else np.asarray(case["z"])[:100]), fs,
                            sort_by_cell=False) if two_sets else None
         if other is not None:
@@ -143,30 +143,75 @@ def test_deletions_and_output_file_with_resident_columns(gpu, tmp_path):
         assert a.equals(b)
 
 
-def test_small_sets_keep_the_eager_protocol(gpu):
-    """Below ParticleSet.RESIDENT_MIN every execute() uploads and downloads all columns: an array held across calls is refreshed in place and
-    a write through such an old reference reaches the device, exactly as with the reference (and with rounds 1-4)."""
+@pytest.mark.parametrize("npart", [500, 100_000])
+def test_an_array_held_across_calls_aliases_like_the_reference(gpu, npart):
+    """The reference hands out the live array and mutates it in place (particleset.py:155-164).  With device-resident columns an array that
+    somebody still holds is refreshed in place by every call, and a write through it -- announced to nobody -- reaches the device with the
+    next call; the columns nobody holds do not move (at every size, 1e5 particles included).  Against the eager path
+    (resident_columns = False: every call uploads and downloads everything) at rtol 0."""
     import parcels_amd as pa
 
-    case = _case(npart=500, kernels=("AdvectionRK4",))
+    def run(resident):
+        case = _case(npart=npart, kernels=("AdvectionRK4",))
+        fs = build_fieldset(case)
+        fs.to_device(0)
+        pset = build_pset(case, fs)
+        pset.resident_columns = resident
+        x_ref = pset._data["x"]  # held across the calls
+        x_view = pset.y[10:20]   # a VIEW keeps its base alive too
+        x0, y0 = x_ref.copy(), x_view.copy()
+        log = []
+        for k in range(3):
+            before = dict(fs._engine.transfers)
+            pset.execute([pa.AdvectionRK4], dt=float(case["dt"]), runtime=2 * float(case["dt"]))
+            log.append({key: fs._engine.transfers[key] - before[key] for key in before})
+            if k == 0:
+                assert not np.array_equal(x_ref, x0) and not np.array_equal(x_view, y0), "a held array was not refreshed by the call"
+                x_ref[:10] += 0.5  # writes nobody announces
+                x_view[:] -= 0.25
+        final = {key: np.array(v) for key, v in pset._data.items()}
+        assert np.array_equal(final["x"], x_ref) and np.array_equal(final["y"][10:20], x_view)
+        return final, log
+
+    lazy, log = run(True)
+    eager, elog = run(False)
+    compare(lazy, eager, rtol=0.0, check_state="all", label="held references: resident vs eager", skip=())
+    assert all(e["h2d_full"] == 1 and e["d2h_full"] == 1 for e in elog), elog
+    # resident: after the first upload only the two held columns move -- down after each call, up before the next
+    assert log[0]["h2d_full"] == 1 and log[0]["columns_down"] == 2 and log[0]["d2h_full"] == 0, log
+    for e in log[1:]:
+        assert e["h2d_full"] == 0 and e["d2h_full"] == 0 and e["columns_up"] == 2 and e["columns_down"] == 2, log
+
+
+def test_mapping_fast_paths_see_current_values(gpu, tmp_path):
+    """dict(pset._data), {**pset._data} and np.savez(p, **pset._data) went through the C fast paths of a dict subclass and got the
+    arrays of BEFORE the launch.  The mirror is a MutableMapping now: every one of them downloads first."""
+    import parcels_amd as pa
+
+    case = _case(npart=3000, kernels=("AdvectionRK4",))
     fs = build_fieldset(case)
     fs.to_device(0)
     pset = build_pset(case, fs)
-    x_ref = pset._data["x"]  # held across the calls
-    x0 = x_ref.copy()
-    pset.execute([pa.AdvectionRK4], dt=float(case["dt"]), runtime=2 * float(case["dt"]))
-    assert not np.array_equal(x_ref, x0), "the held array was not refreshed by the call"
-    x_ref[:10] += 0.5  # a write nobody announces
-    after_write = x_ref.copy()
-    before = dict(fs._engine.transfers)
+    pset.resident_columns = True
+    x0 = np.array(pset._data["x"])
+    pset.execute([pa.AdvectionRK4], dt=float(case["dt"]), runtime=3 * float(case["dt"]))
+    assert "x" in pset._data._stale
+    a = dict(pset._data)
+    assert not np.array_equal(a["x"], x0)
+    del a
     pset.execute([pa.AdvectionRK4], dt=float(case["dt"]), runtime=float(case["dt"]))
-    assert fs._engine.transfers["h2d_full"] == before["h2d_full"] + 1 and fs._engine.transfers["d2h_full"] == before["d2h_full"] + 1
-    assert np.all(np.abs(x_ref[:10] - after_write[:10]) < 0.2) and np.all(np.abs(x_ref[:10] - (x0[:10] + 0.5)) < 0.3), "the write through the old reference was lost"
+    b = {**pset._data}
+    x1 = np.array(b["x"])
+    del b
+    pset.execute([pa.AdvectionRK4], dt=float(case["dt"]), runtime=float(case["dt"]))
+    np.savez(tmp_path / "cols.npz", **pset._data)
+    saved = np.load(tmp_path / "cols.npz")
+    assert not np.array_equal(saved["x"], x1) and np.array_equal(saved["x"], pset.x) and np.array_equal(saved["t"], pset.t)
 
 
-def test_sets_of_1e5_particles_and_more_are_resident_by_default(gpu):
-    """The automatic choice (ParticleSet.RESIDENT_MIN): 2e5 particles stay on the device between three calls -- nothing crosses PCIe in calls 2
-    and 3 -- and end where the eager protocol (resident_columns = False) ends, bit for bit; 5e4 particles are eager."""
+def test_every_size_is_resident_by_default(gpu):
+    """2e5 and 5e4 particles alike stay on the device between three calls -- nothing crosses PCIe in calls 2 and 3 -- and end where the eager
+    protocol (resident_columns = False) ends, bit for bit."""
     import parcels_amd as pa
 
     def run(n, resident):
@@ -183,10 +228,9 @@ def test_sets_of_1e5_particles_and_more_are_resident_by_default(gpu):
             log.append({k: fs._engine.transfers[k] - before[k] for k in before})
         return {k: np.array(v) for k, v in pset._data.items()}, log
 
-    auto, log = run(200_000, None)
-    eager, elog = run(200_000, False)
-    compare(auto, eager, rtol=0.0, check_state="all", label="2e5 particles: automatic (resident) vs eager", skip=())
-    assert log[0]["h2d_full"] == 1 and all(sum(e.values()) == 0 for e in log[1:]), log
-    assert all(e["h2d_full"] == 1 and e["d2h_full"] == 1 for e in elog), elog
-    _, slog = run(50_000, None)
-    assert all(e["h2d_full"] == 1 and e["d2h_full"] == 1 for e in slog), slog
+    for n in (200_000, 50_000):
+        auto, log = run(n, None)
+        eager, elog = run(n, False)
+        compare(auto, eager, rtol=0.0, check_state="all", label=f"{n} particles: automatic (resident) vs eager", skip=())
+        assert log[0]["h2d_full"] == 1 and all(sum(e.values()) == 0 for e in log[1:]), log
+        assert all(e["h2d_full"] == 1 and e["d2h_full"] == 1 for e in elog), elog

@@ -17,7 +17,7 @@ class _FakeEngine:
             if isinstance(lc, LazyColumns):
                 lc.release()
         self._bound = data
-        self.dev = {k: np.array(data.raw(k)) for k in dict.keys(data)}
+        self.dev = {k: np.array(data.raw(k)) for k in data.raw_keys()}
         data._engine = self
 
     def launch(self):  # "kernels" move x and advance t
@@ -26,7 +26,7 @@ class _FakeEngine:
         self._bound.mark_launched(["x", "t", "state"])
 
     def d2h(self, cols=None):
-        cols = list(dict.keys(self._bound)) if cols is None else cols
+        cols = list(self._bound.raw_keys()) if cols is None else cols
         for k in cols:
             self._bound.raw(k)[...] = self.dev[k]
             self.down.append(k)
@@ -108,3 +108,51 @@ def test_items_values_copy_and_raw_items():
 
     c = copy.deepcopy(d)
     assert isinstance(c, LazyColumns) and not c.resident() and c["t"][0] == 10.0
+
+
+def test_c_fast_paths_go_through_the_bookkeeping():
+    """dict(data), {**data} and f(**data) skipped __getitem__ of the dict SUBCLASS and saw the arrays of before the launch."""
+    d, e = _cols(), _FakeEngine()
+    e.bind_and_upload(d)
+    e.launch()
+    assert not isinstance(d, dict)
+    a = dict(d)
+    assert a["x"][0] == 1.0 and a["t"][0] == 10.0 and not d._stale and d._dirty == {"x", "t", "state", "age"}
+    del a
+    e.upload_dirty()
+    e.launch()
+    b = {**d}
+    assert b["x"][0] == 2.0
+    del b
+    e.upload_dirty()
+    e.launch()
+    assert (lambda **kw: kw["x"][0])(**d) == 3.0
+
+
+def test_a_held_array_is_refreshed_by_the_launch_and_its_writes_are_uploaded():
+    """The reference hands out the live array (particleset.py:155-164): a reference taken BEFORE a launch sees the launch, and a write through
+    it lands on the device with the next upload.  Columns nobody holds stay lazy."""
+    d, e = _cols(), _FakeEngine()
+    x = d["x"]  # held from before the set ever went to the device
+    tail = d["t"][3:]  # a view holds its base
+    e.bind_and_upload(d)
+    e.launch()
+    assert e.down == ["t", "x"] and x[0] == 1.0 and tail[0] == 10.0 and d._stale == {"state"} and d._dirty == {"x", "t"}
+    x[:] = 50.0  # announced to nobody
+    e.upload_dirty()
+    assert e.up == ["t", "x"]
+    e.launch()
+    assert x[0] == 51.0 and d["x"] is x
+    del x, tail
+    e.upload_dirty()
+    e.launch()  # nobody holds anything now: nothing comes down
+    assert e.down == ["t", "x", "t", "x"] and d._stale == {"x", "t", "state"}
+
+
+def test_clear_setdefault_popitem_and_ior_release_the_device_rows():
+    for op in (lambda d: d.clear(), lambda d: d.setdefault("new", np.zeros(5)), lambda d: d.popitem(), lambda d: d.__ior__({"age": np.zeros(5)})):
+        d, e = _cols(), _FakeEngine()
+        e.bind_and_upload(d)
+        e.launch()
+        op(d)
+        assert not d.resident() and not d._stale and sorted(e.down) == ["state", "t", "x"]

@@ -29,16 +29,47 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def nemo_like_coords(nx, ny):
+    """Node longitudes / latitudes of the synthetic curvilinear mesh (and the unit index ramps they are made of)."""
+    i = np.arange(nx, dtype=np.float64)[None, :] / (nx - 1)
+    j = np.arange(ny, dtype=np.float64)[:, None] / (ny - 1)
+    lon = -170.0 + 340.0 * i + 2.0 * np.sin(2 * np.pi * j) * (0.3 + i) + 3.0 * j
+    lat = -75.0 + 150.0 * j + 1.5 * np.sin(2 * np.pi * i) * (0.5 + 0.5 * j) - 2.0 * i
+    return lon, lat, i, j
+
+
+HASH_DIGESTS = os.path.join(ROOT, "tools", "bench_hash_digests.json")
+
+
+def independent_hash_table(engine, lon, lat):
+    """The spatial-hash table the bench-size CHECKER hands to the oracle must not simply be the thing checked.  The
+    device-built table is used only after its SHA-256 digests (keys, starts, counts, faces, bit width, bounding box) were compared with
+    the digest the HOST builder (parcels_amd/spatialhash.py, pinned to the reference's table by tests/test_spatialhash_reference.py)
+    produced for this mesh -- committed in tools/bench_hash_digests.json by tools/make_bench_hash_digest.py (the host build of the
+    1.3e7-face mesh takes minutes and ~20 GB of host memory: once, offline).  A mesh without a committed digest is built on the host here."""
+    from parcels_amd import spatialhash as sh
+
+    key = f"{lon.shape[1]}x{lon.shape[0]}"
+    digests = json.load(open(HASH_DIGESTS)) if os.path.exists(HASH_DIGESTS) else {}
+    if key in digests:
+        table = engine.hash_table(0)
+        got = sh.table_checksum(table)
+        want = digests[key]["checksum"]
+        bad = [k for k in want if (got[k] != want[k] if k != "bbox" else list(got[k]) != list(want[k]))]
+        assert not bad, f"device-built hash table of the {key} mesh differs from the host builder's committed digest in {bad}"
+        return table, {"source": "device table, SHA-256 equal to the host builder's committed digest", "digest_file": "tools/bench_hash_digests.json"}
+    t0 = time.perf_counter()
+    table = sh.SpatialHash(lon, lat, True).table()
+    return table, {"source": "host builder (parcels_amd/spatialhash.py)", "build_s": time.perf_counter() - t0}
+
+
 def nemo_like_dataset(nx, ny, nz, nt, with_kh=False, seed=0, shared_dir=None, generate=True):
     """shared_dir: U, V, W live in .npy files there and are memory-mapped (config c4: the ranks of one node share ONE copy of
     the field levels through the page cache instead of holding a private 48 GB each); generate=False opens them read-only."""
     import parcels_amd as pa
 
     t0 = time.perf_counter()
-    i = np.arange(nx, dtype=np.float64)[None, :] / (nx - 1)
-    j = np.arange(ny, dtype=np.float64)[:, None] / (ny - 1)
-    lon = -170.0 + 340.0 * i + 2.0 * np.sin(2 * np.pi * j) * (0.3 + i) + 3.0 * j
-    lat = -75.0 + 150.0 * j + 1.5 * np.sin(2 * np.pi * i) * (0.5 + 0.5 * j) - 2.0 * i
+    lon, lat, i, j = nemo_like_coords(nx, ny)
     depth = np.concatenate([[0.0], np.cumsum(np.linspace(5.0, 150.0, nz - 1))])
     time_s = np.arange(nt) * 86400.0
     zprof = np.exp(-depth / 1500.0).astype(np.float32)[:, None, None]
@@ -221,7 +252,8 @@ def check_against_oracle(*, n_check, dsinfo, engine, pset, kernel_names, context
     case = dict(name="bench_check", mesh="spherical", lon=lon, lat=lat, depth=depth, x_pad="low", y_pad="low", z_pad="high",
                 time_s=np.arange(fields["U"].shape[0]) * 86400.0, fields=fields, field_dims=dims, cgrid=True, kernels=list(kernel_names),
                 spatial_dtype="float64", x=x[:n_check], y=y[:n_check], z=z[:n_check], t0=None, dt=dt, runtime=runtime, seed=0,
-                context={k: v for k, v in context.items() if k == "dres"}, populate=True, hash_table=engine.hash_table(0))
+                context={k: v for k, v in context.items() if k == "dres"}, populate=True)
+    case["hash_table"], hash_source = independent_hash_table(engine, np.asarray(lon), np.asarray(lat))
     t0 = time.perf_counter()
     ref, err, _ = co.run_case(case, nthreads=nthreads or (os.cpu_count() or 1))
     oracle_s = time.perf_counter() - t0
@@ -238,7 +270,7 @@ def check_against_oracle(*, n_check, dsinfo, engine, pset, kernel_names, context
                  for k in ("x", "y", "z")}
     return {"n_check": int(n_check), "survivors": int(sel.sum()), "deleted": int(n_check - sel.sum()), "max_rel_diff": rep,
             "max_abs_diff": worst_abs, "tolerance": f"|a-b| <= {rtol:g} * (|b| + {scale:.0f})",
-            "exact": ["particle ids of the survivors (= deleted set)", "state", "ei", "t"], "oracle_s": oracle_s}
+            "exact": ["particle ids of the survivors (= deleted set)", "state", "ei", "t"], "oracle_s": oracle_s, "oracle_hash_table": hash_source}
 
 
 def run_config(config="c3", scale=1.0, particles=1e7, steps=24, nt=4, nslots=3, nz=75, hash="device", check=0, emit=print, dt=3600.0, reps=5,
