@@ -276,6 +276,54 @@ def repeat_execute(case, fs, calls, steps):
             "unit": "particle-steps/s", "pcie_transfers_per_call": moved, "first_host_read_of_x_ms": t_read * 1e3, "checksum_x": x_sum}
 
 
+def with_output(case, fs, steps, every):
+    """The headline workload WITH trajectory output: a ParticleFile every `every` steps over `steps` steps, three ways on
+    fresh ParticleSets of the headline particles -- no output, the inline write-out (D2H of the to-write columns + filter + Parquet encode
+    between two launches: what rounds 1-2 did and the reference does), the asynchronous one (device write filter -> pinned snapshot on the
+    copy stream -> writer thread; parcels_amd/particlefile.py).  value_incl_output = particle-steps / wall of the asynchronous run;
+    output_hidden_frac = the share of the inline write-out cost that no longer shows in the wall clock."""
+    import tempfile
+
+    import torch
+
+    import parcels_amd as pa
+    from tests.case_utils import build_pset
+
+    dt = case["dt"]
+    res = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for mode in ("warmup", "none", "inline", "async"):
+            pset = build_pset(case, fs, sort_by_cell=True, resort_every=0)
+            pset.async_output = mode == "async"
+            pf = None if mode == "none" else pa.ParticleFile(os.path.join(tmp, f"{mode}.parquet"), outputdt=float(every * dt))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pset.execute(pa.AdvectionRK4, dt=dt, runtime=(2 * every if mode == "warmup" else steps) * dt, output_file=pf)
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+            if mode == "warmup":
+                continue  # (pins the snapshot buffers, starts the thread pools, first touch of the temp directory)
+            res[mode] = {"wall_s": wall}
+            if pf is not None:
+                res[mode].update(file_MB=os.path.getsize(pf.path) / 1e6, parquet_writer_s=getattr(pf, "writer_seconds", None))
+            if mode == "async":
+                res[mode]["writer"] = getattr(pset, "_last_writer_stats", None)
+            os.path.exists(os.path.join(tmp, f"{mode}.parquet")) and os.remove(os.path.join(tmp, f"{mode}.parquet"))
+    n = len(case["x"])
+    tables = steps // every + 1
+    cost_inline = res["inline"]["wall_s"] - res["none"]["wall_s"]
+    cost_async = res["async"]["wall_s"] - res["none"]["wall_s"]
+    row_bytes = 8 * 5  # particle_id, t, z, y, x of the fp64 particle class
+    return {"workload": f"headline FieldSet and particles, AdvectionRK4, {steps} steps, one ParticleFile table every {every} steps ({tables} tables of {n} rows, zstd)",
+            "wall_s": {k: v["wall_s"] for k, v in res.items()}, "detail": res,
+            "value_incl_output": n * steps / res["async"]["wall_s"], "value_no_output_same_run": n * steps / res["none"]["wall_s"], "unit": "particle-steps/s",
+            "write_out_cost_s": {"inline": cost_inline, "async": cost_async}, "async_not_slower_than_inline": bool(res["async"]["wall_s"] <= res["inline"]["wall_s"] * 1.02),
+            "output_hidden_frac": (1.0 - cost_async / cost_inline) if cost_inline > 0 else None,
+            "table_GB_per_s_async": tables * n * row_bytes / 1e9 / max(cost_async, 1e-9),
+            "note": "a table of 1e7 fp64 rows is 400 MB: 7 ms of PCIe alone against 8 ms of kernel per 24 steps -- at this cadence the run is bound by the "
+                    "host's encode + file rate, not by the GPU; tools/bench_writeout.py sweeps the cadence"}
+
+
 def secondary_runs(args):
     """BASELINE configs 3 and 5 at full size on this GPU (tools/bench_configs.py builds them), outside the timed region of the
     headline: per run the particle-steps/s of the fused launch (HIP events on the compute stream), the algorithmic-byte roofline
@@ -382,6 +430,8 @@ def main():
                          "to-write columns (tools/bench_configs.py::run_c4); attached as `c4`; 0 = off")
     ap.add_argument("--particles", type=float, default=1e7, help="particles per GPU")
     ap.add_argument("--sort", type=int, default=1, help="cell-sort the device copy of the particles")
+    ap.add_argument("--with-output", type=int, default=96,
+                    help="N = 1: the headline workload over this many steps with a ParticleFile every 24 steps -- no output / inline / asynchronous (0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", type=float, default=1e5, help="headline: particle ids re-run through the CPU oracle after the timed steps (0 = off)")
     ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="particles of the CPU-baseline sample (~10-20 s on the host cores)")
@@ -520,26 +570,41 @@ def main():
     if dist is not None:
         from parcels_amd.distributed import allgather_output, device_write_rows, gather_write_columns
 
+        from parcels_amd.distributed import ensure_comm
+
+        cabi = ensure_comm(eng)  # the library's own RCCL communicator (include/parcels_hip.h: pk_comm_init); False in the gloo rehearsal
+        allgather_output(eng, world, fetch=False) if cabi else None  # (untimed first exchange: staging buffers are allocated on first use)
+        sync()
         t1 = time.perf_counter()
-        gathered = allgather_output(eng, world)
+        gathered = allgather_output(eng, world, fetch=False) if cabi else allgather_output(eng, world)
         sync()
         t_ag = time.perf_counter() - t1
-        assert gathered["particle_id"].shape[0] == world * npart
+        assert (int(gathered["counts"].sum()) if cabi else gathered["particle_id"].shape[0]) == world * npart
         del gathered
-        cols = device_write_rows(eng, ["particle_id", "t", "z", "y", "x"], (W + K) * dt)  # the product's write filter, on the device
-        sync()
-        t1 = time.perf_counter()
-        rooted = gather_write_columns(cols, device=local_rank)  # (what ParticleFile.write calls: device tensors over RCCL, host tensors over gloo)
-        sync()
-        t_g0 = time.perf_counter() - t1
-        if rank == 0:
-            assert rooted["particle_id"].shape[0] == world * npart, rooted["particle_id"].shape
-        del rooted, cols
+        names_w = ["particle_id", "t", "z", "y", "x"]
+        if cabi:  # what ParticleFile.write calls: the write filter on the device, counts all-gathered, rows to rank 0 -- pk_gather_rows_to_root
+            sync()
+            t1 = time.perf_counter()
+            eng.gather_rows(names_w, (W + K) * dt, fetch=False)
+            sync()
+            t_g0 = time.perf_counter() - t1
+            assert int(eng.comm_last_counts.sum()) == world * npart, eng.comm_last_counts
+        else:
+            cols = device_write_rows(eng, names_w, (W + K) * dt)  # the product's write filter, on the device
+            sync()
+            t1 = time.perf_counter()
+            rooted = gather_write_columns(cols, device=local_rank)  # (host tensors over gloo)
+            sync()
+            t_g0 = time.perf_counter() - t1
+            if rank == 0:
+                assert rooted["particle_id"].shape[0] == world * npart, rooted["particle_id"].shape
+            del rooted, cols
         try:
             ver = torch.cuda.nccl.version()
         except Exception:
             ver = None
-        comm = {"backend": dist.get_backend(), "n_ranks_seen": dist.get_world_size(), "rccl_version": ".".join(str(v) for v in ver) if ver else None}
+        comm = {"backend": dist.get_backend(), "n_ranks_seen": dist.get_world_size(), "rccl_version": ".".join(str(v) for v in ver) if ver else None,
+                "exchange": "C ABI (pk_allgather_output / pk_gather_rows_to_root: RCCL opened by libparcels_hip.so)" if cabi else "torch.distributed"}
     # what the lock-step points of a sharded ParticleSet cost (N > 1): four more steps through DeviceEngine.execute with the batch agreements
     # installed (parcels_amd.distributed.batch_agreement: after every pass the ranks all-reduce the first erring iteration / failing sample, at
     # the end the error codes) -- outside the timed region; calls and seconds inside the all-reduces, max over ranks
@@ -548,7 +613,7 @@ def main():
         try:
             from parcels_amd.distributed import batch_agreement
 
-            eng.agree_min, eng.agree_codes = batch_agreement(None, local_rank)
+            eng.agree_min, eng.agree_codes = batch_agreement(None, local_rank, engine=eng)
             sync()
             t1 = time.perf_counter()
             st_a = eng.execute(kern.kernel_ids, endtime=(W + K + 4) * dt, dt0=dt, sort_by_cell=0, t_start=(W + K) * dt)
@@ -725,6 +790,13 @@ def main():
             except Exception as e:
                 out["repeat_execute"] = {"error": repr(e)[:2000]}
             legs["repeat_execute"] = time.perf_counter() - _t
+        if args.with_output and world == 1:
+            _t = time.perf_counter()
+            try:
+                out["with_output"] = with_output(case, fs, int(args.with_output), 24)
+            except Exception as e:
+                out["with_output"] = {"error": repr(e)[:2000]}
+            legs["with_output"] = time.perf_counter() - _t
         if args.secondary and world == 1:
             # release the headline's device and host memory first: C3 needs 36 GB of HBM and 48 GB of host arrays
             pset = kern = eng = fs = case = None

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PK_ABI_VERSION 8 /* 8: pk_execute_twe_report (all failing samples of a pass at once), pk_particles_h2d_columns / _fill_f64 / _t_stats (device-resident columns across execute calls), pk_exec_stats.pack_ms / packs (the pair-copy packing ahead of a launch, timed) / sclk_mhz, "velocity_pairs" opt-in; 7: the call-wide OutsideTimeInterval of the reference on the device (pk_exec_params.twe_n / twe_key, pk_exec_stats.first_time_error_key, pk_execute_rerun_keys); 6: PK_MAX_FIELDS 64 (descriptors in device memory), PK_MAX_EXTRA 8, pk_particles_checkpoint / _restore, user kernels (PK_KERNEL_USER0 .., pk_generic_variant, pk_set_user_program), "eval_points_f32" option; 5: pk_exec_params.horizon_lo / horizon_hi / max_iters, pk_exec_stats.first_error_iter / program, pk_execute_rerun, "fast_cgrid" option; 4: pk_upload_stats, pk_host_stage_selftest, PK_KERNEL_DO_NOTHING / _MOVE_EAST / _MOVE_NORTH, vector PK_KERNEL_SAMPLE_FIELD, "cell_table" option */
+#define PK_ABI_VERSION 9 /* 9: pk_particles_snapshot_filtered (device-side write filter for the asynchronous write-out); the multi-GPU exchange in the ABI (pk_comm_unique_id / _init / _destroy / _info / _allreduce_i64, pk_gather_rows_to_root, pk_allgather_output, pk_gathered_fetch: RCCL, opened by the library); 8: pk_execute_twe_report (all failing samples of a pass at once), pk_particles_h2d_columns / _fill_f64 / _t_stats (device-resident columns across execute calls), pk_exec_stats.pack_ms / packs (the pair-copy packing ahead of a launch, timed) / sclk_mhz, "velocity_pairs" opt-in; 7: the call-wide OutsideTimeInterval of the reference on the device (pk_exec_params.twe_n / twe_key, pk_exec_stats.first_time_error_key, pk_execute_rerun_keys); 6: PK_MAX_FIELDS 64 (descriptors in device memory), PK_MAX_EXTRA 8, pk_particles_checkpoint / _restore, user kernels (PK_KERNEL_USER0 .., pk_generic_variant, pk_set_user_program), "eval_points_f32" option; 5: pk_exec_params.horizon_lo / horizon_hi / max_iters, pk_exec_stats.first_error_iter / program, pk_execute_rerun, "fast_cgrid" option; 4: pk_upload_stats, pk_host_stage_selftest, PK_KERNEL_DO_NOTHING / _MOVE_EAST / _MOVE_NORTH, vector PK_KERNEL_SAMPLE_FIELD, "cell_table" option */
 #define PK_MAX_GRIDS 4
 #define PK_MAX_FIELDS 64
 #define PK_MAX_KERNELS 8
@@ -298,6 +298,10 @@ int32_t pk_particles_restore(pk_ctx* ctx);
  * Parquet encoder) while the first thread drives the next launch. */
 int32_t pk_particles_snapshot_begin(pk_ctx* ctx, uint32_t column_mask, int32_t slot);
 int32_t pk_particles_snapshot_wait(pk_ctx* ctx, int32_t slot, pk_particles_desc* out_host_columns);
+/* The same snapshot, but only of the rows that pass ParticleFile's write filter `|t_p - t| <= |dt|/2` (particlefile.py:198-221) at output
+ * time t -- selected and packed ON THE DEVICE in host row order (csrc/pk_select.inc): only the rows a table holds cross PCIe, and the
+ * writer thread has nothing left to filter.  pk_particles_snapshot_wait reports their number in pk_particles_desc.n. */
+int32_t pk_particles_snapshot_filtered(pk_ctx* ctx, uint32_t column_mask, int32_t slot, double t);
 /* device pointers of the bound columns in CURRENT device order (for RCCL all-gather of the output
  * columns at write-out; see parcels_amd/distributed.py).  perm (int64*, may be NULL when the particles
  * have not been cell-sorted) maps device row -> original row. */
@@ -443,6 +447,36 @@ int32_t pk_search(pk_ctx* ctx, int32_t grid_id, int64_t m, const double* z, cons
 
 /* achieved copy bandwidth probe (device-to-device float4 copy), GB/s; used as a measured roofline denominator */
 int32_t pk_measure_copy_bandwidth(pk_ctx* ctx, int64_t bytes, int32_t iters, double* gbps);
+
+/* ---- multi-GPU: the exchanges of a run whose particles are sharded by id over one process per GPU ----------------
+ * The reference has no multi-process mode; what these stand in for is what a single process does with ALL particles in one place:
+ *   - ParticleFile.write (particlefile.py:142-221) filters `|t_p - t| <= |dt|/2` over every particle and appends one table:
+ *     pk_gather_rows_to_root applies that filter to this rank's DEVICE rows (in host row order, whatever the cell sort did to the device
+ *     order), all-gathers the row counts and sends the surviving rows of the masked columns to rank 0 (grouped ncclSend / ncclRecv over
+ *     xGMI; ranks may hold different, also zero, counts).  pk_allgather_output is the all-gather variant `north_star` names: every rank
+ *     receives the rows of all ranks, in rank order (= id order for contiguous shards).  pk_gathered_fetch copies the gathered columns to
+ *     the caller's arrays (rank 0, or every rank after pk_allgather_output).
+ *   - Kernel.execute's batch-wide rules (kernel.py:236-245 stops EVERY particle at the iteration of the first error;
+ *     index_search.py:85-86 fails a sample for every particle of the call): the shards agree on them with pk_comm_allreduce_i64
+ *     (element-wise MIN / MAX / SUM of a few int64 over the ranks).
+ * The communicator belongs to the pk_ctx: one per process.  The 128-byte id comes from pk_comm_unique_id on ONE rank and reaches the
+ * others over the host's own channel (a file, MPI, a socket, torch.distributed's store ...).  librccl.so is opened at the first of these
+ * calls -- a single-GPU host never loads it.  Collective semantics: every rank of the communicator must make the same sequence of
+ * pk_gather_rows_to_root / pk_allgather_output / pk_comm_allreduce_i64 calls. */
+#define PK_COMM_ID_BYTES 128
+#define PK_OP_MIN 0
+#define PK_OP_MAX 1
+#define PK_OP_SUM 2
+int32_t pk_comm_unique_id(uint8_t* id128);
+int32_t pk_comm_init(pk_ctx* ctx, int32_t rank, int32_t world, const uint8_t* id128);
+int32_t pk_comm_destroy(pk_ctx* ctx);
+int32_t pk_comm_info(pk_ctx* ctx, int32_t* rank, int32_t* world, int32_t* rccl_version);
+int32_t pk_comm_allreduce_i64(pk_ctx* ctx, int64_t* values, int32_t n, int32_t op); /* in place */
+/* t: the output time; apply_filter 0 = every row; mask: PK_COL_* of the columns to exchange; counts[world]: rows of every rank (out) */
+int32_t pk_gather_rows_to_root(pk_ctx* ctx, double t, int32_t apply_filter, uint32_t mask, int64_t* counts);
+int32_t pk_allgather_output(pk_ctx* ctx, double t, int32_t apply_filter, uint32_t mask, int64_t* counts);
+/* out: arrays of >= `capacity` rows for the columns of the last exchange's mask (the other pointers are ignored) */
+int32_t pk_gathered_fetch(pk_ctx* ctx, const pk_particles_desc* out, int64_t capacity);
 
 #ifdef __cplusplus
 }

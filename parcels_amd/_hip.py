@@ -13,7 +13,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PARCELS_HIP_LIB", os.path.join(_HERE, "libparcels_hip.so"))  # override: A/B builds
 
-PK_ABI_VERSION = 8
+PK_ABI_VERSION = 9
 PK_F32, PK_F64 = 0, 1
 PK_MAX_GRIDS, PK_MAX_FIELDS, PK_MAX_KERNELS, PK_NUM_STATE_CODES = 4, 64, 8, 80
 PK_MAX_EXTRA = 8
@@ -21,6 +21,9 @@ PK_MAX_TWE = 1024
 PK_KERNEL_SAMPLE_FIELD = 10
 PK_EVAL_MASKED = 0x10000  # pk_eval: or'ed into out_state where the value was zeroed for an out-of-bounds index
 PK_COL_EXTRA0 = 0x1000
+PK_COL_T, PK_COL_Z, PK_COL_Y, PK_COL_X, PK_COL_DT, PK_COL_STATE, PK_COL_PARTICLE_ID = 0x001, 0x002, 0x004, 0x008, 0x080, 0x200, 0x800
+PK_COMM_ID_BYTES = 128
+PK_OP_MIN, PK_OP_MAX, PK_OP_SUM = 0, 1, 2
 COLUMN_BITS = {n: 1 << i for i, n in enumerate(
     ["t", "z", "y", "x", "dz", "dy", "dx", "dt", "next_dt", "state", "ei", "particle_id"])}
 
@@ -230,6 +233,15 @@ ABI_SYMBOLS = [
     "pk_set_option",
     "pk_upload_stats",
     "pk_host_stage_selftest",
+    "pk_particles_snapshot_filtered",
+    "pk_comm_unique_id",
+    "pk_comm_init",
+    "pk_comm_destroy",
+    "pk_comm_info",
+    "pk_comm_allreduce_i64",
+    "pk_gather_rows_to_root",
+    "pk_allgather_output",
+    "pk_gathered_fetch",
 ]
 
 _lib = None
@@ -300,6 +312,22 @@ def load():
     lib.pk_measure_copy_bandwidth.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_double)]
     lib.pk_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
     lib.pk_upload_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    if os.environ.get("PARCELS_HIP_ALLOW_ABI") and not hasattr(lib, "pk_comm_init"):
+        # A/B measurements against a library of an OLDER round (tools/ab_*.sh: PARCELS_HIP_LIB + PARCELS_HIP_ALLOW_ABI=<its version>): the
+        # entry points it lacks are simply absent; nothing else is tolerated
+        if lib.pk_abi_version() != int(os.environ["PARCELS_HIP_ALLOW_ABI"]):
+            raise HipLibraryError(f"ABI version mismatch: library {lib.pk_abi_version()}, allowed {os.environ['PARCELS_HIP_ALLOW_ABI']}")
+        _lib = lib
+        return lib
+    lib.pk_particles_snapshot_filtered.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.c_double]
+    lib.pk_comm_unique_id.argtypes = [C.c_void_p]
+    lib.pk_comm_init.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    lib.pk_comm_destroy.argtypes = [C.c_void_p]
+    lib.pk_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.pk_comm_allreduce_i64.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+    lib.pk_gather_rows_to_root.argtypes = [C.c_void_p, C.c_double, C.c_int32, C.c_uint32, C.c_void_p]
+    lib.pk_allgather_output.argtypes = [C.c_void_p, C.c_double, C.c_int32, C.c_uint32, C.c_void_p]
+    lib.pk_gathered_fetch.argtypes = [C.c_void_p, C.POINTER(ParticlesDesc), C.c_int64]
     if lib.pk_abi_version() != PK_ABI_VERSION:
         raise HipLibraryError(f"ABI version mismatch: library {lib.pk_abi_version()}, binding {PK_ABI_VERSION}")
     _lib = lib

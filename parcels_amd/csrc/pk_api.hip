@@ -50,6 +50,15 @@ struct HostField {
 
 constexpr int PK_STAGE_BUFFERS = 3;  // pinned staging chunks of the level stream (see stage_acquire)
 
+// device scratch of the write filter (pk_select.inc): flag per host row, exclusive scan of the flags
+struct PkSelect {
+    uint32_t* d_flag = nullptr;
+    uint32_t* d_offs = nullptr;
+    int64_t cap = 0;
+    void* d_tmp = nullptr;
+    size_t tmp_bytes = 0;
+};
+struct PkComm;
 struct pk_ctx {
     int device = 0;
     hipStream_t compute = nullptr, copy = nullptr;
@@ -172,6 +181,9 @@ struct pk_ctx {
     int cg_tab_grid = -1, cg_tab_field = -1;
     bool cg_tab_ok = false;
     int32_t cg_tab_off[3] = {0, 0, 0};
+
+    PkSelect sel;                   // write filter on the device rows (pk_select.inc): the filtered snapshot and the multi-GPU exchange use it
+    struct PkComm* comm = nullptr;  // the multi-GPU exchange (pk_comm.inc: RCCL communicator + staging), NULL until pk_comm_init
 
     int32_t fail(const char* where, hipError_t e) {
         err = std::string(where) + ": " + hipGetErrorString(e);
@@ -770,6 +782,10 @@ int32_t pk_destroy(pk_ctx* ctx) {
     if (ctx->d_summary) (void)hipFree(ctx->d_summary);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->h_summary) (void)hipHostFree(ctx->h_summary);
+    (void)pk_comm_destroy(ctx);
+    if (ctx->sel.d_flag) (void)hipFree(ctx->sel.d_flag);
+    if (ctx->sel.d_offs) (void)hipFree(ctx->sel.d_offs);
+    if (ctx->sel.d_tmp) (void)hipFree(ctx->sel.d_tmp);
     if (ctx->d_clk) (void)hipFree(ctx->d_clk);
     if (ctx->d_tstats) (void)hipFree(ctx->d_tstats);
     if (ctx->h_clk) (void)hipHostFree(ctx->h_clk);
@@ -1404,6 +1420,8 @@ static int32_t copy_particles(pk_ctx* ctx, bool to_device, uint32_t mask = 0xFFF
     return 0;
 }
 
+#include "pk_select.inc"
+
 extern "C" {
 
 int32_t pk_particles_h2d(pk_ctx* ctx) {
@@ -1574,7 +1592,12 @@ int32_t pk_particles_t_stats(pk_ctx* ctx, double* t_min, double* t_max, int64_t*
 }
 
 // ---- asynchronous write-out (particleset.py:436-459 / particlefile.py:142-180 overlapped with the next interval) -------------
-int32_t pk_particles_snapshot_begin(pk_ctx* ctx, uint32_t mask, int32_t slot) {
+static int32_t snapshot_begin(pk_ctx* ctx, uint32_t mask, int32_t slot, bool filtered, double t_out);
+int32_t pk_particles_snapshot_begin(pk_ctx* ctx, uint32_t mask, int32_t slot) { return snapshot_begin(ctx, mask, slot, false, 0.0); }
+int32_t pk_particles_snapshot_filtered(pk_ctx* ctx, uint32_t mask, int32_t slot, double t) { return snapshot_begin(ctx, mask, slot, true, t); }
+}  // extern "C"
+// filtered: only the rows that pass the write filter of particlefile.py:198-221 at output time t_out, packed in host row order (pk_select.inc)
+static int32_t snapshot_begin(pk_ctx* ctx, uint32_t mask, int32_t slot, bool filtered, double t_out) {
     if (!ctx) return -2;
     if (slot < 0 || slot > 1) return ctx->fail("snapshot slot must be 0 or 1");
     if (!ctx->bound) return ctx->fail("no particles bound");
@@ -1613,7 +1636,18 @@ int32_t pk_particles_snapshot_begin(pk_ctx* ctx, uint32_t mask, int32_t slot) {
     }
     sn.n = n;
     sn.mask = mask;
-    if (n > 0) {
+    int64_t n_out = n;
+    if (filtered && n > 0) {
+        int32_t rc = select_flags(ctx, t_out, 1, &n_out);  // (one 8-byte read-back: the row count the D2H below needs)
+        if (rc) return rc;
+        for (int k = 0; k < PK_NCOLS && n_out > 0; k++) {
+            const ColRef& c = cols[k];
+            if (!((mask >> k) & 1u) || !c.d) continue;
+            select_column(ctx, c, sn.dev[k]);
+        }
+        PK_HIP(ctx, hipGetLastError());
+        sn.n = n_out;
+    } else if (n > 0) {
         for (int k = 0; k < PK_NCOLS; k++) {
             const ColRef& c = cols[k];
             if (!((mask >> k) & 1u) || !c.d) continue;
@@ -1629,15 +1663,16 @@ int32_t pk_particles_snapshot_begin(pk_ctx* ctx, uint32_t mask, int32_t slot) {
     }
     PK_HIP(ctx, hipEventRecord(sn.ready, ctx->compute));  // the next launch may now overwrite the live columns
     PK_HIP(ctx, hipStreamWaitEvent(ctx->copy, sn.ready, 0));
-    for (int k = 0; k < PK_NCOLS && n > 0; k++) {
+    for (int k = 0; k < PK_NCOLS && n_out > 0; k++) {
         const ColRef& c = cols[k];
         if (!((mask >> k) & 1u) || !c.d) continue;
-        PK_HIP(ctx, hipMemcpyAsync(sn.host[k], sn.dev[k], (size_t)n * c.elem * c.width, hipMemcpyDeviceToHost, ctx->copy));
+        PK_HIP(ctx, hipMemcpyAsync(sn.host[k], sn.dev[k], (size_t)n_out * c.elem * c.width, hipMemcpyDeviceToHost, ctx->copy));
     }
     PK_HIP(ctx, hipEventRecord(sn.done, ctx->copy));
     sn.in_flight = true;
     return 0;
 }
+extern "C" {
 
 // Wait for the snapshot in `slot` and hand out its pinned host columns (valid until the next snapshot_begin on that slot).
 // May be called from a second host thread while the first one drives the next launch: it only waits on an event.
@@ -2744,3 +2779,5 @@ int32_t pk_measure_copy_bandwidth(pk_ctx* ctx, int64_t bytes, int32_t iters, dou
 }
 
 }  // extern "C"
+
+#include "pk_comm.inc"

@@ -28,7 +28,19 @@ struct FastTabs {  // LDS-resident {a, 1/width} tables of the main grid and the 
     const pk_tab2* lon;
     pk_tab2* blk;  // this lane's corner-block cache (FCtx::bei): 4 x 16 bytes at stride FAST_WG, NULL = none
     uint32_t fl;   // FA_* bits of the wave-uniform yes / no questions of one evaluation (fast_flags)
+    // Scalars of FastA that every evaluation reads, PINNED in scalar registers by the kernel (pin_scalars: an opaque asm makes them values
+    // the allocator may spill to a VGPR lane -- one v_readlane where it is used -- but can no longer re-load from the kernel-argument
+    // segment: round 5's kernel did `s_load_dwordx2 ... 0x328` (tlen) + `s_waitcnt lgkmcnt(0)` in every evaluation, a scalar-cache
+    // round trip of ~200 cycles that also drains the LDS counter)
+    double tlen;
+    int32_t gny, gnx;
 };
+PK_DEV void pin_scalars(FastTabs& T, const FastA& F) {
+    T.tlen = F.tlen;
+    T.gny = F.gny;
+    T.gnx = F.gnx;
+    asm volatile("" : "+s"(T.tlen), "+s"(T.gny), "+s"(T.gnx));
+}
 // The wave-uniform booleans of an evaluation as bits of ONE scalar register.  Kept as separate loop-invariant i1 values the compiler
 // holds each of them as a 64-bit lane mask (`s_cselect_b64 -1, 0`): two SGPRs per question, 46 SGPRs spilled to VGPR lanes in round 5's
 // kernel and a `v_readlane_b32` -- a VALU instruction -- for every use inside the stage loop.  eval_uvw_fast re-reads the word through
@@ -322,7 +334,7 @@ PK_DEV void eval_uvw_fast(const KArgs& a, const FastTabs& T, FCtx& c, double t, 
     double tau = 0.0;
     if (fl & FA_TI) {  // _search_time_index (index_search.py:65-91); (it, klo): the key of this sample (pk_device.h: twe_note -- a launch with LISTED
                      // samples runs the general program, pk_api.hip)
-        if (__builtin_expect(!(0 <= t) || !(t <= F.tlen), 0)) {
+        if (__builtin_expect(!(0 <= t) || !(t <= T.tlen), 0)) {
             c.state = PK_ERROROUTSIDETIMEINTERVAL;
             twe_note(a, it, klo);
             return;
@@ -352,10 +364,10 @@ PK_DEV void eval_uvw_fast(const KArgs& a, const FastTabs& T, FCtx& c, double t, 
 #endif
     constexpr uint32_t YX2 = FA_Y | FA_X | FA_NY2 | FA_NX2;
     if (PK_FAST_SEARCH2 && (fl & YX2) == YX2) {
-        fast_search2(T.lat, F.gny, F.y0, F.y1, y, c.hy, yi, eta, T.lon, F.gnx, F.x0, F.x1, x, c.hx, xi, xsi);
+        fast_search2(T.lat, T.gny, F.y0, F.y1, y, c.hy, yi, eta, T.lon, T.gnx, F.x0, F.x1, x, c.hx, xi, xsi);
     } else {
-        if (fl & FA_Y) fast_search<true>(T.lat, F.gny, F.y0, F.y1, y, c.hy, yi, eta, (fl & FA_NY2) != 0);
-        if (fl & FA_X) fast_search<true>(T.lon, F.gnx, F.x0, F.x1, x, c.hx, xi, xsi, (fl & FA_NX2) != 0);
+        if (fl & FA_Y) fast_search<true>(T.lat, T.gny, F.y0, F.y1, y, c.hy, yi, eta, (fl & FA_NY2) != 0);
+        if (fl & FA_X) fast_search<true>(T.lon, T.gnx, F.x0, F.x1, x, c.hx, xi, xsi, (fl & FA_NX2) != 0);
     }
     // ravel_index (basegrid.py:83-152): the low 32 bits of the int64 sum are the wrapped 32-bit sum
     c.ei = (int32_t)((uint32_t)xi * F.ex + (uint32_t)yi * F.ey + (uint32_t)zi * F.ez);

@@ -69,7 +69,25 @@ struct CgLds {
     void* fv;              // [fc_fv_lds(CM)][64] of the field dtype + lane
     char* rec_w;           // wave-uniform bases of the same two regions: where the LDS-DMA of CG_DMA lands (it adds lane * size itself)
     char* fv_w;
+    // Scalars of FastC that every cell change / evaluation reads, PINNED in scalar registers by the kernels (cg_pin; see FastTabs::tlen of
+    // pk_fast_agrid.h): round 5's RK45 kernel re-loaded {st_z, st_y, cb, lvl_b} and the table pointer from the kernel-argument segment at
+    // every fetch site -- 14.5 scalar loads per wave-evaluation (profiles/r05f_c5_rk45_pmc.md), each a ~200-cycle `s_waitcnt lgkmcnt(0)`
+    int32_t st_z, st_y, cb;
+    int64_t lvl_b;
+    const double* ct2;
+    double tlen;
 };
+PK_DEV void cg_pin(CgLds& L, const FastC& F) {
+    L.st_z = F.st_z;
+    L.st_y = F.st_y;
+    L.cb = F.cb;
+    L.lvl_b = F.lvl_b;
+    L.ct2 = F.ct2;
+    L.tlen = F.tlen;
+#ifndef PK_NO_PIN
+    asm volatile("" : "+s"(L.st_z), "+s"(L.st_y), "+s"(L.cb), "+s"(L.lvl_b), "+s"(L.ct2), "+s"(L.tlen));
+#endif
+}
 // row k (compile-time) of the record in the lane's slot
 template <int CM>
 PK_DEV double cg_rec_row(const double* rec, int k) {
@@ -123,8 +141,8 @@ PK_DEV void cctx_init(CCtxT<FT, CM>& c, int state, int32_t ei, int gy, int gx) {
 // Byte offsets (b0, b1) of cell element `e` inside the ring slots of levels ti and ti+1 (slot_off of pk_device.h).  A ring needs
 // `level % nslots`: the level is wave-uniform unless particles of one wavefront sit on different levels, so the modulo runs on the
 // scalar unit, once per distinct level of the wavefront (readfirstlane waterfall); every lane keeps the offsets of ITS level.
-PK_DEV void cg_level_offsets(const FastC& F, uint32_t e, int ti, int64_t& b0, int64_t& b1) {
-    const int64_t vb = (int64_t)((uint64_t)e * (uint64_t)(uint32_t)F.cb);
+PK_DEV void cg_level_offsets(const FastC& F, const CgLds& L, uint32_t e, int ti, int64_t& b0, int64_t& b1) {
+    const int64_t vb = (int64_t)((uint64_t)e * (uint64_t)(uint32_t)L.cb);
     int64_t o0 = 0, o1 = 0;
     for (bool done = false; !done;) {
         const int uti = uniform_i32(ti);
@@ -133,7 +151,7 @@ PK_DEV void cg_level_offsets(const FastC& F, uint32_t e, int ti, int64_t& b0, in
             s0 = (int)((uint32_t)s0 % (uint32_t)F.nslots);
             s1 = (int)((uint32_t)s1 % (uint32_t)F.nslots);
         }
-        const int64_t u0 = (int64_t)s0 * F.lvl_b, u1 = (int64_t)s1 * F.lvl_b;  // derived from the uniform level BEFORE the lane test
+        const int64_t u0 = (int64_t)s0 * L.lvl_b, u1 = (int64_t)s1 * L.lvl_b;  // derived from the uniform level BEFORE the lane test
         if (ti == uti) {
             o0 = u0;
             o1 = u1;
@@ -146,8 +164,8 @@ PK_DEV void cg_level_offsets(const FastC& F, uint32_t e, int ti, int64_t& b0, in
 // Fetch the ct2 record of `cell` into the lane's LDS slot -- and, WITH_F, the staggered field values of (zi, yi, xi) at level ti
 // (and ti+1 if lenT) in the same memory round trip.  Returns the packed quantised box of the cell (row 15).
 template <class FT, bool D3>
-PK_DEV void cg_issue_fields(const FastC& F, int zi, int yi, int xi, int ti, bool lenT, FT raw[12]) {
-    const uint32_t e = (uint32_t)zi * (uint32_t)F.st_z + (uint32_t)yi * (uint32_t)F.st_y + (uint32_t)xi;  // < 2^31 elements per level (host check)
+PK_DEV void cg_issue_fields(const FastC& F, const CgLds& L, int zi, int yi, int xi, int ti, bool lenT, FT raw[12]) {
+    const uint32_t e = (uint32_t)zi * (uint32_t)L.st_z + (uint32_t)yi * (uint32_t)L.st_y + (uint32_t)xi;  // < 2^31 elements per level (host check)
     if constexpr (!D3) {
         // (F.vp: wave-uniform) the cell-packed pair copy: both levels of the cell in one 8-value group.
         // pair L holds levels (L, L + 1); a sample exactly on the highest resident level (tau == 0: !lenT) has no pair of its own
@@ -190,7 +208,7 @@ PK_DEV void cg_issue_fields(const FastC& F, int zi, int yi, int xi, int ti, bool
         }
     }
     int64_t b0, b1;
-    cg_level_offsets(F, e, ti, b0, b1);
+    cg_level_offsets(F, L, e, ti, b0, b1);
     raw[0] = *reinterpret_cast<const FT*>(F.U + F.dU0 + b0);
     raw[1] = *reinterpret_cast<const FT*>(F.U + F.dU1 + b0);
     raw[2] = *reinterpret_cast<const FT*>(F.V + F.dV0 + b0);
@@ -214,11 +232,12 @@ PK_DEV void cg_issue_fields(const FastC& F, int zi, int yi, int xi, int ti, bool
 // interpolation reads.  Slots the register path zero-fills (W in the 2-D kernels, level ti+1 of a sample ON a level) stay as they are:
 // the readers never use them (eval_uvw_cgrid reads 6..11 only if lenT, and W only if D3).
 template <class FT, bool D3>
-PK_DEV void cg_issue_fields_dma(const FastC& F, char* fv_w, int zi, int yi, int xi, int ti, bool lenT) {
+PK_DEV void cg_issue_fields_dma(const FastC& F, const CgLds& L, int zi, int yi, int xi, int ti, bool lenT) {
     static_assert(sizeof(FT) == 4, "LDS-DMA moves 4, 12 or 16 bytes per lane");
-    const uint32_t e = (uint32_t)zi * (uint32_t)F.st_z + (uint32_t)yi * (uint32_t)F.st_y + (uint32_t)xi;
+    char* const fv_w = L.fv_w;
+    const uint32_t e = (uint32_t)zi * (uint32_t)L.st_z + (uint32_t)yi * (uint32_t)L.st_y + (uint32_t)xi;
     int64_t b0, b1;
-    cg_level_offsets(F, e, ti, b0, b1);
+    cg_level_offsets(F, L, e, ti, b0, b1);
     cg_dma4(F.U + F.dU0 + b0, fv_w + 0 * 256);
     cg_dma4(F.U + F.dU1 + b0, fv_w + 1 * 256);
     cg_dma4(F.V + F.dV0 + b0, fv_w + 2 * 256);
@@ -262,7 +281,7 @@ template <class FT, bool D3, int CM, bool WAIT>
 PK_DEV void cg_refresh_fields(const FastC& F, const CgLds& L, CCtxT<FT, CM>& c, int cell, int zi, int yi, int xi, int ti, bool lenT) {
     if constexpr ((CM & CG_DMA) != 0 && !(CM & CG_FV_REGS) && sizeof(FT) == 4) {
         if (D3 || !F.vp) {  // (F.vp: wave-uniform; the opt-in pair copies keep the register path)
-            cg_issue_fields_dma<FT, D3>(F, L.fv_w, zi, yi, xi, ti, lenT);
+            cg_issue_fields_dma<FT, D3>(F, L, zi, yi, xi, ti, lenT);
             if (WAIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             c.fv_cell = cell;
             c.fv_zt = (ti << 13) | (zi << 1) | (lenT ? 1 : 0);
@@ -270,13 +289,13 @@ PK_DEV void cg_refresh_fields(const FastC& F, const CgLds& L, CCtxT<FT, CM>& c, 
         }
     }
     FT raw[12];
-    cg_issue_fields<FT, D3>(F, zi, yi, xi, ti, lenT, raw);
+    cg_issue_fields<FT, D3>(F, L, zi, yi, xi, ti, lenT, raw);
     cg_store_fields<FT, CM>(c, L, cell, zi, ti, lenT, raw);
 }
 
 template <class FT, bool D3, bool WITH_F, int CM>
 PK_DEV double cg_fetch_cell(const FastC& F, const CgLds& L, CCtxT<FT, CM>& c, int cell, int yi, int xi, int zi, int ti, bool lenT) {
-    const double* g = F.ct2 + (int64_t)cell * CT2_STRIDE;
+    const double* g = L.ct2 + (int64_t)cell * CT2_STRIDE;
     if constexpr ((CM & CG_DMA) != 0) {
         // record rows 0..15 (and 16..23 unless they live in registers / stay in the table) as 16-byte pairs straight into the slot
         constexpr int NP = fc_rec_rows(CM) / 2;
@@ -305,7 +324,7 @@ PK_DEV double cg_fetch_cell(const FastC& F, const CgLds& L, CCtxT<FT, CM>& c, in
         FT raw[12];
         const bool wantf = WITH_F && zi >= 0 && !cg_fields_cached(c, cell, zi, ti, lenT);
         if (WITH_F) {
-            if (wantf) cg_issue_fields<FT, D3>(F, zi, yi, xi, ti, lenT, raw);
+            if (wantf) cg_issue_fields<FT, D3>(F, L, zi, yi, xi, ti, lenT, raw);
         }
         double* rec = L.rec;
 #pragma unroll
@@ -450,7 +469,7 @@ PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtxT<FT, CM>& c, dou
     int ti = 0;
     double tau = 0.0;
     if (scalar ? F.kh_has_ti[ks] != 0 : F.has_ti != 0) {  // _search_time_index (index_search.py:65-91); (it, klo): pk_device.h, twe_note
-        if (__builtin_expect(!(0 <= t) || !(t <= F.tlen), 0)) {
+        if (__builtin_expect(!(0 <= t) || !(t <= L.tlen), 0)) {
             c.state = PK_ERROROUTSIDETIMEINTERVAL;
             twe_note(a, it, klo);
             return;
@@ -579,7 +598,7 @@ PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtxT<FT, CM>& c, dou
     // ---- CGrid_Velocity.interp (_xinterpolators.py:193-332), float64 coordinates and barycentric arrays ----
     double px[4], py[4];
     if constexpr ((CM & CG_PXY_GLOBAL) != 0) {
-        const double* g = F.ct2 + (int64_t)cell * CT2_STRIDE + 16;
+        const double* g = L.ct2 + (int64_t)cell * CT2_STRIDE + 16;
         ldpair(g, px[0], px[1]);
         ldpair(g + 2, px[2], px[3]);
         ldpair(g + 4, py[0], py[1]);

@@ -716,6 +716,7 @@ __global__ void __launch_bounds__(256, PK_MIN_WAVES_FAST) advect_fast_kernel(con
         ft.lat = s_tab + a.fast.lds_lat;
         ft.lon = s_tab + a.fast.lds_lon;
         ft.blk = s_tab + a.fast.lds_blk + threadIdx.x;  // (read only where lds_blk != 0)
+        pin_scalars(ft, a.fast);
         ft.fl = fast_flags(a.fast) | ((a.win_lo > -INFINITY || a.win_hi < INFINITY) ? FA_WIN : 0u) | (a.prm.dt0 > 0 ? FA_FWD : 0u) |
                 (a.prm.max_iters > 0 ? FA_MAXIT : 0u);
     }
@@ -888,6 +889,7 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID) advect_cgrid_ker
         L.fv = (void*)((FT*)(smem + F.lds_fv) + threadIdx.x);
         L.rec_w = reinterpret_cast<char*>(smem + F.lds_rec);
         L.fv_w = reinterpret_cast<char*>(smem + F.lds_fv);
+        cg_pin(L, F);
     }
     auto row = [&]() { return (int64_t)xcd_swizzle(blockIdx.x, gridDim.x) * FC_LANES + threadIdx.x; };
     unsigned steps = 0, attempts = 0, paused = 0;
@@ -1036,6 +1038,7 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID_RK45) advect_cgri
         L.fv = (void*)((FT*)(smem + F.lds_fv) + threadIdx.x);
         L.rec_w = reinterpret_cast<char*>(smem + F.lds_rec);
         L.fv_w = reinterpret_cast<char*>(smem + F.lds_fv);
+        cg_pin(L, F);
     }
     auto row = [&]() { return (int64_t)xcd_swizzle(blockIdx.x, gridDim.x) * FC_LANES + threadIdx.x; };
     unsigned steps = 0, attempts = 0, paused = 0;
@@ -1209,6 +1212,7 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID_M1) advect_cgrid_
         L.fv = (void*)((FT*)(smem + F.lds_fv) + threadIdx.x);
         L.rec_w = reinterpret_cast<char*>(smem + F.lds_rec);
         L.fv_w = reinterpret_cast<char*>(smem + F.lds_fv);
+        cg_pin(L, F);
     }
     auto row = [&]() { return (int64_t)xcd_swizzle(blockIdx.x, gridDim.x) * FC_LANES + threadIdx.x; };
     unsigned steps = 0, attempts = 0, paused = 0;

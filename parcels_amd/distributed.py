@@ -63,6 +63,30 @@ def allreduce_scalars(values, op: str, group=None, device=None) -> list:
     return t.cpu().tolist()
 
 
+def ensure_comm(engine, group=None) -> bool:
+    """The engine's context joins the library's OWN RCCL communicator for this process group (include/parcels_hip.h: pk_comm_init), so that
+    the write-out exchange and the batch agreements run through the C ABI instead of torch.distributed: rank 0 draws the 128-byte id
+    (pk_comm_unique_id), torch's group only carries it to the others -- any host channel would do.  True when the C-ABI exchange is
+    available; False under gloo (the CPU tests), with a stand-in engine, or with PARCELS_AMD_TORCH_EXCHANGE=1 (the round 1-5 path)."""
+    import os
+
+    import torch.distributed as dist
+
+    if engine is None or not hasattr(engine, "comm_init") or os.environ.get("PARCELS_AMD_TORCH_EXCHANGE") == "1":
+        return False
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_backend(group) != "nccl":
+        return False
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if getattr(engine, "comm", None) == (rank, world):
+        return True
+    if getattr(engine, "comm", None) is not None:
+        engine.comm_destroy()
+    box = [engine.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    engine.comm_init(rank, world, box[0])
+    return True
+
+
 class CollectiveAbort(RuntimeError):
     """Raised on the ranks of a collective run whose pass went fine when ANOTHER rank's pass raised (batch_agreement: agree_min)."""
 
@@ -125,7 +149,7 @@ def clear_abort() -> None:
             pass
 
 
-def batch_agreement(group=None, device=None):
+def batch_agreement(group=None, device=None, engine=None):
     """The two hooks that make a sharded ParticleSet ONE batch for the batch-wide rules of ``Kernel.execute`` (DeviceEngine.execute):
 
     * ``agree_min(first_error_iter, first_time_error_key)`` -> the smallest non-zero value of each over all ranks (0 = none anywhere):
@@ -144,6 +168,15 @@ def batch_agreement(group=None, device=None):
     big = (1 << 62)
     import time as _time
 
+    cabi = ensure_comm(engine, group)  # the all-reduces below through pk_comm_allreduce_i64 (RCCL inside the library) when available
+
+    def _allreduce(values, op):
+        if cabi:
+            return [int(v) for v in engine.comm_allreduce(values, op)]
+        t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op={"min": dist.ReduceOp.MIN, "max": dist.ReduceOp.MAX}[op], group=group)
+        return [int(v) for v in t.tolist()]
+
     # what the lock-step points cost: calls and wall seconds spent inside the two all-reduces (including the wait for the slowest rank);
     # ParticleSet.execute copies it to `pset._agreement_stats`, bench.py --c4 prints it
     stats = {"calls": 0, "seconds": 0.0}
@@ -154,9 +187,7 @@ def batch_agreement(group=None, device=None):
         if not failed:
             check_abort()
         t0 = _time.perf_counter()
-        t = torch.tensor([int(err) or big, int(key) or big, 0 if failed else 1], dtype=torch.int64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
-        e, k, ok = (int(v) for v in t.tolist())
+        e, k, ok = _allreduce([int(err) or big, int(key) or big, 0 if failed else 1], "min")
         stats["calls"] += 1
         stats["seconds"] += _time.perf_counter() - t0
         if not ok and not failed:
@@ -165,9 +196,7 @@ def batch_agreement(group=None, device=None):
 
     def agree_codes(present):
         t0 = _time.perf_counter()
-        t = torch.tensor([int(bool(p)) for p in present], dtype=torch.int64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-        out = [int(v) for v in t.tolist()]
+        out = _allreduce([int(bool(p)) for p in present], "max")
         stats["calls"] += 1
         stats["seconds"] += _time.perf_counter() - t0
         return out
@@ -209,6 +238,7 @@ def batch_agreement(group=None, device=None):
 
     agree_min.keys = agree_keys
     agree_min.stats = agree_codes.stats = stats
+    agree_min.transport = "c-abi" if cabi else "torch"
     return agree_min, agree_codes
 
 
@@ -352,7 +382,13 @@ def device_output_columns(engine) -> dict:
     return device_columns(engine, ("t", "z", "y", "x", "particle_id"))[0]
 
 
-def allgather_output(engine, world: int, group=None) -> dict:
-    """The write-out exchange of the north star: RCCL all-gather of the output columns of every rank."""
+def allgather_output(engine, world: int, group=None, fetch=True):
+    """The write-out exchange of the north star: RCCL all-gather of the output columns of every rank -- through the C ABI
+    (pk_allgather_output; fetch=False leaves the gathered rows in the library's device staging and returns the per-rank counts) when the
+    library's communicator is available, else over torch.distributed."""
+    names = ["t", "z", "y", "x", "particle_id"]
+    if ensure_comm(engine, group):
+        out = engine.gather_rows(names, 0.0, apply_filter=False, to_all=True, fetch=fetch)
+        return out if fetch else {"counts": engine.comm_last_counts}
     cols = device_output_columns(engine)
     return gather_output_columns(cols, group)

@@ -100,6 +100,9 @@ class DeviceEngine:
         self._sorted_t = None  # model time at which the device rows were last cell-sorted (None: host order / unknown)
         # what crossed PCIe for the particle columns: calls and column counts (tests and bench.py's `repeat_execute` leg read it)
         self.transfers = {"h2d_full": 0, "h2d_columns": 0, "d2h_full": 0, "d2h_columns": 0, "columns_up": 0, "columns_down": 0}
+        self.comm = None  # (rank, world) once the context has joined an RCCL communicator (comm_init)
+        self.comm_stats = {"gathers": 0, "allreduces": 0}
+        self.comm_last_counts = None
         self._next_dt_f32 = None
         self.device_variables: list[str] = []  # user Variables bound as extra device columns (set by Kernel: SampleField targets)
         # a sharded ParticleSet is one batch: hooks of parcels_amd.distributed.batch_agreement (set by ParticleSet.execute for a collective run)
@@ -556,16 +559,86 @@ class DeviceEngine:
             else:
                 b._stale -= set(columns)
 
+    # ---- the multi-GPU exchange through the C ABI (csrc/pk_comm.inc: RCCL opened by the library) -------------------
+    def comm_init(self, rank: int, world: int, unique_id: bytes):
+        """pk_comm_init: this engine's context joins a communicator of `world` ranks (the 128-byte id: comm_unique_id() of one rank)."""
+        buf = (C.c_uint8 * _hip.PK_COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        self.ctx.check(self.lib.pk_comm_init(self.ctx.handle, int(rank), int(world), buf), "pk_comm_init")
+        self.comm = (int(rank), int(world))
+
+    def comm_unique_id(self) -> bytes:
+        buf = (C.c_uint8 * _hip.PK_COMM_ID_BYTES)()
+        rc = self.lib.pk_comm_unique_id(buf)
+        if rc != 0:
+            msg = self.lib.pk_last_error(None)
+            raise _hip.HipLibraryError(f"pk_comm_unique_id failed: {msg.decode() if msg else rc}")
+        return bytes(buf)
+
+    def comm_destroy(self):
+        if getattr(self, "comm", None) is not None:
+            self.lib.pk_comm_destroy(self.ctx.handle)
+            self.comm = None
+
+    def comm_allreduce(self, values, op: str):
+        """Element-wise min / max / sum of a few int64 over the ranks (pk_comm_allreduce_i64)."""
+        a = np.ascontiguousarray(values, dtype=np.int64).copy()
+        code = {"min": _hip.PK_OP_MIN, "max": _hip.PK_OP_MAX, "sum": _hip.PK_OP_SUM}[op]
+        self.ctx.check(self.lib.pk_comm_allreduce_i64(self.ctx.handle, _ptr(a), len(a), code), "pk_comm_allreduce_i64")
+        self.comm_stats["allreduces"] += 1
+        return a
+
+    def gather_rows(self, names, t, apply_filter=True, to_all=False, fetch=True):
+        """The write-out exchange (include/parcels_hip.h: pk_gather_rows_to_root / pk_allgather_output): the rows of the device-resident
+        columns `names` that pass the reference's write filter at output time `t`, of ALL ranks in rank order -- NumPy arrays on the
+        receiving rank(s), None on the others.  (counts per rank in `self.comm_last_counts`.)"""
+        mask = 0
+        for n in names:
+            bit = self._column_bit(n)
+            if not bit:
+                raise KeyError(f"'{n}' is not a device-resident particle column")
+            mask |= bit
+        world = self.comm[1]
+        counts = np.zeros(world, np.int64)
+        fn = self.lib.pk_allgather_output if to_all else self.lib.pk_gather_rows_to_root
+        self.ctx.check(fn(self.ctx.handle, float(t), int(bool(apply_filter)), mask, _ptr(counts)), "pk_allgather_output" if to_all else "pk_gather_rows_to_root")
+        self.comm_last_counts = counts
+        self.comm_stats["gathers"] += 1
+        if not fetch or (not to_all and self.comm[0] != 0):
+            return None  # (fetch=False: the gathered rows stay in the library's device staging; bench.py times the exchange alone)
+        total = int(counts.sum())
+        b = self._bound
+        raw = b.raw if isinstance(b, LazyColumns) else b.__getitem__  # (dtypes / widths only)
+        out = {}
+        d = _hip.ParticlesDesc()
+        d.n = total
+        for n in names:
+            src = raw(n)
+            out[n] = np.empty((total,) + src.shape[1:], dtype=np.float64 if (n == "next_dt" and src.dtype == np.float32) else src.dtype)
+            if n in _hip.COLUMN_BITS:
+                setattr(d, n, _ptr(out[n]))
+            else:
+                k = self.device_variables.index(n)
+                d.extra[k] = _ptr(out[n])
+        self.ctx.check(self.lib.pk_gathered_fetch(self.ctx.handle, C.byref(d), total), "pk_gathered_fetch")
+        if "next_dt" in out and raw("next_dt").dtype == np.float32:
+            out["next_dt"] = out["next_dt"].astype(np.float32)
+        return out
+
     # ---- asynchronous write-out snapshots ------------------------------------------------------------------------
     _SNAP_COLS = ("t", "z", "y", "x", "dz", "dy", "dx", "dt", "next_dt", "state", "ei", "particle_id")
 
-    def snapshot_begin(self, columns, slot: int):
-        """Enqueue the copy of the named device columns (host row order) into the pinned host set ``slot``; returns at once."""
+    def snapshot_begin(self, columns, slot: int, filter_t=None):
+        """Enqueue the copy of the named device columns (host row order) into the pinned host set ``slot``; returns at once.
+        filter_t: only the rows that pass ParticleFile's write filter at that output time (pk_particles_snapshot_filtered: selected and
+        packed on the device -- the table's rows are all that crosses PCIe)."""
         mask = 0
         for name in columns:
             mask |= self._column_bit(name)
         self._snap_extra = list(self.device_variables)
-        self.ctx.check(self.lib.pk_particles_snapshot_begin(self.ctx.handle, mask, int(slot)), "pk_particles_snapshot_begin")
+        if filter_t is None:
+            self.ctx.check(self.lib.pk_particles_snapshot_begin(self.ctx.handle, mask, int(slot)), "pk_particles_snapshot_begin")
+        else:
+            self.ctx.check(self.lib.pk_particles_snapshot_filtered(self.ctx.handle, mask, int(slot), float(filter_t)), "pk_particles_snapshot_filtered")
         b = self._bound
         raw = b.raw if isinstance(b, LazyColumns) else b.__getitem__  # (dtypes only: no download, no dirty mark)
         self._snap_dtypes = {k: raw(k).dtype for k in b.keys() if k in _hip.COLUMN_BITS or k in self.device_variables}

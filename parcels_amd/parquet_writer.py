@@ -119,9 +119,22 @@ def supports_schema(schema) -> bool:
     return True
 
 
+def _pwrite_all(fd, parts, pos):
+    for b in parts:
+        mv = memoryview(b).cast("B")
+        done = 0
+        while done < len(mv):
+            done += os.pwrite(fd, mv[done:], pos + done)
+        pos += len(mv)
+
+
 class FastParquetWriter:
-    def __init__(self, path, schema, compression="zstd", row_group_rows=1 << 20, threads=None):
-        """schema: the pyarrow schema of the tables (field + file metadata included), as pyarrow.parquet.ParquetWriter takes it."""
+    def __init__(self, path, schema, compression="zstd", row_group_rows=1 << 20, threads=None, page_rows=1 << 17):
+        """schema: the pyarrow schema of the tables (field + file metadata included), as pyarrow.parquet.ParquetWriter takes it.
+        page_rows: rows per data page.  A column chunk of a row group is a run of pages, each compressed on its own -- round 5 wrote ONE page
+        per chunk: a table of 4e6 rows was 20 jobs of 8 MB, so 32 threads were no faster than 8 (31 ms per 160 MB table, 5 GB/s;
+        profiles/r05_m_writeout_4e6.json).  With 1 MB pages the same table is 160 jobs and the pool is busy until the end; the pages of a row
+        group are then written with positional writes from the pool as well (their offsets are known once the group is compressed)."""
         import pyarrow as pa
 
         if compression not in _CODEC:
@@ -130,15 +143,17 @@ class FastParquetWriter:
         self.compression = None if compression in (None, "none") else compression
         self.codec = _ARROW_CODEC[self.compression] if self.compression else None  # (one pyarrow.Codec object must not be shared by threads)
         self.row_group_rows = int(row_group_rows)
+        self.page_rows = max(int(page_rows), 1024)
         self.names = [f.name for f in schema]
         self.np_dtypes = [np.dtype(f.type.to_pandas_dtype()) for f in schema]
         self.store = [_STORE[str(dt)] for dt in self.np_dtypes]
-        self.f = open(path, "wb")
+        self.f = open(path, "wb", buffering=0)
         self.f.write(b"PAR1")
         self.pos = 4
+        self.seconds = {"compress_wait": 0.0, "file_write": 0.0}  # where write_columns spent its wall time (bench_writeout.py prints it)
         self.row_groups = []  # encoded RowGroup structs
         self.num_rows = 0
-        nthreads = threads or min(32, os.cpu_count() or 1)
+        nthreads = threads or min(64, os.cpu_count() or 1)
         self.pool = ThreadPoolExecutor(max_workers=nthreads, thread_name_prefix="parquet-encode")
 
     # One data page (DataPageV2) of one column chunk: the definition levels (all 1: one RLE run) stay uncompressed in front, the PLAIN
@@ -177,24 +192,36 @@ class FastParquetWriter:
             cols.append(a)
         if not n:
             return
+        import time as _time
+
         starts = list(range(0, n, self.row_group_rows))
         jobs = {}
         for g, lo in enumerate(starts):
             hi = min(lo + self.row_group_rows, n)
             for c, a in enumerate(cols):
-                jobs[(g, c)] = self.pool.submit(self._page, a[lo:hi], self.store[c][0])
+                for p, plo in enumerate(range(lo, hi, self.page_rows)):
+                    jobs[(g, c, p)] = self.pool.submit(self._page, a[plo:min(plo + self.page_rows, hi)], self.store[c][0])
+        fd = self.f.fileno()
+        writes = []
         for g, lo in enumerate(starts):
             hi = min(lo + self.row_group_rows, n)
             chunks = []
             total_unc = total_comp = 0
             rg_start = self.pos
             for c, name in enumerate(self.names):
-                head, comp, unc_size, nv = jobs.pop((g, c)).result()
                 off = self.pos
-                self.f.write(head)
-                self.f.write(comp)
-                size = len(head) + len(comp)
-                self.pos += size
+                unc_size = size = nv = 0
+                for p in range(len(range(lo, hi, self.page_rows))):
+                    t0 = _time.perf_counter()
+                    head, comp, unc_p, nv_p = jobs.pop((g, c, p)).result()
+                    self.seconds["compress_wait"] += _time.perf_counter() - t0
+                    # positional writes from the pool: the page cache copy of a 100 MB table does not serialise behind one thread
+                    writes.append(self.pool.submit(_pwrite_all, fd, (head, comp), self.pos))
+                    psize = len(head) + len(comp)
+                    self.pos += psize
+                    size += psize
+                    unc_size += unc_p
+                    nv += nv_p
                 md = (_Struct().i32(1, _TYPE[self.store[c][0]]).list_(2, 5, [_zigzag(0), _zigzag(3)]).list_(3, 8, [_bin(name)])
                       .i32(4, _CODEC[self.compression]).i64(5, nv).i64(6, unc_size).i64(7, size).i64(9, off))
                 chunks.append(_Struct().i64(2, off + size).struct(3, md).done())
@@ -202,6 +229,10 @@ class FastParquetWriter:
                 total_comp += size
             rg = _Struct().list_(1, 12, chunks).i64(2, total_unc).i64(3, hi - lo).i64(5, rg_start).i64(6, total_comp)
             self.row_groups.append(rg.done())
+        t0 = _time.perf_counter()
+        for w in writes:
+            w.result()
+        self.seconds["file_write"] += _time.perf_counter() - t0
         self.num_rows += n
 
     def close(self):
@@ -219,9 +250,7 @@ class FastParquetWriter:
             kv.append(_Struct().binary(1, k).binary(2, v).done())
         meta = (_Struct().i32(1, 2).list_(2, 12, elems).i64(3, self.num_rows).list_(4, 12, self.row_groups).list_(5, 12, kv)
                 .binary(6, "parcels_amd FastParquetWriter").done())
-        self.f.write(meta)
-        self.f.write(struct.pack("<I", len(meta)))
-        self.f.write(b"PAR1")
+        _pwrite_all(self.f.fileno(), (meta, struct.pack("<I", len(meta)), b"PAR1"), self.pos)
         self.f.close()
         self.f = None
         self.pool.shutdown(wait=True)

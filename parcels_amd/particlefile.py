@@ -7,6 +7,7 @@ which ``Kernel.execute`` refreshes from the device at every output interval.
 
 from __future__ import annotations
 
+import os
 from datetime import timedelta
 from pathlib import Path
 
@@ -155,6 +156,11 @@ class ParticleFile:
         from .columns import readonly
 
         fieldset = fieldset or pset.fieldset
+        if indices is None and getattr(pset, "_prefiltered", False) and not self._collective:
+            # a snapshot whose rows already passed the write filter on the device (_AsyncWriter / pk_particles_snapshot_filtered)
+            names = [v.name for v in _get_vars_to_write(pset._pclass)]
+            self.write_columns(pset._pclass, {k: pset._data[k] for k in names}, fieldset.time_interval)
+            return
         data = readonly(pset._data)  # (reads only: a device-resident set downloads the columns touched here and stays clean)
         if isinstance(t, (np.timedelta64, np.datetime64)):
             t = to_seconds(t - fieldset.time_interval.left)
@@ -168,7 +174,19 @@ class ParticleFile:
             eng = getattr(fieldset, "_engine", None)
             cols = None
             if indices is None and getattr(pset, "_device_rows_current", False) and eng is not None and self._device_gather_ok(eng, names):
-                # the columns are device-resident (ParticleSet.execute): filter there, send the device rows -- no D2H / H2D round trip
+                # the columns are device-resident (ParticleSet.execute): filter there, send the device rows -- no D2H / H2D round trip.
+                # Through the C ABI when the library's own communicator is up (pk_gather_rows_to_root: filter, pack, count exchange and
+                # row exchange inside libparcels_hip.so, RCCL over xGMI), else the same steps over torch.distributed
+                from .distributed import check_abort, ensure_comm
+
+                if ensure_comm(eng, self._group):
+                    check_abort()
+                    cols = eng.gather_rows(names, float(t))
+                    self.gather_seconds += _time.perf_counter() - t0
+                    if cols is None:
+                        return
+                    self.write_columns(pset._pclass, cols, fieldset.time_interval)
+                    return
                 cols = device_write_rows(eng, names, float(t))
             if cols is None:
                 idx = _to_write_particles(data, t) if indices is None else indices  # the reference's filter, applied BEFORE the exchange
@@ -203,6 +221,7 @@ class ParticleFile:
     def close(self):
         if self._writer is not None:
             self._writer.close()
+            self.writer_seconds = dict(getattr(self._writer, "seconds", {}) or {})  # FastParquetWriter: waiting for page compression / for the file writes
             self._writer = None
 
     def __enter__(self):
@@ -215,8 +234,8 @@ class ParticleFile:
 class _SnapshotView:
     """What ParticleFile.write needs of a ParticleSet, over one snapshot of the columns."""
 
-    def __init__(self, data, pclass, fieldset):
-        self._data, self._pclass, self.fieldset = data, pclass, fieldset
+    def __init__(self, data, pclass, fieldset, prefiltered=False):
+        self._data, self._pclass, self.fieldset, self._prefiltered = data, pclass, fieldset, prefiltered
 
 
 class _AsyncWriter:
@@ -234,13 +253,29 @@ class _AsyncWriter:
         self.pending = [None, None]
         self.slot = 0
         self.encode_seconds = 0.0
+        self.block_seconds = 0.0
+        self.wait_seconds = 0.0  # writer thread: waiting for a snapshot's D2H (the rest of its time is filter + encode + file)
 
     def submit(self, data, t):
         slot = self.slot
         self.slot ^= 1
         if self.pending[slot] is not None:  # its pinned columns are about to be reused
+            import time as _time
+
+            t0 = _time.perf_counter()
             self.pending[slot].result()
-        self.engine.snapshot_begin(self.cols, slot)
+            self.block_seconds += _time.perf_counter() - t0  # the launching thread waited for the writer: write-out NOT hidden
+        # the write filter runs on the device when every to-write Variable is a device column (the default Particle classes): only the rows
+        # of the table cross PCIe and the writer thread encodes them as they are.  With host-only Variables to write, the rows must be chosen
+        # on the host, where those live: the full snapshot and NumPy's filter
+        pclass = getattr(self.pset, "_pclass", None)
+        names = [v.name for v in _get_vars_to_write(pclass)] if pclass is not None else None
+        on_device = (names is not None and all(c in self.cols for c in names) and {"t", "dt"} <= set(self.cols)
+                     and os.environ.get("PARCELS_AMD_HOST_WRITE_FILTER") != "1")
+        if on_device:
+            self.engine.snapshot_begin(self.cols, slot, filter_t=float(t))
+        else:
+            self.engine.snapshot_begin(self.cols, slot)
         # host-only Variables: a device kernel list replaces them (compaction), never mutates them -- the writer thread may read the arrays
         # themselves.  With Python kernels on the host path (hostkernels.execute_hosted: `particles.age += particles.dt` works IN PLACE on
         # these very arrays during the next interval) the table needs its own copy, or it would pair this output time's t / x / y with
@@ -250,16 +285,19 @@ class _AsyncWriter:
 
         host_only = {k: (np.array(v, copy=True) if mutable else v) for k, v in raw_items(data)
                      if k not in self.engine._SNAP_COLS and k not in self.engine.device_variables}
-        self.pending[slot] = self.pool.submit(self._task, slot, host_only, float(t))
+        self.pending[slot] = self.pool.submit(self._task, slot, host_only, float(t), on_device)
 
-    def _task(self, slot, host_only, t):
+    def _task(self, slot, host_only, t, prefiltered=False):
         import time as _time
 
-        cols = self.engine.snapshot_wait(slot)
         t0 = _time.perf_counter()
-        cols.update(host_only)
-        self.pfile.write(_SnapshotView(cols, self.pset._pclass, self.pset.fieldset), t)
-        self.encode_seconds += _time.perf_counter() - t0
+        cols = self.engine.snapshot_wait(slot)
+        t1 = _time.perf_counter()
+        self.wait_seconds += t1 - t0
+        if not prefiltered:
+            cols.update(host_only)
+        self.pfile.write(_SnapshotView(cols, self.pset._pclass, self.pset.fieldset, prefiltered=prefiltered), t)
+        self.encode_seconds += _time.perf_counter() - t1
 
     def drain(self):
         for k in (self.slot, self.slot ^ 1):  # oldest first

@@ -377,7 +377,7 @@ class ParticleSet:
             # lock-step -- every rank makes every interval -- which is what lets an agreement sit inside it.)
             from .distributed import batch_agreement
 
-            engine.agree_min, engine.agree_codes = batch_agreement(output_file._group, engine.device)
+            engine.agree_min, engine.agree_codes = batch_agreement(output_file._group, engine.device, engine=engine)
         try:
             with output_file if output_file is not None else nullcontext():  # the Parquet footer is written on error too
                 try:
@@ -477,7 +477,11 @@ class ParticleSet:
                     # pending tables are encoded BEFORE the file is closed (also when a kernel raised: the footer then covers
                     # every table submitted so far)
                     if writer is not None:
-                        writer.close()
+                        try:
+                            writer.close()
+                        finally:  # (where the write-out went: bench.py / tools/bench_writeout.py print it)
+                            self._last_writer_stats = {"snapshot_wait_s": getattr(writer, "wait_seconds", None), "filter_encode_file_s": getattr(writer, "encode_seconds", None),
+                                                       "submit_block_s": getattr(writer, "block_seconds", None)}
         finally:
             if getattr(engine, "agree_min", None) is not None:
                 self._agreement_stats = dict(getattr(engine.agree_min, "stats", {}) or {})  # calls / seconds inside the batch agreements of this execute

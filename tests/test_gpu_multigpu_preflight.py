@@ -78,8 +78,9 @@ def test_batch_agreements_run_over_rccl(gpu, rccl_world1, tmp_path, name):
     calls = {"min": 0, "codes": 0}
     real = pd.batch_agreement
 
-    def counting(group=None, device=None):
-        amin, acodes = real(group, device)
+    def counting(group=None, device=None, engine=None):
+        amin, acodes = real(group, device, engine=engine)
+        assert amin.transport == "c-abi"  # (the all-reduces run through pk_comm_allreduce_i64: RCCL inside the library)
 
         def m(e, k):
             calls["min"] += 1

@@ -23,7 +23,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert sorted(_hip.ABI_SYMBOLS) == declared
     for sym in declared:
         assert hasattr(lib, sym), f"libparcels_hip.so does not export {sym}"
-    assert lib.pk_abi_version() == _hip.PK_ABI_VERSION == 8
+    assert lib.pk_abi_version() == _hip.PK_ABI_VERSION == 9
 
 
 def test_ctypes_structs_match_header_layout(tmp_path):
