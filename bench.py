@@ -357,7 +357,7 @@ def secondary_runs(args):
             ab = algo[r["kernels"]]
             e = {"config": config, "workload": f"{config.upper()}: curvilinear C-grid {r['grid'][0]}x{r['grid'][1]}x{r['grid'][2]} f32 U,V,W, "
                                                f"{r['nslots']}-slot ring, {r['particles']} fp64 particles, {r['kernels']} + DeleteParticle, 24 steps of 3600 s",
-                 "kernels": r["kernels"], "particle_steps": r["particle_steps"], "attempts": r["attempts"], "kernel_ms": r["kernel_ms"],
+                 "kernels": r["kernels"], "particles": r["particles"], "particle_steps": r["particle_steps"], "attempts": r["attempts"], "kernel_ms": r["kernel_ms"],
                  "kernel_ms_stats": r.get("kernel_ms_stats"), "sclk_mhz": r.get("sclk_mhz"),
                  "value": r["particle_steps_per_s_kernel"], "unit": "particle-steps/s (kernel time, levels resident)",
                  "cell_sort_ms": r["sort_ms"], "wall_s_incl_h2d_d2h": r["wall_s"],
@@ -383,9 +383,43 @@ def secondary_runs(args):
             if r.get("check"):
                 c = r["check"]
                 e["check"] = {"passed": True, "n_check": c["n_check"], "deleted": c["deleted"], "exact": c["exact"],
-                              "max_abs_diff": c["max_abs_diff"], "tolerance": c["tolerance"], "oracle_s": c["oracle_s"]}
+                              "max_abs_diff": c["max_abs_diff"], "tolerance": c["tolerance"], "oracle_s": c["oracle_s"],
+                              "oracle_hash_table": c.get("oracle_hash_table")}
             out.append(e)
         out[-1]["total_s"] = time.perf_counter() - t0
+    # The attainable roof of the kernel furthest from its roofline: tools/gather_roof -- the access pattern of the RK45
+    # kernel WITHOUT its arithmetic at the same residency (cell changes with probability 0.141 per lane-evaluation, six dependent 128-byte
+    # lines each, 88 + 96 B of state) -- run here on the same GPU, after the product's fields were released
+    gr = os.path.join(ROOT, "tools", "gather_roof")
+    if args.secondary_scale == 1.0:
+        import gc
+        import subprocess
+
+        if not os.path.exists(gr):  # (normally built by __graft_entry__.build(); hipcc is on the GPU box too)
+            subprocess.run(["bash", os.path.join(ROOT, "tools", "build_gather_roof.sh")], capture_output=True, timeout=300)
+        gc.collect()
+        for e in out:
+            if e.get("kernels") != "AdvectionRK45" or not os.path.exists(gr):
+                continue
+            try:
+                units = e["roofline"]["units"]
+                per_particle = max(int(round(units / e["particles"])) if e.get("particles") else 5, 1)
+                res = {}
+                for label, alu in (("memory_only", 0), ("with_1000_dependent_fp64_fma_per_evaluation", 1000)):
+                    txt = subprocess.run([gr, "--particles", str(int(args.secondary_particles)), "--attempts", str(per_particle), "--alu", str(alu)],
+                                         capture_output=True, text=True, timeout=300).stdout.strip().split("\n")[-1]
+                    res[label] = json.loads(txt)
+                m = res["memory_only"]
+                att_ms = m["ms_per_launch_median"] * units / m["attempts"]  # scaled to this launch's number of attempts
+                e["roofline"]["attainable"] = {
+                    "what": "tools/gather_roof.hip: the kernel's access pattern without its arithmetic, same GPU, same residency (12 one-wavefront workgroups per CU)",
+                    "ms_for_this_launch": att_ms, "GBps_algorithmic": e["roofline"]["algorithmic_bytes_per_unit"] * units / (att_ms * 1e-3) / 1e9,
+                    "frac_of_peak": e["roofline"]["algorithmic_bytes_per_unit"] * units / (att_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                    "kernel_ms_over_attainable_ms": e["kernel_ms"] / att_ms, "runs": res,
+                    "reading": "the memory side alone would allow frac_of_peak; the kernel's distance from it is arithmetic (fp64 VALU issue + dependent "
+                               "latency at 3 waves per SIMD), not bandwidth"}
+            except Exception as ex:  # the bench line must survive a failing side measurement
+                e["roofline"]["attainable"] = {"error": repr(ex)[:500]}
     return out
 
 

@@ -39,7 +39,10 @@ PK_DEV void pin_scalars(FastTabs& T, const FastA& F) {
     T.tlen = F.tlen;
     T.gny = F.gny;
     T.gnx = F.gnx;
+#ifdef PK_FAST_PIN  // measured (profiles/r06c_*): the pinned build is no faster than the one that re-loads them (7.92-7.97 vs 7.60-7.63 ms on
+                    // two boxes whose round-5 baselines differ by 2 %: within noise or slightly worse) -- off
     asm volatile("" : "+s"(T.tlen), "+s"(T.gny), "+s"(T.gnx));
+#endif
 }
 // The wave-uniform booleans of an evaluation as bits of ONE scalar register.  Kept as separate loop-invariant i1 values the compiler
 // holds each of them as a 64-bit lane mask (`s_cselect_b64 -1, 0`): two SGPRs per question, 46 SGPRs spilled to VGPR lanes in round 5's

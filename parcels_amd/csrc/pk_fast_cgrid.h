@@ -47,7 +47,9 @@ constexpr int CT2_STRIDE = 32;
 // of rows, [pair][lane][2] (the test reads them back with 16-byte LDS reads), and row 15 -- the quantised box -- lives there too; the
 // field values keep their [k][lane] layout (4-byte DMA).  Same values from the same addresses: same bits.  Lanes outside the exec mask
 // neither load nor write, so the slots of the lanes that stayed in their cell are untouched.
-constexpr int CG_FV_REGS = 1, CG_PXY_REGS = 2, CG_PXY_GLOBAL = 4, CG_DMA = 8;
+// Bit 4 (CG_PIN): the scalars of FastC that every cell change reads are pinned in scalar registers (cg_pin).  Bit 5 (CG_NO_TMEMO): no memo
+// of the last time searched -- AdvectionRK45's six stage times are all different, the memo never hits there and costs two registers.
+constexpr int CG_FV_REGS = 1, CG_PXY_REGS = 2, CG_PXY_GLOBAL = 4, CG_DMA = 8, CG_PIN = 16, CG_NO_TMEMO = 32;
 constexpr int fc_rec_rows(int cm) {  // LDS rows of a lane's slot: record rows 0..14 (then 16..23); CG_DMA: whole pairs, rows 0..15 (then 16..23)
     return (cm & CG_DMA) ? ((cm & (CG_PXY_REGS | CG_PXY_GLOBAL)) ? 16 : 24) : ((cm & (CG_PXY_REGS | CG_PXY_GLOBAL)) ? 15 : 23);
 }
@@ -77,6 +79,7 @@ struct CgLds {
     const double* ct2;
     double tlen;
 };
+template <int CM>
 PK_DEV void cg_pin(CgLds& L, const FastC& F) {
     L.st_z = F.st_z;
     L.st_y = F.st_y;
@@ -84,9 +87,10 @@ PK_DEV void cg_pin(CgLds& L, const FastC& F) {
     L.lvl_b = F.lvl_b;
     L.ct2 = F.ct2;
     L.tlen = F.tlen;
-#ifndef PK_NO_PIN
-    asm volatile("" : "+s"(L.st_z), "+s"(L.st_y), "+s"(L.cb), "+s"(L.lvl_b), "+s"(L.ct2), "+s"(L.tlen));
-#endif
+    // (measured on BASELINE configs 3 / 5, profiles/r06c_*: the pin halves the scalar loads per wave-evaluation, 13.0 -> 6.9, and is
+    // worth nothing in time -- within +-1 % everywhere, slightly negative for AdvectionRK4_3D and M1; kept for the RK45 kernel, where
+    // together with CG_PXY_GLOBAL | CG_DMA it brings the scratch from 160 to 60 B / lane)
+    if constexpr ((CM & CG_PIN) != 0) asm volatile("" : "+s"(L.st_z), "+s"(L.st_y), "+s"(L.cb), "+s"(L.lvl_b), "+s"(L.ct2), "+s"(L.tlen));
 }
 // row k (compile-time) of the record in the lane's slot
 template <int CM>
@@ -474,10 +478,10 @@ PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtxT<FT, CM>& c, dou
             twe_note(a, it, klo);
             return;
         }
-        if (t != c.mt) {
+        if ((CM & CG_NO_TMEMO) != 0 || t != c.mt) {
             int idx;
             fast_search(L.time, F.nt, F.t0, F.t1, t, c.ht, idx, c.mtau);  // level times start at 0 (host check): idx == c.ht
-            c.mt = t;
+            if constexpr ((CM & CG_NO_TMEMO) == 0) c.mt = t;
         }
         ti = c.ht;
         tau = c.mtau;

@@ -867,7 +867,12 @@ __global__ void __launch_bounds__(256, PK_MIN_WAVES_FAST) advect_fast_kernel(con
 #define PK_CG_CACHE 2
 #endif
 #ifndef PK_CG_CACHE_RK45
-#define PK_CG_CACHE_RK45 2
+// round 6: CG_PXY_GLOBAL | CG_DMA | CG_PIN | CG_NO_TMEMO (pk_fast_cgrid.h).  Rounds 3-5 kept the corner coordinates in registers (2): 160 B
+// / lane of scratch whose write-back was 5.4 of the 6.4 GB the kernel wrote per launch (state: 1.0 GB).  With the coordinates read from the
+// table where they are used, the cell fetch by LDS-DMA, the hot scalars pinned and no time memo the allocator fits the 168 registers of 3
+// waves per SIMD: 28 B of scratch, no spill store inside the step loop.  Kernel time is unchanged (13.8-13.9 ms either way, same box,
+// alternating: profiles/r06c_rk45_variants.md) -- the kernel is bound by dependent latency at this residency, not by the spill traffic.
+#define PK_CG_CACHE_RK45 60
 #endif
 #ifndef PK_CG_CACHE_M1
 #define PK_CG_CACHE_M1 4
@@ -889,7 +894,7 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID) advect_cgrid_ker
         L.fv = (void*)((FT*)(smem + F.lds_fv) + threadIdx.x);
         L.rec_w = reinterpret_cast<char*>(smem + F.lds_rec);
         L.fv_w = reinterpret_cast<char*>(smem + F.lds_fv);
-        cg_pin(L, F);
+        cg_pin<CG_CACHE_RK4>(L, F);
     }
     auto row = [&]() { return (int64_t)xcd_swizzle(blockIdx.x, gridDim.x) * FC_LANES + threadIdx.x; };
     unsigned steps = 0, attempts = 0, paused = 0;
@@ -1038,7 +1043,7 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID_RK45) advect_cgri
         L.fv = (void*)((FT*)(smem + F.lds_fv) + threadIdx.x);
         L.rec_w = reinterpret_cast<char*>(smem + F.lds_rec);
         L.fv_w = reinterpret_cast<char*>(smem + F.lds_fv);
-        cg_pin(L, F);
+        cg_pin<CG_CACHE_RK45>(L, F);
     }
     auto row = [&]() { return (int64_t)xcd_swizzle(blockIdx.x, gridDim.x) * FC_LANES + threadIdx.x; };
     unsigned steps = 0, attempts = 0, paused = 0;
@@ -1212,7 +1217,7 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID_M1) advect_cgrid_
         L.fv = (void*)((FT*)(smem + F.lds_fv) + threadIdx.x);
         L.rec_w = reinterpret_cast<char*>(smem + F.lds_rec);
         L.fv_w = reinterpret_cast<char*>(smem + F.lds_fv);
-        cg_pin(L, F);
+        cg_pin<CG_CACHE_M1>(L, F);
     }
     auto row = [&]() { return (int64_t)xcd_swizzle(blockIdx.x, gridDim.x) * FC_LANES + threadIdx.x; };
     unsigned steps = 0, attempts = 0, paused = 0;

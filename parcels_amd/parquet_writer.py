@@ -119,6 +119,11 @@ def supports_schema(schema) -> bool:
     return True
 
 
+import threading
+
+_tls = threading.local()
+
+
 def _pwrite_all(fd, parts, pos):
     for b in parts:
         mv = memoryview(b).cast("B")
@@ -129,12 +134,14 @@ def _pwrite_all(fd, parts, pos):
 
 
 class FastParquetWriter:
-    def __init__(self, path, schema, compression="zstd", row_group_rows=1 << 20, threads=None, page_rows=1 << 17):
+    def __init__(self, path, schema, compression="zstd", row_group_rows=1 << 20, threads=None, page_rows=1 << 19):
         """schema: the pyarrow schema of the tables (field + file metadata included), as pyarrow.parquet.ParquetWriter takes it.
         page_rows: rows per data page.  A column chunk of a row group is a run of pages, each compressed on its own -- round 5 wrote ONE page
         per chunk: a table of 4e6 rows was 20 jobs of 8 MB, so 32 threads were no faster than 8 (31 ms per 160 MB table, 5 GB/s;
-        profiles/r05_m_writeout_4e6.json).  With 1 MB pages the same table is 160 jobs and the pool is busy until the end; the pages of a row
-        group are then written with positional writes from the pool as well (their offsets are known once the group is compressed)."""
+        profiles/r05_m_writeout_4e6.json).  Smaller pages keep the pool busy to the end, but every page is also a Python job (header, codec
+        call, future): on the 128-thread host of the MI355X box 1 MB pages (160 jobs per 4e6-row table) lost more to that than they won
+        (29 vs 23 ms; profiles/r06c_writeout_*.json), so the default is 4 MB pages of 512K rows (two per column chunk).  The pages are
+        written with positional writes from the pool as well (their offsets are known once compressed)."""
         import pyarrow as pa
 
         if compression not in _CODEC:
@@ -167,9 +174,13 @@ class FastParquetWriter:
         view = memoryview(body).cast("B")
         levels = _varint(n << 1) + b"\x01"  # one run of n definition levels of value 1 (bit width 1)
         if self.codec:
-            import pyarrow as pa
+            codec = getattr(_tls, "codec", None)
+            if codec is None or _tls.codec_name != self.codec:  # one codec per pool thread: its compression context is not thread-safe
+                import pyarrow as pa
 
-            comp = pa.Codec(self.codec).compress(view, asbytes=True)  # a codec per call: its compression context is not thread-safe
+                codec = _tls.codec = pa.Codec(self.codec)
+                _tls.codec_name = self.codec
+            comp = codec.compress(view, asbytes=True)
         else:
             comp = view
         v2 = (_Struct().i32(1, n).i32(2, 0).i32(3, n).i32(4, 0).i32(5, len(levels)).i32(6, 0))  # values, nulls, rows, PLAIN, def / rep level bytes
