@@ -4,7 +4,7 @@ over cadences), per cadence once without output, once with the inline path (D2H 
 between two launches) and once with the asynchronous path (write filter on the device -> pinned snapshot on the copy stream -> writer
 thread), same file byte for byte.  Per cadence: wall seconds, the write-out cost of both paths, `output_hidden_frac` = the share of the inline
 cost that the asynchronous path took out of the wall clock, and where the writer's time went.  Then the Parquet encode of ONE table on its
-own: this writer with one page per column chunk (round 5) and with 128K-row pages, by thread count, against pyarrow's.  One JSON object."""
+own: this writer with one page per column chunk (round 5) and with 512K- / 128K-row pages, by thread count, against pyarrow's.  One JSON object."""
 import argparse
 import json
 import os
@@ -46,7 +46,7 @@ def main():
             pf = None if mode == "none" else pa.ParticleFile(path, outputdt=float(every * case["dt"]), compression=comp)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            pset.execute(pa.AdvectionRK4, dt=case["dt"], runtime=steps * case["dt"], output_file=pf)
+            pset.execute([pa.AdvectionRK4, pa.DeleteParticle], dt=case["dt"], runtime=steps * case["dt"], output_file=pf)  # (DeleteParticle: over weeks a few particles reach the edge)
             torch.cuda.synchronize()
             wall = time.perf_counter() - t0
             r = {"wall_s": wall}
@@ -85,8 +85,8 @@ def main():
         enc = {}
         k = 0
         for label, kw in (("one_page_per_chunk_8_threads (round 5)", dict(threads=8, page_rows=1 << 20)), ("one_page_per_chunk_32_threads (round 5)", dict(threads=32, page_rows=1 << 20)),
-                          ("pages_128k_8_threads", dict(threads=8)), ("pages_128k_32_threads", dict(threads=32)), ("pages_128k_64_threads", dict(threads=64)),
-                          ("pages_128k_64_threads_uncompressed", dict(threads=64, compression=None))):
+                          ("pages_512k_rows_8_threads", dict(threads=8)), ("pages_512k_rows_32_threads", dict(threads=32)), ("pages_512k_rows_64_threads (default)", dict(threads=64)),
+                          ("pages_128k_rows_64_threads", dict(threads=64, page_rows=1 << 17)), ("pages_512k_rows_64_threads_uncompressed", dict(threads=64, compression=None))):
             best, sec = 1e9, None
             for _ in range(3):
                 k += 1
