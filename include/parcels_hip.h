@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PK_ABI_VERSION 9 /* 9: pk_particles_snapshot_filtered (device-side write filter for the asynchronous write-out); the multi-GPU exchange in the ABI (pk_comm_unique_id / _init / _destroy / _info / _allreduce_i64, pk_gather_rows_to_root, pk_allgather_output, pk_gathered_fetch: RCCL, opened by the library); 8: pk_execute_twe_report (all failing samples of a pass at once), pk_particles_h2d_columns / _fill_f64 / _t_stats (device-resident columns across execute calls), pk_exec_stats.pack_ms / packs (the pair-copy packing ahead of a launch, timed) / sclk_mhz, "velocity_pairs" opt-in; 7: the call-wide OutsideTimeInterval of the reference on the device (pk_exec_params.twe_n / twe_key, pk_exec_stats.first_time_error_key, pk_execute_rerun_keys); 6: PK_MAX_FIELDS 64 (descriptors in device memory), PK_MAX_EXTRA 8, pk_particles_checkpoint / _restore, user kernels (PK_KERNEL_USER0 .., pk_generic_variant, pk_set_user_program), "eval_points_f32" option; 5: pk_exec_params.horizon_lo / horizon_hi / max_iters, pk_exec_stats.first_error_iter / program, pk_execute_rerun, "fast_cgrid" option; 4: pk_upload_stats, pk_host_stage_selftest, PK_KERNEL_DO_NOTHING / _MOVE_EAST / _MOVE_NORTH, vector PK_KERNEL_SAMPLE_FIELD, "cell_table" option */
+#define PK_ABI_VERSION 9 /* 9: pk_particles_snapshot_filtered (device-side write filter for the asynchronous write-out); the multi-GPU exchange in the ABI (pk_comm_unique_id / _init / _destroy / _info / _allreduce_i64 / _allgather_i64, pk_gather_rows_to_root, pk_allgather_output, pk_gathered_fetch: RCCL, opened by the library); 8: pk_execute_twe_report (all failing samples of a pass at once), pk_particles_h2d_columns / _fill_f64 / _t_stats (device-resident columns across execute calls), pk_exec_stats.pack_ms / packs (the pair-copy packing ahead of a launch, timed) / sclk_mhz, "velocity_pairs" opt-in; 7: the call-wide OutsideTimeInterval of the reference on the device (pk_exec_params.twe_n / twe_key, pk_exec_stats.first_time_error_key, pk_execute_rerun_keys); 6: PK_MAX_FIELDS 64 (descriptors in device memory), PK_MAX_EXTRA 8, pk_particles_checkpoint / _restore, user kernels (PK_KERNEL_USER0 .., pk_generic_variant, pk_set_user_program), "eval_points_f32" option; 5: pk_exec_params.horizon_lo / horizon_hi / max_iters, pk_exec_stats.first_error_iter / program, pk_execute_rerun, "fast_cgrid" option; 4: pk_upload_stats, pk_host_stage_selftest, PK_KERNEL_DO_NOTHING / _MOVE_EAST / _MOVE_NORTH, vector PK_KERNEL_SAMPLE_FIELD, "cell_table" option */
 #define PK_MAX_GRIDS 4
 #define PK_MAX_FIELDS 64
 #define PK_MAX_KERNELS 8
@@ -472,6 +472,7 @@ int32_t pk_comm_init(pk_ctx* ctx, int32_t rank, int32_t world, const uint8_t* id
 int32_t pk_comm_destroy(pk_ctx* ctx);
 int32_t pk_comm_info(pk_ctx* ctx, int32_t* rank, int32_t* world, int32_t* rccl_version);
 int32_t pk_comm_allreduce_i64(pk_ctx* ctx, int64_t* values, int32_t n, int32_t op); /* in place */
+int32_t pk_comm_allgather_i64(pk_ctx* ctx, const int64_t* send, int32_t n, int64_t* recv); /* recv[world * n], rank order: the failing samples every shard found */
 /* t: the output time; apply_filter 0 = every row; mask: PK_COL_* of the columns to exchange; counts[world]: rows of every rank (out) */
 int32_t pk_gather_rows_to_root(pk_ctx* ctx, double t, int32_t apply_filter, uint32_t mask, int64_t* counts);
 int32_t pk_allgather_output(pk_ctx* ctx, double t, int32_t apply_filter, uint32_t mask, int64_t* counts);

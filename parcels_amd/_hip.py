@@ -239,6 +239,7 @@ ABI_SYMBOLS = [
     "pk_comm_destroy",
     "pk_comm_info",
     "pk_comm_allreduce_i64",
+    "pk_comm_allgather_i64",
     "pk_gather_rows_to_root",
     "pk_allgather_output",
     "pk_gathered_fetch",
@@ -325,6 +326,7 @@ def load():
     lib.pk_comm_destroy.argtypes = [C.c_void_p]
     lib.pk_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.pk_comm_allreduce_i64.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+    lib.pk_comm_allgather_i64.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     lib.pk_gather_rows_to_root.argtypes = [C.c_void_p, C.c_double, C.c_int32, C.c_uint32, C.c_void_p]
     lib.pk_allgather_output.argtypes = [C.c_void_p, C.c_double, C.c_int32, C.c_uint32, C.c_void_p]
     lib.pk_gathered_fetch.argtypes = [C.c_void_p, C.POINTER(ParticlesDesc), C.c_int64]

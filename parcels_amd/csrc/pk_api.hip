@@ -2369,7 +2369,10 @@ int32_t pk_execute_begin(pk_ctx* ctx, const pk_exec_params* prm) {
         size_t cgrid_lds = 0;
         // A launch that knows samples which fail call-wide (pk_exec_params.twe_key: the repeat of a call in which some particle left a
         // field's time interval) runs the general programs: only they test the list (the dedicated kernels report such samples and pay
-        // nothing else for it); same results otherwise, which the parity tests hold them to at rtol 0.
+        // nothing else for it); same results otherwise, which the parity tests hold them to at rtol 0.  (Round 6 built the list test into the
+        // dedicated kernels -- one scalar bit test per sample when nothing is listed -- held it bit-identical and measured it: +2.4 % on the
+        // headline kernel, +0.6 % / +1 % on RK45 / M1 through the register allocation alone (profiles/r06e_summary.txt), for repeats that only
+        // a run past the last time level makes.  Not kept.)
         const bool listed = prm->twe_n > 0;
         const int ufast = (has_user && use_lds && !listed) ? user_fast_shape(prm, ctx->user_flags) : -1;
         const bool user_samples = ctx->user_nsample > 0 || (ctx->user_flags & (PK_USER_SAMPLES_UV | PK_USER_SAMPLES_UVW));

@@ -18,6 +18,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import numpy as np
+
 
 
 def shard_slice(n_total: int, rank: int, world: int) -> slice:
@@ -210,6 +212,28 @@ def batch_agreement(group=None, device=None, engine=None):
         listed key whether a particle of ANY shard justified it (element-wise max).  -> (sorted union, flags); found = None: this rank
         could not validate its pass (DeviceEngine._twe_report) -- then EVERY rank gets (None, None) and falls back to one key per pass."""
         t0 = _time.perf_counter()
+        if cabi:  # the same exchange through the library's communicator (pk_comm_allgather_i64 + pk_comm_allreduce_i64): no torch tensor involved
+            f = [int(k) for k in (found or [])][:NF]
+            mine = np.zeros(NF + 1, np.int64)
+            mine[0] = len(f) if found is not None else -1
+            mine[1:1 + len(f)] = f
+            parts = engine.comm_allgather(mine)
+            union, unvalidated = set(), False
+            for p in parts:
+                n = int(p[0])
+                if n < 0:
+                    unvalidated = True
+                    continue
+                union.update(int(v) for v in p[1:1 + n])
+            h = np.zeros(_hip.PK_MAX_TWE, np.int64)
+            if hits:
+                h[:len(hits)] = [int(bool(x)) for x in hits]
+            h = engine.comm_allreduce(h, "max")
+            stats["calls"] += 2
+            stats["seconds"] += _time.perf_counter() - t0
+            if unvalidated:
+                return None, None
+            return sorted(union), [bool(v) for v in h[:len(hits)]]
         mine = torch.zeros(NF + 1, dtype=torch.int64, device=dev)
         f = [int(k) for k in (found or [])][:NF]
         mine[0] = len(f) if found is not None else -1

@@ -587,6 +587,14 @@ class DeviceEngine:
         self.comm_stats["allreduces"] += 1
         return a
 
+    def comm_allgather(self, values):
+        """Every rank's int64 values to every rank: a (world, n) array in rank order (pk_comm_allgather_i64)."""
+        a = np.ascontiguousarray(values, dtype=np.int64)
+        out = np.zeros((self.comm[1], len(a)), np.int64)
+        self.ctx.check(self.lib.pk_comm_allgather_i64(self.ctx.handle, _ptr(a), len(a), _ptr(out)), "pk_comm_allgather_i64")
+        self.comm_stats["allreduces"] += 1
+        return out
+
     def gather_rows(self, names, t, apply_filter=True, to_all=False, fetch=True):
         """The write-out exchange (include/parcels_hip.h: pk_gather_rows_to_root / pk_allgather_output): the rows of the device-resident
         columns `names` that pass the reference's write filter at output time `t`, of ALL ranks in rank order -- NumPy arrays on the
@@ -891,6 +899,7 @@ class DeviceEngine:
                         prm = self.make_params(kernel_ids, endtime=endtime, dt0=dt0, context=context, seed=seed, reset_state=reset,
                                                have_guess0=(have_guess0 if reset else 1), sort_by_cell=sort_now, samples=samples, horizon=horizon,
                                                max_iters=cap, twe_keys=keys)
+
                         if sort_now and t_live is not None and np.isfinite(t_live):
                             self._sorted_t = float(t_live)
                         elif sort_now:

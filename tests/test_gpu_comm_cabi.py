@@ -52,6 +52,7 @@ def test_comm_info_and_allreduce(engine_with_comm):
         eng.ctx.check(eng.lib.pk_comm_allreduce_i64(eng.ctx.handle, got.ctypes.data_as(C.c_void_p), len(got), op), "pk_comm_allreduce_i64")
         assert np.array_equal(got, vals)
     assert eng.lib.pk_comm_allreduce_i64(eng.ctx.handle, vals.ctypes.data_as(C.c_void_p), 3, 99) != 0
+    assert np.array_equal(eng.comm_allgather(vals), vals[None, :])  # pk_comm_allgather_i64: (world, n) in rank order
 
 
 @pytest.mark.parametrize("sort", [True, False])
