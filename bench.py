@@ -606,8 +606,24 @@ def main():
 
         from parcels_amd.distributed import ensure_comm
 
-        cabi = ensure_comm(eng)  # the library's own RCCL communicator (include/parcels_hip.h: pk_comm_init); False in the gloo rehearsal
-        allgather_output(eng, world, fetch=False) if cabi else None  # (untimed first exchange: staging buffers are allocated on first use)
+        # the library's own RCCL communicator (include/parcels_hip.h: pk_comm_init); False in the gloo rehearsal.  Should it fail on ANY rank
+        # (no librccl.so next to the library, an RCCL error in the first exchange), every rank falls back to the torch.distributed exchange
+        # together -- the line must survive, and says which transport it measured
+        cabi, cabi_err = False, None
+        try:
+            cabi = ensure_comm(eng)
+            allgather_output(eng, world, fetch=False) if cabi else None  # (untimed first exchange: staging buffers are allocated on first use)
+        except Exception as e:
+            cabi, cabi_err = False, repr(e)[:500]
+        okf = torch.tensor([0 if cabi_err else 1], dtype=torch.int64, device="cpu" if rehearsal else "cuda")
+        dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+        if int(okf.item()) == 0:
+            cabi = False
+            os.environ["PARCELS_AMD_TORCH_EXCHANGE"] = "1"
+            try:
+                eng.comm_destroy()
+            except Exception:
+                pass
         sync()
         t1 = time.perf_counter()
         gathered = allgather_output(eng, world, fetch=False) if cabi else allgather_output(eng, world)
@@ -638,7 +654,8 @@ def main():
         except Exception:
             ver = None
         comm = {"backend": dist.get_backend(), "n_ranks_seen": dist.get_world_size(), "rccl_version": ".".join(str(v) for v in ver) if ver else None,
-                "exchange": "C ABI (pk_allgather_output / pk_gather_rows_to_root: RCCL opened by libparcels_hip.so)" if cabi else "torch.distributed"}
+                "exchange": "C ABI (pk_allgather_output / pk_gather_rows_to_root: RCCL opened by libparcels_hip.so)" if cabi else "torch.distributed",
+                **({"c_abi_exchange_error": cabi_err} if cabi_err else {})}
     # what the lock-step points of a sharded ParticleSet cost (N > 1): four more steps through DeviceEngine.execute with the batch agreements
     # installed (parcels_amd.distributed.batch_agreement: after every pass the ranks all-reduce the first erring iteration / failing sample, at
     # the end the error codes) -- outside the timed region; calls and seconds inside the all-reduces, max over ranks
