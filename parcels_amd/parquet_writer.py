@@ -189,6 +189,12 @@ class FastParquetWriter:
 
     def write_columns(self, columns: dict):
         """Append one table given as {name: 1-D NumPy array} (all of one length, no nulls)."""
+        self.commit(self.prepare(columns))
+
+    def prepare(self, columns: dict):
+        """First half of write_columns: check the columns and start compressing their pages on the pool.  Touches nothing of the file, so
+        the table BEHIND the one being committed may prepare meanwhile (two writer threads of ParticleFile's asynchronous writer: the page
+        compression of table k+1 overlaps the file writes of table k).  -> ticket for commit(); tickets must be committed in table order."""
         cols = []
         n = None
         for name, dt in zip(self.names, self.np_dtypes):
@@ -202,9 +208,7 @@ class FastParquetWriter:
                 raise ValueError("columns of one table must have one length")
             cols.append(a)
         if not n:
-            return
-        import time as _time
-
+            return None
         starts = list(range(0, n, self.row_group_rows))
         jobs = {}
         for g, lo in enumerate(starts):
@@ -212,6 +216,15 @@ class FastParquetWriter:
             for c, a in enumerate(cols):
                 for p, plo in enumerate(range(lo, hi, self.page_rows)):
                     jobs[(g, c, p)] = self.pool.submit(self._page, a[plo:min(plo + self.page_rows, hi)], self.store[c][0])
+        return {"n": n, "starts": starts, "jobs": jobs, "cols": cols}  # (cols: the buffers the jobs read stay referenced until the commit)
+
+    def commit(self, ticket):
+        """Second half: the pages in file order -- offsets, positional writes from the pool, row-group metadata."""
+        if ticket is None:
+            return
+        import time as _time
+
+        n, starts, jobs = ticket["n"], ticket["starts"], ticket["jobs"]
         fd = self.f.fileno()
         writes = []
         for g, lo in enumerate(starts):

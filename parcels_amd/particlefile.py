@@ -132,10 +132,29 @@ class ParticleFile:
 
     def write_columns(self, pclass, columns: dict, time_interval=None):
         """Append one table given ready-made columns (used by the multi-GPU write-out on rank 0)."""
-        import pyarrow as pa
+        self.commit_columns(self.prepare_columns(pclass, columns, time_interval))
+
+    def prepare_columns(self, pclass, columns: dict, time_interval=None):
+        """First half of write_columns (FastParquetWriter.prepare: the pages start compressing; the file is not touched) -> ticket for
+        commit_columns, which must be called in table order.  With pyarrow's writer the ticket just carries the columns."""
+        self._ensure_writer(pclass, time_interval)
+        names = [v.name for v in _get_vars_to_write(pclass)]
+        if hasattr(self._writer, "prepare"):
+            return ("fast", self._writer.prepare({n: np.asarray(columns[n]) for n in names}))
+        return ("pyarrow", {n: np.asarray(columns[n]) for n in names})
+
+    def commit_columns(self, ticket):
+        kind, payload = ticket
+        if kind == "fast":
+            self._writer.commit(payload)
+        else:
+            import pyarrow as pa
+
+            self._writer.write_table(pa.table({n: pa.array(a) for n, a in payload.items()}, schema=self._writer.schema))
+
+    def _ensure_writer(self, pclass, time_interval=None):
         import pyarrow.parquet as pq
 
-        names = [v.name for v in _get_vars_to_write(pclass)]
         if self._writer is None:
             schema = get_schema(pclass, self.metadata, time_interval)
             from .parquet_writer import _CODEC, FastParquetWriter, supports_schema
@@ -147,10 +166,6 @@ class ParticleFile:
                 self._writer = FastParquetWriter(self.path, schema, compression=self._compression, threads=self._encode_threads)
             else:
                 self._writer = pq.ParquetWriter(self.path, schema, compression=self._compression, use_dictionary=self._use_dictionary)
-        if hasattr(self._writer, "write_columns"):
-            self._writer.write_columns({n: np.asarray(columns[n]) for n in names})
-        else:
-            self._writer.write_table(pa.table({n: pa.array(np.asarray(columns[n])) for n in names}, schema=self._writer.schema))
 
     def write(self, pset, t, fieldset=None, indices=None):
         from .columns import readonly
@@ -239,22 +254,27 @@ class _SnapshotView:
 
 
 class _AsyncWriter:
-    """Double-buffered write-out: submit() snapshots the to-write device columns (pk_particles_snapshot_begin: device-side copy
-    in host row order + D2H on the copy stream into one of two pinned column sets) and returns; ONE writer thread waits for the
-    copy, applies the write filter and encodes the Parquet table while the caller launches the next interval.  Tables are written
-    in submission order; at most two snapshots are in flight (the third submit waits for the first encode)."""
+    """Double-buffered write-out: submit() snapshots the to-write device columns (pk_particles_snapshot_filtered: the write filter and the
+    packing in host row order on the device, D2H on the copy stream into one of two pinned column sets) and returns; TWO writer threads
+    take the tables: each waits for its copy and starts compressing its pages (FastParquetWriter.prepare), then commits them to the file when
+    it is its table's turn -- the compression of table k+1 overlaps the file writes of table k, the tables land in submission order.  At
+    most two snapshots are in flight (the third submit waits for the first table)."""
 
     def __init__(self, pfile, pset, engine, out_cols):
+        import threading
         from concurrent.futures import ThreadPoolExecutor
 
         self.pfile, self.pset, self.engine = pfile, pset, engine
         self.cols = [c for c in out_cols if c in engine._SNAP_COLS or c in engine.device_variables]
-        self.pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="parcels-writeout")
+        self.pool = ThreadPoolExecutor(max_workers=2, thread_name_prefix="parcels-writeout")
         self.pending = [None, None]
         self.slot = 0
+        self.seq = 0                        # tables submitted
+        self.turn = 0                       # table whose commit is due
+        self.order = threading.Condition()
         self.encode_seconds = 0.0
         self.block_seconds = 0.0
-        self.wait_seconds = 0.0  # writer thread: waiting for a snapshot's D2H (the rest of its time is filter + encode + file)
+        self.wait_seconds = 0.0  # writer threads: waiting for a snapshot's D2H (the rest of their time is filter + encode + file)
 
     def submit(self, data, t):
         slot = self.slot
@@ -285,19 +305,42 @@ class _AsyncWriter:
 
         host_only = {k: (np.array(v, copy=True) if mutable else v) for k, v in raw_items(data)
                      if k not in self.engine._SNAP_COLS and k not in self.engine.device_variables}
-        self.pending[slot] = self.pool.submit(self._task, slot, host_only, float(t), on_device)
+        seq = self.seq
+        self.seq += 1
+        self.pending[slot] = self.pool.submit(self._task, slot, host_only, float(t), on_device, seq)
 
-    def _task(self, slot, host_only, t, prefiltered=False):
+    def _task(self, slot, host_only, t, prefiltered=False, seq=0):
         import time as _time
 
-        t0 = _time.perf_counter()
-        cols = self.engine.snapshot_wait(slot)
-        t1 = _time.perf_counter()
-        self.wait_seconds += t1 - t0
-        if not prefiltered:
-            cols.update(host_only)
-        self.pfile.write(_SnapshotView(cols, self.pset._pclass, self.pset.fieldset, prefiltered=prefiltered), t)
-        self.encode_seconds += _time.perf_counter() - t1
+        ticket = None
+        try:
+            t0 = _time.perf_counter()
+            cols = self.engine.snapshot_wait(slot)
+            t1 = _time.perf_counter()
+            self.wait_seconds += t1 - t0
+            two_phase = prefiltered and hasattr(self.pfile, "prepare_columns") and not getattr(self.pfile, "_collective", False)
+            if two_phase:  # (the page compression starts now, whatever the tables in front of this one are doing)
+                names = [v.name for v in _get_vars_to_write(self.pset._pclass)]
+                ticket = self.pfile.prepare_columns(self.pset._pclass, {k: cols[k] for k in names}, self.pset.fieldset.time_interval)
+            with self.order:
+                while self.turn != seq:
+                    self.order.wait()
+            if two_phase:
+                self.pfile.commit_columns(ticket)
+            else:
+                if not prefiltered:
+                    cols.update(host_only)
+                self.pfile.write(_SnapshotView(cols, self.pset._pclass, self.pset.fieldset, prefiltered=prefiltered), t)
+            self.encode_seconds += _time.perf_counter() - t1
+        finally:
+            with self.order:  # (also when this table failed: the ones behind it must not wait for ever)
+                if self.turn == seq:
+                    self.turn = seq + 1
+                else:  # failed before its turn: wait for it, then pass it on
+                    while self.turn != seq:
+                        self.order.wait()
+                    self.turn = seq + 1
+                self.order.notify_all()
 
     def drain(self):
         for k in (self.slot, self.slot ^ 1):  # oldest first

@@ -174,3 +174,59 @@ def test_async_writer_copies_host_only_variables_of_hosted_kernel_lists():
     gate.set()
     w2.close()
     assert written[-1][1].tolist() == [5.0, 6.0, 7.0]
+
+
+def test_async_writer_two_tables_in_flight_commit_in_submission_order():
+    """Round 6: two writer threads -- table k+1 prepares (compresses) while table k commits (file writes); the commits happen in submission
+    order whatever the threads' timing, and a table that fails passes its turn on instead of blocking the ones behind it."""
+    import threading
+    import time
+    import types
+
+    from parcels_amd.particlefile import _AsyncWriter
+
+    log, lock = [], threading.Lock()
+
+    class Engine:
+        _SNAP_COLS = ("t", "dt", "x")
+        device_variables = []
+
+        def snapshot_begin(self, cols, slot, filter_t=None):
+            assert filter_t is not None  # every to-write Variable is a device column: the filter runs on the device
+
+        def snapshot_wait(self, slot):
+            return {"t": np.zeros(2), "dt": np.ones(2), "x": np.zeros(2)}
+
+    class File:
+        _collective = False
+
+        def prepare_columns(self, pclass, cols, ti):
+            k = len([e for e in log if e[0] == "prepare"])
+            with lock:
+                log.append(("prepare", k))
+            if k == 0:
+                time.sleep(0.3)  # the FIRST table is slow to prepare: the second one is ready to commit long before it
+            if k == 2:
+                raise RuntimeError("table 2 cannot be encoded")
+            return k
+
+        def commit_columns(self, ticket):
+            with lock:
+                log.append(("commit", ticket))
+
+    pclass = types.SimpleNamespace(variables=[types.SimpleNamespace(name="t", to_write=True), types.SimpleNamespace(name="x", to_write=True)])
+    pset = types.SimpleNamespace(_pclass=pclass, fieldset=types.SimpleNamespace(time_interval=None), _kernel=None)
+    w = _AsyncWriter(File(), pset, Engine(), ["t", "dt", "x"])
+    data = {"t": np.zeros(2), "dt": np.ones(2), "x": np.zeros(2)}
+    for k in range(4):
+        try:
+            w.submit(data, float(k))
+        except RuntimeError:
+            pass  # (the failure of table 2 surfaces when its slot is reused)
+    try:
+        w.close()
+    except RuntimeError:
+        pass
+    commits = [e[1] for e in log if e[0] == "commit"]
+    assert commits == [0, 1, 3], log  # in order, table 2 skipped, table 3 not stuck behind it
+    assert log.index(("prepare", 1)) < log.index(("commit", 0)), log  # table 1 prepared while table 0 was still busy
