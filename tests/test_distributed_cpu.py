@@ -678,3 +678,81 @@ def test_a_rank_that_fails_outside_the_agreements_leaves_a_note(world):
     for r in range(world):
         if r != 1:
             assert got[r] == ["CollectiveAbort:True", "stopped", "stopped", "clean"], got
+
+
+class _GlooComm:
+    """Stand-in for the library's RCCL communicator (DeviceEngine.comm_allreduce / comm_allgather = pk_comm_allreduce_i64 / _allgather_i64) over
+    gloo: what the C-ABI branch of distributed.batch_agreement calls, so that ITS logic runs at world 2 / 3 on the CPU (the entry points themselves
+    are tested through ctypes on the GPU, tests/test_gpu_comm_cabi.py; RCCL refuses two ranks on one device)."""
+
+    def __init__(self):
+        self.comm = (dist.get_rank(), dist.get_world_size())
+        self.calls = {"allreduce": 0, "allgather": 0}
+
+    def comm_init(self, *a):  # (ensure_comm looks for the method)
+        raise AssertionError("not reached: ensure_comm is patched")
+
+    def comm_allreduce(self, values, op):
+        import torch
+
+        t = torch.tensor([int(v) for v in values], dtype=torch.int64)
+        dist.all_reduce(t, op={"min": dist.ReduceOp.MIN, "max": dist.ReduceOp.MAX, "sum": dist.ReduceOp.SUM}[op])
+        self.calls["allreduce"] += 1
+        return t.numpy()
+
+    def comm_allgather(self, values):
+        import torch
+
+        t = torch.tensor([int(v) for v in values], dtype=torch.int64)
+        parts = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, t)
+        self.calls["allgather"] += 1
+        return np.stack([p.numpy() for p in parts])
+
+
+def _agree_keys_cabi_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import parcels_amd.distributed as D
+
+        comm = _GlooComm()
+        D.ensure_comm = lambda engine, group=None: engine is comm  # the C-ABI branch for THIS engine
+        a, b = [_k(it, s) for it in (7, 8) for s in range(4)], [_k(it, s) for it in (8, 9) for s in range(4)]
+        both = sorted(set(a) | set(b))
+        script = {0: [(0, a, []), (0, [], [k in a for k in both])], 1: [(0, b, []), (0, [], [k in b for k in both])]}.get(rank)
+        eng = _scripted_engine([])
+        if script:
+            eng.lib = _ReportingLib(script)
+        eng.agree_min, eng.agree_codes = D.batch_agreement(engine=comm)
+        assert eng.agree_min.transport == "c-abi"
+        st = eng.execute([4], endtime=10.0, dt0=1.0) if script else eng.execute_idle()
+        codes = eng.agree_codes([rank == 1, False, False])
+        q.put((rank, st["time_error_keys"], st["reran"], eng.lib.passes if script else None, both, codes, dict(comm.calls)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_the_c_abi_branch_of_the_agreements_at_world_2_and_3(world):
+    """Round 6: under RCCL the agreements go through the library's own communicator (pk_comm_allreduce_i64 / pk_comm_allgather_i64).  The same
+    scenario as above through THAT branch of batch_agreement, the communicator stood in for by gloo: union of the keys, OR of the justifications,
+    error codes present on any rank, two passes on every rank -- and no torch collective of the old path is used for them."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_agree_keys_cabi_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0, "a rank hung or failed"
+    res = {r[0]: r[1:] for r in (q.get(timeout=10) for _ in range(world))}
+    for rank in range(world):
+        keys, reran, passes, both, codes, calls = res[rank]
+        assert keys == both and reran == 1, (rank, res[rank])
+        assert codes == [1, 0, 0], (rank, codes)
+        assert calls["allgather"] >= 1 and calls["allreduce"] >= 3, (rank, calls)
+        if passes is not None:
+            assert passes == [(0, []), (0, both)], (rank, passes)
