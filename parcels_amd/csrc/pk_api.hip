@@ -165,6 +165,7 @@ struct pk_ctx {
     // fast C-grid path (pk_fast_cgrid.h): per-cell records of one grid + {a, 1/width} tables of time | depth, cached per (grid, field)
     double* d_ct2 = nullptr;
     int ct2_grid = -1;
+    int ct2_near = 0;  // FastC::near_edges of that grid
     // cell-packed pair copies of the staggered velocity for the 2-D dedicated C-grid kernels (pk_device.h: FastC::vp)
     char* d_vp = nullptr;
     size_t vp_bytes = 0;
@@ -551,7 +552,7 @@ __global__ void cell_table_kernel(const pk::DGrid g, double* tab) {
 // FastC::ct2 (pk_fast_cgrid.h): per cell, the record of cell_table_kernel re-expressed for the dedicated C-grid kernels -- the
 // query-independent sub-expressions of bilinear_inverse in ITS evaluation order (so that finishing them with the query point gives
 // the bits bilinear_inverse gives) and the corner longitudes after CGrid_Velocity's antimeridian unwrapping (cgrid_velocity).
-__global__ void cell_table2_kernel(const pk::DGrid g, double* tab) {
+__global__ void cell_table2_kernel(const pk::DGrid g, double* tab, int* wide) {
     using namespace pk;
     const int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (cell >= (int64_t)(g.ny - 1) * g.nx) return;
@@ -586,6 +587,10 @@ __global__ void cell_table2_kernel(const pk::DGrid g, double* tab) {
     for (int k = 1; k < 4; k++)
         if (-lon[k] + lon[0] > 180) lon[k] = lon[k] + 360;
     for (int k = 0; k < 4; k++) { out[16 + k] = lon[k]; out[20 + k] = ct[2 * k + 1]; out[24 + k] = py[k]; }
+    // FastC::near_edges (pk_fast_cgrid.h, cos_near): every cell spans less than 2^-8 rad of latitude, so the edge points of CGrid_Velocity's
+    // geodetic distances lie within 2^-7 rad of any sample point found in the cell
+    const double la_lo = fmin(fmin(ct[1], ct[3]), fmin(ct[5], ct[7])), la_hi = fmax(fmax(ct[1], ct[3]), fmax(ct[5], ct[7]));
+    if (!((la_hi - la_lo) * DEG2RAD <= 0.00390625)) atomicOr(wide, 1);
 }
 
 // Cells on which the reference's bilinear inverse (index_search.py:122-177, restated in bilinear_inverse) is numerically unreliable:
@@ -2178,8 +2183,16 @@ static int32_t fill_fastc(pk_ctx* ctx, const pk_exec_params* prm, KArgs& a, bool
             (void)hipGetLastError();
             ctx->d_ct2 = nullptr;
         } else {
-            hipLaunchKernelGGL(cell_table2_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, ctx->compute, g.d, ctx->d_ct2);
+            int* d_wide = nullptr;
+            int h_wide = 1;
+            PK_HIP(ctx, hipMalloc((void**)&d_wide, sizeof(int)));
+            PK_HIP(ctx, hipMemsetAsync(d_wide, 0, sizeof(int), ctx->compute));
+            hipLaunchKernelGGL(cell_table2_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, ctx->compute, g.d, ctx->d_ct2, d_wide);
             PK_HIP(ctx, hipGetLastError());
+            PK_HIP(ctx, hipMemcpyAsync(&h_wide, d_wide, sizeof(int), hipMemcpyDeviceToHost, ctx->compute));
+            PK_HIP(ctx, hipStreamSynchronize(ctx->compute));
+            (void)hipFree(d_wide);
+            ctx->ct2_near = h_wide ? 0 : 1;
         }
     }
     if (!ctx->d_ct2) return 0;
@@ -2187,6 +2200,7 @@ static int32_t fill_fastc(pk_ctx* ctx, const pk_exec_params* prm, KArgs& a, bool
     F.has_ti = f.has_time_interval;
     F.has_z = g.d.has_z;
     F.walk_ok = g.d.walk_ok;
+    F.near_edges = ctx->ct2_near;
     F.nt = f.nt;
     F.nslots = f.nslots;
     F.gnz = g.d.nz; F.gny = g.d.ny; F.gnx = g.d.nx;

@@ -126,7 +126,7 @@ struct FastA {
 // (pk_fast_cgrid.h), folded from the grid / field descriptors by the host (pk_api.hip: fill_fastc).
 struct FastC {
     int32_t ok, grid;                    // preconditions hold; grid id (column of `ei`)
-    int32_t has_ti, has_z, walk_ok, pad0;
+    int32_t has_ti, has_z, walk_ok, near_edges;  // near_edges: no cell spans 2^-8 rad of latitude (pk_fast_cgrid.h: cos_near)
     int32_t nt, nslots;                  // time levels of U / V / W and their ring
     int32_t gnz, gny, gnx;               // node counts of the grid axes
     uint32_t ex, ey, ez;                 // ravel strides of `ei` (basegrid.py:83-152)

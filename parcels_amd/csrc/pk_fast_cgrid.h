@@ -350,6 +350,37 @@ PK_DEV double cg_fetch_cell(const FastC& F, const CgLds& L, CCtxT<FT, CM>& c, in
     }
 }
 
+// Sines / cosines NEAR an angle whose sine and cosine are known (PK_CG_NEAR, round 6): a sample point of a step lies within a fraction of a
+// degree of the particle's own position, and the four edge points of CGrid_Velocity's geodetic distances within a cell of the sample's
+// latitude, so sin / cos(a0 + d) = s0 cos d + c0 sin d / c0 cos d - s0 sin d with the Taylor polynomials of sin d and cos d - 1 for
+// |d| <= 2^-7 rad (0.45 degrees: truncation d^7 / 5040 < 3.5e-19, d^8 / 40320 < 4e-22) -- 13 fp64 operations instead of the 50-odd of a
+// reduction + two minimax kernels, no branch.  Error: that of (s0, c0) (< 1 ulp, sincos_geo) + one rounding: < 2.5 ulp, where the
+// reference's own libm promises <= 1 ulp: trajectories stay within the 1e-12 every parity test states, but
+// are no longer the bits of the general program, which has no "own position" to start from.  Larger |d|: the full routines.
+#ifndef PK_CG_NEAR
+#define PK_CG_NEAR 3  // bit 0: the sample point from the particle's own position; bit 1: the edge points from the sample point
+#endif
+#ifndef PK_CG_NEAR_RK45
+#define PK_CG_NEAR_RK45 PK_CG_NEAR
+#endif
+#ifndef PK_CG_NEAR_M1
+#define PK_CG_NEAR_M1 PK_CG_NEAR
+#endif
+static constexpr double CG_NEAR_MAX = 0.0078125;
+PK_DEV void sincos_near(double d, double s0, double c0, double& s, double& c) {
+    const double z = d * d;
+    const double sd = fma(d * z, fma(z, 8.33333333333333333e-03, -1.66666666666666667e-01), d);
+    const double cm = z * fma(z, fma(z, -1.38888888888888889e-03, 4.16666666666666667e-02), -0.5);
+    s = s0 + fma(c0, sd, s0 * cm);
+    c = c0 + fma(-s0, sd, c0 * cm);
+}
+PK_DEV double cos_near(double d, double s0, double c0) {
+    const double z = d * d;
+    const double sd = fma(d * z, fma(z, 8.33333333333333333e-03, -1.66666666666666667e-01), d);
+    const double cm = z * fma(z, fma(z, -1.38888888888888889e-03, 4.16666666666666667e-02), -0.5);
+    return c0 + fma(-s0, sd, c0 * cm);
+}
+
 template <class FT, int CM>
 PK_DEV void cg_home_sincos(CCtxT<FT, CM>& c, double y, double x) {
     sincos_geo(y * DEG2RAD, c.q_sl, c.q_cl);
@@ -359,6 +390,31 @@ PK_DEV void cg_home_sincos(CCtxT<FT, CM>& c, double y, double x) {
 // curvilinear_point_in_cell (index_search.py:94-177) on the record in the lane's LDS slot.  Bit for bit what point_in_cell ->
 // spherical_project_query -> bilinear_inverse of pk_device.h compute: the cell-only sub-expressions were formed by the table build
 // in the same order.  `cell`: for the degenerate branch (reads pv from the global record).
+// Square root, quotient and reciprocal WITHOUT the library's range scaling and final fix-up (PK_CG_LEAN, round 6; same tolerance argument
+// as sincos_near): the operands here are lengths in metres, squared or not, determinants and Jacobians of cells -- far from the
+// subnormal and overflow ranges the library's 20-instruction sqrt and 10-instruction division guard -- and one Goldschmidt / Newton
+// step + one residual correction on the hardware's v_rsq_f64 / v_rcp_f64 leaves < 1 ulp (not always the correctly rounded bit).
+#ifndef PK_CG_LEAN
+#define PK_CG_LEAN 1
+#endif
+PK_DEV double sqrt_lean(double x) {  // x > 0 (0, negative, NaN: the caller selects)
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    return fma(fma(-g, g, x), h, g);
+}
+PK_DEV double rcp_lean(double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(r, fma(-b, r, 1.0), r);
+    return fma(r, fma(-b, r, 1.0), r);
+}
+PK_DEV double div_lean(double a, double b) {
+    const double r = rcp_lean(b), q = a * r;
+    return fma(fma(-b, q, a), r, q);
+}
+
 template <class Row>
 PK_DEV bool cg_point_in_cell_rows(const FastC& F, Row row, int cell, double qX, double qY, double qZ, double& xsi, double& eta) {
     const double eu0 = row(0), eu1 = row(1), eu2 = row(2);
@@ -371,14 +427,14 @@ PK_DEV bool cg_point_in_cell_rows(const FastC& F, Row row, int cell, double qX, 
     const double bb = bb0 + xq * b3 - yq * a3;
     const double cc = cc0 + xq * b1 - yq * a1;
     const double det2 = bb * bb - aa4 * cc;  // 4 * aa * cc with 4 * aa from the table (exact scaling)
-    const double det = det2 > 0 ? sqrt(det2) : -1.0;
+    const double det = det2 > 0 ? (PK_CG_LEAN ? sqrt_lean(det2) : sqrt(det2)) : -1.0;
     double e;
     if (__builtin_expect(fabs(aa4) < 4 * 1e-12, 0)) {  // |aa| < 1e-12
         double cn = cc;
         asm volatile("" : "+v"(cn));  // keep the rare branch a branch (see div_by_recip)
         e = -cn / bb;
     } else {
-        e = det2 > 0 ? (-bb + det) / (aa4 * 0.5) : -1.0;  // 2 * aa
+        e = det2 > 0 ? (PK_CG_LEAN ? div_lean(-bb + det, aa4 * 0.5) : (-bb + det) / (aa4 * 0.5)) : -1.0;  // 2 * aa
     }
     const double den = a1 + a3 * e;
     double x;
@@ -389,7 +445,7 @@ PK_DEV bool cg_point_in_cell_rows(const FastC& F, Row row, int cell, double qX, 
         ldpair(g + 26, py2, py3);
         x = ((yq - py0) / (py1 - py0) + (yq - py3) / (py2 - py3)) * 0.5;
     } else {
-        x = (xq - a0 - a2 * e) / den;
+        x = PK_CG_LEAN ? div_lean(xq - a0 - a2 * e, den) : (xq - a0 - a2 * e) / den;
     }
     xsi = x;
     eta = e;
@@ -463,7 +519,7 @@ PK_DEV double cg_scalar_xlinear(const FastC& F, int k, int ti, double tau, int z
 // WITH_SCALAR (AdvectionDiffusionM1's program): `sk` >= 0 asks for Field.eval (field.py:145-195) of scalar field FastC::kh[sk] instead --
 // same search on the same grid (the `ei` guess chain of the particle runs through velocity and scalar samples alike), XLinear on the
 // field's nodes; the value is returned in u.  One call site serves all seven samples of a step (sk is a run-time value there).
-template <class FT, bool PF, bool D3, bool WITH_SCALAR = false, int CM = 0, int HOPS = 1>
+template <class FT, bool PF, bool D3, bool WITH_SCALAR = false, int CM = 0, int HOPS = 1, int NEAR = PK_CG_NEAR>
 PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtxT<FT, CM>& c, double t, double z, double y, double x, bool pos_f32, double& u,
                            double& v, double& w, unsigned it, int klo, int sk = -1, double home_y = 0.0, double home_x = 0.0) {
     const FastC& F = a.fastc;
@@ -500,7 +556,18 @@ PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtxT<FT, CM>& c, dou
     // the query point on the unit sphere (make_qpoint / latlon_rad_to_xyz)
     double sl, cl, so, co;
     const bool guess_ok = c.gy >= 0 && c.gy < F.gny - 1 && c.gx >= 0 && c.gx < F.gnx - 1;
-    if (WITH_SCALAR) {  // (home_y, home_x): the particle's own position, whose sines / cosines the kernel left in the context
+    if constexpr ((NEAR & 1) != 0) {  // (home_y, home_x): the particle's own position, whose sines / cosines the kernel left in the context
+        const double dy = (y - home_y) * DEG2RAD, dx = (x - home_x) * DEG2RAD;
+        if (__builtin_expect(fmax(fabs(dy), fabs(dx)) <= CG_NEAR_MAX, 1)) {
+            // (AdvectionDiffusionM1: five of the seven samples of a step at the particle's own latitude, five at its own longitude --
+            // the same for every lane of the wavefront)
+            if (WITH_SCALAR && y == home_y) { sl = c.q_sl; cl = c.q_cl; } else sincos_near(dy, c.q_sl, c.q_cl, sl, cl);
+            if (WITH_SCALAR && x == home_x) { so = c.q_so; co = c.q_co; } else sincos_near(dx, c.q_so, c.q_co, so, co);
+        } else {  // (and NaN)
+            sincos_geo(y * DEG2RAD, sl, cl);
+            sincos_geo(x * DEG2RAD, so, co);
+        }
+    } else if (WITH_SCALAR) {
         if (y == home_y) { sl = c.q_sl; cl = c.q_cl; } else sincos_geo(y * DEG2RAD, sl, cl);
         if (x == home_x) { so = c.q_so; co = c.q_co; } else sincos_geo(x * DEG2RAD, so, co);
     } else {
@@ -632,19 +699,33 @@ PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtxT<FT, CM>& c, dou
     const double omx = 1 - xsi, ome = 1 - eta;
     // einsum("ij,ji->i", phi2D_lin(eta, xsi), py) at (0, xsi), (eta, 1), (1, xsi), (eta, 0): the products with an exact zero weight
     // add +-0 to a finite sum and are left out; 1 * w is w
-    const double lat1 = omx * py[0] + xsi * py[1];
-    const double lat2 = ome * py[1] + eta * py[2];
-    const double lat3 = xsi * py[2] + omx * py[3];
-    const double lat4 = ome * py[0] + eta * py[3];
-    auto geod = [&](double la1, double la2, double lo1, double lo2, double lat) {  // _geodetic_distance (utils/interpolation.py:178-185)
-        const double dl = (lo2 - lo1) * F.deg2m, dla = (la2 - la1) * F.deg2m;
-        const double aa_ = dl * cos_lat(DEG2RAD * lat);
-        return sqrt(aa_ * aa_ + dla * dla);
-    };
-    const double c1 = geod(py[0], py[1], px[0], px[1], lat1);
-    const double c2 = geod(py[1], py[2], px[1], px[2], lat2);
-    const double c3 = geod(py[2], py[3], px[2], px[3], lat3);
-    const double c4 = geod(py[3], py[0], px[3], px[0], lat4);
+    double c1, c2, c3, c4;
+    if constexpr ((NEAR & 2) != 0) {
+        // (kernels launched for a grid with FastC::near_edges) no cell of this grid spans 2^-8 rad of latitude: the edge points lie within
+        // 2^-7 rad of the sample's latitude, whose (sl, cl) are at hand.  A compile-time choice: with both paths in one kernel the register
+        // allocator spills 110 B per lane more in the RK45 kernel
+        auto geodn = [&](double la1, double la2, double lo1, double lo2, double lat) {  // _geodetic_distance (utils/interpolation.py:178-185)
+            const double dl = (lo2 - lo1) * F.deg2m, dla = (la2 - la1) * F.deg2m;
+            const double aa_ = dl * cos_near((lat - y) * DEG2RAD, sl, cl);
+            const double d2 = aa_ * aa_ + dla * dla;
+            return PK_CG_LEAN ? (d2 > 0 ? sqrt_lean(d2) : d2) : sqrt(d2);  // (coincident corners: 0)
+        };
+        c1 = geodn(py[0], py[1], px[0], px[1], omx * py[0] + xsi * py[1]);
+        c2 = geodn(py[1], py[2], px[1], px[2], ome * py[1] + eta * py[2]);
+        c3 = geodn(py[2], py[3], px[2], px[3], xsi * py[2] + omx * py[3]);
+        c4 = geodn(py[3], py[0], px[3], px[0], ome * py[0] + eta * py[3]);
+    } else {
+        auto geod = [&](double la1, double la2, double lo1, double lo2, double lat) {
+            const double dl = (lo2 - lo1) * F.deg2m, dla = (la2 - la1) * F.deg2m;
+            const double aa_ = dl * cos_lat(DEG2RAD * lat);
+            const double d2 = aa_ * aa_ + dla * dla;
+            return PK_CG_LEAN ? (d2 > 0 ? sqrt_lean(d2) : d2) : sqrt(d2);
+        };
+        c1 = geod(py[0], py[1], px[0], px[1], omx * py[0] + xsi * py[1]);
+        c2 = geod(py[1], py[2], px[1], px[2], ome * py[1] + eta * py[2]);
+        c3 = geod(py[2], py[3], px[2], px[3], xsi * py[2] + omx * py[3]);
+        c4 = geod(py[3], py[0], px[3], px[0], ome * py[0] + eta * py[3]);
+    }
     double raw[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) raw[k] = lenT ? (double)rawf[k] * (1 - tau) + (double)rawf[6 + k] * tau : (double)rawf[k];
@@ -666,15 +747,23 @@ PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtxT<FT, CM>& c, dou
     const double B = ome * Uvel - xsi * Vvel;
     const double C = eta * Uvel + xsi * Vvel;
     const double D = -eta * Uvel + omx * Vvel;
-    const Recip rjac = make_recip(jac);
-    double uu = div_shared(A * px[0] + B * px[1] + C * px[2] + D * px[3], rjac);
-    double vv = div_shared(A * py[0] + B * py[1] + C * py[2] + D * py[3], rjac);
     double conv;  // :311-314 (both components divided by deg2m * cos(lat))
     if (PF && pos_f32) conv = (double)((float)F.deg2m * cosf((float)y * DEG2RADF));
     else conv = F.deg2m * cl;  // cl == cos_lat(y * DEG2RAD): same reduction, same kernels (pk_device.h)
-    const Recip rconv = make_recip(conv);
-    uu = div_shared(uu, rconv);
-    vv = div_shared(vv, rconv);
+    double uu = A * px[0] + B * px[1] + C * px[2] + D * px[3], vv = A * py[0] + B * py[1] + C * py[2] + D * py[3];
+    const double jc = jac * conv;
+    if (PK_CG_LEAN && __builtin_expect(fabs(jc) > 1e-280 && fabs(jc) < 1e280, 1)) {  // (x / jac) / conv as x * (1 / (jac * conv)): one reciprocal for both divisions of both components
+        const double r = rcp_lean(jc);
+        uu = uu * r;
+        vv = vv * r;
+    } else {  // a degenerate cell (jac == 0: the reference's inf / NaN), non-finite values
+        const Recip rjac = make_recip(jac);
+        uu = div_shared(uu, rjac);
+        vv = div_shared(vv, rjac);
+        const Recip rconv = make_recip(conv);
+        uu = div_shared(uu, rconv);
+        vv = div_shared(vv, rconv);
+    }
     double ww = 0.0;
     if (D3) ww = raw[4] * (1 - zeta) + raw[5] * zeta;  // :316-328
     if (__builtin_expect(uu != uu || vv != vv || ww != ww, 0)) {  // field.py:373-378

@@ -878,7 +878,7 @@ __global__ void __launch_bounds__(256, PK_MIN_WAVES_FAST) advect_fast_kernel(con
 #define PK_CG_CACHE_M1 4
 #endif
 constexpr int CG_CACHE_RK4 = PK_CG_CACHE, CG_CACHE_RK45 = PK_CG_CACHE_RK45, CG_CACHE_M1 = PK_CG_CACHE_M1;
-template <class FT, int PFM, bool D3>
+template <class FT, int PFM, bool D3, bool NE>
 __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID) advect_cgrid_kernel(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const FastC& F = a.fastc;
@@ -947,6 +947,7 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID) advect_cgrid_ker
 #endif
                 // AdvectionRK4(_3D), _advection.py:42-75: (u1 + 2*u2 + 2*u3 + u4) summed left to right
                 double su = 0.0, sv = 0.0, sw = 0.0, lu = 0.0, lv = 0.0, lw = 0.0;
+                if constexpr ((PK_CG_NEAR & 1) != 0) cg_home_sincos(c, py, px);  // the stage points lie near (py, px): sincos_near
 #pragma unroll 1
                 for (int stage = 0; stage < 4; stage++) {
                     double st = pt, sz = pz, sy = py, sx = px;
@@ -958,7 +959,7 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID) advect_cgrid_ker
                         st = pt + cdt * pdt;
                     }
                     double u, v, w;
-                    eval_uvw_cgrid<FT, pf, D3, false, CG_CACHE_RK4>(a, L, c, st, sz, sy, sx, pf && stage == 0, u, v, w, it, adv * 1000 + stage);
+                    eval_uvw_cgrid<FT, pf, D3, false, CG_CACHE_RK4, 1, (PK_CG_NEAR & 1) | (NE ? (PK_CG_NEAR & 2) : 0)>(a, L, c, st, sz, sy, sx, pf && stage == 0, u, v, w, it, adv * 1000 + stage, -1, py, px);
                     if (stage == 0) { su = u; sv = v; sw = w; }
                     else if (stage == 3) { su = su + u; sv = sv + v; sw = sw + w; }
                     else { su = su + 2 * u; sv = sv + 2 * v; sw = sw + 2 * w; }
@@ -1027,7 +1028,7 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID) advect_cgrid_ker
 // AdvectionRK45 (_advection.py:85-155) on the same evaluation site: the step loop of advect_kernel for the single-kernel RK45 program
 // (Repeat loop, next_dt column, `dt = next_dt` of kernel.py:118-120), the Fehlberg stages written out like `prepare` does.  Every sample
 // of these programs is guessed and float64 (the host checks it), so the float32-array products of the general program never arise.
-template <class FT, int PFM>
+template <class FT, int PFM, bool NE>
 __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID_RK45) advect_cgrid_rk45_kernel(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const FastC& F = a.fastc;
@@ -1086,6 +1087,7 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID_RK45) advect_cgri
                 }
                 it++;
                 pdt = dtc;
+                if constexpr ((PK_CG_NEAR_RK45 & 1) != 0) cg_home_sincos(c, py, px);  // once per iteration: rejected attempts start from the same point
                 int sno = 0;  // samples taken in this iteration: the Repeat re-runs count on (pk_device.h: twe_listed)
                 do {  // the Repeat loop of kernel.py:211-216
                     using namespace rk45c;
@@ -1116,7 +1118,7 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID_RK45) advect_cgri
                             default: break;
                         }
                         double u, v, w;
-                        eval_uvw_cgrid<FT, pf, false, false, CG_CACHE_RK45, PK_CG_HOPS>(a, L, c, st, pzz, sy, sx, pf && stage == 0, u, v, w, it, sno + stage);
+                        eval_uvw_cgrid<FT, pf, false, false, CG_CACHE_RK45, PK_CG_HOPS, (PK_CG_NEAR_RK45 & 1) | (NE ? (PK_CG_NEAR_RK45 & 2) : 0)>(a, L, c, st, pzz, sy, sx, pf && stage == 0, u, v, w, it, sno + stage, -1, py, px);
                         switch (stage) {
                             case 0: u1 = u; v1 = v; break;
                             case 1: u2 = u; v2 = v; break;
@@ -1201,7 +1203,7 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID_RK45) advect_cgri
 // at y +- dres and at y -- seven samples whose `ei` guesses chain through one another exactly like in the general program (a sample that
 // starts in the cell of the point returns float64 (xsi, eta), one that has to move returns the float32-rounded ones of a hash hit:
 // SearchMemo of pk_device.h is that same rule, spelled as a re-use).
-template <class FT, int PFM>
+template <class FT, int PFM, bool NE>
 __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID_M1) advect_cgrid_m1_kernel(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const FastC& F = a.fastc;
@@ -1277,7 +1279,7 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID_M1) advect_cgrid_
                         default: break;
                     }
                     double r0, r1, r2;
-                    eval_uvw_cgrid<FT, pf, false, true, CG_CACHE_M1>(a, L, c, pt, pz, sy, sx, pf, r0, r1, r2, it, stage, sk, py, px);
+                    eval_uvw_cgrid<FT, pf, false, true, CG_CACHE_M1, 1, (PK_CG_NEAR_M1 & 1) | (NE ? (PK_CG_NEAR_M1 & 2) : 0)>(a, L, c, pt, pz, sy, sx, pf, r0, r1, r2, it, stage, sk, py, px);
                     switch (stage) {
                         case 0: Kxp1 = r0; break;
                         case 1: Kxm1 = r0; break;

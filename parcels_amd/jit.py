@@ -1172,8 +1172,10 @@ class UserProgram:
                 launch = (f"hipLaunchKernelGGL((advect_fast_kernel<{ft}, {pfm}, {d3}>), dim3((unsigned)((a.p.n + 255) / 256)), dim3(256), "
                           f"(size_t)lds_bytes, (hipStream_t)stream, a);")
             else:
-                launch = (f"hipLaunchKernelGGL((advect_cgrid_kernel<{ft}, {pfm}, {d3}>), dim3((unsigned)((a.p.n + FC_LANES - 1) / FC_LANES)), dim3(FC_LANES), "
-                          f"(size_t)lds_bytes, (hipStream_t)stream, a);")
+                # (the two variants of pk_prog_cgrid_fast.hip: FastC::near_edges, the edge cosines of CGrid_Velocity from the sample's own)
+                grid_ = "dim3((unsigned)((a.p.n + FC_LANES - 1) / FC_LANES)), dim3(FC_LANES), (size_t)lds_bytes, (hipStream_t)stream, a"
+                launch = (f"if (a.fastc.near_edges) hipLaunchKernelGGL((advect_cgrid_kernel<{ft}, {pfm}, {d3}, true>), {grid_}); "
+                          f"else hipLaunchKernelGGL((advect_cgrid_kernel<{ft}, {pfm}, {d3}, false>), {grid_});")
             fast_launch = f"        if (prog == {int(fast)} && key == {fkey}) {{\n            {launch}\n            return;\n        }}"
         self.source = _TEMPLATE.format(names=", ".join(s.name for s in sources), decl=decl, cases=cases, key=key, lds=lds, ft=ft, kind=kind,
                                        interp=interp, ldsb="true" if lds else "false", fast_launch=fast_launch)

@@ -21,9 +21,9 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 # bench key -> (object, demangled kernel name)
 KERNELS = {
     "AdvectionRK4": ("pk_prog_rk4_fast.o", "void pk::advect_fast_kernel<double, 0, false>(pk::KArgs)"),
-    "AdvectionRK4_3D": ("pk_prog_cgrid_fast.o", "void pk::advect_cgrid_kernel<float, 0, true>(pk::KArgs)"),
-    "AdvectionRK45": ("pk_prog_cgrid_fast.o", "void pk::advect_cgrid_rk45_kernel<float, 0>(pk::KArgs)"),
-    "AdvectionDiffusionM1": ("pk_prog_cgrid_fast.o", "void pk::advect_cgrid_m1_kernel<float, 0>(pk::KArgs)"),
+    "AdvectionRK4_3D": ("pk_prog_cgrid_fast.o", "void pk::advect_cgrid_kernel<float, 0, true, true>(pk::KArgs)"),
+    "AdvectionRK45": ("pk_prog_cgrid_fast.o", "void pk::advect_cgrid_rk45_kernel<float, 0, true>(pk::KArgs)"),
+    "AdvectionDiffusionM1": ("pk_prog_cgrid_fast.o", "void pk::advect_cgrid_m1_kernel<float, 0, true>(pk::KArgs)"),
 }
 
 
