@@ -58,6 +58,42 @@ PK_DEV uint32_t fast_flags(const FastA& F) {
            (F.nslots < F.nt ? FA_RING : 0u) | (F.lds_blk != 0 ? FA_BLK : 0u) | (F.nt >= 2 ? FA_NT2 : 0u) | (F.gnz >= 2 ? FA_NZ2 : 0u) |
            (F.gny >= 2 ? FA_NY2 : 0u) | (F.gnx >= 2 ? FA_NX2 : 0u);
 }
+// Square root, quotient and reciprocal WITHOUT the library's range scaling and final fix-up (PK_CG_LEAN / PK_FAST_LEAN, round 6; the tolerance
+// argument of pk_fast_cgrid.h: sincos_near): the operands here are lengths in metres, squared or not, determinants and Jacobians of cells -- far from the
+// subnormal and overflow ranges the library's 20-instruction sqrt and 10-instruction division guard -- and one Goldschmidt / Newton
+// step + one residual correction on the hardware's v_rsq_f64 / v_rcp_f64 leaves < 1 ulp (not always the correctly rounded bit).
+#ifndef PK_CG_LEAN
+#define PK_CG_LEAN 1
+#endif
+PK_DEV double sqrt_lean(double x) {  // x > 0 (0, negative, NaN: the caller selects)
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    return fma(fma(-g, g, x), h, g);
+}
+PK_DEV double rcp_lean(double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(r, fma(-b, r, 1.0), r);
+    return fma(r, fma(-b, r, 1.0), r);
+}
+PK_DEV double div_lean(double a, double b) {
+    const double r = rcp_lean(b), q = a * r;
+    return fma(fma(-b, q, a), r, q);
+}
+
+// Barycentric coordinate of x in the cell [a, a1] of an {a, 1 / width} table.  PK_FAST_LEAN (round 6, default): (x - a) * RN(1 / width), one
+// multiplication, within 1.5 ulp of the reference's (x - a) / (a1 - a) and never above 1 for x <= a1 (n * RN(1 / d) <= RN(1 + 2^-53) = 1);
+// 0: the correctly rounded quotient (div_by_recip: five fused operations + a guard), the bits of the general program.  The index, the
+// out-of-bounds codes and "exactly on a node / level" (bc == 0) do not depend on the choice.
+#ifndef PK_FAST_LEAN
+#define PK_FAST_LEAN 1
+#endif
+PK_DEV double fast_bary(double x, double a, double a1, double rw) {
+    if constexpr (PK_FAST_LEAN != 0) return (x - a) * rw;
+    else return div_by_recip(x - a, a1 - a, rw);
+}
 constexpr int FAST_WG = 256;                          // lanes per workgroup of advect_fast_kernel
 constexpr int FAST_BLK_BYTES = FAST_WG * 8 * 8;       // LDS of the corner-block cache per workgroup (8 doubles per lane)
 
@@ -109,7 +145,7 @@ PK_DEV void fast_search(const pk_tab2* tab, int n, double first, double last, do
         e = e2;
         a1 = b1;
     }
-    bc = div_by_recip(x - e.x, a1 - e.x, e.y);
+    bc = fast_bary(x, e.x, a1, e.y);
     cell = i;
     // :55-58.  A point left of the first node is in cell 0, one right of the last node in cell n-2 (the clip of :47), so only lanes in
     // an edge cell pay the two fp64 compares (a divergent block most wavefronts skip: the particles live in the interior)
@@ -151,8 +187,8 @@ PK_DEV void fast_search2(const pk_tab2* taba, int na, double firsta, double last
         ia = ja; ea = e2a; a1a = b1a;
         ib = jb; eb = e2b; a1b = b1b;
     }
-    bca = div_by_recip(xa - ea.x, a1a - ea.x, ea.y);
-    bcb = div_by_recip(xb - eb.x, a1b - eb.x, eb.y);
+    bca = fast_bary(xa, ea.x, a1a, ea.y);
+    bcb = fast_bary(xb, eb.x, a1b, eb.y);
     cella = ia;
     cellb = ib;
     if (__builtin_expect(ia == 0 || ia == na - 2 || ib == 0 || ib == nb - 2, 0)) {  // :55-58, see fast_search
@@ -428,8 +464,13 @@ PK_DEV void eval_uvw_fast(const KArgs& a, const FastTabs& T, FCtx& c, double t, 
         double conv;
         if (PF && pos_f32) conv = (double)((float)F.deg2m * cosf((float)y * DEG2RADF));
         else conv = F.deg2m * cos_lat(y * DEG2RAD);
-        uu /= conv;
-        vv = div_by_recip(vv, F.deg2m, F.inv_deg2m);
+        if constexpr (PK_FAST_LEAN != 0) {  // u / conv, v / deg2m within 1.5 ulp: 7 operations instead of 22
+            uu = uu * rcp_lean(conv);
+            vv = vv * F.inv_deg2m;
+        } else {
+            uu /= conv;
+            vv = div_by_recip(vv, F.deg2m, F.inv_deg2m);
+        }
     }
     // field.py:373-378 (one unordered compare answers "uu or vv is NaN")
     if (__builtin_expect(__builtin_isunordered(uu, vv) || (D3 && ww != ww), 0)) {

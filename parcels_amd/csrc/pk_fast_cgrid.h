@@ -390,31 +390,6 @@ PK_DEV void cg_home_sincos(CCtxT<FT, CM>& c, double y, double x) {
 // curvilinear_point_in_cell (index_search.py:94-177) on the record in the lane's LDS slot.  Bit for bit what point_in_cell ->
 // spherical_project_query -> bilinear_inverse of pk_device.h compute: the cell-only sub-expressions were formed by the table build
 // in the same order.  `cell`: for the degenerate branch (reads pv from the global record).
-// Square root, quotient and reciprocal WITHOUT the library's range scaling and final fix-up (PK_CG_LEAN, round 6; same tolerance argument
-// as sincos_near): the operands here are lengths in metres, squared or not, determinants and Jacobians of cells -- far from the
-// subnormal and overflow ranges the library's 20-instruction sqrt and 10-instruction division guard -- and one Goldschmidt / Newton
-// step + one residual correction on the hardware's v_rsq_f64 / v_rcp_f64 leaves < 1 ulp (not always the correctly rounded bit).
-#ifndef PK_CG_LEAN
-#define PK_CG_LEAN 1
-#endif
-PK_DEV double sqrt_lean(double x) {  // x > 0 (0, negative, NaN: the caller selects)
-    const double y = __builtin_amdgcn_rsq(x);
-    double g = x * y, h = 0.5 * y;
-    const double r = fma(-h, g, 0.5);
-    g = fma(g, r, g);
-    h = fma(h, r, h);
-    return fma(fma(-g, g, x), h, g);
-}
-PK_DEV double rcp_lean(double b) {
-    double r = __builtin_amdgcn_rcp(b);
-    r = fma(r, fma(-b, r, 1.0), r);
-    return fma(r, fma(-b, r, 1.0), r);
-}
-PK_DEV double div_lean(double a, double b) {
-    const double r = rcp_lean(b), q = a * r;
-    return fma(fma(-b, q, a), r, q);
-}
-
 template <class Row>
 PK_DEV bool cg_point_in_cell_rows(const FastC& F, Row row, int cell, double qX, double qY, double qZ, double& xsi, double& eta) {
     const double eu0 = row(0), eu1 = row(1), eu2 = row(2);

@@ -788,10 +788,10 @@ __global__ void __launch_bounds__(256, PK_MIN_WAVES_FAST) advect_fast_kernel(con
                     else { su = su + 2 * u; sv = sv + 2 * v; sw = sw + 2 * w; }
                     lu = u; lv = v; lw = w;
                 }
-                constexpr double sixth = 1.0 / 6.0;  // RN(1/6): su / 6.0 exactly (div_by_recip)
-                pdx = pstore(pf, pdx + div_by_recip(su, 6.0, sixth) * pdt);
-                pdy = pstore(pf, pdy + div_by_recip(sv, 6.0, sixth) * pdt);
-                if (D3) pdz = pstore(pf, pdz + div_by_recip(sw, 6.0, sixth) * pdt);
+                constexpr double sixth = 1.0 / 6.0;  // RN(1/6): su / 6.0 exactly (div_by_recip), or within an ulp (PK_FAST_LEAN: one multiplication)
+                pdx = pstore(pf, pdx + (PK_FAST_LEAN ? su * sixth : div_by_recip(su, 6.0, sixth)) * pdt);
+                pdy = pstore(pf, pdy + (PK_FAST_LEAN ? sv * sixth : div_by_recip(sv, 6.0, sixth)) * pdt);
+                if (D3) pdz = pstore(pf, pdz + (PK_FAST_LEAN ? sw * sixth : div_by_recip(sw, 6.0, sixth)) * pdt);
                 for (int k = adv + 1; k < prm.nk; k++) {  // the sampling-free recovery kernels that may follow (Delete*)
                     const int kid = prm.kernels[k];
                     attempts++;
@@ -965,10 +965,10 @@ __global__ void __launch_bounds__(FC_LANES, PK_MIN_WAVES_CGRID) advect_cgrid_ker
                     else { su = su + 2 * u; sv = sv + 2 * v; sw = sw + 2 * w; }
                     lu = u; lv = v; lw = w;
                 }
-                constexpr double sixth = 1.0 / 6.0;  // RN(1/6): su / 6.0 exactly (div_by_recip)
-                pdx = pstore(pf, pdx + div_by_recip(su, 6.0, sixth) * pdt);
-                pdy = pstore(pf, pdy + div_by_recip(sv, 6.0, sixth) * pdt);
-                if (D3) pdz = pstore(pf, pdz + div_by_recip(sw, 6.0, sixth) * pdt);
+                constexpr double sixth = 1.0 / 6.0;  // RN(1/6): su / 6.0 exactly (div_by_recip), or within an ulp (PK_FAST_LEAN: one multiplication)
+                pdx = pstore(pf, pdx + (PK_FAST_LEAN ? su * sixth : div_by_recip(su, 6.0, sixth)) * pdt);
+                pdy = pstore(pf, pdy + (PK_FAST_LEAN ? sv * sixth : div_by_recip(sv, 6.0, sixth)) * pdt);
+                if (D3) pdz = pstore(pf, pdz + (PK_FAST_LEAN ? sw * sixth : div_by_recip(sw, 6.0, sixth)) * pdt);
                 for (int k = adv + 1; k < prm.nk; k++) {  // the sampling-free recovery kernels that may follow (Delete*)
                     const int kid = prm.kernels[k];
                     attempts++;

@@ -1181,7 +1181,10 @@ class UserProgram:
                                        interp=interp, ldsb="true" if lds else "false", fast_launch=fast_launch)
         # (measured on C2 with a sampling kernel riding in the dedicated A-grid kernel, tools/bench_user_kernels.py: 4 waves per SIMD 12.6 ms,
         # 3 waves 13.8 ms, 2 waves 12.5 ms -- the library's own occupancy target stays; PARCELS_AMD_JIT_FAST_WAVES overrides for A/B runs)
-        self.defines = []
+        # A dedicated kernel that carries user kernels keeps the correctly rounded quotients and full-range sines / cosines of the general
+        # program (pk_fast_agrid.h: PK_FAST_LEAN, pk_fast_cgrid.h: PK_CG_NEAR / PK_CG_LEAN): a user kernel may branch on a sampled value or a
+        # position, and the compiled list has to do what the host path (general program between NumPy kernels) does, bit for bit
+        self.defines = ["-DPK_FAST_LEAN=0", "-DPK_CG_NEAR=0", "-DPK_CG_LEAN=0"]
         if os.environ.get("PARCELS_AMD_JIT_FAST_WAVES"):
             self.defines.append("-DPK_MIN_WAVES_FAST=" + os.environ["PARCELS_AMD_JIT_FAST_WAVES"])
         self.digest = hashlib.sha256((self.source + " ".join(self.defines) + _csrc_hash()).encode()).hexdigest()[:20]

@@ -1,6 +1,7 @@
 """The dedicated RK4 kernels of csrc/pk_fast_agrid.h (rectilinear A-grid, float64 coordinates) against the general
-program of the same library -- bit for bit -- and against the CPU oracle, on the inputs where the two code paths differ
-most: sample points exactly on nodes and time levels (the reciprocal division falls back to the hardware quotient),
+program of the same library -- t, state, ei, ids and the counters exactly, positions to FAST_VS_GENERAL_RTOL -- and against the
+CPU oracle at 1e-12, on the inputs where the two code paths differ
+most: sample points exactly on nodes and time levels (barycentric coordinate exactly 0: one level / plane is read),
 particles of one wavefront on different time levels (the readfirstlane waterfall iterates), time-level rings, domain exits,
 float32 fields / particles, missing depth axis, 3-D advection."""
 
@@ -12,6 +13,23 @@ import pytest
 from case_utils import build_fieldset, build_pset, compare, endtime_of, run_oracle
 
 pytestmark = pytest.mark.gpu
+
+# Until round 6 the dedicated kernel gave the BITS of the general program.  It now forms a barycentric coordinate as (x - a) * RN(1 / width)
+# and u / (deg2m cos lat), v / deg2m, sum / 6 with reciprocals (pk_fast_agrid.h: PK_FAST_LEAN, within 1.5 ulp each, 41 instructions less per
+# evaluation); the general program keeps the correctly rounded quotients.  Everything discrete still has to agree exactly; float32 particle
+# storage rounds every step's position to float32, where a last-bit difference of the float64 sum can move the stored value by one float32 ulp.
+FAST_VS_GENERAL_RTOL = 1e-12
+
+
+def _scale(case):
+    """Yardstick of the position comparisons: the coordinate scale (longitudes and metre axes run through 0: |x| alone is none there),
+    |a - b| <= rtol * (|b| + scale) like tests/test_gpu_fuzz.py and the bench-size checks"""
+    return float(max(np.abs(np.asarray(case["lon"])).max(), np.abs(np.asarray(case["lat"])).max()))
+
+
+def _cmp_general(fast, gen, case, label):
+    rtol = 5e-7 if case.get("spatial_dtype", "float64") == "float32" else FAST_VS_GENERAL_RTOL
+    compare(fast, gen, rtol=rtol, atol_pos=rtol * _scale(case), check_state="all", label=label, skip=())
 
 
 def _run(case, fast, nslots=None, endtime=None):
@@ -40,12 +58,12 @@ def _check(case, *, nslots=None, oracle=True, rtol=1e-12):
     gen, gerr, gstats = _run(case, False, nslots)
     assert ferr == gerr
     assert fstats["steps"] == gstats["steps"] and fstats["attempts"] == gstats["attempts"]
-    compare(fast, gen, rtol=0.0, check_state="all", label=case["name"] + ": fast vs general", skip=())
+    _cmp_general(fast, gen, case, case["name"] + ": fast vs general")
     if oracle:
         ref, oerr, _ = run_oracle(case)
         assert ferr == oerr
         if ferr is None:
-            compare(fast, ref, rtol=rtol, check_state="all", label=case["name"] + ": fast vs oracle", skip=())
+            compare(fast, ref, rtol=rtol, atol_pos=rtol * _scale(case), check_state="all", label=case["name"] + ": fast vs oracle", skip=())
     return fast
 
 
@@ -91,9 +109,9 @@ def test_staggered_release_times_share_a_wavefront(gpu):
     fast, ferr, _ = _run(case, True, endtime=case["endtime"])
     gen, gerr, _ = _run(case, False, endtime=case["endtime"])
     assert ferr == gerr is None
-    compare(fast, gen, rtol=0.0, check_state="all", label="stagger", skip=())
+    _cmp_general(fast, gen, case, "stagger")
     ref, oerr, _ = run_oracle(case, endtime=case["endtime"])
-    compare(fast, ref, rtol=1e-12, check_state="all", label="stagger vs oracle", skip=())
+    compare(fast, ref, rtol=1e-12, atol_pos=1e-12 * _scale(case), check_state="all", label="stagger vs oracle", skip=())
     # and through a ring of 3 levels (pause / resume per launch window)
     ring, rerr, rstats = _run(case, True, nslots=3, endtime=case["endtime"])
     assert rerr is None and rstats["launches"] > 1
@@ -115,9 +133,9 @@ def test_domain_exits_and_backward_time(gpu, kernel):
         gen, gerr, gst = _run(case, False)
         assert ferr == gerr is None
         assert len(fast["x"]) < 4000, "nothing left the domain: the test does not test"
-        compare(fast, gen, rtol=0.0, check_state="all", label=f"exit {sign}", skip=())
+        _cmp_general(fast, gen, case, f"exit {sign}")
         ref, oerr, _ = run_oracle(case)
-        compare(fast, ref, rtol=1e-12, check_state="all", label=f"exit vs oracle {sign}", skip=())
+        compare(fast, ref, rtol=1e-12, atol_pos=1e-12 * _scale(case), check_state="all", label=f"exit vs oracle {sign}", skip=())
 
 
 def test_errors_raise_the_same(gpu):
@@ -129,7 +147,7 @@ def test_errors_raise_the_same(gpu):
     fast, ferr, _ = _run(case, True)
     gen, gerr, _ = _run(case, False)
     assert ferr == gerr and ferr is not None
-    compare(fast, gen, rtol=0.0, check_state="all", label="raise", skip=())
+    _cmp_general(fast, gen, case, "raise")
 
 
 def test_field_without_depth_axis(gpu):
@@ -142,7 +160,7 @@ def test_field_without_depth_axis(gpu):
     fast, ferr, _ = _run(case, True)
     gen, gerr, _ = _run(case, False)
     assert ferr == gerr
-    compare(fast, gen, rtol=0.0, check_state="all", label="2d", skip=())
+    _cmp_general(fast, gen, case, "2d")
 
 
 def test_fast_path_is_taken_and_can_be_switched_off(gpu):

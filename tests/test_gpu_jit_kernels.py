@@ -262,9 +262,8 @@ def test_compiled_list_with_output_file(gpu, tmp_path):
 def test_user_kernels_ride_in_the_dedicated_cgrid_kernel(gpu):
     """BASELINE config 3's shape (spherical curvilinear C-grid, AdvectionRK4_3D, populated `ei`) with an ageing kernel and the user's own
     recovery kernel around the advection kernel: the module carries advect_cgrid_kernel with the user kernels riding along
-    (pk_exec_stats.program 101).  Against the host path (the general program between the user kernels): t, state, ei, ids and the user
-    variables exactly, positions to 1e-12 of the coordinate scale -- the dedicated kernel forms the sines / cosines of a stage point
-    from those of the particle's own position (tests/test_gpu_fast_cgrid.py: FAST_VS_GENERAL_RTOL)."""
+    (pk_exec_stats.program 101), bit-identical to the host path (the module is compiled with the exact quotients and full-range
+    sines / cosines of the general program: parcels_amd/jit.py, PK_FAST_LEAN=0 PK_CG_NEAR=0 PK_CG_LEAN=0)."""
     from case_utils import build_fieldset
     from oracle import cases
 
@@ -284,12 +283,8 @@ def test_user_kernels_ride_in_the_dedicated_cgrid_kernel(gpu):
     (pj, dj), (ph, dh) = out
     assert pj._kernel.user_program is not None and pj._kernel.user_program.flags == 1 and pj._last_stats["program"] == 101, pj._last_stats
     assert ph._kernel.user_program is None
-    scale = float(max(np.abs(case["lon"]).max(), np.abs(case["lat"]).max()))
     for k in dj:
-        if k in ("x", "y", "z", "dx", "dy", "dz"):
-            assert np.allclose(dj[k], dh[k], rtol=1e-12, atol=1e-12 * scale, equal_nan=True), k
-        else:
-            assert np.array_equal(dj[k], dh[k], equal_nan=True), k
+        assert np.array_equal(dj[k], dh[k], equal_nan=True), k
     assert dj["age"].max() == 10 * 1800.0
 
 

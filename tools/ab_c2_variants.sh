@@ -6,7 +6,7 @@ mkdir -p $out
 for r in $(seq 1 $reps); do
   for v in $vs; do
     if [ $v = new ]; then unset PARCELS_HIP_LIB; else export PARCELS_HIP_LIB=$PWD/parcels_amd/libparcels_hip_$v.so; fi
-    if [ $v = base ]; then export PARCELS_HIP_ALLOW_ABI=${PK_BASE_ABI:-8}; else unset PARCELS_HIP_ALLOW_ABI; fi  # (the library of the previous round)
+    if [ $v = base ] && [ -n "$PK_BASE_ABI" ]; then export PARCELS_HIP_ALLOW_ABI=$PK_BASE_ABI; else unset PARCELS_HIP_ALLOW_ABI; fi  # (the library of the previous round)
     timeout 300 python bench.py --steps 24 --warmup 2 --secondary 0 --no-cpu-baseline --user-kernels 0 > $out/c2_${v}_$r.json 2> $out/c2_${v}_$r.err
     python - $out/c2_${v}_$r.json $v $r <<'PY'
 import json,sys
