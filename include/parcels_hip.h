@@ -96,7 +96,10 @@ const char* pk_last_error(const pk_ctx* ctx); /* ctx may be NULL: error of the l
 
 /* Tuning / A-B switches of the library (the reference has no counterpart; its behaviour is the same for every setting):
  *   "fast_path"        1 (default) AdvectionRK4 / AdvectionRK4_3D with XLinear_Velocity on a rectilinear grid with float64
- *                      coordinates run the dedicated kernels of csrc/pk_fast_agrid.h; 0 = the general program
+ *                      coordinates run the dedicated kernels of csrc/pk_fast_agrid.h; 0 = the general program.  (This and
+ *                      "fast_cgrid": same discrete results -- state, ei, t, deleted set -- and positions within 1e-12 of the
+ *                      coordinate scale; since ABI 9's second build the dedicated kernels no longer give the general program's
+ *                      bits: quotients by reciprocals, sines / cosines near known ones)
  *   "fast_cgrid"       1 (default) AdvectionRK4 / AdvectionRK4_3D with CGrid_Velocity on a spherical curvilinear grid with float64
  *                      node coordinates run the dedicated kernels of csrc/pk_fast_cgrid.h (needs "cell_table"; 256 B more per
  *                      cell); 0 = the general program
@@ -363,7 +366,7 @@ typedef struct pk_exec_params {
                             the code); the caller runs the call again from the state before it with that key listed here, and every
                             particle that reaches a listed sample takes code 70 and the value 0 there -- and so on until a run reports
                             no new key (parcels_amd/engine.py: DeviceEngine.execute; pk_execute_rerun_keys).  A launch with listed
-                            samples runs the general programs (same results as the dedicated kernels, which only report).             */
+                            samples runs the general programs (same time keys as the dedicated kernels, which only report).             */
 } pk_exec_params;
 
 typedef struct pk_exec_stats {
