@@ -3,7 +3,7 @@
 # 4000 fuzz seeds, smoke, trace + PMC passes of every profiled kernel (profiles/$N_*), the default bench line        (N=r06s SEED0=500000 bash ...)
 N=${N:-r06p}; out=gpurun_out/$N; mkdir -p $out
 export TMPDIR=/tmp
-/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off tools/lean_math_check.hip -o /tmp/lean_math_check 2> /dev/null && /tmp/lean_math_check | tee -a $out/summary.txt; echo "lean_math_check rc $?" | tee -a $out/summary.txt
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -Wno-unused-function -I parcels_amd/csrc tools/lean_math_check.hip -o /tmp/lean_math_check 2> /dev/null && /tmp/lean_math_check | tee -a $out/summary.txt; echo "lean_math_check rc $?" | tee -a $out/summary.txt
 timeout 1800 python -m pytest tests -m gpu -q -n 4 > $out/pytest_all.log 2>&1; echo "pytest all rc $?" | tee -a $out/summary.txt; grep -E "^FAILED" $out/pytest_all.log | cut -c1-200 | tee -a $out/summary.txt; tail -1 $out/pytest_all.log | tee -a $out/summary.txt
 PARCELS_FUZZ_SEED0=${SEED0:-200000} PARCELS_FUZZ_SEEDS=4000 timeout 1200 python -m pytest tests/test_gpu_fuzz.py -m gpu -q -k random_configuration -n 4 > $out/fuzz.log 2>&1; echo "fuzz rc $?" | tee -a $out/summary.txt; grep -E "passed|failed" $out/fuzz.log | tee -a $out/summary.txt; grep -E "^FAILED" $out/fuzz.log | head | tee -a $out/summary.txt
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1; echo "smoke rc $?" | tee -a $out/summary.txt; tail -1 $out/smoke.log | tee -a $out/summary.txt

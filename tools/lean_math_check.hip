@@ -1,6 +1,7 @@
 // tools/lean_math_check.hip -- accuracy of sqrt_lean / div_lean / rcp_lean / sincos_near (parcels_amd/csrc/pk_fast_cgrid.h) on the device,
 // against the correctly rounded library routines over random operands of the magnitudes the C-grid evaluation feeds them.
-//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -I parcels_amd/csrc tools/lean_math_check.hip -o /tmp/lean_math_check && /tmp/lean_math_check
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -I parcels_amd/csrc tools/lean_math_check.hip -o /tmp/lean_math_check && /tmp/lean_math_check
+// (tests/test_gpu_lean_math.py does that on the GPU box)
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -8,34 +9,7 @@
 #include <cstdio>
 #include <vector>
 
-#define PK_DEV __device__ __forceinline__
-namespace pk {
-static constexpr double DEG2RAD = 3.14159265358979323846 / 180.0;
-PK_DEV double sqrt_lean(double x) {
-    const double y = __builtin_amdgcn_rsq(x);
-    double g = x * y, h = 0.5 * y;
-    const double r = fma(-h, g, 0.5);
-    g = fma(g, r, g);
-    h = fma(h, r, h);
-    return fma(fma(-g, g, x), h, g);
-}
-PK_DEV double rcp_lean(double b) {
-    double r = __builtin_amdgcn_rcp(b);
-    r = fma(r, fma(-b, r, 1.0), r);
-    return fma(r, fma(-b, r, 1.0), r);
-}
-PK_DEV double div_lean(double a, double b) {
-    const double r = rcp_lean(b), q = a * r;
-    return fma(fma(-b, q, a), r, q);
-}
-PK_DEV void sincos_near(double d, double s0, double c0, double& s, double& c) {
-    const double z = d * d;
-    const double sd = fma(d * z, fma(z, 8.33333333333333333e-03, -1.66666666666666667e-01), d);
-    const double cm = z * fma(z, fma(z, -1.38888888888888889e-03, 4.16666666666666667e-02), -0.5);
-    s = s0 + fma(c0, sd, s0 * cm);
-    c = c0 + fma(-s0, sd, c0 * cm);
-}
-}  // namespace pk
+#include "pk_fast_cgrid.h"  // the routines under test, as shipped (-I parcels_amd/csrc)
 
 __device__ uint64_t rng(uint64_t& s) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; }
 __device__ double uni(uint64_t& s) { return (double)(rng(s) >> 11) * (1.0 / 9007199254740992.0); }
