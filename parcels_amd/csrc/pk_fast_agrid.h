@@ -90,6 +90,9 @@ PK_DEV double div_lean(double a, double b) {
 #ifndef PK_FAST_LEAN
 #define PK_FAST_LEAN 1
 #endif
+// (Contracting the lerps and bilinear sums of this kernel into fused multiply-adds -- `#pragma clang fp contract(fast)` in lerp_rows / uvw_fast,
+// 70 of its 286 fp64 instructions -- was measured and is not done: 6.99 -> 6.98 ms, profiles/r06v_contraction_ab.txt.  The C-grid
+// evaluation is contracted: pk_fast_cgrid.h, PK_CG_FMA.)
 PK_DEV double fast_bary(double x, double a, double a1, double rw) {
     if constexpr (PK_FAST_LEAN != 0) return (x - a) * rw;
     else return div_by_recip(x - a, a1 - a, rw);

@@ -357,6 +357,18 @@ PK_DEV double cg_fetch_cell(const FastC& F, const CgLds& L, CCtxT<FT, CM>& c, in
 // reduction + two minimax kernels, no branch.  Error: that of (s0, c0) (< 1 ulp, sincos_geo) + one rounding: < 2.5 ulp, where the
 // reference's own libm promises <= 1 ulp: trajectories stay within the 1e-12 every parity test states, but
 // are no longer the bits of the general program, which has no "own position" to start from.  Larger |d|: the full routines.
+#ifndef PK_CG_LEAN
+#define PK_CG_LEAN 1
+#endif
+#if PK_CG_LEAN
+// With PK_CG_LEAN the arithmetic of the evaluation below (query point, edge points, time lerp of the staggered values, Jacobian, the weighted
+// sums of CGrid_Velocity, XLinear of the scalar samples) may be CONTRACTED: a * b + c as one fused operation, one rounding instead of NumPy's
+// two -- never further from the exact value.  The translation units are compiled with -ffp-contract=off (the general programs reproduce the
+// two roundings); the pragma opens these functions only.  RK4_3D -3.2 %, M1 -1.6 %, RK45 -1 % (profiles/r06v_contraction_ab.txt).
+#define PK_CG_FMA _Pragma("clang fp contract(fast)")
+#else
+#define PK_CG_FMA
+#endif
 #ifndef PK_CG_NEAR
 #define PK_CG_NEAR 3  // bit 0: the sample point from the particle's own position; bit 1: the edge points from the sample point
 #endif
@@ -392,6 +404,8 @@ PK_DEV void cg_home_sincos(CCtxT<FT, CM>& c, double y, double x) {
 // in the same order.  `cell`: for the degenerate branch (reads pv from the global record).
 template <class Row>
 PK_DEV bool cg_point_in_cell_rows(const FastC& F, Row row, int cell, double qX, double qY, double qZ, double& xsi, double& eta) {
+    // (NOT contracted: bb * bb - 4 aa cc cancels on near-parallelogram cells, and which cells the host flags as ill-conditioned --
+    // illconditioned_cell_kernel, neighbour probing off -- is decided with the reference's two roundings)
     const double eu0 = row(0), eu1 = row(1), eu2 = row(2);
     const double ev0 = row(3), ev1 = row(4), ev2 = row(5);
     const double a0 = row(6), a1 = row(7), a2 = row(8), a3 = row(9);
@@ -436,6 +450,7 @@ PK_DEV bool cg_point_in_cell(const FastC& F, const double* rec, int cell, double
 // values, and c * (1 - zeta) + c * zeta is still formed, like the reference does)
 template <class FT>
 PK_DEV double cg_scalar_xlinear(const FastC& F, int k, int ti, double tau, int zi, double zeta, int yi, int xi, double xsi, double eta) {
+    PK_CG_FMA
     const bool lenT = tau > 0, lenZ = !(zeta <= 0);
     if (F.kh_nt[k] == 1 && F.kh_nz[k] == 1) {
         // a field without time and depth axes (the 2-D Kh fields of BASELINE config 5): both "depth levels" are the same two rows -- the
@@ -497,6 +512,7 @@ PK_DEV double cg_scalar_xlinear(const FastC& F, int k, int ti, double tau, int z
 template <class FT, bool PF, bool D3, bool WITH_SCALAR = false, int CM = 0, int HOPS = 1, int NEAR = PK_CG_NEAR>
 PK_DEV void eval_uvw_cgrid(const KArgs& a, const CgLds& L, CCtxT<FT, CM>& c, double t, double z, double y, double x, bool pos_f32, double& u,
                            double& v, double& w, unsigned it, int klo, int sk = -1, double home_y = 0.0, double home_x = 0.0) {
+    PK_CG_FMA
     const FastC& F = a.fastc;
     const bool scalar = WITH_SCALAR && sk >= 0;
     const int ks = scalar ? (sk & 1) : 0;
