@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 6: HEAD the way the driver runs it -- the GPU suite serially with -x, smoke(), the default bench line -- plus the --gpus 2 rehearsal (gloo, one GPU)
-out=gpurun_out/r06u; mkdir -p $out
+out=gpurun_out/${OUT:-r06u}; mkdir -p $out
 export TMPDIR=/tmp
 timeout 2400 python -m pytest tests/ -x -q -m gpu > $out/pytest_all.log 2>&1; echo "pytest -x -q -m gpu rc $?" | tee -a $out/summary.txt; grep -E "^FAILED" $out/pytest_all.log | cut -c1-200 | tee -a $out/summary.txt; tail -1 $out/pytest_all.log | tee -a $out/summary.txt
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1; echo "smoke rc $?" | tee -a $out/summary.txt; tail -1 $out/smoke.log | tee -a $out/summary.txt
