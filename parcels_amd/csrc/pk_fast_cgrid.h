@@ -399,9 +399,11 @@ PK_DEV void cg_home_sincos(CCtxT<FT, CM>& c, double y, double x) {
     sincos_geo(x * DEG2RAD, c.q_so, c.q_co);
 }
 
-// curvilinear_point_in_cell (index_search.py:94-177) on the record in the lane's LDS slot.  Bit for bit what point_in_cell ->
-// spherical_project_query -> bilinear_inverse of pk_device.h compute: the cell-only sub-expressions were formed by the table build
-// in the same order.  `cell`: for the degenerate branch (reads pv from the global record).
+// curvilinear_point_in_cell (index_search.py:94-177) on the record in the lane's LDS slot.  The operations of point_in_cell ->
+// spherical_project_query -> bilinear_inverse of pk_device.h in their order (the cell-only sub-expressions were formed by the table
+// build in the same order); with PK_CG_LEAN = 0 bit for bit their result, with the lean square root and quotients the same bits in
+// practice (0 ulp from the library's over 1e8 operands, tools/lean_math_check.hip).  `cell`: for the degenerate branch (reads pv from the
+// global record).
 template <class Row>
 PK_DEV bool cg_point_in_cell_rows(const FastC& F, Row row, int cell, double qX, double qY, double qZ, double& xsi, double& eta) {
     // (NOT contracted: bb * bb - 4 aa cc cancels on near-parallelogram cells, and which cells the host flags as ill-conditioned --
